@@ -1,0 +1,219 @@
+"""Portable synthetic inputs and weights for the GIMS matcher hot path.
+
+Everything here is produced by a counter-based integer hash evaluated with NumPy
+uint64 arithmetic, followed only by exactly-representable float operations
+(24-bit uniforms, Irwin-Hall sums), so the same seed yields the *same bits* on
+the build container and on the GPU box.  No libm call (log/sin/cos) is involved
+before the final L2 normalisation of descriptors, which is a plain float32
+sqrt/divide (IEEE-exact).
+
+The recipes follow SURVEY.md section 8(d) / BASELINE.md section 3:
+
+* keypoints ~ U(canvas) with density-matched canvases so the adaptive graph
+  (r=15, p=2, min_size=7) keeps (almost) every keypoint;
+* descriptors: L2-normalised 128-d, duplicated to 256-d -- mirrors the
+  reference's ``torch.cat([d, d])`` in utils/common.py:891;
+* image 1 = permutation of image 0 + position noise + descriptor noise;
+* weights: N(0, g^2 / fan_in) with per-module gains chosen so that the match
+  matrix is non-degenerate (default PyTorch init collapses to zero matches).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+# canvas (W, H) per keypoint count -- mean radius-15 degree ~ 9
+CANVAS = {64: (80, 60), 128: (112, 84), 256: (160, 120), 512: (224, 168),
+          1024: (320, 240), 2048: (448, 336), 4096: (640, 480), 8192: (896, 672)}
+
+
+def canvas_for(n: int):
+    if n in CANVAS:
+        return CANVAS[n]
+    # keep density of 1024 @ 320x240
+    s = (n / 1024.0) ** 0.5
+    return int(round(320 * s)), int(round(240 * s))
+
+
+def _mix(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on a uint64 array (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def _stream_key(seed: int, stream: int) -> np.uint64:
+    k = _mix(np.array([seed & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))
+    k = _mix(k ^ np.uint64(stream & 0xFFFFFFFFFFFFFFFF))
+    return k[0]
+
+
+def uniform(seed: int, stream: int, n: int, offset: int = 0) -> np.ndarray:
+    """n float64 values k/2^24, k in [0, 2^24) -- exactly representable in f32."""
+    key = _stream_key(seed, stream)
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(offset, offset + n, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95)) & _M64
+    h = _mix(ctr ^ key)
+    return (h >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
+
+
+def normal(seed: int, stream: int, n: int) -> np.ndarray:
+    """Approximately N(0,1): Irwin-Hall sum of 4 uniforms, exact in float64."""
+    u = uniform(seed, stream, 4 * n).reshape(4, n)
+    s = (u[0] + u[1]) + (u[2] + u[3])          # exact: multiples of 2^-24 below 4
+    return (s - 2.0) * 1.7320508075688772       # var of sum = 4/12 -> scale sqrt(3)
+
+
+def permutation(seed: int, stream: int, n: int) -> np.ndarray:
+    """Deterministic permutation: argsort of hash keys (stable, ties broken by index)."""
+    key = _stream_key(seed, stream)
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(n, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95)) & _M64
+    h = _mix(ctr ^ key)
+    return np.argsort(h, kind="stable").astype(np.int64)
+
+
+def _l2n(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.float32)
+    n = np.sqrt((x * x).sum(axis=1, dtype=np.float32)).astype(np.float32)
+    return (x / n[:, None]).astype(np.float32)
+
+
+def make_pair(n: int, seed: int, canvas=None, pos_noise=0.5, desc_noise=0.03, outlier_frac=0.1):
+    """One synthetic image pair in the reference's GMatcher input layout.
+
+    Returns a dict of NumPy arrays:
+      keypoints0/1 (1,N,2) f32, descriptors0/1 (1,256,N) f32, scores0/1 (1,N) f32,
+      image0/1 zero uint8 (1,H,W,3) (only .shape is consumed -- gmatcher.py:28,265),
+      gt_perm (N,) int64: keypoint i of image0 corresponds to keypoint gt_perm[i]
+      of image1, or -1 when its partner was replaced by an outlier.
+
+    ``outlier_frac`` of the image-1 keypoints are replaced by fresh random keypoints with
+    unrelated descriptors, so a realistic share of rows/columns must end in the dustbin.
+    """
+    w, h = canvas if canvas is not None else canvas_for(n)
+    xy0 = np.stack([uniform(seed, 1, n) * w, uniform(seed, 2, n) * h], axis=1).astype(np.float32)
+    d0 = _l2n(normal(seed, 3, n * 128).reshape(n, 128))
+    s0 = uniform(seed, 4, n).astype(np.float32)
+
+    perm = permutation(seed, 5, n)                    # image1[j] = image0[perm[j]]
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n, dtype=np.int64)
+    xy1 = xy0[perm].astype(np.float64) + pos_noise * normal(seed, 6, 2 * n).reshape(n, 2)
+    xy1[:, 0] = np.clip(xy1[:, 0], 0.0, float(w))
+    xy1[:, 1] = np.clip(xy1[:, 1], 0.0, float(h))
+    xy1 = xy1.astype(np.float32)
+    d1 = d0[perm].astype(np.float64) + desc_noise * normal(seed, 7, n * 128).reshape(n, 128)
+    d1 = _l2n(d1)
+    s1 = uniform(seed, 8, n).astype(np.float32)
+    n_out = int(n * outlier_frac)
+    if n_out > 0:
+        sel = permutation(seed, 9, n)[:n_out]                     # image-1 slots that become outliers
+        xy1[sel] = np.stack([uniform(seed, 10, n_out) * w, uniform(seed, 11, n_out) * h], axis=1).astype(np.float32)
+        d1[sel] = _l2n(normal(seed, 12, n_out * 128).reshape(n_out, 128))
+        inv[perm[sel]] = -1
+
+    def dup(d):  # (N,128) -> (1,256,N)
+        return np.ascontiguousarray(np.concatenate([d, d], axis=1).T[None]).astype(np.float32)
+
+    return {
+        "keypoints0": xy0[None].copy(), "keypoints1": xy1[None].copy(),
+        "descriptors0": dup(d0), "descriptors1": dup(d1),
+        "scores0": s0[None].copy(), "scores1": s1[None].copy(),
+        "image0": np.zeros((1, h, w, 3), dtype=np.uint8),
+        "image1": np.zeros((1, h, w, 3), dtype=np.uint8),
+        "gt_perm": inv,
+    }
+
+
+# ----------------------------------------------------------------------------- weights
+
+GAINS = {"kenc": 0.5, "gnn_encoder": 3.0, "gnn": 0.3, "final_proj": 1.0}
+
+
+def _gain_for(name: str) -> float:
+    for k in ("gnn_encoder", "kenc", "final_proj", "gnn"):
+        if name.startswith(k + "."):
+            return GAINS[k]
+    return 1.0
+
+
+def state_dict_spec(descriptor_dim=256, keypoint_encoder=(32, 64, 128, 256), n_layers=18,
+                    sage_bias_layout="fc_self"):
+    """Ordered (name, shape) list mirroring GMatcher.state_dict() (gmatcher.py:177-207).
+
+    Key names follow the reference module tree: ``bin_score``, ``kenc.encoder.*``,
+    ``gnn.layers.{i}.attn.{merge,proj.{0,1,2}}``, ``gnn.layers.{i}.mlp.{0,1,3}``,
+    ``gnn_encoder.layers.{i}.{fc_neigh,fc_self}``, ``final_proj``.
+    """
+    D = descriptor_dim
+    spec = [("bin_score", ())]
+    ch = [2] + list(keypoint_encoder) + [D]
+    idx = 0
+    for i in range(1, len(ch)):
+        spec += [(f"kenc.encoder.{idx}.weight", (ch[i], ch[i - 1], 1)), (f"kenc.encoder.{idx}.bias", (ch[i],))]
+        idx += 1
+        if i < len(ch) - 1:
+            for nm in ("weight", "bias", "running_mean", "running_var"):
+                spec.append((f"kenc.encoder.{idx}.{nm}", (ch[i],)))
+            spec.append((f"kenc.encoder.{idx}.num_batches_tracked", ()))
+            idx += 2  # BN + ReLU
+    for l in range(n_layers):
+        p = f"gnn.layers.{l}."
+        spec += [(p + "attn.merge.weight", (D, D, 1)), (p + "attn.merge.bias", (D,))]
+        for j in range(3):
+            spec += [(p + f"attn.proj.{j}.weight", (D, D, 1)), (p + f"attn.proj.{j}.bias", (D,))]
+        spec += [(p + "mlp.0.weight", (2 * D, 2 * D, 1)), (p + "mlp.0.bias", (2 * D,))]
+        for nm in ("weight", "bias", "running_mean", "running_var"):
+            spec.append((p + f"mlp.1.{nm}", (2 * D,)))
+        spec.append((p + "mlp.1.num_batches_tracked", ()))
+        spec += [(p + "mlp.3.weight", (D, 2 * D, 1)), (p + "mlp.3.bias", (D,))]
+    dims = [(D, D // 2), (D // 2, D // 2), (D // 2, D)]
+    for i, (ci, co) in enumerate(dims):
+        p = f"gnn_encoder.layers.{i}."
+        if sage_bias_layout == "fc_self":      # DGL >= 1.0
+            spec += [(p + "fc_neigh.weight", (co, ci)), (p + "fc_self.weight", (co, ci)), (p + "fc_self.bias", (co,))]
+        else:                                  # older DGL: separate bias parameter
+            spec += [(p + "bias", (co,)), (p + "fc_neigh.weight", (co, ci)), (p + "fc_self.weight", (co, ci))]
+    spec += [("final_proj.weight", (D, D, 1)), ("final_proj.bias", (D,))]
+    return spec
+
+
+def make_state_dict(seed: int = 123, bias_std: float = 0.02, bn_jitter: float = 0.2, **kw):
+    """Synthetic GMatcher weights as {name: np.ndarray}.
+
+    Conv/linear weights ~ N(0, g^2/fan_in); biases ~ N(0, bias_std^2) (non-zero so the bias
+    paths are exercised); BatchNorm gamma/var ~ 1 +- bn_jitter, beta/mean small -- so the
+    BN-folding path is exercised as well.  ``bin_score`` = 1 (gmatcher.py:206).
+    """
+    out = {}
+    for i, (name, shape) in enumerate(state_dict_spec(**kw)):
+        n = int(np.prod(shape)) if len(shape) else 1
+        stream = 1000 + i
+        if name == "bin_score":
+            a = np.array(1.0, dtype=np.float32)
+        elif name.endswith("num_batches_tracked"):
+            a = np.array(0, dtype=np.int64)
+        elif name.endswith("running_var"):
+            a = (1.0 + bn_jitter * (2.0 * uniform(seed, stream, n) - 1.0)).astype(np.float32).reshape(shape)
+        elif name.endswith("running_mean"):
+            a = (bias_std * normal(seed, stream, n)).astype(np.float32).reshape(shape)
+        elif ".mlp.1." in name or (name.startswith("kenc.encoder.") and len(shape) == 1
+                                   and int(name.split(".")[2]) in (1, 4, 7, 10)):
+            # BatchNorm affine
+            if name.endswith("weight"):
+                a = (1.0 + bn_jitter * (2.0 * uniform(seed, stream, n) - 1.0)).astype(np.float32).reshape(shape)
+            else:
+                a = (bias_std * normal(seed, stream, n)).astype(np.float32).reshape(shape)
+        elif name.endswith("bias"):
+            a = (bias_std * normal(seed, stream, n)).astype(np.float32).reshape(shape)
+        else:
+            fan_in = shape[1]
+            g = _gain_for(name)
+            a = (normal(seed, stream, n) * (g / np.sqrt(float(fan_in)))).astype(np.float32).reshape(shape)
+        out[name] = a
+    return out
