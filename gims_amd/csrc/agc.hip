@@ -1,0 +1,612 @@
+// Adaptive graph construction on the GPU -- models/agc.py:682-709 (live subset) for one image.
+//
+//   K1 cosine similarity  S = Dn Dn^T                      (agc.py:382-391)  exact-f32 MFMA GEMM (linear.hip)
+//   K2 exact percentile threshold over the strict upper triangle (agc.py:367-380, 439-440)
+//        4-pass 8-bit radix select on order-preserving uint keys -- exact, no sort, no host round trip
+//   K3 radius candidates (float64, inclusive) AND sim >= thr  (agc.py:435-447) -> adjacency BIT MATRIX
+//   K4 connect_isolated_nodes, sequential semantics           (agc.py:476-495)
+//   K5 connected components (min-label union-find in LDS) + small-component removal (agc.py:497-516)
+//   K6 fast_connect_components, one round                     (agc.py:518-565)
+//   K7 sorted relabel + bidirectional CSR                     (dgl.from_networkx, agc.py:704)
+//
+// Everything here is integer / byte / latency-bound work (N <= 16384 nodes, a few 10^4 edges) except K1/K2,
+// which stream the N x N similarity matrix (HBM-bound).  The adjacency lives in an N x N bit matrix so that
+// the sequential fix-ups only flip bits and the CSR falls out of popcounts in ascending neighbour order.
+#include "common.h"
+
+namespace gims {
+
+constexpr int AGC_MAX_N = 16384;
+
+struct AgcWs {
+  float* dn;            // [n][d] normalised descriptors
+  float* S;             // [n][lds]
+  uint64_t* bits;       // [n][nw]
+  uint32_t* hist;       // [256]
+  uint32_t* sel;        // [4]: prefix, k_lo, k_hi, pad
+  int32_t* deg;         // [n]
+  int32_t* nn;          // [n]
+  int32_t* label;       // [n]
+  int32_t* alive;       // [n]
+  int32_t* newid;       // [n]
+  int32_t* crank;       // [n] component rank of a root (ascending root id), -1 otherwise
+  int32_t* coff;        // [n+1]
+  int32_t* members;     // [n]
+  int32_t* nnc;         // [n]
+  int32_t* link;        // [n][2]
+  double* cent;         // [n][2]
+  int32_t* ptr0;        // [n+1] CSR of the pre-removal graph (original ids)
+  int32_t* idx0;        // [cap]
+  int32_t* counters;    // [16] scratch counters: 0 coarse directed edges, 1 components, 2 pre-removal directed edges
+  int32_t* coff2;       // [n+1] component offsets (scan of sizes)
+  int n, d, lds, nw, cap;
+};
+
+// ---------------------------------------------------------------------------------------------- K1 prologue
+__global__ __launch_bounds__(256) void agc_normalize_kernel(const float* __restrict__ desc, int64_t ldd, int n, int d,
+                                                            float* __restrict__ dn) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= n) return;
+  const float* x = desc + (int64_t)row * ldd;
+  float s = 0.f;
+  for (int j = lane; j < d; j += 64) s = fmaf(x[j], x[j], s);
+  s = wave_sum(s);
+  const float nrm = fmaxf(sqrtf(s), 1e-12f);   // F.normalize: x / max(||x||, eps)
+  for (int j = lane; j < d; j += 64) dn[(int64_t)row * d + j] = x[j] / nrm;
+}
+
+// ---------------------------------------------------------------------------------------------- K2 radix select
+__global__ __launch_bounds__(256) void agc_hist_kernel(AgcWs w, int pass) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t prefix = w.sel[0];
+  const int shift = 24 - 8 * pass;
+  const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+  for (int i = blockIdx.x; i < w.n; i += gridDim.x) {
+    const float* row = w.S + (int64_t)i * w.lds;
+    for (int j = i + 1 + threadIdx.x; j < w.n; j += 256) {
+      const uint32_t k = f32_key(row[j]);
+      if ((k & himask) == (prefix & himask)) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&w.hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void agc_pick_kernel(AgcWs w, int pass) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = w.hist[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t k = (uint64_t)w.sel[1] | ((uint64_t)w.sel[2] << 32);
+    uint64_t cum = 0;
+    int b = 0;
+    for (; b < 255; ++b) {
+      if (cum + h[b] > k) break;
+      cum += h[b];
+    }
+    k -= cum;
+    const int shift = 24 - 8 * pass;
+    w.sel[0] |= ((uint32_t)b) << shift;
+    w.sel[1] = (uint32_t)k;
+    w.sel[2] = (uint32_t)(k >> 32);
+  }
+  __syncthreads();
+  w.hist[threadIdx.x] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------- K3 adjacency bits
+// one wave per (row i, 64-column word): bit j set iff j != i, ||xi-xj||^2 <= r^2 in float64 (inclusive),
+// and S[min(i,j)][max(i,j)] >= thr  (the reference tests sim_matrix[i,j] with i<j, agc.py:445-446)
+__global__ __launch_bounds__(256) void agc_adj_kernel(AgcWs w, const float* __restrict__ kpts, double r2) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const int i = (int)(wid / w.nw), wj = (int)(wid % w.nw);
+  if (i >= w.n) return;
+  const float thr = key_f32(w.sel[0]);
+  const int j = wj * 64 + lane;
+  bool pred = false;
+  if (j < w.n && j != i) {
+    const double dx = (double)kpts[2 * i] - (double)kpts[2 * j];
+    const double dy = (double)kpts[2 * i + 1] - (double)kpts[2 * j + 1];
+    if (dx * dx + dy * dy <= r2) {
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      pred = w.S[(int64_t)a * w.lds + b] >= thr;
+    }
+  }
+  const uint64_t mask = __ballot(pred);
+  if (lane == 0) w.bits[(int64_t)i * w.nw + wj] = mask;
+}
+
+__global__ __launch_bounds__(256) void agc_deg_kernel(AgcWs w, int32_t* __restrict__ deg, int32_t* total) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= w.n) return;
+  int c = 0;
+  for (int k = lane; k < w.nw; k += 64) c += __popcll(w.bits[(int64_t)i * w.nw + k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (lane == 0) {
+    deg[i] = c;
+    if (total && c) atomicAdd(total, c);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- K4 isolated nodes
+__global__ __launch_bounds__(256) void agc_iso_nn_kernel(AgcWs w, const float* __restrict__ kpts) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= w.n) return;
+  if (w.deg[i] != 0) {
+    if (lane == 0) w.nn[i] = -1;
+    return;
+  }
+  const double xi = kpts[2 * i], yi = kpts[2 * i + 1];
+  double bd = 1e300;
+  int bj = 0x7fffffff;
+  for (int j = lane; j < w.n; j += 64) {
+    if (j == i) continue;
+    const double dx = (double)kpts[2 * j] - xi, dy = (double)kpts[2 * j + 1] - yi;
+    const double dd = dx * dx + dy * dy;
+    if (dd < bd) { bd = dd; bj = j; }   // ascending j: first minimum kept
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double od = __shfl_xor(bd, o, 64);
+    const int oj = __shfl_xor(bj, o, 64);
+    if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+  }
+  if (lane == 0) w.nn[i] = bj;
+}
+
+// sequential semantics of agc.py:489-494: ascending node order; a node is still isolated at its turn iff it
+// started isolated and no earlier isolated node attached to it.  Only the (few) initially isolated nodes
+// are walked, from an ordered compaction held in LDS.
+__global__ __launch_bounds__(1024) void agc_iso_seq_kernel(AgcWs w, int32_t* info) {
+  extern __shared__ int32_t sm[];
+  int32_t* list = sm;                       // [n] ordered isolated ids
+  uint32_t* touched = (uint32_t*)(sm + w.n);  // [n/32+1]
+  __shared__ int wcount[17];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int total_dir = w.counters[0];
+  for (int k = t; k < (w.n + 31) / 32; k += 1024) touched[k] = 0;
+  if (t == 0) wcount[16] = 0;
+  __syncthreads();
+  int n_added = 0;
+  if (total_dir != 0 && w.n > 1) {       // agc.py:486 early return when the graph has no edges
+    for (int base = 0; base < w.n; base += 1024) {
+      const int i = base + t;
+      const bool iso = i < w.n && w.deg[i] == 0;
+      const uint64_t m = __ballot(iso);
+      if (lane == 0) wcount[wave] = __popcll(m);
+      __syncthreads();
+      int off = wcount[16];
+      for (int q = 0; q < wave; ++q) off += wcount[q];
+      if (iso) list[off + __popcll(m & ((1ull << lane) - 1))] = i;
+      __syncthreads();
+      if (t == 0) {
+        int s = 0;
+        for (int q = 0; q < 16; ++q) s += wcount[q];
+        wcount[16] += s;
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      const int cnt = wcount[16];
+      for (int q = 0; q < cnt; ++q) {
+        const int i = list[q];
+        if (touched[i >> 5] & (1u << (i & 31))) continue;
+        const int j = w.nn[i];
+        w.bits[(int64_t)i * w.nw + (j >> 6)] |= 1ull << (j & 63);
+        w.bits[(int64_t)j * w.nw + (i >> 6)] |= 1ull << (i & 63);
+        touched[j >> 5] |= 1u << (j & 31);
+        ++n_added;
+      }
+    }
+  }
+  if (t == 0) info[3] = n_added;
+}
+
+// ---------------------------------------------------------------------------------------------- bits -> CSR
+__global__ __launch_bounds__(1024) void agc_scan_kernel(const int32_t* __restrict__ deg, const int32_t* __restrict__ sel_flag,
+                                                        int n, int32_t* __restrict__ ptr, int32_t* total_out) {
+  // exclusive scan of deg[i] (only rows with sel_flag[i] != 0 when sel_flag given), single workgroup
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + t;
+    int v = (i < n && (!sel_flag || sel_flag[i])) ? deg[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int off = carry;
+    for (int q = 0; q < wave; ++q) off += wsum[q];
+    if (i < n) ptr[i] = off + x - v;
+    __syncthreads();
+    if (t == 0) {
+      int s = 0;
+      for (int q = 0; q < 16; ++q) s += wsum[q];
+      carry += s;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    ptr[n] = carry;
+    if (total_out) *total_out = carry;
+  }
+}
+
+// row i of the bit matrix -> idx[ptr[i] ...] ascending; optional relabel through newid (rows with newid<0 skipped)
+__global__ __launch_bounds__(256) void agc_fill_kernel(AgcWs w, const int32_t* __restrict__ ptr_by_row,
+                                                       const int32_t* __restrict__ newid, int32_t* __restrict__ idx,
+                                                       int cap) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= w.n) return;
+  if (newid && newid[i] < 0) return;
+  int off = ptr_by_row[newid ? newid[i] : i];
+  for (int k0 = 0; k0 < w.nw; k0 += 64) {
+    const int k = k0 + lane;
+    const uint64_t word = k < w.nw ? w.bits[(int64_t)i * w.nw + k] : 0ull;
+    int c = __popcll(word);
+    int x = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    int pos = off + x - c;
+    uint64_t m = word;
+    while (m) {
+      const int b = __ffsll((unsigned long long)m) - 1;
+      m &= m - 1;
+      const int j = k * 64 + b;
+      if (pos < cap) idx[pos] = newid ? newid[j] : j;
+      ++pos;
+    }
+    off += __shfl(x, 63, 64);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- K5 components
+// single workgroup; LDS: parent[n], count[n]
+__global__ __launch_bounds__(1024) void agc_cc_kernel(AgcWs w, int min_size, int32_t* __restrict__ kept, int32_t* info) {
+  extern __shared__ int32_t sm[];
+  int32_t* parent = sm;
+  int32_t* count = sm + w.n;
+  __shared__ int changed;
+  __shared__ int wsum[16];
+  __shared__ int carry[2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = w.n;
+  for (int u = t; u < n; u += 1024) { parent[u] = u; count[u] = 0; }
+  __syncthreads();
+  volatile int32_t* vp = parent;
+  auto find = [&](int x) {
+    for (;;) {
+      const int p = vp[x];
+      if (p == x) return x;
+      const int g = vp[p];
+      if (g != p) vp[x] = g;   // path compression step (benign race: g is always an ancestor of x)
+      x = p;
+    }
+  };
+  for (int iter = 0; iter < 100000; ++iter) {
+    if (t == 0) changed = 0;
+    __syncthreads();
+    for (int u = t; u < n; u += 1024) {
+      const int beg = w.ptr0[u], end = w.ptr0[u + 1] < w.cap ? w.ptr0[u + 1] : w.cap;
+      for (int e = beg; e < end; ++e) {
+        const int v = w.idx0[e];
+        if (v < u) continue;   // each undirected edge once
+        int ru = find(u), rv = find(v);
+        if (ru != rv) {
+          const int hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
+          atomicMin(&parent[hi], lo);
+          changed = 1;
+        }
+      }
+    }
+    __syncthreads();
+    const int c = changed;
+    __syncthreads();
+    if (!c) break;
+  }
+  for (int u = t; u < n; u += 1024) {
+    const int x = find(u);
+    w.label[u] = x;
+    atomicAdd(&count[x], 1);
+  }
+  __syncthreads();
+  // ordered compaction of alive nodes (kept) and of alive roots (component ranks)
+  if (t == 0) { carry[0] = 0; carry[1] = 0; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int u = base + t;
+    bool al = false, root = false;
+    if (u < n) {
+      const int l = w.label[u];
+      al = count[l] >= min_size;
+      root = al && l == u;
+      w.alive[u] = al ? 1 : 0;
+    }
+    const uint64_t ma = __ballot(al), mr = __ballot(root);
+    const uint64_t lt = (1ull << lane) - 1;
+    if (lane == 0) wsum[wave] = __popcll(ma) | (__popcll(mr) << 16);
+    __syncthreads();
+    int offa = carry[0], offr = carry[1];
+    for (int q = 0; q < wave; ++q) { offa += wsum[q] & 0xffff; offr += wsum[q] >> 16; }
+    if (u < n) {
+      const int id = al ? offa + __popcll(ma & lt) : -1;
+      w.newid[u] = id;
+      if (al) kept[id] = u;
+      w.crank[u] = root ? offr + __popcll(mr & lt) : -1;
+    }
+    __syncthreads();
+    if (t == 0) {
+      int sa = 0, sr = 0;
+      for (int q = 0; q < 16; ++q) { sa += wsum[q] & 0xffff; sr += wsum[q] >> 16; }
+      carry[0] += sa; carry[1] += sr;
+    }
+    __syncthreads();
+  }
+  // component offsets (size of each alive component, in rank order)
+  for (int u = t; u < n; u += 1024) {
+    const int r = w.crank[u];
+    if (r >= 0) w.coff[r] = count[u];   // temporarily sizes
+  }
+  if (t == 0) {
+    info[0] = carry[0];
+    info[4] = carry[1];
+    w.counters[1] = carry[1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- K6 linking
+// members of each alive component in ascending node order + float64 centroid (one wave per component)
+__global__ __launch_bounds__(256) void agc_members_kernel(AgcWs w, const float* __restrict__ kpts,
+                                                          const int32_t* __restrict__ coff) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + wave;
+  const int C = w.counters[1];
+  if (c >= C) return;
+  int off = coff[c];
+  double sx = 0.0, sy = 0.0;
+  int cnt = 0;
+  for (int base = 0; base < w.n; base += 64) {
+    const int u = base + lane;
+    bool mem = false;
+    if (u < w.n && w.alive[u]) mem = w.crank[w.label[u]] == c;
+    const uint64_t m = __ballot(mem);
+    if (mem) {
+      w.members[off + __popcll(m & ((1ull << lane) - 1))] = u;
+      sx += (double)kpts[2 * u];
+      sy += (double)kpts[2 * u + 1];
+    }
+    const int pc = __popcll(m);
+    off += pc;
+    cnt += pc;
+  }
+  sx = wave_sum_f64(sx);
+  sy = wave_sum_f64(sy);
+  if (lane == 0) { w.cent[2 * c] = sx / (double)cnt; w.cent[2 * c + 1] = sy / (double)cnt; }
+}
+
+__global__ __launch_bounds__(256) void agc_nnc_kernel(AgcWs w) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + wave;
+  const int C = w.counters[1];
+  if (c >= C) return;
+  const double cx = w.cent[2 * c], cy = w.cent[2 * c + 1];
+  double bd = 1e300;
+  int bj = 0x7fffffff;
+  for (int j = lane; j < C; j += 64) {
+    if (j == c) continue;
+    const double dx = w.cent[2 * j] - cx, dy = w.cent[2 * j + 1] - cy;
+    const double dd = dx * dx + dy * dy;
+    if (dd < bd) { bd = dd; bj = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double od = __shfl_xor(bd, o, 64);
+    const int oj = __shfl_xor(bj, o, 64);
+    if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+  }
+  if (lane == 0) w.nnc[c] = bj;
+}
+
+// one workgroup per component i: closest (v in comp nn(i), u in comp i) pair, lexicographic (d2, v, u)
+__global__ __launch_bounds__(256) void agc_link_kernel(AgcWs w, const float* __restrict__ kpts,
+                                                       const int32_t* __restrict__ coff) {
+  __shared__ double sd[256];
+  __shared__ int sv[256], su[256];
+  const int i = blockIdx.x, t = threadIdx.x;
+  const int C = w.counters[1];
+  if (i >= C || C <= 1) return;
+  const int j = w.nnc[i];
+  // agc.py:550-552: skip when the reverse pair was linked earlier (j < i and nn(j) == i)
+  if (j < i && w.nnc[j] == i) {
+    if (t == 0) { w.link[2 * i] = -1; w.link[2 * i + 1] = -1; }
+    return;
+  }
+  const int ai = coff[i], na = coff[i + 1] - ai;
+  const int aj = coff[j], nb = coff[j + 1] - aj;
+  double bd = 1e300;
+  int bv = 0x7fffffff, bu = 0x7fffffff;
+  const int64_t total = (int64_t)na * nb;
+  for (int64_t p = t; p < total; p += 256) {
+    const int v = w.members[aj + (int)(p / na)], u = w.members[ai + (int)(p % na)];
+    const double dx = (double)kpts[2 * u] - (double)kpts[2 * v], dy = (double)kpts[2 * u + 1] - (double)kpts[2 * v + 1];
+    const double dd = dx * dx + dy * dy;
+    if (dd < bd || (dd == bd && (v < bv || (v == bv && u < bu)))) { bd = dd; bv = v; bu = u; }
+  }
+  sd[t] = bd; sv[t] = bv; su[t] = bu;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      const double od = sd[t + s];
+      const int ov = sv[t + s], ou = su[t + s];
+      if (od < sd[t] || (od == sd[t] && (ov < sv[t] || (ov == sv[t] && ou < su[t])))) { sd[t] = od; sv[t] = ov; su[t] = ou; }
+    }
+    __syncthreads();
+  }
+  if (t == 0) { w.link[2 * i] = su[0]; w.link[2 * i + 1] = sv[0]; }
+}
+
+__global__ __launch_bounds__(256) void agc_link_apply_kernel(AgcWs w, int32_t* info) {
+  const int C = w.counters[1];
+  if (C <= 1) { if (threadIdx.x == 0 && blockIdx.x == 0) info[5] = 0; return; }
+  int added = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < C; i += gridDim.x * 256) {
+    const int u = w.link[2 * i], v = w.link[2 * i + 1];
+    if (u < 0) continue;
+    atomicOr((unsigned long long*)&w.bits[(int64_t)u * w.nw + (v >> 6)], 1ull << (v & 63));
+    atomicOr((unsigned long long*)&w.bits[(int64_t)v * w.nw + (u >> 6)], 1ull << (u & 63));
+    ++added;
+  }
+  if (added) atomicAdd(&info[5], added);
+}
+
+__global__ void agc_finish_kernel(AgcWs w, int32_t* info, int max_edges_dir) {
+  info[2] = w.counters[0] / 2;
+  info[6] = (int32_t)__float_as_uint(key_f32(w.sel[0]));
+  info[7] = (info[1] > max_edges_dir || w.counters[0] > w.cap || w.counters[2] > w.cap) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void agc_kept_deg_kernel(AgcWs w, const int32_t* __restrict__ deg_by_row,
+                                                           int32_t* __restrict__ deg_kept) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= w.n) return;
+  const int id = w.newid[u];
+  if (id >= 0) deg_kept[id] = deg_by_row[u];
+}
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t agc_layout(int n, int d, int cap, char* base, AgcWs* w) {
+  const int lds = (n + 3) & ~3, nw = (n + 63) / 64;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return base ? base + o : (char*)nullptr; };
+  char* p;
+  p = take((size_t)n * d * 4); if (w) w->dn = (float*)p;
+  p = take((size_t)n * lds * 4); if (w) w->S = (float*)p;
+  p = take((size_t)n * nw * 8); if (w) w->bits = (uint64_t*)p;
+  p = take(256 * 4); if (w) w->hist = (uint32_t*)p;
+  p = take(16); if (w) w->sel = (uint32_t*)p;
+  p = take((size_t)n * 4); if (w) w->deg = (int32_t*)p;
+  p = take((size_t)n * 4); if (w) w->nn = (int32_t*)p;
+  p = take((size_t)n * 4); if (w) w->label = (int32_t*)p;
+  p = take((size_t)n * 4); if (w) w->alive = (int32_t*)p;
+  p = take((size_t)n * 4); if (w) w->newid = (int32_t*)p;
+  p = take((size_t)n * 4); if (w) w->crank = (int32_t*)p;
+  p = take((size_t)(n + 1) * 4); if (w) w->coff = (int32_t*)p;
+  p = take((size_t)n * 4); if (w) w->members = (int32_t*)p;
+  p = take((size_t)n * 4); if (w) w->nnc = (int32_t*)p;
+  p = take((size_t)n * 8); if (w) w->link = (int32_t*)p;
+  p = take((size_t)n * 16); if (w) w->cent = (double*)p;
+  p = take((size_t)(n + 1) * 4); if (w) w->ptr0 = (int32_t*)p;
+  p = take((size_t)cap * 4); if (w) w->idx0 = (int32_t*)p;
+  p = take(64); if (w) w->counters = (int32_t*)p;
+  p = take((size_t)(n + 1) * 4); if (w) w->coff2 = (int32_t*)p;
+  if (w) { w->n = n; w->d = d; w->lds = lds; w->nw = nw; w->cap = cap; }
+  return off;
+}
+
+constexpr int AGC_CAP_PER_NODE = 64;  // scratch CSR capacity of the pre-removal graph: 64 directed edges per node
+
+}  // namespace gims
+
+extern "C" size_t gims_agc_workspace_bytes(int32_t n, int32_t d) {
+  using namespace gims;
+  if (n <= 0 || d <= 0) return 0;
+  return agc_layout(n, d, n * AGC_CAP_PER_NODE, nullptr, nullptr);
+}
+
+extern "C" int gims_agc_build(const float* kpts, const float* desc, int64_t ldd, int32_t n, int32_t d, double radius,
+                              double percentile, int32_t min_size, void* work, size_t work_bytes, int32_t* kept,
+                              int32_t* indptr, int32_t* indices, int32_t max_edges_dir, int32_t* info, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(kpts && desc && work && kept && indptr && indices && info, "gims_agc_build: null pointer");
+  GIMS_CHECK_ARG(n >= 2 && n <= AGC_MAX_N, "gims_agc_build: n=%d out of range [2, %d]", n, AGC_MAX_N);
+  GIMS_CHECK_ARG(d > 0 && (d % 32) == 0 && (ldd % 4) == 0, "gims_agc_build: d=%d must be a multiple of 32 (ldd %% 4 == 0)", d);
+  GIMS_CHECK_ARG(work_bytes >= gims_agc_workspace_bytes(n, d), "gims_agc_build: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  AgcWs w;
+  const int cap = n * AGC_CAP_PER_NODE;
+  agc_layout(n, d, cap, (char*)work, &w);
+  int32_t* sizes = w.coff;  // component sizes land in coff, are scanned in place into offsets via ptr scratch
+
+  // K1
+  hipLaunchKernelGGL(agc_normalize_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, desc, ldd, n, d, w.dn);
+  gims_linear_args la = {};
+  la.a0 = w.dn; la.lda0 = d; la.a1 = nullptr; la.lda1 = 0; la.w = w.dn; la.w_lo = nullptr; la.ldw = d;
+  la.bias = nullptr; la.residual = nullptr; la.out_f32 = w.S; la.ldc = w.lds; la.out_bf16 = nullptr; la.ldc_bf16 = 0;
+  la.m = n; la.n = n; la.k = d; la.k0 = d; la.act = GIMS_ACT_NONE; la.precision = GIMS_PREC_F32; la.scale = 1.f;
+  int rc = gims_linear(&la, stream);
+  if (rc != GIMS_OK) return rc;
+
+  // K2: k = int(L * p / 100), clamped (agc.py:378-379)
+  const int64_t L = (int64_t)n * (n - 1) / 2;
+  int64_t k = (int64_t)(((double)L * percentile) / 100.0);
+  if (k >= L) k = L - 1;
+  if (k < 0) k = 0;
+  uint32_t sel_init[4] = {0u, (uint32_t)(k & 0xffffffffll), (uint32_t)(k >> 32), 0u};
+  GIMS_HIP(hipMemsetAsync(w.hist, 0, 256 * 4, s));
+  GIMS_HIP(hipMemsetAsync(w.counters, 0, 64, s));
+  GIMS_HIP(hipMemsetAsync(info, 0, 8 * 4, s));
+  GIMS_HIP(hipMemcpyAsync(w.sel, sel_init, 16, hipMemcpyHostToDevice, s));
+  GIMS_HIP(hipStreamSynchronize(s));   // sel_init lives on this stack frame
+  const int hgrid = n < 2048 ? n : 2048;
+  for (int pass = 0; pass < 4; ++pass) {
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid), dim3(256), 0, s, w, pass);
+    hipLaunchKernelGGL(agc_pick_kernel, dim3(1), dim3(256), 0, s, w, pass);
+  }
+  // K3
+  const int64_t nwaves = (int64_t)n * w.nw;
+  hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv(nwaves, 4)), dim3(256), 0, s, w, kpts, radius * radius);
+  hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, w.deg, w.counters + 0);
+  // info[2] = undirected coarse edges is filled by agc_finish from counters[0] / 2 (see below)
+  // K4
+  hipLaunchKernelGGL(agc_iso_nn_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, kpts);
+  const size_t iso_lds = (size_t)n * 4 + ((size_t)(n + 31) / 32 + 1) * 4;
+  hipLaunchKernelGGL(agc_iso_seq_kernel, dim3(1), dim3(1024), iso_lds, s, w, info);
+  // CSR of the pre-removal graph (original ids) for the component search
+  hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, w.deg, (int32_t*)nullptr);
+  hipLaunchKernelGGL(agc_scan_kernel, dim3(1), dim3(1024), 0, s, w.deg, (const int32_t*)nullptr, n, w.ptr0, w.counters + 2);
+  hipLaunchKernelGGL(agc_fill_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, w.ptr0, (const int32_t*)nullptr, w.idx0, cap);
+  // K5
+  static bool attr_set = false;
+  const size_t cc_lds = (size_t)n * 8;
+  if (!attr_set) {
+    GIMS_HIP(hipFuncSetAttribute((const void*)agc_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AGC_MAX_N * 8));
+    GIMS_HIP(hipFuncSetAttribute((const void*)agc_iso_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AGC_MAX_N * 4 + (AGC_MAX_N / 32 + 2) * 4));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(agc_cc_kernel, dim3(1), dim3(1024), cc_lds, s, w, min_size, kept, info);
+  // K6: component sizes (in coff, rank order) -> offsets; members, centroids, nearest component, links
+  int32_t* coff_scan = w.coff2;
+  hipLaunchKernelGGL(agc_scan_kernel, dim3(1), dim3(1024), 0, s, sizes, (const int32_t*)nullptr, n, coff_scan, (int32_t*)nullptr);
+  hipLaunchKernelGGL(agc_members_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, kpts, coff_scan);
+  hipLaunchKernelGGL(agc_nnc_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w);
+  hipLaunchKernelGGL(agc_link_kernel, dim3(n), dim3(256), 0, s, w, kpts, coff_scan);
+  hipLaunchKernelGGL(agc_link_apply_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w, info);
+  // K7: final CSR over the kept nodes, relabelled in sorted order
+  hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, w.deg, (int32_t*)nullptr);
+  GIMS_HIP(hipMemsetAsync(w.nn, 0, (size_t)n * 4, s));
+  hipLaunchKernelGGL(agc_kept_deg_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w, w.deg, w.nn /* reuse as deg_kept */);
+  hipLaunchKernelGGL(agc_scan_kernel, dim3(1), dim3(1024), 0, s, w.nn, (const int32_t*)nullptr, n, indptr, info + 1);
+  hipLaunchKernelGGL(agc_fill_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, indptr, w.newid, indices, max_edges_dir);
+  hipLaunchKernelGGL(agc_finish_kernel, dim3(1), dim3(1), 0, s, w, info, max_edges_dir);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}

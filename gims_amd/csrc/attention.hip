@@ -1,0 +1,224 @@
+// Flash-style multi-head attention on bf16 MFMA (v_mfma_f32_32x32x16_bf16), head dim 64.
+//
+//   O[q, h*64+d] = sum_k softmax_k( Q[q,h,:] . K[k,h,:] / 8 ) V[k,h,d]        (gmatcher.py:35-39,109-113)
+//
+// The N x M score / probability matrices of the reference (two (1,4,N,M) f32 temporaries) are never
+// materialised: each wave owns 32 queries and walks the keys in tiles of 64 with an online softmax.
+//
+// Structure (CDNA4 idioms):
+//   * swapped QK^T: S^T = K Q^T, so the MFMA C layout puts ONE query per lane column (col = lane&31) and
+//     32 of the tile's 64 keys in that lane's registers -- row max / row sum are in-lane plus a single
+//     exchange with lane^32, and the O^T accumulator rescale is lane-local;
+//   * P never leaves registers: the C-layout of S^T already is a valid B-operand layout for
+//     O^T += V^T P^T once the k-index of that MFMA is *defined* as the key order the lane holds
+//     (keys {0-3, 8-11} for lanes 0-31, {4-7, 12-15} for lanes 32-63 of each 16-key step) and V^T is
+//     read from LDS in the same order (two ds_read_b64 per fragment) -- no permlane / bpermute;
+//   * K tile in LDS row-major with XOR-swizzled 16-byte chunks (conflict-free ds_read_b128),
+//     V tile transposed on the way into LDS ([d][key], pitch 68 elements: conflict-free ds_read_b64);
+//   * global->register prefetch of the next K/V tile is issued before the MFMAs of the current one.
+#include "common.h"
+
+namespace gims {
+
+constexpr int DH = 64;          // head dim
+constexpr int KB = 64;          // keys per tile
+constexpr int QW = 32;          // queries per wave
+constexpr int ATT_WAVES = 4;    // waves per workgroup
+constexpr int QB = QW * ATT_WAVES;
+constexpr int VT_LD = KB + 4;   // V^T pitch in bf16 elements (136 bytes)
+
+__device__ __forceinline__ int k_off(int row, int chunk) {  // K tile: [64 keys][64 d], 16-byte chunks swizzled
+  return row * DH + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+__global__ __launch_bounds__(256) void attention_bf16_kernel(
+    const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
+    const gims_attn_problem* __restrict__ problems, float* __restrict__ out, int64_t ld_out) {
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[KB * DH];
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[DH * VT_LD];
+
+  const gims_attn_problem pr = problems[blockIdx.z];
+  const int q0 = blockIdx.x * QB;
+  if (q0 >= pr.n_q) return;
+  const int head = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- Q^T B-operand fragments: lane holds Q[q = li][d = 16*s + 8*lh .. +8]
+  bf16x8 qf[4];
+  {
+    int qr = q0 + wave * QW + li;
+    qr = qr < pr.n_q ? qr : pr.n_q - 1;
+    const uint16_t* qp = qkv + (int64_t)(pr.q_off + qr) * ld + q_col + head * DH + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+  }
+
+  f32x16 o[2];  // O^T accumulator: d-block x 16 regs, column = query li
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+  float m_run = -1e30f;                           // running max of raw scores (same for lane and lane^32)
+  float l_run = 0.f;                              // this lane's share of the row sum
+
+  // staging: K tile 64 rows x 8 chunks = 512 chunks (2 per thread); V tile 32 key-pairs x 8 d-octets = 256
+  uint4 rk[2], rv[2];
+  const int n_tiles = (pr.n_kv + KB - 1) / KB;
+  auto load_tile = [&](int kt) {
+    const int kbase = kt * KB;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int f = t + 256 * it, row = f >> 3, ch = f & 7;
+      int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      rk[it] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * ch);
+    }
+    {
+      const int kp = t >> 3, oct = t & 7;  // key pair (2kp, 2kp+1), d = 8*oct..+8
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        int kr = kbase + 2 * kp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+        rv[e] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * oct);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int f = t + 256 * it, row = f >> 3, ch = f & 7;
+      *(uint4*)(Ks + k_off(row, ch)) = rk[it];
+    }
+    {
+      const int kp = t >> 3, oct = t & 7;
+      const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
+      const uint32_t b[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // d = 8*oct + 2j, 2j+1 ; pack (key 2kp, key 2kp+1) per d
+        const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
+        const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
+        *(uint32_t*)(Vt + (8 * oct + 2 * j) * VT_LD + 2 * kp) = lo;
+        *(uint32_t*)(Vt + (8 * oct + 2 * j + 1) * VT_LD + 2 * kp) = hi;
+      }
+    }
+  };
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    if (kt + 1 < n_tiles) load_tile(kt + 1);
+
+    // ---- S^T = K Q^T : two 32-key blocks x 32 queries, K = 64 (4 steps of 16)
+    f32x16 sacc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(Ks + k_off(b * 32 + li, 2 * s + lh));
+        sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[b], 0, 0, 0);
+      }
+    }
+    // ---- mask keys past the end (last tile only), tile max
+    const int kbase = kt * KB;
+    float tmax = -1e30f;
+    if (kbase + KB > pr.n_kv) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= pr.n_kv) sacc[b][r] = -1e30f;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    m_run = m_new;
+    const float mc = m_new * c;
+    // ---- P = exp2(S*c - m*c), packed to bf16 B-operand fragments in the lane's own key order
+    float lsum = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[b][r], c, -mc));
+        lsum += pv[r];
+      }
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {  // 16-key step h2 of block b: regs 8*h2 .. 8*h2+7
+        uint4 pk;
+        pk.x = pack_bf2(pv[8 * h2 + 0], pv[8 * h2 + 1]);
+        pk.y = pack_bf2(pv[8 * h2 + 2], pv[8 * h2 + 3]);
+        pk.z = pack_bf2(pv[8 * h2 + 4], pv[8 * h2 + 5]);
+        pk.w = pack_bf2(pv[8 * h2 + 6], pv[8 * h2 + 7]);
+        pf[2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
+      }
+    }
+    l_run = l_run * alpha + lsum;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // ---- O^T += V^T P^T : two 32-d blocks, 4 steps of 16 keys
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        // lane's k-slots of step s: keys 16s + {0-3, 8-11} + 4*lh
+        const uint16_t* vp = Vt + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
+        const uint2 v0 = *(const uint2*)(vp);
+        const uint2 v1 = *(const uint2*)(vp + 8);
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < n_tiles) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // ---- normalise and store: lane holds query li, d = 32*i + 8*(r>>2) + 4*lh + (r&3)
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  const int qr = q0 + wave * QW + li;
+  if (qr < pr.n_q) {
+    float* op = out + (int64_t)(pr.q_off + qr) * ld_out + head * DH + 4 * lh;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+        *(float4*)(op + 32 * i + 8 * g) = v;
+      }
+  }
+}
+
+}  // namespace gims
+
+extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
+                              const gims_attn_problem* problems, int32_t n_problems, int32_t max_n_q,
+                              int32_t n_heads, float* out, int64_t ld_out, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(qkv && problems && out, "gims_attention: null pointer");
+  GIMS_CHECK_ARG(n_problems > 0 && max_n_q > 0 && n_heads > 0, "gims_attention: empty launch");
+  GIMS_CHECK_ARG((ld % 8) == 0 && (q_col % 8) == 0 && (k_col % 8) == 0 && (v_col % 8) == 0,
+                 "gims_attention: qkv ld / column offsets must be multiples of 8 (16-byte loads)");
+  GIMS_CHECK_ARG((ld_out % 4) == 0, "gims_attention: ld_out must be a multiple of 4");
+  dim3 grid(cdiv(max_n_q, QB), n_heads, n_problems);
+  hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col,
+                     problems, out, ld_out);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}

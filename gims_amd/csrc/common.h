@@ -1,0 +1,84 @@
+// Shared helpers for the gfx950 kernels of libgims_hip.so.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gims_hip.h"
+
+namespace gims {
+
+void set_error(const char* fmt, ...);
+
+#define GIMS_CHECK_ARG(cond, ...)                    \
+  do {                                               \
+    if (!(cond)) {                                   \
+      ::gims::set_error(__VA_ARGS__);                \
+      return GIMS_EINVAL;                            \
+    }                                                \
+  } while (0)
+
+#define GIMS_HIP(call)                                                                     \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      ::gims::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GIMS_EHIP;                                                                    \
+    }                                                                                      \
+  } while (0)
+
+#define GIMS_LAUNCH_CHECK()                                                                \
+  do {                                                                                     \
+    hipError_t e_ = hipGetLastError();                                                     \
+    if (e_ != hipSuccess) {                                                                \
+      ::gims::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GIMS_EHIP;                                                                    \
+    }                                                                                      \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// round-to-nearest-even f32 -> bf16 (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  f32x2 f = {lo, hi};
+  hwbf16x2 h = __builtin_convertvector(f, hwbf16x2);
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ uint16_t f2bf(float x) { return (uint16_t)(pack_bf2(x, 0.f) & 0xffffu); }
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// order-preserving map f32 -> u32 (ascending), for exact radix selection
+__device__ __forceinline__ uint32_t f32_key(float x) {
+  uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace gims

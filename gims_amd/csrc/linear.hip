@@ -1,0 +1,294 @@
+// Linear layers / dense contractions on the gfx950 matrix cores.
+//
+//   C[m,n] = act(scale * sum_k A[m,k] W[n,k] + bias[n]) (+ R[m,n])        (see include/gims_hip.h)
+//
+// GIMS_PREC_F32   : v_mfma_f32_32x32x2_f32 -- exact f32 (bitwise a k-ordered fmaf chain), 157 TF peak.
+// GIMS_PREC_BF16X3: v_mfma_f32_32x32x16_bf16 on split operands, hi*hi + hi*lo + lo*hi (~2^-17 relative),
+//                   3 MFMAs per product at 16x the f32 rate.
+//
+// Tiling (both): 128x128 output tile per 256-thread workgroup, 2x2 waves, each wave a 64x64 sub-tile as
+// 2x2 MFMA tiles of 32x32 (64 accumulator registers).  Operands are staged through LDS; the next K-tile
+// is prefetched into registers while the current one is consumed (issue-early / write-late).
+// Activations are point-major, so rows of A and of W are both K-contiguous: every global load is a full
+// 128-byte line per row.
+#include "common.h"
+
+namespace gims {
+
+constexpr int BM = 128, BN = 128;
+
+// ------------------------------------------------------------------------------------------ epilogue
+__device__ __forceinline__ void epilogue_store(const gims_linear_args& p, int row, int col, float acc) {
+  if (row >= p.m || col >= p.n) return;
+  float v = acc * p.scale;
+  if (p.bias) v += p.bias[col];
+  if (p.act == GIMS_ACT_RELU) v = fmaxf(v, 0.f);
+  if (p.residual) v += p.residual[(int64_t)row * p.ldc + col];
+  if (p.out_f32) p.out_f32[(int64_t)row * p.ldc + col] = v;
+  if (p.out_bf16) p.out_bf16[(int64_t)row * p.ldc_bf16 + col] = f2bf(v);
+}
+
+// ------------------------------------------------------------------------------------------ f32 MFMA
+// LDS image: As[k][m] / Ws[k][n] (k-major) so an MFMA operand read (lane -> row l&31, k = l>>5) is
+// 32 consecutive floats per half-wave: conflict-free ds_read_b32.  Row pitch 129 makes the transposing
+// ds_write_b32 of the staging pass conflict-free too (lane -> k-quad l&7, row l>>3).
+constexpr int F32_BK = 32;
+constexpr int F32_LD = BM + 1;
+
+__global__ __launch_bounds__(256) void linear_f32_kernel(gims_linear_args p) {
+  __shared__ float As[F32_BK * F32_LD];
+  __shared__ float Ws[F32_BK * F32_LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const float* w = (const float*)p.w;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[4], rw[4];
+  const int nk = p.k / F32_BK;
+
+  auto load_tile = [&](int kt) {
+    const int k = kt * F32_BK;
+    const float* abase;
+    int64_t lda;
+    int kk;
+    if (k < p.k0) { abase = p.a0; lda = p.lda0; kk = k; } else { abase = p.a1; lda = p.lda1; kk = k - p.k0; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int f = t + 256 * it, row = f >> 3, kq = f & 7;
+      int ar = m0 + row; ar = ar < p.m ? ar : p.m - 1;
+      int wr = n0 + row; wr = wr < p.n ? wr : p.n - 1;
+      ra[it] = *(const float4*)(abase + (int64_t)ar * lda + kk + 4 * kq);
+      rw[it] = *(const float4*)(w + (int64_t)wr * p.ldw + k + 4 * kq);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int f = t + 256 * it, row = f >> 3, kq = f & 7;
+      float* a = As + (4 * kq) * F32_LD + row;
+      a[0] = ra[it].x; a[F32_LD] = ra[it].y; a[2 * F32_LD] = ra[it].z; a[3 * F32_LD] = ra[it].w;
+      float* b = Ws + (4 * kq) * F32_LD + row;
+      b[0] = rw[it].x; b[F32_LD] = rw[it].y; b[2 * F32_LD] = rw[it].z; b[3 * F32_LD] = rw[it].w;
+    }
+  };
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int s = 0; s < F32_BK / 2; ++s) {
+      const float* ap = As + (2 * s + lh) * F32_LD + wm * 64 + li;
+      const float* bp = Ws + (2 * s + lh) * F32_LD + wn * 64 + li;
+      const float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = n0 + wn * 64 + j * 32 + li;
+        epilogue_store(p, row, col, acc[i][j][r]);
+      }
+}
+
+// ------------------------------------------------------------------------------------------ split-bf16 MFMA
+// LDS image per plane: [128 rows][64 k] bf16 = 128-byte rows, 16-byte chunks XOR-swizzled with
+// (row>>1)&7 so the ds_read_b128 of an MFMA operand (16 lanes of a group -> 16 different rows, same
+// logical chunk) spreads over all 16 slots of the 256-byte bank line.
+constexpr int X3_BK = 64;
+constexpr int X3_PLANE = BM * X3_BK;  // bf16 elements per plane
+
+__device__ __forceinline__ int x3_off(int row, int chunk) {  // element offset of a 16-byte chunk
+  return row * X3_BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+__global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(gims_linear_args p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Ah = smem;
+  uint16_t* Al = smem + X3_PLANE;
+  uint16_t* Wh = smem + 2 * X3_PLANE;
+  uint16_t* Wl = smem + 3 * X3_PLANE;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const uint16_t* wh = (const uint16_t*)p.w;
+  const uint16_t* wl = (const uint16_t*)p.w_lo;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[8];
+  uint4 rwh[4], rwl[4];
+  const int nk = p.k / X3_BK;
+
+  auto load_tile = [&](int kt) {
+    const int k = kt * X3_BK;
+    const float* abase;
+    int64_t lda;
+    int kk;
+    if (k < p.k0) { abase = p.a0; lda = p.lda0; kk = k; } else { abase = p.a1; lda = p.lda1; kk = k - p.k0; }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {  // A: 128 rows x 16 float4
+      const int f = t + 256 * it, row = f >> 4, kq = f & 15;
+      int ar = m0 + row; ar = ar < p.m ? ar : p.m - 1;
+      ra[it] = *(const float4*)(abase + (int64_t)ar * lda + kk + 4 * kq);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {  // W planes: 128 rows x 8 chunks of 8 bf16
+      const int f = t + 256 * it, row = f >> 3, ch = f & 7;
+      int wr = n0 + row; wr = wr < p.n ? wr : p.n - 1;
+      rwh[it] = *(const uint4*)(wh + (int64_t)wr * p.ldw + k + 8 * ch);
+      rwl[it] = *(const uint4*)(wl + (int64_t)wr * p.ldw + k + 8 * ch);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int f = t + 256 * it, row = f >> 4, kq = f & 15;
+      const float4 x = ra[it];
+      const uint32_t h01 = pack_bf2(x.x, x.y), h23 = pack_bf2(x.z, x.w);
+      const uint32_t l01 = pack_bf2(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xffff0000u));
+      const uint32_t l23 = pack_bf2(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xffff0000u));
+      const int off = x3_off(row, kq >> 1) + 4 * (kq & 1);
+      *(uint2*)(Ah + off) = make_uint2(h01, h23);
+      *(uint2*)(Al + off) = make_uint2(l01, l23);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int f = t + 256 * it, row = f >> 3, ch = f & 7;
+      *(uint4*)(Wh + x3_off(row, ch)) = rwh[it];
+      *(uint4*)(Wl + x3_off(row, ch)) = rwl[it];
+    }
+  };
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int s = 0; s < X3_BK / 16; ++s) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ar = wm * 64 + i * 32 + li, br = wn * 64 + i * 32 + li;
+        ah[i] = *(const bf16x8*)(Ah + x3_off(ar, 2 * s + lh));
+        al[i] = *(const bf16x8*)(Al + x3_off(ar, 2 * s + lh));
+        bh[i] = *(const bf16x8*)(Wh + x3_off(br, 2 * s + lh));
+        bl[i] = *(const bf16x8*)(Wl + x3_off(br, 2 * s + lh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // small terms first, then the dominant hi*hi product
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = n0 + wn * 64 + j * 32 + li;
+        epilogue_store(p, row, col, acc[i][j][r]);
+      }
+}
+
+// ------------------------------------------------------------------------------------------ split kernel
+__global__ void split_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ hi,
+                                  uint16_t* __restrict__ lo, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float x = src[i];
+    const uint16_t h = f2bf(x);
+    hi[i] = h;
+    lo[i] = f2bf(x - bf2f(h));
+  }
+}
+
+}  // namespace gims
+
+extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(a != nullptr, "gims_linear: null args");
+  GIMS_CHECK_ARG(a->m > 0 && a->n > 0 && a->k > 0, "gims_linear: empty problem m=%d n=%d k=%d", a->m, a->n, a->k);
+  GIMS_CHECK_ARG(a->a0 && a->w, "gims_linear: null operand");
+  GIMS_CHECK_ARG(a->k0 > 0 && a->k0 <= a->k, "gims_linear: k0=%d out of range", a->k0);
+  GIMS_CHECK_ARG(a->k0 == a->k || a->a1 != nullptr, "gims_linear: second A segment missing");
+  GIMS_CHECK_ARG(a->out_f32 || a->out_bf16, "gims_linear: no output");
+  GIMS_CHECK_ARG(!a->residual || a->out_f32, "gims_linear: residual needs an f32 output (shared ldc)");
+  GIMS_CHECK_ARG((a->lda0 % 4) == 0 && (a->lda1 % 4) == 0, "gims_linear: lda must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(a->n, BN), cdiv(a->m, BM));
+  if (a->precision == GIMS_PREC_F32) {
+    GIMS_CHECK_ARG((a->k % F32_BK) == 0 && (a->k0 % F32_BK) == 0, "gims_linear(f32): K=%d k0=%d must be multiples of %d", a->k, a->k0, F32_BK);
+    GIMS_CHECK_ARG((a->ldw % 4) == 0, "gims_linear(f32): ldw must be a multiple of 4");
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, s, *a);
+  } else if (a->precision == GIMS_PREC_BF16X3) {
+    GIMS_CHECK_ARG((a->k % X3_BK) == 0 && (a->k0 % X3_BK) == 0, "gims_linear(bf16x3): K=%d k0=%d must be multiples of %d", a->k, a->k0, X3_BK);
+    GIMS_CHECK_ARG(a->w_lo != nullptr && (a->ldw % 8) == 0, "gims_linear(bf16x3): needs w_lo and ldw %% 8 == 0");
+    static bool attr_set = false;
+    const size_t lds = 4 * X3_PLANE * sizeof(uint16_t);
+    if (!attr_set) {
+      GIMS_HIP(hipFuncSetAttribute((const void*)linear_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(linear_bf16x3_kernel, grid, dim3(256), lds, s, *a);
+  } else {
+    GIMS_CHECK_ARG(false, "gims_linear: unknown precision %d", a->precision);
+  }
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(src && hi && lo && n >= 0, "gims_split_bf16: bad args");
+  if (n == 0) return GIMS_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, hi, lo, n);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}

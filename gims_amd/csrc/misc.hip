@@ -1,0 +1,109 @@
+// Small HBM/latency-bound kernels of the matcher path: keypoint-encoder front end, GraphSAGE mean
+// aggregation, row gather.  One wave per row, float4 lanes, no LDS.
+#include "common.h"
+
+#include <stdarg.h>
+
+namespace gims {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// normalize_keypoints (gmatcher.py:26-33) + Conv1d(2->c1) + BN(eval, folded) + ReLU (gmatcher.py:87-97)
+__global__ __launch_bounds__(256) void kenc_first_kernel(const float* __restrict__ kpts, const float* __restrict__ norm3,
+                                                         const int32_t* __restrict__ seg, const float* __restrict__ w1,
+                                                         const float* __restrict__ b1, int c1, float* __restrict__ out,
+                                                         int64_t n) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = idx / c1;
+  const int ch = (int)(idx - row * c1);
+  if (row >= n) return;
+  const float* nm = norm3 + 3 * seg[row];
+  const float x = (kpts[2 * row] - nm[0]) / nm[2];
+  const float y = (kpts[2 * row + 1] - nm[1]) / nm[2];
+  float v = fmaf(w1[2 * ch + 1], y, fmaf(w1[2 * ch], x, b1[ch]));
+  out[row * c1 + ch] = fmaxf(v, 0.f);
+}
+
+// out[i,:] = mean over CSR neighbours of h[j,:]   (one wave per node, lanes over channel quads)
+__global__ __launch_bounds__(256) void sage_mean_kernel(const float* __restrict__ h, int64_t ldh,
+                                                        const int32_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices, int n, int c,
+                                                        float* __restrict__ out, int64_t ldo) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int node = blockIdx.x * 4 + wave;
+  if (node >= n) return;
+  const int beg = indptr[node], end = indptr[node + 1];
+  for (int q = lane; 4 * q < c; q += 64) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = beg; e < end; ++e) {
+      const float4 x = *(const float4*)(h + (int64_t)indices[e] * ldh + 4 * q);
+      s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+    }
+    // sum / deg, like DGL's mean reducer (a true division, not a multiply by the reciprocal)
+    if (end > beg) {
+      const float d = (float)(end - beg);
+      s.x /= d; s.y /= d; s.z /= d; s.w /= d;
+    }
+    *(float4*)(out + (int64_t)node * ldo + 4 * q) = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                          const int32_t* __restrict__ idx, int n, int c,
+                                                          float* __restrict__ dst, int64_t ldd) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= n) return;
+  const float* s = src + (int64_t)idx[row] * lds;
+  float* d = dst + (int64_t)row * ldd;
+  for (int j = lane; j < c; j += 64) d[j] = s[j];
+}
+
+}  // namespace gims
+
+extern "C" int gims_abi_version(void) { return GIMS_ABI_VERSION; }
+extern "C" const char* gims_last_error(void) { return gims::g_err; }
+extern "C" int gims_stream_sync(void* stream) {
+  using namespace gims;
+  GIMS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return GIMS_OK;
+}
+
+extern "C" int gims_kenc_first(const float* kpts, const float* norm3, const int32_t* seg_of_row, const float* w1,
+                               const float* b1, int32_t c1, float* out, int64_t n, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(kpts && norm3 && seg_of_row && w1 && b1 && out && c1 > 0 && n >= 0, "gims_kenc_first: bad arguments");
+  if (n == 0) return GIMS_OK;
+  hipLaunchKernelGGL(kenc_first_kernel, dim3(cdiv(n * c1, 256)), dim3(256), 0, (hipStream_t)stream, kpts, norm3,
+                     seg_of_row, w1, b1, c1, out, n);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_sage_mean(const float* h, int64_t ldh, const int32_t* indptr, const int32_t* indices, int32_t n,
+                              int32_t c, float* out, int64_t ldo, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(h && indptr && indices && out && n >= 0, "gims_sage_mean: bad arguments");
+  GIMS_CHECK_ARG((c % 4) == 0 && (ldh % 4) == 0 && (ldo % 4) == 0, "gims_sage_mean: c / ld must be multiples of 4");
+  if (n == 0) return GIMS_OK;
+  hipLaunchKernelGGL(sage_mean_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, h, ldh, indptr, indices, n, c,
+                     out, ldo);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_gather_rows(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t c, float* dst,
+                                int64_t ldd, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(src && idx && dst && n >= 0 && c > 0, "gims_gather_rows: bad arguments");
+  if (n == 0) return GIMS_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, src, lds, idx, n, c, dst, ldd);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}

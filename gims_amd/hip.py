@@ -1,0 +1,215 @@
+"""ctypes binding of libgims_hip.so (C ABI declared in include/gims_hip.h).
+
+PyTorch is plumbing only: tensors own the device memory, ``torch.cuda.current_stream()`` provides the
+hipStream_t.  There is NO CPU fallback: if the shared library is missing or a call fails this module
+raises -- the product path never routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgims_hip.so")
+
+PREC_F32, PREC_BF16X3 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+
+
+class GimsHipError(RuntimeError):
+    pass
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("a0", C.c_void_p), ("lda0", C.c_int64), ("a1", C.c_void_p), ("lda1", C.c_int64),
+                ("w", C.c_void_p), ("w_lo", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
+                ("residual", C.c_void_p), ("out_f32", C.c_void_p), ("ldc", C.c_int64),
+                ("out_bf16", C.c_void_p), ("ldc_bf16", C.c_int64), ("m", C.c_int32), ("n", C.c_int32),
+                ("k", C.c_int32), ("k0", C.c_int32), ("act", C.c_int32), ("precision", C.c_int32),
+                ("scale", C.c_float)]
+
+
+class OtProblem(C.Structure):
+    _fields_ = [("scores", C.c_void_p), ("ld", C.c_int64), ("n", C.c_int32), ("m", C.c_int32),
+                ("matches0", C.c_void_p), ("matches1", C.c_void_p), ("mscores0", C.c_void_p),
+                ("mscores1", C.c_void_p), ("uv", C.c_void_p)]
+
+
+_SIGNATURES = {
+    "gims_abi_version": (C.c_int, []),
+    "gims_last_error": (C.c_char_p, []),
+    "gims_stream_sync": (C.c_int, [C.c_void_p]),
+    "gims_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                 C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_kenc_first": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                  C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_sage_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_int64, C.c_void_p]),
+    "gims_agc_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gims_agc_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                 C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                 C.c_void_p, C.c_void_p]),
+    "gims_sinkhorn_workspace_bytes": (C.c_size_t, [C.POINTER(OtProblem), C.c_int32]),
+    "gims_sinkhorn_match": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_float,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gims_ot_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """dlopen the kernel library and type its entry points.  Raises if it is not there."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise GimsHipError(f"{p} is missing: build it with `python -m gims_amd.build` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(p)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.gims_abi_version() != 1:
+        raise GimsHipError(f"ABI version mismatch: library {lib.gims_abi_version()} != binding 1")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gims_last_error()
+        raise GimsHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t: torch.Tensor, dtype=None):
+    if not t.is_cuda:
+        raise GimsHipError("expected a device tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise GimsHipError(f"expected {dtype}, got {t.dtype}")
+    return t
+
+
+def linear(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
+           precision=PREC_F32, scale=1.0, n=None):
+    """C = act(scale * [a0 | a1] @ w[:n].T + bias) (+ residual).  a*: f32 [m, k*]; w: [n, K] f32 or bf16 planes."""
+    lib = load()
+    m, k0 = a0.shape
+    k = k0 + (a1.shape[1] if a1 is not None else 0)
+    n = w.shape[0] if n is None else n
+    assert w.shape[1] == k, (w.shape, k)
+    assert a0.stride(1) == 1 and w.stride(1) == 1
+    if out is None and out_bf16 is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a0.device)
+    args = LinearArgs(_p(_dev(a0, torch.float32)), a0.stride(0), _p(a1), a1.stride(0) if a1 is not None else 0,
+                      _p(w), _p(w_lo), w.stride(0), _p(bias), _p(residual), _p(out),
+                      out.stride(0) if out is not None else 0, _p(out_bf16),
+                      out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale))
+    if residual is not None:
+        assert out is not None and residual.stride(0) == out.stride(0)
+    _check(lib.gims_linear(C.byref(args), _stream()), "gims_linear")
+    return out if out is not None else out_bf16
+
+
+def split_bf16(x: torch.Tensor):
+    lib = load()
+    x = x.contiguous()
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _check(lib.gims_split_bf16(_p(_dev(x, torch.float32)), _p(hi), _p(lo), x.numel(), _stream()), "gims_split_bf16")
+    return hi, lo
+
+
+def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: int, out: torch.Tensor,
+              q_col=0, k_col=256, v_col=512):
+    """qkv bf16 [rows, ld]; problems int32 [P,4] (q_off, n_q, kv_off, n_kv) on device; out f32 [rows, ld_out]."""
+    lib = load()
+    assert qkv.dtype == torch.bfloat16 and problems.dtype == torch.int32 and problems.is_cuda
+    _check(lib.gims_attention(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0],
+                              max_n_q, n_heads, _p(_dev(out, torch.float32)), out.stride(0), _stream()),
+           "gims_attention")
+    return out
+
+
+def kenc_first(kpts, norm3, seg_of_row, w1, b1, out):
+    lib = load()
+    c1 = w1.shape[0]
+    _check(lib.gims_kenc_first(_p(_dev(kpts, torch.float32)), _p(norm3), _p(seg_of_row), _p(w1), _p(b1), c1,
+                               _p(out), kpts.shape[0], _stream()), "gims_kenc_first")
+    return out
+
+
+def sage_mean(h, indptr, indices, out, n=None, c=None):
+    lib = load()
+    n = h.shape[0] if n is None else n
+    c = h.shape[1] if c is None else c
+    _check(lib.gims_sage_mean(_p(_dev(h, torch.float32)), h.stride(0), _p(indptr), _p(indices), n, c, _p(out),
+                              out.stride(0), _stream()), "gims_sage_mean")
+    return out
+
+
+def gather_rows(src, idx, out):
+    lib = load()
+    _check(lib.gims_gather_rows(_p(_dev(src, torch.float32)), src.stride(0), _p(idx), idx.shape[0], src.shape[1],
+                                _p(out), out.stride(0), _stream()), "gims_gather_rows")
+    return out
+
+
+def agc_workspace_bytes(n: int, d: int) -> int:
+    return int(load().gims_agc_workspace_bytes(n, d))
+
+
+def agc_build(kpts, desc, radius, percentile, min_size, work, kept, indptr, indices, info):
+    """Asynchronous adaptive-graph build for one image; see include/gims_hip.h."""
+    lib = load()
+    n, d = desc.shape
+    assert desc.stride(1) == 1 and kpts.is_contiguous()
+    _check(lib.gims_agc_build(_p(_dev(kpts, torch.float32)), _p(_dev(desc, torch.float32)), desc.stride(0), n, d,
+                              float(radius), float(percentile), int(min_size), _p(work), work.numel() * work.element_size(),
+                              _p(kept), _p(indptr), _p(indices), indices.numel(), _p(info), _stream()), "gims_agc_build")
+
+
+def make_ot_problems(items):
+    """items: list of dicts with scores (f32 [n, ld>=m] view), n, m, matches0/1, mscores0/1, uv tensors."""
+    arr = (OtProblem * len(items))()
+    for i, it in enumerate(items):
+        s = it["scores"]
+        arr[i] = OtProblem(_p(s), s.stride(0), it["n"], it["m"], _p(it["matches0"]), _p(it["matches1"]),
+                           _p(it["mscores0"]), _p(it["mscores1"]), _p(it["uv"]))
+    return arr
+
+
+def sinkhorn_workspace_bytes(problems) -> int:
+    return int(load().gims_sinkhorn_workspace_bytes(problems, len(problems)))
+
+
+def sinkhorn_match(problems, alpha: float, iters: int, match_threshold: float, work: torch.Tensor):
+    lib = load()
+    _check(lib.gims_sinkhorn_match(problems, len(problems), float(alpha), int(iters), float(match_threshold), _p(work),
+                                   work.numel() * work.element_size(), _stream()), "gims_sinkhorn_match")
+
+
+def ot_matrix(scores, n, m, alpha, uv):
+    lib = load()
+    out = torch.empty((n + 1, m + 1), dtype=torch.float32, device=scores.device)
+    _check(lib.gims_ot_matrix(_p(scores), scores.stride(0), n, m, float(alpha), _p(uv), _p(out), _stream()),
+           "gims_ot_matrix")
+    return out

@@ -1,0 +1,166 @@
+/*
+ * gims_hip.h -- C ABI of libgims_hip.so: the MI355X (gfx950) kernels behind the GIMS matcher hot path.
+ *
+ * The reference (songxf1024/GIMS) has no FFI boundary of its own for this path: the boundary is the
+ * Python nn.Module API  GMatcher(config).forward(data)  (models/gmatcher.py:177,219) and
+ * Matching(config).forward(data)  (models/matching.py:10,15).  gims_amd/gmatcher.py keeps that API and
+ * calls the entry points below through ctypes; each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless its name starts with h_ (host);
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns immediately,
+ *     except the two calls documented as synchronising;
+ *   - return value: 0 on success, a negative GIMS_E* code on failure (never throws across the ABI);
+ *     gims_last_error() returns a thread-local message for the last failure;
+ *   - activations are POINT-MAJOR: row = keypoint, column = channel (the reference is channel-major
+ *     (B,C,N); the Python shell transposes at the boundary);
+ *   - no hidden global state; safe to call from several threads on different streams.
+ */
+#ifndef GIMS_HIP_H
+#define GIMS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIMS_ABI_VERSION 1
+
+#define GIMS_OK 0
+#define GIMS_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
+#define GIMS_EHIP (-2)     /* a HIP runtime call failed */
+#define GIMS_ENUMERIC (-3) /* numeric guard tripped (non-finite Sinkhorn marginal) */
+
+int gims_abi_version(void);
+const char* gims_last_error(void);
+/* Blocks until `stream` is idle (hipStreamSynchronize). */
+int gims_stream_sync(void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Linear layers (1x1 Conv1d / nn.Linear):   C[m, n] = act( sum_k A[m,k] * W[n,k] + bias[n] ) (+ R[m,n])
+ * replaces: nn.Conv1d(k=1) stacks of MLP / MultiHeadedAttention / final_proj (gmatcher.py:11-24,
+ * 106-125, 202-205, 273), SAGEConv's fc_self / fc_neigh (gmatcher.py:149-151) and the two dense
+ * contractions of the path: cosine similarity D D^T (agc.py:390) and the score matrix
+ * einsum('bdn,bdm->bnm') (gmatcher.py:274).
+ * A is given as up to two K-segments (concat-free torch.cat([x, message]), gmatcher.py:125):
+ *   k <  k0 : a0[m*lda0 + k]          k >= k0 : a1[m*lda1 + (k-k0)]
+ * W is row-major [n][K] (PyTorch weight layout).  K and k0 must be multiples of 32.
+ * precision: GIMS_PREC_F32   -> exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 operands in a0/a1/w;
+ *            GIMS_PREC_BF16X3-> split-bf16 MFMA (hi*hi + hi*lo + lo*hi); W comes pre-split in
+ *                               w (hi plane) / w_lo (lo plane), A is split on the fly.
+ * out_f32 / out_bf16 may each be NULL; `residual` (f32, same ld as out_f32) may alias out_f32.
+ */
+#define GIMS_PREC_F32 0
+#define GIMS_PREC_BF16X3 1
+#define GIMS_ACT_NONE 0
+#define GIMS_ACT_RELU 1
+
+typedef struct gims_linear_args {
+  const float* a0; int64_t lda0;
+  const float* a1; int64_t lda1;       /* may be NULL when k0 == K */
+  const void* w; const void* w_lo; int64_t ldw;  /* f32 (F32) or bf16 planes (BF16X3) */
+  const float* bias;                   /* [n] or NULL */
+  const float* residual;               /* [m][ldc] or NULL */
+  float* out_f32; int64_t ldc;         /* may be NULL */
+  uint16_t* out_bf16; int64_t ldc_bf16;/* may be NULL */
+  int32_t m, n, k, k0;
+  int32_t act;                         /* GIMS_ACT_* */
+  int32_t precision;                   /* GIMS_PREC_* */
+  float scale;                         /* applied to the accumulator before bias (1.0 = none) */
+} gims_linear_args;
+
+int gims_linear(const gims_linear_args* args, void* stream);
+
+/* Split an f32 array into bf16 hi/lo planes (hi = bf16_rne(x), lo = bf16_rne(x - hi)). */
+int gims_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-head attention message   O = softmax(Q K^T / sqrt(dh)) V   per head, flash-style.
+ * replaces: attention() + the head view of MultiHeadedAttention.forward (gmatcher.py:35-39,109-113).
+ * qkv: bf16 [rows][ld] with, per row, Q at column q_col + h*64 + d, K at k_col + ..., V at v_col + ...
+ *      (head-BLOCKED channels; the Python shell permutes the reference's interleaved heads
+ *      (view(B, dh, H, N), gmatcher.py:111) into the projection weights).
+ * Each problem p attends queries [q_off, q_off+n_q) to keys/values [kv_off, kv_off+n_kv).
+ * out: f32 [rows][ld_out], head-blocked columns h*64 + d.       dh = 64, heads = n_heads.
+ */
+typedef struct gims_attn_problem { int32_t q_off, n_q, kv_off, n_kv; } gims_attn_problem;
+
+int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
+                   const gims_attn_problem* problems /* device */, int32_t n_problems, int32_t max_n_q,
+                   int32_t n_heads, float* out, int64_t ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Keypoint encoder front end: normalize_keypoints (gmatcher.py:26-33, with the reference's NHWC-as-NCHW
+ * quirk resolved by the caller into cx, cy, scale) fused with the first Conv1d(2->c1)+BN(eval)+ReLU of
+ * KeypointEncoder (gmatcher.py:87-97).  w1: [c1][2] and b1: [c1] have BatchNorm already folded in.
+ * kpts: [n][2] pixel xy.  out: [n][c1].  Per-row normalisation parameters: norm[row_seg[i]] = {cx,cy,scale}.
+ */
+int gims_kenc_first(const float* kpts, const float* norm3 /* [n_seg][3] */, const int32_t* seg_of_row,
+                    const float* w1, const float* b1, int32_t c1, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GraphSAGE mean aggregation over the adaptive graph (CSR by destination, both edge directions):
+ *   out[i, :] = mean_{j in indices[indptr[i]:indptr[i+1]]} h[j, :]     (zero for isolated nodes)
+ * replaces: the message passing of dgl.nn.SAGEConv(...,'mean') (call sites gmatcher.py:149-151,158).
+ * Row ids in `indices` are absolute rows of h.  c must be a multiple of 4.
+ */
+int gims_sage_mean(const float* h, int64_t ldh, const int32_t* indptr, const int32_t* indices,
+                   int32_t n, int32_t c, float* out, int64_t ldo, void* stream);
+
+/* Gather rows: dst[i, :] = src[idx[i], :]  (kept-keypoint compaction, gmatcher.py:244-249). */
+int gims_gather_rows(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t c,
+                     float* dst, int64_t ldd, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Adaptive graph construction for ONE image (models/agc.py:682-709, live subset):
+ *   cosine similarity (382-391) -> exact percentile threshold over the strict upper triangle (367-380,
+ *   439-440) -> radius pairs in float64, inclusive (435-436) filtered by sim >= thr (445-447) ->
+ *   connect_isolated_nodes (476-495) -> remove_small_components (497-516) -> fast_connect_components
+ *   (518-565, one round) -> sorted relabel + bidirectional CSR (dgl.from_networkx, 704).
+ * kpts [n][2] f32, desc [n][d] f32 (point-major, un-normalised).  `work` is scratch of at least
+ * gims_agc_workspace_bytes(n, d) bytes.  Outputs (device): kept[<=n] (sorted original ids),
+ * indptr[n_kept+1], indices[<= max_edges_dir] in kept-relabelled ids, info[8] =
+ *   {n_kept, n_dir_edges, n_coarse_edges, n_iso_added, n_components_after_removal, n_link_added,
+ *    threshold bits (f32), overflow flag}.
+ * Exact-distance ties in the two sequential fix-ups resolve to the lowest node index.
+ * Asynchronous; read info[] after synchronising the stream.
+ */
+size_t gims_agc_workspace_bytes(int32_t n, int32_t d);
+int gims_agc_build(const float* kpts, const float* desc, int64_t ldd, int32_t n, int32_t d, double radius,
+                   double percentile, int32_t min_size, void* work, size_t work_bytes, int32_t* kept,
+                   int32_t* indptr, int32_t* indices, int32_t max_edges_dir, int32_t* info, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Log-domain Sinkhorn optimal transport + mutual-argmax match selection.
+ * replaces: log_optimal_transport / log_sinkhorn_iterations (gmatcher.py:41-69) and the selection block
+ * (gmatcher.py:284-294).  The (N+1)x(M+1) couplings matrix is never materialised: the dustbin row and
+ * column (= alpha) are handled analytically, and the iteration runs in the absorbed-potential form
+ *   P_ij = exp(Z_ij + u_i + v_j);  u_i += log mu_i - log sum_j P_ij;  v_j += log nu_j - log sum_i P_ij
+ * which is the reference recurrence u = log mu - LSE_j(Z + v), v = log nu - LSE_i(Z + u) rewritten so
+ * that one sweep over Z serves both the row update and the following column update.
+ * scores: f32 [n][ld] (inner N x M block, already divided by sqrt(D)).  Problems are independent
+ * (one per image pair); `work` needs gims_sinkhorn_workspace_bytes(...) bytes.
+ * Outputs per problem (device): matches0 [n] int64, matches1 [m] int64, mscores0 [n] f32, mscores1 [m]
+ * f32, uv: u [n+1] then v [m+1] (log-potentials, so that OT = Z + u + v - norm can be rebuilt) then one
+ * status word (0 = ok, 1 = a marginal left the finite range: matches are then all -1).
+ */
+typedef struct gims_ot_problem {
+  const float* scores; int64_t ld; int32_t n, m;
+  int64_t* matches0; int64_t* matches1; float* mscores0; float* mscores1;
+  float* uv;                                /* [n+1 + m+1 + 1] */
+} gims_ot_problem;
+
+size_t gims_sinkhorn_workspace_bytes(const gims_ot_problem* h_problems, int32_t n_problems);
+int gims_sinkhorn_match(const gims_ot_problem* h_problems /* HOST array */, int32_t n_problems, float alpha,
+                        int32_t iters, float match_threshold, void* work, size_t work_bytes, void* stream);
+
+/* Rebuild the full (n+1)x(m+1) OT matrix Z + u + v - norm (gmatcher.py:47,68) -- for forward_train and tests. */
+int gims_ot_matrix(const float* scores, int64_t ld, int32_t n, int32_t m, float alpha, const float* uv,
+                   float* out /* [(n+1)][(m+1)] */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIMS_HIP_H */

@@ -1,0 +1,85 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/gims_hip.h declares, the host
+mirror keeps the reference's interface (state-dict names, config keys, checkpoint layouts, error behaviour).
+No compute call is made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from gims_amd import GMatcher, Matching, hip, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gims_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gims_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 14
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.load().gims_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler produces for the structs in include/gims_hip.h (LP64)
+    assert ctypes.sizeof(hip.LinearArgs) == 13 * 8 + 6 * 4 + 4 + 4   # 13 pointers/int64 + 6 int32 + float + pad
+    assert ctypes.sizeof(hip.OtProblem) == 8 + 8 + 4 + 4 + 5 * 8
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(hip.GimsHipError):
+        hip.load(str(tmp_path / "nope.so"))
+
+
+def test_state_dict_names_and_checkpoint_layouts(tmp_path, synth_sd):
+    m = GMatcher({})
+    names = list(m.state_dict().keys())
+    assert len(names) == 348 and "bin_score" in names
+    assert "gnn.layers.17.attn.proj.2.weight" in names and "kenc.encoder.12.bias" in names
+    assert "gnn_encoder.layers.0.fc_neigh.weight" in names and "gnn.layers.0.mlp.1.running_var" in names
+    assert set(names) == set(synth_sd.keys())
+    sd_t = {k: torch.from_numpy(np.asarray(v)) for k, v in synth_sd.items()}
+    for layout in ("raw", "model", "ema", "module."):
+        blob = {"raw": sd_t, "model": {"model": sd_t, "ema": None}, "ema": {"ema": sd_t, "model": {}},
+                "module.": {"module." + k: v for k, v in sd_t.items()}}[layout]
+        p = tmp_path / f"{layout}.pt"
+        torch.save(blob, p)
+        mm = GMatcher({"weights_path": str(p)})
+        assert torch.equal(mm.state_dict()["final_proj.weight"], sd_t["final_proj.weight"])
+    # older-DGL SAGEConv bias layout
+    old = dict(synth.make_state_dict(123, sage_bias_layout="bias"))
+    assert "gnn_encoder.layers.0.bias" in old
+    mm = GMatcher({})
+    mm.load_state_dict(old)
+    assert torch.equal(mm.state_dict()["gnn_encoder.layers.1.fc_self.bias"], torch.from_numpy(old["gnn_encoder.layers.1.bias"]))
+
+
+def test_default_config_keys_match_reference():
+    for k, v in {"descriptor_dim": 256, "weights_path": None, "keypoint_encoder": [32, 64, 128, 256],
+                 "transformer_layers": ["self", "cross"] * 9, "sinkhorn_iterations": 100, "match_threshold": 0.2,
+                 "use_layernorm": False, "input_dim": 256, "num_heads": 4}.items():
+        assert GMatcher.default_config[k] == v
+
+
+def test_no_cpu_fallback_and_matching_shell():
+    m = Matching({})
+    pair = synth.make_pair(64, 1000)
+    data = {k: torch.from_numpy(v) for k, v in pair.items() if k != "gt_perm"}
+    with pytest.raises(hip.GimsHipError):
+        m(data)
+    with pytest.raises(NotImplementedError):
+        m({"image0": pair["image0"], "image1": pair["image1"]})
+
+
+def test_product_code_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "gims_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f
