@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the GIMS matcher hot path on MI355X:  image-pairs/sec at 2 x N keypoints.
+
+    python bench.py --gpus N --steps K --warmup W [--kpts 1024] [--pairs 16] [--sinkhorn-iters 100]
+
+A "step" is one pass of the whole hot path (adaptive graph build -> GraphSAGE -> keypoint encoder ->
+18-layer self/cross attention -> Sinkhorn -> mutual matching) over one ragged batch of `--pairs` synthetic
+image pairs per GPU (BASELINE.json configs[1]: 1024-keypoint pairs, 256-d descriptors, 9x(self,cross) GNN
+layers, 100 Sinkhorn iterations).  Inputs are resident in HBM before the timed region.  Pairs are
+independent units: with N > 1 every rank (one per GPU, RCCL) matches its own pairs and the per-pair match
+statistics are all-gathered over xGMI each step -- the only collective of the path (weak scaling).
+
+Rank 0 prints ONE JSON line: whole-job pairs/s, the roofline of the dominant kernel (timed live with HIP
+events on the launch stream) and the CPU baseline (the oracle timed on this host's cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_inputs(n_pairs, kpts, seed0, device):
+    from gims_amd import synth
+    datas = []
+    for p in range(n_pairs):
+        pair = synth.make_pair(kpts, seed0 + p)
+        d = {k: torch.from_numpy(v).to(device) for k, v in pair.items() if k not in ("gt_perm", "image0", "image1")}
+        d["image0"], d["image1"] = pair["image0"], pair["image1"]
+        d.update(device=torch.device(device), radius=15, percentile=2, min_size=7)
+        datas.append((d, pair["gt_perm"]))
+    return datas
+
+
+def cpu_baseline(kpts, iters, budget_s=20.0):
+    """The oracle (CPU restatement of the reference, oracle/gims_oracle.py) on this host's cores."""
+    from gims_amd import synth
+    from oracle import gims_oracle as O
+    # intra-op threads: the small per-op tensors of this path stop scaling (and then collapse from
+    # oversubscription) well before the host's core count, so the baseline uses min(cores, 16) threads
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    sd = synth.make_state_dict(123)
+    done, t_used = 0, 0.0
+    while True:
+        pair = synth.make_pair(kpts, 1000 + done)
+        d = {k: torch.from_numpy(v) for k, v in pair.items() if k not in ("gt_perm", "image0", "image1")}
+        d["image0"], d["image1"] = pair["image0"], pair["image1"]
+        d.update(device=torch.device("cpu"), radius=15, percentile=2, min_size=7)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.gmatcher_forward(sd, d, {"sinkhorn_iterations": iters})
+        t_used += time.perf_counter() - t0
+        done += 1
+        if t_used > budget_s * 0.6 or done >= 6:
+            break
+    return {"value": done / t_used, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} pair(s) of 2x{kpts} keypoints, {iters} Sinkhorn iterations, oracle/gims_oracle.py "
+                      f"(torch CPU, {t_used:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--kpts", type=int, default=1024)
+    ap.add_argument("--pairs", type=int, default=16, help="image pairs per step per GPU")
+    ap.add_argument("--sinkhorn-iters", type=int, default=100)
+    ap.add_argument("--linear-precision", default="bf16x3", choices=["bf16x3", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = f"cuda:{torch.cuda.current_device()}"
+    torch.set_grad_enabled(False)
+
+    import __graft_entry__
+    __graft_entry__.build()
+    from gims_amd import GMatcher, synth
+
+    model = GMatcher({"sinkhorn_iterations": args.sinkhorn_iters, "linear_precision": args.linear_precision}).eval()
+    model.load_state_dict(synth.make_state_dict(123))
+    inputs = make_inputs(args.pairs, args.kpts, 1000 + rank * args.pairs, dev)
+    torch.cuda.synchronize()
+
+    def step():
+        datas = [dict(d) for d, _ in inputs]              # shallow copies: forward mutates the dict, tensors stay resident
+        outs = model.match_pairs(datas)
+        # per-pair match statistics {pair id, kept0, kept1, n_matches}; the path's only collective
+        stats = torch.stack([torch.stack([torch.tensor(float(rank * args.pairs + i), device=dev),
+                                          torch.tensor(float(o["matches0"].shape[1]), device=dev),
+                                          torch.tensor(float(o["matches1"].shape[1]), device=dev),
+                                          (o["matches0"] >= 0).sum().float()]) for i, o in enumerate(outs)])
+        if world > 1:
+            gathered = [torch.empty_like(stats) for _ in range(world)]
+            dist.all_gather(gathered, stats)
+            stats = torch.cat(gathered)
+        return outs, stats
+
+    for _ in range(args.warmup):
+        step()
+    model.enable_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs, stats = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+    elapsed = float(et.item())
+    stage = model.stage_times_ms()
+    stage_host = model.stage_host_ms()
+    model.enable_timing(False)
+
+    # ---- correctness guard of what was timed: planted correspondences must be recovered
+    o, (d, gt) = outs[0], inputs[0]
+    m0 = o["matches0"][0].cpu().numpy()
+    st = stats.cpu().numpy()
+
+    if rank == 0:
+        total_pairs = world * args.pairs * args.steps
+        value = total_pairs / elapsed
+        img = model._last["images"]
+        problems = [(img[2 * p]["n_kept"], img[2 * p + 1]["n_kept"]) for p in range(args.pairs)]
+        stage_ms = {k: float(np.sum(v)) / args.steps for k, v in stage.items()}
+        for k, v in stage.items():
+            per = np.asarray(v).reshape(args.steps, -1).sum(1)
+            perh = np.asarray(stage_host[k]).reshape(args.steps, -1).sum(1)
+            log(f"stage {k:14s} gpu ms/step: " + " ".join(f"{x:7.2f}" for x in per) + "   | host ms/step: " + " ".join(f"{x:7.2f}" for x in perh))
+        # algorithmic work per step on this rank (SURVEY 8d formulas, on the kept counts)
+        attn_flops_layer = sum(1024.0 * (a * a + b * b) for a, b in problems)          # self layer (both images)
+        cross_flops_layer = sum(1024.0 * (2 * a * b) for a, b in problems)
+        n_rows = sum(a + b for a, b in problems)
+        lin_flops_layer = 2.0 * n_rows * (3 * 256 * 256 + 256 * 256 + 512 * 512 + 512 * 256)
+        ot_bytes = sum(2.0 * args.sinkhorn_iters * (a + 1) * (b + 1) * 4 for a, b in problems)
+        n_self = sum(1 for t in model.config["transformer_layers"] if t == "self")
+        n_cross = len(model.config["transformer_layers"]) - n_self
+        cand = {
+            "attention_bf16_kernel(cross)": ("mfma", cross_flops_layer, np.mean(stage["attn_cross"]), PEAK_BF16_TFLOPS, "TFLOP/s", n_cross),
+            "attention_bf16_kernel(self)": ("mfma", attn_flops_layer, np.mean(stage["attn_self"]), PEAK_BF16_TFLOPS, "TFLOP/s", n_self),
+            "ot_iter_kernel": ("hbm", ot_bytes / args.sinkhorn_iters, np.mean(stage["sinkhorn"]) / max(1, args.sinkhorn_iters), PEAK_HBM_GBS, "GB/s", args.sinkhorn_iters),
+            "linear_kernel(mlp: merge+mlp0+mlp1)": ("mfma", 2.0 * n_rows * (256 * 256 + 512 * 512 + 512 * 256), np.mean(stage["mlp"]), PEAK_BF16_TFLOPS, "TFLOP/s", len(stage["mlp"]) // args.steps),
+        }
+        totals = {k: v[2] * v[5] for k, v in cand.items()}
+        dom = max(totals, key=totals.get)
+        bound, work, ms, peak, unit, _ = cand[dom]
+        achieved = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+        roofline = {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                    "frac": achieved / peak, "traffic": None,
+                    "avg_launch_ms": float(ms), "algorithmic_work_per_launch": work,
+                    "all": {k: {"ms_per_launch": float(v[2]), "achieved": v[1] / (v[2] * 1e-3) / (1e12 if v[4] == "TFLOP/s" else 1e9),
+                                "unit": v[4], "frac": v[1] / (v[2] * 1e-3) / (1e12 if v[4] == "TFLOP/s" else 1e9) / v[3]}
+                            for k, v in cand.items()}}
+        k0 = img[0]["kept"].cpu().numpy()
+        k1 = img[1]["kept"].cpu().numpy()
+        v = m0 >= 0
+        correct = int((k1[m0[v]] == gt[k0[v]]).sum())
+        assert v.sum() > 0.5 * args.kpts and correct > 0.9 * v.sum(), ("benchmark output is not a valid matching", int(v.sum()), correct)
+        res = {
+            "metric": f"image-pairs/sec at 2x{args.kpts} keypoints", "value": value, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 MFMA attention + split-bf16x3 (f32-class) MFMA linears + f32 Sinkhorn" if args.linear_precision == "bf16x3"
+                     else "bf16 MFMA attention + f32 MFMA linears + f32 Sinkhorn",
+            "data": "synthetic",
+            "config": {"workload": f"{args.pairs} pairs/step/GPU of 2x{args.kpts} synthetic keypoints (kept {problems[0][0]}/{problems[0][1]} after AGC r=15 p=2 m=7), "
+                                   f"256-d descriptors, 18 attentional layers (9 self + 9 cross), {args.sinkhorn_iters} Sinkhorn iterations, match_threshold 0.2",
+                       "pairs_per_step_per_gpu": args.pairs, "keypoints": args.kpts, "sinkhorn_iterations": args.sinkhorn_iters,
+                       "parallelism": f"pairs sharded over {world} GPU(s), all-gather of match statistics"},
+            "roofline": roofline,
+            "stage_ms_per_step": stage_ms,
+            "matches_pair0": {"matched": int(v.sum()), "correct_vs_planted": correct},
+            "stats_rows_gathered": int(st.shape[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.kpts, args.sinkhorn_iters)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,16 +39,39 @@ struct AgcWs {
   int32_t* idx0;        // [cap]
   int32_t* counters;    // [16] scratch counters: 0 coarse directed edges, 1 components, 2 pre-removal directed edges
   int32_t* coff2;       // [n+1] component offsets (scan of sizes)
-  int n, d, lds, nw, cap;
+  int32_t* degk;        // [n] degree by kept id
+  // per-image inputs / outputs (caller-owned)
+  const float* kpts; const float* desc; int64_t ldd;
+  int32_t* kept; int32_t* indptr; int32_t* indices; int32_t* info;
+  int64_t krank;        // percentile rank k (agc.py:378-379)
+  int n, d, lds, nw, cap, max_edges_dir;
 };
 
+struct Blob512 { char b[512]; };
+static_assert(sizeof(AgcWs) <= sizeof(Blob512), "AgcWs must fit the by-value upload blob");
+
+// uploads one descriptor by value (kernel argument) and resets the per-image counters: no host staging
+// buffer, no hipMemcpy, no stream synchronisation
+__global__ void agc_setup_kernel(Blob512 blob, AgcWs* __restrict__ dst) {
+  const AgcWs* src = (const AgcWs*)blob.b;
+  if (threadIdx.x == 0) {
+    *dst = *src;
+    src->sel[0] = 0u; src->sel[1] = (uint32_t)(src->krank & 0xffffffffll); src->sel[2] = (uint32_t)(src->krank >> 32); src->sel[3] = 0u;
+    for (int i = 0; i < 8; ++i) src->info[i] = 0;
+    for (int i = 0; i < 16; ++i) src->counters[i] = 0;
+  }
+  src->hist[threadIdx.x] = 0u;
+}
+
 // ---------------------------------------------------------------------------------------------- K1 prologue
-__global__ __launch_bounds__(256) void agc_normalize_kernel(const float* __restrict__ desc, int64_t ldd, int n, int d,
-                                                            float* __restrict__ dn) {
+__global__ __launch_bounds__(256) void agc_normalize_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  const int n = w.n, d = w.d;
+  float* dn = w.dn;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   if (row >= n) return;
-  const float* x = desc + (int64_t)row * ldd;
+  const float* x = w.desc + (int64_t)row * w.ldd;
   float s = 0.f;
   for (int j = lane; j < d; j += 64) s = fmaf(x[j], x[j], s);
   s = wave_sum(s);
@@ -57,7 +80,8 @@ __global__ __launch_bounds__(256) void agc_normalize_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------- K2 radix select
-__global__ __launch_bounds__(256) void agc_hist_kernel(AgcWs w, int pass) {
+__global__ __launch_bounds__(256) void agc_hist_kernel(const AgcWs* __restrict__ ws, int pass) {
+  const AgcWs& w = ws[blockIdx.y];
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -75,7 +99,8 @@ __global__ __launch_bounds__(256) void agc_hist_kernel(AgcWs w, int pass) {
   if (h[threadIdx.x]) atomicAdd(&w.hist[threadIdx.x], h[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void agc_pick_kernel(AgcWs w, int pass) {
+__global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__ ws, int pass) {
+  const AgcWs& w = ws[blockIdx.y];
   __shared__ uint32_t h[256];
   h[threadIdx.x] = w.hist[threadIdx.x];
   __syncthreads();
@@ -100,7 +125,9 @@ __global__ __launch_bounds__(256) void agc_pick_kernel(AgcWs w, int pass) {
 // ---------------------------------------------------------------------------------------------- K3 adjacency bits
 // one wave per (row i, 64-column word): bit j set iff j != i, ||xi-xj||^2 <= r^2 in float64 (inclusive),
 // and S[min(i,j)][max(i,j)] >= thr  (the reference tests sim_matrix[i,j] with i<j, agc.py:445-446)
-__global__ __launch_bounds__(256) void agc_adj_kernel(AgcWs w, const float* __restrict__ kpts, double r2) {
+__global__ __launch_bounds__(256) void agc_adj_kernel(const AgcWs* __restrict__ ws, double r2) {
+  const AgcWs& w = ws[blockIdx.y];
+  const float* __restrict__ kpts = w.kpts;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
   const int i = (int)(wid / w.nw), wj = (int)(wid % w.nw);
@@ -120,7 +147,10 @@ __global__ __launch_bounds__(256) void agc_adj_kernel(AgcWs w, const float* __re
   if (lane == 0) w.bits[(int64_t)i * w.nw + wj] = mask;
 }
 
-__global__ __launch_bounds__(256) void agc_deg_kernel(AgcWs w, int32_t* __restrict__ deg, int32_t* total) {
+__global__ __launch_bounds__(256) void agc_deg_kernel(const AgcWs* __restrict__ ws, int count_total) {
+  const AgcWs& w = ws[blockIdx.y];
+  int32_t* deg = w.deg;
+  int32_t* total = count_total ? w.counters + 0 : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
   if (i >= w.n) return;
@@ -135,7 +165,9 @@ __global__ __launch_bounds__(256) void agc_deg_kernel(AgcWs w, int32_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------- K4 isolated nodes
-__global__ __launch_bounds__(256) void agc_iso_nn_kernel(AgcWs w, const float* __restrict__ kpts) {
+__global__ __launch_bounds__(256) void agc_iso_nn_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  const float* __restrict__ kpts = w.kpts;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
   if (i >= w.n) return;
@@ -164,7 +196,9 @@ __global__ __launch_bounds__(256) void agc_iso_nn_kernel(AgcWs w, const float* _
 // sequential semantics of agc.py:489-494: ascending node order; a node is still isolated at its turn iff it
 // started isolated and no earlier isolated node attached to it.  Only the (few) initially isolated nodes
 // are walked, from an ordered compaction held in LDS.
-__global__ __launch_bounds__(1024) void agc_iso_seq_kernel(AgcWs w, int32_t* info) {
+__global__ __launch_bounds__(1024) void agc_iso_seq_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  int32_t* info = w.info;
   extern __shared__ int32_t sm[];
   int32_t* list = sm;                       // [n] ordered isolated ids
   uint32_t* touched = (uint32_t*)(sm + w.n);  // [n/32+1]
@@ -210,9 +244,14 @@ __global__ __launch_bounds__(1024) void agc_iso_seq_kernel(AgcWs w, int32_t* inf
 }
 
 // ---------------------------------------------------------------------------------------------- bits -> CSR
-__global__ __launch_bounds__(1024) void agc_scan_kernel(const int32_t* __restrict__ deg, const int32_t* __restrict__ sel_flag,
-                                                        int n, int32_t* __restrict__ ptr, int32_t* total_out) {
-  // exclusive scan of deg[i] (only rows with sel_flag[i] != 0 when sel_flag given), single workgroup
+// exclusive scan, one workgroup per image.  mode 0: deg -> ptr0 (total -> counters[2]);
+// mode 1: component sizes (coff) -> coff2; mode 2: degk -> indptr (total -> info[1])
+__global__ __launch_bounds__(1024) void agc_scan_kernel(const AgcWs* __restrict__ ws, int mode) {
+  const AgcWs& w = ws[blockIdx.y];
+  const int n = w.n;
+  const int32_t* deg = mode == 0 ? w.deg : (mode == 1 ? w.coff : w.degk);
+  int32_t* ptr = mode == 0 ? w.ptr0 : (mode == 1 ? w.coff2 : w.indptr);
+  int32_t* total_out = mode == 0 ? w.counters + 2 : (mode == 1 ? nullptr : w.info + 1);
   __shared__ int wsum[16];
   __shared__ int carry;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -220,7 +259,7 @@ __global__ __launch_bounds__(1024) void agc_scan_kernel(const int32_t* __restric
   __syncthreads();
   for (int base = 0; base < n; base += 1024) {
     const int i = base + t;
-    int v = (i < n && (!sel_flag || sel_flag[i])) ? deg[i] : 0;
+    int v = i < n ? deg[i] : 0;
     int x = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -247,9 +286,12 @@ __global__ __launch_bounds__(1024) void agc_scan_kernel(const int32_t* __restric
 }
 
 // row i of the bit matrix -> idx[ptr[i] ...] ascending; optional relabel through newid (rows with newid<0 skipped)
-__global__ __launch_bounds__(256) void agc_fill_kernel(AgcWs w, const int32_t* __restrict__ ptr_by_row,
-                                                       const int32_t* __restrict__ newid, int32_t* __restrict__ idx,
-                                                       int cap) {
+__global__ __launch_bounds__(256) void agc_fill_kernel(const AgcWs* __restrict__ ws, int final_pass) {
+  const AgcWs& w = ws[blockIdx.y];
+  const int32_t* __restrict__ ptr_by_row = final_pass ? w.indptr : w.ptr0;
+  const int32_t* __restrict__ newid = final_pass ? w.newid : nullptr;
+  int32_t* __restrict__ idx = final_pass ? w.indices : w.idx0;
+  const int cap = final_pass ? w.max_edges_dir : w.cap;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
   if (i >= w.n) return;
@@ -280,7 +322,10 @@ __global__ __launch_bounds__(256) void agc_fill_kernel(AgcWs w, const int32_t* _
 
 // ---------------------------------------------------------------------------------------------- K5 components
 // single workgroup; LDS: parent[n], count[n]
-__global__ __launch_bounds__(1024) void agc_cc_kernel(AgcWs w, int min_size, int32_t* __restrict__ kept, int32_t* info) {
+__global__ __launch_bounds__(1024) void agc_cc_kernel(const AgcWs* __restrict__ ws, int min_size) {
+  const AgcWs& w = ws[blockIdx.y];
+  int32_t* __restrict__ kept = w.kept;
+  int32_t* info = w.info;
   extern __shared__ int32_t sm[];
   int32_t* parent = sm;
   int32_t* count = sm + w.n;
@@ -374,8 +419,10 @@ __global__ __launch_bounds__(1024) void agc_cc_kernel(AgcWs w, int min_size, int
 
 // ---------------------------------------------------------------------------------------------- K6 linking
 // members of each alive component in ascending node order + float64 centroid (one wave per component)
-__global__ __launch_bounds__(256) void agc_members_kernel(AgcWs w, const float* __restrict__ kpts,
-                                                          const int32_t* __restrict__ coff) {
+__global__ __launch_bounds__(256) void agc_members_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  const float* __restrict__ kpts = w.kpts;
+  const int32_t* __restrict__ coff = w.coff2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + wave;
   const int C = w.counters[1];
@@ -402,7 +449,8 @@ __global__ __launch_bounds__(256) void agc_members_kernel(AgcWs w, const float* 
   if (lane == 0) { w.cent[2 * c] = sx / (double)cnt; w.cent[2 * c + 1] = sy / (double)cnt; }
 }
 
-__global__ __launch_bounds__(256) void agc_nnc_kernel(AgcWs w) {
+__global__ __launch_bounds__(256) void agc_nnc_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + wave;
   const int C = w.counters[1];
@@ -426,8 +474,10 @@ __global__ __launch_bounds__(256) void agc_nnc_kernel(AgcWs w) {
 }
 
 // one workgroup per component i: closest (v in comp nn(i), u in comp i) pair, lexicographic (d2, v, u)
-__global__ __launch_bounds__(256) void agc_link_kernel(AgcWs w, const float* __restrict__ kpts,
-                                                       const int32_t* __restrict__ coff) {
+__global__ __launch_bounds__(256) void agc_link_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  const float* __restrict__ kpts = w.kpts;
+  const int32_t* __restrict__ coff = w.coff2;
   __shared__ double sd[256];
   __shared__ int sv[256], su[256];
   const int i = blockIdx.x, t = threadIdx.x;
@@ -463,7 +513,9 @@ __global__ __launch_bounds__(256) void agc_link_kernel(AgcWs w, const float* __r
   if (t == 0) { w.link[2 * i] = su[0]; w.link[2 * i + 1] = sv[0]; }
 }
 
-__global__ __launch_bounds__(256) void agc_link_apply_kernel(AgcWs w, int32_t* info) {
+__global__ __launch_bounds__(256) void agc_link_apply_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  int32_t* info = w.info;
   const int C = w.counters[1];
   if (C <= 1) { if (threadIdx.x == 0 && blockIdx.x == 0) info[5] = 0; return; }
   int added = 0;
@@ -477,24 +529,31 @@ __global__ __launch_bounds__(256) void agc_link_apply_kernel(AgcWs w, int32_t* i
   if (added) atomicAdd(&info[5], added);
 }
 
-__global__ void agc_finish_kernel(AgcWs w, int32_t* info, int max_edges_dir) {
+__global__ void agc_finish_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  int32_t* info = w.info;
+  const int max_edges_dir = w.max_edges_dir;
   info[2] = w.counters[0] / 2;
   info[6] = (int32_t)__float_as_uint(key_f32(w.sel[0]));
   info[7] = (info[1] > max_edges_dir || w.counters[0] > w.cap || w.counters[2] > w.cap) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void agc_kept_deg_kernel(AgcWs w, const int32_t* __restrict__ deg_by_row,
-                                                           int32_t* __restrict__ deg_kept) {
+// degree by kept id (rows past n_kept get 0 so that the scan over n entries ends at the edge total)
+__global__ __launch_bounds__(256) void agc_kept_deg_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
   const int u = blockIdx.x * 256 + threadIdx.x;
   if (u >= w.n) return;
   const int id = w.newid[u];
-  if (id >= 0) deg_kept[id] = deg_by_row[u];
+  if (id >= 0) w.degk[id] = w.deg[u];
+  if (u >= w.info[0]) w.degk[u] = 0;
 }
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static size_t agc_layout(int n, int d, int cap, char* base, AgcWs* w) {
-  const int lds = (n + 3) & ~3, nw = (n + 63) / 64;
+constexpr int AGC_CAP_PER_NODE = 64;  // scratch CSR capacity of the pre-removal graph: 64 directed edges per node
+
+static size_t agc_layout(int n, int d, char* base, AgcWs* w) {
+  const int lds = (n + 3) & ~3, nw = (n + 63) / 64, cap = n * AGC_CAP_PER_NODE;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return base ? base + o : (char*)nullptr; };
   char* p;
@@ -518,95 +577,104 @@ static size_t agc_layout(int n, int d, int cap, char* base, AgcWs* w) {
   p = take((size_t)cap * 4); if (w) w->idx0 = (int32_t*)p;
   p = take(64); if (w) w->counters = (int32_t*)p;
   p = take((size_t)(n + 1) * 4); if (w) w->coff2 = (int32_t*)p;
+  p = take((size_t)n * 4); if (w) w->degk = (int32_t*)p;
   if (w) { w->n = n; w->d = d; w->lds = lds; w->nw = nw; w->cap = cap; }
   return off;
 }
 
-constexpr int AGC_CAP_PER_NODE = 64;  // scratch CSR capacity of the pre-removal graph: 64 directed edges per node
+static size_t agc_batch_header(int n_images) {
+  return al256(sizeof(AgcWs) * (size_t)n_images) + al256(sizeof(gims_linear_args) * (size_t)n_images);
+}
 
 }  // namespace gims
 
-extern "C" size_t gims_agc_workspace_bytes(int32_t n, int32_t d) {
+extern "C" size_t gims_agc_workspace_bytes(const gims_agc_image* images, int32_t n_images) {
   using namespace gims;
-  if (n <= 0 || d <= 0) return 0;
-  return agc_layout(n, d, n * AGC_CAP_PER_NODE, nullptr, nullptr);
+  if (!images || n_images <= 0) return 0;
+  size_t b = agc_batch_header(n_images);
+  for (int i = 0; i < n_images; ++i) b += agc_layout(images[i].n, images[i].d, nullptr, nullptr);
+  return b;
 }
 
-extern "C" int gims_agc_build(const float* kpts, const float* desc, int64_t ldd, int32_t n, int32_t d, double radius,
-                              double percentile, int32_t min_size, void* work, size_t work_bytes, int32_t* kept,
-                              int32_t* indptr, int32_t* indices, int32_t max_edges_dir, int32_t* info, void* stream) {
+extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, double radius, double percentile,
+                              int32_t min_size, void* work, size_t work_bytes, void* stream) {
   using namespace gims;
-  GIMS_CHECK_ARG(kpts && desc && work && kept && indptr && indices && info, "gims_agc_build: null pointer");
-  GIMS_CHECK_ARG(n >= 2 && n <= AGC_MAX_N, "gims_agc_build: n=%d out of range [2, %d]", n, AGC_MAX_N);
-  GIMS_CHECK_ARG(d > 0 && (d % 32) == 0 && (ldd % 4) == 0, "gims_agc_build: d=%d must be a multiple of 32 (ldd %% 4 == 0)", d);
-  GIMS_CHECK_ARG(work_bytes >= gims_agc_workspace_bytes(n, d), "gims_agc_build: workspace too small");
+  GIMS_CHECK_ARG(images && n_images > 0 && work, "gims_agc_build: null / empty arguments");
+  GIMS_CHECK_ARG(work_bytes >= gims_agc_workspace_bytes(images, n_images), "gims_agc_build: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  AgcWs w;
-  const int cap = n * AGC_CAP_PER_NODE;
-  agc_layout(n, d, cap, (char*)work, &w);
-  int32_t* sizes = w.coff;  // component sizes land in coff, are scanned in place into offsets via ptr scratch
-
-  // K1
-  hipLaunchKernelGGL(agc_normalize_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, desc, ldd, n, d, w.dn);
-  gims_linear_args la = {};
-  la.a0 = w.dn; la.lda0 = d; la.a1 = nullptr; la.lda1 = 0; la.w = w.dn; la.w_lo = nullptr; la.ldw = d;
-  la.bias = nullptr; la.residual = nullptr; la.out_f32 = w.S; la.ldc = w.lds; la.out_bf16 = nullptr; la.ldc_bf16 = 0;
-  la.m = n; la.n = n; la.k = d; la.k0 = d; la.act = GIMS_ACT_NONE; la.precision = GIMS_PREC_F32; la.scale = 1.f;
-  int rc = gims_linear(&la, stream);
-  if (rc != GIMS_OK) return rc;
-
-  // K2: k = int(L * p / 100), clamped (agc.py:378-379)
-  const int64_t L = (int64_t)n * (n - 1) / 2;
-  int64_t k = (int64_t)(((double)L * percentile) / 100.0);
-  if (k >= L) k = L - 1;
-  if (k < 0) k = 0;
-  uint32_t sel_init[4] = {0u, (uint32_t)(k & 0xffffffffll), (uint32_t)(k >> 32), 0u};
-  GIMS_HIP(hipMemsetAsync(w.hist, 0, 256 * 4, s));
-  GIMS_HIP(hipMemsetAsync(w.counters, 0, 64, s));
-  GIMS_HIP(hipMemsetAsync(info, 0, 8 * 4, s));
-  GIMS_HIP(hipMemcpyAsync(w.sel, sel_init, 16, hipMemcpyHostToDevice, s));
-  GIMS_HIP(hipStreamSynchronize(s));   // sel_init lives on this stack frame
-  const int hgrid = n < 2048 ? n : 2048;
-  for (int pass = 0; pass < 4; ++pass) {
-    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid), dim3(256), 0, s, w, pass);
-    hipLaunchKernelGGL(agc_pick_kernel, dim3(1), dim3(256), 0, s, w, pass);
-  }
-  // K3
-  const int64_t nwaves = (int64_t)n * w.nw;
-  hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv(nwaves, 4)), dim3(256), 0, s, w, kpts, radius * radius);
-  hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, w.deg, w.counters + 0);
-  // info[2] = undirected coarse edges is filled by agc_finish from counters[0] / 2 (see below)
-  // K4
-  hipLaunchKernelGGL(agc_iso_nn_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, kpts);
-  const size_t iso_lds = (size_t)n * 4 + ((size_t)(n + 31) / 32 + 1) * 4;
-  hipLaunchKernelGGL(agc_iso_seq_kernel, dim3(1), dim3(1024), iso_lds, s, w, info);
-  // CSR of the pre-removal graph (original ids) for the component search
-  hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, w.deg, (int32_t*)nullptr);
-  hipLaunchKernelGGL(agc_scan_kernel, dim3(1), dim3(1024), 0, s, w.deg, (const int32_t*)nullptr, n, w.ptr0, w.counters + 2);
-  hipLaunchKernelGGL(agc_fill_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, w.ptr0, (const int32_t*)nullptr, w.idx0, cap);
-  // K5
+  AgcWs* dws = (AgcWs*)work;
+  gims_linear_args* dla = (gims_linear_args*)((char*)work + al256(sizeof(AgcWs) * (size_t)n_images));
+  char* base = (char*)work + agc_batch_header(n_images);
+  int maxn = 0, maxnw = 0;
   static bool attr_set = false;
-  const size_t cc_lds = (size_t)n * 8;
   if (!attr_set) {
     GIMS_HIP(hipFuncSetAttribute((const void*)agc_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AGC_MAX_N * 8));
     GIMS_HIP(hipFuncSetAttribute((const void*)agc_iso_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AGC_MAX_N * 4 + (AGC_MAX_N / 32 + 2) * 4));
     attr_set = true;
   }
-  hipLaunchKernelGGL(agc_cc_kernel, dim3(1), dim3(1024), cc_lds, s, w, min_size, kept, info);
-  // K6: component sizes (in coff, rank order) -> offsets; members, centroids, nearest component, links
-  int32_t* coff_scan = w.coff2;
-  hipLaunchKernelGGL(agc_scan_kernel, dim3(1), dim3(1024), 0, s, sizes, (const int32_t*)nullptr, n, coff_scan, (int32_t*)nullptr);
-  hipLaunchKernelGGL(agc_members_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, kpts, coff_scan);
-  hipLaunchKernelGGL(agc_nnc_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w);
-  hipLaunchKernelGGL(agc_link_kernel, dim3(n), dim3(256), 0, s, w, kpts, coff_scan);
-  hipLaunchKernelGGL(agc_link_apply_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w, info);
+  for (int i = 0; i < n_images; ++i) {
+    const gims_agc_image& im = images[i];
+    GIMS_CHECK_ARG(im.kpts && im.desc && im.kept && im.indptr && im.indices && im.info, "gims_agc_build: image %d has a null pointer", i);
+    GIMS_CHECK_ARG(im.n >= 2 && im.n <= AGC_MAX_N, "gims_agc_build: image %d: n=%d out of range [2, %d]", i, im.n, AGC_MAX_N);
+    GIMS_CHECK_ARG(im.d > 0 && (im.d % 32) == 0 && (im.ldd % 4) == 0, "gims_agc_build: image %d: d=%d must be a multiple of 32 (ldd %% 4 == 0)", i, im.d);
+    Blob512 blob;
+    AgcWs* w = (AgcWs*)blob.b;
+    base += agc_layout(im.n, im.d, base, w);
+    w->kpts = im.kpts; w->desc = im.desc; w->ldd = im.ldd; w->kept = im.kept; w->indptr = im.indptr; w->indices = im.indices;
+    w->info = im.info; w->max_edges_dir = im.max_edges_dir;
+    // K2 rank: k = int(L * p / 100), clamped (agc.py:378-379)
+    const int64_t L = (int64_t)im.n * (im.n - 1) / 2;
+    int64_t k = (int64_t)(((double)L * percentile) / 100.0);
+    if (k >= L) k = L - 1;
+    if (k < 0) k = 0;
+    w->krank = k;
+    hipLaunchKernelGGL(agc_setup_kernel, dim3(1), dim3(256), 0, s, blob, dws + i);
+    // K1 GEMM descriptor: S = Dn Dn^T in exact f32
+    gims_linear_args la = {};
+    la.a0 = w->dn; la.lda0 = im.d; la.w = w->dn; la.ldw = im.d; la.out_f32 = w->S; la.ldc = w->lds;
+    la.m = im.n; la.n = im.n; la.k = im.d; la.k0 = im.d; la.act = GIMS_ACT_NONE; la.precision = GIMS_PREC_F32; la.scale = 1.f;
+    int rc = gims_linear_put(&la, dla + i, stream);
+    if (rc != GIMS_OK) return rc;
+    maxn = im.n > maxn ? im.n : maxn;
+    maxnw = w->nw > maxnw ? w->nw : maxnw;
+  }
+  const int B = n_images;
+  const dim3 gw(cdiv(maxn, 4), B), g1(1, B);
+  // K1
+  hipLaunchKernelGGL(agc_normalize_kernel, gw, dim3(256), 0, s, dws);
+  int rc = gims_linear_batch(dla, B, maxn, maxn, GIMS_PREC_F32, stream);
+  if (rc != GIMS_OK) return rc;
+  // K2
+  const int hgrid = maxn < 1024 ? maxn : 1024;
+  for (int pass = 0; pass < 4; ++pass) {
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, pass);
+    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, pass);
+  }
+  // K3
+  hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv((int64_t)maxn * maxnw, 4), B), dim3(256), 0, s, dws, radius * radius);
+  hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 1);
+  // K4
+  hipLaunchKernelGGL(agc_iso_nn_kernel, gw, dim3(256), 0, s, dws);
+  const size_t iso_lds = (size_t)maxn * 4 + ((size_t)(maxn + 31) / 32 + 1) * 4;
+  hipLaunchKernelGGL(agc_iso_seq_kernel, g1, dim3(1024), iso_lds, s, dws);
+  // CSR of the pre-removal graph (original ids) for the component search
+  hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 0);
+  hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 0);
+  hipLaunchKernelGGL(agc_fill_kernel, gw, dim3(256), 0, s, dws, 0);
+  // K5
+  hipLaunchKernelGGL(agc_cc_kernel, g1, dim3(1024), (size_t)maxn * 8, s, dws, min_size);
+  // K6: component sizes -> offsets; members, centroids, nearest component, links
+  hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 1);
+  hipLaunchKernelGGL(agc_members_kernel, gw, dim3(256), 0, s, dws);
+  hipLaunchKernelGGL(agc_nnc_kernel, gw, dim3(256), 0, s, dws);
+  hipLaunchKernelGGL(agc_link_kernel, dim3(maxn, B), dim3(256), 0, s, dws);
+  hipLaunchKernelGGL(agc_link_apply_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
   // K7: final CSR over the kept nodes, relabelled in sorted order
-  hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, w.deg, (int32_t*)nullptr);
-  GIMS_HIP(hipMemsetAsync(w.nn, 0, (size_t)n * 4, s));
-  hipLaunchKernelGGL(agc_kept_deg_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w, w.deg, w.nn /* reuse as deg_kept */);
-  hipLaunchKernelGGL(agc_scan_kernel, dim3(1), dim3(1024), 0, s, w.nn, (const int32_t*)nullptr, n, indptr, info + 1);
-  hipLaunchKernelGGL(agc_fill_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, w, indptr, w.newid, indices, max_edges_dir);
-  hipLaunchKernelGGL(agc_finish_kernel, dim3(1), dim3(1), 0, s, w, info, max_edges_dir);
+  hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 0);
+  hipLaunchKernelGGL(agc_kept_deg_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
+  hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 2);
+  hipLaunchKernelGGL(agc_fill_kernel, gw, dim3(256), 0, s, dws, 1);
+  hipLaunchKernelGGL(agc_finish_kernel, g1, dim3(1), 0, s, dws);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

@@ -35,12 +35,11 @@ __device__ __forceinline__ void epilogue_store(const gims_linear_args& p, int ro
 constexpr int F32_BK = 32;
 constexpr int F32_LD = BM + 1;
 
-__global__ __launch_bounds__(256) void linear_f32_kernel(gims_linear_args p) {
-  __shared__ float As[F32_BK * F32_LD];
-  __shared__ float Ws[F32_BK * F32_LD];
+__device__ __forceinline__ void linear_f32_body(const gims_linear_args& p, float* As, float* Ws) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (m0 >= p.m || n0 >= p.n) return;   // batched launches are sized for the largest problem
   const float* w = (const float*)p.w;
 
   f32x16 acc[2][2];
@@ -114,6 +113,19 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(gims_linear_args p) {
       }
 }
 
+__global__ __launch_bounds__(256) void linear_f32_kernel(gims_linear_args p) {
+  __shared__ float As[F32_BK * F32_LD];
+  __shared__ float Ws[F32_BK * F32_LD];
+  linear_f32_body(p, As, Ws);
+}
+// one launch, many independent problems (blockIdx.z): descriptors live in device memory
+__global__ __launch_bounds__(256) void linear_f32_batch_kernel(const gims_linear_args* __restrict__ args) {
+  __shared__ float As[F32_BK * F32_LD];
+  __shared__ float Ws[F32_BK * F32_LD];
+  const gims_linear_args p = args[blockIdx.z];
+  linear_f32_body(p, As, Ws);
+}
+
 // ------------------------------------------------------------------------------------------ split-bf16 MFMA
 // LDS image per plane: [128 rows][64 k] bf16 = 128-byte rows, 16-byte chunks XOR-swizzled with
 // (row>>1)&7 so the ds_read_b128 of an MFMA operand (16 lanes of a group -> 16 different rows, same
@@ -125,8 +137,7 @@ __device__ __forceinline__ int x3_off(int row, int chunk) {  // element offset o
   return row * X3_BK + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-__global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(gims_linear_args p) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+__device__ __forceinline__ void linear_bf16x3_body(const gims_linear_args& p, uint16_t* smem) {
   uint16_t* Ah = smem;
   uint16_t* Al = smem + X3_PLANE;
   uint16_t* Wh = smem + 2 * X3_PLANE;
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(gims_linear_args 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (m0 >= p.m || n0 >= p.n) return;
   const uint16_t* wh = (const uint16_t*)p.w;
   const uint16_t* wl = (const uint16_t*)p.w_lo;
 
@@ -234,6 +246,17 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(gims_linear_args 
       }
 }
 
+__global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(gims_linear_args p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  linear_bf16x3_body(p, smem);
+}
+__global__ __launch_bounds__(256, 2) void linear_bf16x3_batch_kernel(const gims_linear_args* __restrict__ args) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const gims_linear_args p = args[blockIdx.z];
+  linear_bf16x3_body(p, smem);
+}
+__global__ void put_linear_args_kernel(gims_linear_args a, gims_linear_args* __restrict__ dst) { *dst = a; }
+
 // ------------------------------------------------------------------------------------------ split kernel
 __global__ void split_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ hi,
                                   uint16_t* __restrict__ lo, int64_t n) {
@@ -249,7 +272,7 @@ __global__ void split_bf16_kernel(const float* __restrict__ src, uint16_t* __res
 
 }  // namespace gims
 
-extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
+static int linear_validate(const gims_linear_args* a) {
   using namespace gims;
   GIMS_CHECK_ARG(a != nullptr, "gims_linear: null args");
   GIMS_CHECK_ARG(a->m > 0 && a->n > 0 && a->k > 0, "gims_linear: empty problem m=%d n=%d k=%d", a->m, a->n, a->k);
@@ -259,24 +282,70 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
   GIMS_CHECK_ARG(a->out_f32 || a->out_bf16, "gims_linear: no output");
   GIMS_CHECK_ARG(!a->residual || a->out_f32, "gims_linear: residual needs an f32 output (shared ldc)");
   GIMS_CHECK_ARG((a->lda0 % 4) == 0 && (a->lda1 % 4) == 0, "gims_linear: lda must be a multiple of 4");
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(cdiv(a->n, BN), cdiv(a->m, BM));
   if (a->precision == GIMS_PREC_F32) {
     GIMS_CHECK_ARG((a->k % F32_BK) == 0 && (a->k0 % F32_BK) == 0, "gims_linear(f32): K=%d k0=%d must be multiples of %d", a->k, a->k0, F32_BK);
     GIMS_CHECK_ARG((a->ldw % 4) == 0, "gims_linear(f32): ldw must be a multiple of 4");
-    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, s, *a);
   } else if (a->precision == GIMS_PREC_BF16X3) {
     GIMS_CHECK_ARG((a->k % X3_BK) == 0 && (a->k0 % X3_BK) == 0, "gims_linear(bf16x3): K=%d k0=%d must be multiples of %d", a->k, a->k0, X3_BK);
     GIMS_CHECK_ARG(a->w_lo != nullptr && (a->ldw % 8) == 0, "gims_linear(bf16x3): needs w_lo and ldw %% 8 == 0");
-    static bool attr_set = false;
-    const size_t lds = 4 * X3_PLANE * sizeof(uint16_t);
-    if (!attr_set) {
-      GIMS_HIP(hipFuncSetAttribute((const void*)linear_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(linear_bf16x3_kernel, grid, dim3(256), lds, s, *a);
   } else {
     GIMS_CHECK_ARG(false, "gims_linear: unknown precision %d", a->precision);
+  }
+  return GIMS_OK;
+}
+
+static int x3_attr() {
+  using namespace gims;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int lds = 4 * X3_PLANE * (int)sizeof(uint16_t);
+    GIMS_HIP(hipFuncSetAttribute((const void*)linear_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    GIMS_HIP(hipFuncSetAttribute((const void*)linear_bf16x3_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  return GIMS_OK;
+}
+
+extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
+  using namespace gims;
+  int rc = linear_validate(a);
+  if (rc != GIMS_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(a->n, BN), cdiv(a->m, BM));
+  if (a->precision == GIMS_PREC_F32) {
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, s, *a);
+  } else {
+    if ((rc = x3_attr()) != GIMS_OK) return rc;
+    hipLaunchKernelGGL(linear_bf16x3_kernel, grid, dim3(256), 4 * X3_PLANE * sizeof(uint16_t), s, *a);
+  }
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_linear_put(const gims_linear_args* a, gims_linear_args* dev_dst, void* stream) {
+  using namespace gims;
+  int rc = linear_validate(a);
+  if (rc != GIMS_OK) return rc;
+  GIMS_CHECK_ARG(dev_dst != nullptr, "gims_linear_put: null destination");
+  hipLaunchKernelGGL(put_linear_args_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *a, dev_dst);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_linear_batch(const gims_linear_args* dev_args, int32_t count, int32_t max_m, int32_t max_n,
+                                 int32_t precision, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(dev_args && count > 0 && max_m > 0 && max_n > 0, "gims_linear_batch: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(max_n, BN), cdiv(max_m, BM), count);
+  if (precision == GIMS_PREC_F32) {
+    hipLaunchKernelGGL(linear_f32_batch_kernel, grid, dim3(256), 0, s, dev_args);
+  } else if (precision == GIMS_PREC_BF16X3) {
+    int rc = x3_attr();
+    if (rc != GIMS_OK) return rc;
+    hipLaunchKernelGGL(linear_bf16x3_batch_kernel, grid, dim3(256), 4 * X3_PLANE * sizeof(uint16_t), s, dev_args);
+  } else {
+    GIMS_CHECK_ARG(false, "gims_linear_batch: unknown precision %d", precision);
   }
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;

@@ -65,7 +65,54 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   for (int j = lane; j < c; j += 64) d[j] = s[j];
 }
 
+// kept-keypoint compaction of a whole batch in one launch (gmatcher.py:244-249): blockIdx.y = image
+__global__ __launch_bounds__(256) void pack_graphs_kernel(const gims_pack_image* __restrict__ imgs, int d,
+                                                          float* __restrict__ feat, int64_t ldf,
+                                                          float* __restrict__ kpts_out, float* __restrict__ score_out,
+                                                          int32_t* __restrict__ seg, int32_t* __restrict__ indptr_out,
+                                                          int32_t* __restrict__ indices_out, int n_rows_total,
+                                                          int n_edges_total) {
+  const gims_pack_image im = imgs[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // rows: one wave per kept keypoint
+  for (int r = blockIdx.x * 4 + wave; r < im.n_kept; r += gridDim.x * 4) {
+    const int src = im.kept[r];
+    const float4* s = (const float4*)(im.desc + (int64_t)src * im.ldd);
+    float4* o = (float4*)(feat + (int64_t)(im.row_off + r) * ldf);
+    for (int q = lane; 4 * q < d; q += 64) o[q] = s[q];
+    if (lane == 0) {
+      kpts_out[2 * (im.row_off + r)] = im.kpts[2 * src];
+      kpts_out[2 * (im.row_off + r) + 1] = im.kpts[2 * src + 1];
+      if (score_out && im.score) score_out[im.row_off + r] = im.score[src];
+      seg[im.row_off + r] = blockIdx.y;
+      indptr_out[im.row_off + r] = im.indptr[r] + im.edge_off;
+    }
+  }
+  // edges
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < im.n_edges; e += gridDim.x * 256)
+    indices_out[im.edge_off + e] = im.indices[e] + im.row_off;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) indptr_out[n_rows_total] = n_edges_total;
+}
+
 }  // namespace gims
+
+extern "C" int gims_pack_graphs(const gims_pack_image* dev_images, int32_t n_images, int32_t max_kept, int32_t max_edges,
+                                int32_t d, float* feat, int64_t ldf, float* kpts_out, float* score_out, int32_t* seg,
+                                int32_t* indptr_out, int32_t* indices_out, int32_t n_rows_total, int32_t n_edges_total,
+                                void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(dev_images && n_images > 0 && feat && kpts_out && seg && indptr_out && indices_out, "gims_pack_graphs: null pointer");
+  GIMS_CHECK_ARG((d % 4) == 0 && (ldf % 4) == 0, "gims_pack_graphs: d / ldf must be multiples of 4");
+  int gx = cdiv(max_kept, 4);
+  const int ge = cdiv(max_edges, 256);
+  gx = gx > ge ? gx : ge;
+  if (gx < 1) gx = 1;
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(pack_graphs_kernel, dim3(gx, n_images), dim3(256), 0, (hipStream_t)stream, dev_images, d, feat, ldf,
+                     kpts_out, score_out, seg, indptr_out, indices_out, n_rows_total, n_edges_total);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
 
 extern "C" int gims_abi_version(void) { return GIMS_ABI_VERSION; }
 extern "C" const char* gims_last_error(void) { return gims::g_err; }

@@ -15,7 +15,7 @@
 // Traffic per iteration: N*M*4 bytes of Z + 2 * G*(M+1)*4 bytes of partials (G <= 512 workgroups).
 #include "common.h"
 
-#include <vector>
+#include <string.h>
 
 namespace gims {
 
@@ -33,6 +33,11 @@ struct OtDev {
   int G;
   float norm, log_mu_bin, log_nu_bin;  // norm = -log(n+m); log(m)+norm; log(n)+norm
 };
+
+struct OtBlob { char b[256]; };
+static_assert(sizeof(OtDev) <= sizeof(OtBlob), "OtDev must fit the by-value upload blob");
+// one descriptor per launch, passed by value: no host staging buffer, no memcpy, no stream synchronisation
+__global__ void ot_setup_kernel(OtBlob blob, OtDev* __restrict__ dst) { *dst = *(const OtDev*)blob.b; }
 
 // ---------------------------------------------------------------------------------------------- init
 __global__ void ot_init_kernel(const OtDev* __restrict__ probs, float alpha, int zero_init) {
@@ -200,20 +205,34 @@ __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__
   if (t == 0) pp[p.m] = accbin;
 }
 
-// v_j += log nu_j - log(sum of partials)    block = 64 columns x 4 partial groups
-__global__ __launch_bounds__(256) void ot_colreduce_kernel(const OtDev* __restrict__ probs) {
-  __shared__ float red[4][64];
+// v_j += log nu_j - log(sum of partials)    block = 64 columns x 16 partial groups; every thread issues its
+// (<= 32) loads back to back so the fold is one memory round trip, not a dependent chain
+__global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restrict__ probs) {
+  __shared__ float red[16][64];
   const OtDev p = probs[blockIdx.y];
   const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
   if (blockIdx.x * 64 > p.m) return;
   float s = 0.f;
-  if (col <= p.m)
-    for (int b = g; b < p.G; b += 4) s += p.partial[(int64_t)b * (p.m + 1) + col];
+  if (col <= p.m) {
+    const float* pp = p.partial + col;
+    const int64_t st = p.m + 1;
+    for (int b0 = g; b0 < p.G; b0 += 128) {   // 8 independent loads per trip
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int b = b0 + 16 * q;
+        x[q] = b < p.G ? pp[(int64_t)b * st] : 0.f;
+      }
+      s += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    }
+  }
   red[g][cl] = s;
   __syncthreads();
   if (g == 0 && col <= p.m) {
-    const float c = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    float c = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c += red[q][cl];
     if (!(c > 0.f) || !(c < 3.0e38f)) p.status[0] = 1.f;
     const float lognu = col < p.m ? p.norm : p.log_nu_bin;
     p.v[col] += lognu - logf(c);
@@ -410,7 +429,7 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   int threads, cpt, maxn, maxm;
   ot_launch_shape(pr, np, threads, cpt, maxn, maxm);
   GIMS_CHECK_ARG(cpt <= 4, "gims_sinkhorn_match: m=%d too large (max 16384)", maxm);
-  std::vector<OtDev> h(np);
+  OtDev* dprob = (OtDev*)work;
   char* base = (char*)work;
   size_t off = al256(sizeof(OtDev) * (size_t)np);
   int maxG = 0;
@@ -436,10 +455,10 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     d.norm = -logf(ms + ns);
     d.log_mu_bin = logf(ns) + d.norm;                        // gmatcher.py:63
     d.log_nu_bin = logf(ms) + d.norm;                        // gmatcher.py:64
-    h[i] = d;
+    OtBlob blob;
+    memcpy(blob.b, &d, sizeof(OtDev));
+    hipLaunchKernelGGL(ot_setup_kernel, dim3(1), dim3(1), 0, s, blob, dprob + i);
   }
-  GIMS_HIP(hipMemcpyAsync(work, h.data(), sizeof(OtDev) * (size_t)np, hipMemcpyHostToDevice, s));
-  GIMS_HIP(hipStreamSynchronize(s));  // h is a stack-owned staging buffer
   const OtDev* dp = (const OtDev*)work;
   hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, iters == 0 ? 1 : 0);
   dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
@@ -447,7 +466,7 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     if (cpt == 1) hipLaunchKernelGGL(ot_iter_kernel<1>, gi, dim3(threads), 0, s, dp, alpha);
     else if (cpt == 2) hipLaunchKernelGGL(ot_iter_kernel<2>, gi, dim3(threads), 0, s, dp, alpha);
     else hipLaunchKernelGGL(ot_iter_kernel<4>, gi, dim3(threads), 0, s, dp, alpha);
-    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(256), 0, s, dp);
+    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp);
   }
   if (cpt == 1) hipLaunchKernelGGL(ot_select_kernel<1>, gi, dim3(threads), 0, s, dp);
   else if (cpt == 2) hipLaunchKernelGGL(ot_select_kernel<2>, gi, dim3(threads), 0, s, dp);

@@ -18,6 +18,7 @@ so that every linear layer is ONE launch for the whole batch.
 from __future__ import annotations
 
 import math
+import time
 from typing import Dict, List
 
 import numpy as np
@@ -202,143 +203,206 @@ class GMatcher(nn.Module):
     def _lin(e, a0, **kw):
         return hip.linear(a0, e["w"], w_lo=e["w_lo"], bias=e["b"], precision=e["prec"], **kw)
 
-    # ------------------------------------------------------------------ forward
-    @torch.no_grad()
-    def forward(self, data, **kwargs):
-        cfg = self.config
-        radius = data.get('radius', 25)
-        percentile = data.get('percentile', 7)
-        min_size = data.get('min_size', 8)
-        if data.get('delaunay', False):
-            raise NotImplementedError("delaunay=True is broken in the reference snapshot (UnboundLocalError, gmatcher.py:250)")
-        if kwargs.get('mode', 'test') == "train":
-            raise NotImplementedError("forward_train (gmatcher.py:309-386) is not on the HIP path yet")
-        dev = data['keypoints0'].device
-        if dev.type != "cuda":
-            raise hip.GimsHipError("GMatcher runs on the GPU only (no CPU fallback): move the inputs to 'cuda'")
-        P = self._packed(dev)
-        B = data['keypoints0'].shape[0]
-        D = cfg['descriptor_dim']
+    # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
+    def enable_timing(self, on: bool = True):
+        """Record a (start, end) HIP-event pair around every stage on the stream the kernels are launched on;
+        read them back with ``stage_times_ms()`` after a synchronize."""
+        self._timers = {} if on else None
 
-        # ---- adaptive graph construction, all images of the call enqueued back to back, ONE sync
-        builds = []
-        for b in range(B):
-            for side in ("0", "1"):
-                kp = data['keypoints' + side][b].to(torch.float32).contiguous()
-                de = data['descriptors' + side][b].to(torch.float32).t().contiguous()      # (N, D) point-major
-                n = kp.shape[0]
+    def stage_times_ms(self):
+        out = {}
+        for name, evs in (self._timers or {}).items():
+            out[name] = [a.elapsed_time(b) for a, b, _ in evs]
+        return out
+
+    def stage_host_ms(self):
+        """Host wall time spent inside each stage (enqueue cost), same keys as stage_times_ms()."""
+        return {name: [h for _, _, h in evs] for name, evs in (self._timers or {}).items()}
+
+    class _Stage:
+        def __init__(self, owner, name):
+            self.o, self.name = owner, name
+
+        def __enter__(self):
+            if self.o._timers is not None:
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.a.record()
+                self.t0 = time.perf_counter()
+
+        def __exit__(self, *exc):
+            if self.o._timers is not None:
+                b = torch.cuda.Event(enable_timing=True)
+                b.record()
+                self.o._timers.setdefault(self.name, []).append((self.a, b, 1e3 * (time.perf_counter() - self.t0)))
+
+    _timers = None
+
+    # ------------------------------------------------------------------ persistent scratch (grown on demand, reused across calls)
+    def _buf(self, name: str, nbytes: int) -> torch.Tensor:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        arena = self.__dict__.setdefault("_arena", {})
+        t = arena.get((name, dev))
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+            arena[(name, dev)] = t
+        return t
+
+    # ------------------------------------------------------------------ ragged core: 2P images -> P pair results
+    def _run(self, images, radius, percentile, min_size):
+        """images: list of dicts {kp (N,2) f32, de (N,D) f32 point-major, sc (N,), shape}; consecutive entries
+        (2p, 2p+1) form pair p.  Every pair may keep a different number of keypoints (ragged batch)."""
+        cfg = self.config
+        dev = images[0]["kp"].device
+        P = self._packed(dev)
+        D = cfg['descriptor_dim']
+        St = lambda name: GMatcher._Stage(self, name)   # noqa: E731
+
+        # ---- adaptive graph construction: every stage ONE launch for all images; ONE host sync for the counts
+        with St("agc"):
+            for g in images:
+                n = g["kp"].shape[0]
                 if n < 2:
                     raise ValueError("need at least one array to concatenate")           # what the reference raises (agc.py:701)
-                cap = n * 64
-                work = torch.empty(hip.agc_workspace_bytes(n, D), dtype=torch.uint8, device=dev)
-                kept = torch.empty(n, dtype=torch.int32, device=dev)
-                indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
-                indices = torch.empty(cap, dtype=torch.int32, device=dev)
-                info = torch.empty(8, dtype=torch.int32, device=dev)
-                hip.agc_build(kp, de, radius, percentile, min_size, work, kept, indptr, indices, info)
-                builds.append(dict(b=b, side=side, kp=kp, de=de, kept=kept, indptr=indptr, indices=indices, info=info, work=work))
-        infos = torch.stack([g["info"] for g in builds]).cpu().numpy()                     # the one host sync of the build
-        for g, inf in zip(builds, infos):
+                g["kept"] = torch.empty(n, dtype=torch.int32, device=dev)
+                g["indptr"] = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                g["indices"] = torch.empty(n * 64, dtype=torch.int32, device=dev)
+            info_all = torch.empty((len(images), 8), dtype=torch.int32, device=dev)
+            agc_imgs = hip.make_agc_images([dict(kpts=g["kp"], desc=g["de"], kept=g["kept"], indptr=g["indptr"],
+                                                 indices=g["indices"], info=info_all[i]) for i, g in enumerate(images)])
+            hip.agc_build(agc_imgs, radius, percentile, min_size, self._buf("agc", hip.agc_workspace_bytes(agc_imgs)))
+        infos = info_all.cpu().numpy()                                                    # the one host sync of the build
+        for g, inf in zip(images, infos):
             if inf[7]:
                 raise hip.GimsHipError("adaptive graph exceeded the edge capacity (64 directed edges per node)")
             g["n_kept"], g["n_edges"] = int(inf[0]), int(inf[1])
             if g["n_kept"] == 0:
                 raise ValueError("need at least one array to concatenate")               # np.vstack([]) in agc.py:701
-            g["kept"] = g["kept"][:g["n_kept"]]
-            g["indptr"] = g["indptr"][:g["n_kept"] + 1]
-            g["indices"] = g["indices"][:g["n_edges"]]
             g["info_host"] = inf
 
-        # ---- kept-keypoint compaction + the reference's in-place dict mutation (gmatcher.py:244-252)
-        row_off, off = [], 0
-        for g in builds:
-            row_off.append(off)
-            off += g["n_kept"]
-        n_tot = off
-        feat = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
-        kpts_all = torch.empty((n_tot, 2), dtype=torch.float32, device=dev)
-        graphs = {"0": [], "1": []}
-        for g, ro in zip(builds, row_off):
-            nk = g["n_kept"]
-            hip.gather_rows(g["de"], g["kept"], feat[ro:ro + nk])
-            idx = g["kept"].long()
-            kpts_all[ro:ro + nk] = g["kp"][idx]
-            sc = data['scores' + g["side"]][g["b"]][idx]
-            g["rows"] = (ro, nk)
-            graphs[g["side"]].append(GraphHandle(g["indptr"], g["indices"],
-                                                 {"point": kpts_all[ro:ro + nk], "feat": feat[ro:ro + nk], "score": sc}))
-        for side in ("0", "1"):
-            gs = graphs[side]
-            data['keypoints' + side] = torch.stack([h.ndata['point'] for h in gs])
-            data['descriptors' + side] = torch.stack([h.ndata['feat'] for h in gs]).permute(0, 2, 1)
-            data['scores' + side] = torch.stack([h.ndata['score'] for h in gs])
-            data['kept_kpts%s_indices' % side] = [g["kept"].tolist() for g in builds if g["side"] == side]
-            data['graph' + side] = gs
-
+        # ---- kept-keypoint compaction (gmatcher.py:244-249): rows of all images concatenated, one launch
+        row_off = np.cumsum([0] + [g["n_kept"] for g in images]).tolist()
+        e_off = np.cumsum([0] + [g["n_edges"] for g in images]).tolist()
+        n_tot, e_tot = row_off[-1], e_off[-1]
+        with St("gather"):
+            feat = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
+            kpts_all = torch.empty((n_tot, 2), dtype=torch.float32, device=dev)
+            score_all = torch.empty((n_tot,), dtype=torch.float32, device=dev)
+            seg = torch.empty((n_tot,), dtype=torch.int32, device=dev)
+            indptr_all = torch.empty((n_tot + 1,), dtype=torch.int32, device=dev)
+            indices_all = torch.empty((max(e_tot, 1),), dtype=torch.int32, device=dev)
+            packs = []
+            for i, g in enumerate(images):
+                sc = g["sc"].to(torch.float32).contiguous()
+                g["_sc32"] = sc
+                packs.append(hip.PackImage(g["kp"].data_ptr(), g["de"].data_ptr(), g["de"].stride(0), sc.data_ptr(),
+                                           g["kept"].data_ptr(), g["indptr"].data_ptr(), g["indices"].data_ptr(),
+                                           g["n_kept"], g["n_edges"], row_off[i], e_off[i]))
+            g_keep = hip.pack_graphs(packs, D, feat, kpts_all, score_all, seg, indptr_all, indices_all, n_tot, e_tot)
+            norm3 = torch.empty((len(images), 3), dtype=torch.float32)
+            for i, g in enumerate(images):
+                height, width = g["shape"][2], g["shape"][3]     # NHWC callers => (W, 3): the reference's quirk, kept verbatim
+                one = torch.tensor(1, dtype=torch.float32)
+                size = torch.stack([one * width, one * height])
+                norm3[i, 0], norm3[i, 1] = size[0] / 2, size[1] / 2
+                norm3[i, 2] = size.max() * 0.7
+            norm3 = norm3.to(dev)
+            for g, ro in zip(images, row_off):
+                nk = g["n_kept"]
+                g["rows"] = (ro, nk)
+                g["kept"] = g["kept"][:nk]
+                g["indptr"] = g["indptr"][:nk + 1]
+                g["indices"] = g["indices"][:g["n_edges"]]
+                g["graph"] = GraphHandle(g["indptr"], g["indices"],
+                                         {"point": kpts_all[ro:ro + nk], "feat": feat[ro:ro + nk], "score": score_all[ro:ro + nk]})
         # ---- GraphSAGE over the merged CSR of all images (gmatcher.py:145-162, 268-269)
-        e_off = np.cumsum([0] + [g["n_edges"] for g in builds]).tolist()
-        indptr_all = torch.cat([g["indptr"][:-1] + e0 for g, e0 in zip(builds, e_off[:-1])]
-                               + [torch.tensor([e_off[-1]], dtype=torch.int32, device=dev)]).to(torch.int32)
-        indices_all = torch.cat([g["indices"] + ro for g, ro in zip(builds, row_off)]).to(torch.int32)
-        h = feat
-        for i, e in enumerate(P["sage"]):
-            agg = torch.empty_like(h)
-            hip.sage_mean(h, indptr_all, indices_all, agg)
-            h = self._lin(e, h, a1=agg, act=hip.ACT_RELU if i < 2 else hip.ACT_NONE)
-        sage = h
+        with St("sage"):
+            h = feat
+            for i, e in enumerate(P["sage"]):
+                agg = torch.empty_like(h)
+                hip.sage_mean(h, indptr_all, indices_all, agg)
+                h = self._lin(e, h, a1=agg, act=hip.ACT_RELU if i < 2 else hip.ACT_NONE)
+            sage = h
         # ---- keypoint encoder (gmatcher.py:26-33, 87-97) ; desc = sage + kenc (gmatcher.py:270-271)
-        norm3 = torch.empty((len(builds), 3), dtype=torch.float32)
-        for i, g in enumerate(builds):
-            shp = data['image' + g["side"]].shape
-            height, width = shp[2], shp[3]                      # NHWC callers => (W, 3): the reference's quirk, kept verbatim
-            one = torch.tensor(1, dtype=torch.float32)
-            size = torch.stack([one * width, one * height])
-            norm3[i, 0], norm3[i, 1] = size[0] / 2, size[1] / 2
-            norm3[i, 2] = size.max() * 0.7
-        seg = torch.cat([torch.full((g["n_kept"],), i, dtype=torch.int32) for i, g in enumerate(builds)]).to(dev)
-        x = torch.empty((n_tot, P["kenc_w1"].shape[0]), dtype=torch.float32, device=dev)
-        hip.kenc_first(kpts_all, norm3.to(dev), seg, P["kenc_w1"], P["kenc_b1"], x)
-        for i, e in enumerate(P["kenc"]):
-            last = i == len(P["kenc"]) - 1
-            x = self._lin(e, x, act=hip.ACT_NONE if last else hip.ACT_RELU, residual=sage if last else None,
-                          out=torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev))
-        desc = x
-
+        with St("kenc"):
+            x = torch.empty((n_tot, P["kenc_w1"].shape[0]), dtype=torch.float32, device=dev)
+            hip.kenc_first(kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], x)
+            for i, e in enumerate(P["kenc"]):
+                last = i == len(P["kenc"]) - 1
+                x = self._lin(e, x, act=hip.ACT_NONE if last else hip.ACT_RELU, residual=sage if last else None,
+                              out=torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev))
+            desc = x
         # ---- attentional GNN (gmatcher.py:99-143): per layer QKV -> flash attention -> merge -> MLP -> residual
-        pairs = []
-        for b in range(B):
-            g0, g1 = builds[2 * b], builds[2 * b + 1]
-            pairs.append((g0["rows"], g1["rows"]))
+        pairs = [(images[2 * p]["rows"], images[2 * p + 1]["rows"]) for p in range(len(images) // 2)]
         self_pr = torch.tensor([[o, n, o, n] for pr in pairs for (o, n) in pr], dtype=torch.int32, device=dev)
         cross_pr = torch.tensor([q for (o0, n0), (o1, n1) in pairs for q in ((o0, n0, o1, n1), (o1, n1, o0, n0))],
                                 dtype=torch.int32, device=dev)
-        max_nq = max(g["n_kept"] for g in builds)
+        max_nq = max(g["n_kept"] for g in images)
         qkv = torch.empty((n_tot, 3 * D), dtype=torch.bfloat16, device=dev)
         msg = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
         mrg = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
         hid = torch.empty((n_tot, 2 * D), dtype=torch.float32, device=dev)
         for L in P["layers"]:
-            self._lin(L["qkv"], desc, out_bf16=qkv)
-            hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D)
-            self._lin(L["merge"], msg, out=mrg)
-            self._lin(L["mlp0"], desc, a1=mrg, act=hip.ACT_RELU, out=hid)
-            self._lin(L["mlp1"], hid, residual=desc, out=desc)          # desc += delta  (gmatcher.py:142)
+            with St("qkv"):
+                self._lin(L["qkv"], desc, out_bf16=qkv)
+            with St("attn_cross" if L["cross"] else "attn_self"):
+                hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D)
+            with St("mlp"):
+                self._lin(L["merge"], msg, out=mrg)
+                self._lin(L["mlp0"], desc, a1=mrg, act=hip.ACT_RELU, out=hid)
+                self._lin(L["mlp1"], hid, residual=desc, out=desc)          # desc += delta  (gmatcher.py:142)
         # ---- final projection, score matrix, Sinkhorn, selection (gmatcher.py:273-294)
-        mdesc = self._lin(P["final"], desc)
-        items, keep = [], []
-        for (o0, n0), (o1, n1) in pairs:
-            ld = (n1 + 3) // 4 * 4
-            scores = torch.empty((n0, ld), dtype=torch.float32, device=dev)
-            hip.linear(mdesc[o0:o0 + n0], mdesc[o1:o1 + n1], out=scores, precision=hip.PREC_F32, scale=1.0 / math.sqrt(D), n=n1)
-            it = dict(scores=scores, n=n0, m=n1,
-                      matches0=torch.empty(n0, dtype=torch.int64, device=dev), matches1=torch.empty(n1, dtype=torch.int64, device=dev),
-                      mscores0=torch.empty(n0, dtype=torch.float32, device=dev), mscores1=torch.empty(n1, dtype=torch.float32, device=dev),
-                      uv=torch.empty(n0 + n1 + 3, dtype=torch.float32, device=dev))
-            items.append(it)
-        probs = hip.make_ot_problems(items)
-        work = torch.empty(hip.sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device=dev)
-        hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
-        self._last = dict(items=items, pairs=pairs, mdesc=mdesc, desc=desc, sage=sage, builds=builds)   # introspection for tests
+        with St("final_scores"):
+            mdesc = self._lin(P["final"], desc)
+            items, largs = [], []
+            for (o0, n0), (o1, n1) in pairs:
+                ld = (n1 + 3) // 4 * 4
+                scores = torch.empty((n0, ld), dtype=torch.float32, device=dev)
+                largs.append(hip.linear_args(mdesc[o0:o0 + n0], mdesc[o1:o1 + n1], out=scores, precision=hip.PREC_F32,
+                                             scale=1.0 / math.sqrt(D), n=n1))
+                items.append(dict(scores=scores, n=n0, m=n1,
+                                  matches0=torch.empty(n0, dtype=torch.int64, device=dev), matches1=torch.empty(n1, dtype=torch.int64, device=dev),
+                                  mscores0=torch.empty(n0, dtype=torch.float32, device=dev), mscores1=torch.empty(n1, dtype=torch.float32, device=dev),
+                                  uv=torch.empty(n0 + n1 + 3, dtype=torch.float32, device=dev)))
+            hip.linear_batch(largs, self._buf("score_args", 256 * len(largs)), hip.PREC_F32)
+        with St("sinkhorn"):
+            probs = hip.make_ot_problems(items)
+            work = self._buf("ot", hip.sinkhorn_workspace_bytes(probs))
+            hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
+        self._last = dict(items=items, pairs=pairs, mdesc=mdesc, desc=desc, sage=sage, images=images)
+        return items, pairs, mdesc
+
+    @staticmethod
+    def _image(kp, de_dn, sc, shape):
+        return {"kp": kp.to(torch.float32).contiguous(), "de": de_dn.to(torch.float32).t().contiguous(), "sc": sc, "shape": tuple(shape)}
+
+    def _check_call(self, data, kwargs):
+        if data.get('delaunay', False):
+            raise NotImplementedError("delaunay=True is broken in the reference snapshot (UnboundLocalError, gmatcher.py:250)")
+        if kwargs.get('mode', 'test') == "train":
+            raise NotImplementedError("forward_train (gmatcher.py:309-386) is not on the HIP path yet")
+        if data['keypoints0'].device.type != "cuda":
+            raise hip.GimsHipError("GMatcher runs on the GPU only (no CPU fallback): move the inputs to 'cuda'")
+
+    # ------------------------------------------------------------------ reference-shaped forward (gmatcher.py:219-307)
+    @torch.no_grad()
+    def forward(self, data, **kwargs):
+        self._check_call(data, kwargs)
+        radius, percentile, min_size = data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)
+        B = data['keypoints0'].shape[0]
+        images = []
+        for b in range(B):
+            for side in ("0", "1"):
+                images.append(self._image(data['keypoints' + side][b], data['descriptors' + side][b], data['scores' + side][b],
+                                          data['image' + side].shape))
+        items, pairs, mdesc = self._run(images, radius, percentile, min_size)
+        # the reference's in-place dict mutation (gmatcher.py:244-252); torch.stack raises for ragged B>1, as there
+        for s, side in enumerate(("0", "1")):
+            gs = [images[2 * b + s]["graph"] for b in range(B)]
+            data['keypoints' + side] = torch.stack([h.ndata['point'] for h in gs])
+            data['descriptors' + side] = torch.stack([h.ndata['feat'] for h in gs]).permute(0, 2, 1)
+            data['scores' + side] = torch.stack([h.ndata['score'] for h in gs])
+            data['kept_kpts%s_indices' % side] = [images[2 * b + s]["kept"].tolist() for b in range(B)]
+            data['graph' + side] = gs
         md0 = torch.stack([mdesc[o0:o0 + n0] for (o0, n0), _ in pairs])
         md1 = torch.stack([mdesc[o1:o1 + n1] for _, (o1, n1) in pairs])
         return {
@@ -350,3 +414,39 @@ class GMatcher(nn.Module):
             'matching_scores1': torch.stack([it["mscores1"] for it in items]),
             'mdesc0': md0.squeeze(), 'mdesc1': md1.squeeze(),
         }
+
+    # ------------------------------------------------------------------ ragged batch of independent pairs
+    @torch.no_grad()
+    def match_pairs(self, datas: List[dict], **kwargs):
+        """Throughput API: a list of single-pair dicts (each exactly what ``forward`` takes with B == 1) is
+        matched in ONE batched pass even when every pair keeps a different number of keypoints (the reference's
+        ``forward`` can only stack equal-sized pairs, gmatcher.py:244-249).  Each dict is mutated like ``forward``
+        does and a list of per-pair result dicts (same keys as ``forward``) is returned."""
+        images = []
+        for data in datas:
+            self._check_call(data, kwargs)
+            if data['keypoints0'].shape[0] != 1:
+                raise ValueError("match_pairs takes single-pair dicts (B == 1)")
+            for side in ("0", "1"):
+                images.append(self._image(data['keypoints' + side][0], data['descriptors' + side][0], data['scores' + side][0],
+                                          data['image' + side].shape))
+        d0 = datas[0]
+        items, pairs, mdesc = self._run(images, d0.get('radius', 25), d0.get('percentile', 7), d0.get('min_size', 8))
+        outs = []
+        for p, (data, it) in enumerate(zip(datas, items)):
+            for s, side in enumerate(("0", "1")):
+                g = images[2 * p + s]["graph"]
+                data['keypoints' + side] = g.ndata['point'][None]
+                data['descriptors' + side] = g.ndata['feat'].t()[None]
+                data['scores' + side] = g.ndata['score'][None]
+                data['kept_kpts%s_indices' % side] = [images[2 * p + s]["kept"]]      # device tensor (no host sync here)
+                data['graph' + side] = [g]
+            (o0, n0), (o1, n1) = pairs[p]
+            outs.append({
+                'keypoints0': data['keypoints0'], 'keypoints1': data['keypoints1'],
+                'descriptors0': data['descriptors0'], 'descriptors1': data['descriptors1'],
+                'matches0': it["matches0"][None], 'matches1': it["matches1"][None],
+                'matching_scores0': it["mscores0"][None], 'matching_scores1': it["mscores1"][None],
+                'mdesc0': mdesc[o0:o0 + n0], 'mdesc1': mdesc[o1:o1 + n1],
+            })
+        return outs

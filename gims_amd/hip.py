@@ -31,6 +31,18 @@ class LinearArgs(C.Structure):
                 ("scale", C.c_float)]
 
 
+class AgcImage(C.Structure):
+    _fields_ = [("kpts", C.c_void_p), ("desc", C.c_void_p), ("ldd", C.c_int64), ("n", C.c_int32), ("d", C.c_int32),
+                ("kept", C.c_void_p), ("indptr", C.c_void_p), ("indices", C.c_void_p), ("max_edges_dir", C.c_int32),
+                ("info", C.c_void_p)]
+
+
+class PackImage(C.Structure):
+    _fields_ = [("kpts", C.c_void_p), ("desc", C.c_void_p), ("ldd", C.c_int64), ("score", C.c_void_p),
+                ("kept", C.c_void_p), ("indptr", C.c_void_p), ("indices", C.c_void_p),
+                ("n_kept", C.c_int32), ("n_edges", C.c_int32), ("row_off", C.c_int32), ("edge_off", C.c_int32)]
+
+
 class OtProblem(C.Structure):
     _fields_ = [("scores", C.c_void_p), ("ld", C.c_int64), ("n", C.c_int32), ("m", C.c_int32),
                 ("matches0", C.c_void_p), ("matches1", C.c_void_p), ("mscores0", C.c_void_p),
@@ -42,6 +54,8 @@ _SIGNATURES = {
     "gims_last_error": (C.c_char_p, []),
     "gims_stream_sync": (C.c_int, [C.c_void_p]),
     "gims_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    "gims_linear_put": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p, C.c_void_p]),
+    "gims_linear_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -51,10 +65,12 @@ _SIGNATURES = {
                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
-    "gims_agc_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
-    "gims_agc_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double,
-                                 C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                 C.c_void_p, C.c_void_p]),
+    "gims_agc_workspace_bytes": (C.c_size_t, [C.POINTER(AgcImage), C.c_int32]),
+    "gims_agc_build": (C.c_int, [C.POINTER(AgcImage), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_void_p,
+                                 C.c_size_t, C.c_void_p]),
+    "gims_pack_graphs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                   C.c_void_p]),
     "gims_sinkhorn_workspace_bytes": (C.c_size_t, [C.POINTER(OtProblem), C.c_int32]),
     "gims_sinkhorn_match": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_float,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -106,6 +122,30 @@ def _dev(t: torch.Tensor, dtype=None):
     if dtype is not None and t.dtype != dtype:
         raise GimsHipError(f"expected {dtype}, got {t.dtype}")
     return t
+
+
+def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
+                precision=PREC_F32, scale=1.0, n=None):
+    m, k0 = a0.shape
+    k = k0 + (a1.shape[1] if a1 is not None else 0)
+    n = w.shape[0] if n is None else n
+    assert w.shape[1] == k and a0.stride(1) == 1 and w.stride(1) == 1
+    return LinearArgs(_p(_dev(a0, torch.float32)), a0.stride(0), _p(a1), a1.stride(0) if a1 is not None else 0,
+                      _p(w), _p(w_lo), w.stride(0), _p(bias), _p(residual), _p(out),
+                      out.stride(0) if out is not None else 0, _p(out_bf16),
+                      out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale))
+
+
+def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):
+    """Many independent problems in one launch; dev_args: uint8 device scratch of >= len * sizeof(LinearArgs)."""
+    lib = load()
+    sz = C.sizeof(LinearArgs)
+    assert dev_args.numel() * dev_args.element_size() >= sz * len(arg_list)
+    st = _stream()
+    for i, a in enumerate(arg_list):
+        _check(lib.gims_linear_put(C.byref(a), dev_args.data_ptr() + i * sz, st), "gims_linear_put")
+    _check(lib.gims_linear_batch(dev_args.data_ptr(), len(arg_list), max(a.m for a in arg_list), max(a.n for a in arg_list),
+                                 precision, st), "gims_linear_batch")
 
 
 def linear(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
@@ -173,18 +213,39 @@ def gather_rows(src, idx, out):
     return out
 
 
-def agc_workspace_bytes(n: int, d: int) -> int:
-    return int(load().gims_agc_workspace_bytes(n, d))
+def make_agc_images(items):
+    """items: dicts with kpts [n,2], desc [n,d] (point-major f32), kept [n], indptr [n+1], indices [cap], info [8]."""
+    arr = (AgcImage * len(items))()
+    for i, it in enumerate(items):
+        de = it["desc"]
+        assert de.stride(1) == 1 and it["kpts"].is_contiguous()
+        arr[i] = AgcImage(_p(_dev(it["kpts"], torch.float32)), _p(_dev(de, torch.float32)), de.stride(0), de.shape[0], de.shape[1],
+                          _p(it["kept"]), _p(it["indptr"]), _p(it["indices"]), it["indices"].numel(), _p(it["info"]))
+    return arr
 
 
-def agc_build(kpts, desc, radius, percentile, min_size, work, kept, indptr, indices, info):
-    """Asynchronous adaptive-graph build for one image; see include/gims_hip.h."""
+def agc_workspace_bytes(images) -> int:
+    return int(load().gims_agc_workspace_bytes(images, len(images)))
+
+
+def agc_build(images, radius, percentile, min_size, work: torch.Tensor):
+    """Asynchronous adaptive-graph build for a batch of images; see include/gims_hip.h."""
     lib = load()
-    n, d = desc.shape
-    assert desc.stride(1) == 1 and kpts.is_contiguous()
-    _check(lib.gims_agc_build(_p(_dev(kpts, torch.float32)), _p(_dev(desc, torch.float32)), desc.stride(0), n, d,
-                              float(radius), float(percentile), int(min_size), _p(work), work.numel() * work.element_size(),
-                              _p(kept), _p(indptr), _p(indices), indices.numel(), _p(info), _stream()), "gims_agc_build")
+    _check(lib.gims_agc_build(images, len(images), float(radius), float(percentile), int(min_size), _p(work),
+                              work.numel() * work.element_size(), _stream()), "gims_agc_build")
+
+
+def pack_graphs(pack_items, d, feat, kpts_out, score_out, seg, indptr_out, indices_out, n_rows, n_edges):
+    """pack_items: list of PackImage (host); uploaded as one small H2D copy, then one launch for the batch."""
+    lib = load()
+    arr = (PackImage * len(pack_items))(*pack_items)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    dev_arr = host.to(feat.device, non_blocking=False)
+    _check(lib.gims_pack_graphs(_p(dev_arr), len(pack_items), max(p.n_kept for p in pack_items),
+                                max(max(p.n_edges for p in pack_items), 1), d, _p(feat), feat.stride(0), _p(kpts_out),
+                                _p(score_out), _p(seg), _p(indptr_out), _p(indices_out), n_rows, n_edges, _stream()),
+           "gims_pack_graphs")
+    return dev_arr
 
 
 def make_ot_problems(items):

@@ -72,6 +72,13 @@ typedef struct gims_linear_args {
 } gims_linear_args;
 
 int gims_linear(const gims_linear_args* args, void* stream);
+/* Many independent problems in ONE launch (ragged batch: per-pair score matrices, per-image similarity
+ * matrices).  gims_linear_put validates one descriptor and stores it into device memory (by-value kernel
+ * argument: no host staging copy, no synchronisation); gims_linear_batch launches all `count` problems,
+ * grid sized for the largest (max_m x max_n).  All problems of a batch share `precision`. */
+int gims_linear_put(const gims_linear_args* args, gims_linear_args* dev_dst, void* stream);
+int gims_linear_batch(const gims_linear_args* dev_args, int32_t count, int32_t max_m, int32_t max_n,
+                      int32_t precision, void* stream);
 
 /* Split an f32 array into bf16 hi/lo planes (hi = bf16_rne(x), lo = bf16_rne(x - hi)). */
 int gims_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
@@ -114,23 +121,44 @@ int gims_gather_rows(const float* src, int64_t lds, const int32_t* idx, int32_t 
                      float* dst, int64_t ldd, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Adaptive graph construction for ONE image (models/agc.py:682-709, live subset):
+ * Adaptive graph construction for a BATCH of images (models/agc.py:682-709, live subset), every stage one
+ * launch for all images (blockIdx.y = image):
  *   cosine similarity (382-391) -> exact percentile threshold over the strict upper triangle (367-380,
  *   439-440) -> radius pairs in float64, inclusive (435-436) filtered by sim >= thr (445-447) ->
  *   connect_isolated_nodes (476-495) -> remove_small_components (497-516) -> fast_connect_components
  *   (518-565, one round) -> sorted relabel + bidirectional CSR (dgl.from_networkx, 704).
- * kpts [n][2] f32, desc [n][d] f32 (point-major, un-normalised).  `work` is scratch of at least
- * gims_agc_workspace_bytes(n, d) bytes.  Outputs (device): kept[<=n] (sorted original ids),
- * indptr[n_kept+1], indices[<= max_edges_dir] in kept-relabelled ids, info[8] =
- *   {n_kept, n_dir_edges, n_coarse_edges, n_iso_added, n_components_after_removal, n_link_added,
- *    threshold bits (f32), overflow flag}.
+ * Per image: kpts [n][2] f32, desc [n][d] f32 (point-major, un-normalised); outputs (device): kept[n]
+ * (first n_kept entries: sorted original ids), indptr[n+1] (first n_kept+1 valid), indices[max_edges_dir]
+ * in kept-relabelled ids, info[8] = {n_kept, n_dir_edges, n_coarse_edges, n_iso_added,
+ * n_components_after_removal, n_link_added, threshold bits (f32), overflow flag}.
+ * `work` is scratch of at least gims_agc_workspace_bytes(images, n_images) bytes.
  * Exact-distance ties in the two sequential fix-ups resolve to the lowest node index.
  * Asynchronous; read info[] after synchronising the stream.
  */
-size_t gims_agc_workspace_bytes(int32_t n, int32_t d);
-int gims_agc_build(const float* kpts, const float* desc, int64_t ldd, int32_t n, int32_t d, double radius,
-                   double percentile, int32_t min_size, void* work, size_t work_bytes, int32_t* kept,
-                   int32_t* indptr, int32_t* indices, int32_t max_edges_dir, int32_t* info, void* stream);
+typedef struct gims_agc_image {
+  const float* kpts; const float* desc; int64_t ldd; int32_t n, d;
+  int32_t* kept; int32_t* indptr; int32_t* indices; int32_t max_edges_dir; int32_t* info;
+} gims_agc_image;
+
+size_t gims_agc_workspace_bytes(const gims_agc_image* h_images /* HOST array */, int32_t n_images);
+int gims_agc_build(const gims_agc_image* h_images /* HOST array */, int32_t n_images, double radius, double percentile,
+                   int32_t min_size, void* work, size_t work_bytes, void* stream);
+
+/* Pack the kept keypoints of a batch of images into the row-concatenated layout the rest of the path uses
+ * (gmatcher.py:244-249): for image i with row offset ro_i and edge offset eo_i,
+ *   feat[ro_i + r, :] = desc_i[kept_i[r], :],  kpts_out[ro_i + r] = kpts_i[kept_i[r]],  score_out likewise,
+ *   seg[ro_i + r] = i,  indptr_out[ro_i + r] = indptr_i[r] + eo_i,  indices_out[eo_i + e] = indices_i[e] + ro_i
+ * and indptr_out[n_rows_total] = n_edges_total. */
+typedef struct gims_pack_image {
+  const float* kpts; const float* desc; int64_t ldd; const float* score;
+  const int32_t* kept; const int32_t* indptr; const int32_t* indices;
+  int32_t n_kept, n_edges, row_off, edge_off;
+} gims_pack_image;
+
+int gims_pack_graphs(const gims_pack_image* dev_images /* DEVICE array */, int32_t n_images, int32_t max_kept,
+                     int32_t max_edges, int32_t d, float* feat, int64_t ldf, float* kpts_out, float* score_out,
+                     int32_t* seg, int32_t* indptr_out, int32_t* indices_out, int32_t n_rows_total,
+                     int32_t n_edges_total, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Log-domain Sinkhorn optimal transport + mutual-argmax match selection.

@@ -81,7 +81,7 @@ def test_intermediates_vs_reference_golden(models, name):
     out = m(data)
     last = m._last
     (o0, n0), (o1, n1) = last["pairs"][0]
-    sage = last["sage"].cpu().numpy()
+    sage = last["sage"].cpu().numpy()  # noqa
     np.testing.assert_allclose(sage[o0:o0 + n0], g["out/sage0"], atol=5e-5, rtol=1e-5)
     np.testing.assert_allclose(sage[o1:o1 + n1], g["out/sage1"], atol=5e-5, rtol=1e-5)
     desc = last["desc"].cpu().numpy()
@@ -127,6 +127,21 @@ def test_full_size_properties(models):
     gt = pair["gt_perm"][k0[v]]
     correct = (k1[m0[v]] == gt).sum()
     assert correct > 0.95 * v.sum() and v.sum() > 3000, (correct, v.sum())
+
+
+def test_match_pairs_ragged_equals_forward(models):
+    """The ragged batch API returns, pair by pair, exactly what forward() returns for that pair alone."""
+    m = models[("bf16x3", 100)]
+    specs = [(256, 1002), (200, 1001), (512, 1004)]
+    pairs = [synth.make_pair(n, s, canvas=synth.canvas_for(256) if n == 200 else None) for n, s in specs]
+    singles = [m(pair_to_data(p, 15, 2, 7, device="cuda")) for p in pairs]
+    datas = [pair_to_data(p, 15, 2, 7, device="cuda") for p in pairs]
+    outs = m.match_pairs(datas)
+    for o, s, d in zip(outs, singles, datas):
+        np.testing.assert_array_equal(o["matches0"].cpu().numpy(), s["matches0"].cpu().numpy())
+        np.testing.assert_array_equal(o["matches1"].cpu().numpy(), s["matches1"].cpu().numpy())
+        np.testing.assert_allclose(o["matching_scores0"].cpu().numpy(), s["matching_scores0"].cpu().numpy(), atol=2e-6)
+        assert d["keypoints0"].shape[1] == o["matches0"].shape[1]
 
 
 def test_errors_like_reference():

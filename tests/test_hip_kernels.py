@@ -226,17 +226,28 @@ def test_kenc_first(hip):
 
 
 # --------------------------------------------------------------------------------------------- adaptive graph
+def _run_agc_batch(hip, imgs, rad, pct, ms):
+    """imgs: list of (kp [n,2], de [n,d]) NumPy arrays -> list of (kept, indptr, indices, info) per image (one batched call)."""
+    items = []
+    for kp, de in imgs:
+        n = de.shape[0]
+        items.append(dict(kpts=_dev(kp), desc=_dev(de), kept=torch.empty(n, dtype=torch.int32, device="cuda"),
+                          indptr=torch.empty(n + 1, dtype=torch.int32, device="cuda"),
+                          indices=torch.empty(n * 64, dtype=torch.int32, device="cuda"),
+                          info=torch.empty(8, dtype=torch.int32, device="cuda")))
+    arr = hip.make_agc_images(items)
+    work = torch.empty(hip.agc_workspace_bytes(arr), dtype=torch.uint8, device="cuda")
+    hip.agc_build(arr, rad, pct, ms, work)
+    out = []
+    for it in items:
+        inf = it["info"].cpu().numpy()
+        nk, ne = int(inf[0]), int(inf[1])
+        out.append((it["kept"][:nk].cpu().numpy(), it["indptr"][:nk + 1].cpu().numpy(), it["indices"][:ne].cpu().numpy(), inf))
+    return out
+
+
 def _run_agc(hip, kp, de, rad, pct, ms):
-    n, d = de.shape
-    work = torch.empty(hip.agc_workspace_bytes(n, d), dtype=torch.uint8, device="cuda")
-    kept = torch.empty(n, dtype=torch.int32, device="cuda")
-    indptr = torch.empty(n + 1, dtype=torch.int32, device="cuda")
-    indices = torch.empty(n * 64, dtype=torch.int32, device="cuda")
-    info = torch.empty(8, dtype=torch.int32, device="cuda")
-    hip.agc_build(_dev(kp), _dev(de), rad, pct, ms, work, kept, indptr, indices, info)
-    inf = info.cpu().numpy()
-    nk, ne = int(inf[0]), int(inf[1])
-    return kept[:nk].cpu().numpy(), indptr[:nk + 1].cpu().numpy(), indices[:ne].cpu().numpy(), inf
+    return _run_agc_batch(hip, [(kp, de)], rad, pct, ms)[0]
 
 
 def _csr_edges(indptr, indices):
@@ -275,6 +286,20 @@ def test_agc_vs_reference_golden(hip, name):
         for i in (0, len(kept) // 2, len(kept) - 1):
             row = indices[indptr[i]:indptr[i + 1]]
             assert (np.diff(row) > 0).all()
+
+
+def test_agc_batched_ragged_equals_single(hip):
+    """Images of different sizes in one batched call give exactly the per-image results."""
+    imgs = []
+    for n, seed, canvas in ((300, 2003, (200, 150)), (1024, 2001, (800, 600)), (512, 1004, None), (64, 1000, None)):
+        pair = synth.make_pair(n, seed, canvas=canvas)
+        imgs.append((pair["keypoints0"][0], np.ascontiguousarray(pair["descriptors0"][0].T)))
+        imgs.append((pair["keypoints1"][0], np.ascontiguousarray(pair["descriptors1"][0].T)))
+    batched = _run_agc_batch(hip, imgs, 15, 2, 7)
+    for im, b in zip(imgs, batched):
+        s = _run_agc(hip, im[0], im[1], 15, 2, 7)
+        for x, y in zip(s, b):
+            np.testing.assert_array_equal(x, y)
 
 
 def test_agc_vs_oracle_random(hip):
