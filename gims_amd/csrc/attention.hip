@@ -33,7 +33,8 @@ __device__ __forceinline__ int k_off(int row, int chunk) {  // K tile: [64 keys]
 
 __global__ __launch_bounds__(256) void attention_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
-    const gims_attn_problem* __restrict__ problems, float* __restrict__ out, int64_t ld_out) {
+    const gims_attn_problem* __restrict__ problems, float* __restrict__ out, int64_t ld_out,
+    uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[KB * DH];
   __shared__ __attribute__((aligned(16))) uint16_t Vt[DH * VT_LD];
 
@@ -194,13 +195,22 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
   const float inv = 1.f / l_tot;
   const int qr = q0 + wave * QW + li;
   if (qr < pr.n_q) {
-    float* op = out + (int64_t)(pr.q_off + qr) * ld_out + head * DH + 4 * lh;
+    const int64_t grow = pr.q_off + qr;
+    const int col0 = head * DH + 4 * lh;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float4 v = make_float4(o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
-        *(float4*)(op + 32 * i + 8 * g) = v;
+        const float4 v = make_float4(o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+        const int col = col0 + 32 * i + 8 * g;
+        if (out) *(float4*)(out + grow * ld_out + col) = v;
+        if (out_hi) {
+          const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
+          const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+          const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+          *(uint2*)(out_hi + grow * ld_split + col) = make_uint2(h01, h23);
+          *(uint2*)(out_lo + grow * ld_split + col) = make_uint2(l01, l23);
+        }
       }
   }
 }
@@ -209,16 +219,18 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 
 extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
                               const gims_attn_problem* problems, int32_t n_problems, int32_t max_n_q,
-                              int32_t n_heads, float* out, int64_t ld_out, void* stream) {
+                              int32_t n_heads, float* out, int64_t ld_out, uint16_t* out_hi, uint16_t* out_lo,
+                              int64_t ld_split, void* stream) {
   using namespace gims;
-  GIMS_CHECK_ARG(qkv && problems && out, "gims_attention: null pointer");
+  GIMS_CHECK_ARG(qkv && problems && (out || out_hi), "gims_attention: null pointer");
+  GIMS_CHECK_ARG((out_hi == nullptr) == (out_lo == nullptr) && (ld_split % 4) == 0, "gims_attention: out_hi/out_lo come together, ld_split %% 4 == 0");
   GIMS_CHECK_ARG(n_problems > 0 && max_n_q > 0 && n_heads > 0, "gims_attention: empty launch");
   GIMS_CHECK_ARG((ld % 8) == 0 && (q_col % 8) == 0 && (k_col % 8) == 0 && (v_col % 8) == 0,
                  "gims_attention: qkv ld / column offsets must be multiples of 8 (16-byte loads)");
   GIMS_CHECK_ARG((ld_out % 4) == 0, "gims_attention: ld_out must be a multiple of 4");
   dim3 grid(cdiv(max_n_q, QB), n_heads, n_problems);
   hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col,
-                     problems, out, ld_out);
+                     problems, out, ld_out, out_hi, out_lo, ld_split);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

@@ -26,6 +26,11 @@ __device__ __forceinline__ void epilogue_store(const gims_linear_args& p, int ro
   if (p.residual) v += p.residual[(int64_t)row * p.ldc + col];
   if (p.out_f32) p.out_f32[(int64_t)row * p.ldc + col] = v;
   if (p.out_bf16) p.out_bf16[(int64_t)row * p.ldc_bf16 + col] = f2bf(v);
+  if (p.out_hi) {
+    const uint16_t h = f2bf(v);
+    p.out_hi[(int64_t)row * p.ld_split + col] = h;
+    p.out_lo[(int64_t)row * p.ld_split + col] = f2bf(v - bf2f(h));
+  }
 }
 
 // ------------------------------------------------------------------------------------------ f32 MFMA
@@ -255,6 +260,127 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_batch_kernel(const gims_
   const gims_linear_args p = args[blockIdx.z];
   linear_bf16x3_body(p, smem);
 }
+// ------------------------------------------------------------------------------------------ split-bf16 MFMA, pre-split A
+// The hot linears of the attentional GNN.  Activations arrive ALREADY split into bf16 hi/lo planes (written by
+// the producing kernel's epilogue), so all four operand planes (A hi/lo, W hi/lo) go HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, no VGPR staging, no ds_write), double-buffered with ONE barrier per K-step:
+//   stage = 4 planes x [128 rows][32 k] bf16 (64-byte rows); each wave streams one plane per K-step as
+//   8 x 1 KiB pieces.  The LDS image is lane-linear per piece, so the bank-conflict swizzle
+//   (16-byte chunk ^= (row>>2)&3) is applied to the per-lane SOURCE address and again on the ds_read_b128.
+// The MFMA is issued with swapped operands (D^T = W A^T): a lane then owns 4 CONSECUTIVE output channels of
+// one row per accumulator group, so every epilogue store is 8-16 bytes wide (f32x4 / bf16x4) and bias /
+// residual are vector loads.
+constexpr int P_BK = 32;
+constexpr int P_PLANE = BM * P_BK;     // bf16 elements per plane per stage (8 KiB)
+constexpr int P_STAGE = 4 * P_PLANE;   // 32 KiB
+
+__device__ __forceinline__ int p_off(int row, int chunk) { return row * P_BK + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
+__global__ __launch_bounds__(256, 2) void linear_x3p_kernel(gims_linear_args p) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * P_STAGE];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nk = p.k / P_BK;
+
+  // this wave's DMA duty: plane `wave` (0: A hi, 1: A lo, 2: W hi, 3: W lo), 8 pieces of 16 rows
+  const int drow = lane >> 2, dpos = lane & 3;
+  auto issue = [&](int kt, int buf) {
+    const int k = kt * P_BK;
+    const uint16_t* base;
+    int64_t ld;
+    int kk, rmax, r0;
+    if (wave < 2) {
+      if (k < p.k0) { base = (const uint16_t*)(wave == 0 ? (const void*)p.a0 : (const void*)p.a0_lo); ld = p.lda0; kk = k; }
+      else { base = (const uint16_t*)(wave == 0 ? (const void*)p.a1 : (const void*)p.a1_lo); ld = p.lda1; kk = k - p.k0; }
+      rmax = p.m - 1; r0 = m0;
+    } else {
+      base = (const uint16_t*)(wave == 2 ? p.w : p.w_lo); ld = p.ldw; kk = k; rmax = p.n - 1; r0 = n0;
+    }
+    uint16_t* dst = smem + buf * P_STAGE + wave * P_PLANE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 16 * i + drow;
+      int gr = r0 + row; gr = gr < rmax ? gr : rmax;
+      const uint16_t* g = base + (int64_t)gr * ld + kk + 8 * (dpos ^ ((row >> 2) & 3));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(dst + i * 512), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];   // [n-block][m-block], D^T layout: column = row m (lane&31), rows = output channels
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const uint16_t* st = smem + (kt & 1) * P_STAGE;
+#pragma unroll
+    for (int s = 0; s < P_BK / 16; ++s) {
+      bf16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ar = wm * 64 + i * 32 + li, wr = wn * 64 + i * 32 + li;
+        ah[i] = *(const bf16x8*)(st + p_off(ar, 2 * s + lh));
+        al[i] = *(const bf16x8*)(st + P_PLANE + p_off(ar, 2 * s + lh));
+        wh[i] = *(const bf16x8*)(st + 2 * P_PLANE + p_off(wr, 2 * s + lh));
+        wl[i] = *(const bf16x8*)(st + 3 * P_PLANE + p_off(wr, 2 * s + lh));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // next stage has landed (the fence drains the LDS-DMA) and everyone is done with this one
+  }
+
+  // ---- epilogue: lane owns row m, 4 consecutive channels per accumulator group
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int row = m0 + wm * 64 + mi * 32 + li;
+    if (row >= p.m) continue;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = n0 + wn * 64 + ni * 32 + 8 * g + 4 * lh;
+        if (col >= p.n) continue;
+        float4 v = make_float4(acc[ni][mi][4 * g] * p.scale, acc[ni][mi][4 * g + 1] * p.scale,
+                               acc[ni][mi][4 * g + 2] * p.scale, acc[ni][mi][4 * g + 3] * p.scale);
+        if (p.bias) {
+          const float4 b = *(const float4*)(p.bias + col);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (p.act == GIMS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.residual) {
+          const float4 r = *(const float4*)(p.residual + (int64_t)row * p.ldc + col);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (p.out_f32) *(float4*)(p.out_f32 + (int64_t)row * p.ldc + col) = v;
+        if (p.out_bf16) *(uint2*)(p.out_bf16 + (int64_t)row * p.ldc_bf16 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+        if (p.out_hi) {
+          const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
+          const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+          const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+          *(uint2*)(p.out_hi + (int64_t)row * p.ld_split + col) = make_uint2(h01, h23);
+          *(uint2*)(p.out_lo + (int64_t)row * p.ld_split + col) = make_uint2(l01, l23);
+        }
+      }
+  }
+}
+
 __global__ void put_linear_args_kernel(gims_linear_args a, gims_linear_args* __restrict__ dst) { *dst = a; }
 
 // ------------------------------------------------------------------------------------------ split kernel
@@ -279,7 +405,17 @@ static int linear_validate(const gims_linear_args* a) {
   GIMS_CHECK_ARG(a->a0 && a->w, "gims_linear: null operand");
   GIMS_CHECK_ARG(a->k0 > 0 && a->k0 <= a->k, "gims_linear: k0=%d out of range", a->k0);
   GIMS_CHECK_ARG(a->k0 == a->k || a->a1 != nullptr, "gims_linear: second A segment missing");
-  GIMS_CHECK_ARG(a->out_f32 || a->out_bf16, "gims_linear: no output");
+  GIMS_CHECK_ARG(a->out_f32 || a->out_bf16 || a->out_hi, "gims_linear: no output");
+  GIMS_CHECK_ARG((a->out_hi == nullptr) == (a->out_lo == nullptr), "gims_linear: out_hi and out_lo come together");
+  if (a->a0_lo) {   // pre-split activations: bf16 hi/lo planes, LDS-DMA kernel
+    GIMS_CHECK_ARG(a->precision == GIMS_PREC_BF16X3 && a->w_lo, "gims_linear: pre-split A needs GIMS_PREC_BF16X3 and w_lo");
+    GIMS_CHECK_ARG(a->k0 == a->k || a->a1_lo, "gims_linear: second A segment needs its lo plane");
+    GIMS_CHECK_ARG((a->k % P_BK) == 0 && (a->k0 % P_BK) == 0, "gims_linear(pre-split): K=%d k0=%d must be multiples of %d", a->k, a->k0, P_BK);
+    GIMS_CHECK_ARG((a->lda0 % 8) == 0 && (a->lda1 % 8) == 0 && (a->ldw % 8) == 0, "gims_linear(pre-split): lda / ldw must be multiples of 8");
+    GIMS_CHECK_ARG((a->n % 4) == 0 && (a->ldc % 4) == 0 && (a->ldc_bf16 % 4) == 0 && (a->ld_split % 4) == 0,
+                   "gims_linear(pre-split): n and output pitches must be multiples of 4");
+    return GIMS_OK;
+  }
   GIMS_CHECK_ARG(!a->residual || a->out_f32, "gims_linear: residual needs an f32 output (shared ldc)");
   GIMS_CHECK_ARG((a->lda0 % 4) == 0 && (a->lda1 % 4) == 0, "gims_linear: lda must be a multiple of 4");
   if (a->precision == GIMS_PREC_F32) {
@@ -312,7 +448,9 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
   if (rc != GIMS_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(a->n, BN), cdiv(a->m, BM));
-  if (a->precision == GIMS_PREC_F32) {
+  if (a->a0_lo) {
+    hipLaunchKernelGGL(linear_x3p_kernel, grid, dim3(256), 0, s, *a);
+  } else if (a->precision == GIMS_PREC_F32) {
     hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, s, *a);
   } else {
     if ((rc = x3_attr()) != GIMS_OK) return rc;

@@ -203,6 +203,11 @@ class GMatcher(nn.Module):
     def _lin(e, a0, **kw):
         return hip.linear(a0, e["w"], w_lo=e["w_lo"], bias=e["b"], precision=e["prec"], **kw)
 
+    @staticmethod
+    def _planes(rows, cols, dev):
+        t = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=dev)
+        return t[0], t[1]
+
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
     def enable_timing(self, on: bool = True):
         """Record a (start, end) HIP-event pair around every stage on the stream the kernels are launched on;
@@ -323,13 +328,16 @@ class GMatcher(nn.Module):
                 h = self._lin(e, h, a1=agg, act=hip.ACT_RELU if i < 2 else hip.ACT_NONE)
             sage = h
         # ---- keypoint encoder (gmatcher.py:26-33, 87-97) ; desc = sage + kenc (gmatcher.py:270-271)
+        x3 = P["x3"]
         with St("kenc"):
             x = torch.empty((n_tot, P["kenc_w1"].shape[0]), dtype=torch.float32, device=dev)
             hip.kenc_first(kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], x)
+            dpl = self._planes(n_tot, D, dev) if x3 else None      # bf16 hi/lo planes of the residual stream
             for i, e in enumerate(P["kenc"]):
                 last = i == len(P["kenc"]) - 1
                 x = self._lin(e, x, act=hip.ACT_NONE if last else hip.ACT_RELU, residual=sage if last else None,
-                              out=torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev))
+                              out=torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev),
+                              out_split=dpl if (last and x3) else None)
             desc = x
         # ---- attentional GNN (gmatcher.py:99-143): per layer QKV -> flash attention -> merge -> MLP -> residual
         pairs = [(images[2 * p]["rows"], images[2 * p + 1]["rows"]) for p in range(len(images) // 2)]
@@ -338,21 +346,35 @@ class GMatcher(nn.Module):
                                 dtype=torch.int32, device=dev)
         max_nq = max(g["n_kept"] for g in images)
         qkv = torch.empty((n_tot, 3 * D), dtype=torch.bfloat16, device=dev)
-        msg = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
-        mrg = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
-        hid = torch.empty((n_tot, 2 * D), dtype=torch.float32, device=dev)
-        for L in P["layers"]:
-            with St("qkv"):
-                self._lin(L["qkv"], desc, out_bf16=qkv)
-            with St("attn_cross" if L["cross"] else "attn_self"):
-                hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D)
-            with St("mlp"):
-                self._lin(L["merge"], msg, out=mrg)
-                self._lin(L["mlp0"], desc, a1=mrg, act=hip.ACT_RELU, out=hid)
-                self._lin(L["mlp1"], hid, residual=desc, out=desc)          # desc += delta  (gmatcher.py:142)
+        if x3:
+            # all GEMM operands travel as bf16 hi/lo planes written by the producing kernel's epilogue; only the
+            # residual stream `desc` also exists in f32
+            mpl, gpl, hpl = self._planes(n_tot, D, dev), self._planes(n_tot, D, dev), self._planes(n_tot, 2 * D, dev)
+            for L in P["layers"]:
+                with St("qkv"):
+                    self._lin(L["qkv"], dpl[0], a0_lo=dpl[1], out_bf16=qkv)
+                with St("attn_cross" if L["cross"] else "attn_self"):
+                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl)
+                with St("mlp"):
+                    self._lin(L["merge"], mpl[0], a0_lo=mpl[1], out_split=gpl)
+                    self._lin(L["mlp0"], dpl[0], a0_lo=dpl[1], a1=gpl[0], a1_lo=gpl[1], act=hip.ACT_RELU, out_split=hpl)
+                    self._lin(L["mlp1"], hpl[0], a0_lo=hpl[1], residual=desc, out=desc, out_split=dpl)   # desc += delta (gmatcher.py:142)
+        else:
+            msg = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
+            mrg = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
+            hid = torch.empty((n_tot, 2 * D), dtype=torch.float32, device=dev)
+            for L in P["layers"]:
+                with St("qkv"):
+                    self._lin(L["qkv"], desc, out_bf16=qkv)
+                with St("attn_cross" if L["cross"] else "attn_self"):
+                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D)
+                with St("mlp"):
+                    self._lin(L["merge"], msg, out=mrg)
+                    self._lin(L["mlp0"], desc, a1=mrg, act=hip.ACT_RELU, out=hid)
+                    self._lin(L["mlp1"], hid, residual=desc, out=desc)          # desc += delta  (gmatcher.py:142)
         # ---- final projection, score matrix, Sinkhorn, selection (gmatcher.py:273-294)
         with St("final_scores"):
-            mdesc = self._lin(P["final"], desc)
+            mdesc = self._lin(P["final"], dpl[0], a0_lo=dpl[1]) if x3 else self._lin(P["final"], desc)
             items, largs = [], []
             for (o0, n0), (o1, n1) in pairs:
                 ld = (n1 + 3) // 4 * 4

@@ -28,7 +28,8 @@ class LinearArgs(C.Structure):
                 ("residual", C.c_void_p), ("out_f32", C.c_void_p), ("ldc", C.c_int64),
                 ("out_bf16", C.c_void_p), ("ldc_bf16", C.c_int64), ("m", C.c_int32), ("n", C.c_int32),
                 ("k", C.c_int32), ("k0", C.c_int32), ("act", C.c_int32), ("precision", C.c_int32),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("a0_lo", C.c_void_p), ("a1_lo", C.c_void_p), ("out_hi", C.c_void_p),
+                ("out_lo", C.c_void_p), ("ld_split", C.c_int64)]
 
 
 class AgcImage(C.Structure):
@@ -58,7 +59,8 @@ _SIGNATURES = {
     "gims_linear_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
-                                 C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+                                 C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_void_p]),
     "gims_kenc_first": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_sage_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
@@ -125,15 +127,27 @@ def _dev(t: torch.Tensor, dtype=None):
 
 
 def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
-                precision=PREC_F32, scale=1.0, n=None):
+                precision=PREC_F32, scale=1.0, n=None, a0_lo=None, a1_lo=None, out_split=None):
+    """Build the C struct.  a0/a1: f32 [m,k*] -- or, with a0_lo/a1_lo, bf16 hi/lo planes (pre-split activations).
+    out_split = (hi, lo) bf16 planes."""
     m, k0 = a0.shape
     k = k0 + (a1.shape[1] if a1 is not None else 0)
     n = w.shape[0] if n is None else n
-    assert w.shape[1] == k and a0.stride(1) == 1 and w.stride(1) == 1
-    return LinearArgs(_p(_dev(a0, torch.float32)), a0.stride(0), _p(a1), a1.stride(0) if a1 is not None else 0,
+    assert w.shape[1] == k and a0.stride(1) == 1 and w.stride(1) == 1, (w.shape, k)
+    if a0_lo is not None:
+        assert a0.dtype == torch.bfloat16 and a0_lo.dtype == torch.bfloat16 and a0_lo.stride(0) == a0.stride(0)
+        assert a1 is None or (a1_lo is not None and a1_lo.stride(0) == a1.stride(0))
+    else:
+        _dev(a0, torch.float32)
+    if residual is not None:
+        assert out is not None and residual.stride(0) == out.stride(0)
+    hi, lo = out_split if out_split is not None else (None, None)
+    assert hi is None or hi.stride(0) == lo.stride(0)
+    return LinearArgs(_p(a0), a0.stride(0), _p(a1), a1.stride(0) if a1 is not None else 0,
                       _p(w), _p(w_lo), w.stride(0), _p(bias), _p(residual), _p(out),
                       out.stride(0) if out is not None else 0, _p(out_bf16),
-                      out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale))
+                      out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale),
+                      _p(a0_lo), _p(a1_lo), _p(hi), _p(lo), hi.stride(0) if hi is not None else 0)
 
 
 def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):
@@ -148,25 +162,15 @@ def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):
                                  precision, st), "gims_linear_batch")
 
 
-def linear(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
-           precision=PREC_F32, scale=1.0, n=None):
-    """C = act(scale * [a0 | a1] @ w[:n].T + bias) (+ residual).  a*: f32 [m, k*]; w: [n, K] f32 or bf16 planes."""
+def linear(a0, w, *, out=None, out_bf16=None, out_split=None, **kw):
+    """C = act(scale * [a0 | a1] @ w[:n].T + bias) (+ residual); see linear_args / include/gims_hip.h."""
     lib = load()
-    m, k0 = a0.shape
-    k = k0 + (a1.shape[1] if a1 is not None else 0)
-    n = w.shape[0] if n is None else n
-    assert w.shape[1] == k, (w.shape, k)
-    assert a0.stride(1) == 1 and w.stride(1) == 1
-    if out is None and out_bf16 is None:
-        out = torch.empty((m, n), dtype=torch.float32, device=a0.device)
-    args = LinearArgs(_p(_dev(a0, torch.float32)), a0.stride(0), _p(a1), a1.stride(0) if a1 is not None else 0,
-                      _p(w), _p(w_lo), w.stride(0), _p(bias), _p(residual), _p(out),
-                      out.stride(0) if out is not None else 0, _p(out_bf16),
-                      out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale))
-    if residual is not None:
-        assert out is not None and residual.stride(0) == out.stride(0)
+    if out is None and out_bf16 is None and out_split is None:
+        n = kw.get("n") or w.shape[0]
+        out = torch.empty((a0.shape[0], n), dtype=torch.float32, device=a0.device)
+    args = linear_args(a0, w, out=out, out_bf16=out_bf16, out_split=out_split, **kw)
     _check(lib.gims_linear(C.byref(args), _stream()), "gims_linear")
-    return out if out is not None else out_bf16
+    return out if out is not None else (out_bf16 if out_bf16 is not None else out_split)
 
 
 def split_bf16(x: torch.Tensor):
@@ -178,15 +182,17 @@ def split_bf16(x: torch.Tensor):
     return hi, lo
 
 
-def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: int, out: torch.Tensor,
-              q_col=0, k_col=256, v_col=512):
-    """qkv bf16 [rows, ld]; problems int32 [P,4] (q_off, n_q, kv_off, n_kv) on device; out f32 [rows, ld_out]."""
+def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: int, out=None,
+              q_col=0, k_col=256, v_col=512, out_split=None):
+    """qkv bf16 [rows, ld]; problems int32 [P,4] (q_off, n_q, kv_off, n_kv) on device; out f32 [rows, ld_out]
+    and/or out_split = (hi, lo) bf16 planes."""
     lib = load()
     assert qkv.dtype == torch.bfloat16 and problems.dtype == torch.int32 and problems.is_cuda
+    hi, lo = out_split if out_split is not None else (None, None)
     _check(lib.gims_attention(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0],
-                              max_n_q, n_heads, _p(_dev(out, torch.float32)), out.stride(0), _stream()),
-           "gims_attention")
-    return out
+                              max_n_q, n_heads, _p(out), out.stride(0) if out is not None else 0, _p(hi), _p(lo),
+                              hi.stride(0) if hi is not None else 0, _stream()), "gims_attention")
+    return out if out is not None else out_split
 
 
 def kenc_first(kpts, norm3, seg_of_row, w1, b1, out):

@@ -50,7 +50,7 @@ int gims_stream_sync(void* stream);
  * precision: GIMS_PREC_F32   -> exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 operands in a0/a1/w;
  *            GIMS_PREC_BF16X3-> split-bf16 MFMA (hi*hi + hi*lo + lo*hi); W comes pre-split in
  *                               w (hi plane) / w_lo (lo plane), A is split on the fly.
- * out_f32 / out_bf16 may each be NULL; `residual` (f32, same ld as out_f32) may alias out_f32.
+ * out_f32 / out_bf16 / (out_hi,out_lo) may each be NULL; `residual` (f32, same ld as out_f32) may alias out_f32.
  */
 #define GIMS_PREC_F32 0
 #define GIMS_PREC_BF16X3 1
@@ -69,6 +69,12 @@ typedef struct gims_linear_args {
   int32_t act;                         /* GIMS_ACT_* */
   int32_t precision;                   /* GIMS_PREC_* */
   float scale;                         /* applied to the accumulator before bias (1.0 = none) */
+  /* pre-split activations (hot path of the attentional GNN): when a0_lo != NULL, a0/a0_lo (and a1/a1_lo)
+   * are bf16 hi/lo PLANES [m][lda] written by the producing kernel (lda in bf16 elements), precision must
+   * be GIMS_PREC_BF16X3, and the LDS-DMA kernel is used.  Not available through gims_linear_batch. */
+  const uint16_t* a0_lo; const uint16_t* a1_lo;
+  /* optional split output: hi = bf16(v), lo = bf16(v - hi), both [m][ld_split] */
+  uint16_t* out_hi; uint16_t* out_lo; int64_t ld_split;
 } gims_linear_args;
 
 int gims_linear(const gims_linear_args* args, void* stream);
@@ -91,12 +97,15 @@ int gims_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, voi
  *      (view(B, dh, H, N), gmatcher.py:111) into the projection weights).
  * Each problem p attends queries [q_off, q_off+n_q) to keys/values [kv_off, kv_off+n_kv).
  * out: f32 [rows][ld_out], head-blocked columns h*64 + d.       dh = 64, heads = n_heads.
+ * out_hi/out_lo: the same result as split-bf16 planes (hi = bf16(o), lo = bf16(o - hi)) for the pre-split
+ * linear that consumes the message.
  */
 typedef struct gims_attn_problem { int32_t q_off, n_q, kv_off, n_kv; } gims_attn_problem;
 
 int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
                    const gims_attn_problem* problems /* device */, int32_t n_problems, int32_t max_n_q,
-                   int32_t n_heads, float* out, int64_t ld_out, void* stream);
+                   int32_t n_heads, float* out /* may be NULL */, int64_t ld_out,
+                   uint16_t* out_hi /* may be NULL */, uint16_t* out_lo, int64_t ld_split, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Keypoint encoder front end: normalize_keypoints (gmatcher.py:26-33, with the reference's NHWC-as-NCHW

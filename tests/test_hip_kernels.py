@@ -70,6 +70,35 @@ def test_linear(hip, prec, m, n, k, k0):
     assert errb.max() <= 0, f"bf16 out exceeds bf16 rounding + f32 error by {errb.max():.3e}"
 
 
+@pytest.mark.parametrize("m,n,k,k0", [(128, 128, 32, 32), (300, 768, 256, 256), (1000, 512, 512, 256), (77, 100, 128, 64),
+                                       (4096, 256, 512, 512), (513, 132, 64, 32)])
+def test_linear_presplit(hip, m, n, k, k0):
+    """LDS-DMA kernel on pre-split bf16 planes: same contract as gims_linear, all three output kinds at once."""
+    r = _rng(m * 3 + n)
+    a = r.normal(size=(m, k)).astype(np.float32)
+    a[3, 5] = 321.5
+    w = (r.normal(size=(n, k)) / np.sqrt(k)).astype(np.float32)
+    bias = r.normal(size=n).astype(np.float32)
+    res = r.normal(size=(m, n)).astype(np.float32)
+    ref = np.maximum(a.astype(np.float64) @ w.astype(np.float64).T * 0.5 + bias, 0) + res
+    scale_ref = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T * 0.5 + np.abs(bias) + np.abs(res)
+    ah, al = hip.split_bf16(_dev(a))
+    wh, wl = hip.split_bf16(_dev(w))
+    out = _dev(res)
+    ob = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    hi = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    lo = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    kw = dict(a1=ah[:, k0:], a1_lo=al[:, k0:]) if k0 < k else {}
+    hip.linear(ah[:, :k0], wh, a0_lo=al[:, :k0], w_lo=wl, bias=_dev(bias), residual=out, out=out, out_bf16=ob, out_split=(hi, lo),
+               act=hip.ACT_RELU, precision=hip.PREC_BF16X3, scale=0.5, **kw)
+    o = out.cpu().numpy()
+    err = np.abs(o - ref) / scale_ref
+    assert err.max() < 4e-5, f"max scaled err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    rec = hi.float().cpu().numpy().astype(np.float64) + lo.float().cpu().numpy()
+    assert (np.abs(rec - o) <= np.abs(o) * 2.0 ** -15 + 1e-30).all()
+    np.testing.assert_array_equal(ob.cpu().view(torch.int16).numpy(), torch.from_numpy(o).to(torch.bfloat16).view(torch.int16).numpy())
+
+
 def test_split_bf16(hip):
     x = _rng(1).normal(size=100003).astype(np.float32) * 37
     hi, lo = hip.split_bf16(_dev(x))
@@ -113,6 +142,13 @@ def test_attention(hip, sizes, sharp):
         assert np.isfinite(o[qo:qo + nq]).all()
         assert err < 1.5e-2 * max(1.0, np.abs(v).max() / 4), f"attention err {err:.3e} (nq={nq}, nk={nk})"
         assert np.isnan(o[ko:ko + nk]).all()      # rows that are not queries are untouched
+    # split-plane output carries the same values
+    hi = torch.zeros((rows, 256), dtype=torch.bfloat16, device="cuda")
+    lo = torch.zeros((rows, 256), dtype=torch.bfloat16, device="cuda")
+    hip.attention(qkv_b.cuda(), torch.tensor(probs, dtype=torch.int32, device="cuda"), max(s[0] for s in sizes), 4, None, out_split=(hi, lo))
+    rec = hi.float().cpu().numpy().astype(np.float64) + lo.float().cpu().numpy()
+    for qo, nq, ko, nk in probs:
+        assert (np.abs(rec[qo:qo + nq] - o[qo:qo + nq]) <= np.abs(o[qo:qo + nq]) * 2.0 ** -15 + 1e-30).all()
 
 
 def test_attention_online_rescale(hip):
