@@ -10,6 +10,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgims_hip.so")
 SOURCES = ["linear.hip", "attention.hip", "sinkhorn.hip", "misc.hip", "agc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+# per-file extras: keep MFMA accumulators in VGPRs (gfx950 has a unified VGPR/AGPR file) -- the softmax reads S
+# straight out of the MFMA result registers instead of through v_accvgpr_read copies
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale() -> bool:
@@ -30,7 +33,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -15,7 +15,10 @@
 //     read from LDS in the same order (two ds_read_b64 per fragment) -- no permlane / bpermute;
 //   * K tile in LDS row-major with XOR-swizzled 16-byte chunks (conflict-free ds_read_b128),
 //     V tile transposed on the way into LDS ([d][key], pitch 68 elements: conflict-free ds_read_b64);
-//   * global->register prefetch of the next K/V tile is issued before the MFMAs of the current one.
+//   * global->register prefetch of the next K/V tile is issued before the MFMAs of the current one and written
+//     to the OTHER LDS buffer after them: one barrier per key tile;
+//   * the running max is deferred (rescale threshold): the O^T accumulator is only rescaled when a row's max
+//     grows by more than 2^5 in probability units -- after the first tiles the accumulators stay in place.
 #include "common.h"
 
 namespace gims {
@@ -35,8 +38,8 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, float* __restrict__ out, int64_t ld_out,
     uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split) {
-  __shared__ __attribute__((aligned(16))) uint16_t Ks[KB * DH];
-  __shared__ __attribute__((aligned(16))) uint16_t Vt[DH * VT_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KB * DH];      // double-buffered: one barrier per key tile
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[2][DH * VT_LD];
 
   const gims_attn_problem pr = problems[blockIdx.z];
   const int q0 = blockIdx.x * QB;
@@ -61,12 +64,18 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
-  float m_run = -1e30f;                           // running max of raw scores (same for lane and lane^32)
+  // Deferred running max (rescale threshold): the accumulator is rescaled only when some row's tile max
+  // exceeds its reference max by more than 2^DEFER in probability units; until then P is bounded by 2^DEFER
+  // instead of 1, which bf16 (relative precision) and the f32 accumulators tolerate unchanged.
+  constexpr float DEFER = 5.0f;
+  const float defer_raw = DEFER / c;
+  float m_run = -1e30f;                           // reference max of raw scores (same for lane and lane^32)
   float l_run = 0.f;                              // this lane's share of the row sum
 
-  // staging: K tile 64 rows x 8 chunks = 512 chunks (2 per thread); V tile 32 key-pairs x 8 d-octets = 256
+  // staging: K tile 64 rows x 8 chunks = 512 chunks (2 per thread); V tile: key pair kp = t&31, d-octet t>>5
   uint4 rk[2], rv[2];
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
+  const int vkp = t & 31, voct = t >> 5;
   auto load_tile = [&](int kt) {
     const int kbase = kt * KB;
 #pragma unroll
@@ -75,54 +84,51 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
       int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
       rk[it] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * ch);
     }
-    {
-      const int kp = t >> 3, oct = t & 7;  // key pair (2kp, 2kp+1), d = 8*oct..+8
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        int kr = kbase + 2 * kp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-        rv[e] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * oct);
-      }
+    for (int e = 0; e < 2; ++e) {
+      int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      rv[e] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * voct);
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int f = t + 256 * it, row = f >> 3, ch = f & 7;
-      *(uint4*)(Ks + k_off(row, ch)) = rk[it];
+      *(uint4*)(Ks[buf] + k_off(row, ch)) = rk[it];
     }
-    {
-      const int kp = t >> 3, oct = t & 7;
-      const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
-      const uint32_t b[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
+    const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
+    const uint32_t b[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {  // d = 8*oct + 2j, 2j+1 ; pack (key 2kp, key 2kp+1) per d
-        const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
-        const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
-        *(uint32_t*)(Vt + (8 * oct + 2 * j) * VT_LD + 2 * kp) = lo;
-        *(uint32_t*)(Vt + (8 * oct + 2 * j + 1) * VT_LD + 2 * kp) = hi;
-      }
+    for (int j = 0; j < 4; ++j) {  // d = 8*voct + 2j, 2j+1 ; pack (key 2kp, key 2kp+1) per d: lanes -> consecutive dwords
+      const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
+      const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
+      *(uint32_t*)(Vt[buf] + (8 * voct + 2 * j) * VT_LD + 2 * vkp) = lo;
+      *(uint32_t*)(Vt[buf] + (8 * voct + 2 * j + 1) * VT_LD + 2 * vkp) = hi;
     }
   };
 
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
 
   for (int kt = 0; kt < n_tiles; ++kt) {
+    const int buf = kt & 1;
     if (kt + 1 < n_tiles) load_tile(kt + 1);
 
     // ---- S^T = K Q^T : two 32-key blocks x 32 queries, K = 64 (4 steps of 16)
     f32x16 sacc[2];
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *(const bf16x8*)(Ks + k_off(b * 32 + li, 2 * s + lh));
+        const bf16x8 kf = *(const bf16x8*)(Ks[buf] + k_off(b * 32 + li, 2 * s + lh));
         sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[b], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- mask keys past the end (last tile only), tile max
     const int kbase = kt * KB;
     float tmax = -1e30f;
@@ -140,10 +146,17 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    m_run = m_new;
-    const float mc = m_new * c;
+    if (__any(tmax > m_run + defer_raw)) {          // wave-uniform, rare after the first tiles
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    const float mc = m_run * c;
     // ---- P = exp2(S*c - m*c), packed to bf16 B-operand fragments in the lane's own key order
     float lsum = 0.f;
     bf16x8 pf[4];
@@ -165,29 +178,24 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
         pf[2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
       }
     }
-    l_run = l_run * alpha + lsum;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    l_run += lsum;
     // ---- O^T += V^T P^T : two 32-d blocks, 4 steps of 16 keys
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         // lane's k-slots of step s: keys 16s + {0-3, 8-11} + 4*lh
-        const uint16_t* vp = Vt + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
+        const uint16_t* vp = Vt[buf] + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
         const uint2 v0 = *(const uint2*)(vp);
         const uint2 v1 = *(const uint2*)(vp + 8);
         const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
         o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o[i], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
+    if (kt + 1 < n_tiles) store_tile(buf ^ 1);
     __syncthreads();
-    if (kt + 1 < n_tiles) {
-      store_tile();
-      __syncthreads();
-    }
   }
 
   // ---- normalise and store: lane holds query li, d = 32*i + 8*(r>>2) + 4*lh + (r&3)

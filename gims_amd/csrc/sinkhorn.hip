@@ -34,6 +34,35 @@ struct OtDev {
   float norm, log_mu_bin, log_nu_bin;  // norm = -log(n+m); log(m)+norm; log(n)+norm
 };
 
+// Reduce R (= 8, 4 or 2) per-lane values over the 64 lanes of a wave with a reduce-scatter butterfly:
+// log2(R) exchange steps halve the number of live values, the rest fold the single survivor -- R-1 + (6-log2 R)
+// cross-lane moves instead of 6*R.  On return lane l holds the total of row
+// ((l>>5)&1)*R/2 + ((l>>4)&1)*R/4 + ... ; lanes with the low (6 - log2 R) bits clear are the writers.
+template <int R>
+__device__ __forceinline__ float wave_reduce_rows(float (&v)[R], int lane, int& row_out) {
+  float cur[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) cur[i] = v[i];
+  int n = R, bit = 32, row = 0;
+#pragma unroll
+  for (; n > 1; n >>= 1, bit >>= 1) {
+    const bool up = lane & bit;
+    const int h = n >> 1;
+#pragma unroll
+    for (int i = 0; i < h; ++i) {
+      const float send = up ? cur[i] : cur[i + h];
+      const float mine = up ? cur[i + h] : cur[i];
+      cur[i] = mine + __shfl_xor(send, bit, 64);
+    }
+    row += up ? h : 0;
+  }
+  float x = cur[0];
+#pragma unroll
+  for (; bit > 0; bit >>= 1) x += __shfl_xor(x, bit, 64);
+  row_out = row;
+  return x;
+}
+
 struct OtBlob { char b[256]; };
 static_assert(sizeof(OtDev) <= sizeof(OtBlob), "OtDev must fit the by-value upload blob");
 // one descriptor per launch, passed by value: no host staging buffer, no memcpy, no stream synchronisation
@@ -57,10 +86,10 @@ __global__ void ot_init_kernel(const OtDev* __restrict__ probs, float alpha, int
 }
 
 // ---------------------------------------------------------------------------------------------- fused iteration
-template <int CPT>
+template <int CPT, int R>
 __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__ probs, float alpha) {
-  __shared__ float red[16][OT_R];
-  __shared__ float fac[OT_R];
+  __shared__ float red[16][R];
+  __shared__ float fac[R];
   const OtDev p = probs[blockIdx.y];
   if ((int)blockIdx.x >= p.G) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
@@ -117,48 +146,71 @@ __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__
     __syncthreads();
   }
 
-  // ---- slabs of OT_R rows
-  const int n_slabs = (p.n + OT_R - 1) / OT_R;
+  // ---- slabs of R rows.  The Z rows of the NEXT slab are requested before the current slab is reduced, so
+  // the HBM stream keeps running through the barrier-separated reduce / rescale phases (one workgroup per CU).
+  const int n_slabs = (p.n + R - 1) / R;
+  float4 zn[R][CPT];
+  float un[R];
+  // branch-free loads: rows are clamped, column quads past m are redirected to column 0 and masked by value
+  // (scores rows are padded to a multiple of 4 floats, so a quad that starts inside the row ends inside it)
+  int cl[CPT];
+  bool cm[CPT][4];
+#pragma unroll
+  for (int s = 0; s < CPT; ++s) {
+    const int c0 = 4 * (t + blockDim.x * s);
+    cl[s] = c0 < p.m ? c0 : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cm[s][k] = c0 + k < p.m;
+  }
+  const float* __restrict__ zbase = p.z;
+  const float* __restrict__ ubase = p.u;
+  auto load_slab = [&](int slab) {
+    const int r0 = slab * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = r0 + r < p.n ? r0 + r : p.n - 1;
+      un[r] = ubase[row];
+      const float* zr = zbase + (int64_t)row * p.ld;
+#pragma unroll
+      for (int s = 0; s < CPT; ++s) zn[r][s] = *(const float4*)(zr + cl[s]);
+    }
+  };
+  if ((int)blockIdx.x < n_slabs) load_slab(blockIdx.x);
   for (int slab = blockIdx.x; slab < n_slabs; slab += p.G) {
-    const int r0 = slab * OT_R;
-    float4 e[OT_R][CPT];
-    float rs[OT_R];
+    const int r0 = slab * R;
+    float4 e[R][CPT];
+    float rs[R], ucur[R];
 #pragma unroll
-    for (int r = 0; r < OT_R; ++r) {
-      const int row = r0 + r;
+    for (int r = 0; r < R; ++r) {
+      ucur[r] = un[r];
+#pragma unroll
+      for (int s = 0; s < CPT; ++s) e[r][s] = zn[r][s];
+    }
+    if (slab + p.G < n_slabs) load_slab(slab + p.G);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool live = r0 + r < p.n;
+      const float ui = ucur[r];
       rs[r] = 0.f;
-      if (row < p.n) {
-        const float ui = p.u[row];
-        const float* zr = p.z + (int64_t)row * p.ld;
 #pragma unroll
-        for (int s = 0; s < CPT; ++s) {
-          const int c0 = 4 * (t + blockDim.x * s);
-          float4 z = make_float4(-1e30f, -1e30f, -1e30f, -1e30f);
-          if (c0 + 3 < p.m) {
-            z = *(const float4*)(zr + c0);
-          } else if (c0 < p.m) {
-            z.x = zr[c0];
-            if (c0 + 1 < p.m) z.y = zr[c0 + 1];
-            if (c0 + 2 < p.m) z.z = zr[c0 + 2];
-          }
-          e[r][s].x = __expf(z.x + ui + vq[s].x);
-          e[r][s].y = __expf(z.y + ui + vq[s].y);
-          e[r][s].z = __expf(z.z + ui + vq[s].z);
-          e[r][s].w = __expf(z.w + ui + vq[s].w);
-          rs[r] += (e[r][s].x + e[r][s].y) + (e[r][s].z + e[r][s].w);
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < CPT; ++s) e[r][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < CPT; ++s) {
+        const float4 z = e[r][s];
+        float4 x;
+        x.x = (live && cm[s][0]) ? __expf(z.x + ui + vq[s].x) : 0.f;
+        x.y = (live && cm[s][1]) ? __expf(z.y + ui + vq[s].y) : 0.f;
+        x.z = (live && cm[s][2]) ? __expf(z.z + ui + vq[s].z) : 0.f;
+        x.w = (live && cm[s][3]) ? __expf(z.w + ui + vq[s].w) : 0.f;
+        e[r][s] = x;
+        rs[r] += (x.x + x.y) + (x.z + x.w);
       }
     }
-#pragma unroll
-    for (int r = 0; r < OT_R; ++r) {
-      const float w = wave_sum(rs[r]);
-      if (lane == 0) red[wave][r] = w;
+    {
+      int rrow;
+      const float w = wave_reduce_rows<R>(rs, lane, rrow);
+      if ((lane & (64 / R - 1)) == 0) red[wave][rrow] = w;
     }
     __syncthreads();
-    if (t < OT_R) {
+    if (t < R) {
       const int row = r0 + t;
       float f = 0.f;
       if (row < p.n) {
@@ -179,7 +231,7 @@ __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < OT_R; ++r) {
+    for (int r = 0; r < R; ++r) {
       const float f = fac[r];
 #pragma unroll
       for (int s = 0; s < CPT; ++s) {
@@ -188,7 +240,7 @@ __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__
     }
     if (t == 0) {
 #pragma unroll
-      for (int r = 0; r < OT_R; ++r) accbin += red[0][r];
+      for (int r = 0; r < R; ++r) accbin += red[0][r];
     }
     __syncthreads();
   }
@@ -275,13 +327,8 @@ __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict
 #pragma unroll
         for (int s = 0; s < CPT; ++s) {
           const int c0 = 4 * (t + blockDim.x * s);
-          float zz[4] = {0.f, 0.f, 0.f, 0.f};
-          if (c0 + 3 < p.m) {
-            const float4 z = *(const float4*)(zr + c0);
-            zz[0] = z.x; zz[1] = z.y; zz[2] = z.z; zz[3] = z.w;
-          } else {
-            for (int k = 0; k < 4; ++k) if (c0 + k < p.m) zz[k] = zr[c0 + k];
-          }
+          const float4 z = *(const float4*)(zr + (c0 < p.m ? c0 : 0));     // rows are padded to 4 floats: in bounds
+          const float zz[4] = {z.x, z.y, z.z, z.w};
           const float vv[4] = {vq[s].x, vq[s].y, vq[s].z, vq[s].w};
           float* cbp = (float*)&cb[s];
           int* cip = (int*)&cbi[s];
@@ -393,10 +440,14 @@ static void ot_launch_shape(const gims_ot_problem* pr, int np, int& threads, int
   if (threads < 64) threads = 64;
   cpt = (quads + threads - 1) / threads;
 }
-static int ot_G(int n, int np) {
-  int cap = 512 / (np > 0 ? np : 1);
-  if (cap < 8) cap = 8;
-  int g = (n + OT_R - 1) / OT_R;
+// workgroups per problem.  Large workgroups (one resident per CU) run persistent-style: ~256 in total, each
+// walking several slabs with the prefetch above; small workgroups want ~4 per CU for latency hiding.
+static int ot_G(int n, int np, int threads, int cpt) {
+  const int rows = cpt >= 4 ? 2 : (cpt == 2 ? 4 : OT_R);   // rows per slab of ot_iter_kernel<CPT, R>
+  const int total = threads >= 1024 ? 256 : (threads >= 512 ? 512 : 1024);
+  int cap = total / (np > 0 ? np : 1);
+  if (cap < 4) cap = 4;
+  int g = (n + rows - 1) / rows;
   return g < cap ? g : cap;
 }
 static size_t ot_problem_bytes(const gims_ot_problem& q, int G) {
@@ -413,8 +464,10 @@ static size_t ot_problem_bytes(const gims_ot_problem& q, int G) {
 extern "C" size_t gims_sinkhorn_workspace_bytes(const gims_ot_problem* pr, int32_t np) {
   using namespace gims;
   if (!pr || np <= 0) return 0;
+  int threads, cpt, maxn, maxm;
+  ot_launch_shape(pr, np, threads, cpt, maxn, maxm);
   size_t b = al256(sizeof(OtDev) * (size_t)np);
-  for (int i = 0; i < np; ++i) b += ot_problem_bytes(pr[i], ot_G(pr[i].n, np));
+  for (int i = 0; i < np; ++i) b += ot_problem_bytes(pr[i], ot_G(pr[i].n, np, threads, cpt));
   return b;
 }
 
@@ -441,7 +494,7 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     OtDev d;
     d.z = q.scores; d.ld = q.ld; d.n = q.n; d.m = q.m;
     d.u = q.uv; d.v = q.uv + q.n + 1; d.status = q.uv + q.n + 1 + q.m + 1;
-    d.G = ot_G(q.n, np);
+    d.G = ot_G(q.n, np, threads, cpt);
     maxG = d.G > maxG ? d.G : maxG;
     d.partial = (float*)(base + off); off += al256((size_t)d.G * (q.m + 1) * 4);
     d.cbest_val = (float*)(base + off); off += al256((size_t)d.G * q.m * 4);
@@ -463,9 +516,9 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, iters == 0 ? 1 : 0);
   dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
   for (int it = 0; it < iters; ++it) {
-    if (cpt == 1) hipLaunchKernelGGL(ot_iter_kernel<1>, gi, dim3(threads), 0, s, dp, alpha);
-    else if (cpt == 2) hipLaunchKernelGGL(ot_iter_kernel<2>, gi, dim3(threads), 0, s, dp, alpha);
-    else hipLaunchKernelGGL(ot_iter_kernel<4>, gi, dim3(threads), 0, s, dp, alpha);
+    if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha);
+    else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha);
+    else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha);
     hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp);
   }
   if (cpt == 1) hipLaunchKernelGGL(ot_select_kernel<1>, gi, dim3(threads), 0, s, dp);

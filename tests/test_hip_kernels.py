@@ -168,7 +168,8 @@ def test_attention_online_rescale(hip):
 
 # --------------------------------------------------------------------------------------------- sinkhorn + selection
 @pytest.mark.parametrize("n,m,iters,scale", [(37, 53, 20, 3.0), (2, 2, 100, 1.0), (200, 180, 100, 5.0), (1025, 1000, 100, 8.0),
-                                              (64, 64, 0, 3.0), (5, 300, 1, 2.0), (300, 1111, 50, 30.0)])
+                                              (64, 64, 0, 3.0), (5, 300, 1, 2.0), (300, 1111, 50, 30.0), (130, 4500, 10, 4.0),
+                                              (40, 9000, 5, 4.0)])
 def test_sinkhorn_match(hip, n, m, iters, scale):
     r = _rng(n * 1000 + m)
     z = (r.normal(size=(n, m)) * scale).astype(np.float32)
