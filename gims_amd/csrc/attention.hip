@@ -36,15 +36,20 @@ __device__ __forceinline__ int k_off(int row, int chunk) {  // K tile: [64 keys]
 
 __global__ __launch_bounds__(256) void attention_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
-    const gims_attn_problem* __restrict__ problems, float* __restrict__ out, int64_t ld_out,
-    uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split) {
+    const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KB * DH];      // double-buffered: one barrier per key tile
   __shared__ __attribute__((aligned(16))) uint16_t Vt[2][DH * VT_LD];
 
-  const gims_attn_problem pr = problems[blockIdx.z];
-  const int q0 = blockIdx.x * QB;
+  // XCD-aware order (workgroup b -> XCD b % 8, private L2 per XCD): all query tiles of one (problem, head) get
+  // consecutive slots on ONE XCD, so its K/V panel is fetched from HBM once, not once per query tile.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int group = (slot / n_qt) * 8 + xcd;
+  if (group >= n_groups) return;
+  const gims_attn_problem pr = problems[group / n_heads];
+  const int q0 = (slot % n_qt) * QB;
   if (q0 >= pr.n_q) return;
-  const int head = blockIdx.y;
+  const int head = group % n_heads;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -236,9 +241,10 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
   GIMS_CHECK_ARG((ld % 8) == 0 && (q_col % 8) == 0 && (k_col % 8) == 0 && (v_col % 8) == 0,
                  "gims_attention: qkv ld / column offsets must be multiples of 8 (16-byte loads)");
   GIMS_CHECK_ARG((ld_out % 4) == 0, "gims_attention: ld_out must be a multiple of 4");
-  dim3 grid(cdiv(max_n_q, QB), n_heads, n_problems);
+  const int n_qt = cdiv(max_n_q, QB), n_groups = n_heads * n_problems;
+  dim3 grid(8 * cdiv(n_groups, 8) * n_qt);
   hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col,
-                     problems, out, ld_out, out_hi, out_lo, ld_split);
+                     problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

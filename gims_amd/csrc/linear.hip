@@ -13,6 +13,8 @@
 // 128-byte line per row.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace gims {
 
 constexpr int BM = 128, BN = 128;
@@ -263,32 +265,52 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_batch_kernel(const gims_
 // ------------------------------------------------------------------------------------------ split-bf16 MFMA, pre-split A
 // The hot linears of the attentional GNN.  Activations arrive ALREADY split into bf16 hi/lo planes (written by
 // the producing kernel's epilogue), so all four operand planes (A hi/lo, W hi/lo) go HBM/L2 -> LDS by LDS-DMA
-// (global_load_lds_dwordx4, no VGPR staging, no ds_write), double-buffered with ONE barrier per K-step:
-//   stage = 4 planes x [128 rows][32 k] bf16 (64-byte rows); each wave streams one plane per K-step as
-//   8 x 1 KiB pieces.  The LDS image is lane-linear per piece, so the bank-conflict swizzle
-//   (16-byte chunk ^= (row>>2)&3) is applied to the per-lane SOURCE address and again on the ds_read_b128.
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write) through an S-stage ring with COUNTED waits:
+//   * stage = 4 planes x [128 rows][BK k] bf16; each wave streams one plane per stage as BK/4 pieces of 1 KiB;
+//   * S-1 stages are kept in flight: before computing stage t a wave waits only until its own pieces of stage t have
+//     landed (s_waitcnt vmcnt(newer pieces)), crosses ONE raw s_barrier (every wave's pieces landed, and everyone is
+//     done reading the slot about to be refilled), issues stage t+S-1 and computes -- the LDS-DMA queue never drains;
+//   * the LDS image is lane-linear per piece, so the bank-conflict swizzle is applied to the per-lane SOURCE address
+//     and again on the ds_read_b128 (same involution on both sides).
 // The MFMA is issued with swapped operands (D^T = W A^T): a lane then owns 4 CONSECUTIVE output channels of
 // one row per accumulator group, so every epilogue store is 8-16 bytes wide (f32x4 / bf16x4) and bias /
 // residual are vector loads.
-constexpr int P_BK = 32;
-constexpr int P_PLANE = BM * P_BK;     // bf16 elements per plane per stage (8 KiB)
-constexpr int P_STAGE = 4 * P_PLANE;   // 32 KiB
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ int p_off(int row, int chunk) { return row * P_BK + ((chunk ^ ((row >> 2) & 3)) << 3); }
+template <int BK, int S>
+struct X3P {
+  static constexpr int PLANE = BM * BK;            // bf16 elements per plane per stage
+  static constexpr int STAGE = 4 * PLANE;
+  static constexpr int CPR = BK / 8;               // 16-byte chunks per row
+  static constexpr int PIECES = BK / 4;            // 1 KiB pieces per plane per stage (= per wave per stage)
+  static constexpr int ROWS_PER_PIECE = 64 / CPR;
+  static constexpr int LDS_BYTES = S * STAGE * 2;
+  __device__ static __forceinline__ int swz(int row) { return (row / (16 / CPR)) & (CPR - 1); }
+  __device__ static __forceinline__ int off(int row, int chunk) { return row * BK + ((chunk ^ swz(row)) << 3); }
+};
 
-__global__ __launch_bounds__(256, 2) void linear_x3p_kernel(gims_linear_args p) {
-  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * P_STAGE];
+template <int BK, int S>
+__global__ __launch_bounds__(256, (S * BK <= 64) ? 2 : 1) void linear_x3p_kernel(gims_linear_args p) {
+  using T = X3P<BK, S>;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed; used for speed only), and each XCD has
+  // its own L2.  All column tiles of one 128-row panel of A are therefore given consecutive slots on ONE XCD, so the
+  // panel is fetched from HBM once instead of once per column tile.
+  const int nt_n = (p.n + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int m0 = ((slot / nt_n) * 8 + xcd) * BM, n0 = (slot % nt_n) * BN;
+  if (m0 >= p.m) return;
   const int li = lane & 31, lh = lane >> 5;
-  const int nk = p.k / P_BK;
+  const int nk = p.k / BK;
 
-  // this wave's DMA duty: plane `wave` (0: A hi, 1: A lo, 2: W hi, 3: W lo), 8 pieces of 16 rows
-  const int drow = lane >> 2, dpos = lane & 3;
-  auto issue = [&](int kt, int buf) {
-    const int k = kt * P_BK;
+  // this wave's DMA duty: plane `wave` (0: A hi, 1: A lo, 2: W hi, 3: W lo)
+  const int drow = lane / T::CPR, dpos = lane % T::CPR;
+  auto issue = [&](int kt) {
+    const int k = kt * BK;
     const uint16_t* base;
     int64_t ld;
     int kk, rmax, r0;
@@ -299,12 +321,12 @@ __global__ __launch_bounds__(256, 2) void linear_x3p_kernel(gims_linear_args p) 
     } else {
       base = (const uint16_t*)(wave == 2 ? p.w : p.w_lo); ld = p.ldw; kk = k; rmax = p.n - 1; r0 = n0;
     }
-    uint16_t* dst = smem + buf * P_STAGE + wave * P_PLANE;
+    uint16_t* dst = smem + (kt % S) * T::STAGE + wave * T::PLANE;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = 16 * i + drow;
+    for (int i = 0; i < T::PIECES; ++i) {
+      const int row = T::ROWS_PER_PIECE * i + drow;
       int gr = r0 + row; gr = gr < rmax ? gr : rmax;
-      const uint16_t* g = base + (int64_t)gr * ld + kk + 8 * (dpos ^ ((row >> 2) & 3));
+      const uint16_t* g = base + (int64_t)gr * ld + kk + 8 * (dpos ^ T::swz(row));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(dst + i * 512), 16, 0, 0);
     }
@@ -318,21 +340,29 @@ __global__ __launch_bounds__(256, 2) void linear_x3p_kernel(gims_linear_args p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  issue(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    const uint16_t* st = smem + (kt & 1) * P_STAGE;
+  constexpr int D = S - 1;   // stages in flight
 #pragma unroll
-    for (int s = 0; s < P_BK / 16; ++s) {
+  for (int s0 = 0; s0 < D; ++s0)
+    if (s0 < nk) issue(s0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // own pieces of stage kt landed: at most `newer` stages (P pieces each) may still be in flight
+    const int newer = (nk - 1 - kt) < (D - 1) ? (nk - 1 - kt) : (D - 1);
+    if (newer >= 2) wait_vm<2 * T::PIECES>();
+    else if (newer == 1) wait_vm<T::PIECES>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + D < nk) issue(kt + D);
+    const uint16_t* st = smem + (kt % S) * T::STAGE;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
       bf16x8 ah[2], al[2], wh[2], wl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ar = wm * 64 + i * 32 + li, wr = wn * 64 + i * 32 + li;
-        ah[i] = *(const bf16x8*)(st + p_off(ar, 2 * s + lh));
-        al[i] = *(const bf16x8*)(st + P_PLANE + p_off(ar, 2 * s + lh));
-        wh[i] = *(const bf16x8*)(st + 2 * P_PLANE + p_off(wr, 2 * s + lh));
-        wl[i] = *(const bf16x8*)(st + 3 * P_PLANE + p_off(wr, 2 * s + lh));
+        ah[i] = *(const bf16x8*)(st + T::off(ar, 2 * s + lh));
+        al[i] = *(const bf16x8*)(st + T::PLANE + T::off(ar, 2 * s + lh));
+        wh[i] = *(const bf16x8*)(st + 2 * T::PLANE + T::off(wr, 2 * s + lh));
+        wl[i] = *(const bf16x8*)(st + 3 * T::PLANE + T::off(wr, 2 * s + lh));
       }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
@@ -343,7 +373,6 @@ __global__ __launch_bounds__(256, 2) void linear_x3p_kernel(gims_linear_args p) 
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
         }
     }
-    __syncthreads();   // next stage has landed (the fence drains the LDS-DMA) and everyone is done with this one
   }
 
   // ---- epilogue: lane owns row m, 4 consecutive channels per accumulator group
@@ -410,7 +439,7 @@ static int linear_validate(const gims_linear_args* a) {
   if (a->a0_lo) {   // pre-split activations: bf16 hi/lo planes, LDS-DMA kernel
     GIMS_CHECK_ARG(a->precision == GIMS_PREC_BF16X3 && a->w_lo, "gims_linear: pre-split A needs GIMS_PREC_BF16X3 and w_lo");
     GIMS_CHECK_ARG(a->k0 == a->k || a->a1_lo, "gims_linear: second A segment needs its lo plane");
-    GIMS_CHECK_ARG((a->k % P_BK) == 0 && (a->k0 % P_BK) == 0, "gims_linear(pre-split): K=%d k0=%d must be multiples of %d", a->k, a->k0, P_BK);
+    GIMS_CHECK_ARG((a->k % 32) == 0 && (a->k0 % 32) == 0, "gims_linear(pre-split): K=%d k0=%d must be multiples of 32", a->k, a->k0);
     GIMS_CHECK_ARG((a->lda0 % 8) == 0 && (a->lda1 % 8) == 0 && (a->ldw % 8) == 0, "gims_linear(pre-split): lda / ldw must be multiples of 8");
     GIMS_CHECK_ARG((a->n % 4) == 0 && (a->ldc % 4) == 0 && (a->ldc_bf16 % 4) == 0 && (a->ld_split % 4) == 0,
                    "gims_linear(pre-split): n and output pitches must be multiples of 4");
@@ -449,7 +478,30 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(a->n, BN), cdiv(a->m, BM));
   if (a->a0_lo) {
-    hipLaunchKernelGGL(linear_x3p_kernel, grid, dim3(256), 0, s, *a);
+    const int nt_m = cdiv(a->m, BM), nt_n = cdiv(a->n, BN);
+    const dim3 g(8 * cdiv(nt_m, 8) * nt_n);
+    // ring geometry.  Default BK 32 x 2 stages (64 KiB, 2 workgroups per CU) measured fastest on MI355X for these
+    // shapes (M >> N, K <= 512); the deeper rings (GIMS_X3P_VARIANT=0: BK 16 x 4, 1: BK 32 x 3, 2: BK 32 x 4 with one
+    // workgroup per CU) are kept for experiments -- the kernel is bound by operand bytes per MFMA, not by latency.
+    static int variant = -1;
+    if (variant < 0) {
+      const char* e = getenv("GIMS_X3P_VARIANT");
+      variant = e ? atoi(e) : 3;
+      const void* f3 = (const void*)linear_x3p_kernel<32, 2>;
+      GIMS_HIP(hipFuncSetAttribute(f3, hipFuncAttributeMaxDynamicSharedMemorySize, X3P<32, 2>::LDS_BYTES));
+      constexpr int l0 = X3P<16, 4>::LDS_BYTES, l1 = X3P<32, 3>::LDS_BYTES, l2 = X3P<32, 4>::LDS_BYTES;
+      const void* f0 = (const void*)linear_x3p_kernel<16, 4>;
+      const void* f1 = (const void*)linear_x3p_kernel<32, 3>;
+      const void* f2 = (const void*)linear_x3p_kernel<32, 4>;
+      GIMS_HIP(hipFuncSetAttribute(f0, hipFuncAttributeMaxDynamicSharedMemorySize, l0));
+      GIMS_HIP(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, l1));
+      GIMS_HIP(hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
+    }
+    constexpr size_t lds0 = X3P<16, 4>::LDS_BYTES, lds1 = X3P<32, 3>::LDS_BYTES, lds2 = X3P<32, 4>::LDS_BYTES, lds3 = X3P<32, 2>::LDS_BYTES;
+    if (variant == 3) hipLaunchKernelGGL((linear_x3p_kernel<32, 2>), g, dim3(256), lds3, s, *a);
+    else if (variant == 1) hipLaunchKernelGGL((linear_x3p_kernel<32, 3>), g, dim3(256), lds1, s, *a);
+    else if (variant == 2) hipLaunchKernelGGL((linear_x3p_kernel<32, 4>), g, dim3(256), lds2, s, *a);
+    else hipLaunchKernelGGL((linear_x3p_kernel<16, 4>), g, dim3(256), lds0, s, *a);
   } else if (a->precision == GIMS_PREC_F32) {
     hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, s, *a);
   } else {
