@@ -94,7 +94,50 @@ __global__ __launch_bounds__(256) void pack_graphs_kernel(const gims_pack_image*
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) indptr_out[n_rows_total] = n_edges_total;
 }
 
+// channel-major (D,N) descriptors of a whole batch -> one point-major [rows][D] buffer (64x64 LDS tile transpose),
+// plus the keypoint / score rows; blockIdx.z = image
+__global__ __launch_bounds__(256) void ingest_kernel(const gims_ingest_image* __restrict__ imgs, int d,
+                                                     float* __restrict__ desc_out, int64_t ldo,
+                                                     float* __restrict__ kpts_out, float* __restrict__ score_out) {
+  __shared__ float tile[64][65];
+  const gims_ingest_image im = imgs[blockIdx.z];
+  const int n0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+  if (n0 >= im.n) return;
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = 4 * i + r4;                       // channel within the tile
+    const int n = n0 + c;
+    tile[r][c] = (d0 + r < d && n < im.n) ? im.desc[(int64_t)(d0 + r) * im.ldd + n] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = 4 * i + r4;                       // keypoint within the tile
+    const int n = n0 + r;
+    if (n < im.n && d0 + c < d) desc_out[(int64_t)(im.row_off + n) * ldo + d0 + c] = tile[c][r];
+  }
+  if (blockIdx.y == 0 && threadIdx.x < 64) {
+    const int n = n0 + threadIdx.x;
+    if (n < im.n) {
+      kpts_out[2 * (im.row_off + n)] = im.kpts[2 * n];
+      kpts_out[2 * (im.row_off + n) + 1] = im.kpts[2 * n + 1];
+      if (score_out) score_out[im.row_off + n] = im.score ? im.score[n] : 0.f;
+    }
+  }
+}
+
 }  // namespace gims
+
+extern "C" int gims_ingest_images(const gims_ingest_image* dev_images, int32_t n_images, int32_t max_n, int32_t d,
+                                  float* desc_out, int64_t ldo, float* kpts_out, float* score_out, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(dev_images && n_images > 0 && max_n > 0 && d > 0 && desc_out && kpts_out, "gims_ingest_images: bad arguments");
+  hipLaunchKernelGGL(ingest_kernel, dim3(cdiv(max_n, 64), cdiv(d, 64), n_images), dim3(256), 0, (hipStream_t)stream,
+                     dev_images, d, desc_out, ldo, kpts_out, score_out);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
 
 extern "C" int gims_pack_graphs(const gims_pack_image* dev_images, int32_t n_images, int32_t max_kept, int32_t max_edges,
                                 int32_t d, float* feat, int64_t ldf, float* kpts_out, float* score_out, int32_t* seg,

@@ -47,6 +47,12 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool):
         mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
+class PairResults(list):
+    """List of per-pair result dicts; ``.flat`` additionally exposes the batch-concatenated match tensors (what the
+    per-pair entries are views of) so statistics can be reduced without touching each pair separately."""
+    flat = None
+
+
 class GraphHandle:
     """What the reference hands back as ``data['graph0/1'][b]`` (a DGLGraph there): CSR of the adaptive
     graph over the kept keypoints (both edge directions), plus the node data the reference stores on it."""
@@ -217,12 +223,13 @@ class GMatcher(nn.Module):
     def stage_times_ms(self):
         out = {}
         for name, evs in (self._timers or {}).items():
-            out[name] = [a.elapsed_time(b) for a, b, _ in evs]
+            if not name.startswith("_"):
+                out[name] = [a.elapsed_time(b) for a, b, _ in evs]
         return out
 
     def stage_host_ms(self):
         """Host wall time spent inside each stage (enqueue cost), same keys as stage_times_ms()."""
-        return {name: [h for _, _, h in evs] for name, evs in (self._timers or {}).items()}
+        return {name: [h for _, _, h in evs] for name, evs in (self._timers or {}).items() if not name.startswith("_")}
 
     class _Stage:
         def __init__(self, owner, name):
@@ -264,18 +271,21 @@ class GMatcher(nn.Module):
 
         # ---- adaptive graph construction: every stage ONE launch for all images; ONE host sync for the counts
         with St("agc"):
-            for g in images:
-                n = g["kp"].shape[0]
-                if n < 2:
-                    raise ValueError("need at least one array to concatenate")           # what the reference raises (agc.py:701)
-                g["kept"] = torch.empty(n, dtype=torch.int32, device=dev)
-                g["indptr"] = torch.empty(n + 1, dtype=torch.int32, device=dev)
-                g["indices"] = torch.empty(n * 64, dtype=torch.int32, device=dev)
+            ns = [g["kp"].shape[0] for g in images]
+            if min(ns) < 2:
+                raise ValueError("need at least one array to concatenate")               # what the reference raises (agc.py:701)
+            pool = torch.empty(sum(66 * n + 4 for n in ns), dtype=torch.int32, device=dev)   # kept | indptr | indices per image
+            o = 0
+            for g, n in zip(images, ns):
+                g["kept"], g["indptr"], g["indices"] = pool[o:o + n], pool[o + n:o + 2 * n + 1], pool[o + 2 * n + 4:o + 66 * n + 4]
+                o += 66 * n + 4
             info_all = torch.empty((len(images), 8), dtype=torch.int32, device=dev)
             agc_imgs = hip.make_agc_images([dict(kpts=g["kp"], desc=g["de"], kept=g["kept"], indptr=g["indptr"],
                                                  indices=g["indices"], info=info_all[i]) for i, g in enumerate(images)])
             hip.agc_build(agc_imgs, radius, percentile, min_size, self._buf("agc", hip.agc_workspace_bytes(agc_imgs)))
+        ts0 = time.perf_counter()
         infos = info_all.cpu().numpy()                                                    # the one host sync of the build
+        self._sync_ms = 1e3 * (time.perf_counter() - ts0)
         for g, inf in zip(images, infos):
             if inf[7]:
                 raise hip.GimsHipError("adaptive graph exceeded the edge capacity (64 directed edges per node)")
@@ -297,20 +307,15 @@ class GMatcher(nn.Module):
             indices_all = torch.empty((max(e_tot, 1),), dtype=torch.int32, device=dev)
             packs = []
             for i, g in enumerate(images):
-                sc = g["sc"].to(torch.float32).contiguous()
-                g["_sc32"] = sc
-                packs.append(hip.PackImage(g["kp"].data_ptr(), g["de"].data_ptr(), g["de"].stride(0), sc.data_ptr(),
+                packs.append(hip.PackImage(g["kp"].data_ptr(), g["de"].data_ptr(), g["de"].stride(0), g["sc"].data_ptr(),
                                            g["kept"].data_ptr(), g["indptr"].data_ptr(), g["indices"].data_ptr(),
                                            g["n_kept"], g["n_edges"], row_off[i], e_off[i]))
             g_keep = hip.pack_graphs(packs, D, feat, kpts_all, score_all, seg, indptr_all, indices_all, n_tot, e_tot)
-            norm3 = torch.empty((len(images), 3), dtype=torch.float32)
-            for i, g in enumerate(images):
-                height, width = g["shape"][2], g["shape"][3]     # NHWC callers => (W, 3): the reference's quirk, kept verbatim
-                one = torch.tensor(1, dtype=torch.float32)
-                size = torch.stack([one * width, one * height])
-                norm3[i, 0], norm3[i, 1] = size[0] / 2, size[1] / 2
-                norm3[i, 2] = size.max() * 0.7
-            norm3 = norm3.to(dev)
+            # normalize_keypoints parameters (gmatcher.py:26-33) in float32 arithmetic, like the reference's tensors.
+            # NHWC callers => (height, width) = (W, 3): the reference's quirk, kept verbatim.
+            hw = np.asarray([[g["shape"][3], g["shape"][2]] for g in images], dtype=np.float32)   # size = [width, height]
+            norm3 = np.concatenate([hw / np.float32(2), (hw.max(axis=1, keepdims=True) * np.float32(0.7))], axis=1).astype(np.float32)
+            norm3 = torch.from_numpy(norm3).to(dev)
             for g, ro in zip(images, row_off):
                 nk = g["n_kept"]
                 g["rows"] = (ro, nk)
@@ -376,26 +381,55 @@ class GMatcher(nn.Module):
         with St("final_scores"):
             mdesc = self._lin(P["final"], dpl[0], a0_lo=dpl[1]) if x3 else self._lin(P["final"], desc)
             items, largs = [], []
+            tot0, tot1 = sum(n0 for (_, n0), _ in pairs), sum(n1 for _, (_, n1) in pairs)
+            m0_all = torch.empty(tot0, dtype=torch.int64, device=dev)
+            m1_all = torch.empty(tot1, dtype=torch.int64, device=dev)
+            s0_all = torch.empty(tot0, dtype=torch.float32, device=dev)
+            s1_all = torch.empty(tot1, dtype=torch.float32, device=dev)
+            uv_all = torch.empty(tot0 + tot1 + 3 * len(pairs), dtype=torch.float32, device=dev)
+            c0 = c1 = cu = 0
             for (o0, n0), (o1, n1) in pairs:
                 ld = (n1 + 3) // 4 * 4
                 scores = torch.empty((n0, ld), dtype=torch.float32, device=dev)
                 largs.append(hip.linear_args(mdesc[o0:o0 + n0], mdesc[o1:o1 + n1], out=scores, precision=hip.PREC_F32,
                                              scale=1.0 / math.sqrt(D), n=n1))
-                items.append(dict(scores=scores, n=n0, m=n1,
-                                  matches0=torch.empty(n0, dtype=torch.int64, device=dev), matches1=torch.empty(n1, dtype=torch.int64, device=dev),
-                                  mscores0=torch.empty(n0, dtype=torch.float32, device=dev), mscores1=torch.empty(n1, dtype=torch.float32, device=dev),
-                                  uv=torch.empty(n0 + n1 + 3, dtype=torch.float32, device=dev)))
+                items.append(dict(scores=scores, n=n0, m=n1, matches0=m0_all[c0:c0 + n0], matches1=m1_all[c1:c1 + n1],
+                                  mscores0=s0_all[c0:c0 + n0], mscores1=s1_all[c1:c1 + n1], uv=uv_all[cu:cu + n0 + n1 + 3]))
+                c0, c1, cu = c0 + n0, c1 + n1, cu + n0 + n1 + 3
             hip.linear_batch(largs, self._buf("score_args", 256 * len(largs)), hip.PREC_F32)
         with St("sinkhorn"):
             probs = hip.make_ot_problems(items)
             work = self._buf("ot", hip.sinkhorn_workspace_bytes(probs))
             hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
-        self._last = dict(items=items, pairs=pairs, mdesc=mdesc, desc=desc, sage=sage, images=images)
+        self._last = dict(items=items, pairs=pairs, mdesc=mdesc, desc=desc, sage=sage, images=images,
+                          flat=dict(matches0=m0_all, scores0=s0_all, n0=[n0 for (_, n0), _ in pairs], n1=[n1 for _, (_, n1) in pairs]))
         return items, pairs, mdesc
 
-    @staticmethod
-    def _image(kp, de_dn, sc, shape):
-        return {"kp": kp.to(torch.float32).contiguous(), "de": de_dn.to(torch.float32).t().contiguous(), "sc": sc, "shape": tuple(shape)}
+    def _ingest(self, raw):
+        """raw: list of (kp (N,2), desc (D,N) channel-major, scores (N,), image shape).  ONE launch transposes the whole
+        batch into point-major descriptors (no per-image torch ops); per-image views share the big buffers."""
+        dev = raw[0][0].device
+        D = self.config['descriptor_dim']
+        ns = [int(r[0].shape[0]) for r in raw]
+        offs = np.cumsum([0] + ns).tolist()
+        tot = offs[-1]
+        arena = self._buf("ingest", tot * (D + 3) * 4).view(torch.float32)
+        de_all = arena[:tot * D].view(tot, D)
+        kp_all = arena[tot * D:tot * (D + 2)].view(tot, 2)
+        sc_all = arena[tot * (D + 2):tot * (D + 3)]
+        items, keep = [], []
+        for (kp, de, sc, _), n, off in zip(raw, ns, offs):
+            kp = kp if (kp.dtype == torch.float32 and kp.is_contiguous()) else kp.to(torch.float32).contiguous()
+            de = de if (de.dtype == torch.float32 and de.stride(1) == 1) else de.to(torch.float32).contiguous()
+            sc = sc if (sc.dtype == torch.float32 and sc.is_contiguous()) else sc.to(torch.float32).contiguous()
+            keep.append((kp, de, sc))
+            items.append(hip.IngestImage(kp.data_ptr(), de.data_ptr(), de.stride(0), sc.data_ptr(), n, off))
+        keep.append(hip.ingest_images(items, D, de_all, kp_all, sc_all))
+        images = []
+        for (_, _, _, shape), n, off in zip(raw, ns, offs):
+            images.append({"kp": kp_all[off:off + n], "de": de_all[off:off + n], "sc": sc_all[off:off + n], "shape": tuple(shape)})
+        images[0]["_keep"] = keep
+        return images
 
     def _check_call(self, data, kwargs):
         if data.get('delaunay', False):
@@ -411,11 +445,8 @@ class GMatcher(nn.Module):
         self._check_call(data, kwargs)
         radius, percentile, min_size = data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)
         B = data['keypoints0'].shape[0]
-        images = []
-        for b in range(B):
-            for side in ("0", "1"):
-                images.append(self._image(data['keypoints' + side][b], data['descriptors' + side][b], data['scores' + side][b],
-                                          data['image' + side].shape))
+        images = self._ingest([(data['keypoints' + side][b], data['descriptors' + side][b], data['scores' + side][b],
+                                data['image' + side].shape) for b in range(B) for side in ("0", "1")])
         items, pairs, mdesc = self._run(images, radius, percentile, min_size)
         # the reference's in-place dict mutation (gmatcher.py:244-252); torch.stack raises for ragged B>1, as there
         for s, side in enumerate(("0", "1")):
@@ -444,16 +475,19 @@ class GMatcher(nn.Module):
         matched in ONE batched pass even when every pair keeps a different number of keypoints (the reference's
         ``forward`` can only stack equal-sized pairs, gmatcher.py:244-249).  Each dict is mutated like ``forward``
         does and a list of per-pair result dicts (same keys as ``forward``) is returned."""
-        images = []
+        tm0 = time.perf_counter()
+        raw = []
         for data in datas:
             self._check_call(data, kwargs)
             if data['keypoints0'].shape[0] != 1:
                 raise ValueError("match_pairs takes single-pair dicts (B == 1)")
             for side in ("0", "1"):
-                images.append(self._image(data['keypoints' + side][0], data['descriptors' + side][0], data['scores' + side][0],
-                                          data['image' + side].shape))
+                raw.append((data['keypoints' + side][0], data['descriptors' + side][0], data['scores' + side][0], data['image' + side].shape))
+        images = self._ingest(raw)
+        tm1 = time.perf_counter()
         d0 = datas[0]
         items, pairs, mdesc = self._run(images, d0.get('radius', 25), d0.get('percentile', 7), d0.get('min_size', 8))
+        tm2 = time.perf_counter()
         outs = []
         for p, (data, it) in enumerate(zip(datas, items)):
             for s, side in enumerate(("0", "1")):
@@ -471,4 +505,9 @@ class GMatcher(nn.Module):
                 'matching_scores0': it["mscores0"][None], 'matching_scores1': it["mscores1"][None],
                 'mdesc0': mdesc[o0:o0 + n0], 'mdesc1': mdesc[o1:o1 + n1],
             })
+        outs = PairResults(outs)
+        outs.flat = self._last["flat"]
+        if self._timers is not None:
+            self._timers.setdefault("_host_marks", []).append((None, None, (1e3 * (tm1 - tm0), 1e3 * (tm2 - tm1), 1e3 * (time.perf_counter() - tm2),
+                                                                            getattr(self, "_sync_ms", 0.0))))
         return outs

@@ -44,6 +44,11 @@ class PackImage(C.Structure):
                 ("n_kept", C.c_int32), ("n_edges", C.c_int32), ("row_off", C.c_int32), ("edge_off", C.c_int32)]
 
 
+class IngestImage(C.Structure):
+    _fields_ = [("kpts", C.c_void_p), ("desc", C.c_void_p), ("ldd", C.c_int64), ("score", C.c_void_p), ("n", C.c_int32),
+                ("row_off", C.c_int32)]
+
+
 class OtProblem(C.Structure):
     _fields_ = [("scores", C.c_void_p), ("ld", C.c_int64), ("n", C.c_int32), ("m", C.c_int32),
                 ("matches0", C.c_void_p), ("matches1", C.c_void_p), ("mscores0", C.c_void_p),
@@ -70,6 +75,8 @@ _SIGNATURES = {
     "gims_agc_workspace_bytes": (C.c_size_t, [C.POINTER(AgcImage), C.c_int32]),
     "gims_agc_build": (C.c_int, [C.POINTER(AgcImage), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
+    "gims_ingest_images": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     "gims_pack_graphs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_void_p]),
@@ -239,6 +246,21 @@ def agc_build(images, radius, percentile, min_size, work: torch.Tensor):
     lib = load()
     _check(lib.gims_agc_build(images, len(images), float(radius), float(percentile), int(min_size), _p(work),
                               work.numel() * work.element_size(), _stream()), "gims_agc_build")
+
+
+def _upload_structs(arr, device):
+    """Small descriptor table -> device (one tiny H2D copy)."""
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+def ingest_images(items, d, desc_out, kpts_out, score_out):
+    """items: list of IngestImage (host).  One launch for the batch."""
+    lib = load()
+    arr = (IngestImage * len(items))(*items)
+    dev_arr = _upload_structs(arr, desc_out.device)
+    _check(lib.gims_ingest_images(_p(dev_arr), len(items), max(i.n for i in items), d, _p(desc_out), desc_out.stride(0),
+                                  _p(kpts_out), _p(score_out), _stream()), "gims_ingest_images")
+    return dev_arr
 
 
 def pack_graphs(pack_items, d, feat, kpts_out, score_out, seg, indptr_out, indices_out, n_rows, n_edges):

@@ -153,6 +153,16 @@ size_t gims_agc_workspace_bytes(const gims_agc_image* h_images /* HOST array */,
 int gims_agc_build(const gims_agc_image* h_images /* HOST array */, int32_t n_images, double radius, double percentile,
                    int32_t min_size, void* work, size_t work_bytes, void* stream);
 
+/* Ingest a batch of images given in the reference's layout (descriptors channel-major (D,N), gmatcher.py:245) into
+ * one row-concatenated point-major buffer: desc_out[row_off_i + n, :] = desc_i[:, n], same for keypoints and scores.
+ * One launch for the whole batch (64x64 LDS-tile transpose). */
+typedef struct gims_ingest_image {
+  const float* kpts; const float* desc; int64_t ldd; const float* score; int32_t n, row_off;
+} gims_ingest_image;
+
+int gims_ingest_images(const gims_ingest_image* dev_images /* DEVICE array */, int32_t n_images, int32_t max_n, int32_t d,
+                       float* desc_out, int64_t ldo, float* kpts_out, float* score_out /* may be NULL */, void* stream);
+
 /* Pack the kept keypoints of a batch of images into the row-concatenated layout the rest of the path uses
  * (gmatcher.py:244-249): for image i with row offset ro_i and edge offset eo_i,
  *   feat[ro_i + r, :] = desc_i[kept_i[r], :],  kpts_out[ro_i + r] = kpts_i[kept_i[r]],  score_out likewise,

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "gims_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(gims_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 17
+    assert len(declared) >= 18
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
@@ -32,6 +32,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(hip.OtProblem) == 8 + 8 + 4 + 4 + 5 * 8
     assert ctypes.sizeof(hip.AgcImage) == 3 * 8 + 2 * 4 + 3 * 8 + 8 + 8      # max_edges_dir is padded to 8
     assert ctypes.sizeof(hip.PackImage) == 7 * 8 + 4 * 4
+    assert ctypes.sizeof(hip.IngestImage) == 4 * 8 + 2 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path):
