@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--kpts", type=int, default=1024)
-    ap.add_argument("--pairs", type=int, default=16, help="image pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=32, help="image pairs per step per GPU")
     ap.add_argument("--sinkhorn-iters", type=int, default=100)
     ap.add_argument("--linear-precision", default="bf16x3", choices=["bf16x3", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,7 +181,10 @@ def main():
         attn_flops_layer = sum(1024.0 * (a * a + b * b) for a, b in problems)          # self layer (both images)
         cross_flops_layer = sum(1024.0 * (2 * a * b) for a, b in problems)
         n_rows = sum(a + b for a, b in problems)
-        lin_flops_layer = 2.0 * n_rows * (3 * 256 * 256 + 256 * 256 + 512 * 512 + 512 * 256)
+        fused = bool(model.config["fuse_merge"])
+        lpl = 3 if fused else 4                         # linear_x3p launches per layer
+        # executed linear flops per layer (with the merge conv folded into MLP0 the 256x256 merge GEMM disappears)
+        lin_flops_layer = 2.0 * n_rows * (3 * 256 * 256 + (0 if fused else 256 * 256) + 512 * 512 + 512 * 256)
         ot_bytes = sum(2.0 * args.sinkhorn_iters * (a + 1) * (b + 1) * 4 for a, b in problems)
         n_self = sum(1 for t in model.config["transformer_layers"] if t == "self")
         n_cross = len(model.config["transformer_layers"]) - n_self
@@ -190,13 +193,13 @@ def main():
         # kernel -> (bound, algorithmic work per launch, avg launch ms (HIP events on the launch stream), peak, unit, launches/step)
         # The "qkv" and "mlp" stages contain ONLY launches of linear_x3p_kernel (1 and 3 per layer).
         cand = {
-            "linear_x3p_kernel": ("mfma", L * lin_flops_layer / (4 * L), (per_step("qkv") + per_step("mlp")) / (4 * L), PEAK_BF16_TFLOPS, "TFLOP/s", 4 * L),
+            "linear_x3p_kernel": ("mfma", lin_flops_layer / lpl, (per_step("qkv") + per_step("mlp")) / (lpl * L), PEAK_BF16_TFLOPS, "TFLOP/s", lpl * L),
             "attention_bf16_kernel": ("mfma", (n_self * attn_flops_layer + n_cross * cross_flops_layer) / L,
                                       (per_step("attn_self") + per_step("attn_cross")) / L, PEAK_BF16_TFLOPS, "TFLOP/s", L),
             "ot_iter_kernel": ("hbm", ot_bytes / max(1, args.sinkhorn_iters), per_step("sinkhorn") / max(1, args.sinkhorn_iters), PEAK_HBM_GBS, "GB/s", args.sinkhorn_iters),
         }
         if args.linear_precision != "bf16x3":
-            cand["linear_f32_kernel"] = cand.pop("linear_x3p_kernel")[:3] + (157.3, "TFLOP/s", 4 * L)
+            cand["linear_f32_kernel"] = cand.pop("linear_x3p_kernel")[:3] + (157.3, "TFLOP/s", lpl * L)
         totals = {k: v[2] * v[5] for k, v in cand.items()}
         dom = max(totals, key=totals.get)
         rate = lambda v: v[1] / (v[2] * 1e-3) / (1e12 if v[4] == "TFLOP/s" else 1e9)     # noqa: E731

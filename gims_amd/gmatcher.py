@@ -86,6 +86,11 @@ class GMatcher(nn.Module):
         # --- additions (defaults keep the reference behaviour) ---
         'linear_precision': 'bf16x3',   # 'bf16x3' (split-bf16 MFMA, ~2^-17) or 'f32' (exact-f32 MFMA)
         'verbose': False,               # the reference prints '>> ...' timing lines; off by default here
+        # fold the attention 'merge' conv into the first MLP conv at load time:
+        #   W0 [x ; Wm o + bm] + b0  ==  W0x x + (W0m Wm) o + (W0m bm + b0)        (gmatcher.py:114,125)
+        # exact in real arithmetic (products formed in float64), removes one GEMM and one activation round trip per
+        # layer; set False to run the reference's operation order
+        'fuse_merge': True,
     }
 
     def __init__(self, config):
@@ -140,7 +145,8 @@ class GMatcher(nn.Module):
 
     # ------------------------------------------------------------------ weight packing
     def _packed(self, device):
-        key = (str(device), self.config['linear_precision'], sum(int(p._version) for p in self.parameters()))
+        key = (str(device), self.config['linear_precision'], bool(self.config['fuse_merge']),
+               sum(int(p._version) for p in self.parameters()))
         if self._pack is not None and self._pack_key == key:
             return self._pack
         sd = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
@@ -193,7 +199,13 @@ class GMatcher(nn.Module):
             bq, bk, bv = [sd[p + f"attn.proj.{j}.bias"][perm] for j in range(3)]
             wm = sd[p + "attn.merge.weight"][:, :, 0][:, perm]
             w0, b0 = fold(sd[p + "mlp.0.weight"][:, :, 0], sd[p + "mlp.0.bias"], p + "mlp.1")
+            w0f = b0f = None
+            if self.config['fuse_merge']:
+                w0m = w0[:, D:].double()
+                w0f = torch.cat([w0[:, :D].double(), w0m @ wm.double()], 1).float()
+                b0f = (b0.double() + w0m @ sd[p + "attn.merge.bias"].double()).float()
             P["layers"].append({
+                "mlp0_fused": lin(w0f, b0f) if w0f is not None else None,
                 "qkv": lin(torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)),
                 "merge": lin(wm, sd[p + "attn.merge.bias"]),
                 "mlp0": lin(w0, b0),
@@ -361,8 +373,11 @@ class GMatcher(nn.Module):
                 with St("attn_cross" if L["cross"] else "attn_self"):
                     hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl)
                 with St("mlp"):
-                    self._lin(L["merge"], mpl[0], a0_lo=mpl[1], out_split=gpl)
-                    self._lin(L["mlp0"], dpl[0], a0_lo=dpl[1], a1=gpl[0], a1_lo=gpl[1], act=hip.ACT_RELU, out_split=hpl)
+                    if L["mlp0_fused"] is not None:
+                        self._lin(L["mlp0_fused"], dpl[0], a0_lo=dpl[1], a1=mpl[0], a1_lo=mpl[1], act=hip.ACT_RELU, out_split=hpl)
+                    else:
+                        self._lin(L["merge"], mpl[0], a0_lo=mpl[1], out_split=gpl)
+                        self._lin(L["mlp0"], dpl[0], a0_lo=dpl[1], a1=gpl[0], a1_lo=gpl[1], act=hip.ACT_RELU, out_split=hpl)
                     self._lin(L["mlp1"], hpl[0], a0_lo=hpl[1], residual=desc, out=desc, out_split=dpl)   # desc += delta (gmatcher.py:142)
         else:
             msg = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
@@ -374,8 +389,11 @@ class GMatcher(nn.Module):
                 with St("attn_cross" if L["cross"] else "attn_self"):
                     hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D)
                 with St("mlp"):
-                    self._lin(L["merge"], msg, out=mrg)
-                    self._lin(L["mlp0"], desc, a1=mrg, act=hip.ACT_RELU, out=hid)
+                    if L["mlp0_fused"] is not None:
+                        self._lin(L["mlp0_fused"], desc, a1=msg, act=hip.ACT_RELU, out=hid)
+                    else:
+                        self._lin(L["merge"], msg, out=mrg)
+                        self._lin(L["mlp0"], desc, a1=mrg, act=hip.ACT_RELU, out=hid)
                     self._lin(L["mlp1"], hid, residual=desc, out=desc)          # desc += delta  (gmatcher.py:142)
         # ---- final projection, score matrix, Sinkhorn, selection (gmatcher.py:273-294)
         with St("final_scores"):

@@ -18,9 +18,10 @@ torch.set_grad_enabled(False)
 @pytest.fixture(scope="module")
 def models(synth_sd):
     out = {}
-    for prec in ("bf16x3", "f32"):
+    for prec in ("bf16x3", "f32", "bf16x3-unfused"):
         for iters, thr in ((100, 0.2), (20, 0.02)):
-            m = GMatcher({"sinkhorn_iterations": iters, "match_threshold": thr, "linear_precision": prec}).eval()
+            m = GMatcher({"sinkhorn_iterations": iters, "match_threshold": thr, "linear_precision": prec.split("-")[0],
+                          "fuse_merge": not prec.endswith("unfused")}).eval()
             m.load_state_dict(synth_sd)
             out[(prec, iters)] = m
     return out
@@ -50,7 +51,7 @@ def _compare(out, data, g, thr):
     return dict(n=len(m0), mismatched_unsafe=int((m0 != r0).sum()), score_err=float(err))
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f32", "bf16x3-unfused"])
 @pytest.mark.parametrize("name", golden_names("e2e_"))
 def test_e2e_vs_reference_golden(models, name, prec):
     g = load_golden(name)
