@@ -90,9 +90,18 @@ __global__ __launch_bounds__(256) void agc_hist_kernel(const AgcWs* __restrict__
   const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
   for (int i = blockIdx.x; i < w.n; i += gridDim.x) {
     const float* row = w.S + (int64_t)i * w.lds;
-    for (int j = i + 1 + threadIdx.x; j < w.n; j += 256) {
-      const uint32_t k = f32_key(row[j]);
-      if ((k & himask) == (prefix & himask)) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    // 16-byte loads over the strict upper triangle of row i (rows are 16-byte aligned: lds % 4 == 0)
+    for (int j4 = ((i + 1) & ~3) + 4 * threadIdx.x; j4 < w.n; j4 += 4 * 256) {
+      const float4 v = *(const float4*)(row + j4);
+      const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = j4 + q;
+        if (j > i && j < w.n) {
+          const uint32_t k = f32_key(x[q]);
+          if ((k & himask) == (prefix & himask)) atomicAdd(&h[(k >> shift) & 255u], 1u);
+        }
+      }
     }
   }
   __syncthreads();
@@ -633,6 +642,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     gims_linear_args la = {};
     la.a0 = w->dn; la.lda0 = im.d; la.w = w->dn; la.ldw = im.d; la.out_f32 = w->S; la.ldc = w->lds;
     la.m = im.n; la.n = im.n; la.k = im.d; la.k0 = im.d; la.act = GIMS_ACT_NONE; la.precision = GIMS_PREC_F32; la.scale = 1.f;
+    la.flags = GIMS_LINEAR_UPPER;    // only S[i][j], i < j, is ever read (threshold select and edge test)
     int rc = gims_linear_put(&la, dla + i, stream);
     if (rc != GIMS_OK) return rc;
     maxn = im.n > maxn ? im.n : maxn;

@@ -47,6 +47,7 @@ __device__ __forceinline__ void linear_f32_body(const gims_linear_args& p, float
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   if (m0 >= p.m || n0 >= p.n) return;   // batched launches are sized for the largest problem
+  if ((p.flags & GIMS_LINEAR_UPPER) && n0 + BN <= m0) return;   // symmetric product: tile entirely below the diagonal
   const float* w = (const float*)p.w;
 
   f32x16 acc[2][2];

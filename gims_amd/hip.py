@@ -29,7 +29,7 @@ class LinearArgs(C.Structure):
                 ("out_bf16", C.c_void_p), ("ldc_bf16", C.c_int64), ("m", C.c_int32), ("n", C.c_int32),
                 ("k", C.c_int32), ("k0", C.c_int32), ("act", C.c_int32), ("precision", C.c_int32),
                 ("scale", C.c_float), ("a0_lo", C.c_void_p), ("a1_lo", C.c_void_p), ("out_hi", C.c_void_p),
-                ("out_lo", C.c_void_p), ("ld_split", C.c_int64)]
+                ("out_lo", C.c_void_p), ("ld_split", C.c_int64), ("flags", C.c_int32)]
 
 
 class AgcImage(C.Structure):
@@ -154,7 +154,7 @@ def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None
                       _p(w), _p(w_lo), w.stride(0), _p(bias), _p(residual), _p(out),
                       out.stride(0) if out is not None else 0, _p(out_bf16),
                       out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale),
-                      _p(a0_lo), _p(a1_lo), _p(hi), _p(lo), hi.stride(0) if hi is not None else 0)
+                      _p(a0_lo), _p(a1_lo), _p(hi), _p(lo), hi.stride(0) if hi is not None else 0, 0)
 
 
 def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):

@@ -75,7 +75,10 @@ typedef struct gims_linear_args {
   const uint16_t* a0_lo; const uint16_t* a1_lo;
   /* optional split output: hi = bf16(v), lo = bf16(v - hi), both [m][ld_split] */
   uint16_t* out_hi; uint16_t* out_lo; int64_t ld_split;
+  /* GIMS_LINEAR_UPPER: symmetric product (A == W): skip output tiles that lie entirely below the diagonal */
+  int32_t flags;
 } gims_linear_args;
+#define GIMS_LINEAR_UPPER 1
 
 int gims_linear(const gims_linear_args* args, void* stream);
 /* Many independent problems in ONE launch (ragged batch: per-pair score matrices, per-image similarity
