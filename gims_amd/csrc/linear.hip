@@ -279,53 +279,66 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_batch_kernel(const gims_
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BK, int S>
+// Geometry: TM x TN output tile per workgroup, WM x WN waves, each wave (TM/WM) x (TN/WN) as 32x32 MFMA tiles,
+// BK-deep stages in an S-stage LDS ring.  Two instantiations are used:
+//   128x128, 2x2 waves (64x64 per wave),  64 KiB LDS, 2 workgroups/CU -- small problems (fills the chip sooner);
+//   256x256, 4x2 waves (64x128 per wave), 128 KiB LDS, 1 workgroup/CU -- half the operand bytes per MFMA, used when
+//   the launch still yields at least ~one workgroup per CU.
+template <int TM, int TN, int WM, int WN, int BK, int S>
 struct X3P {
-  static constexpr int PLANE = BM * BK;            // bf16 elements per plane per stage
-  static constexpr int STAGE = 4 * PLANE;
-  static constexpr int CPR = BK / 8;               // 16-byte chunks per row
-  static constexpr int PIECES = BK / 4;            // 1 KiB pieces per plane per stage (= per wave per stage)
-  static constexpr int ROWS_PER_PIECE = 64 / CPR;
+  static constexpr int WAVES = WM * WN;
+  static constexpr int MI = TM / WM / 32, NI = TN / WN / 32;     // 32x32 tiles per wave
+  static constexpr int A_PLANE = TM * BK, W_PLANE = TN * BK;     // bf16 elements per plane per stage
+  static constexpr int STAGE = 2 * A_PLANE + 2 * W_PLANE;
+  static constexpr int CPR = BK / 8;                             // 16-byte chunks per row
+  static constexpr int ROWS_PER_PIECE = 64 / CPR;                // a 1 KiB LDS-DMA piece covers this many rows
+  static constexpr int PA = TM / ROWS_PER_PIECE, PW = TN / ROWS_PER_PIECE;   // pieces per A / W plane
+  static constexpr int PIECES = (2 * PA + 2 * PW) / WAVES;       // pieces per wave per stage
   static constexpr int LDS_BYTES = S * STAGE * 2;
+  static_assert((2 * PA + 2 * PW) % WAVES == 0 && PA % PIECES == 0 && PW % PIECES == 0, "a wave's pieces stay in one plane");
   __device__ static __forceinline__ int swz(int row) { return (row / (16 / CPR)) & (CPR - 1); }
   __device__ static __forceinline__ int off(int row, int chunk) { return row * BK + ((chunk ^ swz(row)) << 3); }
 };
 
-template <int BK, int S>
-__global__ __launch_bounds__(256, (S * BK <= 64) ? 2 : 1) void linear_x3p_kernel(gims_linear_args p) {
-  using T = X3P<BK, S>;
+template <int TM, int TN, int WM, int WN, int BK, int S>
+__global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_args p) {
+  using T = X3P<TM, TN, WM, WN, BK, S>;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed; used for speed only), and each XCD has
-  // its own L2.  All column tiles of one 128-row panel of A are therefore given consecutive slots on ONE XCD, so the
+  // its own L2.  All column tiles of one row panel of A are therefore given consecutive slots on ONE XCD, so the
   // panel is fetched from HBM once instead of once per column tile.
-  const int nt_n = (p.n + BN - 1) / BN;
+  const int nt_n = (p.n + TN - 1) / TN;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int m0 = ((slot / nt_n) * 8 + xcd) * BM, n0 = (slot % nt_n) * BN;
+  const int m0 = ((slot / nt_n) * 8 + xcd) * TM, n0 = (slot % nt_n) * TN;
   if (m0 >= p.m) return;
   const int li = lane & 31, lh = lane >> 5;
   const int nk = p.k / BK;
 
-  // this wave's DMA duty: plane `wave` (0: A hi, 1: A lo, 2: W hi, 3: W lo)
+  // this wave's LDS-DMA duty: PIECES consecutive pieces of ONE plane (A hi | A lo | W hi | W lo)
+  const int p0 = wave * T::PIECES;
+  const int region = p0 < T::PA ? 0 : (p0 < 2 * T::PA ? 1 : (p0 < 2 * T::PA + T::PW ? 2 : 3));
+  const int piece0 = region == 0 ? p0 : (region == 1 ? p0 - T::PA : (region == 2 ? p0 - 2 * T::PA : p0 - 2 * T::PA - T::PW));
+  const int plane_off = region == 0 ? 0 : (region == 1 ? T::A_PLANE : (region == 2 ? 2 * T::A_PLANE : 2 * T::A_PLANE + T::W_PLANE));
   const int drow = lane / T::CPR, dpos = lane % T::CPR;
   auto issue = [&](int kt) {
     const int k = kt * BK;
     const uint16_t* base;
     int64_t ld;
     int kk, rmax, r0;
-    if (wave < 2) {
-      if (k < p.k0) { base = (const uint16_t*)(wave == 0 ? (const void*)p.a0 : (const void*)p.a0_lo); ld = p.lda0; kk = k; }
-      else { base = (const uint16_t*)(wave == 0 ? (const void*)p.a1 : (const void*)p.a1_lo); ld = p.lda1; kk = k - p.k0; }
+    if (region < 2) {
+      if (k < p.k0) { base = (const uint16_t*)(region == 0 ? (const void*)p.a0 : (const void*)p.a0_lo); ld = p.lda0; kk = k; }
+      else { base = (const uint16_t*)(region == 0 ? (const void*)p.a1 : (const void*)p.a1_lo); ld = p.lda1; kk = k - p.k0; }
       rmax = p.m - 1; r0 = m0;
     } else {
-      base = (const uint16_t*)(wave == 2 ? p.w : p.w_lo); ld = p.ldw; kk = k; rmax = p.n - 1; r0 = n0;
+      base = (const uint16_t*)(region == 2 ? p.w : p.w_lo); ld = p.ldw; kk = k; rmax = p.n - 1; r0 = n0;
     }
-    uint16_t* dst = smem + (kt % S) * T::STAGE + wave * T::PLANE;
+    uint16_t* dst = smem + (kt % S) * T::STAGE + plane_off + piece0 * 512;
 #pragma unroll
     for (int i = 0; i < T::PIECES; ++i) {
-      const int row = T::ROWS_PER_PIECE * i + drow;
+      const int row = T::ROWS_PER_PIECE * (piece0 + i) + drow;
       int gr = r0 + row; gr = gr < rmax ? gr : rmax;
       const uint16_t* g = base + (int64_t)gr * ld + kk + 8 * (dpos ^ T::swz(row));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -333,11 +346,11 @@ __global__ __launch_bounds__(256, (S * BK <= 64) ? 2 : 1) void linear_x3p_kernel
     }
   };
 
-  f32x16 acc[2][2];   // [n-block][m-block], D^T layout: column = row m (lane&31), rows = output channels
+  f32x16 acc[T::NI][T::MI];   // [n-block][m-block], D^T layout: column = row m (lane&31), rows = output channels
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < T::NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < T::MI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256, (S * BK <= 64) ? 2 : 1) void linear_x3p_kernel
   for (int s0 = 0; s0 < D; ++s0)
     if (s0 < nk) issue(s0);
   for (int kt = 0; kt < nk; ++kt) {
-    // own pieces of stage kt landed: at most `newer` stages (P pieces each) may still be in flight
+    // own pieces of stage kt landed: at most `newer` stages (PIECES each) may still be in flight
     const int newer = (nk - 1 - kt) < (D - 1) ? (nk - 1 - kt) : (D - 1);
     if (newer >= 2) wait_vm<2 * T::PIECES>();
     else if (newer == 1) wait_vm<T::PIECES>();
@@ -356,19 +369,23 @@ __global__ __launch_bounds__(256, (S * BK <= 64) ? 2 : 1) void linear_x3p_kernel
     const uint16_t* st = smem + (kt % S) * T::STAGE;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 ah[2], al[2], wh[2], wl[2];
+      bf16x8 ah[T::MI], al[T::MI], wh[T::NI], wl[T::NI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ar = wm * 64 + i * 32 + li, wr = wn * 64 + i * 32 + li;
+      for (int i = 0; i < T::MI; ++i) {
+        const int ar = wm * (TM / WM) + i * 32 + li;
         ah[i] = *(const bf16x8*)(st + T::off(ar, 2 * s + lh));
-        al[i] = *(const bf16x8*)(st + T::PLANE + T::off(ar, 2 * s + lh));
-        wh[i] = *(const bf16x8*)(st + 2 * T::PLANE + T::off(wr, 2 * s + lh));
-        wl[i] = *(const bf16x8*)(st + 3 * T::PLANE + T::off(wr, 2 * s + lh));
+        al[i] = *(const bf16x8*)(st + T::A_PLANE + T::off(ar, 2 * s + lh));
       }
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int i = 0; i < T::NI; ++i) {
+        const int wr = wn * (TN / WN) + i * 32 + li;
+        wh[i] = *(const bf16x8*)(st + 2 * T::A_PLANE + T::off(wr, 2 * s + lh));
+        wl[i] = *(const bf16x8*)(st + 2 * T::A_PLANE + T::W_PLANE + T::off(wr, 2 * s + lh));
+      }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+      for (int ni = 0; ni < T::NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < T::MI; ++mi) {
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
@@ -376,38 +393,51 @@ __global__ __launch_bounds__(256, (S * BK <= 64) ? 2 : 1) void linear_x3p_kernel
     }
   }
 
-  // ---- epilogue: lane owns row m, 4 consecutive channels per accumulator group
+  // ---- epilogue: lane owns row m, 4 consecutive channels per accumulator group.  The bias / residual vectors of a
+  // chunk of two 32-channel blocks (8 + 8 float4) are requested BEFORE the first one is consumed, so their latencies
+  // overlap instead of adding up (the compiler otherwise waits vmcnt(0) per group).
+  const int colbase = n0 + wn * (TN / WN) + 4 * lh;
+  constexpr int NB = T::NI < 2 ? T::NI : 2;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int row = m0 + wm * 64 + mi * 32 + li;
-    if (row >= p.m) continue;
+  for (int mi = 0; mi < T::MI; ++mi) {
+    const int row = m0 + wm * (TM / WM) + mi * 32 + li;
+    const bool rok = row < p.m;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int nc = 0; nc < T::NI; nc += NB) {
+      float4 bias4[NB][4], res4[NB][4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = n0 + wn * 64 + ni * 32 + 8 * g + 4 * lh;
-        if (col >= p.n) continue;
-        float4 v = make_float4(acc[ni][mi][4 * g] * p.scale, acc[ni][mi][4 * g + 1] * p.scale,
-                               acc[ni][mi][4 * g + 2] * p.scale, acc[ni][mi][4 * g + 3] * p.scale);
-        if (p.bias) {
-          const float4 b = *(const float4*)(p.bias + col);
-          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = colbase + (nc + q) * 32 + 8 * g;
+          const bool ok = rok && col < p.n;
+          bias4[q][g] = (p.bias && ok) ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+          res4[q][g] = (p.residual && ok) ? *(const float4*)(p.residual + (int64_t)row * p.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (p.act == GIMS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (p.residual) {
-          const float4 r = *(const float4*)(p.residual + (int64_t)row * p.ldc + col);
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ni = nc + q;
+          const int col = colbase + ni * 32 + 8 * g;
+          if (!rok || col >= p.n) continue;
+          const float4 b = bias4[q][g];
+          float4 v = make_float4(fmaf(acc[ni][mi][4 * g], p.scale, b.x), fmaf(acc[ni][mi][4 * g + 1], p.scale, b.y),
+                                 fmaf(acc[ni][mi][4 * g + 2], p.scale, b.z), fmaf(acc[ni][mi][4 * g + 3], p.scale, b.w));
+          if (p.act == GIMS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          const float4 r = res4[q][g];
           v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          if (p.out_f32) *(float4*)(p.out_f32 + (int64_t)row * p.ldc + col) = v;
+          if (p.out_bf16) *(uint2*)(p.out_bf16 + (int64_t)row * p.ldc_bf16 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+          if (p.out_hi) {
+            const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
+            const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+            const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+            *(uint2*)(p.out_hi + (int64_t)row * p.ld_split + col) = make_uint2(h01, h23);
+            *(uint2*)(p.out_lo + (int64_t)row * p.ld_split + col) = make_uint2(l01, l23);
+          }
         }
-        if (p.out_f32) *(float4*)(p.out_f32 + (int64_t)row * p.ldc + col) = v;
-        if (p.out_bf16) *(uint2*)(p.out_bf16 + (int64_t)row * p.ldc_bf16 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-        if (p.out_hi) {
-          const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
-          const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
-          const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
-          *(uint2*)(p.out_hi + (int64_t)row * p.ld_split + col) = make_uint2(h01, h23);
-          *(uint2*)(p.out_lo + (int64_t)row * p.ld_split + col) = make_uint2(l01, l23);
-        }
-      }
+    }
   }
 }
 
@@ -479,30 +509,29 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(a->n, BN), cdiv(a->m, BM));
   if (a->a0_lo) {
-    const int nt_m = cdiv(a->m, BM), nt_n = cdiv(a->n, BN);
-    const dim3 g(8 * cdiv(nt_m, 8) * nt_n);
-    // ring geometry.  Default BK 32 x 2 stages (64 KiB, 2 workgroups per CU) measured fastest on MI355X for these
-    // shapes (M >> N, K <= 512); the deeper rings (GIMS_X3P_VARIANT=0: BK 16 x 4, 1: BK 32 x 3, 2: BK 32 x 4 with one
-    // workgroup per CU) are kept for experiments -- the kernel is bound by operand bytes per MFMA, not by latency.
-    static int variant = -1;
-    if (variant < 0) {
-      const char* e = getenv("GIMS_X3P_VARIANT");
-      variant = e ? atoi(e) : 3;
-      const void* f3 = (const void*)linear_x3p_kernel<32, 2>;
-      GIMS_HIP(hipFuncSetAttribute(f3, hipFuncAttributeMaxDynamicSharedMemorySize, X3P<32, 2>::LDS_BYTES));
-      constexpr int l0 = X3P<16, 4>::LDS_BYTES, l1 = X3P<32, 3>::LDS_BYTES, l2 = X3P<32, 4>::LDS_BYTES;
-      const void* f0 = (const void*)linear_x3p_kernel<16, 4>;
-      const void* f1 = (const void*)linear_x3p_kernel<32, 3>;
-      const void* f2 = (const void*)linear_x3p_kernel<32, 4>;
-      GIMS_HIP(hipFuncSetAttribute(f0, hipFuncAttributeMaxDynamicSharedMemorySize, l0));
-      GIMS_HIP(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, l1));
-      GIMS_HIP(hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
+    // tile geometry: 256x256 (half the operand bytes per MFMA) when that still gives ~one workgroup per CU,
+    // else 128x128.  GIMS_X3P_TILE=128|256 forces one (experiments).
+    using TS = X3P<128, 128, 2, 2, 32, 2>;
+    using TL = X3P<256, 256, 4, 2, 32, 2>;
+    static int force = -1;
+    if (force < 0) {
+      const char* e = getenv("GIMS_X3P_TILE");
+      force = e ? atoi(e) : 0;
+      const void* fs = (const void*)linear_x3p_kernel<128, 128, 2, 2, 32, 2>;
+      const void* fl = (const void*)linear_x3p_kernel<256, 256, 4, 2, 32, 2>;
+      constexpr int ls = TS::LDS_BYTES, ll = TL::LDS_BYTES;
+      GIMS_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
+      GIMS_HIP(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
     }
-    constexpr size_t lds0 = X3P<16, 4>::LDS_BYTES, lds1 = X3P<32, 3>::LDS_BYTES, lds2 = X3P<32, 4>::LDS_BYTES, lds3 = X3P<32, 2>::LDS_BYTES;
-    if (variant == 3) hipLaunchKernelGGL((linear_x3p_kernel<32, 2>), g, dim3(256), lds3, s, *a);
-    else if (variant == 1) hipLaunchKernelGGL((linear_x3p_kernel<32, 3>), g, dim3(256), lds1, s, *a);
-    else if (variant == 2) hipLaunchKernelGGL((linear_x3p_kernel<32, 4>), g, dim3(256), lds2, s, *a);
-    else hipLaunchKernelGGL((linear_x3p_kernel<16, 4>), g, dim3(256), lds0, s, *a);
+    const int big_blocks = cdiv(a->m, 256) * cdiv(a->n, 256);
+    const bool big = force == 256 || (force != 128 && big_blocks >= 192);
+    if (big) {
+      constexpr size_t lds = TL::LDS_BYTES;
+      hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 32, 2>), dim3(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256)), dim3(512), lds, s, *a);
+    } else {
+      constexpr size_t lds = TS::LDS_BYTES;
+      hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 32, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
+    }
   } else if (a->precision == GIMS_PREC_F32) {
     hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, s, *a);
   } else {
