@@ -221,8 +221,8 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
           const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
           const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
           const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
-          *(uint2*)(out_hi + grow * ld_split + col) = make_uint2(h01, h23);
-          *(uint2*)(out_lo + grow * ld_split + col) = make_uint2(l01, l23);
+          *(uint2*)(out_hi + grow * ld_split + spl_col(col)) = make_uint2(h01, h23);
+          *(uint2*)(out_lo + grow * ld_split + spl_col(col)) = make_uint2(l01, l23);
         }
       }
   }

@@ -53,6 +53,12 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 __device__ __forceinline__ uint16_t f2bf(float x) { return (uint16_t)(pack_bf2(x, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
+// SPL32: the split-bf16 activation / weight layout.  A logical [rows][K] f32 matrix is stored as ONE bf16 buffer
+// [rows][2K]: per row and per block of 32 channels, 32 hi values then 32 lo values (hi = bf16(x), lo = bf16(x - hi)),
+// i.e. each (row, 32-channel block) is one full 128-byte line holding everything an MFMA k-step pair needs.
+// Column k -> hi at spl_col(k), lo at spl_col(k) + 32.
+__device__ __forceinline__ int spl_col(int k) { return ((k >> 5) << 6) + (k & 31); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -30,8 +30,8 @@ __device__ __forceinline__ void epilogue_store(const gims_linear_args& p, int ro
   if (p.out_bf16) p.out_bf16[(int64_t)row * p.ldc_bf16 + col] = f2bf(v);
   if (p.out_hi) {
     const uint16_t h = f2bf(v);
-    p.out_hi[(int64_t)row * p.ld_split + col] = h;
-    p.out_lo[(int64_t)row * p.ld_split + col] = f2bf(v - bf2f(h));
+    p.out_hi[(int64_t)row * p.ld_split + spl_col(col)] = h;
+    p.out_lo[(int64_t)row * p.ld_split + spl_col(col)] = f2bf(v - bf2f(h));
   }
 }
 
@@ -264,15 +264,15 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_batch_kernel(const gims_
   linear_bf16x3_body(p, smem);
 }
 // ------------------------------------------------------------------------------------------ split-bf16 MFMA, pre-split A
-// The hot linears of the attentional GNN.  Activations arrive ALREADY split into bf16 hi/lo planes (written by
-// the producing kernel's epilogue), so all four operand planes (A hi/lo, W hi/lo) go HBM/L2 -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: no VGPR staging, no ds_write) through an S-stage ring with COUNTED waits:
-//   * stage = 4 planes x [128 rows][BK k] bf16; each wave streams one plane per stage as BK/4 pieces of 1 KiB;
-//   * S-1 stages are kept in flight: before computing stage t a wave waits only until its own pieces of stage t have
-//     landed (s_waitcnt vmcnt(newer pieces)), crosses ONE raw s_barrier (every wave's pieces landed, and everyone is
-//     done reading the slot about to be refilled), issues stage t+S-1 and computes -- the LDS-DMA queue never drains;
-//   * the LDS image is lane-linear per piece, so the bank-conflict swizzle is applied to the per-lane SOURCE address
-//     and again on the ds_read_b128 (same involution on both sides).
+// The hot linears of the attentional GNN.  Activations and weights arrive ALREADY split, in the SPL32 layout
+// (common.h): per row and 32-channel block one 128-byte line [32 hi | 32 lo], written by the producing kernel's
+// epilogue.  Operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write):
+//   * a K-step is one 32-channel block: every DMA piece (1 KiB) moves 8 FULL cache lines (hi and lo of 8 rows), so
+//     the L2 sees half the requests of a plane-per-buffer layout with 64-byte rows (measured: that variant was
+//     pinned at ~5.7 TB/s of L2->LDS traffic whatever the tile size);
+//   * S-stage LDS ring, ONE raw s_barrier per K-step, counted s_waitcnt vmcnt so the DMA queue need not drain;
+//   * the LDS image is lane-linear per piece, so the bank-conflict swizzle (16-byte chunk ^= (row>>1)&7) is applied
+//     to the per-lane SOURCE address and again on the ds_read_b128 (same involution on both sides).
 // The MFMA is issued with swapped operands (D^T = W A^T): a lane then owns 4 CONSECUTIVE output channels of
 // one row per accumulator group, so every epilogue store is 8-16 bytes wide (f32x4 / bf16x4) and bias /
 // residual are vector loads.
@@ -280,29 +280,29 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Geometry: TM x TN output tile per workgroup, WM x WN waves, each wave (TM/WM) x (TN/WN) as 32x32 MFMA tiles,
-// BK-deep stages in an S-stage LDS ring.  Two instantiations are used:
+// 32-channel stages in an S-stage LDS ring.  Two instantiations are used:
 //   128x128, 2x2 waves (64x64 per wave),  64 KiB LDS, 2 workgroups/CU -- small problems (fills the chip sooner);
 //   256x256, 4x2 waves (64x128 per wave), 128 KiB LDS, 1 workgroup/CU -- half the operand bytes per MFMA, used when
 //   the launch still yields at least ~one workgroup per CU.
-template <int TM, int TN, int WM, int WN, int BK, int S>
+template <int TM, int TN, int WM, int WN, int S>
 struct X3P {
+  static constexpr int BK = 32;
   static constexpr int WAVES = WM * WN;
   static constexpr int MI = TM / WM / 32, NI = TN / WN / 32;     // 32x32 tiles per wave
-  static constexpr int A_PLANE = TM * BK, W_PLANE = TN * BK;     // bf16 elements per plane per stage
-  static constexpr int STAGE = 2 * A_PLANE + 2 * W_PLANE;
-  static constexpr int CPR = BK / 8;                             // 16-byte chunks per row
-  static constexpr int ROWS_PER_PIECE = 64 / CPR;                // a 1 KiB LDS-DMA piece covers this many rows
-  static constexpr int PA = TM / ROWS_PER_PIECE, PW = TN / ROWS_PER_PIECE;   // pieces per A / W plane
-  static constexpr int PIECES = (2 * PA + 2 * PW) / WAVES;       // pieces per wave per stage
+  static constexpr int A_TILE = TM * 64, W_TILE = TN * 64;       // bf16 elements per stage (128-byte rows)
+  static constexpr int STAGE = A_TILE + W_TILE;
+  static constexpr int PA = TM / 8, PW = TN / 8;                 // 1 KiB pieces (8 rows) per operand per stage
+  static constexpr int PIECES = (PA + PW) / WAVES;               // pieces per wave per stage
   static constexpr int LDS_BYTES = S * STAGE * 2;
-  static_assert((2 * PA + 2 * PW) % WAVES == 0 && PA % PIECES == 0 && PW % PIECES == 0, "a wave's pieces stay in one plane");
-  __device__ static __forceinline__ int swz(int row) { return (row / (16 / CPR)) & (CPR - 1); }
-  __device__ static __forceinline__ int off(int row, int chunk) { return row * BK + ((chunk ^ swz(row)) << 3); }
+  static_assert((PA + PW) % WAVES == 0 && PA % PIECES == 0 && PW % PIECES == 0, "a wave's pieces stay in one operand");
+  __device__ static __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+  __device__ static __forceinline__ int off(int row, int chunk) { return row * 64 + ((chunk ^ swz(row)) << 3); }
 };
 
-template <int TM, int TN, int WM, int WN, int BK, int S>
+template <int TM, int TN, int WM, int WN, int S>
 __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_args p) {
-  using T = X3P<TM, TN, WM, WN, BK, S>;
+  using T = X3P<TM, TN, WM, WN, S>;
+  constexpr int BK = T::BK;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -317,30 +317,29 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   const int li = lane & 31, lh = lane >> 5;
   const int nk = p.k / BK;
 
-  // this wave's LDS-DMA duty: PIECES consecutive pieces of ONE plane (A hi | A lo | W hi | W lo)
+  // this wave's LDS-DMA duty: PIECES consecutive 8-row pieces of ONE operand (A rows | W rows)
   const int p0 = wave * T::PIECES;
-  const int region = p0 < T::PA ? 0 : (p0 < 2 * T::PA ? 1 : (p0 < 2 * T::PA + T::PW ? 2 : 3));
-  const int piece0 = region == 0 ? p0 : (region == 1 ? p0 - T::PA : (region == 2 ? p0 - 2 * T::PA : p0 - 2 * T::PA - T::PW));
-  const int plane_off = region == 0 ? 0 : (region == 1 ? T::A_PLANE : (region == 2 ? 2 * T::A_PLANE : 2 * T::A_PLANE + T::W_PLANE));
-  const int drow = lane / T::CPR, dpos = lane % T::CPR;
+  const bool is_a = p0 < T::PA;
+  const int piece0 = is_a ? p0 : p0 - T::PA;
+  const int drow = lane >> 3, dpos = lane & 7;
   auto issue = [&](int kt) {
     const int k = kt * BK;
     const uint16_t* base;
     int64_t ld;
     int kk, rmax, r0;
-    if (region < 2) {
-      if (k < p.k0) { base = (const uint16_t*)(region == 0 ? (const void*)p.a0 : (const void*)p.a0_lo); ld = p.lda0; kk = k; }
-      else { base = (const uint16_t*)(region == 0 ? (const void*)p.a1 : (const void*)p.a1_lo); ld = p.lda1; kk = k - p.k0; }
+    if (is_a) {
+      if (k < p.k0) { base = (const uint16_t*)p.a0; ld = p.lda0; kk = k; }
+      else { base = (const uint16_t*)p.a1; ld = p.lda1; kk = k - p.k0; }
       rmax = p.m - 1; r0 = m0;
     } else {
-      base = (const uint16_t*)(region == 2 ? p.w : p.w_lo); ld = p.ldw; kk = k; rmax = p.n - 1; r0 = n0;
+      base = (const uint16_t*)p.w; ld = p.ldw; kk = k; rmax = p.n - 1; r0 = n0;
     }
-    uint16_t* dst = smem + (kt % S) * T::STAGE + plane_off + piece0 * 512;
+    uint16_t* dst = smem + (kt % S) * T::STAGE + (is_a ? 0 : T::A_TILE) + piece0 * 512;
 #pragma unroll
     for (int i = 0; i < T::PIECES; ++i) {
-      const int row = T::ROWS_PER_PIECE * (piece0 + i) + drow;
+      const int row = 8 * (piece0 + i) + drow;
       int gr = r0 + row; gr = gr < rmax ? gr : rmax;
-      const uint16_t* g = base + (int64_t)gr * ld + kk + 8 * (dpos ^ T::swz(row));
+      const uint16_t* g = base + (int64_t)gr * ld + 2 * kk + 8 * (dpos ^ T::swz(row));   // SPL32: block kk/32 starts at 2*kk
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(dst + i * 512), 16, 0, 0);
     }
@@ -373,14 +372,14 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
 #pragma unroll
       for (int i = 0; i < T::MI; ++i) {
         const int ar = wm * (TM / WM) + i * 32 + li;
-        ah[i] = *(const bf16x8*)(st + T::off(ar, 2 * s + lh));
-        al[i] = *(const bf16x8*)(st + T::A_PLANE + T::off(ar, 2 * s + lh));
+        ah[i] = *(const bf16x8*)(st + T::off(ar, 2 * s + lh));         // chunks 0-3: hi of channels 0-31
+        al[i] = *(const bf16x8*)(st + T::off(ar, 4 + 2 * s + lh));     // chunks 4-7: lo
       }
 #pragma unroll
       for (int i = 0; i < T::NI; ++i) {
         const int wr = wn * (TN / WN) + i * 32 + li;
-        wh[i] = *(const bf16x8*)(st + 2 * T::A_PLANE + T::off(wr, 2 * s + lh));
-        wl[i] = *(const bf16x8*)(st + 2 * T::A_PLANE + T::W_PLANE + T::off(wr, 2 * s + lh));
+        wh[i] = *(const bf16x8*)(st + T::A_TILE + T::off(wr, 2 * s + lh));
+        wl[i] = *(const bf16x8*)(st + T::A_TILE + T::off(wr, 4 + 2 * s + lh));
       }
 #pragma unroll
       for (int ni = 0; ni < T::NI; ++ni)
@@ -433,8 +432,8 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
             const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
             const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
             const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
-            *(uint2*)(p.out_hi + (int64_t)row * p.ld_split + col) = make_uint2(h01, h23);
-            *(uint2*)(p.out_lo + (int64_t)row * p.ld_split + col) = make_uint2(l01, l23);
+            *(uint2*)(p.out_hi + (int64_t)row * p.ld_split + spl_col(col)) = make_uint2(h01, h23);
+            *(uint2*)(p.out_lo + (int64_t)row * p.ld_split + spl_col(col)) = make_uint2(l01, l23);
           }
         }
     }
@@ -456,6 +455,21 @@ __global__ void split_bf16_kernel(const float* __restrict__ src, uint16_t* __res
   }
 }
 
+// f32 [rows][k] -> SPL32 bf16 [rows][2k]
+__global__ void split_spl32_kernel(const float* __restrict__ src, int64_t lds, uint16_t* __restrict__ dst, int64_t ldd,
+                                   int64_t rows, int k) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = rows * k, stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int64_t r = i / k;
+    const int c = (int)(i - r * k);
+    const float x = src[r * lds + c];
+    const uint16_t h = f2bf(x);
+    dst[r * ldd + spl_col(c)] = h;
+    dst[r * ldd + spl_col(c) + 32] = f2bf(x - bf2f(h));
+  }
+}
+
 }  // namespace gims
 
 static int linear_validate(const gims_linear_args* a) {
@@ -471,7 +485,9 @@ static int linear_validate(const gims_linear_args* a) {
     GIMS_CHECK_ARG(a->precision == GIMS_PREC_BF16X3 && a->w_lo, "gims_linear: pre-split A needs GIMS_PREC_BF16X3 and w_lo");
     GIMS_CHECK_ARG(a->k0 == a->k || a->a1_lo, "gims_linear: second A segment needs its lo plane");
     GIMS_CHECK_ARG((a->k % 32) == 0 && (a->k0 % 32) == 0, "gims_linear(pre-split): K=%d k0=%d must be multiples of 32", a->k, a->k0);
-    GIMS_CHECK_ARG((a->lda0 % 8) == 0 && (a->lda1 % 8) == 0 && (a->ldw % 8) == 0, "gims_linear(pre-split): lda / ldw must be multiples of 8");
+    GIMS_CHECK_ARG((a->lda0 % 64) == 0 && (a->lda1 % 64) == 0 && (a->ldw % 64) == 0 && a->lda0 >= 2 * a->k0 && a->ldw >= 2 * a->k,
+                   "gims_linear(pre-split): SPL32 operands have row pitch >= 2*K, a multiple of 64 elements");
+    GIMS_CHECK_ARG((((uintptr_t)a->a0 | (uintptr_t)a->w | (uintptr_t)a->a1) & 127) == 0, "gims_linear(pre-split): SPL32 operands must be 128-byte aligned");
     GIMS_CHECK_ARG((a->n % 4) == 0 && (a->ldc % 4) == 0 && (a->ldc_bf16 % 4) == 0 && (a->ld_split % 4) == 0,
                    "gims_linear(pre-split): n and output pitches must be multiples of 4");
     return GIMS_OK;
@@ -511,14 +527,14 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
   if (a->a0_lo) {
     // tile geometry: 256x256 (half the operand bytes per MFMA) when that still gives ~one workgroup per CU,
     // else 128x128.  GIMS_X3P_TILE=128|256 forces one (experiments).
-    using TS = X3P<128, 128, 2, 2, 32, 2>;
-    using TL = X3P<256, 256, 4, 2, 32, 2>;
+    using TS = X3P<128, 128, 2, 2, 2>;
+    using TL = X3P<256, 256, 4, 2, 2>;
     static int force = -1;
     if (force < 0) {
       const char* e = getenv("GIMS_X3P_TILE");
       force = e ? atoi(e) : 0;
-      const void* fs = (const void*)linear_x3p_kernel<128, 128, 2, 2, 32, 2>;
-      const void* fl = (const void*)linear_x3p_kernel<256, 256, 4, 2, 32, 2>;
+      const void* fs = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2>;
+      const void* fl = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2>;
       constexpr int ls = TS::LDS_BYTES, ll = TL::LDS_BYTES;
       GIMS_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
       GIMS_HIP(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
@@ -527,10 +543,10 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
     const bool big = force == 256 || (force != 128 && big_blocks >= 192);
     if (big) {
       constexpr size_t lds = TL::LDS_BYTES;
-      hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 32, 2>), dim3(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256)), dim3(512), lds, s, *a);
+      hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256)), dim3(512), lds, s, *a);
     } else {
       constexpr size_t lds = TS::LDS_BYTES;
-      hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 32, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
+      hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
     }
   } else if (a->precision == GIMS_PREC_F32) {
     hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, s, *a);
@@ -567,6 +583,17 @@ extern "C" int gims_linear_batch(const gims_linear_args* dev_args, int32_t count
   } else {
     GIMS_CHECK_ARG(false, "gims_linear_batch: unknown precision %d", precision);
   }
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_split_spl32(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int32_t k, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(src && dst && rows >= 0 && k > 0 && (k % 32) == 0 && ldd >= 2 * (int64_t)k, "gims_split_spl32: bad arguments");
+  if (rows == 0) return GIMS_OK;
+  int64_t blocks = (rows * k + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_spl32_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, k);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

@@ -162,10 +162,12 @@ class GMatcher(nn.Module):
         def dev(t):
             return t.contiguous().to(device)
 
-        def lin(w, b):   # a linear layer in the configured precision
+        def lin(w, b, spl=False):   # a linear layer in the configured precision (spl: SPL32 operands, LDS-DMA kernel)
             w = w.contiguous()
-            e = {"b": dev(b), "n": w.shape[0], "k": w.shape[1]}
-            if x3 and w.shape[1] % 64 == 0:
+            e = {"b": dev(b), "n": w.shape[0], "k": w.shape[1], "spl": False}
+            if x3 and spl:
+                e.update(w=hip.split_spl32(dev(w)), w_lo=None, prec=hip.PREC_BF16X3, spl=True)
+            elif x3 and w.shape[1] % 64 == 0:
                 hi, lo = hip.split_bf16(dev(w))
                 e.update(w=hi, w_lo=lo, prec=hip.PREC_BF16X3)
             else:
@@ -205,26 +207,26 @@ class GMatcher(nn.Module):
                 w0f = torch.cat([w0[:, :D].double(), w0m @ wm.double()], 1).float()
                 b0f = (b0.double() + w0m @ sd[p + "attn.merge.bias"].double()).float()
             P["layers"].append({
-                "mlp0_fused": lin(w0f, b0f) if w0f is not None else None,
-                "qkv": lin(torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)),
-                "merge": lin(wm, sd[p + "attn.merge.bias"]),
-                "mlp0": lin(w0, b0),
-                "mlp1": lin(sd[p + "mlp.3.weight"][:, :, 0], sd[p + "mlp.3.bias"]),
+                "mlp0_fused": lin(w0f, b0f, True) if w0f is not None else None,
+                "qkv": lin(torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0), True),
+                "merge": lin(wm, sd[p + "attn.merge.bias"], True),
+                "mlp0": lin(w0, b0, True),
+                "mlp1": lin(sd[p + "mlp.3.weight"][:, :, 0], sd[p + "mlp.3.bias"], True),
                 "cross": self.config['transformer_layers'][l] == 'cross',
             })
-        P["final"] = lin(sd["final_proj.weight"][:, :, 0], sd["final_proj.bias"])
+        P["final"] = lin(sd["final_proj.weight"][:, :, 0], sd["final_proj.bias"], True)
         P["alpha"] = float(sd["bin_score"])
         self._pack, self._pack_key = P, key
         return P
 
     @staticmethod
     def _lin(e, a0, **kw):
-        return hip.linear(a0, e["w"], w_lo=e["w_lo"], bias=e["b"], precision=e["prec"], **kw)
+        return hip.linear(a0, e["w"], w_lo=e["w_lo"], bias=e["b"], precision=e["prec"], spl=e["spl"], **kw)
 
     @staticmethod
-    def _planes(rows, cols, dev):
-        t = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=dev)
-        return t[0], t[1]
+    def _spl(rows, cols, dev):
+        """SPL32 split-bf16 activation buffer for a logical [rows, cols] matrix (see include/gims_hip.h)."""
+        return torch.empty((rows, 2 * cols), dtype=torch.bfloat16, device=dev)
 
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
     def enable_timing(self, on: bool = True):
@@ -349,7 +351,7 @@ class GMatcher(nn.Module):
         with St("kenc"):
             x = torch.empty((n_tot, P["kenc_w1"].shape[0]), dtype=torch.float32, device=dev)
             hip.kenc_first(kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], x)
-            dpl = self._planes(n_tot, D, dev) if x3 else None      # bf16 hi/lo planes of the residual stream
+            dpl = self._spl(n_tot, D, dev) if x3 else None          # split-bf16 (SPL32) copy of the residual stream
             for i, e in enumerate(P["kenc"]):
                 last = i == len(P["kenc"]) - 1
                 x = self._lin(e, x, act=hip.ACT_NONE if last else hip.ACT_RELU, residual=sage if last else None,
@@ -364,21 +366,21 @@ class GMatcher(nn.Module):
         max_nq = max(g["n_kept"] for g in images)
         qkv = torch.empty((n_tot, 3 * D), dtype=torch.bfloat16, device=dev)
         if x3:
-            # all GEMM operands travel as bf16 hi/lo planes written by the producing kernel's epilogue; only the
+            # all GEMM operands travel as split-bf16 SPL32 buffers written by the producing kernel's epilogue; only the
             # residual stream `desc` also exists in f32
-            mpl, gpl, hpl = self._planes(n_tot, D, dev), self._planes(n_tot, D, dev), self._planes(n_tot, 2 * D, dev)
+            mpl, gpl, hpl = self._spl(n_tot, D, dev), self._spl(n_tot, D, dev), self._spl(n_tot, 2 * D, dev)
             for L in P["layers"]:
                 with St("qkv"):
-                    self._lin(L["qkv"], dpl[0], a0_lo=dpl[1], out_bf16=qkv)
+                    self._lin(L["qkv"], dpl, out_bf16=qkv)
                 with St("attn_cross" if L["cross"] else "attn_self"):
                     hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl)
                 with St("mlp"):
                     if L["mlp0_fused"] is not None:
-                        self._lin(L["mlp0_fused"], dpl[0], a0_lo=dpl[1], a1=mpl[0], a1_lo=mpl[1], act=hip.ACT_RELU, out_split=hpl)
+                        self._lin(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl)
                     else:
-                        self._lin(L["merge"], mpl[0], a0_lo=mpl[1], out_split=gpl)
-                        self._lin(L["mlp0"], dpl[0], a0_lo=dpl[1], a1=gpl[0], a1_lo=gpl[1], act=hip.ACT_RELU, out_split=hpl)
-                    self._lin(L["mlp1"], hpl[0], a0_lo=hpl[1], residual=desc, out=desc, out_split=dpl)   # desc += delta (gmatcher.py:142)
+                        self._lin(L["merge"], mpl, out_split=gpl)
+                        self._lin(L["mlp0"], dpl, a1=gpl, act=hip.ACT_RELU, out_split=hpl)
+                    self._lin(L["mlp1"], hpl, residual=desc, out=desc, out_split=dpl)   # desc += delta (gmatcher.py:142)
         else:
             msg = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
             mrg = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
@@ -397,7 +399,7 @@ class GMatcher(nn.Module):
                     self._lin(L["mlp1"], hid, residual=desc, out=desc)          # desc += delta  (gmatcher.py:142)
         # ---- final projection, score matrix, Sinkhorn, selection (gmatcher.py:273-294)
         with St("final_scores"):
-            mdesc = self._lin(P["final"], dpl[0], a0_lo=dpl[1]) if x3 else self._lin(P["final"], desc)
+            mdesc = self._lin(P["final"], dpl) if x3 else self._lin(P["final"], desc)
             items, largs = [], []
             tot0, tot1 = sum(n0 for (_, n0), _ in pairs), sum(n1 for _, (_, n1) in pairs)
             m0_all = torch.empty(tot0, dtype=torch.int64, device=dev)

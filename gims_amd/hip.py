@@ -63,6 +63,7 @@ _SIGNATURES = {
     "gims_linear_put": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p, C.c_void_p]),
     "gims_linear_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_split_spl32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_void_p]),
@@ -134,27 +135,36 @@ def _dev(t: torch.Tensor, dtype=None):
 
 
 def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
-                precision=PREC_F32, scale=1.0, n=None, a0_lo=None, a1_lo=None, out_split=None):
-    """Build the C struct.  a0/a1: f32 [m,k*] -- or, with a0_lo/a1_lo, bf16 hi/lo planes (pre-split activations).
-    out_split = (hi, lo) bf16 planes."""
-    m, k0 = a0.shape
-    k = k0 + (a1.shape[1] if a1 is not None else 0)
-    n = w.shape[0] if n is None else n
-    assert w.shape[1] == k and a0.stride(1) == 1 and w.stride(1) == 1, (w.shape, k)
-    if a0_lo is not None:
-        assert a0.dtype == torch.bfloat16 and a0_lo.dtype == torch.bfloat16 and a0_lo.stride(0) == a0.stride(0)
-        assert a1 is None or (a1_lo is not None and a1_lo.stride(0) == a1.stride(0))
+                precision=PREC_F32, scale=1.0, n=None, spl=False, out_split=None):
+    """Build the C struct.
+    spl=False: a0/a1 f32 [m,k*]; w f32 [n,K] (PREC_F32) or bf16 hi plane with w_lo (PREC_BF16X3).
+    spl=True : a0/a1/w are SPL32 bf16 buffers [rows, 2*k] (see include/gims_hip.h), precision BF16X3.
+    out_split: SPL32 bf16 buffer [m, >= 2n] receiving the result split into hi/lo."""
+    m = a0.shape[0]
+    if spl:
+        assert a0.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and precision == PREC_BF16X3
+        k0 = a0.shape[1] // 2
+        k = k0 + (a1.shape[1] // 2 if a1 is not None else 0)
+        assert w.shape[1] == 2 * k, (w.shape, k)
+        a0_lo, a1_lo, w_lo = a0[:, 32:], (a1[:, 32:] if a1 is not None else None), w[:, 32:]
     else:
         _dev(a0, torch.float32)
+        k0 = a0.shape[1]
+        k = k0 + (a1.shape[1] if a1 is not None else 0)
+        assert w.shape[1] == k, (w.shape, k)
+        a0_lo = a1_lo = None
+    n = w.shape[0] if n is None else n
+    assert a0.stride(1) == 1 and w.stride(1) == 1
     if residual is not None:
         assert out is not None and residual.stride(0) == out.stride(0)
-    hi, lo = out_split if out_split is not None else (None, None)
-    assert hi is None or hi.stride(0) == lo.stride(0)
+    if out_split is not None:
+        assert out_split.dtype == torch.bfloat16 and out_split.shape[1] >= 2 * n and out_split.stride(1) == 1
     return LinearArgs(_p(a0), a0.stride(0), _p(a1), a1.stride(0) if a1 is not None else 0,
                       _p(w), _p(w_lo), w.stride(0), _p(bias), _p(residual), _p(out),
                       out.stride(0) if out is not None else 0, _p(out_bf16),
                       out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale),
-                      _p(a0_lo), _p(a1_lo), _p(hi), _p(lo), hi.stride(0) if hi is not None else 0, 0)
+                      _p(a0_lo), _p(a1_lo), _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
+                      out_split.stride(0) if out_split is not None else 0, 0)
 
 
 def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):
@@ -180,6 +190,24 @@ def linear(a0, w, *, out=None, out_bf16=None, out_split=None, **kw):
     return out if out is not None else (out_bf16 if out_bf16 is not None else out_split)
 
 
+def split_spl32(x: torch.Tensor, out: torch.Tensor | None = None):
+    """f32 [rows, k] -> SPL32 bf16 [rows, 2k] (32 hi | 32 lo per 32-channel block)."""
+    lib = load()
+    rows, k = x.shape
+    assert x.stride(1) == 1 and k % 32 == 0
+    if out is None:
+        out = torch.empty((rows, 2 * k), dtype=torch.bfloat16, device=x.device)
+    _check(lib.gims_split_spl32(_p(_dev(x, torch.float32)), x.stride(0), _p(out), out.stride(0), rows, k, _stream()), "gims_split_spl32")
+    return out
+
+
+def spl32_planes(buf: torch.Tensor):
+    """Decode an SPL32 buffer [rows, 2k] into (hi, lo) bf16 tensors [rows, k] (test / debug helper)."""
+    rows, k2 = buf.shape
+    v = buf.reshape(rows, k2 // 64, 2, 32)
+    return v[:, :, 0, :].reshape(rows, k2 // 2), v[:, :, 1, :].reshape(rows, k2 // 2)
+
+
 def split_bf16(x: torch.Tensor):
     lib = load()
     x = x.contiguous()
@@ -192,13 +220,13 @@ def split_bf16(x: torch.Tensor):
 def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: int, out=None,
               q_col=0, k_col=256, v_col=512, out_split=None):
     """qkv bf16 [rows, ld]; problems int32 [P,4] (q_off, n_q, kv_off, n_kv) on device; out f32 [rows, ld_out]
-    and/or out_split = (hi, lo) bf16 planes."""
+    and/or out_split = SPL32 bf16 buffer [rows, >= 512]."""
     lib = load()
     assert qkv.dtype == torch.bfloat16 and problems.dtype == torch.int32 and problems.is_cuda
-    hi, lo = out_split if out_split is not None else (None, None)
     _check(lib.gims_attention(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0],
-                              max_n_q, n_heads, _p(out), out.stride(0) if out is not None else 0, _p(hi), _p(lo),
-                              hi.stride(0) if hi is not None else 0, _stream()), "gims_attention")
+                              max_n_q, n_heads, _p(out), out.stride(0) if out is not None else 0, _p(out_split),
+                              (out_split.data_ptr() + 64) if out_split is not None else None,
+                              out_split.stride(0) if out_split is not None else 0, _stream()), "gims_attention")
     return out if out is not None else out_split
 
 

@@ -69,11 +69,13 @@ typedef struct gims_linear_args {
   int32_t act;                         /* GIMS_ACT_* */
   int32_t precision;                   /* GIMS_PREC_* */
   float scale;                         /* applied to the accumulator before bias (1.0 = none) */
-  /* pre-split activations (hot path of the attentional GNN): when a0_lo != NULL, a0/a0_lo (and a1/a1_lo)
-   * are bf16 hi/lo PLANES [m][lda] written by the producing kernel (lda in bf16 elements), precision must
-   * be GIMS_PREC_BF16X3, and the LDS-DMA kernel is used.  Not available through gims_linear_batch. */
+  /* pre-split operands (hot path of the attentional GNN): when a0_lo != NULL, a0 (and a1) and w are bf16 buffers in
+   * the SPL32 layout written by the producing kernel / gims_split_spl32: logical [rows][K] stored as [rows][pitch >= 2K],
+   * per row and 32-channel block 32 hi values then 32 lo values (hi = bf16(x), lo = bf16(x - hi)); channel k sits at
+   * (k/32)*64 + k%32 (hi) and +32 (lo).  a0_lo = a0 + 32, w_lo = w + 32 (the kernel only uses them as flags), lda/ldw
+   * are the pitches, 128-byte aligned.  precision must be GIMS_PREC_BF16X3.  Not available through gims_linear_batch. */
   const uint16_t* a0_lo; const uint16_t* a1_lo;
-  /* optional split output: hi = bf16(v), lo = bf16(v - hi), both [m][ld_split] */
+  /* optional split output in the SPL32 layout: out_hi = base, out_lo = base + 32, ld_split = pitch (>= 2n) */
   uint16_t* out_hi; uint16_t* out_lo; int64_t ld_split;
   /* GIMS_LINEAR_UPPER: symmetric product (A == W): skip output tiles that lie entirely below the diagonal */
   int32_t flags;
@@ -91,6 +93,8 @@ int gims_linear_batch(const gims_linear_args* dev_args, int32_t count, int32_t m
 
 /* Split an f32 array into bf16 hi/lo planes (hi = bf16_rne(x), lo = bf16_rne(x - hi)). */
 int gims_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
+/* f32 [rows][k] (pitch lds) -> SPL32 bf16 [rows][2k] (pitch ldd); k % 32 == 0. */
+int gims_split_spl32(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int32_t k, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-head attention message   O = softmax(Q K^T / sqrt(dh)) V   per head, flash-style.
@@ -100,8 +104,8 @@ int gims_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, voi
  *      (view(B, dh, H, N), gmatcher.py:111) into the projection weights).
  * Each problem p attends queries [q_off, q_off+n_q) to keys/values [kv_off, kv_off+n_kv).
  * out: f32 [rows][ld_out], head-blocked columns h*64 + d.       dh = 64, heads = n_heads.
- * out_hi/out_lo: the same result as split-bf16 planes (hi = bf16(o), lo = bf16(o - hi)) for the pre-split
- * linear that consumes the message.
+ * out_hi/out_lo: the same result in the SPL32 split-bf16 layout (out_lo = out_hi + 32, ld_split = pitch >= 512) for
+ * the pre-split linear that consumes the message.
  */
 typedef struct gims_attn_problem { int32_t q_off, n_q, kv_off, n_kv; } gims_attn_problem;
 

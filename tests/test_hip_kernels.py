@@ -71,7 +71,7 @@ def test_linear(hip, prec, m, n, k, k0):
 
 
 @pytest.mark.parametrize("m,n,k,k0", [(128, 128, 32, 32), (300, 768, 256, 256), (1000, 512, 512, 256), (77, 100, 128, 64),
-                                       (4096, 256, 512, 512), (513, 132, 64, 32)])
+                                       (4096, 256, 512, 512), (513, 132, 64, 32), (60000, 256, 256, 256)])
 def test_linear_presplit(hip, m, n, k, k0):
     """LDS-DMA kernel on pre-split bf16 planes: same contract as gims_linear, all three output kinds at once."""
     r = _rng(m * 3 + n)
@@ -82,21 +82,31 @@ def test_linear_presplit(hip, m, n, k, k0):
     res = r.normal(size=(m, n)).astype(np.float32)
     ref = np.maximum(a.astype(np.float64) @ w.astype(np.float64).T * 0.5 + bias, 0) + res
     scale_ref = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T * 0.5 + np.abs(bias) + np.abs(res)
-    ah, al = hip.split_bf16(_dev(a))
-    wh, wl = hip.split_bf16(_dev(w))
+    A, W = hip.split_spl32(_dev(a)), hip.split_spl32(_dev(w))          # SPL32 buffers [rows, 2K]
     out = _dev(res)
     ob = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
-    hi = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
-    lo = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
-    kw = dict(a1=ah[:, k0:], a1_lo=al[:, k0:]) if k0 < k else {}
-    hip.linear(ah[:, :k0], wh, a0_lo=al[:, :k0], w_lo=wl, bias=_dev(bias), residual=out, out=out, out_bf16=ob, out_split=(hi, lo),
+    osp = torch.zeros((m, 2 * ((n + 31) // 32 * 32)), dtype=torch.bfloat16, device="cuda")
+    kw = dict(a1=A[:, 2 * k0:]) if k0 < k else {}
+    hip.linear(A[:, :2 * k0], W, spl=True, bias=_dev(bias), residual=out, out=out, out_bf16=ob, out_split=osp,
                act=hip.ACT_RELU, precision=hip.PREC_BF16X3, scale=0.5, **kw)
     o = out.cpu().numpy()
     err = np.abs(o - ref) / scale_ref
     assert err.max() < 4e-5, f"max scaled err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
-    rec = hi.float().cpu().numpy().astype(np.float64) + lo.float().cpu().numpy()
+    hi, lo = hip.spl32_planes(osp)
+    rec = (hi.float().cpu().numpy().astype(np.float64) + lo.float().cpu().numpy())[:, :n]
     assert (np.abs(rec - o) <= np.abs(o) * 2.0 ** -15 + 1e-30).all()
     np.testing.assert_array_equal(ob.cpu().view(torch.int16).numpy(), torch.from_numpy(o).to(torch.bfloat16).view(torch.int16).numpy())
+
+
+def test_split_spl32_layout(hip):
+    x = _rng(2).normal(size=(37, 96)).astype(np.float32) * 5
+    buf = hip.split_spl32(_dev(x))
+    hi, lo = hip.spl32_planes(buf)
+    h2, l2 = hip.split_bf16(_dev(x))
+    assert torch.equal(hi, h2) and torch.equal(lo, l2)
+    b = buf.cpu().view(torch.int16).numpy()
+    np.testing.assert_array_equal(b[:, 64:96], h2.cpu().view(torch.int16).numpy()[:, 32:64])     # block 1 hi
+    np.testing.assert_array_equal(b[:, 96:128], l2.cpu().view(torch.int16).numpy()[:, 32:64])    # block 1 lo
 
 
 def test_split_bf16(hip):
@@ -143,9 +153,9 @@ def test_attention(hip, sizes, sharp):
         assert err < 1.5e-2 * max(1.0, np.abs(v).max() / 4), f"attention err {err:.3e} (nq={nq}, nk={nk})"
         assert np.isnan(o[ko:ko + nk]).all()      # rows that are not queries are untouched
     # split-plane output carries the same values
-    hi = torch.zeros((rows, 256), dtype=torch.bfloat16, device="cuda")
-    lo = torch.zeros((rows, 256), dtype=torch.bfloat16, device="cuda")
-    hip.attention(qkv_b.cuda(), torch.tensor(probs, dtype=torch.int32, device="cuda"), max(s[0] for s in sizes), 4, None, out_split=(hi, lo))
+    osp = torch.zeros((rows, 512), dtype=torch.bfloat16, device="cuda")
+    hip.attention(qkv_b.cuda(), torch.tensor(probs, dtype=torch.int32, device="cuda"), max(s[0] for s in sizes), 4, None, out_split=osp)
+    hi, lo = hip.spl32_planes(osp)
     rec = hi.float().cpu().numpy().astype(np.float64) + lo.float().cpu().numpy()
     for qo, nq, ko, nk in probs:
         assert (np.abs(rec[qo:qo + nq] - o[qo:qo + nq]) <= np.abs(o[qo:qo + nq]) * 2.0 ** -15 + 1e-30).all()
