@@ -14,6 +14,8 @@
 // the sequential fix-ups only flip bits and the CSR falls out of popcounts in ascending neighbour order.
 #include "common.h"
 
+#include <vector>
+
 namespace gims {
 
 constexpr int AGC_MAX_N = 16384;
@@ -47,20 +49,15 @@ struct AgcWs {
   int n, d, lds, nw, cap, max_edges_dir;
 };
 
-struct Blob512 { char b[512]; };
-static_assert(sizeof(AgcWs) <= sizeof(Blob512), "AgcWs must fit the by-value upload blob");
-
-// uploads one descriptor by value (kernel argument) and resets the per-image counters: no host staging
-// buffer, no hipMemcpy, no stream synchronisation
-__global__ void agc_setup_kernel(Blob512 blob, AgcWs* __restrict__ dst) {
-  const AgcWs* src = (const AgcWs*)blob.b;
+// per-image reset of the select state and counters (descriptors are already in device memory, see upload_table)
+__global__ void agc_init_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
   if (threadIdx.x == 0) {
-    *dst = *src;
-    src->sel[0] = 0u; src->sel[1] = (uint32_t)(src->krank & 0xffffffffll); src->sel[2] = (uint32_t)(src->krank >> 32); src->sel[3] = 0u;
-    for (int i = 0; i < 8; ++i) src->info[i] = 0;
-    for (int i = 0; i < 16; ++i) src->counters[i] = 0;
+    w.sel[0] = 0u; w.sel[1] = (uint32_t)(w.krank & 0xffffffffll); w.sel[2] = (uint32_t)(w.krank >> 32); w.sel[3] = 0u;
+    for (int i = 0; i < 8; ++i) w.info[i] = 0;
+    for (int i = 0; i < 16; ++i) w.counters[i] = 0;
   }
-  src->hist[threadIdx.x] = 0u;
+  w.hist[threadIdx.x] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------- K1 prologue
@@ -621,13 +618,14 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     GIMS_HIP(hipFuncSetAttribute((const void*)agc_iso_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AGC_MAX_N * 4 + (AGC_MAX_N / 32 + 2) * 4));
     attr_set = true;
   }
+  std::vector<AgcWs> hws(n_images);
+  std::vector<gims_linear_args> hla(n_images);
   for (int i = 0; i < n_images; ++i) {
     const gims_agc_image& im = images[i];
     GIMS_CHECK_ARG(im.kpts && im.desc && im.kept && im.indptr && im.indices && im.info, "gims_agc_build: image %d has a null pointer", i);
     GIMS_CHECK_ARG(im.n >= 2 && im.n <= AGC_MAX_N, "gims_agc_build: image %d: n=%d out of range [2, %d]", i, im.n, AGC_MAX_N);
     GIMS_CHECK_ARG(im.d > 0 && (im.d % 32) == 0 && (im.ldd % 4) == 0, "gims_agc_build: image %d: d=%d must be a multiple of 32 (ldd %% 4 == 0)", i, im.d);
-    Blob512 blob;
-    AgcWs* w = (AgcWs*)blob.b;
+    AgcWs* w = &hws[i];
     base += agc_layout(im.n, im.d, base, w);
     w->kpts = im.kpts; w->desc = im.desc; w->ldd = im.ldd; w->kept = im.kept; w->indptr = im.indptr; w->indices = im.indices;
     w->info = im.info; w->max_edges_dir = im.max_edges_dir;
@@ -637,18 +635,23 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     if (k >= L) k = L - 1;
     if (k < 0) k = 0;
     w->krank = k;
-    hipLaunchKernelGGL(agc_setup_kernel, dim3(1), dim3(256), 0, s, blob, dws + i);
     // K1 GEMM descriptor: S = Dn Dn^T in exact f32
     gims_linear_args la = {};
     la.a0 = w->dn; la.lda0 = im.d; la.w = w->dn; la.ldw = im.d; la.out_f32 = w->S; la.ldc = w->lds;
     la.m = im.n; la.n = im.n; la.k = im.d; la.k0 = im.d; la.act = GIMS_ACT_NONE; la.precision = GIMS_PREC_F32; la.scale = 1.f;
     la.flags = GIMS_LINEAR_UPPER;    // only S[i][j], i < j, is ever read (threshold select and edge test)
-    int rc = gims_linear_put(&la, dla + i, stream);
-    if (rc != GIMS_OK) return rc;
+    hla[i] = la;
     maxn = im.n > maxn ? im.n : maxn;
     maxnw = w->nw > maxnw ? w->nw : maxnw;
   }
   const int B = n_images;
+  {
+    int rc = upload_table(hws.data(), sizeof(AgcWs) * (size_t)B, dws, s);
+    if (rc != GIMS_OK) return rc;
+    rc = upload_table(hla.data(), sizeof(gims_linear_args) * (size_t)B, dla, s);
+    if (rc != GIMS_OK) return rc;
+    hipLaunchKernelGGL(agc_init_kernel, dim3(1, B), dim3(256), 0, s, dws);
+  }
   const dim3 gw(cdiv(maxn, 4), B), g1(1, B);
   // K1
   hipLaunchKernelGGL(agc_normalize_kernel, gw, dim3(256), 0, s, dws);

@@ -87,4 +87,8 @@ __device__ __forceinline__ float key_f32(uint32_t k) {
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Host descriptor table -> device memory through KERNEL ARGUMENTS (chunks of <= 3968 bytes per launch): asynchronous on
+// the stream, no staging buffer whose lifetime would need a synchronisation, no pageable-memory pinning by the runtime.
+int upload_table(const void* host, size_t bytes, void* dev, hipStream_t stream);
+
 }  // namespace gims

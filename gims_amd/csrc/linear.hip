@@ -568,6 +568,17 @@ extern "C" int gims_linear_put(const gims_linear_args* a, gims_linear_args* dev_
   return GIMS_OK;
 }
 
+extern "C" int gims_linear_put_many(const gims_linear_args* h_args, int32_t count, gims_linear_args* dev_dst, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(h_args && count > 0 && dev_dst, "gims_linear_put_many: bad arguments");
+  for (int i = 0; i < count; ++i) {
+    const int rc = linear_validate(h_args + i);
+    if (rc != GIMS_OK) return rc;
+    GIMS_CHECK_ARG(h_args[i].a0_lo == nullptr, "gims_linear_put_many: pre-split operands are not available in batches");
+  }
+  return upload_table(h_args, sizeof(gims_linear_args) * (size_t)count, dev_dst, (hipStream_t)stream);
+}
+
 extern "C" int gims_linear_batch(const gims_linear_args* dev_args, int32_t count, int32_t max_m, int32_t max_n,
                                  int32_t precision, void* stream) {
   using namespace gims;

@@ -3,6 +3,7 @@
 #include "common.h"
 
 #include <stdarg.h>
+#include <string.h>
 
 namespace gims {
 
@@ -12,6 +13,24 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+struct Blob4K { uint4 v[248]; };   // 3968 bytes: below the 4 KiB kernel-argument limit
+__global__ void put_blob_kernel(Blob4K blob, uint4* __restrict__ dst, int n16) {
+  if ((int)threadIdx.x < n16) dst[threadIdx.x] = blob.v[threadIdx.x];
+}
+
+int upload_table(const void* host, size_t bytes, void* dev, hipStream_t stream) {
+  const char* h = (const char*)host;
+  char* d = (char*)dev;
+  for (size_t off = 0; off < bytes; off += sizeof(Blob4K)) {
+    Blob4K blob;
+    const size_t n = bytes - off < sizeof(Blob4K) ? bytes - off : sizeof(Blob4K);
+    memcpy(&blob, h + off, n);
+    hipLaunchKernelGGL(put_blob_kernel, dim3(1), dim3(256), 0, stream, blob, (uint4*)(d + off), (int)((n + 15) / 16));
+  }
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
 }
 
 // normalize_keypoints (gmatcher.py:26-33) + Conv1d(2->c1) + BN(eval, folded) + ReLU (gmatcher.py:87-97)

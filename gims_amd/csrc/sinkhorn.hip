@@ -17,6 +17,8 @@
 
 #include <string.h>
 
+#include <vector>
+
 namespace gims {
 
 constexpr int OT_R = 8;  // rows per slab
@@ -62,11 +64,6 @@ __device__ __forceinline__ float wave_reduce_rows(float (&v)[R], int lane, int& 
   row_out = row;
   return x;
 }
-
-struct OtBlob { char b[256]; };
-static_assert(sizeof(OtDev) <= sizeof(OtBlob), "OtDev must fit the by-value upload blob");
-// one descriptor per launch, passed by value: no host staging buffer, no memcpy, no stream synchronisation
-__global__ void ot_setup_kernel(OtBlob blob, OtDev* __restrict__ dst) { *dst = *(const OtDev*)blob.b; }
 
 // ---------------------------------------------------------------------------------------------- init
 __global__ void ot_init_kernel(const OtDev* __restrict__ probs, float alpha, int zero_init) {
@@ -482,7 +479,7 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   int threads, cpt, maxn, maxm;
   ot_launch_shape(pr, np, threads, cpt, maxn, maxm);
   GIMS_CHECK_ARG(cpt <= 4, "gims_sinkhorn_match: m=%d too large (max 16384)", maxm);
-  OtDev* dprob = (OtDev*)work;
+  std::vector<OtDev> hprob(np);
   char* base = (char*)work;
   size_t off = al256(sizeof(OtDev) * (size_t)np);
   int maxG = 0;
@@ -508,9 +505,11 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     d.norm = -logf(ms + ns);
     d.log_mu_bin = logf(ns) + d.norm;                        // gmatcher.py:63
     d.log_nu_bin = logf(ms) + d.norm;                        // gmatcher.py:64
-    OtBlob blob;
-    memcpy(blob.b, &d, sizeof(OtDev));
-    hipLaunchKernelGGL(ot_setup_kernel, dim3(1), dim3(1), 0, s, blob, dprob + i);
+    hprob[i] = d;
+  }
+  {
+    const int rc = upload_table(hprob.data(), sizeof(OtDev) * (size_t)np, work, s);   // by kernel arguments: no sync
+    if (rc != GIMS_OK) return rc;
   }
   const OtDev* dp = (const OtDev*)work;
   hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, iters == 0 ? 1 : 0);

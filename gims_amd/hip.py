@@ -61,6 +61,7 @@ _SIGNATURES = {
     "gims_stream_sync": (C.c_int, [C.c_void_p]),
     "gims_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "gims_linear_put": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p, C.c_void_p]),
+    "gims_linear_put_many": (C.c_int, [C.POINTER(LinearArgs), C.c_int32, C.c_void_p, C.c_void_p]),
     "gims_linear_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_split_spl32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
@@ -173,8 +174,8 @@ def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):
     sz = C.sizeof(LinearArgs)
     assert dev_args.numel() * dev_args.element_size() >= sz * len(arg_list)
     st = _stream()
-    for i, a in enumerate(arg_list):
-        _check(lib.gims_linear_put(C.byref(a), dev_args.data_ptr() + i * sz, st), "gims_linear_put")
+    arr = (LinearArgs * len(arg_list))(*arg_list)
+    _check(lib.gims_linear_put_many(arr, len(arg_list), dev_args.data_ptr(), st), "gims_linear_put_many")
     _check(lib.gims_linear_batch(dev_args.data_ptr(), len(arg_list), max(a.m for a in arg_list), max(a.n for a in arg_list),
                                  precision, st), "gims_linear_batch")
 

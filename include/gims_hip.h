@@ -88,6 +88,7 @@ int gims_linear(const gims_linear_args* args, void* stream);
  * argument: no host staging copy, no synchronisation); gims_linear_batch launches all `count` problems,
  * grid sized for the largest (max_m x max_n).  All problems of a batch share `precision`. */
 int gims_linear_put(const gims_linear_args* args, gims_linear_args* dev_dst, void* stream);
+int gims_linear_put_many(const gims_linear_args* h_args /* HOST array */, int32_t count, gims_linear_args* dev_dst, void* stream);
 int gims_linear_batch(const gims_linear_args* dev_args, int32_t count, int32_t max_m, int32_t max_n,
                       int32_t precision, void* stream);
 
