@@ -21,6 +21,8 @@
 //     grows by more than 2^5 in probability units -- after the first tiles the accumulators stay in place.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace gims {
 
 constexpr int DH = 64;          // head dim
@@ -34,12 +36,15 @@ __device__ __forceinline__ int k_off(int row, int chunk) {  // K tile: [64 keys]
   return row * DH + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
+template <int QP>   // 32-query blocks per wave: 1 (32 queries/wave, 128/workgroup) or 2 (64 / 256)
 __global__ __launch_bounds__(256) void attention_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
     int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KB * DH];      // double-buffered: one barrier per key tile
   __shared__ __attribute__((aligned(16))) uint16_t Vt[2][DH * VT_LD];
+  constexpr int QWV = QW * QP;            // queries per wave
+  constexpr int QBK = QWV * ATT_WAVES;    // queries per workgroup
 
   // XCD-aware order (workgroup b -> XCD b % 8, private L2 per XCD): all query tiles of one (problem, head) get
   // consecutive slots on ONE XCD, so its K/V panel is fetched from HBM once, not once per query tile.
@@ -47,35 +52,39 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
   const int group = (slot / n_qt) * 8 + xcd;
   if (group >= n_groups) return;
   const gims_attn_problem pr = problems[group / n_heads];
-  const int q0 = (slot % n_qt) * QB;
+  const int q0 = (slot % n_qt) * QBK;
   if (q0 >= pr.n_q) return;
   const int head = group % n_heads;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 31, lh = lane >> 5;
 
-  // ---- Q^T B-operand fragments: lane holds Q[q = li][d = 16*s + 8*lh .. +8]
-  bf16x8 qf[4];
-  {
-    int qr = q0 + wave * QW + li;
+  // ---- Q^T B-operand fragments: lane holds Q[q = li][d = 16*s + 8*lh .. +8] for each of its QP query blocks
+  bf16x8 qf[QP][4];
+#pragma unroll
+  for (int qi = 0; qi < QP; ++qi) {
+    int qr = q0 + wave * QWV + qi * QW + li;
     qr = qr < pr.n_q ? qr : pr.n_q - 1;
     const uint16_t* qp = qkv + (int64_t)(pr.q_off + qr) * ld + q_col + head * DH + 8 * lh;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+    for (int s = 0; s < 4; ++s) qf[qi][s] = *(const bf16x8*)(qp + 16 * s);
   }
 
-  f32x16 o[2];  // O^T accumulator: d-block x 16 regs, column = query li
+  f32x16 o[QP][2];  // O^T accumulators: d-block x 16 regs, column = query li
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int qi = 0; qi < QP; ++qi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qi][i][r] = 0.f;
   const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
   // Deferred running max (rescale threshold): the accumulator is rescaled only when some row's tile max
   // exceeds its reference max by more than 2^DEFER in probability units; until then P is bounded by 2^DEFER
   // instead of 1, which bf16 (relative precision) and the f32 accumulators tolerate unchanged.
   constexpr float DEFER = 5.0f;
   const float defer_raw = DEFER / c;
-  float m_run = -1e30f;                           // reference max of raw scores (same for lane and lane^32)
-  float l_run = 0.f;                              // this lane's share of the row sum
+  float m_run[QP], l_run[QP];
+#pragma unroll
+  for (int qi = 0; qi < QP; ++qi) { m_run[qi] = -1e30f; l_run[qi] = 0.f; }
 
   // staging: K tile 64 rows x 8 chunks = 512 chunks (2 per thread); V tile: key pair kp = t&31, d-octet t>>5
   uint4 rk[2], rv[2];
@@ -120,71 +129,79 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
     const int buf = kt & 1;
     if (kt + 1 < n_tiles) load_tile(kt + 1);
 
-    // ---- S^T = K Q^T : two 32-key blocks x 32 queries, K = 64 (4 steps of 16)
-    f32x16 sacc[2];
-    __builtin_amdgcn_s_setprio(1);
+    // ---- S^T = K Q^T : two 32-key blocks x QP query blocks, K = 64 (4 steps of 16); K fragments shared by the query blocks
+    f32x16 sacc[QP][2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *(const bf16x8*)(Ks[buf] + k_off(b * 32 + li, 2 * s + lh));
-        sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[b], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    // ---- mask keys past the end (last tile only), tile max
-    const int kbase = kt * KB;
-    float tmax = -1e30f;
-    if (kbase + KB > pr.n_kv) {
+    for (int qi = 0; qi < QP; ++qi)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kbase + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= pr.n_kv) sacc[b][r] = -1e30f;
-        }
-    }
+        for (int r = 0; r < 16; ++r) sacc[qi][b][r] = 0.f;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    if (__any(tmax > m_run + defer_raw)) {          // wave-uniform, rare after the first tiles
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
-      l_run *= alpha;
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(Ks[buf] + k_off(b * 32 + li, 2 * s + lh));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int qi = 0; qi < QP; ++qi) sacc[qi][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][s], sacc[qi][b], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    const int kbase = kt * KB;
+    const bool partial = kbase + KB > pr.n_kv;
+    bf16x8 pf[QP][4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    }
-    const float mc = m_run * c;
-    // ---- P = exp2(S*c - m*c), packed to bf16 B-operand fragments in the lane's own key order
-    float lsum = 0.f;
-    bf16x8 pf[4];
+    for (int qi = 0; qi < QP; ++qi) {
+      // ---- mask keys past the end (last tile only), tile max
+      float tmax = -1e30f;
+      if (partial) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      float pv[16];
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[b][r], c, -mc));
-        lsum += pv[r];
+          for (int r = 0; r < 16; ++r) {
+            const int key = kbase + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (key >= pr.n_kv) sacc[qi][b][r] = -1e30f;
+          }
       }
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {  // 16-key step h2 of block b: regs 8*h2 .. 8*h2+7
-        uint4 pk;
-        pk.x = pack_bf2(pv[8 * h2 + 0], pv[8 * h2 + 1]);
-        pk.y = pack_bf2(pv[8 * h2 + 2], pv[8 * h2 + 3]);
-        pk.z = pack_bf2(pv[8 * h2 + 4], pv[8 * h2 + 5]);
-        pk.w = pack_bf2(pv[8 * h2 + 6], pv[8 * h2 + 7]);
-        pf[2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      if (__any(tmax > m_run[qi] + defer_raw)) {          // wave-uniform, rare after the first tiles
+        const float m_new = fmaxf(m_run[qi], tmax);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
+        m_run[qi] = m_new;
+        l_run[qi] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qi][i][r] *= alpha;
       }
+      const float mc = m_run[qi] * c;
+      // ---- P = exp2(S*c - m*c), packed to bf16 B-operand fragments in the lane's own key order
+      float lsum = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[qi][b][r], c, -mc));
+          lsum += pv[r];
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {  // 16-key step h2 of block b: regs 8*h2 .. 8*h2+7
+          uint4 pk;
+          pk.x = pack_bf2(pv[8 * h2 + 0], pv[8 * h2 + 1]);
+          pk.y = pack_bf2(pv[8 * h2 + 2], pv[8 * h2 + 3]);
+          pk.z = pack_bf2(pv[8 * h2 + 4], pv[8 * h2 + 5]);
+          pk.w = pack_bf2(pv[8 * h2 + 6], pv[8 * h2 + 7]);
+          pf[qi][2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
+        }
+      }
+      l_run[qi] += lsum;
     }
-    l_run += lsum;
-    // ---- O^T += V^T P^T : two 32-d blocks, 4 steps of 16 keys
+    // ---- O^T += V^T P^T : two 32-d blocks, 4 steps of 16 keys; V^T fragments shared by the query blocks
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -195,7 +212,8 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
         const uint2 v0 = *(const uint2*)(vp);
         const uint2 v1 = *(const uint2*)(vp + 8);
         const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
-        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o[i], 0, 0, 0);
+#pragma unroll
+        for (int qi = 0; qi < QP; ++qi) o[qi][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][s], o[qi][i], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -204,27 +222,30 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
   }
 
   // ---- normalise and store: lane holds query li, d = 32*i + 8*(r>>2) + 4*lh + (r&3)
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
-  const int qr = q0 + wave * QW + li;
-  if (qr < pr.n_q) {
-    const int64_t grow = pr.q_off + qr;
-    const int col0 = head * DH + 4 * lh;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int qi = 0; qi < QP; ++qi) {
+    const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+    const float inv = 1.f / l_tot;
+    const int qr = q0 + wave * QWV + qi * QW + li;
+    if (qr < pr.n_q) {
+      const int64_t grow = pr.q_off + qr;
+      const int col0 = head * DH + 4 * lh;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 v = make_float4(o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
-        const int col = col0 + 32 * i + 8 * g;
-        if (out) *(float4*)(out + grow * ld_out + col) = v;
-        if (out_hi) {
-          const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
-          const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
-          const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
-          *(uint2*)(out_hi + grow * ld_split + spl_col(col)) = make_uint2(h01, h23);
-          *(uint2*)(out_lo + grow * ld_split + spl_col(col)) = make_uint2(l01, l23);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = make_float4(o[qi][i][4 * g] * inv, o[qi][i][4 * g + 1] * inv, o[qi][i][4 * g + 2] * inv, o[qi][i][4 * g + 3] * inv);
+          const int col = col0 + 32 * i + 8 * g;
+          if (out) *(float4*)(out + grow * ld_out + col) = v;
+          if (out_hi) {
+            const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
+            const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+            const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+            *(uint2*)(out_hi + grow * ld_split + spl_col(col)) = make_uint2(h01, h23);
+            *(uint2*)(out_lo + grow * ld_split + spl_col(col)) = make_uint2(l01, l23);
+          }
         }
-      }
+    }
   }
 }
 
@@ -241,10 +262,21 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
   GIMS_CHECK_ARG((ld % 8) == 0 && (q_col % 8) == 0 && (k_col % 8) == 0 && (v_col % 8) == 0,
                  "gims_attention: qkv ld / column offsets must be multiples of 8 (16-byte loads)");
   GIMS_CHECK_ARG((ld_out % 4) == 0, "gims_attention: ld_out must be a multiple of 4");
-  const int n_qt = cdiv(max_n_q, QB), n_groups = n_heads * n_problems;
-  dim3 grid(8 * cdiv(n_groups, 8) * n_qt);
-  hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col,
-                     problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split);
+  const int n_groups = n_heads * n_problems;
+  // 64 queries per wave (K/V fragments and barriers shared by two query blocks) when that still fills the chip
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("GIMS_ATTN_QP"); force = e ? atoi(e) : 0; }
+  const int blocks2 = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB);
+  const bool two = force == 2 || (force != 1 && blocks2 >= 512);
+  if (two) {
+    const int n_qt = cdiv(max_n_q, 2 * QB);
+    hipLaunchKernelGGL(attention_bf16_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, (hipStream_t)stream, qkv, ld,
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split);
+  } else {
+    const int n_qt = cdiv(max_n_q, QB);
+    hipLaunchKernelGGL(attention_bf16_kernel<1>, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, (hipStream_t)stream, qkv, ld,
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split);
+  }
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

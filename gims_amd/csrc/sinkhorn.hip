@@ -169,7 +169,10 @@ __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__
       un[r] = ubase[row];
       const float* zr = zbase + (int64_t)row * p.ld;
 #pragma unroll
-      for (int s = 0; s < CPT; ++s) zn[r][s] = *(const float4*)(zr + cl[s]);
+      for (int s = 0; s < CPT; ++s) {   // streamed once per launch: non-temporal
+        const f32x4 z = __builtin_nontemporal_load((const f32x4*)(zr + cl[s]));
+        zn[r][s] = make_float4(z[0], z[1], z[2], z[3]);
+      }
     }
   };
   if ((int)blockIdx.x < n_slabs) load_slab(blockIdx.x);
