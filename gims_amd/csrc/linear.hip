@@ -294,7 +294,7 @@ struct X3P {
   static constexpr int PA = TM / 8, PW = TN / 8;                 // 1 KiB pieces (8 rows) per operand per stage
   static constexpr int PIECES = (PA + PW) / WAVES;               // pieces per wave per stage
   static constexpr int LDS_BYTES = S * STAGE * 2;
-  static_assert((PA + PW) % WAVES == 0 && PA % PIECES == 0 && PW % PIECES == 0, "a wave's pieces stay in one operand");
+  static_assert((PA + PW) % WAVES == 0, "pieces divide evenly over the waves");
   __device__ static __forceinline__ int swz(int row) { return (row >> 1) & 7; }
   __device__ static __forceinline__ int off(int row, int chunk) { return row * 64 + ((chunk ^ swz(row)) << 3); }
 };
@@ -317,29 +317,26 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   const int li = lane & 31, lh = lane >> 5;
   const int nk = p.k / BK;
 
-  // this wave's LDS-DMA duty: PIECES consecutive 8-row pieces of ONE operand (A rows | W rows)
+  // this wave's LDS-DMA duty: PIECES consecutive 8-row pieces of the stage image [A rows | W rows]
   const int p0 = wave * T::PIECES;
-  const bool is_a = p0 < T::PA;
-  const int piece0 = is_a ? p0 : p0 - T::PA;
   const int drow = lane >> 3, dpos = lane & 7;
   auto issue = [&](int kt) {
     const int k = kt * BK;
-    const uint16_t* base;
-    int64_t ld;
-    int kk, rmax, r0;
-    if (is_a) {
-      if (k < p.k0) { base = (const uint16_t*)p.a0; ld = p.lda0; kk = k; }
-      else { base = (const uint16_t*)p.a1; ld = p.lda1; kk = k - p.k0; }
-      rmax = p.m - 1; r0 = m0;
-    } else {
-      base = (const uint16_t*)p.w; ld = p.ldw; kk = k; rmax = p.n - 1; r0 = n0;
-    }
-    uint16_t* dst = smem + (kt % S) * T::STAGE + (is_a ? 0 : T::A_TILE) + piece0 * 512;
+    const bool second = k >= p.k0;
+    const uint16_t* abase = (const uint16_t*)(second ? p.a1 : p.a0);
+    const int64_t alda = second ? p.lda1 : p.lda0;
+    const int akk = second ? k - p.k0 : k;
+    uint16_t* dst = smem + (kt % S) * T::STAGE + p0 * 512;
 #pragma unroll
     for (int i = 0; i < T::PIECES; ++i) {
-      const int row = 8 * (piece0 + i) + drow;
-      int gr = r0 + row; gr = gr < rmax ? gr : rmax;
-      const uint16_t* g = base + (int64_t)gr * ld + 2 * kk + 8 * (dpos ^ T::swz(row));   // SPL32: block kk/32 starts at 2*kk
+      const int pp = p0 + i;                               // wave-uniform
+      const bool is_a = pp < T::PA;
+      const int row = 8 * (is_a ? pp : pp - T::PA) + drow;
+      int gr = (is_a ? m0 : n0) + row;
+      const int rmax = (is_a ? p.m : p.n) - 1;
+      gr = gr < rmax ? gr : rmax;
+      const uint16_t* g = (is_a ? abase + (int64_t)gr * alda + 2 * akk : (const uint16_t*)p.w + (int64_t)gr * p.ldw + 2 * k)
+                          + 8 * (dpos ^ T::swz(row));   // SPL32: block k/32 starts at element 2*k
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(dst + i * 512), 16, 0, 0);
     }
@@ -381,14 +378,20 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
         wh[i] = *(const bf16x8*)(st + T::A_TILE + T::off(wr, 2 * s + lh));
         wl[i] = *(const bf16x8*)(st + T::A_TILE + T::off(wr, 4 + 2 * s + lh));
       }
+      // term-major order: consecutive MFMAs hit DIFFERENT accumulators (no back-to-back dependent issue); per
+      // accumulator the order stays lo*hi, hi*lo, hi*hi (small terms first)
 #pragma unroll
       for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < T::MI; ++mi) {
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
-        }
+        for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
     }
   }
 
@@ -541,7 +544,32 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
     }
     const int big_blocks = cdiv(a->m, 256) * cdiv(a->n, 256);
     const bool big = force == 256 || (force != 128 && big_blocks >= 192);
-    if (big) {
+    if (force == 1283 || force == 1284 || force == 2563) {      // experimental ring geometries
+      static bool attr2 = false;
+      using T3 = X3P<256, 128, 4, 2, 3>;
+      using T4 = X3P<128, 128, 2, 2, 4>;
+      using T5 = X3P<128, 128, 2, 2, 3>;
+      if (!attr2) {
+        const void* f3 = (const void*)linear_x3p_kernel<256, 128, 4, 2, 3>;
+        const void* f4 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 4>;
+        const void* f5 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 3>;
+        constexpr int l3 = T3::LDS_BYTES, l4 = T4::LDS_BYTES, l5 = T5::LDS_BYTES;
+        GIMS_HIP(hipFuncSetAttribute(f3, hipFuncAttributeMaxDynamicSharedMemorySize, l3));
+        GIMS_HIP(hipFuncSetAttribute(f4, hipFuncAttributeMaxDynamicSharedMemorySize, l4));
+        GIMS_HIP(hipFuncSetAttribute(f5, hipFuncAttributeMaxDynamicSharedMemorySize, l5));
+        attr2 = true;
+      }
+      if (force == 2563) {
+        constexpr size_t lds = T3::LDS_BYTES;
+        hipLaunchKernelGGL((linear_x3p_kernel<256, 128, 4, 2, 3>), dim3(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 128)), dim3(512), lds, s, *a);
+      } else if (force == 1284) {
+        constexpr size_t lds = T4::LDS_BYTES;
+        hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 4>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
+      } else {
+        constexpr size_t lds = T5::LDS_BYTES;
+        hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 3>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
+      }
+    } else if (big) {
       constexpr size_t lds = TL::LDS_BYTES;
       hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256)), dim3(512), lds, s, *a);
     } else {
