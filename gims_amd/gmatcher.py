@@ -91,6 +91,9 @@ class GMatcher(nn.Module):
         # exact in real arithmetic (products formed in float64), removes one GEMM and one activation round trip per
         # layer; set False to run the reference's operation order
         'fuse_merge': True,
+        # match_pairs can split a batch into independent sub-batches on separate HIP streams.  Measured on MI355X: no gain
+        # (1840 vs 1874 pairs/s at 2x1024, 271 vs 267 at 2x4096) -- every stage already fills the chip -- so default 1.
+        'streams': 1,
     }
 
     def __init__(self, config):
@@ -267,16 +270,23 @@ class GMatcher(nn.Module):
     def _buf(self, name: str, nbytes: int) -> torch.Tensor:
         dev = torch.device("cuda", torch.cuda.current_device())
         arena = self.__dict__.setdefault("_arena", {})
-        t = arena.get((name, dev))
+        key = (name, dev, self._lane)              # one scratch set per stream lane (lanes run concurrently)
+        t = arena.get(key)
         if t is None or t.numel() < nbytes:
             t = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
-            arena[(name, dev)] = t
+            arena[key] = t
         return t
+
+    _lane = 0
 
     # ------------------------------------------------------------------ ragged core: 2P images -> P pair results
     def _run(self, images, radius, percentile, min_size):
         """images: list of dicts {kp (N,2) f32, de (N,D) f32 point-major, sc (N,), shape}; consecutive entries
         (2p, 2p+1) form pair p.  Every pair may keep a different number of keypoints (ragged batch)."""
+        return self._run_rest(self._run_build(images, radius, percentile, min_size))
+
+    def _run_build(self, images, radius, percentile, min_size):
+        """Phase 1: enqueue the adaptive graph construction (asynchronous; no host sync)."""
         cfg = self.config
         dev = images[0]["kp"].device
         P = self._packed(dev)
@@ -297,6 +307,16 @@ class GMatcher(nn.Module):
             agc_imgs = hip.make_agc_images([dict(kpts=g["kp"], desc=g["de"], kept=g["kept"], indptr=g["indptr"],
                                                  indices=g["indices"], info=info_all[i]) for i, g in enumerate(images)])
             hip.agc_build(agc_imgs, radius, percentile, min_size, self._buf("agc", hip.agc_workspace_bytes(agc_imgs)))
+        return dict(images=images, info_all=info_all, pool=pool)
+
+    def _run_rest(self, ctx):
+        """Phase 2: read the kept counts (the one host sync), then enqueue everything else."""
+        images, info_all = ctx["images"], ctx["info_all"]
+        cfg = self.config
+        dev = images[0]["kp"].device
+        P = self._packed(dev)
+        D = cfg['descriptor_dim']
+        St = lambda name: GMatcher._Stage(self, name)   # noqa: E731
         ts0 = time.perf_counter()
         infos = info_all.cpu().numpy()                                                    # the one host sync of the build
         self._sync_ms = 1e3 * (time.perf_counter() - ts0)
@@ -422,7 +442,8 @@ class GMatcher(nn.Module):
             work = self._buf("ot", hip.sinkhorn_workspace_bytes(probs))
             hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
         self._last = dict(items=items, pairs=pairs, mdesc=mdesc, desc=desc, sage=sage, images=images,
-                          flat=dict(matches0=m0_all, scores0=s0_all, n0=[n0 for (_, n0), _ in pairs], n1=[n1 for _, (_, n1) in pairs]))
+                          flat=dict(matches0=m0_all, scores0=s0_all, n0=[n0 for (_, n0), _ in pairs], n1=[n1 for _, (_, n1) in pairs]),
+                          outputs=[m0_all, m1_all, s0_all, s1_all, uv_all, mdesc, feat, kpts_all, score_all, ctx["pool"]])
         return items, pairs, mdesc
 
     def _ingest(self, raw):
@@ -496,37 +517,68 @@ class GMatcher(nn.Module):
         ``forward`` can only stack equal-sized pairs, gmatcher.py:244-249).  Each dict is mutated like ``forward``
         does and a list of per-pair result dicts (same keys as ``forward``) is returned."""
         tm0 = time.perf_counter()
-        raw = []
+        n_lanes = int(self.config.get('streams', 1))
+        if n_lanes < 2 or len(datas) < 2 * n_lanes:
+            n_lanes = 1
+        cuts = [round(i * len(datas) / n_lanes) for i in range(n_lanes + 1)]
+        groups = [datas[cuts[i]:cuts[i + 1]] for i in range(n_lanes)]
         for data in datas:
             self._check_call(data, kwargs)
             if data['keypoints0'].shape[0] != 1:
                 raise ValueError("match_pairs takes single-pair dicts (B == 1)")
-            for side in ("0", "1"):
-                raw.append((data['keypoints' + side][0], data['descriptors' + side][0], data['scores' + side][0], data['image' + side].shape))
-        images = self._ingest(raw)
-        tm1 = time.perf_counter()
         d0 = datas[0]
-        items, pairs, mdesc = self._run(images, d0.get('radius', 25), d0.get('percentile', 7), d0.get('min_size', 8))
+        params = (d0.get('radius', 25), d0.get('percentile', 7), d0.get('min_size', 8))
+        cur = torch.cuda.current_stream()
+        if n_lanes > 1:
+            # independent sub-batches on separate HIP streams: the HBM-bound stages of one lane (Sinkhorn, epilogues) overlap
+            # the MFMA-bound stages of the other, and the host sync of one lane's graph build hides behind the other's work
+            lanes = self.__dict__.setdefault("_lanes", {}).setdefault((cur.device, n_lanes), [torch.cuda.Stream() for _ in range(n_lanes)])
+            for L in lanes:
+                L.wait_stream(cur)
+        else:
+            lanes = [cur]
+        ctxs = []
+        for gi, grp in enumerate(groups):
+            with torch.cuda.stream(lanes[gi]):
+                self._lane = gi
+                raw = [(data['keypoints' + side][0], data['descriptors' + side][0], data['scores' + side][0], data['image' + side].shape)
+                       for data in grp for side in ("0", "1")]
+                ctxs.append(self._run_build(self._ingest(raw), *params))
+        tm1 = time.perf_counter()
+        outs, flats = [], []
+        for gi, grp in enumerate(groups):
+            with torch.cuda.stream(lanes[gi]):
+                self._lane = gi
+                items, pairs, mdesc = self._run_rest(ctxs[gi])
+                images = ctxs[gi]["images"]
+                flats.append(self._last["flat"])
+                if n_lanes > 1:
+                    for t_ in self._last["outputs"]:
+                        t_.record_stream(cur)
+                for p, (data, it) in enumerate(zip(grp, items)):
+                    for s, side in enumerate(("0", "1")):
+                        g = images[2 * p + s]["graph"]
+                        data['keypoints' + side] = g.ndata['point'][None]
+                        data['descriptors' + side] = g.ndata['feat'].t()[None]
+                        data['scores' + side] = g.ndata['score'][None]
+                        data['kept_kpts%s_indices' % side] = [images[2 * p + s]["kept"]]      # device tensor (no host sync here)
+                        data['graph' + side] = [g]
+                    (o0, n0), (o1, n1) = pairs[p]
+                    outs.append({
+                        'keypoints0': data['keypoints0'], 'keypoints1': data['keypoints1'],
+                        'descriptors0': data['descriptors0'], 'descriptors1': data['descriptors1'],
+                        'matches0': it["matches0"][None], 'matches1': it["matches1"][None],
+                        'matching_scores0': it["mscores0"][None], 'matching_scores1': it["mscores1"][None],
+                        'mdesc0': mdesc[o0:o0 + n0], 'mdesc1': mdesc[o1:o1 + n1],
+                    })
+        self._lane = 0
+        if n_lanes > 1:
+            for L in lanes:
+                cur.wait_stream(L)
         tm2 = time.perf_counter()
-        outs = []
-        for p, (data, it) in enumerate(zip(datas, items)):
-            for s, side in enumerate(("0", "1")):
-                g = images[2 * p + s]["graph"]
-                data['keypoints' + side] = g.ndata['point'][None]
-                data['descriptors' + side] = g.ndata['feat'].t()[None]
-                data['scores' + side] = g.ndata['score'][None]
-                data['kept_kpts%s_indices' % side] = [images[2 * p + s]["kept"]]      # device tensor (no host sync here)
-                data['graph' + side] = [g]
-            (o0, n0), (o1, n1) = pairs[p]
-            outs.append({
-                'keypoints0': data['keypoints0'], 'keypoints1': data['keypoints1'],
-                'descriptors0': data['descriptors0'], 'descriptors1': data['descriptors1'],
-                'matches0': it["matches0"][None], 'matches1': it["matches1"][None],
-                'matching_scores0': it["mscores0"][None], 'matching_scores1': it["mscores1"][None],
-                'mdesc0': mdesc[o0:o0 + n0], 'mdesc1': mdesc[o1:o1 + n1],
-            })
         outs = PairResults(outs)
-        outs.flat = self._last["flat"]
+        outs.flat = flats
+        self.n_lanes_last = n_lanes
         if self._timers is not None:
             self._timers.setdefault("_host_marks", []).append((None, None, (1e3 * (tm1 - tm0), 1e3 * (tm2 - tm1), 1e3 * (time.perf_counter() - tm2),
                                                                             getattr(self, "_sync_ms", 0.0))))

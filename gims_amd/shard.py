@@ -24,8 +24,12 @@ def pair_stats(pair_ids: Sequence[int], outs: Sequence[dict], device) -> torch.T
     if not outs:
         return torch.zeros((0, len(STAT_FIELDS)), dtype=torch.float32, device=device)
     flat = getattr(outs, "flat", None)
-    if flat is not None:            # batch-concatenated outputs of GMatcher.match_pairs: no per-pair ops at all
-        n0, n1, m0, s0 = flat["n0"], flat["n1"], flat["matches0"], flat["scores0"]
+    if flat is not None:            # batch-concatenated outputs of GMatcher.match_pairs (one entry per stream lane)
+        flats = flat if isinstance(flat, (list, tuple)) else [flat]
+        n0 = [n for f in flats for n in f["n0"]]
+        n1 = [n for f in flats for n in f["n1"]]
+        m0 = flats[0]["matches0"] if len(flats) == 1 else torch.cat([f["matches0"] for f in flats])
+        s0 = flats[0]["scores0"] if len(flats) == 1 else torch.cat([f["scores0"] for f in flats])
     else:
         n0 = [int(o["matches0"].numel()) for o in outs]
         n1 = [int(o["matches1"].numel()) for o in outs]

@@ -151,3 +151,19 @@ def test_errors_like_reference():
     data = pair_to_data(pair, 15, 2, 7, device="cpu")
     with pytest.raises(RuntimeError):
         m(data)            # no CPU fallback
+
+
+def test_two_stream_lanes_equal_single_stream(synth_sd):
+    """match_pairs with two stream lanes returns exactly the single-stream results."""
+    pairs = [synth.make_pair(n, s, canvas=synth.canvas_for(256) if n == 200 else None)
+             for n, s in ((256, 1002), (200, 1001), (512, 1004), (64, 1000), (256, 1003))]
+    res = []
+    for lanes in (1, 2):
+        m = GMatcher({"streams": lanes}).eval()
+        m.load_state_dict(synth_sd)
+        outs = m.match_pairs([pair_to_data(p, 15, 2, 7, device="cuda") for p in pairs])
+        torch.cuda.synchronize()
+        res.append(outs)
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a["matches0"].cpu().numpy(), b["matches0"].cpu().numpy())
+        np.testing.assert_allclose(a["matching_scores0"].cpu().numpy(), b["matching_scores0"].cpu().numpy(), atol=2e-6)
