@@ -273,7 +273,7 @@ class GMatcher(nn.Module):
         key = (name, dev, self._lane)              # one scratch set per stream lane (lanes run concurrently)
         t = arena.get(key)
         if t is None or t.numel() < nbytes:
-            t = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+            t = torch.empty(((int(nbytes * 1.25) + 511) // 256) * 256, dtype=torch.uint8, device=dev)   # multiple of 256 bytes
             arena[key] = t
         return t
 

@@ -167,3 +167,43 @@ def test_two_stream_lanes_equal_single_stream(synth_sd):
     for a, b in zip(*res):
         np.testing.assert_array_equal(a["matches0"].cpu().numpy(), b["matches0"].cpu().numpy())
         np.testing.assert_allclose(a["matching_scores0"].cpu().numpy(), b["matching_scores0"].cpu().numpy(), atol=2e-6)
+
+
+def test_unequal_keypoint_counts_vs_oracle(models, synth_sd):
+    """N0 != N1 (image 1 lost a third of its keypoints): HIP path vs the CPU oracle on the same inputs."""
+    pair = synth.make_pair(384, 1010)
+    keep = 250
+    for k in ("keypoints1", "scores1"):
+        pair[k] = np.ascontiguousarray(pair[k][:, :keep])
+    pair["descriptors1"] = np.ascontiguousarray(pair["descriptors1"][:, :, :keep])
+    m = models[("bf16x3", 100)]
+    d_gpu = pair_to_data(pair, 15, 2, 7, device="cuda")
+    out = m(d_gpu)
+    d_cpu = pair_to_data(pair, 15, 2, 7, device="cpu")
+    st = {}
+    ref = O.gmatcher_forward(synth_sd, d_cpu, {}, stages=st)
+    assert d_gpu["kept_kpts0_indices"] == d_cpu["kept_kpts0_indices"] and d_gpu["kept_kpts1_indices"] == d_cpu["kept_kpts1_indices"]
+    assert out["matches0"].shape == ref["matches0"].shape and out["matches1"].shape == ref["matches1"].shape
+    inner = st["ot"][0][:-1, :-1]
+    t2 = inner.topk(2, dim=1).values
+    rs0 = ref["matching_scores0"][0].numpy()
+    safe = ((t2[:, 0] - t2[:, 1]).numpy() > 1e-3) & (np.abs(rs0 - 0.2) > 1e-3)
+    m0, r0 = out["matches0"][0].cpu().numpy(), ref["matches0"][0].numpy()
+    assert safe.mean() > 0.9 and (m0[safe] == r0[safe]).all()
+    assert np.abs(out["matching_scores0"][0].cpu().numpy() - rs0)[m0 == r0].max() < 1e-4
+
+
+def test_stress_8192_keypoints(models):
+    """BASELINE config 5 size: one 2x8192 pair -- properties only (the oracle would take minutes)."""
+    m = models[("bf16x3", 20)]
+    pair = synth.make_pair(8192, 1000)
+    data = pair_to_data(pair, 15, 2, 7, device="cuda")
+    o = m(data)
+    m0, m1 = o["matches0"][0].cpu().numpy(), o["matches1"][0].cpu().numpy()
+    s0 = o["matching_scores0"][0].cpu().numpy()
+    v = m0 >= 0
+    assert (m1[m0[v]] == np.nonzero(v)[0]).all() and (s0[v] > 0.02).all() and np.isfinite(s0).all()
+    k0, k1 = np.asarray(data["kept_kpts0_indices"][0]), np.asarray(data["kept_kpts1_indices"][0])
+    assert len(k0) > 8000 and len(k1) > 8000
+    correct = (k1[m0[v]] == pair["gt_perm"][k0[v]]).sum()
+    assert v.sum() > 6000 and correct > 0.9 * v.sum(), (int(v.sum()), int(correct))
