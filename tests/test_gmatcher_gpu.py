@@ -207,3 +207,39 @@ def test_stress_8192_keypoints(models):
     assert len(k0) > 8000 and len(k1) > 8000
     correct = (k1[m0[v]] == pair["gt_perm"][k0[v]]).sum()
     assert v.sum() > 6000 and correct > 0.9 * v.sum(), (int(v.sum()), int(correct))
+
+
+def test_sparse_graph_few_kept_vs_oracle(models, synth_sd):
+    """Sparse keypoints: the adaptive graph drops most of them (512 on 800x600 keeps a few dozen); the
+    rest of the path then runs on tiny, different-sized images."""
+    pair = synth.make_pair(512, 2000, canvas=(800, 600))
+    m = models[("bf16x3", 100)]
+    d_gpu = pair_to_data(pair, 15, 2, 7, device="cuda")
+    out = m(d_gpu)
+    d_cpu = pair_to_data(pair, 15, 2, 7, device="cpu")
+    ref = O.gmatcher_forward(synth_sd, d_cpu, {})
+    assert d_gpu["kept_kpts0_indices"] == d_cpu["kept_kpts0_indices"] and d_gpu["kept_kpts1_indices"] == d_cpu["kept_kpts1_indices"]
+    n0, n1 = len(d_cpu["kept_kpts0_indices"][0]), len(d_cpu["kept_kpts1_indices"][0])
+    assert 0 < n0 < 200 and 0 < n1 < 200
+    assert out["matches0"].shape == (1, n0) and out["matches1"].shape == (1, n1)
+    np.testing.assert_allclose(out["matching_scores0"][0].cpu().numpy(), ref["matching_scores0"][0].numpy(), atol=1e-4)
+    agree = (out["matches0"][0].cpu().numpy() == ref["matches0"][0].numpy()).mean()
+    assert agree > 0.95
+
+
+def test_everything_removed_raises_like_reference(models):
+    """No radius edges at all -> every node is a size-1 component -> all removed -> the reference dies in np.vstack([])
+    with ValueError (agc.py:701); same exception type here."""
+    pair = synth.make_pair(64, 1000, canvas=(100000, 100000))
+    with pytest.raises(ValueError):
+        models[("bf16x3", 100)](pair_to_data(pair, 1, 2, 7, device="cuda"))
+
+
+def test_tiny_pair(models, synth_sd):
+    pair = synth.make_pair(24, 7, canvas=(40, 30))
+    d_gpu = pair_to_data(pair, 15, 2, 3, device="cuda")
+    out = models[("f32", 100)](d_gpu)
+    d_cpu = pair_to_data(pair, 15, 2, 3, device="cpu")
+    ref = O.gmatcher_forward(synth_sd, d_cpu, {})
+    assert d_gpu["kept_kpts0_indices"] == d_cpu["kept_kpts0_indices"]
+    np.testing.assert_allclose(out["matching_scores0"][0].cpu().numpy(), ref["matching_scores0"][0].numpy(), atol=1e-4)
