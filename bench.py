@@ -208,7 +208,7 @@ def main():
         totals = {k: v[2] * v[5] for k, v in cand.items()}
         dom = max(totals, key=totals.get)
         rate = lambda v: v[1] / (v[2] * 1e-3) / (1e12 if v[4] == "TFLOP/s" else 1e9)     # noqa: E731
-        bound, work, ms, peak, unit, nl = cand[dom]
+        bound, work, ms, peak, unit, n_launch = cand[dom]
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # HBM bytes per launch from rocprofv3 --pmc runs of this command
         if os.path.exists(tf):
@@ -229,7 +229,7 @@ def main():
                         "`achieved` counts ALGORITHMIC flops 2MNK, so its ceiling against the 2.5 PF/s bf16 peak is 1/3")
         roofline = {"kernel": dom, "bound": bound, "achieved": rate(cand[dom]), "peak": peak, "unit": unit,
                     "frac": rate(cand[dom]) / peak, "traffic": traffic,
-                    "avg_launch_ms": float(ms), "launches_per_step": nl, "algorithmic_work_per_launch": work,
+                    "avg_launch_ms": float(ms), "launches_per_step": n_launch, "algorithmic_work_per_launch": work,
                     "note": dom_note + dom_note_extra,
                     "all": {k: {"bound": v[0], "avg_launch_ms": float(v[2]), "launches_per_step": v[5], "achieved": rate(v), "unit": v[4],
                                 "peak": v[3], "frac": rate(v) / v[3]} for k, v in cand.items()}}

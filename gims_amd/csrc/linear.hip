@@ -293,7 +293,9 @@ struct X3P {
   static constexpr int STAGE = A_TILE + W_TILE;
   static constexpr int PA = TM / 8, PW = TN / 8;                 // 1 KiB pieces (8 rows) per operand per stage
   static constexpr int PIECES = (PA + PW) / WAVES;               // pieces per wave per stage
-  static constexpr int LDS_BYTES = S * STAGE * 2;
+  static constexpr int EP_PITCH = TN / WN + 4;                    // epilogue transpose slice: 32 rows x EP_PITCH floats per wave
+  static constexpr int RING_BYTES = S * STAGE * 2, EP_BYTES = WAVES * 32 * EP_PITCH * 4;
+  static constexpr int LDS_BYTES = RING_BYTES > EP_BYTES ? RING_BYTES : EP_BYTES;
   static_assert((PA + PW) % WAVES == 0, "pieces divide evenly over the waves");
   __device__ static __forceinline__ int swz(int row) { return (row >> 1) & 7; }
   __device__ static __forceinline__ int off(int row, int chunk) { return row * 64 + ((chunk ^ swz(row)) << 3); }
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   const int m0 = ((slot / nt_n) * 8 + xcd) * TM, n0 = (slot % nt_n) * TN;
   if (m0 >= p.m) return;
   const int li = lane & 31, lh = lane >> 5;
-  const int nk = p.k / BK;
+  // diagnostic bits (tools/gemm_probe.py only): 0x100 = no main loop, 0x200 = no epilogue memory traffic
+  const int nk = (p.flags & 0x100) ? 0 : p.k / BK;
 
   // this wave's LDS-DMA duty: PIECES consecutive 8-row pieces of the stage image [A rows | W rows]
   const int p0 = wave * T::PIECES;
@@ -395,51 +398,91 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
     }
   }
 
-  // ---- epilogue: lane owns row m, 4 consecutive channels per accumulator group.  The bias / residual vectors of a
-  // chunk of two 32-channel blocks (8 + 8 float4) are requested BEFORE the first one is consumed, so their latencies
-  // overlap instead of adding up (the compiler otherwise waits vmcnt(0) per group).
-  const int colbase = n0 + wn * (TN / WN) + 4 * lh;
-  constexpr int NB = T::NI < 2 ? T::NI : 2;
+  // ---- epilogue.  In the MFMA (D^T) layout a lane owns 4 consecutive channels of ONE row, so a wave-wide store would
+  // scatter 16-byte pieces over 32 rows; the memory system then sees 4-8x the transactions of a row-contiguous store and
+  // the epilogue becomes transaction-bound (measured: ~45 us per launch at 65k rows whatever the output bytes).  Each
+  // wave therefore transposes its accumulators through a private slice of the (now idle) LDS ring, 32 rows at a time,
+  // and reads them back row-contiguous: a wave-wide access then covers whole 128-byte lines of bias / residual / outputs.
+  if ((p.flags & 0x200) && acc[0][0][0] != 12345.678f) return;
+  __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
+  constexpr int WCOLS = TN / WN;                      // columns of the wave tile
+  constexpr int PITCH = T::EP_PITCH;                  // floats; +4 keeps the 16-byte LDS writes of 16 lanes on distinct banks
+  constexpr int LPR = WCOLS / 8;                      // lanes per row in the read-back (8 consecutive channels per lane)
+  constexpr int RPI = 64 / LPR;                       // rows per wave-wide access
+  constexpr int ITERS = 32 / RPI;
+  float* ep = (float*)smem + wave * (32 * PITCH);
+  const int c8 = (lane % LPR) * 8, rsub = lane / LPR;
+  const int col = n0 + wn * WCOLS + c8;
+  const bool cok = col < p.n, full = col + 4 < p.n;   // n % 4 == 0: a lane's 8 channels are all, half or not in range
+  float4 b4[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) b4[h] = (p.bias && col + 4 * h < p.n) ? *(const float4*)(p.bias + col + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int scol = spl_col(col);
 #pragma unroll
   for (int mi = 0; mi < T::MI; ++mi) {
-    const int row = m0 + wm * (TM / WM) + mi * 32 + li;
-    const bool rok = row < p.m;
 #pragma unroll
-    for (int nc = 0; nc < T::NI; nc += NB) {
-      float4 bias4[NB][4], res4[NB][4];
+    for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
-      for (int q = 0; q < NB; ++q)
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(ep + li * PITCH + ni * 32 + 8 * g + 4 * lh) =
+            make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no workgroup barrier needed
+    const int rbase = m0 + wm * (TM / WM) + mi * 32 + rsub;
+    constexpr int CH = ITERS < 4 ? ITERS : 4;            // residual loads of a chunk are all in flight before the first use
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = colbase + (nc + q) * 32 + 8 * g;
-          const bool ok = rok && col < p.n;
-          bias4[q][g] = (p.bias && ok) ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-          res4[q][g] = (p.residual && ok) ? *(const float4*)(p.residual + (int64_t)row * p.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int it0 = 0; it0 < ITERS; it0 += CH) {
+      float4 res[CH][2];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int row = rbase + (it0 + q) * RPI;
+        const bool ok = p.residual && cok && row < p.m;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          res[q][h] = (ok && (h == 0 || full)) ? *(const float4*)(p.residual + (int64_t)row * p.ldc + col + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int row = rbase + (it0 + q) * RPI;
+        const float* src = ep + (rsub + (it0 + q) * RPI) * PITCH + c8;
+        const float4 a0 = *(const float4*)src, a1 = *(const float4*)(src + 4);
+        if (!cok || row >= p.m) continue;
+        float v[8] = {fmaf(a0.x, p.scale, b4[0].x), fmaf(a0.y, p.scale, b4[0].y), fmaf(a0.z, p.scale, b4[0].z), fmaf(a0.w, p.scale, b4[0].w),
+                      fmaf(a1.x, p.scale, b4[1].x), fmaf(a1.y, p.scale, b4[1].y), fmaf(a1.z, p.scale, b4[1].z), fmaf(a1.w, p.scale, b4[1].w)};
+        if (p.act == GIMS_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        v[0] += res[q][0].x; v[1] += res[q][0].y; v[2] += res[q][0].z; v[3] += res[q][0].w;
+        v[4] += res[q][1].x; v[5] += res[q][1].y; v[6] += res[q][1].z; v[7] += res[q][1].w;
+        if (p.out_f32) {
+          float* o = p.out_f32 + (int64_t)row * p.ldc + col;
+          *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+          if (full) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        uint32_t h[4];
 #pragma unroll
-      for (int q = 0; q < NB; ++q)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int ni = nc + q;
-          const int col = colbase + ni * 32 + 8 * g;
-          if (!rok || col >= p.n) continue;
-          const float4 b = bias4[q][g];
-          float4 v = make_float4(fmaf(acc[ni][mi][4 * g], p.scale, b.x), fmaf(acc[ni][mi][4 * g + 1], p.scale, b.y),
-                                 fmaf(acc[ni][mi][4 * g + 2], p.scale, b.z), fmaf(acc[ni][mi][4 * g + 3], p.scale, b.w));
-          if (p.act == GIMS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          const float4 r = res4[q][g];
-          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-          if (p.out_f32) *(float4*)(p.out_f32 + (int64_t)row * p.ldc + col) = v;
-          if (p.out_bf16) *(uint2*)(p.out_bf16 + (int64_t)row * p.ldc_bf16 + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-          if (p.out_hi) {
-            const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
-            const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
-            const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
-            *(uint2*)(p.out_hi + (int64_t)row * p.ld_split + spl_col(col)) = make_uint2(h01, h23);
-            *(uint2*)(p.out_lo + (int64_t)row * p.ld_split + spl_col(col)) = make_uint2(l01, l23);
+        for (int e = 0; e < 4; ++e) h[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        if (p.out_bf16) {
+          uint16_t* o = p.out_bf16 + (int64_t)row * p.ldc_bf16 + col;
+          if (full && (p.ldc_bf16 & 7) == 0) *(uint4*)o = make_uint4(h[0], h[1], h[2], h[3]);
+          else {
+            *(uint2*)o = make_uint2(h[0], h[1]);
+            if (full) *(uint2*)(o + 4) = make_uint2(h[2], h[3]);
           }
         }
+        if (p.out_hi) {
+          uint32_t l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            l[e] = pack_bf2(v[2 * e] - __uint_as_float(h[e] << 16), v[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u));
+          uint16_t* oh = p.out_hi + (int64_t)row * p.ld_split + scol;
+          uint16_t* ol = p.out_lo + (int64_t)row * p.ld_split + scol;
+          if (full) { *(uint4*)oh = make_uint4(h[0], h[1], h[2], h[3]); *(uint4*)ol = make_uint4(l[0], l[1], l[2], l[3]); }
+          else { *(uint2*)oh = make_uint2(h[0], h[1]); *(uint2*)ol = make_uint2(l[0], l[1]); }
+        }
+      }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read-back complete before the slice is overwritten
   }
 }
 
@@ -491,8 +534,11 @@ static int linear_validate(const gims_linear_args* a) {
     GIMS_CHECK_ARG((a->lda0 % 64) == 0 && (a->lda1 % 64) == 0 && (a->ldw % 64) == 0 && a->lda0 >= 2 * a->k0 && a->ldw >= 2 * a->k,
                    "gims_linear(pre-split): SPL32 operands have row pitch >= 2*K, a multiple of 64 elements");
     GIMS_CHECK_ARG((((uintptr_t)a->a0 | (uintptr_t)a->w | (uintptr_t)a->a1) & 127) == 0, "gims_linear(pre-split): SPL32 operands must be 128-byte aligned");
-    GIMS_CHECK_ARG((a->n % 4) == 0 && (a->ldc % 4) == 0 && (a->ldc_bf16 % 4) == 0 && (a->ld_split % 4) == 0,
-                   "gims_linear(pre-split): n and output pitches must be multiples of 4");
+    GIMS_CHECK_ARG((a->n % 4) == 0 && (a->ldc % 4) == 0 && (a->ldc_bf16 % 4) == 0 && (a->ld_split % 8) == 0,
+                   "gims_linear(pre-split): n, ldc and ldc_bf16 must be multiples of 4, ld_split of 8");
+    GIMS_CHECK_ARG((((uintptr_t)a->out_f32 | (uintptr_t)a->out_hi | (uintptr_t)a->residual | (uintptr_t)a->bias) & 15) == 0 &&
+                   ((uintptr_t)a->out_bf16 & 7) == 0 && (((uintptr_t)a->out_bf16 & 15) == 0 || (a->ldc_bf16 & 7) != 0),
+                   "gims_linear(pre-split): bias, residual and outputs must be 16-byte aligned");
     return GIMS_OK;
   }
   GIMS_CHECK_ARG(!a->residual || a->out_f32, "gims_linear: residual needs an f32 output (shared ldc)");
