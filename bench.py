@@ -108,6 +108,7 @@ def main():
                       "streams": args.streams}).eval()
     model.load_state_dict(synth.make_state_dict(123))
     my_pairs = shard.shard_indices(world * args.pairs, rank, world)     # pair i -> rank i mod world
+    rank_counts = [len(shard.shard_indices(world * args.pairs, r, world)) for r in range(world)]
     inputs = make_inputs(my_pairs, args.kpts, dev)
     torch.cuda.synchronize()
 
@@ -120,7 +121,7 @@ def main():
         host_t["datas"] = datas
         t1 = time.perf_counter()
         # per-pair match statistics, all-gathered over RCCL/xGMI: the path's only collective
-        stats = shard.gather_stats(shard.pair_stats(my_pairs, outs, dev))
+        stats = shard.gather_stats(shard.pair_stats(my_pairs, outs, dev), counts=rank_counts)
         ms = torch.cuda.memory_stats()
         host_t.setdefault("dev_alloc", []).append((ms.get("num_device_alloc", 0), ms.get("num_device_free", 0), ms.get("reserved_bytes.all.current", 0) >> 20))
         host_t["match_pairs"].append(1e3 * (t1 - t0))

@@ -33,6 +33,16 @@ int upload_table(const void* host, size_t bytes, void* dev, hipStream_t stream) 
   return GIMS_OK;
 }
 
+}  // namespace gims
+
+extern "C" int gims_upload_table(const void* host, int64_t bytes, void* dev, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(host && dev && bytes >= 0 && bytes <= (1 << 20) && ((uintptr_t)dev & 15) == 0, "gims_upload_table: bad arguments");
+  if (bytes == 0) return GIMS_OK;
+  return upload_table(host, (size_t)bytes, dev, (hipStream_t)stream);
+}
+
+namespace gims {
 // normalize_keypoints (gmatcher.py:26-33) + Conv1d(2->c1) + BN(eval, folded) + ReLU (gmatcher.py:87-97)
 __global__ __launch_bounds__(256) void kenc_first_kernel(const float* __restrict__ kpts, const float* __restrict__ norm3,
                                                          const int32_t* __restrict__ seg, const float* __restrict__ w1,

@@ -349,7 +349,7 @@ class GMatcher(nn.Module):
             # NHWC callers => (height, width) = (W, 3): the reference's quirk, kept verbatim.
             hw = np.asarray([[g["shape"][3], g["shape"][2]] for g in images], dtype=np.float32)   # size = [width, height]
             norm3 = np.concatenate([hw / np.float32(2), (hw.max(axis=1, keepdims=True) * np.float32(0.7))], axis=1).astype(np.float32)
-            norm3 = torch.from_numpy(norm3).to(dev)
+            norm3 = hip.upload(norm3, dev)
             for g, ro in zip(images, row_off):
                 nk = g["n_kept"]
                 g["rows"] = (ro, nk)
@@ -380,9 +380,11 @@ class GMatcher(nn.Module):
             desc = x
         # ---- attentional GNN (gmatcher.py:99-143): per layer QKV -> flash attention -> merge -> MLP -> residual
         pairs = [(images[2 * p]["rows"], images[2 * p + 1]["rows"]) for p in range(len(images) // 2)]
-        self_pr = torch.tensor([[o, n, o, n] for pr in pairs for (o, n) in pr], dtype=torch.int32, device=dev)
-        cross_pr = torch.tensor([q for (o0, n0), (o1, n1) in pairs for q in ((o0, n0, o1, n1), (o1, n1, o0, n0))],
-                                dtype=torch.int32, device=dev)
+        # problem tables travel as kernel arguments (hip.upload): a pageable torch.tensor(..., device=) would block this
+        # thread until the stream drains and stop the host from running ahead of the GPU
+        self_pr = hip.upload(np.asarray([[o, n, o, n] for pr in pairs for (o, n) in pr], dtype=np.int32), dev)
+        cross_pr = hip.upload(np.asarray([q for (o0, n0), (o1, n1) in pairs for q in ((o0, n0, o1, n1), (o1, n1, o0, n0))],
+                                         dtype=np.int32), dev)
         max_nq = max(g["n_kept"] for g in images)
         qkv = torch.empty((n_tot, 3 * D), dtype=torch.bfloat16, device=dev)
         if x3:

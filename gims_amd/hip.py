@@ -59,6 +59,7 @@ _SIGNATURES = {
     "gims_abi_version": (C.c_int, []),
     "gims_last_error": (C.c_char_p, []),
     "gims_stream_sync": (C.c_int, [C.c_void_p]),
+    "gims_upload_table": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gims_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "gims_linear_put": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p, C.c_void_p]),
     "gims_linear_put_many": (C.c_int, [C.POINTER(LinearArgs), C.c_int32, C.c_void_p, C.c_void_p]),
@@ -125,6 +126,23 @@ def _stream() -> int:
 
 def _p(t) -> int | None:
     return None if t is None else t.data_ptr()
+
+
+_NP2TORCH = {"float32": torch.float32, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8}
+
+
+def upload(arr, device="cuda") -> torch.Tensor:
+    """Small host table (numpy array) -> device tensor, asynchronously and in stream order (gims_upload_table): the
+    bytes ride in kernel arguments, so unlike ``torch.tensor(..., device=...)`` / ``.to(device)`` from pageable memory
+    the calling thread never waits for the stream to drain."""
+    import numpy as np
+    a = np.ascontiguousarray(arr)
+    dt = _NP2TORCH[a.dtype.name]
+    nbytes = a.nbytes
+    buf = torch.empty(((nbytes + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=device)   # caching allocator: 512-B aligned
+    if nbytes:
+        _check(load().gims_upload_table(a.ctypes.data, nbytes, buf.data_ptr(), _stream()), "gims_upload_table")
+    return buf[:nbytes].view(dt).view(a.shape)
 
 
 def _dev(t: torch.Tensor, dtype=None):
@@ -278,8 +296,11 @@ def agc_build(images, radius, percentile, min_size, work: torch.Tensor):
 
 
 def _upload_structs(arr, device):
-    """Small descriptor table -> device (one tiny H2D copy)."""
-    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    """ctypes descriptor table -> device through gims_upload_table (stream-ordered, never blocks the host)."""
+    nbytes = C.sizeof(arr)
+    buf = torch.empty(((nbytes + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=device)
+    _check(load().gims_upload_table(C.addressof(arr), nbytes, buf.data_ptr(), _stream()), "gims_upload_table")
+    return buf
 
 
 def ingest_images(items, d, desc_out, kpts_out, score_out):
@@ -293,11 +314,10 @@ def ingest_images(items, d, desc_out, kpts_out, score_out):
 
 
 def pack_graphs(pack_items, d, feat, kpts_out, score_out, seg, indptr_out, indices_out, n_rows, n_edges):
-    """pack_items: list of PackImage (host); uploaded as one small H2D copy, then one launch for the batch."""
+    """pack_items: list of PackImage (host); uploaded as kernel arguments, then one launch for the batch."""
     lib = load()
     arr = (PackImage * len(pack_items))(*pack_items)
-    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-    dev_arr = host.to(feat.device, non_blocking=False)
+    dev_arr = _upload_structs(arr, feat.device)
     _check(lib.gims_pack_graphs(_p(dev_arr), len(pack_items), max(p.n_kept for p in pack_items),
                                 max(max(p.n_edges for p in pack_items), 1), d, _p(feat), feat.stride(0), _p(kpts_out),
                                 _p(score_out), _p(seg), _p(indptr_out), _p(indices_out), n_rows, n_edges, _stream()),

@@ -18,6 +18,17 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
+def _to_device(values, dtype: str, device) -> torch.Tensor:
+    """Small host list -> tensor on `device`.  On the GPU the bytes go through the kernel library's table upload
+    (stream-ordered, never blocks the host on the stream); on the CPU (gloo tests) it is a plain tensor."""
+    import numpy as np
+    arr = np.asarray(values, dtype=dtype)
+    if torch.device(device).type == "cuda":
+        from . import hip
+        return hip.upload(arr, device)
+    return torch.from_numpy(arr).to(device)
+
+
 def pair_stats(pair_ids: Sequence[int], outs: Sequence[dict], device) -> torch.Tensor:
     """[n_pairs, 5] float32 record per pair, built on the device with a handful of batched ops: no host sync and no
     per-pair host->device copies (those would each wait for the stream to drain)."""
@@ -37,8 +48,8 @@ def pair_stats(pair_ids: Sequence[int], outs: Sequence[dict], device) -> torch.T
         s0 = torch.cat([o["matching_scores0"].reshape(-1) for o in outs])
     # only two tiny (<= a few hundred bytes) host->device copies: larger pageable copies make the HIP runtime pin and
     # unpin the source pages on the fly, which stalls the submitting thread for tens of milliseconds
-    host = torch.tensor([[float(p), float(a), float(b)] for p, a, b in zip(pair_ids, n0, n1)], dtype=torch.float32).to(device)
-    reps = torch.tensor(n0, dtype=torch.int64).to(device)
+    host = _to_device([[float(p), float(a), float(b)] for p, a, b in zip(pair_ids, n0, n1)], "float32", device)
+    reps = _to_device(n0, "int64", device)
     seg = torch.repeat_interleave(torch.arange(len(outs), device=device), reps, output_size=int(sum(n0)))
     valid = (m0 >= 0).to(torch.float32)
     nm = torch.zeros(len(outs), dtype=torch.float32, device=device).index_add_(0, seg, valid)
@@ -46,20 +57,25 @@ def pair_stats(pair_ids: Sequence[int], outs: Sequence[dict], device) -> torch.T
     return torch.cat([host, nm[:, None], (ss / nm.clamp(min=1.0))[:, None]], dim=1)
 
 
-def gather_stats(stats: torch.Tensor, world: int | None = None) -> torch.Tensor:
+def gather_stats(stats: torch.Tensor, world: int | None = None, counts: Sequence[int] | None = None) -> torch.Tensor:
     """All-gather the per-pair records of every rank (ragged counts are padded with pair_id = -1 rows and
-    dropped again); returns the records of the whole job sorted by pair id, identical on every rank."""
+    dropped again); returns the records of the whole job sorted by pair id, identical on every rank.
+    counts: records per rank when the caller knows them (shard_indices is deterministic) -- then no count exchange and
+    no host sync happens here, so the host keeps running ahead of the GPU."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return stats[torch.argsort(stats[:, 0])] if stats.numel() else stats
     world = dist.get_world_size() if world is None else world
-    n_local = torch.tensor([stats.shape[0]], dtype=torch.int64, device=stats.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    n_max = int(max(int(c.item()) for c in counts))
+    if counts is None:
+        n_local = torch.tensor([stats.shape[0]], dtype=torch.int64, device=stats.device)
+        cl = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(cl, n_local)
+        counts = [int(c.item()) for c in cl]
+    assert len(counts) == world and counts[dist.get_rank()] == stats.shape[0], (counts, stats.shape)
+    n_max, n_total = int(max(counts)), int(sum(counts))
     padded = torch.full((n_max, stats.shape[1]), -1.0, dtype=stats.dtype, device=stats.device)
     padded[: stats.shape[0]] = stats
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded)
     allr = torch.cat(bufs)
-    allr = allr[allr[:, 0] >= 0]
-    return allr[torch.argsort(allr[:, 0])]
+    key = torch.where(allr[:, 0] >= 0, allr[:, 0], torch.full_like(allr[:, 0], float("inf")))   # padding rows sort last
+    return allr[torch.argsort(key)[:n_total]]

@@ -37,6 +37,11 @@ int gims_abi_version(void);
 const char* gims_last_error(void);
 /* Blocks until `stream` is idle (hipStreamSynchronize). */
 int gims_stream_sync(void* stream);
+/* Copies a small host table (descriptor arrays, offsets, <= 1 MiB) to device memory IN STREAM ORDER without touching the
+ * copy engines: the bytes travel as kernel arguments (chunks of 3968 B).  Unlike a pageable hipMemcpy this never blocks
+ * the submitting thread on the stream and never pins pages, so the host can keep running ahead of the GPU.  `dev` must be
+ * 16-byte aligned and padded to a multiple of 16 bytes.  No reference counterpart (host-side plumbing of this build). */
+int gims_upload_table(const void* host, int64_t bytes, void* dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Linear layers (1x1 Conv1d / nn.Linear):   C[m, n] = act( sum_k A[m,k] * W[n,k] + bias[n] ) (+ R[m,n])

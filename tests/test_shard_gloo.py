@@ -30,6 +30,9 @@ def _worker(rank, world, port, n_pairs, q):
                          "matching_scores0": torch.full((1, n0), 0.5)})
         st = shard.pair_stats(mine, outs, "cpu")
         allr = shard.gather_stats(st)
+        # the sync-free form (counts known from the deterministic sharding) must return the same table
+        counts = [len(shard.shard_indices(n_pairs, r, world)) for r in range(world)]
+        assert torch.equal(allr, shard.gather_stats(st, counts=counts))
         q.put((rank, mine, allr.numpy().tolist()))
     finally:
         dist.destroy_process_group()
