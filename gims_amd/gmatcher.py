@@ -307,7 +307,23 @@ class GMatcher(nn.Module):
             agc_imgs = hip.make_agc_images([dict(kpts=g["kp"], desc=g["de"], kept=g["kept"], indptr=g["indptr"],
                                                  indices=g["indices"], info=info_all[i]) for i, g in enumerate(images)])
             hip.agc_build(agc_imgs, radius, percentile, min_size, self._buf("agc", hip.agc_workspace_bytes(agc_imgs)))
-        return dict(images=images, info_all=info_all, pool=pool)
+            # everything of the next stage that does not depend on the kept counts is prepared NOW, while the GPU builds the
+            # graphs: after the host sync only two cumsums stand between the counts and the next launch
+            ptab = hip.pack_table([(g["kp"].data_ptr(), g["de"].data_ptr(), g["de"].stride(0), g["sc"].data_ptr(),
+                                    g["kept"].data_ptr(), g["indptr"].data_ptr(), g["indices"].data_ptr()) for g in images])
+            # normalize_keypoints parameters (gmatcher.py:26-33) in float32 arithmetic, like the reference's tensors.
+            # NHWC callers => (height, width) = (W, 3): the reference's quirk, kept verbatim.
+            hw = np.asarray([[g["shape"][3], g["shape"][2]] for g in images], dtype=np.float32)   # size = [width, height]
+            norm3 = np.concatenate([hw / np.float32(2), (hw.max(axis=1, keepdims=True) * np.float32(0.7))], axis=1).astype(np.float32)
+            norm3 = hip.upload(norm3, dev)
+            n_up = sum(ns)                                  # upper bounds: kept <= n, edges <= 64 n
+            bufs = dict(feat=torch.empty((n_up, D), dtype=torch.float32, device=dev),
+                        kpts=torch.empty((n_up, 2), dtype=torch.float32, device=dev),
+                        score=torch.empty((n_up,), dtype=torch.float32, device=dev),
+                        seg=torch.empty((n_up,), dtype=torch.int32, device=dev),
+                        indptr=torch.empty((n_up + 1,), dtype=torch.int32, device=dev),
+                        indices=torch.empty((64 * n_up + 1,), dtype=torch.int32, device=dev))
+        return dict(images=images, info_all=info_all, pool=pool, ptab=ptab, norm3=norm3, bufs=bufs)
 
     def _run_rest(self, ctx):
         """Phase 2: read the kept counts (the one host sync), then enqueue everything else."""
@@ -320,44 +336,26 @@ class GMatcher(nn.Module):
         ts0 = time.perf_counter()
         infos = info_all.cpu().numpy()                                                    # the one host sync of the build
         self._sync_ms = 1e3 * (time.perf_counter() - ts0)
-        for g, inf in zip(images, infos):
-            if inf[7]:
-                raise hip.GimsHipError("adaptive graph exceeded the edge capacity (64 directed edges per node)")
-            g["n_kept"], g["n_edges"] = int(inf[0]), int(inf[1])
-            if g["n_kept"] == 0:
-                raise ValueError("need at least one array to concatenate")               # np.vstack([]) in agc.py:701
-            g["info_host"] = inf
+        if infos[:, 7].any():
+            raise hip.GimsHipError("adaptive graph exceeded the edge capacity (64 directed edges per node)")
+        if (infos[:, 0] == 0).any():
+            raise ValueError("need at least one array to concatenate")               # np.vstack([]) in agc.py:701
 
         # ---- kept-keypoint compaction (gmatcher.py:244-249): rows of all images concatenated, one launch
-        row_off = np.cumsum([0] + [g["n_kept"] for g in images]).tolist()
-        e_off = np.cumsum([0] + [g["n_edges"] for g in images]).tolist()
-        n_tot, e_tot = row_off[-1], e_off[-1]
+        row_off = np.concatenate([[0], np.cumsum(infos[:, 0], dtype=np.int64)])
+        e_off = np.concatenate([[0], np.cumsum(infos[:, 1], dtype=np.int64)])
+        n_tot, e_tot = int(row_off[-1]), int(e_off[-1])
         with St("gather"):
-            feat = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
-            kpts_all = torch.empty((n_tot, 2), dtype=torch.float32, device=dev)
-            score_all = torch.empty((n_tot,), dtype=torch.float32, device=dev)
-            seg = torch.empty((n_tot,), dtype=torch.int32, device=dev)
-            indptr_all = torch.empty((n_tot + 1,), dtype=torch.int32, device=dev)
-            indices_all = torch.empty((max(e_tot, 1),), dtype=torch.int32, device=dev)
-            packs = []
-            for i, g in enumerate(images):
-                packs.append(hip.PackImage(g["kp"].data_ptr(), g["de"].data_ptr(), g["de"].stride(0), g["sc"].data_ptr(),
-                                           g["kept"].data_ptr(), g["indptr"].data_ptr(), g["indices"].data_ptr(),
-                                           g["n_kept"], g["n_edges"], row_off[i], e_off[i]))
-            g_keep = hip.pack_graphs(packs, D, feat, kpts_all, score_all, seg, indptr_all, indices_all, n_tot, e_tot)
-            # normalize_keypoints parameters (gmatcher.py:26-33) in float32 arithmetic, like the reference's tensors.
-            # NHWC callers => (height, width) = (W, 3): the reference's quirk, kept verbatim.
-            hw = np.asarray([[g["shape"][3], g["shape"][2]] for g in images], dtype=np.float32)   # size = [width, height]
-            norm3 = np.concatenate([hw / np.float32(2), (hw.max(axis=1, keepdims=True) * np.float32(0.7))], axis=1).astype(np.float32)
-            norm3 = hip.upload(norm3, dev)
-            for g, ro in zip(images, row_off):
-                nk = g["n_kept"]
-                g["rows"] = (ro, nk)
-                g["kept"] = g["kept"][:nk]
-                g["indptr"] = g["indptr"][:nk + 1]
-                g["indices"] = g["indices"][:g["n_edges"]]
-                g["graph"] = GraphHandle(g["indptr"], g["indices"],
-                                         {"point": kpts_all[ro:ro + nk], "feat": feat[ro:ro + nk], "score": score_all[ro:ro + nk]})
+            ptab, b = ctx["ptab"], ctx["bufs"]
+            ptab["n_kept"], ptab["n_edges"], ptab["row_off"], ptab["edge_off"] = infos[:, 0], infos[:, 1], row_off[:-1], e_off[:-1]
+            feat, kpts_all, score_all, seg = b["feat"][:n_tot], b["kpts"][:n_tot], b["score"][:n_tot], b["seg"][:n_tot]
+            indptr_all, indices_all = b["indptr"][:n_tot + 1], b["indices"][:max(e_tot, 1)]
+            g_keep = hip.pack_graphs_table(ptab, D, feat, kpts_all, score_all, seg, indptr_all, indices_all, n_tot, e_tot)
+            norm3 = ctx["norm3"]
+        row_off, e_off = row_off.tolist(), e_off.tolist()
+        for g, inf, ro in zip(images, infos, row_off):
+            g["n_kept"], g["n_edges"], g["info_host"] = int(inf[0]), int(inf[1]), inf
+            g["rows"] = (ro, g["n_kept"])
         # ---- GraphSAGE over the merged CSR of all images (gmatcher.py:145-162, 268-269)
         with St("sage"):
             h = feat
@@ -443,6 +441,14 @@ class GMatcher(nn.Module):
             probs = hip.make_ot_problems(items)
             work = self._buf("ot", hip.sinkhorn_workspace_bytes(probs))
             hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
+        # per-image views and graph handles: host-only bookkeeping, done after everything is enqueued
+        for g in images:
+            ro, nk = g["rows"]
+            g["kept"] = g["kept"][:nk]
+            g["indptr"] = g["indptr"][:nk + 1]
+            g["indices"] = g["indices"][:g["n_edges"]]
+            g["graph"] = GraphHandle(g["indptr"], g["indices"],
+                                     {"point": kpts_all[ro:ro + nk], "feat": feat[ro:ro + nk], "score": score_all[ro:ro + nk]})
         self._last = dict(items=items, pairs=pairs, mdesc=mdesc, desc=desc, sage=sage, images=images,
                           flat=dict(matches0=m0_all, scores0=s0_all, n0=[n0 for (_, n0), _ in pairs], n1=[n1 for _, (_, n1) in pairs]),
                           outputs=[m0_all, m1_all, s0_all, s1_all, uv_all, mdesc, feat, kpts_all, score_all, ctx["pool"]])

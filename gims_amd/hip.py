@@ -313,6 +313,38 @@ def ingest_images(items, d, desc_out, kpts_out, score_out):
     return dev_arr
 
 
+PACK_DTYPE = None
+
+
+def pack_table(images_ptrs):
+    """numpy structured array mirroring gims_pack_image (one record per image) with the pointer columns filled;
+    the count/offset columns are filled after the graph build's host sync (vectorised: no per-image Python work then)."""
+    import numpy as np
+    global PACK_DTYPE
+    if PACK_DTYPE is None:
+        PACK_DTYPE = np.dtype([("kpts", "<u8"), ("desc", "<u8"), ("ldd", "<i8"), ("score", "<u8"), ("kept", "<u8"),
+                               ("indptr", "<u8"), ("indices", "<u8"), ("n_kept", "<i4"), ("n_edges", "<i4"),
+                               ("row_off", "<i4"), ("edge_off", "<i4")])
+        assert PACK_DTYPE.itemsize == C.sizeof(PackImage)
+    t = np.zeros(len(images_ptrs), dtype=PACK_DTYPE)
+    for i, r in enumerate(images_ptrs):
+        t[i] = r + (0, 0, 0, 0)
+    return t
+
+
+def pack_graphs_table(table, d, feat, kpts_out, score_out, seg, indptr_out, indices_out, n_rows, n_edges):
+    """pack_graphs with the descriptor table given as the numpy array of pack_table()."""
+    lib = load()
+    nbytes = table.nbytes
+    dev_arr = torch.empty(((nbytes + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=feat.device)
+    st = _stream()
+    _check(lib.gims_upload_table(table.ctypes.data, nbytes, dev_arr.data_ptr(), st), "gims_upload_table")
+    _check(lib.gims_pack_graphs(_p(dev_arr), len(table), int(table["n_kept"].max()), max(int(table["n_edges"].max()), 1), d,
+                                _p(feat), feat.stride(0), _p(kpts_out), _p(score_out), _p(seg), _p(indptr_out),
+                                _p(indices_out), n_rows, n_edges, st), "gims_pack_graphs")
+    return dev_arr
+
+
 def pack_graphs(pack_items, d, feat, kpts_out, score_out, seg, indptr_out, indices_out, n_rows, n_edges):
     """pack_items: list of PackImage (host); uploaded as kernel arguments, then one launch for the batch."""
     lib = load()
