@@ -12,7 +12,9 @@ SOURCES = ["linear.hip", "attention.hip", "sinkhorn.hip", "misc.hip", "agc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 # per-file extras: keep MFMA accumulators in VGPRs (gfx950 has a unified VGPR/AGPR file) -- the softmax reads S
 # straight out of the MFMA result registers instead of through v_accvgpr_read copies
-EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# sinkhorn.hip: no SLP packing -- v_pk_*_f32 wants aligned register pairs and, next to the 192 registers the resident
+# Sinkhorn kernel pins for its slab of the transport matrix, the pairing copies push that kernel into scratch spills
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "sinkhorn.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale() -> bool:

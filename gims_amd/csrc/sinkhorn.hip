@@ -15,6 +15,8 @@
 // Traffic per iteration: N*M*4 bytes of Z + 2 * G*(M+1)*4 bytes of partials (G <= 512 workgroups).
 #include "common.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -429,6 +431,529 @@ __global__ void ot_matrix_kernel(const float* __restrict__ z, int64_t ld, int n,
   out[(int64_t)i * (m + 1) + j] = ((zz + uv[i]) + uv[n + 1 + j]) - norm;
 }
 
+// ---------------------------------------------------------------------------------------------- resident Sinkhorn
+// All iterations in ONE launch with the transport matrix held ON CHIP.  The streamed kernels above are pinned to the HBM
+// rate (one 4-byte read per matrix entry per iteration); here every workgroup (one per CU) keeps a slab of rows of
+//     P_ij = exp(Z_ij + u_i + v_j)
+// in its registers (192 values per thread) and in LDS (up to 144 KiB), and the iteration becomes the classical scaling
+//     row:  f_i = mu_i / sum_j P_ij ;  P_ij *= f_i ;  u_i += log f_i
+//     col:  g_j = nu_j / sum_i P_ij ;  P_ij *= g_j ;  v_j += log g_j
+// -- two multiplies and two adds per entry per iteration, no transcendental, no HBM traffic.  Only the column sums cross
+// workgroups: per iteration each workgroup publishes its partial column sums, a barrier, every workgroup folds an equal
+// share of the columns (fixed order: deterministic) and publishes g, a second barrier.  When all workgroups of a problem
+// sit on one XCD the barrier is XCD-local (0.8 us), else a two-level chip barrier (2.1 us; tools/probes/gridbar_probe.hip).
+// The multiplicative form accumulates one rounding per multiply, so P is re-derived from Z, u and v (one HBM sweep)
+// every `refresh` iterations; u and v themselves are updated in the log domain exactly like the streamed path.
+// The dustbin row is an ordinary row (index n, all alpha); the dustbin column is kept per row in LDS (pb_i).
+struct OtResProb {
+  const float* z; int64_t ld; int n, m;
+  float* u; float* v; float* status;
+  float norm, log_mu_bin, log_nu_bin;
+  float* partial;     // [nblk][mpad]   partial column sums (column m = dustbin column)
+  float* gbuf;        // [2][mpad]      g_j, and v_j on the iterations that precede a refresh
+  int nblk, rpb, mpad, cpb;   // workgroups, rows per workgroup, padded columns (= nblk * cpb), columns folded per workgroup
+};
+struct OtResBlock { int prob, slab; };
+struct OtResArgs {
+  const OtResProb* probs; const OtResBlock* blocks;
+  unsigned* cnt;      // barrier counters: [0] chip, [64 * (1 + x)] XCD x (one 256-byte line each)
+  float alpha; int iters, refresh, local_mode;
+  int act[8];         // active workgroups per XCD slot (blockIdx & 7)
+  int nact_xcd;
+  unsigned long long* prof;   // diagnostics (GIMS_OT_PROF=1): cycles per phase of workgroup 0, else null
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st4_agent(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 ld4_agent(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+
+// ---- cross-lane sums without LDS traffic (gfx950): v_permlane16_swap / v_permlane32_swap fold two registers at a time
+// across the 16-lane rows of a wave, DPP finishes inside a row.  (Inline asm: the ROCm 7.2 builtins for the two swaps
+// return the same register for both halves of the result.)
+__device__ __forceinline__ void swap16(float& x, float& y) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+__device__ __forceinline__ void swap32(float& x, float& y) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_sum(float x) {
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float x) {   // all-reduce over the 16 lanes of a DPP row
+  x = dpp_sum<0xB1>(x);     // quad_perm [1,0,3,2]
+  x = dpp_sum<0x4E>(x);     // quad_perm [2,3,0,1]
+  x = dpp_sum<0x141>(x);    // row_half_mirror
+  return dpp_sum<0x140>(x); // row_mirror
+}
+// 8 per-lane values -> their totals over the 64 lanes.  Every lane of 16-lane row q (= lane >> 4) returns the total of
+// v[q] in t0 and of v[4 + q] in t1.  Fixed association order: deterministic.
+__device__ __forceinline__ void wave_rows8(float (&v)[8], float& t0, float& t1) {
+  swap16(v[0], v[1]); float s0 = v[0] + v[1];     // rows 0,2: v0 partials; rows 1,3: v1 partials
+  swap16(v[2], v[3]); float s1 = v[2] + v[3];
+  swap16(v[4], v[5]); float s2 = v[4] + v[5];
+  swap16(v[6], v[7]); float s3 = v[6] + v[7];
+  swap32(s0, s1); t0 = row16_sum(s0 + s1);        // row q: v[q]
+  swap32(s2, s3); t1 = row16_sum(s2 + s3);        // row q: v[4 + q]
+}
+
+// Returns false when the spin bound is hit (a workgroup of the launch is not resident): the caller flags the problem and
+// leaves -- a persistent kernel must never be able to hang the GPU.
+__device__ __forceinline__ bool ot_grid_barrier(const OtResArgs& a, unsigned epoch) {
+  __shared__ int ok_flag;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int x = blockIdx.x & 7;
+    unsigned* xc = a.cnt + 64 * (1 + x);
+    unsigned* wait_on = xc;
+    unsigned target = epoch * (unsigned)a.act[x];
+    if (a.local_mode) {
+      __hip_atomic_fetch_add(xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const unsigned old = __hip_atomic_fetch_add(xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == target - 1) __hip_atomic_fetch_add(a.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wait_on = a.cnt;
+      target = epoch * (unsigned)a.nact_xcd;
+    }
+    int spins = 0, ok = 1;
+    while (__hip_atomic_load(wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 18)) { ok = 0; break; }
+    }
+    ok_flag = ok;
+  }
+  __syncthreads();
+  return ok_flag != 0;
+}
+
+template <int C> struct OtResGeom {
+  static constexpr int RR = 192 / C;                                  // register rows per workgroup
+  static constexpr int RL = C == 1 ? 64 : (C == 2 ? 36 : (C == 4 ? 18 : 9));   // LDS rows per workgroup
+  static constexpr int RMAX = RR + RL;                                // rows per workgroup
+  static constexpr int COLS = 512 * C;
+  static constexpr int COLRED_OFF = (RL * COLS + 11 * RMAX + 3) & ~3;
+  static constexpr int LDS_FLOATS = COLRED_OFF + 2048;
+};
+
+template <int C, bool PROF>
+__global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
+  // No fma contraction in here: with it the compiler turns `P *= f; cs += P` into an fma on the OLD P plus a separate
+  // multiply, sinks all the multiplies behind the pass and keeps every row factor alive meanwhile -- 100+ spills.
+#pragma clang fp contract(off)
+  __shared__ unsigned long long prof_acc[8];
+  unsigned long long prof_t = 0;
+  auto stamp = [&](int phase) {
+    if (PROF && threadIdx.x == 0) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      if (phase >= 0) prof_acc[phase] += now - prof_t;
+      prof_t = now;
+    }
+  };
+  if (PROF && threadIdx.x < 8) prof_acc[threadIdx.x] = 0;
+  using G = OtResGeom<C>;
+  constexpr int RR = G::RR, RMAX = G::RMAX, COLS = G::COLS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* plds = lds;                       // [RL][COLS]
+  float* red = plds + G::RL * COLS;        // [8][RMAX]
+  float* us = red + 8 * RMAX;              // [RMAX] u of the slab rows
+  float* fac = us + RMAX;                  // [RMAX] row factors of the current iteration
+  float* pb = fac + RMAX;                  // [RMAX] dustbin-column entry of the slab rows
+  float* colred = lds + G::COLRED_OFF;     // [2048], 16-byte aligned
+
+  const OtResBlock bk = a.blocks[blockIdx.x];
+  if (bk.prob < 0) return;
+  const OtResProb p = a.probs[bk.prob];
+  const int t = threadIdx.x;
+  const int row0 = bk.slab * p.rpb;
+  int nrows = p.n + 1 - row0;
+  nrows = nrows < p.rpb ? nrows : p.rpb;
+  nrows = nrows > 0 ? nrows : 0;                          // a workgroup past the last row only folds columns
+  const int nl = nrows > RR ? nrows - RR : 0;            // rows kept in LDS
+  const float alpha = a.alpha;
+
+  float P[RR][C];
+  // g: column factors of the last column step, applied lazily in the next row pass.  Ahead of a fresh iteration the
+  // same registers carry v instead (P is re-derived from Z, u, v there and needs no g); v0 = 0.
+  float g[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) g[k] = 0.f;
+  float gbin = 0.f;
+  for (int r = t; r < RMAX; r += 512) {
+    fac[r] = 0.f;
+    pb[r] = 0.f;
+    us[r] = r < nrows ? p.u[row0 + r] : 0.f;
+  }
+  // column fold duty: columns [slab * cpb, slab * cpb + cpb) in groups of 4, slabs split over S thread subsets
+  const int G4 = p.cpb >> 2;
+  const int S = 512 / G4 < p.nblk ? 512 / G4 : p.nblk;
+  float vfold = 0.f;                                      // v of that column, carried across iterations
+  __syncthreads();
+
+  // P = exp(Z + u + v) for one row held in registers / LDS
+  // row0_o / c0_o / z_o are re-materialised through an empty asm at every fresh iteration: without that the compiler
+  // treats all RR rows' addresses and predicates as loop invariants, hoists them out of the iteration loop and spills
+  auto fresh_row = [&](int r, float (&out)[C], int row0_o, int c0_o, const float* z_o) {
+    const int grow = r < nrows ? row0_o + r : p.n + 1;     // rows past the slab stay zero
+    const float ui = us[r];
+    if (grow < p.n) {
+      const float* zr = z_o + (int64_t)grow * p.ld + c0_o;
+      float z[C];
+      if (C >= 4) {
+#pragma unroll
+        for (int k = 0; k < C; k += 4) {
+          const bool in = c0_o + k < p.m;                    // rows are padded to 4 floats: a quad that starts inside ends inside
+          const f32x4 q = in ? __builtin_nontemporal_load((const f32x4*)(zr + k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          z[k] = q[0]; z[k + 1] = q[1]; z[k + 2] = q[2]; z[k + 3] = q[3];
+        }
+      } else if (C == 2) {
+        const bool in = c0_o < p.m;                          // ld % 4 == 0, c0 even: the pair is inside the padded row
+        const f32x2 q = in ? __builtin_nontemporal_load((const f32x2*)zr) : f32x2{0.f, 0.f};
+        z[0] = q[0]; z[C - 1] = q[1];
+      } else {
+        z[0] = c0_o < p.m ? __builtin_nontemporal_load(zr) : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < C; ++k) out[k] = c0_o + k < p.m ? __expf((z[k] + ui) + g[k]) : 0.f;
+    } else if (grow == p.n) {                              // the dustbin row: every entry alpha
+#pragma unroll
+      for (int k = 0; k < C; ++k) out[k] = c0_o + k < p.m ? __expf((alpha + ui) + g[k]) : 0.f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < C; ++k) out[k] = 0.f;
+    }
+  };
+
+  unsigned epoch = 0;
+  for (int it = 0; it < a.iters; ++it) {
+    // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration: as loop invariants
+    // the compiler would keep ~20 registers of hoisted addresses alive next to the 192 registers of P
+    int tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));
+    const int t = tq, lane = t & 63, wave = t >> 6, c0 = t * C;
+    const int fg4 = t % G4, fss = t / G4, fcol = bk.slab * p.cpb + t;
+    const bool fresh = it == 0 || it == a.iters - 1 || (a.refresh > 0 && it % a.refresh == 0);   // the last one: exact P behind the final u, v
+    const bool publish_v = it + 1 < a.iters && (it + 2 == a.iters || (a.refresh > 0 && (it + 1) % a.refresh == 0));
+    // ---------------- row pass: P *= g (P re-derived from Z, u, v first on a fresh iteration), row sums
+    stamp(-1);
+    if (fresh) {
+      int row0_o = row0, c0_o = c0;
+      const float* z_o = p.z;
+      asm volatile("" : "+s"(row0_o), "+s"(z_o));
+      constexpr int FB = C == 8 ? 4 : 8;                 // rows of loads in flight, then their exps; the fences keep the
+#pragma unroll                                           // compiler from hoisting all RR rows' addresses and loads at once
+      for (int rb = 0; rb < RR; rb += FB) {
+#pragma unroll
+        for (int r8 = 0; r8 < FB; ++r8) fresh_row(rb + r8, P[rb + r8], row0_o, c0_o, z_o);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      for (int r = 0; r < nl; ++r) {
+        float x[C];
+        fresh_row(RR + r, x, row0_o, c0_o, z_o);
+        float* q = plds + r * COLS + c0;
+#pragma unroll
+        for (int k = 0; k < C; ++k) q[k] = x[k];
+      }
+      for (int r = t; r < nrows; r += 512) pb[r] = __expf((alpha + us[r]) + gbin);
+#pragma unroll
+      for (int k = 0; k < C; ++k) g[k] = 1.f;
+      gbin = 1.f;
+    } else {
+      for (int r = t; r < nrows; r += 512) pb[r] *= gbin;
+    }
+#pragma unroll
+    for (int rb = 0; rb < RR; rb += 8) {
+      float rs[8];
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int r = rb + r8;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) { P[r][k] *= g[k]; s += P[r][k]; }
+        rs[r8] = s;
+      }
+      float t0, t1;
+      wave_rows8(rs, t0, t1);
+      if ((lane & 15) == 0) { red[wave * RMAX + rb + (lane >> 4)] = t0; red[wave * RMAX + rb + 4 + (lane >> 4)] = t1; }
+      if (rb % 16 == 8) __builtin_amdgcn_sched_barrier(0);   // two batches may interleave (reduction chains are latency-bound)
+    }
+    for (int rb = 0; rb < nl; rb += 8) {
+      float rs[8];
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int r = rb + r8;
+        float s = 0.f;
+        if (r < nl) {
+          float* q = plds + r * COLS + c0;
+#pragma unroll
+          for (int k = 0; k < C; ++k) { const float x = q[k] * g[k]; q[k] = x; s += x; }
+        }
+        rs[r8] = s;
+      }
+      float t0, t1;
+      wave_rows8(rs, t0, t1);
+      if ((lane & 15) == 0) {
+        const int ra = rb + (lane >> 4), rc = ra + 4;
+        if (ra < nl) red[wave * RMAX + RR + ra] = t0;
+        if (rc < nl) red[wave * RMAX + RR + rc] = t1;
+      }
+    }
+    __syncthreads();
+    stamp(0);
+    for (int r = t; r < nrows; r += 512) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tot += red[w * RMAX + r];
+      const float pbi = pb[r];
+      tot += pbi;
+      if (!(tot > 0.f) || !(tot < 3.0e38f)) p.status[0] = 1.f;
+      const float du = (row0 + r < p.n ? p.norm : p.log_mu_bin) - logf(tot);
+      us[r] += du;
+      const float f = __expf(du);
+      fac[r] = f;
+      pb[r] = pbi * f;
+    }
+    __syncthreads();
+    stamp(1);
+    // ---------------- column pass: P *= f, partial column sums of this slab
+    float cs[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) cs[k] = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < RR; rb += 8) {
+      const f32x4 fa = *(const f32x4*)(fac + rb), fb = *(const f32x4*)(fac + rb + 4);   // LDS broadcast reads
+      const float f8[8] = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) { P[rb + r8][k] *= f8[r8]; cs[k] += P[rb + r8][k]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int r = 0; r < nl; ++r) {
+      const float f = fac[RR + r];
+      float* q = plds + r * COLS + c0;
+#pragma unroll
+      for (int k = 0; k < C; ++k) { const float x = q[k] * f; q[k] = x; cs[k] += x; }
+    }
+    stamp(2);
+    float* mine = p.partial + (int64_t)bk.slab * p.mpad;
+    if (C >= 4) {
+#pragma unroll
+      for (int k = 0; k < C; k += 4)
+        if (c0 + k + 3 < p.m) {
+          st4_agent(mine + c0 + k, f32x4{cs[k], cs[k + 1], cs[k + 2], cs[k + 3]});
+        } else {                                         // the quad that straddles m must not touch the dustbin slot
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c0 + k + j < p.m) st_agent(mine + c0 + k + j, cs[k + j]);
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+        if (c0 + k < p.m) st_agent(mine + c0 + k, cs[k]);
+    }
+    if (wave == 0) {                                    // dustbin column: sum of pb over the slab rows
+      float s = 0.f;
+      for (int r = lane; r < nrows; r += 64) s += pb[r];
+      s = wave_sum(s);
+      if (lane == 0) st_agent(mine + p.m, s);
+    }
+    if (!ot_grid_barrier(a, ++epoch)) { p.status[0] = 2.f; return; }
+    stamp(3);
+    // ---------------- fold this workgroup's share of the columns over all slabs; v += log g
+    if (fss < S) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* src = p.partial + bk.slab * p.cpb + 4 * fg4;
+      for (int k = fss; k < p.nblk; k += S) acc += ld4_agent(src + (int64_t)k * p.mpad);
+      *(f32x4*)(colred + (fss * G4 + fg4) * 4) = acc;
+    }
+    __syncthreads();
+    if (t < p.cpb && fcol <= p.m) {
+      float tot = 0.f;
+      const int j4 = t >> 2, jc = t & 3;
+      for (int s = 0; s < S; ++s) tot += colred[(s * G4 + j4) * 4 + jc];
+      if (!(tot > 0.f) || !(tot < 3.0e38f)) p.status[0] = 1.f;
+      const float dv = (fcol < p.m ? p.norm : p.log_nu_bin) - logf(tot);
+      vfold += dv;
+      st_agent(p.gbuf + fcol, __expf(dv));
+      if (publish_v) st_agent(p.gbuf + p.mpad + fcol, vfold);
+    }
+    stamp(4);
+    if (!ot_grid_barrier(a, ++epoch)) { p.status[0] = 2.f; return; }
+    stamp(5);
+    if (it + 1 < a.iters) {
+      // next column factors -- or, ahead of a fresh iteration, v itself (see the declaration of g)
+      const float* src = p.gbuf + (publish_v ? p.mpad : 0);
+      const float idle = publish_v ? 0.f : 1.f;          // columns >= m hold zeros in P: keep their factor finite
+      if (C >= 4) {
+#pragma unroll
+        for (int k = 0; k < C; k += 4) {
+          const f32x4 q = c0 + k < p.m ? ld4_agent(src + c0 + k) : f32x4{idle, idle, idle, idle};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[k + j] = c0 + k + j < p.m ? q[j] : idle;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) g[k] = c0 + k < p.m ? ld_agent(src + c0 + k) : idle;
+      }
+      gbin = ld_agent(src + p.m);
+    }
+    stamp(6);
+  }
+  if (PROF && blockIdx.x == 0 && threadIdx.x < 7) a.prof[threadIdx.x] = prof_acc[threadIdx.x];
+  // ---------------- potentials out (the selection kernels read Z, u, v)
+  for (int r = t; r < nrows; r += 512) p.u[row0 + r] = us[r];
+  if (t < p.cpb && bk.slab * p.cpb + t <= p.m) p.v[bk.slab * p.cpb + t] = vfold;
+}
+
+// ---- host side of the resident path: geometry, workspace, launches
+struct OtResPlan {
+  bool ok; int C, local, nbu, ppg, ngroups;
+  size_t bytes;       // workspace bytes on top of the streamed path's
+};
+static int ot_res_cap(int C) { return C == 1 ? OtResGeom<1>::RMAX : (C == 2 ? OtResGeom<2>::RMAX : (C == 4 ? OtResGeom<4>::RMAX : OtResGeom<8>::RMAX)); }
+static int ot_env(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+static int ot_res_cus() {
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+  }
+  return n;
+}
+static inline int roundup4(int x) { return (x + 3) & ~3; }
+static inline size_t al256r(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// One launch = 256 workgroups (one per CU, all resident).  Every problem of a call gets the same number of workgroups
+// `nbu`; when nbu <= 32 the problems are placed XCD by XCD (workgroup b runs on XCD b % 8) and synchronise per XCD.
+static OtResPlan ot_res_plan(const gims_ot_problem* pr, int np, int iters) {
+  OtResPlan P{};
+  if (!ot_env("GIMS_OT_RESIDENT", 1) || iters < 1 || ot_res_cus() < 256) return P;
+  int maxm = 0;
+  double cells = 0.0;
+  for (int i = 0; i < np; ++i) {
+    maxm = pr[i].m > maxm ? pr[i].m : maxm;
+    cells += (double)pr[i].n * pr[i].m;
+  }
+  // an iteration of the resident kernel costs ~12 us whatever the size (two barriers + the register sweep); below
+  // ~6 M matrix entries the streamed kernels finish an iteration sooner (GIMS_OT_RESIDENT=2 forces the resident path)
+  if (cells < 6.0e6 && ot_env("GIMS_OT_RESIDENT", 1) != 2) return P;
+  const int C = maxm <= 512 ? 1 : (maxm <= 1024 ? 2 : (maxm <= 2048 ? 4 : (maxm <= 4096 ? 8 : 0)));
+  if (!C) return P;
+  const int cap = ot_res_cap(C);
+  int need = 1;
+  for (int i = 0; i < np; ++i) {
+    const int a = cdiv(pr[i].n + 1, cap), b = cdiv(pr[i].m + 1, 508);   // rows fit on chip; fold duty: cpb <= 512 columns
+    need = a > need ? a : need;
+    need = b > need ? b : need;
+  }
+  if (need > 256) return P;
+  P.C = C;
+  if (need <= 32) {
+    P.local = 1;
+    int nbu = 1;
+    while (nbu < need) nbu *= 2;
+    while (nbu < 32 && np <= 8 * (32 / (2 * nbu))) nbu *= 2;       // spare CUs: spread every problem over more of them
+    P.nbu = nbu;
+    P.ppg = 8 * (32 / nbu);
+  } else {
+    P.local = 0;
+    int ppg = 256 / need;
+    ppg = np < ppg ? np : ppg;
+    P.ppg = ppg;
+    P.nbu = 256 / ppg;
+  }
+  P.ngroups = cdiv(np, P.ppg);
+  if (P.ngroups > 16) return P;
+  size_t b = al256r(sizeof(OtResProb) * (size_t)np) + (size_t)P.ngroups * (al256r(sizeof(OtResBlock) * 256) + al256r(64 * 9 * 4));
+  for (int i = 0; i < np; ++i) {
+    const size_t mpad = (size_t)P.nbu * roundup4(cdiv(pr[i].m + 1, P.nbu));
+    b += al256r((size_t)P.nbu * mpad * 4) + al256r(2 * mpad * 4);
+  }
+  P.bytes = b;
+  P.ok = true;
+  return P;
+}
+
+template <int C>
+static int ot_res_launch(OtResArgs a, hipStream_t s) {
+  static bool attr = false;
+  constexpr size_t lds = OtResGeom<C>::LDS_FLOATS * sizeof(float);
+  if (!attr) {
+    GIMS_HIP(hipFuncSetAttribute((const void*)ot_resident_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ot_resident_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  if (ot_env("GIMS_OT_PROF", 0)) {     // diagnostics: per-phase cycles of workgroup 0 (synchronous; tools/ot_probe.py)
+    static unsigned long long* dprof = nullptr;
+    if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 8 * sizeof(unsigned long long)));
+    a.prof = dprof;
+    hipLaunchKernelGGL((ot_resident_kernel<C, true>), dim3(256), dim3(512), lds, s, a);
+    GIMS_LAUNCH_CHECK();
+    unsigned long long h[8];
+    GIMS_HIP(hipStreamSynchronize(s));
+    GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
+    static const char* names[7] = {"row pass", "row totals", "column pass", "publish + barrier 1", "fold", "barrier 2", "read g"};
+    fprintf(stderr, "[ot_resident C=%d iters=%d] cycles/iteration of workgroup 0:", C, a.iters);
+    for (int i = 0; i < 7; ++i) fprintf(stderr, "  %s %.0f;", names[i], (double)h[i] / a.iters);
+    fprintf(stderr, "\n");
+    return GIMS_OK;
+  }
+  hipLaunchKernelGGL((ot_resident_kernel<C, false>), dim3(256), dim3(512), lds, s, a);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+// Runs all `iters` iterations of every problem; `base` is the resident part of the workspace (P.bytes).
+static int ot_res_run(const OtResPlan& P, const std::vector<OtDev>& hprob, float alpha, int iters, char* base, hipStream_t s) {
+  const int np = (int)hprob.size();
+  size_t off = 0;
+  OtResProb* dprob = (OtResProb*)(base + off); off += al256r(sizeof(OtResProb) * (size_t)np);
+  std::vector<OtResProb> hp(np);
+  for (int i = 0; i < np; ++i) {
+    const OtDev& d = hprob[i];
+    OtResProb q;
+    q.z = d.z; q.ld = d.ld; q.n = d.n; q.m = d.m; q.u = d.u; q.v = d.v; q.status = d.status;
+    q.norm = d.norm; q.log_mu_bin = d.log_mu_bin; q.log_nu_bin = d.log_nu_bin;
+    q.nblk = P.nbu; q.rpb = cdiv(d.n + 1, P.nbu); q.cpb = roundup4(cdiv(d.m + 1, P.nbu)); q.mpad = q.nblk * q.cpb;
+    q.partial = (float*)(base + off); off += al256r((size_t)q.nblk * q.mpad * 4);
+    q.gbuf = (float*)(base + off); off += al256r((size_t)2 * q.mpad * 4);
+    hp[i] = q;
+  }
+  int rc = upload_table(hp.data(), sizeof(OtResProb) * (size_t)np, dprob, s);
+  if (rc != GIMS_OK) return rc;
+  const int refresh = ot_env("GIMS_OT_REFRESH", 33);
+  for (int gi = 0; gi < P.ngroups; ++gi) {
+    OtResBlock* dblk = (OtResBlock*)(base + off); off += al256r(sizeof(OtResBlock) * 256);
+    unsigned* dcnt = (unsigned*)(base + off); off += al256r(64 * 9 * 4);
+    OtResBlock hb[256];
+    for (int b = 0; b < 256; ++b) hb[b] = OtResBlock{-1, 0};
+    OtResArgs a{};
+    const int p0 = gi * P.ppg, p1 = (p0 + P.ppg < np) ? p0 + P.ppg : np;
+    for (int q = 0; q < p1 - p0; ++q)
+      for (int sl = 0; sl < P.nbu; ++sl) {
+        const int b = P.local ? ((q / 8) * P.nbu + sl) * 8 + (q % 8) : q * P.nbu + sl;
+        hb[b] = OtResBlock{p0 + q, sl};
+        a.act[b & 7] += 1;
+      }
+    for (int x = 0; x < 8; ++x) a.nact_xcd += a.act[x] > 0;
+    rc = upload_table(hb, sizeof(hb), dblk, s);
+    if (rc != GIMS_OK) return rc;
+    GIMS_HIP(hipMemsetAsync(dcnt, 0, 64 * 9 * 4, s));
+    a.probs = dprob; a.blocks = dblk; a.cnt = dcnt; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.local_mode = P.local;
+    rc = P.C == 1 ? ot_res_launch<1>(a, s) : (P.C == 2 ? ot_res_launch<2>(a, s) : (P.C == 4 ? ot_res_launch<4>(a, s) : ot_res_launch<8>(a, s)));
+    if (rc != GIMS_OK) return rc;
+  }
+  return GIMS_OK;
+}
+
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static void ot_launch_shape(const gims_ot_problem* pr, int np, int& threads, int& cpt, int& maxn, int& maxm) {
@@ -468,7 +993,7 @@ extern "C" size_t gims_sinkhorn_workspace_bytes(const gims_ot_problem* pr, int32
   ot_launch_shape(pr, np, threads, cpt, maxn, maxm);
   size_t b = al256(sizeof(OtDev) * (size_t)np);
   for (int i = 0; i < np; ++i) b += ot_problem_bytes(pr[i], ot_G(pr[i].n, np, threads, cpt));
-  return b;
+  return b + al256(ot_res_plan(pr, np, 1).bytes);       // resident-path buffers (0 when that path is off or does not fit)
 }
 
 extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float alpha, int32_t iters,
@@ -517,7 +1042,12 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   const OtDev* dp = (const OtDev*)work;
   hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, iters == 0 ? 1 : 0);
   dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
-  for (int it = 0; it < iters; ++it) {
+  const OtResPlan plan = ot_res_plan(pr, np, iters);
+  if (plan.ok) {      // whole iteration loop on chip (one launch per group of problems)
+    const int rc = ot_res_run(plan, hprob, alpha, iters, base + off, s);
+    if (rc != GIMS_OK) return rc;
+  }
+  for (int it = 0; it < (plan.ok ? 0 : iters); ++it) {
     if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha);
     else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha);
     else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha);

@@ -180,7 +180,9 @@ def test_attention_online_rescale(hip):
 @pytest.mark.parametrize("n,m,iters,scale", [(37, 53, 20, 3.0), (2, 2, 100, 1.0), (200, 180, 100, 5.0), (1025, 1000, 100, 8.0),
                                               (64, 64, 0, 3.0), (5, 300, 1, 2.0), (300, 1111, 50, 30.0), (130, 4500, 10, 4.0),
                                               (40, 9000, 5, 4.0)])
-def test_sinkhorn_match(hip, n, m, iters, scale):
+@pytest.mark.parametrize("resident", ["0", "2"])      # streamed kernels / on-chip resident kernel (forced where it fits)
+def test_sinkhorn_match(hip, monkeypatch, n, m, iters, scale, resident):
+    monkeypatch.setenv("GIMS_OT_RESIDENT", resident)
     r = _rng(n * 1000 + m)
     z = (r.normal(size=(n, m)) * scale).astype(np.float32)
     k = min(n, m)
@@ -211,9 +213,14 @@ def test_sinkhorn_match(hip, n, m, iters, scale):
         np.testing.assert_allclose(it["mscores1"].cpu().numpy(), s1[0].numpy(), atol=1e-4)
 
 
-def test_sinkhorn_batched_ragged(hip):
+@pytest.mark.parametrize("resident,shapes", [("0", [(100, 90), (257, 300), (31, 33)]), ("2", [(100, 90), (257, 300), (31, 33)]),
+                                             # chip-wide barrier mode (a problem needs more than the 32 CUs of one XCD), two launches
+                                             ("2", [(2300, 2200), (2100, 2250), (1500, 2300), (2290, 2100)]),
+                                             # XCD-local mode with more problems than one launch holds
+                                             ("2", [(600 + 7 * i, 640 - 5 * i) for i in range(40)])])
+def test_sinkhorn_batched_ragged(hip, monkeypatch, resident, shapes):
+    monkeypatch.setenv("GIMS_OT_RESIDENT", resident)
     r = _rng(9)
-    shapes = [(100, 90), (257, 300), (31, 33)]
     items, refs = [], []
     for n, m in shapes:
         z = (r.normal(size=(n, m)) * 4).astype(np.float32)
@@ -233,6 +240,36 @@ def test_sinkhorn_batched_ragged(hip):
         i0, _, _, _ = O.select_matches(ref, 0.2)
         agree = (it["matches0"].cpu().numpy() == i0[0].numpy()).mean()
         assert agree > 0.99
+        assert float(it["uv"][-1]) == 0.0
+
+
+def test_sinkhorn_resident_matches_streamed(hip, monkeypatch):
+    """The two Sinkhorn implementations (streamed log-domain sweeps / on-chip multiplicative scaling with periodic
+    re-derivation) must agree on the potentials to f32 noise and on every match, at the bench's problem shape."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("GIMS_OT_RESIDENT", mode)
+        items = []
+        gg = torch.Generator(device="cpu").manual_seed(3)
+        for i in range(9):
+            n, m = 1022 - 3 * i, 1024 - 5 * i
+            z = torch.zeros((n, (m + 3) // 4 * 4))
+            z[:, :m] = torch.randn(n, m, generator=gg) * 5
+            k = min(n, m)
+            z[torch.arange(k), torch.randperm(m, generator=gg)[:k]] += 20.0
+            items.append(dict(scores=z.cuda(), n=n, m=m, matches0=torch.empty(n, dtype=torch.int64, device="cuda"),
+                              matches1=torch.empty(m, dtype=torch.int64, device="cuda"), mscores0=torch.empty(n, device="cuda"),
+                              mscores1=torch.empty(m, device="cuda"), uv=torch.empty(n + m + 3, device="cuda")))
+        probs = hip.make_ot_problems(items)
+        work = torch.empty(hip.sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device="cuda")
+        hip.sinkhorn_match(probs, 1.0, 100, 0.2, work)
+        outs[mode] = items
+    for a, b in zip(outs["0"], outs["2"]):
+        assert float(b["uv"][-1]) == 0.0
+        assert float((a["uv"][:-1] - b["uv"][:-1]).abs().max()) < 1e-4
+        assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches1"], b["matches1"])
+        assert float((a["mscores0"] - b["mscores0"]).abs().max()) < 1e-5
 
 
 # --------------------------------------------------------------------------------------------- small kernels
