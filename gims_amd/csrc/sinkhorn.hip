@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 namespace gims {
@@ -439,9 +440,10 @@ __global__ void ot_matrix_kernel(const float* __restrict__ z, int64_t ld, int n,
 //     row:  f_i = mu_i / sum_j P_ij ;  P_ij *= f_i ;  u_i += log f_i
 //     col:  g_j = nu_j / sum_i P_ij ;  P_ij *= g_j ;  v_j += log g_j
 // -- two multiplies and two adds per entry per iteration, no transcendental, no HBM traffic.  Only the column sums cross
-// workgroups: per iteration each workgroup publishes its partial column sums, a barrier, every workgroup folds an equal
-// share of the columns (fixed order: deterministic) and publishes g, a second barrier.  When all workgroups of a problem
-// sit on one XCD the barrier is XCD-local (0.8 us), else a two-level chip barrier (2.1 us; tools/probes/gridbar_probe.hip).
+// workgroups: per iteration each workgroup publishes its partial column sums, every workgroup folds an equal share of the
+// columns over all slabs (fixed order: deterministic) and publishes g.  There is no barrier: the exchanged values carry
+// the parity of their iteration in the sign bit and readers re-read until it matches (see "publish" in the kernel).
+// Problems that fit the 32 CUs of one XCD are placed XCD by XCD (workgroup b runs on XCD b % 8).
 // The multiplicative form accumulates one rounding per multiply, so P is re-derived from Z, u and v (one HBM sweep)
 // every `refresh` iterations; u and v themselves are updated in the log domain exactly like the streamed path.
 // The dustbin row is an ordinary row (index n, all alpha); the dustbin column is kept per row in LDS (pb_i).
@@ -456,10 +458,7 @@ struct OtResProb {
 struct OtResBlock { int prob, slab; };
 struct OtResArgs {
   const OtResProb* probs; const OtResBlock* blocks;
-  unsigned* cnt;      // barrier counters: [0] chip, [64 * (1 + x)] XCD x (one 256-byte line each)
-  float alpha; int iters, refresh, local_mode;
-  int act[8];         // active workgroups per XCD slot (blockIdx & 7)
-  int nact_xcd;
+  float alpha; int iters, refresh;
   unsigned long long* prof;   // diagnostics (GIMS_OT_PROF=1): cycles per phase of workgroup 0, else null
 };
 
@@ -467,6 +466,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st4_agent(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+// Several agent-scope 16-byte loads in flight: the loads are issued back to back and ONE wait covers them.  The wait asm
+// takes the destination registers as read-write operands, so every later use depends on it (no stale read).
+__device__ __forceinline__ void ld4_agent_issue(f32x4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void ld4_agent_wait(f32x4& a, f32x4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
+__device__ __forceinline__ void ld4_agent_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
 __device__ __forceinline__ f32x4 ld4_agent(const float* p) {
   f32x4 v;
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
@@ -500,36 +506,6 @@ __device__ __forceinline__ void wave_rows8(float (&v)[8], float& t0, float& t1) 
   swap32(s2, s3); t1 = row16_sum(s2 + s3);        // row q: v[4 + q]
 }
 
-// Returns false when the spin bound is hit (a workgroup of the launch is not resident): the caller flags the problem and
-// leaves -- a persistent kernel must never be able to hang the GPU.
-__device__ __forceinline__ bool ot_grid_barrier(const OtResArgs& a, unsigned epoch) {
-  __shared__ int ok_flag;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int x = blockIdx.x & 7;
-    unsigned* xc = a.cnt + 64 * (1 + x);
-    unsigned* wait_on = xc;
-    unsigned target = epoch * (unsigned)a.act[x];
-    if (a.local_mode) {
-      __hip_atomic_fetch_add(xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      const unsigned old = __hip_atomic_fetch_add(xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == target - 1) __hip_atomic_fetch_add(a.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      wait_on = a.cnt;
-      target = epoch * (unsigned)a.nact_xcd;
-    }
-    int spins = 0, ok = 1;
-    while (__hip_atomic_load(wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 18)) { ok = 0; break; }
-    }
-    ok_flag = ok;
-  }
-  __syncthreads();
-  return ok_flag != 0;
-}
-
 template <int C> struct OtResGeom {
   static constexpr int RR = 192 / C;                                  // register rows per workgroup
   static constexpr int RL = C == 1 ? 64 : (C == 2 ? 36 : (C == 4 ? 18 : 9));   // LDS rows per workgroup
@@ -544,6 +520,7 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
   // No fma contraction in here: with it the compiler turns `P *= f; cs += P` into an fma on the OLD P plus a separate
   // multiply, sinks all the multiplies behind the pass and keeps every row factor alive meanwhile -- 100+ spills.
 #pragma clang fp contract(off)
+  __shared__ int fail_flag;
   __shared__ unsigned long long prof_acc[8];
   unsigned long long prof_t = 0;
   auto stamp = [&](int phase) {
@@ -554,6 +531,7 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
     }
   };
   if (PROF && threadIdx.x < 8) prof_acc[threadIdx.x] = 0;
+  if (threadIdx.x == 0) fail_flag = 0;
   using G = OtResGeom<C>;
   constexpr int RR = G::RR, RMAX = G::RMAX, COLS = G::COLS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -575,7 +553,16 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
   const int nl = nrows > RR ? nrows - RR : 0;            // rows kept in LDS
   const float alpha = a.alpha;
 
-  float P[RR][C];
+  // P lives in registers as aligned pairs (two adjacent columns): the sweeps then run on v_pk_mul_f32 / v_pk_add_f32,
+  // half the VALU instructions of scalar code
+  constexpr int H = C >= 2 ? C / 2 : 1;
+  using E = typename std::conditional<(C >= 2), f32x2, float>::type;
+  auto mk = [](float x, float y) -> E { if constexpr (C >= 2) return E{x, y}; else return x; };
+  auto lo = [](E v) -> float { if constexpr (C >= 2) return v[0]; else return v; };
+  auto hi = [](E v) -> float { if constexpr (C >= 2) return v[1]; else return 0.f; };
+  E P[RR][H];
+  // LDS rows keep the same pairs, pair h of thread t at [(row * H + h) * 512 + t]: consecutive lanes, no bank conflicts
+  E* pl2 = (E*)plds;
   // g: column factors of the last column step, applied lazily in the next row pass.  Ahead of a fresh iteration the
   // same registers carry v instead (P is re-derived from Z, u, v there and needs no g); v0 = 0.
   float g[C];
@@ -627,7 +614,6 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
     }
   };
 
-  unsigned epoch = 0;
   for (int it = 0; it < a.iters; ++it) {
     // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration: as loop invariants
     // the compiler would keep ~20 registers of hoisted addresses alive next to the 192 registers of P
@@ -647,15 +633,19 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
 #pragma unroll                                           // compiler from hoisting all RR rows' addresses and loads at once
       for (int rb = 0; rb < RR; rb += FB) {
 #pragma unroll
-        for (int r8 = 0; r8 < FB; ++r8) fresh_row(rb + r8, P[rb + r8], row0_o, c0_o, z_o);
+        for (int r8 = 0; r8 < FB; ++r8) {
+          float x[C];
+          fresh_row(rb + r8, x, row0_o, c0_o, z_o);
+#pragma unroll
+          for (int h = 0; h < H; ++h) P[rb + r8][h] = mk(x[2 * h], x[(2 * h + 1) % C]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       for (int r = 0; r < nl; ++r) {
         float x[C];
         fresh_row(RR + r, x, row0_o, c0_o, z_o);
-        float* q = plds + r * COLS + c0;
 #pragma unroll
-        for (int k = 0; k < C; ++k) q[k] = x[k];
+        for (int h = 0; h < H; ++h) pl2[(r * H + h) * 512 + t] = mk(x[2 * h], x[(2 * h + 1) % C]);
       }
       for (int r = t; r < nrows; r += 512) pb[r] = __expf((alpha + us[r]) + gbin);
 #pragma unroll
@@ -664,22 +654,27 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
     } else {
       for (int r = t; r < nrows; r += 512) pb[r] *= gbin;
     }
+    E g2[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) g2[h] = mk(g[2 * h], g[(2 * h + 1) % C]);
 #pragma unroll
     for (int rb = 0; rb < RR; rb += 8) {
       float rs[8];
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int r = rb + r8;
-        float s = 0.f;
+        E s2 = P[r][0] * g2[0];
+        P[r][0] = s2;
 #pragma unroll
-        for (int k = 0; k < C; ++k) { P[r][k] *= g[k]; s += P[r][k]; }
-        rs[r8] = s;
+        for (int h = 1; h < H; ++h) { P[r][h] *= g2[h]; s2 += P[r][h]; }
+        rs[r8] = lo(s2) + hi(s2);
       }
       float t0, t1;
       wave_rows8(rs, t0, t1);
       if ((lane & 15) == 0) { red[wave * RMAX + rb + (lane >> 4)] = t0; red[wave * RMAX + rb + 4 + (lane >> 4)] = t1; }
       if (rb % 16 == 8) __builtin_amdgcn_sched_barrier(0);   // two batches may interleave (reduction chains are latency-bound)
     }
+    stamp(5);
     for (int rb = 0; rb < nl; rb += 8) {
       float rs[8];
 #pragma unroll
@@ -687,9 +682,12 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
         const int r = rb + r8;
         float s = 0.f;
         if (r < nl) {
-          float* q = plds + r * COLS + c0;
+          E* q = pl2 + r * H * 512 + t;
+          E s2 = q[0] * g2[0];
+          q[0] = s2;
 #pragma unroll
-          for (int k = 0; k < C; ++k) { const float x = q[k] * g[k]; q[k] = x; s += x; }
+          for (int h = 1; h < H; ++h) { const E x = q[h * 512] * g2[h]; q[h * 512] = x; s2 += x; }
+          s = lo(s2) + hi(s2);
         }
         rs[r8] = s;
       }
@@ -702,6 +700,10 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
       }
     }
     __syncthreads();
+    if (fail_flag) {                                     // a bounded wait ran out somewhere in this workgroup (uniform exit)
+      if (threadIdx.x == 0) p.status[0] = 2.f;
+      return;
+    }
     stamp(0);
     for (int r = t; r < nrows; r += 512) {
       float tot = 0.f;
@@ -719,56 +721,101 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
     __syncthreads();
     stamp(1);
     // ---------------- column pass: P *= f, partial column sums of this slab
-    float cs[C];
+    E cs2[H];
 #pragma unroll
-    for (int k = 0; k < C; ++k) cs[k] = 0.f;
+    for (int h = 0; h < H; ++h) cs2[h] = mk(0.f, 0.f);
 #pragma unroll
     for (int rb = 0; rb < RR; rb += 8) {
       const f32x4 fa = *(const f32x4*)(fac + rb), fb = *(const f32x4*)(fac + rb + 4);   // LDS broadcast reads
       const float f8[8] = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
+        const E f2 = mk(f8[r8], f8[r8]);
 #pragma unroll
-        for (int k = 0; k < C; ++k) { P[rb + r8][k] *= f8[r8]; cs[k] += P[rb + r8][k]; }
+        for (int h = 0; h < H; ++h) { P[rb + r8][h] *= f2; cs2[h] += P[rb + r8][h]; }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(7);
     for (int r = 0; r < nl; ++r) {
       const float f = fac[RR + r];
-      float* q = plds + r * COLS + c0;
+      const E f2 = mk(f, f);
+      E* q = pl2 + r * H * 512 + t;
 #pragma unroll
-      for (int k = 0; k < C; ++k) { const float x = q[k] * f; q[k] = x; cs[k] += x; }
+      for (int h = 0; h < H; ++h) { const E x = q[h * 512] * f2; q[h * 512] = x; cs2[h] += x; }
     }
+    float cs[C];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { cs[2 * h] = lo(cs2[h]); if (C >= 2) cs[(2 * h + 1) % C] = hi(cs2[h]); }
     stamp(2);
+    // ---------------- publish.  No barrier anywhere: every exchanged value is >= +0, so its sign bit carries the parity of
+    // the iteration that wrote it and a reader simply re-reads until the parity is the one it is waiting for.  Safe with
+    // ONE bit: a slab overwrites its partials of iteration i only after it has read g of iteration i from every fold
+    // workgroup, and a fold workgroup publishes that g only after it has read the partials of iteration i of every slab
+    // (likewise for g); so a location holds the value of iteration i or i-1, never anything older.  The buffers start as
+    // 0xFF.. (sign 1) and iteration 0 waits for sign 0.
+    const unsigned tagbit = (unsigned)(it & 1) << 31;
+    auto tg = [&](float x) { return __uint_as_float(__float_as_uint(x) | tagbit); };
     float* mine = p.partial + (int64_t)bk.slab * p.mpad;
     if (C >= 4) {
 #pragma unroll
       for (int k = 0; k < C; k += 4)
         if (c0 + k + 3 < p.m) {
-          st4_agent(mine + c0 + k, f32x4{cs[k], cs[k + 1], cs[k + 2], cs[k + 3]});
+          st4_agent(mine + c0 + k, f32x4{tg(cs[k]), tg(cs[k + 1]), tg(cs[k + 2]), tg(cs[k + 3])});
         } else {                                         // the quad that straddles m must not touch the dustbin slot
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (c0 + k + j < p.m) st_agent(mine + c0 + k + j, cs[k + j]);
+            if (c0 + k + j < p.m) st_agent(mine + c0 + k + j, tg(cs[k + j]));
         }
     } else {
 #pragma unroll
       for (int k = 0; k < C; ++k)
-        if (c0 + k < p.m) st_agent(mine + c0 + k, cs[k]);
+        if (c0 + k < p.m) st_agent(mine + c0 + k, tg(cs[k]));
     }
     if (wave == 0) {                                    // dustbin column: sum of pb over the slab rows
       float s = 0.f;
       for (int r = lane; r < nrows; r += 64) s += pb[r];
       s = wave_sum(s);
-      if (lane == 0) st_agent(mine + p.m, s);
+      if (lane == 0) st_agent(mine + p.m, tg(s));
     }
-    if (!ot_grid_barrier(a, ++epoch)) { p.status[0] = 2.f; return; }
     stamp(3);
     // ---------------- fold this workgroup's share of the columns over all slabs; v += log g
     if (fss < S) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* src = p.partial + bk.slab * p.cpb + 4 * fg4;
-      for (int k = fss; k < p.nblk; k += S) acc += ld4_agent(src + (int64_t)k * p.mpad);
+      const int colbase = bk.slab * p.cpb + 4 * fg4;
+      const float* src = p.partial + colbase;
+      unsigned vmask = 0;                                 // lanes of the quad that are real columns (<= m: dustbin included)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vmask |= (colbase + j <= p.m ? 1u : 0u) << j;
+      for (int k = fss; k < p.nblk; k += 4 * S) {         // 4 loads in flight per trip (slabs past the end re-read slab k)
+        f32x4 q0, q1, q2, q3;
+        const int k1 = k + S, k2 = k + 2 * S, k3 = k + 3 * S;
+        int spins = 0;
+        for (;;) {
+          ld4_agent_issue(q0, src + (int64_t)k * p.mpad);
+          ld4_agent_issue(q1, src + (int64_t)(k1 < p.nblk ? k1 : k) * p.mpad);
+          ld4_agent_issue(q2, src + (int64_t)(k2 < p.nblk ? k2 : k) * p.mpad);
+          ld4_agent_issue(q3, src + (int64_t)(k3 < p.nblk ? k3 : k) * p.mpad);
+          ld4_agent_wait(q0, q1, q2, q3);
+          unsigned stale = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned w = (__float_as_uint(q0[j]) ^ tagbit) | (__float_as_uint(q1[j]) ^ tagbit) | (__float_as_uint(q2[j]) ^ tagbit) |
+                               (__float_as_uint(q3[j]) ^ tagbit);
+            stale |= (w >> 31) << j;
+          }
+          if ((stale & vmask) == 0) break;
+          if (++spins > (1 << 16)) { fail_flag = 1; break; }    // a workgroup of the launch is not resident: give up, never hang
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                     // same order as a one-by-one loop: deterministic
+          acc[j] += fabsf(q0[j]);
+          if (k1 < p.nblk) acc[j] += fabsf(q1[j]);
+          if (k2 < p.nblk) acc[j] += fabsf(q2[j]);
+          if (k3 < p.nblk) acc[j] += fabsf(q3[j]);
+        }
+      }
       *(f32x4*)(colred + (fss * G4 + fg4) * 4) = acc;
     }
     __syncthreads();
@@ -779,32 +826,76 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
       if (!(tot > 0.f) || !(tot < 3.0e38f)) p.status[0] = 1.f;
       const float dv = (fcol < p.m ? p.norm : p.log_nu_bin) - logf(tot);
       vfold += dv;
-      st_agent(p.gbuf + fcol, __expf(dv));
-      if (publish_v) st_agent(p.gbuf + p.mpad + fcol, vfold);
+      if (publish_v) {                                    // v first, acknowledged, then the tagged g that readers wait on
+        st_agent(p.gbuf + p.mpad + fcol, vfold);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      st_agent(p.gbuf + fcol, tg(__expf(dv)));
     }
     stamp(4);
-    if (!ot_grid_barrier(a, ++epoch)) { p.status[0] = 2.f; return; }
-    stamp(5);
     if (it + 1 < a.iters) {
-      // next column factors -- or, ahead of a fresh iteration, v itself (see the declaration of g)
-      const float* src = p.gbuf + (publish_v ? p.mpad : 0);
+      // next column factors -- or, ahead of a fresh iteration, v itself (see the declaration of g); either way the wait
+      // is on the tagged g
       const float idle = publish_v ? 0.f : 1.f;          // columns >= m hold zeros in P: keep their factor finite
+      int spins = 0;
       if (C >= 4) {
+        f32x4 q0, q1;
+        const int ka = c0 < p.m ? c0 : 0, kb = (C > 4 && c0 + 4 < p.m) ? c0 + 4 : 0;
+        unsigned vmask = 0;
 #pragma unroll
-        for (int k = 0; k < C; k += 4) {
-          const f32x4 q = c0 + k < p.m ? ld4_agent(src + c0 + k) : f32x4{idle, idle, idle, idle};
+        for (int j = 0; j < 8; ++j) vmask |= ((j < C && c0 + j < p.m) ? 1u : 0u) << j;
+        for (;;) {
+          ld4_agent_issue(q0, p.gbuf + ka);
+          ld4_agent_issue(q1, p.gbuf + kb);
+          ld4_agent_wait(q0, q1);
+          unsigned stale = 0;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) g[k + j] = c0 + k + j < p.m ? q[j] : idle;
+          for (int j = 0; j < 4; ++j) {
+            stale |= ((__float_as_uint(q0[j]) ^ tagbit) >> 31) << j;
+            stale |= ((__float_as_uint(q1[j]) ^ tagbit) >> 31) << (4 + j);
+          }
+          if ((stale & vmask) == 0) break;
+          if (++spins > (1 << 16)) { fail_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (publish_v) {
+          ld4_agent_issue(q0, p.gbuf + p.mpad + ka);
+          ld4_agent_issue(q1, p.gbuf + p.mpad + kb);
+          ld4_agent_wait(q0, q1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          g[j] = c0 + j < p.m ? (publish_v ? q0[j] : fabsf(q0[j])) : idle;
+          if (C > 4) g[(4 + j) % C] = c0 + 4 + j < p.m ? (publish_v ? q1[j] : fabsf(q1[j])) : idle;
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < C; ++k) g[k] = c0 + k < p.m ? ld_agent(src + c0 + k) : idle;
+        for (int k = 0; k < C; ++k) {
+          float x = idle;
+          if (c0 + k < p.m) {
+            for (;;) {
+              x = ld_agent(p.gbuf + c0 + k);
+              if (((__float_as_uint(x) ^ tagbit) >> 31) == 0) break;
+              if (++spins > (1 << 16)) { fail_flag = 1; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            x = publish_v ? ld_agent(p.gbuf + p.mpad + c0 + k) : fabsf(x);
+          }
+          g[k] = x;
+        }
       }
-      gbin = ld_agent(src + p.m);
+      float xb;
+      for (;;) {
+        xb = ld_agent(p.gbuf + p.m);
+        if (((__float_as_uint(xb) ^ tagbit) >> 31) == 0) break;
+        if (++spins > (1 << 16)) { fail_flag = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      gbin = publish_v ? ld_agent(p.gbuf + p.mpad + p.m) : fabsf(xb);
     }
     stamp(6);
   }
-  if (PROF && blockIdx.x == 0 && threadIdx.x < 7) a.prof[threadIdx.x] = prof_acc[threadIdx.x];
+  if (PROF && blockIdx.x == 0 && threadIdx.x < 8) a.prof[threadIdx.x] = prof_acc[threadIdx.x];
   // ---------------- potentials out (the selection kernels read Z, u, v)
   for (int r = t; r < nrows; r += 512) p.u[row0 + r] = us[r];
   if (t < p.cpb && bk.slab * p.cpb + t <= p.m) p.v[bk.slab * p.cpb + t] = vfold;
@@ -872,7 +963,7 @@ static OtResPlan ot_res_plan(const gims_ot_problem* pr, int np, int iters) {
   }
   P.ngroups = cdiv(np, P.ppg);
   if (P.ngroups > 16) return P;
-  size_t b = al256r(sizeof(OtResProb) * (size_t)np) + (size_t)P.ngroups * (al256r(sizeof(OtResBlock) * 256) + al256r(64 * 9 * 4));
+  size_t b = al256r(sizeof(OtResProb) * (size_t)np) + (size_t)P.ngroups * al256r(sizeof(OtResBlock) * 256);
   for (int i = 0; i < np; ++i) {
     const size_t mpad = (size_t)P.nbu * roundup4(cdiv(pr[i].m + 1, P.nbu));
     b += al256r((size_t)P.nbu * mpad * 4) + al256r(2 * mpad * 4);
@@ -900,9 +991,9 @@ static int ot_res_launch(OtResArgs a, hipStream_t s) {
     unsigned long long h[8];
     GIMS_HIP(hipStreamSynchronize(s));
     GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
-    static const char* names[7] = {"row pass", "row totals", "column pass", "publish + barrier 1", "fold", "barrier 2", "read g"};
+    static const char* names[8] = {"row pass LDS rows + sync", "row totals", "column pass LDS rows", "publish", "fold (incl. wait)", "row pass register rows", "read g (incl. wait)", "column pass register rows"};
     fprintf(stderr, "[ot_resident C=%d iters=%d] cycles/iteration of workgroup 0:", C, a.iters);
-    for (int i = 0; i < 7; ++i) fprintf(stderr, "  %s %.0f;", names[i], (double)h[i] / a.iters);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.0f;", names[i], (double)h[i] / a.iters);
     fprintf(stderr, "\n");
     return GIMS_OK;
   }
@@ -927,12 +1018,13 @@ static int ot_res_run(const OtResPlan& P, const std::vector<OtDev>& hprob, float
     q.gbuf = (float*)(base + off); off += al256r((size_t)2 * q.mpad * 4);
     hp[i] = q;
   }
+  // exchange buffers start with every sign bit set: iteration 0 waits for sign 0 (see the kernel)
+  GIMS_HIP(hipMemsetAsync(base + al256r(sizeof(OtResProb) * (size_t)np), 0xFF, off - al256r(sizeof(OtResProb) * (size_t)np), s));
   int rc = upload_table(hp.data(), sizeof(OtResProb) * (size_t)np, dprob, s);
   if (rc != GIMS_OK) return rc;
   const int refresh = ot_env("GIMS_OT_REFRESH", 33);
   for (int gi = 0; gi < P.ngroups; ++gi) {
     OtResBlock* dblk = (OtResBlock*)(base + off); off += al256r(sizeof(OtResBlock) * 256);
-    unsigned* dcnt = (unsigned*)(base + off); off += al256r(64 * 9 * 4);
     OtResBlock hb[256];
     for (int b = 0; b < 256; ++b) hb[b] = OtResBlock{-1, 0};
     OtResArgs a{};
@@ -941,13 +1033,10 @@ static int ot_res_run(const OtResPlan& P, const std::vector<OtDev>& hprob, float
       for (int sl = 0; sl < P.nbu; ++sl) {
         const int b = P.local ? ((q / 8) * P.nbu + sl) * 8 + (q % 8) : q * P.nbu + sl;
         hb[b] = OtResBlock{p0 + q, sl};
-        a.act[b & 7] += 1;
       }
-    for (int x = 0; x < 8; ++x) a.nact_xcd += a.act[x] > 0;
     rc = upload_table(hb, sizeof(hb), dblk, s);
     if (rc != GIMS_OK) return rc;
-    GIMS_HIP(hipMemsetAsync(dcnt, 0, 64 * 9 * 4, s));
-    a.probs = dprob; a.blocks = dblk; a.cnt = dcnt; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.local_mode = P.local;
+    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh;
     rc = P.C == 1 ? ot_res_launch<1>(a, s) : (P.C == 2 ? ot_res_launch<2>(a, s) : (P.C == 4 ? ot_res_launch<4>(a, s) : ot_res_launch<8>(a, s)));
     if (rc != GIMS_OK) return rc;
   }
