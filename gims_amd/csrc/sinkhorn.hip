@@ -1085,6 +1085,13 @@ extern "C" size_t gims_sinkhorn_workspace_bytes(const gims_ot_problem* pr, int32
   return b + al256(ot_res_plan(pr, np, 1).bytes);       // resident-path buffers (0 when that path is off or does not fit)
 }
 
+extern "C" int gims_sinkhorn_plan(const gims_ot_problem* pr, int32_t np, int32_t iters) {
+  using namespace gims;
+  if (!pr || np <= 0) return 0;
+  const OtResPlan plan = ot_res_plan(pr, np, iters);
+  return plan.ok ? plan.ngroups : 0;
+}
+
 extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float alpha, int32_t iters,
                                    float match_threshold, void* work, size_t work_bytes, void* stream) {
   using namespace gims;

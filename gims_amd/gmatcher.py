@@ -440,6 +440,7 @@ class GMatcher(nn.Module):
         with St("sinkhorn"):
             probs = hip.make_ot_problems(items)
             work = self._buf("ot", hip.sinkhorn_workspace_bytes(probs))
+            self.sinkhorn_plan_last = hip.sinkhorn_plan(probs, cfg['sinkhorn_iterations'])   # 0 streamed / k resident launches
             hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
         # per-image views and graph handles: host-only bookkeeping, done after everything is enqueued
         for g in images:

@@ -84,6 +84,7 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_void_p]),
     "gims_sinkhorn_workspace_bytes": (C.c_size_t, [C.POINTER(OtProblem), C.c_int32]),
+    "gims_sinkhorn_plan": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_int32]),
     "gims_sinkhorn_match": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_float,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "gims_ot_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
@@ -369,6 +370,11 @@ def make_ot_problems(items):
 
 def sinkhorn_workspace_bytes(problems) -> int:
     return int(load().gims_sinkhorn_workspace_bytes(problems, len(problems)))
+
+
+def sinkhorn_plan(problems, iters: int) -> int:
+    """0: streamed kernels (one launch per iteration); k > 0: on-chip resident kernel in k launches."""
+    return int(load().gims_sinkhorn_plan(problems, len(problems), int(iters)))
 
 
 def sinkhorn_match(problems, alpha: float, iters: int, match_threshold: float, work: torch.Tensor):

@@ -204,7 +204,15 @@ int gims_pack_graphs(const gims_pack_image* dev_images /* DEVICE array */, int32
  * (one per image pair); `work` needs gims_sinkhorn_workspace_bytes(...) bytes.
  * Outputs per problem (device): matches0 [n] int64, matches1 [m] int64, mscores0 [n] f32, mscores1 [m]
  * f32, uv: u [n+1] then v [m+1] (log-potentials, so that OT = Z + u + v - norm can be rebuilt) then one
- * status word (0 = ok, 1 = a marginal left the finite range: matches are then all -1).
+ * status word (0 = ok, 1 = a marginal left the finite range, 2 = the on-chip kernel could not get all its
+ * workgroups resident and gave up: matches are then all -1).
+ * Two implementations of the iteration loop (same recurrence, results agree to f32 rounding):
+ *   streamed  -- one launch per iteration, Z read from HBM once per iteration (any size);
+ *   resident  -- ONE launch for all iterations of a group of problems: exp(Z + u + v) is held in the registers and LDS
+ *                of the 256 CUs and updated multiplicatively (re-derived from Z every 33 iterations and on the last),
+ *                no HBM traffic inside the loop.  Used when the matrices fit on chip (m <= 4096, about 134 MB of
+ *                matrix per launch) and are large enough to pay (>= 6 M entries); GIMS_OT_RESIDENT=0 / 2 in the
+ *                environment forces streamed / resident.  gims_sinkhorn_plan() tells which one a call will take.
  */
 typedef struct gims_ot_problem {
   const float* scores; int64_t ld; int32_t n, m;
@@ -213,6 +221,8 @@ typedef struct gims_ot_problem {
 } gims_ot_problem;
 
 size_t gims_sinkhorn_workspace_bytes(const gims_ot_problem* h_problems, int32_t n_problems);
+/* 0: the call will run streamed; k > 0: resident, in k launches.  (Query only; no reference counterpart.) */
+int gims_sinkhorn_plan(const gims_ot_problem* h_problems, int32_t n_problems, int32_t iters);
 int gims_sinkhorn_match(const gims_ot_problem* h_problems /* HOST array */, int32_t n_problems, float alpha,
                         int32_t iters, float match_threshold, void* work, size_t work_bytes, void* stream);
 
