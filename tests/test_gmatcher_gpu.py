@@ -51,16 +51,18 @@ def _compare(out, data, g, thr):
     return dict(n=len(m0), mismatched_unsafe=int((m0 != r0).sum()), score_err=float(err))
 
 
+@pytest.mark.parametrize("sinkhorn", ["streamed", "resident"])     # both Sinkhorn implementations against the reference
 @pytest.mark.parametrize("prec", ["bf16x3", "f32", "bf16x3-unfused"])
 @pytest.mark.parametrize("name", golden_names("e2e_"))
-def test_e2e_vs_reference_golden(models, name, prec):
+def test_e2e_vs_reference_golden(models, monkeypatch, name, prec, sinkhorn):
+    monkeypatch.setenv("GIMS_OT_RESIDENT", "0" if sinkhorn == "streamed" else "2")
     g = load_golden(name)
     n, seed, rad, pct, ms, iters = [int(x) for x in g["meta"]]
     pair = synth.make_pair(n, seed)
     data = pair_to_data(pair, rad, pct, ms, device="cuda")
     out = models[(prec, iters)](data)
     stats = _compare(out, data, g, float(g["match_threshold"]))
-    print(name, prec, stats)
+    print(name, prec, sinkhorn, stats)
     # mutated dict, like the reference (gmatcher.py:244-252)
     nk0 = len(g["out/kept0"])
     assert data["keypoints0"].shape == (1, nk0, 2) and data["descriptors0"].shape == (1, 256, nk0)
