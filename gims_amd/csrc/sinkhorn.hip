@@ -561,8 +561,31 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
   auto lo = [](E v) -> float { if constexpr (C >= 2) return v[0]; else return v; };
   auto hi = [](E v) -> float { if constexpr (C >= 2) return v[1]; else return 0.f; };
   E P[RR][H];
-  // LDS rows keep the same pairs, pair h of thread t at [(row * H + h) * 512 + t]: consecutive lanes, no bank conflicts
-  E* pl2 = (E*)plds;
+  // LDS rows: a thread's C values as 16-byte quads (C >= 4), one pair (C == 2) or one float, element q of thread t at
+  // [(row * NQ + q) * 512 + t]: consecutive lanes are adjacent, so ds_read/write_b128 (b64, b32) are conflict-free
+  constexpr int NQ = C >= 4 ? C / 4 : 1;
+  auto lds_load = [&](int r, E (&x)[H]) {
+    if constexpr (C >= 4) {
+      const f32x4* b = (const f32x4*)plds + r * NQ * 512 + t;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 v = b[q * 512];
+        x[2 * q] = E{v[0], v[1]};
+        x[2 * q + 1] = E{v[2], v[3]};
+      }
+    } else {
+      x[0] = ((const E*)plds)[r * 512 + t];
+    }
+  };
+  auto lds_store = [&](int r, const E (&x)[H]) {
+    if constexpr (C >= 4) {
+      f32x4* b = (f32x4*)plds + r * NQ * 512 + t;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) b[q * 512] = f32x4{x[2 * q][0], x[2 * q][1], x[2 * q + 1][0], x[2 * q + 1][1]};
+    } else {
+      ((E*)plds)[r * 512 + t] = x[0];
+    }
+  };
   // g: column factors of the last column step, applied lazily in the next row pass.  Ahead of a fresh iteration the
   // same registers carry v instead (P is re-derived from Z, u, v there and needs no g); v0 = 0.
   float g[C];
@@ -644,8 +667,10 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
       for (int r = 0; r < nl; ++r) {
         float x[C];
         fresh_row(RR + r, x, row0_o, c0_o, z_o);
+        E y[H];
 #pragma unroll
-        for (int h = 0; h < H; ++h) pl2[(r * H + h) * 512 + t] = mk(x[2 * h], x[(2 * h + 1) % C]);
+        for (int h = 0; h < H; ++h) y[h] = mk(x[2 * h], x[(2 * h + 1) % C]);
+        lds_store(r, y);
       }
       for (int r = t; r < nrows; r += 512) pb[r] = __expf((alpha + us[r]) + gbin);
 #pragma unroll
@@ -682,11 +707,13 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
         const int r = rb + r8;
         float s = 0.f;
         if (r < nl) {
-          E* q = pl2 + r * H * 512 + t;
-          E s2 = q[0] * g2[0];
-          q[0] = s2;
+          E x[H];
+          lds_load(r, x);
+          x[0] *= g2[0];
+          E s2 = x[0];
 #pragma unroll
-          for (int h = 1; h < H; ++h) { const E x = q[h * 512] * g2[h]; q[h * 512] = x; s2 += x; }
+          for (int h = 1; h < H; ++h) { x[h] *= g2[h]; s2 += x[h]; }
+          lds_store(r, x);
           s = lo(s2) + hi(s2);
         }
         rs[r8] = s;
@@ -740,9 +767,11 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
     for (int r = 0; r < nl; ++r) {
       const float f = fac[RR + r];
       const E f2 = mk(f, f);
-      E* q = pl2 + r * H * 512 + t;
+      E x[H];
+      lds_load(r, x);
 #pragma unroll
-      for (int h = 0; h < H; ++h) { const E x = q[h * 512] * f2; q[h * 512] = x; cs2[h] += x; }
+      for (int h = 0; h < H; ++h) { x[h] *= f2; cs2[h] += x[h]; }
+      lds_store(r, x);
     }
     float cs[C];
 #pragma unroll
