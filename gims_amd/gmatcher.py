@@ -336,6 +336,7 @@ class GMatcher(nn.Module):
         ts0 = time.perf_counter()
         infos = info_all.cpu().numpy()                                                    # the one host sync of the build
         self._sync_ms = 1e3 * (time.perf_counter() - ts0)
+        self._check_pending_status()          # the previous batch's Sinkhorn status words are on the host side of this sync
         if infos[:, 7].any():
             raise hip.GimsHipError("adaptive graph exceeded the edge capacity (64 directed edges per node)")
         if (infos[:, 0] == 0).any():
@@ -442,6 +443,12 @@ class GMatcher(nn.Module):
             work = self._buf("ot", hip.sinkhorn_workspace_bytes(probs))
             self.sinkhorn_plan_last = hip.sinkhorn_plan(probs, cfg['sinkhorn_iterations'])   # 0 streamed / k resident launches
             hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
+            if self.sinkhorn_plan_last > 0:
+                # the on-chip kernel gives up (status 2, all matches -1) when it cannot get its 256 workgroups resident, e.g.
+                # next to another process's kernels; that must not pass silently: the worst status word of this batch is read
+                # at the next host sync (no extra sync here) and raises there
+                offs = np.cumsum([it["n"] + it["m"] + 3 for it in items]) - 1
+                self._pending_status = uv_all[hip.upload(offs.astype(np.int64), dev)].max()
         # per-image views and graph handles: host-only bookkeeping, done after everything is enqueued
         for g in images:
             ro, nk = g["rows"]
@@ -481,6 +488,15 @@ class GMatcher(nn.Module):
         images[0]["_keep"] = keep
         return images
 
+    _pending_status = None
+
+    def _check_pending_status(self):
+        """Raises if the previous batch's resident Sinkhorn gave up; call only right after a host sync."""
+        st, self._pending_status = self._pending_status, None
+        if st is not None and float(st) == 2.0:
+            raise hip.GimsHipError("the on-chip Sinkhorn kernel could not get all its workgroups resident (is another process "
+                                   "using this GPU?): the matches of the previous batch are invalid; set GIMS_OT_RESIDENT=0")
+
     def _check_call(self, data, kwargs):
         if data.get('delaunay', False):
             raise NotImplementedError("delaunay=True is broken in the reference snapshot (UnboundLocalError, gmatcher.py:250)")
@@ -506,6 +522,7 @@ class GMatcher(nn.Module):
             data['scores' + side] = torch.stack([h.ndata['score'] for h in gs])
             data['kept_kpts%s_indices' % side] = [images[2 * b + s]["kept"].tolist() for b in range(B)]
             data['graph' + side] = gs
+        self._check_pending_status()          # .tolist() above synchronised: this batch's own status is readable now
         md0 = torch.stack([mdesc[o0:o0 + n0] for (o0, n0), _ in pairs])
         md1 = torch.stack([mdesc[o1:o1 + n1] for _, (o1, n1) in pairs])
         return {
