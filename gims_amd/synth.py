@@ -217,3 +217,44 @@ def make_state_dict(seed: int = 123, bias_std: float = 0.02, bn_jitter: float = 
             a = (normal(seed, stream, n) * (g / np.sqrt(float(fan_in)))).astype(np.float32).reshape(shape)
         out[name] = a
     return out
+
+
+# ------------------------------------------------------------------------------------------------ homography pairs
+def make_homography(seed: int, canvas, strength: float = 1.0) -> np.ndarray:
+    """A mild random homography (float32 3x3, H[2,2] = 1) of a (width, height) canvas around its centre: rotation up to
+    +-15 deg, scale 0.9-1.1, shear and perspective terms small enough that every point keeps a positive w.  Portable
+    (same hash generator as everything else here), so fixtures only store the seed."""
+    w, h = float(canvas[0]), float(canvas[1])
+    r = uniform(seed, 77, 8).astype(np.float64)
+    ang = np.deg2rad(15.0) * (2 * r[0] - 1) * strength
+    sc = 1.0 + 0.1 * (2 * r[1] - 1) * strength
+    shx = 0.05 * (2 * r[2] - 1) * strength
+    tx, ty = 0.05 * w * (2 * r[3] - 1) * strength, 0.05 * h * (2 * r[4] - 1) * strength
+    px, py = 1e-4 * (2 * r[5] - 1) * strength, 1e-4 * (2 * r[6] - 1) * strength
+    c, s = np.cos(ang), np.sin(ang)
+    A = np.array([[sc * c, -sc * s + shx, 0.0], [sc * s, sc * c, 0.0], [0.0, 0.0, 1.0]])
+    T0 = np.array([[1, 0, -w / 2], [0, 1, -h / 2], [0, 0, 1.0]])
+    T1 = np.array([[1, 0, w / 2 + tx], [0, 1, h / 2 + ty], [0, 0, 1.0]])
+    Pm = np.array([[1, 0, 0], [0, 1, 0], [px, py, 1.0]])
+    H = T1 @ Pm @ A @ T0
+    return (H / H[2, 2]).astype(np.float32)
+
+
+def make_homography_pair(n: int, seed: int, canvas=None, pos_noise: float = 0.5, desc_noise: float = 0.03, outlier_frac: float = 0.1):
+    """Like make_pair, but image 1's keypoints are image 0's warped by a random homography (then permuted, jittered by
+    `pos_noise` px, with `outlier_frac` of them replaced): the ground truth the reference's eval loop is given as
+    `homo_matrix` (eval_homography.py:164-165).  Returns (pair dict, H float32 3x3)."""
+    pair = make_pair(n, seed, canvas=canvas, pos_noise=0.0, desc_noise=desc_noise, outlier_frac=outlier_frac)
+    cv = canvas_for(n) if canvas is None else canvas
+    H = make_homography(seed, cv)
+    gt = pair["gt_perm"]
+    k0 = pair["keypoints0"][0].astype(np.float64)
+    src = np.concatenate([k0, np.ones((len(k0), 1))], axis=1)
+    dst = (H.astype(np.float64) @ src.T).T
+    dst = dst[:, :2] / dst[:, 2:3]
+    k1 = pair["keypoints1"][0].copy()
+    jitter = normal(seed, 78, 2 * len(k0)).reshape(len(k0), 2) * pos_noise
+    ok = gt >= 0
+    k1[gt[ok]] = (dst[ok] + jitter[ok]).astype(np.float32)
+    pair["keypoints1"] = k1[None]
+    return pair, H
