@@ -171,6 +171,14 @@ def main():
     m0 = o["matches0"][0].cpu().numpy()
     st = stats.cpu().numpy()
 
+    # ---- evaluation of what was timed (outside the timed region): the synthetic pairs are a permutation + jitter of one
+    # point set, i.e. their ground-truth homography is the identity; GT matching, precision / recall, 4-point and RANSAC
+    # homographies and the corner-error AUC run on the device (gims_eval_pairs) and the per-pair records are all-gathered
+    # exactly like the reference's eval loop would (eval_homography.py:186-259)
+    eval_rec = shard.gather_stats(shard.eval_stats(my_pairs, host_t["datas"], outs, [np.eye(3, dtype=np.float32)] * len(my_pairs), dev,
+                                                   ransac_iters=2000, seed=1), counts=rank_counts)
+    eval_summary = shard.eval_summary(eval_rec)
+
     if rank == 0:
         total_pairs = world * args.pairs * args.steps
         value = total_pairs / elapsed
@@ -263,6 +271,10 @@ def main():
             "stage_ms_per_step": stage_ms,
             "matches_pair0": {"matched": int(v.sum()), "correct_vs_planted": correct},
             "stats_rows_gathered": int(st.shape[0]), "stat_fields": list(shard.STAT_FIELDS),
+            "eval": {"note": "quality of the timed outputs against the planted correspondences (identity homography): GT matching, "
+                             "precision / recall, corner-error AUC of the 4-point and RANSAC homographies (gims_eval_pairs + all-gather)",
+                     **{k: (round(v, 3) if isinstance(v, float) else [round(x, 3) for x in v] if isinstance(v, list) else v)
+                        for k, v in eval_summary.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.kpts, args.sinkhorn_iters)

@@ -55,6 +55,12 @@ class OtProblem(C.Structure):
                 ("mscores1", C.c_void_p), ("uv", C.c_void_p)]
 
 
+class EvalPair(C.Structure):
+    _fields_ = [("kpts0", C.c_void_p), ("kpts1", C.c_void_p), ("matches0", C.c_void_p), ("mscores0", C.c_void_p),
+                ("n0", C.c_int32), ("n1", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("h_gt", C.c_float * 9),
+                ("gt0", C.c_void_p), ("inlier", C.c_void_p), ("record", C.c_void_p), ("homographies", C.c_void_p)]
+
+
 _SIGNATURES = {
     "gims_abi_version": (C.c_int, []),
     "gims_last_error": (C.c_char_p, []),
@@ -87,6 +93,9 @@ _SIGNATURES = {
     "gims_sinkhorn_plan": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_int32]),
     "gims_sinkhorn_match": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_float,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gims_eval_workspace_bytes": (C.c_size_t, [C.POINTER(EvalPair), C.c_int32, C.c_int32]),
+    "gims_eval_pairs": (C.c_int, [C.POINTER(EvalPair), C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_uint64,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "gims_ot_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
 }
@@ -389,3 +398,33 @@ def ot_matrix(scores, n, m, alpha, uv):
     _check(lib.gims_ot_matrix(_p(scores), scores.stride(0), n, m, float(alpha), _p(uv), _p(out), _stream()),
            "gims_ot_matrix")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ evaluation
+EVAL_FIELDS = ("n_valid", "n_gt", "n_correct", "n_fn", "precision", "recall", "n_inliers", "err_dlt", "err_ransac", "dlt_ok",
+               "ransac_ok")
+
+
+def eval_pairs(items, dist_thresh=3.0, n_iters=3, ransac_thresh=3.0, ransac_iters=2000, seed=0, work=None):
+    """items: list of dicts with device tensors kpts0 [n0,2] f32, kpts1 [n1,2] f32, matches0 [n0] int64, mscores0 [n0] f32,
+    h_gt (3x3 array-like), height, width, and outputs gt0 [n0] int32, inlier [n0] uint8, record [16] f32,
+    homographies [18] f32.  One batched asynchronous call; see include/gims_hip.h."""
+    import numpy as np
+    lib = load()
+    arr = (EvalPair * len(items))()
+    for i, it in enumerate(items):
+        k0, k1 = it["kpts0"], it["kpts1"]
+        assert k0.dtype == torch.float32 and k1.dtype == torch.float32 and k0.is_contiguous() and k1.is_contiguous()
+        assert it["matches0"].dtype == torch.int64 and it["mscores0"].dtype == torch.float32
+        assert it["gt0"].dtype == torch.int32 and it["inlier"].dtype == torch.uint8
+        h = np.asarray(it["h_gt"], dtype=np.float32).reshape(9)
+        arr[i] = EvalPair(_p(k0), _p(k1), _p(it["matches0"]), _p(it["mscores0"]), k0.shape[0], k1.shape[0], int(it["height"]),
+                          int(it["width"]), (C.c_float * 9)(*h.tolist()), _p(it["gt0"]), _p(it["inlier"]), _p(it["record"]),
+                          _p(it["homographies"]))
+    need = int(lib.gims_eval_workspace_bytes(arr, len(items), int(ransac_iters)))
+    if work is None or work.numel() * work.element_size() < need:
+        work = torch.empty(need, dtype=torch.uint8, device=items[0]["kpts0"].device)
+    _check(lib.gims_eval_pairs(arr, len(items), float(dist_thresh), int(n_iters), float(ransac_thresh), int(ransac_iters),
+                               int(seed) & 0xFFFFFFFFFFFFFFFF, _p(work), work.numel() * work.element_size(), _stream()),
+           "gims_eval_pairs")
+    return work

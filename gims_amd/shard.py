@@ -11,6 +11,8 @@ import torch
 import torch.distributed as dist
 
 STAT_FIELDS = ("pair_id", "n_kept0", "n_kept1", "n_matches", "mean_score")
+# the record SURVEY 8(e) names for the evaluation all-gather (rank 0 runs pose_auc on the gathered rows)
+EVAL_STAT_FIELDS = ("pair_id", "n_kept0", "n_matches", "n_inliers", "err_dlt", "err_ransac", "precision", "recall", "dlt_ok", "ransac_ok")
 
 
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
@@ -55,6 +57,36 @@ def pair_stats(pair_ids: Sequence[int], outs: Sequence[dict], device) -> torch.T
     nm = torch.zeros(len(outs), dtype=torch.float32, device=device).index_add_(0, seg, valid)
     ss = torch.zeros(len(outs), dtype=torch.float32, device=device).index_add_(0, seg, s0 * valid)
     return torch.cat([host, nm[:, None], (ss / nm.clamp(min=1.0))[:, None]], dim=1)
+
+
+def eval_stats(pair_ids: Sequence[int], datas: Sequence[dict], outs: Sequence[dict], h_gts, device, **eval_kw) -> torch.Tensor:
+    """[n_pairs, 10] float32 evaluation record per pair (EVAL_STAT_FIELDS), computed on the device by the kernel library
+    (gims_amd.evalh: GT matching from the known homography, precision / recall, 4-point and RANSAC homographies, corner
+    errors -- the per-pair body of the reference's eval loop, eval_homography.py:186-226).  No host sync."""
+    from . import evalh
+    ev = evalh.evaluate_pairs(datas, outs, h_gts, **eval_kw)
+    rec = ev["records"]
+    col = {k: i for i, k in enumerate(evalh.RECORD_FIELDS)}
+    n0 = _to_device([float(o["matches0"].shape[-1]) for o in outs], "float32", device)
+    ids = _to_device([float(p) for p in pair_ids], "float32", device)
+    pick = [col["n_valid"], col["n_inliers"], col["err_dlt"], col["err_ransac"], col["precision"], col["recall"], col["dlt_ok"], col["ransac_ok"]]
+    out = torch.cat([ids[:, None], n0[:, None], rec[:, pick]], dim=1)
+    out._eval_keep = ev          # keeps the per-pair outputs (gt0, inlier masks, homographies) alive for the caller
+    return out
+
+
+def eval_summary(gathered: torch.Tensor, min_matches: int = 12) -> dict:
+    """AUC@5/10/25 (4-point and RANSAC), mean precision / recall over the gathered evaluation records (host side; what
+    rank 0 prints at the end of the reference's eval loop, eval_homography.py:237-259)."""
+    from . import evalh
+    import numpy as np
+    g = gathered.detach().cpu().numpy().astype(np.float64)
+    rec = np.zeros((len(g), 16))
+    col = {k: i for i, k in enumerate(evalh.RECORD_FIELDS)}
+    for name, src in (("n_valid", 2), ("n_inliers", 3), ("err_dlt", 4), ("err_ransac", 5), ("precision", 6), ("recall", 7),
+                      ("dlt_ok", 8), ("ransac_ok", 9)):
+        rec[:, col[name]] = g[:, src]
+    return evalh.summarize(rec, min_matches=min_matches)
 
 
 def gather_stats(stats: torch.Tensor, world: int | None = None, counts: Sequence[int] | None = None) -> torch.Tensor:

@@ -226,6 +226,47 @@ int gims_sinkhorn_plan(const gims_ot_problem* h_problems, int32_t n_problems, in
 int gims_sinkhorn_match(const gims_ot_problem* h_problems /* HOST array */, int32_t n_problems, float alpha,
                         int32_t iters, float match_threshold, void* work, size_t work_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-pair evaluation after the matcher -- batched over pairs, everything stays on the device.
+ * replaces: the per-pair block of eval_homography.py:186-226 --
+ *   torch_find_matches(kp0, kp1, H_gt, dist_thresh=3, n_iters=3) (utils/preprocess_utils.py:98-132, with warp_keypoints
+ *   :86-96 and torch_cdist :74-78), precision / recall (:207-209, 222-226), cv2.getPerspectiveTransform on the four most
+ *   confident matches (:216-217), cv2.findHomography(RANSAC) (:193, 218) and the corner error (:210, 219-223,
+ *   utils/common.py:477-481).  The GT matching reproduces the reference's float32 arithmetic (index sets are exact); the
+ *   two OpenCV calls are restated from their documented semantics -- the RANSAC is this build's own deterministic one,
+ *   OpenCV's sampler is not reproducible.  Specification (float64; also restated in oracle/eval_oracle.py):
+ *     hypothesis h = 0 .. iters-1: state = seed ^ (h * 0xD1342543DE82EF95); four DISTINCT indices into the ascending list of
+ *     valid matches are successive splitmix64(state) % K values (duplicates skipped); H_h = exact 4-point homography
+ *     (h22 = 1); score = #matches with ||H_h p0 - p1||^2 <= thresh^2; best = highest score, lowest h on ties; then ONE
+ *     least-squares refit (normal equations of the 2K x 8 DLT system) on the inliers of the best hypothesis, and the final
+ *     inlier mask / count / corner error under the refit model.  The four most confident matches of the DLT are taken
+ *     with ties broken by the earlier match.
+ * Outputs per pair: gt0 [n0] int32 (GT partner in image 1 or -1), inlier [n0] uint8 (1 where the match of keypoint i is
+ * a RANSAC inlier), record float[16] (GIMS_EVAL_* below), homographies float[18] (H_dlt then H_ransac, row-major).
+ */
+typedef struct gims_eval_pair {
+  const float* kpts0; const float* kpts1;   /* kept keypoints [n0][2], [n1][2] (what GMatcher returns as keypoints0/1) */
+  const int64_t* matches0;                  /* [n0] */
+  const float* mscores0;                    /* [n0] */
+  int32_t n0, n1, height, width;            /* image 0 size for the corner error */
+  float h_gt[9];                            /* ground-truth homography, row-major */
+  int32_t* gt0; uint8_t* inlier; float* record; float* homographies;
+} gims_eval_pair;
+#define GIMS_EVAL_NVALID 0      /* matches0 > -1 */
+#define GIMS_EVAL_NGT 1         /* GT correspondences found */
+#define GIMS_EVAL_NCORRECT 2    /* matches0[i] == gt0[i] >= 0 */
+#define GIMS_EVAL_NFN 3         /* unmatched keypoints that have a GT partner */
+#define GIMS_EVAL_PRECISION 4
+#define GIMS_EVAL_RECALL 5
+#define GIMS_EVAL_NINLIERS 6
+#define GIMS_EVAL_ERR_DLT 7     /* mean corner distance, -1 when no model */
+#define GIMS_EVAL_ERR_RANSAC 8
+#define GIMS_EVAL_DLT_OK 9
+#define GIMS_EVAL_RANSAC_OK 10
+size_t gims_eval_workspace_bytes(const gims_eval_pair* h_pairs, int32_t n_pairs, int32_t ransac_iters);
+int gims_eval_pairs(const gims_eval_pair* h_pairs /* HOST array */, int32_t n_pairs, float dist_thresh, int32_t n_iters,
+                    float ransac_thresh, int32_t ransac_iters, uint64_t seed, void* work, size_t work_bytes, void* stream);
+
 /* Rebuild the full (n+1)x(m+1) OT matrix Z + u + v - norm (gmatcher.py:47,68) -- for forward_train and tests. */
 int gims_ot_matrix(const float* scores, int64_t ld, int32_t n, int32_t m, float alpha, const float* uv,
                    float* out /* [(n+1)][(m+1)] */, void* stream);

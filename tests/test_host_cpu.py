@@ -86,3 +86,19 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f
+
+
+def test_pose_auc_and_summarize_equal_reference():
+    """gims_amd.evalh.pose_auc against the reference's pose_auc outputs (tests/golden/eval_metrics.npz)."""
+    from gims_amd import evalh
+    from tests.helpers import load_golden
+    g = load_golden("eval_metrics")
+    for i in range(4):
+        np.testing.assert_allclose(evalh.pose_auc(g[f"errors{i}"], [5, 10, 25]), g[f"auc{i}"], rtol=0, atol=1e-12)
+    rec = np.zeros((3, 16))
+    rec[:, 0] = [100, 5, 50]          # n_valid: the second pair has too few matches
+    rec[:, 9] = rec[:, 10] = 1
+    rec[:, 4], rec[:, 5], rec[:, 7], rec[:, 8] = [0.5, 0.1, 1.0], [0.25, 0.1, 0.75], [2.0, 1.0, 30.0], [1.0, 1.0, 3.0]
+    s = evalh.summarize(rec)
+    assert s["n_pairs"] == 2 and s["precision"] == 75.0 and s["recall"] == 50.0
+    np.testing.assert_allclose(s["auc_ransac"], [100 * a for a in evalh.pose_auc([1.0, 3.0])], atol=1e-12)
