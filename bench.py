@@ -93,8 +93,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # GIMS_BENCH_BACKEND=gloo + fewer GPUs than ranks is a DRY RUN of the multi-rank code path on one GPU (ranks share
+        # the device; combine with GIMS_OT_RESIDENT=0: the on-chip Sinkhorn kernel needs the whole GPU to itself)
+        backend = os.environ.get("GIMS_BENCH_BACKEND", "nccl")
+        local_dev = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = f"cuda:{torch.cuda.current_device()}"
