@@ -21,6 +21,7 @@
 //     grows by more than 2^5 in probability units -- after the first tiles the accumulators stay in place.
 #include "common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace gims {
@@ -249,6 +250,288 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- 8-wave variant
+// Same math and register layout as attention_bf16_kernel<2> (64 queries per wave), but a workgroup is EIGHT waves, two per
+// SIMD, and the two waves of a SIMD are kept half a key tile apart by the barriers: while group A (waves 0-3) runs a
+// matrix segment (QK^T or PV: 16 MFMAs) group B (waves 4-7) runs a softmax segment (one 32-query block: ~130 VALU +
+// 32 exp) on the same SIMD, and vice versa.  In the 4-wave kernel the two co-resident waves of a SIMD belong to different
+// workgroups and drift freely: knock-out experiments showed its tile time to be the SUM of its parts (MFMA, softmax,
+// staging each ~25 %), i.e. almost no overlap.  Per key tile, four phases, one barrier each:
+//     phase 0:  A: S = K Q^T of tile t          B: softmax block 1 of tile t-1      everyone: global loads of tile t+1
+//     phase 1:  A: softmax block 0 of tile t    B: O += V P of tile t-1
+//     phase 2:  A: softmax block 1 of tile t    B: S = K Q^T of tile t
+//     phase 3:  A: O += V P of tile t           B: softmax block 0 of tile t        everyone: tile t+1 into LDS
+// K/V tiles are shared by 512 queries (half the staging traffic per query of the 4-wave kernel).
+constexpr int ATT8_WAVES = 8;
+
+template <bool PROF>
+__global__ __launch_bounds__(512) void attention8_bf16_kernel(
+    const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
+    const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, unsigned long long* prof) {
+  // diagnostics (GIMS_ATTN_PROF=1): cycles of wave 0 (group A) and wave 4 (group B) of workgroup 0 per phase, split into
+  // work (phase start -> barrier reached) and wait (inside the barrier)
+  unsigned long long pt = 0, pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp_work = [&](int ph) { if (PROF) { const unsigned long long n = __builtin_readcyclecounter(); pacc[2 * ph] += n - pt; pt = n; } };
+  auto stamp_wait = [&](int ph) { if (PROF) { const unsigned long long n = __builtin_readcyclecounter(); pacc[2 * ph + 1] += n - pt; pt = n; } };
+  // Barriers inside the tile loop are RAW s_barrier + lgkmcnt(0): __syncthreads() also waits vmcnt(0), which would stall
+  // every wave at the first barrier after load_tile until the global loads of the NEXT tile have landed.  The loads are
+  // only needed by store_tile three phases later (register dependency).
+  auto raw_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+#define ATT8_BAR(ph) do { stamp_work(ph); raw_barrier(); stamp_wait(ph); } while (0)
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KB * DH];
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[2][DH * VT_LD];
+  constexpr int QP = 2, QWV = QW * QP, QBK = QWV * ATT8_WAVES;   // 64 queries per wave, 512 per workgroup
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int group = (slot / n_qt) * 8 + xcd;
+  if (group >= n_groups) return;
+  const gims_attn_problem pr = problems[group / n_heads];
+  const int q0 = (slot % n_qt) * QBK;
+  if (q0 >= pr.n_q) return;
+  const int head = group % n_heads;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool groupB = wave >= 4;
+  const int li = lane & 31, lh = lane >> 5;
+
+  bf16x8 qf[QP][4];
+#pragma unroll
+  for (int qi = 0; qi < QP; ++qi) {
+    int qr = q0 + wave * QWV + qi * QW + li;
+    qr = qr < pr.n_q ? qr : pr.n_q - 1;
+    const uint16_t* qp = qkv + (int64_t)(pr.q_off + qr) * ld + q_col + head * DH + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[qi][s] = *(const bf16x8*)(qp + 16 * s);
+  }
+  // Q must have LANDED before the tile loop: otherwise the compiler guards the first MFMAs of EVERY iteration with
+  // s_waitcnt vmcnt(..0), and since vmcnt retires in order those waits also sit out the loads of the next K/V tile that
+  // were issued a moment earlier (measured: ~1100 of the 1575 cycles of that phase)
+  __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) only
+  f32x16 o[QP][2];
+#pragma unroll
+  for (int qi = 0; qi < QP; ++qi)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qi][i][r] = 0.f;
+  const float c = 0.125f * 1.4426950408889634f;
+  constexpr float DEFER = 5.0f;
+  const float defer_raw = DEFER / c;
+  float m_run[QP], l_run[QP];
+#pragma unroll
+  for (int qi = 0; qi < QP; ++qi) { m_run[qi] = -1e30f; l_run[qi] = 0.f; }
+
+  // staging: K tile 64 rows x 8 chunks = 512 chunks, one per thread; V tile: key pair kp = t & 31, d-octet (t >> 5) & 7,
+  // element e = t >> 8 of the pair (threads 0-255 carry the even key, 256-511 the odd one)
+  uint4 rk, rv;
+  const int n_tiles = (pr.n_kv + KB - 1) / KB;
+  const int vkp = t & 31, voct = (t >> 5) & 7, ve = t >> 8;
+  auto load_tile = [&](int kt) {
+    const int kbase = kt * KB;
+    {
+      const int row = t >> 3, ch = t & 7;
+      int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      rk = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * ch);
+    }
+    {
+      int kr = kbase + 2 * vkp + ve; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      rv = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * voct);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    *(uint4*)(Ks[buf] + k_off(t >> 3, t & 7)) = rk;
+    const uint32_t a[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // d = 8*voct + 2j, 2j+1; this thread's key is 2*vkp + ve: 16-bit stores
+      Vt[buf][(8 * voct + 2 * j) * VT_LD + 2 * vkp + ve] = (uint16_t)(a[j] & 0xffffu);
+      Vt[buf][(8 * voct + 2 * j + 1) * VT_LD + 2 * vkp + ve] = (uint16_t)(a[j] >> 16);
+    }
+  };
+
+  f32x16 sacc[QP][2];
+  bf16x8 pf[QP][4];
+  auto seg_qk = [&](int kt) {                 // S^T = K Q^T of tile kt (16 MFMAs)
+    const int buf = kt & 1;
+#pragma unroll
+    for (int qi = 0; qi < QP; ++qi)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[qi][b][r] = 0.f;
+    // all 8 K fragments are requested before the first MFMA (P is dead here, its 32 registers are free): one LDS latency
+    // per segment instead of one per fragment -- only ONE wave per SIMD is in a matrix segment, nobody else hides it
+    bf16x8 kf[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[b][s] = *(const bf16x8*)(Ks[buf] + k_off(b * 32 + li, 2 * s + lh));
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int qi = 0; qi < QP; ++qi) sacc[qi][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][s], qf[qi][s], sacc[qi][b], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // 8 LDS reads ...
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);    // ... then the 16 MFMAs (the scheduler otherwise serialises read -> wait -> MFMA)
+  };
+  auto seg_softmax = [&](int kt, int qi) {     // online softmax of query block qi on tile kt
+    const int kbase = kt * KB;
+    float tmax = -1e30f;
+    if (kbase + KB > pr.n_kv) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= pr.n_kv) sacc[qi][b][r] = -1e30f;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (__any(tmax > m_run[qi] + defer_raw)) {          // wave-uniform, rare after the first tiles
+      const float m_new = fmaxf(m_run[qi], tmax);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
+      m_run[qi] = m_new;
+      l_run[qi] *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[qi][i][r] *= alpha;
+    }
+    const float mc = m_run[qi] * c;
+    float lsum = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[qi][b][r], c, -mc));
+        lsum += pv[r];
+      }
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        uint4 pk;
+        pk.x = pack_bf2(pv[8 * h2 + 0], pv[8 * h2 + 1]);
+        pk.y = pack_bf2(pv[8 * h2 + 2], pv[8 * h2 + 3]);
+        pk.z = pack_bf2(pv[8 * h2 + 4], pv[8 * h2 + 5]);
+        pk.w = pack_bf2(pv[8 * h2 + 6], pv[8 * h2 + 7]);
+        pf[qi][2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
+      }
+    }
+    l_run[qi] += lsum;
+  };
+  auto seg_pv = [&](int kt) {                  // O^T += V^T P^T of tile kt (16 MFMAs)
+    const int buf = kt & 1;
+    bf16x8 vf[4][2];                           // S is dead here: all 8 V fragments in flight before the first MFMA
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint16_t* vp = Vt[buf] + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
+        const uint2 v0 = *(const uint2*)(vp);
+        const uint2 v1 = *(const uint2*)(vp + 8);
+        vf[s][i] = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+      }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int qi = 0; qi < QP; ++qi) o[qi][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s][i], pf[qi][s], o[qi][i], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);    // the V fragments are two 8-byte reads each (compiled to 8 ds_read2_b64)
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  // Two straight-line instruction streams (one per group, wave-uniform branch) with the SAME number of barriers:
+  // 4 per key tile + 1 in the drain round.  Group B trails group A by two phases.
+  if (PROF) pt = __builtin_readcyclecounter();
+  if (!groupB) {
+    for (int kt = 0; kt < n_tiles; ++kt) {
+      const bool more = kt + 1 < n_tiles;
+      if (more) load_tile(kt + 1);            // phase 0
+      seg_qk(kt);
+      ATT8_BAR(0);
+      seg_softmax(kt, 0);                     // phase 1
+      ATT8_BAR(1);
+      seg_softmax(kt, 1);                     // phase 2
+      ATT8_BAR(2);
+      seg_pv(kt);                             // phase 3
+      if (more) store_tile((kt + 1) & 1);
+      ATT8_BAR(3);
+    }
+    raw_barrier();                            // drain round: group B finishes its last tile
+  } else {
+    {                                         // tile 0: phases 0 and 1 have nothing to trail yet
+      const bool more = 1 < n_tiles;
+      if (more) load_tile(1);
+      raw_barrier();
+      raw_barrier();
+      seg_qk(0);                              // phase 2
+      raw_barrier();
+      seg_softmax(0, 0);                      // phase 3
+      if (more) store_tile(1);
+      raw_barrier();
+    }
+    if (PROF) pt = __builtin_readcyclecounter();
+    for (int kt = 1; kt < n_tiles; ++kt) {
+      const bool more = kt + 1 < n_tiles;
+      if (more) load_tile(kt + 1);            // phase 0
+      seg_softmax(kt - 1, 1);
+      ATT8_BAR(0);
+      seg_pv(kt - 1);                         // phase 1
+      ATT8_BAR(1);
+      seg_qk(kt);                             // phase 2
+      ATT8_BAR(2);
+      seg_softmax(kt, 0);                     // phase 3
+      if (more) store_tile((kt + 1) & 1);
+      ATT8_BAR(3);
+    }
+    seg_softmax(n_tiles - 1, 1);              // drain round
+    raw_barrier();
+    seg_pv(n_tiles - 1);
+  }
+  if (PROF && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
+    for (int i = 0; i < 8; ++i) prof[(wave >> 2) * 8 + i] = pacc[i];
+
+#pragma unroll
+  for (int qi = 0; qi < QP; ++qi) {
+    const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+    const float inv = 1.f / l_tot;
+    const int qr = q0 + wave * QWV + qi * QW + li;
+    if (qr < pr.n_q) {
+      const int64_t grow = pr.q_off + qr;
+      const int col0 = head * DH + 4 * lh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = make_float4(o[qi][i][4 * g] * inv, o[qi][i][4 * g + 1] * inv, o[qi][i][4 * g + 2] * inv, o[qi][i][4 * g + 3] * inv);
+          const int col = col0 + 32 * i + 8 * g;
+          if (out) *(float4*)(out + grow * ld_out + col) = v;
+          if (out_hi) {
+            const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
+            const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+            const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+            *(uint2*)(out_hi + grow * ld_split + spl_col(col)) = make_uint2(h01, h23);
+            *(uint2*)(out_lo + grow * ld_split + spl_col(col)) = make_uint2(l01, l23);
+          }
+        }
+    }
+  }
+}
+
 }  // namespace gims
 
 extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
@@ -268,7 +551,31 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
   if (force < 0) { const char* e = getenv("GIMS_ATTN_QP"); force = e ? atoi(e) : 0; }
   const int blocks2 = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB);
   const bool two = force == 2 || (force != 1 && blocks2 >= 512);
-  if (two) {
+  const int n_qt8 = cdiv(max_n_q, 512);
+  const bool eight = force == 8 || (force == 0 && 8 * cdiv(n_groups, 8) * n_qt8 >= 256);   // 8-wave workgroups of 512 queries
+  if (eight) {
+    static int prof = -1;
+    if (prof < 0) { const char* e = getenv("GIMS_ATTN_PROF"); prof = e ? atoi(e) : 0; }
+    if (prof) {                                 // diagnostics only: synchronous, prints the phase anatomy of workgroup 0
+      static unsigned long long* dprof = nullptr;
+      if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 16 * sizeof(unsigned long long)));
+      hipLaunchKernelGGL(attention8_bf16_kernel<true>, dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
+                         q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof);
+      GIMS_HIP(hipStreamSynchronize((hipStream_t)stream));
+      unsigned long long h[16];
+      GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
+      const char* nm[2][4] = {{"QK", "softmax0", "softmax1", "PV+store"}, {"softmax1", "PV", "QK", "softmax0+store"}};
+      for (int g = 0; g < 2; ++g) {
+        fprintf(stderr, "[attention8 group %c] cycles over the whole tile loop, work/wait per phase:", 'A' + g);
+        for (int ph = 0; ph < 4; ++ph) fprintf(stderr, "  %s %llu/%llu;", nm[g][ph], h[g * 8 + 2 * ph], h[g * 8 + 2 * ph + 1]);
+        fprintf(stderr, "
+");
+      }
+    } else {
+      hipLaunchKernelGGL(attention8_bf16_kernel<false>, dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
+                         q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr);
+    }
+  } else if (two) {
     const int n_qt = cdiv(max_n_q, 2 * QB);
     hipLaunchKernelGGL(attention_bf16_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, (hipStream_t)stream, qkv, ld,
                        q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split);
