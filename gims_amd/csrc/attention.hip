@@ -568,8 +568,7 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
       for (int g = 0; g < 2; ++g) {
         fprintf(stderr, "[attention8 group %c] cycles over the whole tile loop, work/wait per phase:", 'A' + g);
         for (int ph = 0; ph < 4; ++ph) fprintf(stderr, "  %s %llu/%llu;", nm[g][ph], h[g * 8 + 2 * ph], h[g * 8 + 2 * ph + 1]);
-        fprintf(stderr, "
-");
+        fprintf(stderr, "\n");
       }
     } else {
       hipLaunchKernelGGL(attention8_bf16_kernel<false>, dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
