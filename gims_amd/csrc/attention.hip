@@ -258,10 +258,10 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 // 32 exp) on the same SIMD, and vice versa.  In the 4-wave kernel the two co-resident waves of a SIMD belong to different
 // workgroups and drift freely: knock-out experiments showed its tile time to be the SUM of its parts (MFMA, softmax,
 // staging each ~25 %), i.e. almost no overlap.  Per key tile, four phases, one barrier each:
-//     phase 0:  A: S = K Q^T of tile t          B: softmax block 1 of tile t-1      everyone: global loads of tile t+1
+//     phase 0:  A: S = K Q^T of tile t          B: softmax block 1 of tile t-1
 //     phase 1:  A: softmax block 0 of tile t    B: O += V P of tile t-1
-//     phase 2:  A: softmax block 1 of tile t    B: S = K Q^T of tile t
-//     phase 3:  A: O += V P of tile t           B: softmax block 0 of tile t        everyone: tile t+1 into LDS
+//     phase 2:  A: softmax block 1 of tile t    B: S = K Q^T of tile t, then tile t+1 into LDS, request tile t+2
+//     phase 3:  A: O += V P of tile t, then tile t+1 into LDS, request tile t+2       B: softmax block 0 of tile t
 // K/V tiles are shared by 512 queries (half the staging traffic per query of the 4-wave kernel).
 constexpr int ATT8_WAVES = 8;
 
@@ -454,48 +454,49 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   load_tile(0);
   store_tile(0);
   __syncthreads();
+  if (1 < n_tiles) load_tile(1);
   // Two straight-line instruction streams (one per group, wave-uniform branch) with the SAME number of barriers:
   // 4 per key tile + 1 in the drain round.  Group B trails group A by two phases.
+  // Staging: every thread stores its pieces of tile t+1 at the end of its group's SHORT phase of tile t (after the 16 MFMAs:
+  // group A in phase 3, group B in phase 2 -- the buffer's last readers finished in phase 1) and immediately requests its
+  // pieces of tile t+2, so the global loads have four phases to land and the long (softmax) phases carry no staging.
   if (PROF) pt = __builtin_readcyclecounter();
   if (!groupB) {
     for (int kt = 0; kt < n_tiles; ++kt) {
-      const bool more = kt + 1 < n_tiles;
-      if (more) load_tile(kt + 1);            // phase 0
-      seg_qk(kt);
+      seg_qk(kt);                             // phase 0
       ATT8_BAR(0);
       seg_softmax(kt, 0);                     // phase 1
       ATT8_BAR(1);
       seg_softmax(kt, 1);                     // phase 2
       ATT8_BAR(2);
       seg_pv(kt);                             // phase 3
-      if (more) store_tile((kt + 1) & 1);
+      if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
+      if (kt + 2 < n_tiles) load_tile(kt + 2);
       ATT8_BAR(3);
     }
     raw_barrier();                            // drain round: group B finishes its last tile
   } else {
     {                                         // tile 0: phases 0 and 1 have nothing to trail yet
-      const bool more = 1 < n_tiles;
-      if (more) load_tile(1);
       raw_barrier();
       raw_barrier();
       seg_qk(0);                              // phase 2
+      if (1 < n_tiles) store_tile(1);
+      if (2 < n_tiles) load_tile(2);
       raw_barrier();
       seg_softmax(0, 0);                      // phase 3
-      if (more) store_tile(1);
       raw_barrier();
     }
     if (PROF) pt = __builtin_readcyclecounter();
     for (int kt = 1; kt < n_tiles; ++kt) {
-      const bool more = kt + 1 < n_tiles;
-      if (more) load_tile(kt + 1);            // phase 0
-      seg_softmax(kt - 1, 1);
+      seg_softmax(kt - 1, 1);                 // phase 0
       ATT8_BAR(0);
       seg_pv(kt - 1);                         // phase 1
       ATT8_BAR(1);
       seg_qk(kt);                             // phase 2
+      if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
+      if (kt + 2 < n_tiles) load_tile(kt + 2);
       ATT8_BAR(2);
       seg_softmax(kt, 0);                     // phase 3
-      if (more) store_tile((kt + 1) & 1);
       ATT8_BAR(3);
     }
     seg_softmax(n_tiles - 1, 1);              // drain round
@@ -564,7 +565,7 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
       GIMS_HIP(hipStreamSynchronize((hipStream_t)stream));
       unsigned long long h[16];
       GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
-      const char* nm[2][4] = {{"QK", "softmax0", "softmax1", "PV+store"}, {"softmax1", "PV", "QK", "softmax0+store"}};
+      const char* nm[2][4] = {{"QK", "softmax0", "softmax1", "PV+store+load"}, {"softmax1", "PV", "QK+store+load", "softmax0"}};
       for (int g = 0; g < 2; ++g) {
         fprintf(stderr, "[attention8 group %c] cycles over the whole tile loop, work/wait per phase:", 'A' + g);
         for (int ph = 0; ph < 4; ++ph) fprintf(stderr, "  %s %llu/%llu;", nm[g][ph], h[g * 8 + 2 * ph], h[g * 8 + 2 * ph + 1]);
