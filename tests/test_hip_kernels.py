@@ -403,3 +403,37 @@ def test_agc_vs_oracle_random(hip):
     np.testing.assert_array_equal(indptr, ref["indptr"])
     np.testing.assert_array_equal(indices, ref["indices"])
     assert int(inf[5]) == len(ref["link_edges"]) and int(inf[5]) > 0 and int(inf[3]) > 0
+
+
+@pytest.mark.parametrize("resident", ["0", "2"])
+def test_sinkhorn_full_size_marginals(hip, monkeypatch, resident):
+    """BASELINE size (4096 x 4096, 100 iterations), too large for the CPU oracle in a test: size-independent property of the
+    recurrence instead -- the last update is the column one, so the column marginals of exp(Z + u + v) equal nu exactly
+    (to f32 summation noise) and the row marginals equal mu up to the convergence residual; both Sinkhorn paths."""
+    monkeypatch.setenv("GIMS_OT_RESIDENT", resident)
+    n = m = 4096
+    g = torch.Generator(device="cpu").manual_seed(11)
+    z = torch.randn(n, m, generator=g) * 6
+    z[torch.arange(n), torch.randperm(m, generator=g)] += 25.0
+    zs = z.cuda()
+    it = dict(scores=zs, n=n, m=m, matches0=torch.empty(n, dtype=torch.int64, device="cuda"), matches1=torch.empty(m, dtype=torch.int64, device="cuda"),
+              mscores0=torch.empty(n, device="cuda"), mscores1=torch.empty(m, device="cuda"), uv=torch.empty(n + m + 3, device="cuda"))
+    probs = hip.make_ot_problems([it])
+    work = torch.empty(hip.sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device="cuda")
+    assert (hip.sinkhorn_plan(probs, 100) > 0) == (resident == "2")
+    hip.sinkhorn_match(probs, 1.0, 100, 0.2, work)
+    assert float(it["uv"][-1]) == 0.0
+    full = hip.ot_matrix(zs, n, m, 1.0, it["uv"]).double()             # Z + u + v - norm, (n+1) x (m+1)
+    norm = -torch.log(torch.tensor(float(n + m), dtype=torch.float64))
+    P = torch.exp(full + norm)                                          # couplings in probability units
+    col = P.sum(0).cpu().numpy()
+    row = P.sum(1).cpu().numpy()
+    nu = np.r_[np.full(m, 1.0 / (n + m)), n / (n + m)]
+    mu = np.r_[np.full(n, 1.0 / (n + m)), m / (n + m)]
+    assert np.abs(col / nu - 1).max() < 2e-5, np.abs(col / nu - 1).max()
+    assert np.abs(row / mu - 1).max() < 5e-2                            # not yet converged after 100 iterations, but close
+    assert abs(P.sum().item() - 1.0) < 1e-5
+    # mutual matches are a partial permutation
+    m0, m1 = it["matches0"].cpu().numpy(), it["matches1"].cpu().numpy()
+    v = m0 >= 0
+    assert v.sum() > 0.9 * n and (m1[m0[v]] == np.nonzero(v)[0]).all()
