@@ -143,7 +143,7 @@ def _gain_for(name: str) -> float:
 
 
 def state_dict_spec(descriptor_dim=256, keypoint_encoder=(32, 64, 128, 256), n_layers=18,
-                    sage_bias_layout="fc_self"):
+                    sage_bias_layout="fc_self", use_layernorm=False):
     """Ordered (name, shape) list mirroring GMatcher.state_dict() (gmatcher.py:177-207).
 
     Key names follow the reference module tree: ``bin_score``, ``kenc.encoder.*``,
@@ -158,19 +158,25 @@ def state_dict_spec(descriptor_dim=256, keypoint_encoder=(32, 64, 128, 256), n_l
         spec += [(f"kenc.encoder.{idx}.weight", (ch[i], ch[i - 1], 1)), (f"kenc.encoder.{idx}.bias", (ch[i],))]
         idx += 1
         if i < len(ch) - 1:
-            for nm in ("weight", "bias", "running_mean", "running_var"):
-                spec.append((f"kenc.encoder.{idx}.{nm}", (ch[i],)))
-            spec.append((f"kenc.encoder.{idx}.num_batches_tracked", ()))
-            idx += 2  # BN + ReLU
+            if use_layernorm:                      # gmatcher.py:19-20, 78-79
+                spec += [(f"kenc.encoder.{idx}.a_2", (ch[i],)), (f"kenc.encoder.{idx}.b_2", (ch[i],))]
+            else:
+                for nm in ("weight", "bias", "running_mean", "running_var"):
+                    spec.append((f"kenc.encoder.{idx}.{nm}", (ch[i],)))
+                spec.append((f"kenc.encoder.{idx}.num_batches_tracked", ()))
+            idx += 2  # norm + ReLU
     for l in range(n_layers):
         p = f"gnn.layers.{l}."
         spec += [(p + "attn.merge.weight", (D, D, 1)), (p + "attn.merge.bias", (D,))]
         for j in range(3):
             spec += [(p + f"attn.proj.{j}.weight", (D, D, 1)), (p + f"attn.proj.{j}.bias", (D,))]
         spec += [(p + "mlp.0.weight", (2 * D, 2 * D, 1)), (p + "mlp.0.bias", (2 * D,))]
-        for nm in ("weight", "bias", "running_mean", "running_var"):
-            spec.append((p + f"mlp.1.{nm}", (2 * D,)))
-        spec.append((p + "mlp.1.num_batches_tracked", ()))
+        if use_layernorm:
+            spec += [(p + "mlp.1.a_2", (2 * D,)), (p + "mlp.1.b_2", (2 * D,))]
+        else:
+            for nm in ("weight", "bias", "running_mean", "running_var"):
+                spec.append((p + f"mlp.1.{nm}", (2 * D,)))
+            spec.append((p + "mlp.1.num_batches_tracked", ()))
         spec += [(p + "mlp.3.weight", (D, 2 * D, 1)), (p + "mlp.3.bias", (D,))]
     dims = [(D, D // 2), (D // 2, D // 2), (D // 2, D)]
     for i, (ci, co) in enumerate(dims):
@@ -198,6 +204,10 @@ def make_state_dict(seed: int = 123, bias_std: float = 0.02, bn_jitter: float = 
             a = np.array(1.0, dtype=np.float32)
         elif name.endswith("num_batches_tracked"):
             a = np.array(0, dtype=np.int64)
+        elif name.endswith(".a_2"):
+            a = (1.0 + bn_jitter * (2.0 * uniform(seed, stream, n) - 1.0)).astype(np.float32).reshape(shape)
+        elif name.endswith(".b_2"):
+            a = (bias_std * normal(seed, stream, n)).astype(np.float32).reshape(shape)
         elif name.endswith("running_var"):
             a = (1.0 + bn_jitter * (2.0 * uniform(seed, stream, n) - 1.0)).astype(np.float32).reshape(shape)
         elif name.endswith("running_mean"):

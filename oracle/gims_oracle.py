@@ -314,15 +314,22 @@ def normalize_keypoints(kpts: torch.Tensor, image_shape) -> torch.Tensor:
 
 
 def _mlp(sd, prefix: str, n_convs: int, x: torch.Tensor) -> torch.Tensor:
-    """gmatcher.py:11-24 -- Conv1d(k=1) [+ BatchNorm1d(eval) + ReLU] stack; Sequential indices 0,1,2 / 3,4,5 ..."""
+    """gmatcher.py:11-24 -- Conv1d(k=1) [+ BatchNorm1d(eval) | LayerNorm + ReLU] stack; Sequential indices 0,1,2 / 3,4,5 ...
+    Which norm a checkpoint uses is read off its keys (LayerNorm stores a_2 / b_2, gmatcher.py:78-79)."""
     idx = 0
     for i in range(n_convs):
         x = F.conv1d(x, _t(sd, f"{prefix}.{idx}.weight"), _t(sd, f"{prefix}.{idx}.bias"))
         idx += 1
         if i < n_convs - 1:
-            x = F.batch_norm(x, _t(sd, f"{prefix}.{idx}.running_mean"), _t(sd, f"{prefix}.{idx}.running_var"),
-                             _t(sd, f"{prefix}.{idx}.weight"), _t(sd, f"{prefix}.{idx}.bias"),
-                             training=False, eps=BN_EPS)
+            if f"{prefix}.{idx}.a_2" in sd:
+                # use_layernorm=True (gmatcher.py:19-20, 74-85): over the CHANNEL dim of (B,C,N), unbiased std, eps added to std
+                mean = x.mean(-2, keepdim=True)
+                std = x.std(-2, keepdim=True)
+                x = _t(sd, f"{prefix}.{idx}.a_2").reshape(1, -1, 1) * ((x - mean) / (std + 1e-6)) + _t(sd, f"{prefix}.{idx}.b_2").reshape(1, -1, 1)
+            else:
+                x = F.batch_norm(x, _t(sd, f"{prefix}.{idx}.running_mean"), _t(sd, f"{prefix}.{idx}.running_var"),
+                                 _t(sd, f"{prefix}.{idx}.weight"), _t(sd, f"{prefix}.{idx}.bias"),
+                                 training=False, eps=BN_EPS)
             x = F.relu(x)
             idx += 2
     return x

@@ -113,3 +113,19 @@ def test_full_with_intermediates(name, synth_sd):
     np.testing.assert_array_equal(out["matches0"][0].numpy(), g["out/matches0"])
     np.testing.assert_array_equal(out["matches1"][0].numpy(), g["out/matches1"])
     np.testing.assert_allclose(out["matching_scores0"][0].numpy(), g["out/matching_scores0"], atol=5e-5)
+
+
+@pytest.mark.parametrize("name", golden_names("lne2e_"))
+def test_e2e_layernorm(name):
+    """use_layernorm=True (gmatcher.py:19-20, 74-85): the oracle's LayerNorm variant against the reference's outputs."""
+    g = load_golden(name)
+    n, seed, rad, pct, ms, iters = [int(x) for x in g["meta"]]
+    pair = synth.make_pair(n, seed)
+    data = pair_to_data(pair, rad, pct, ms)
+    sd = synth.make_state_dict(123, use_layernorm=True)
+    out = O.gmatcher_forward(sd, data, {"sinkhorn_iterations": iters, "match_threshold": float(g["match_threshold"]), "use_layernorm": True})
+    np.testing.assert_array_equal(np.asarray(data["kept_kpts0_indices"][0]), g["out/kept0"])
+    np.testing.assert_array_equal(out["matches0"][0].numpy(), g["out/matches0"])
+    np.testing.assert_array_equal(out["matches1"][0].numpy(), g["out/matches1"])
+    np.testing.assert_allclose(out["matching_scores0"][0].numpy(), g["out/matching_scores0"], atol=5e-5)
+    np.testing.assert_allclose(out["matching_scores1"][0].numpy(), g["out/matching_scores1"], atol=5e-5)

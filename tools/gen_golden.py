@@ -156,11 +156,12 @@ def main():
          kpts0=p["keypoints0"], desc0_sum=np.float64(p["descriptors0"].astype(np.float64).sum()),
          kpts1=p["keypoints1"], gt_perm=p["gt_perm"], scores1=p["scores1"])
 
+    only_ln = "--only-ln" in sys.argv
     model100 = ref_model(sd, {})                                                    # GMatcher defaults
     model20 = ref_model(sd, {"sinkhorn_iterations": 20, "match_threshold": 0.02})   # eval-script setting
 
     # ---- full pipeline, with intermediates (small) -------------------------------------------
-    for n, seed in ((64, 1000), (200, 1001)):
+    for n, seed in (() if only_ln else ((64, 1000), (200, 1001))):
         pair = synth.make_pair(n, seed, canvas=synth.canvas_for(256) if n == 200 else None)
         r = run_reference(model100, pair, 15, 2, 7, capture=True)
         arrs = {"in/" + k: v for k, v in pair.items()}
@@ -173,7 +174,7 @@ def main():
         save(f"full_n{n}_s{seed}", **arrs)
 
     # ---- end-to-end outputs only (inputs regenerated from the seed) ---------------------------
-    for n, seed, (rad, pct, ms), mdl, iters, thr in (
+    for n, seed, (rad, pct, ms), mdl, iters, thr in () if only_ln else (
             (256, 1002, (15, 2, 7), model100, 100, 0.2),
             (256, 1003, (25, 7, 8), model100, 100, 0.2),          # GMatcher default AGC params
             (512, 1004, (15, 2, 7), model20, 20, 0.02),           # eval-script setting
@@ -188,6 +189,19 @@ def main():
         arrs["meta"] = np.asarray([n, seed, rad, pct, ms, iters], dtype=np.int64)
         arrs["match_threshold"] = np.float64(thr)
         save(f"e2e_n{n}_s{seed}_r{rad}p{pct}m{ms}_i{iters}", **arrs)
+
+    # ---- use_layernorm=True (gmatcher.py:19-20, 74-85): the LayerNorm variant of every MLP --------
+    sd_ln = synth.make_state_dict(123, use_layernorm=True)
+    model_ln = ref_model(sd_ln, {"use_layernorm": True})
+    for n, seed in ((256, 1005), (1024, 1006)):
+        pair = synth.make_pair(n, seed)
+        r = run_reference(model_ln, pair, 15, 2, 7)
+        arrs = {"out/" + k: v for k, v in r.items()}
+        arrs["meta"] = np.asarray([n, seed, 15, 2, 7, 100], dtype=np.int64)
+        arrs["match_threshold"] = np.float64(0.2)
+        save(f"lne2e_n{n}_s{seed}_r15p2m7_i100", **arrs)
+    if "--only-ln" in sys.argv:
+        return
 
     # ---- AGC-only cases that exercise isolated-node fix-up, component removal and linking ------
     for n, seed, canvas, (rad, pct, ms) in (
