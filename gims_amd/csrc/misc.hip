@@ -44,6 +44,7 @@ extern "C" int gims_upload_table(const void* host, int64_t bytes, void* dev, voi
 
 namespace gims {
 // normalize_keypoints (gmatcher.py:26-33) + Conv1d(2->c1) + BN(eval, folded) + ReLU (gmatcher.py:87-97)
+template <bool RELU>
 __global__ __launch_bounds__(256) void kenc_first_kernel(const float* __restrict__ kpts, const float* __restrict__ norm3,
                                                          const int32_t* __restrict__ seg, const float* __restrict__ w1,
                                                          const float* __restrict__ b1, int c1, float* __restrict__ out,
@@ -56,7 +57,51 @@ __global__ __launch_bounds__(256) void kenc_first_kernel(const float* __restrict
   const float x = (kpts[2 * row] - nm[0]) / nm[2];
   const float y = (kpts[2 * row + 1] - nm[1]) / nm[2];
   float v = fmaf(w1[2 * ch + 1], y, fmaf(w1[2 * ch], x, b1[ch]));
-  out[row * c1 + ch] = fmaxf(v, 0.f);
+  out[row * c1 + ch] = RELU ? fmaxf(v, 0.f) : v;
+}
+
+// LayerNorm of the reference's use_layernorm=True variant (gmatcher.py:74-85) + ReLU: per point (row) over its c channels,
+// UNBIASED standard deviation, eps added to the std (not to the variance).  One wave per row, values held in registers
+// (c <= 512), two passes (mean, then squared deviations).  Output f32 and/or split-bf16 SPL32 planes for the next GEMM.
+__global__ __launch_bounds__(256) void layernorm_act_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int c,
+                                                            const float* __restrict__ a2, const float* __restrict__ b2, float eps, int act,
+                                                            float* __restrict__ out, int64_t ldo, uint16_t* __restrict__ out_hi,
+                                                            uint16_t* __restrict__ out_lo, int64_t ld_split) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ch = lane + 64 * k;
+    v[k] = ch < c ? xr[ch] : 0.f;
+    s += v[k];
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float d = lane + 64 * k < c ? v[k] - mean : 0.f;
+    q += d * d;
+  }
+  const float sd = sqrtf(wave_sum(q) / (float)(c - 1));
+  const float inv = 1.f / (sd + eps);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < c) {
+      float y = a2[ch] * ((v[k] - mean) * inv) + b2[ch];
+      if (act == GIMS_ACT_RELU) y = fmaxf(y, 0.f);
+      if (out) out[row * ldo + ch] = y;
+      if (out_hi) {
+        const uint16_t h = f2bf(y);
+        out_hi[row * ld_split + spl_col(ch)] = h;
+        out_lo[row * ld_split + spl_col(ch)] = f2bf(y - bf2f(h));
+      }
+    }
+  }
 }
 
 // out[i,:] = mean over CSR neighbours of h[j,:]   (one wave per node, lanes over channel quads)
@@ -199,8 +244,32 @@ extern "C" int gims_kenc_first(const float* kpts, const float* norm3, const int3
   using namespace gims;
   GIMS_CHECK_ARG(kpts && norm3 && seg_of_row && w1 && b1 && out && c1 > 0 && n >= 0, "gims_kenc_first: bad arguments");
   if (n == 0) return GIMS_OK;
-  hipLaunchKernelGGL(kenc_first_kernel, dim3(cdiv(n * c1, 256)), dim3(256), 0, (hipStream_t)stream, kpts, norm3,
+  hipLaunchKernelGGL(kenc_first_kernel<true>, dim3(cdiv(n * c1, 256)), dim3(256), 0, (hipStream_t)stream, kpts, norm3,
                      seg_of_row, w1, b1, c1, out, n);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_kenc_first_linear(const float* kpts, const float* norm3, const int32_t* seg_of_row, const float* w1,
+                                      const float* b1, int32_t c1, float* out, int64_t n, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(kpts && norm3 && seg_of_row && w1 && b1 && out && c1 > 0 && n >= 0, "gims_kenc_first_linear: bad arguments");
+  if (n == 0) return GIMS_OK;
+  hipLaunchKernelGGL(kenc_first_kernel<false>, dim3(cdiv(n * c1, 256)), dim3(256), 0, (hipStream_t)stream, kpts, norm3,
+                     seg_of_row, w1, b1, c1, out, n);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_layernorm_act(const float* x, int64_t ldx, int64_t rows, int32_t c, const float* a2, const float* b2, float eps,
+                                  int32_t act, float* out, int64_t ldo, uint16_t* out_hi, uint16_t* out_lo, int64_t ld_split,
+                                  void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(x && a2 && b2 && (out || out_hi) && rows >= 0 && c >= 2 && c <= 512, "gims_layernorm_act: bad arguments (2 <= c <= 512)");
+  GIMS_CHECK_ARG((out_hi == nullptr) == (out_lo == nullptr), "gims_layernorm_act: out_hi and out_lo come together");
+  if (rows == 0) return GIMS_OK;
+  hipLaunchKernelGGL(layernorm_act_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, c, a2, b2, eps,
+                     act, out, ldo, out_hi, out_lo, ld_split);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

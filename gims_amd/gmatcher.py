@@ -100,8 +100,6 @@ class GMatcher(nn.Module):
         super().__init__()
         self.config = {**self.default_config, **config}
         cfg = self.config
-        if cfg['use_layernorm']:
-            raise NotImplementedError("use_layernorm=True (gmatcher.py:74-85) is not on the HIP path yet")
         if cfg['input_dim'] != cfg['descriptor_dim']:
             raise NotImplementedError("input_proj is built but never called by the reference forward (gmatcher.py:198-201)")
         D = cfg['descriptor_dim']
@@ -110,15 +108,15 @@ class GMatcher(nn.Module):
         self.n_layers = len(cfg['transformer_layers'])
         self._heads = 4   # AttentionalGNN hard-codes 4 heads (gmatcher.py:131); config['num_heads'] is ignored there too
         from .synth import state_dict_spec
-        for name, shape in state_dict_spec(D, tuple(cfg['keypoint_encoder']), self.n_layers):
+        for name, shape in state_dict_spec(D, tuple(cfg['keypoint_encoder']), self.n_layers, use_layernorm=bool(cfg['use_layernorm'])):
             if name.endswith("num_batches_tracked"):
                 _register(self, name, torch.zeros((), dtype=torch.int64), buffer=True)
             elif name.endswith("running_mean"):
                 _register(self, name, torch.zeros(shape), buffer=True)
             elif name.endswith("running_var"):
                 _register(self, name, torch.ones(shape), buffer=True)
-            elif name == "bin_score":
-                _register(self, name, torch.tensor(1.0), buffer=False)
+            elif name == "bin_score" or name.endswith(".a_2"):
+                _register(self, name, torch.tensor(1.0) if name == "bin_score" else torch.ones(shape), buffer=False)
             else:
                 _register(self, name, torch.zeros(shape), buffer=False)
         self._pack = None
@@ -156,11 +154,17 @@ class GMatcher(nn.Module):
         x3 = self.config['linear_precision'] == 'bf16x3'
         if self.config['linear_precision'] not in ('bf16x3', 'f32'):
             raise ValueError("linear_precision must be 'bf16x3' or 'f32'")
-        P: Dict[str, object] = {"x3": x3}
+        ln = bool(self.config['use_layernorm'])
+        P: Dict[str, object] = {"x3": x3, "ln": ln}
 
         def fold(w, b, prefix):   # Conv1d(k=1) followed by BatchNorm1d(eval)  (gmatcher.py:17-22)
+            if ln:                # use_layernorm=True: LayerNorm sits there instead (gmatcher.py:19-20) -- nothing to fold
+                return w, b
             g = sd[prefix + ".weight"] / torch.sqrt(sd[prefix + ".running_var"] + BN_EPS)
             return w * g[:, None], (b - sd[prefix + ".running_mean"]) * g + sd[prefix + ".bias"]
+
+        def lnp(prefix):          # LayerNorm parameters (a_2, b_2) of the norm that follows a conv, on the device
+            return (dev(sd[prefix + ".a_2"]), dev(sd[prefix + ".b_2"])) if ln else None
 
         def dev(t):
             return t.contiguous().to(device)
@@ -181,6 +185,7 @@ class GMatcher(nn.Module):
         nk = len(self.config['keypoint_encoder']) + 1
         w, b = fold(sd["kenc.encoder.0.weight"][:, :, 0], sd["kenc.encoder.0.bias"], "kenc.encoder.1")
         P["kenc_w1"], P["kenc_b1"] = dev(w), dev(b)
+        P["kenc_ln"] = [lnp(f"kenc.encoder.{3 * i + 1}") for i in range(nk - 1)]       # norm after conv i (i < nk - 1)
         P["kenc"] = []
         for i in range(1, nk):
             w, b = sd[f"kenc.encoder.{3 * i}.weight"][:, :, 0], sd[f"kenc.encoder.{3 * i}.bias"]
@@ -215,6 +220,7 @@ class GMatcher(nn.Module):
                 "merge": lin(wm, sd[p + "attn.merge.bias"], True),
                 "mlp0": lin(w0, b0, True),
                 "mlp1": lin(sd[p + "mlp.3.weight"][:, :, 0], sd[p + "mlp.3.bias"], True),
+                "ln": lnp(p + "mlp.1"),
                 "cross": self.config['transformer_layers'][l] == 'cross',
             })
         P["final"] = lin(sd["final_proj.weight"][:, :, 0], sd["final_proj.bias"], True)
@@ -368,14 +374,19 @@ class GMatcher(nn.Module):
         # ---- keypoint encoder (gmatcher.py:26-33, 87-97) ; desc = sage + kenc (gmatcher.py:270-271)
         x3 = P["x3"]
         with St("kenc"):
+            ln = P["ln"]
             x = torch.empty((n_tot, P["kenc_w1"].shape[0]), dtype=torch.float32, device=dev)
-            hip.kenc_first(kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], x)
+            hip.kenc_first(kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], x, relu=not ln)
+            if ln:      # use_layernorm=True: conv -> LayerNorm -> ReLU (gmatcher.py:17-23), the norm as its own kernel
+                hip.layernorm_act(x, *P["kenc_ln"][0], out=x)
             dpl = self._spl(n_tot, D, dev) if x3 else None          # split-bf16 (SPL32) copy of the residual stream
             for i, e in enumerate(P["kenc"]):
                 last = i == len(P["kenc"]) - 1
-                x = self._lin(e, x, act=hip.ACT_NONE if last else hip.ACT_RELU, residual=sage if last else None,
+                x = self._lin(e, x, act=hip.ACT_NONE if (last or ln) else hip.ACT_RELU, residual=sage if last else None,
                               out=torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev),
                               out_split=dpl if (last and x3) else None)
+                if ln and not last:
+                    hip.layernorm_act(x, *P["kenc_ln"][i + 1], out=x)
             desc = x
         # ---- attentional GNN (gmatcher.py:99-143): per layer QKV -> flash attention -> merge -> MLP -> residual
         pairs = [(images[2 * p]["rows"], images[2 * p + 1]["rows"]) for p in range(len(images) // 2)]
@@ -390,13 +401,23 @@ class GMatcher(nn.Module):
             # all GEMM operands travel as split-bf16 SPL32 buffers written by the producing kernel's epilogue; only the
             # residual stream `desc` also exists in f32
             mpl, gpl, hpl = self._spl(n_tot, D, dev), self._spl(n_tot, D, dev), self._spl(n_tot, 2 * D, dev)
+            hid_ln = None
             for L in P["layers"]:
                 with St("qkv"):
                     self._lin(L["qkv"], dpl, out_bf16=qkv)
                 with St("attn_cross" if L["cross"] else "attn_self"):
                     hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl)
                 with St("mlp"):
-                    if L["mlp0_fused"] is not None:
+                    if ln:        # LayerNorm between the two MLP convs: hidden activations in f32, normalised + split by the norm kernel
+                        if hid_ln is None:
+                            hid_ln = torch.empty((n_tot, 2 * D), dtype=torch.float32, device=dev)
+                        if L["mlp0_fused"] is not None:
+                            self._lin(L["mlp0_fused"], dpl, a1=mpl, out=hid_ln)
+                        else:
+                            self._lin(L["merge"], mpl, out_split=gpl)
+                            self._lin(L["mlp0"], dpl, a1=gpl, out=hid_ln)
+                        hip.layernorm_act(hid_ln, *L["ln"], out_split=hpl)
+                    elif L["mlp0_fused"] is not None:
                         self._lin(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl)
                     else:
                         self._lin(L["merge"], mpl, out_split=gpl)
@@ -412,11 +433,14 @@ class GMatcher(nn.Module):
                 with St("attn_cross" if L["cross"] else "attn_self"):
                     hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D)
                 with St("mlp"):
+                    act0 = hip.ACT_NONE if ln else hip.ACT_RELU
                     if L["mlp0_fused"] is not None:
-                        self._lin(L["mlp0_fused"], desc, a1=msg, act=hip.ACT_RELU, out=hid)
+                        self._lin(L["mlp0_fused"], desc, a1=msg, act=act0, out=hid)
                     else:
                         self._lin(L["merge"], msg, out=mrg)
-                        self._lin(L["mlp0"], desc, a1=mrg, act=hip.ACT_RELU, out=hid)
+                        self._lin(L["mlp0"], desc, a1=mrg, act=act0, out=hid)
+                    if ln:
+                        hip.layernorm_act(hid, *L["ln"], out=hid)
                     self._lin(L["mlp1"], hid, residual=desc, out=desc)          # desc += delta  (gmatcher.py:142)
         # ---- final projection, score matrix, Sinkhorn, selection (gmatcher.py:273-294)
         with St("final_scores"):

@@ -77,6 +77,10 @@ _SIGNATURES = {
                                  C.c_void_p]),
     "gims_kenc_first": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_kenc_first_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_layernorm_act": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
+                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_sage_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
@@ -259,12 +263,26 @@ def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: 
     return out if out is not None else out_split
 
 
-def kenc_first(kpts, norm3, seg_of_row, w1, b1, out):
+def kenc_first(kpts, norm3, seg_of_row, w1, b1, out, relu=True):
     lib = load()
     c1 = w1.shape[0]
-    _check(lib.gims_kenc_first(_p(_dev(kpts, torch.float32)), _p(norm3), _p(seg_of_row), _p(w1), _p(b1), c1,
-                               _p(out), kpts.shape[0], _stream()), "gims_kenc_first")
+    fn = lib.gims_kenc_first if relu else lib.gims_kenc_first_linear
+    _check(fn(_p(_dev(kpts, torch.float32)), _p(norm3), _p(seg_of_row), _p(w1), _p(b1), c1,
+              _p(out), kpts.shape[0], _stream()), "gims_kenc_first")
     return out
+
+
+def layernorm_act(x, a2, b2, out=None, out_split=None, act=ACT_RELU, eps=1e-6):
+    """LayerNorm over the channels of every row (unbiased std, eps on the std; gmatcher.py:74-85) + activation.
+    out: f32 [rows, c] (may be x itself) and/or out_split: SPL32 bf16 [rows, >= 2c]."""
+    lib = load()
+    rows, c = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and (out is not None or out_split is not None)
+    _check(lib.gims_layernorm_act(_p(x), x.stride(0), rows, c, _p(a2), _p(b2), float(eps), act, _p(out),
+                                  out.stride(0) if out is not None else 0, _p(out_split),
+                                  (out_split.data_ptr() + 64) if out_split is not None else None,
+                                  out_split.stride(0) if out_split is not None else 0, _stream()), "gims_layernorm_act")
+    return out if out is not None else out_split
 
 
 def sage_mean(h, indptr, indices, out, n=None, c=None):

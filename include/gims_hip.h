@@ -128,6 +128,20 @@ int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col
  */
 int gims_kenc_first(const float* kpts, const float* norm3 /* [n_seg][3] */, const int32_t* seg_of_row,
                     const float* w1, const float* b1, int32_t c1, float* out, int64_t n, void* stream);
+/* Same without the ReLU (the use_layernorm=True variant normalises before activating). */
+int gims_kenc_first_linear(const float* kpts, const float* norm3, const int32_t* seg_of_row,
+                           const float* w1, const float* b1, int32_t c1, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm of the reference's use_layernorm=True variant + activation.
+ * replaces: class LayerNorm (gmatcher.py:74-85) as MLP() inserts it between Conv1d and ReLU (gmatcher.py:19-23):
+ *   y[r, :] = a2 * (x[r, :] - mean_r) / (std_r + eps) + b2   over the c channels of point r, std UNBIASED (c - 1),
+ *   eps added to the std.  out (f32, may be NULL or == x) and/or out_hi/out_lo (SPL32 split planes, see gims_linear).
+ * 2 <= c <= 512.
+ */
+int gims_layernorm_act(const float* x, int64_t ldx, int64_t rows, int32_t c, const float* a2, const float* b2, float eps,
+                       int32_t act, float* out /* may be NULL */, int64_t ldo, uint16_t* out_hi /* may be NULL */,
+                       uint16_t* out_lo, int64_t ld_split, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GraphSAGE mean aggregation over the adaptive graph (CSR by destination, both edge directions):

@@ -245,3 +245,37 @@ def test_tiny_pair(models, synth_sd):
     ref = O.gmatcher_forward(synth_sd, d_cpu, {})
     assert d_gpu["kept_kpts0_indices"] == d_cpu["kept_kpts0_indices"]
     np.testing.assert_allclose(out["matching_scores0"][0].cpu().numpy(), ref["matching_scores0"][0].numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("name", golden_names("lne2e_"))
+def test_e2e_layernorm_vs_reference_golden(name, prec):
+    """use_layernorm=True (gmatcher.py:19-20, 74-85): conv -> LayerNorm (unbiased std, eps on the std) -> ReLU in every MLP."""
+    g = load_golden(name)
+    n, seed, rad, pct, ms, iters = [int(x) for x in g["meta"]]
+    m = GMatcher({"use_layernorm": True, "sinkhorn_iterations": iters, "linear_precision": prec}).eval()
+    m.load_state_dict(synth.make_state_dict(123, use_layernorm=True))
+    pair = synth.make_pair(n, seed)
+    data = pair_to_data(pair, rad, pct, ms, device="cuda")
+    out = m(data)
+    stats = _compare(out, data, g, float(g["match_threshold"]))
+    print(name, prec, stats)
+
+
+def test_layernorm_kernel(models):
+    from gims_amd import hip
+    r = np.random.default_rng(4)
+    for rows, c in ((1000, 512), (77, 32), (300, 64), (513, 256)):
+        x = (r.normal(size=(rows, c)) * 3 + 1).astype(np.float32)
+        a2, b2 = r.normal(size=c).astype(np.float32), r.normal(size=c).astype(np.float32)
+        xt = torch.from_numpy(x)
+        ref = torch.from_numpy(a2) * ((xt - xt.mean(1, keepdim=True)) / (xt.std(1, keepdim=True) + 1e-6)) + torch.from_numpy(b2)
+        ref = torch.relu(ref).numpy()
+        xd = torch.from_numpy(x).cuda()
+        osp = torch.zeros((rows, 2 * c), dtype=torch.bfloat16, device="cuda")
+        out = hip.layernorm_act(xd, torch.from_numpy(a2).cuda(), torch.from_numpy(b2).cuda(), out=torch.empty_like(xd))
+        hip.layernorm_act(xd, torch.from_numpy(a2).cuda(), torch.from_numpy(b2).cuda(), out_split=osp)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-5 * max(1.0, np.abs(ref).max()), rtol=0)
+        hi, lo = hip.spl32_planes(osp)
+        rec = hi.float().cpu().numpy().astype(np.float64) + lo.float().cpu().numpy()
+        assert (np.abs(rec - out.cpu().numpy()) <= np.abs(out.cpu().numpy()) * 2.0 ** -15 + 1e-30).all()
