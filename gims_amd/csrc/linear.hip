@@ -589,7 +589,8 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       GIMS_HIP(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
     }
     const int big_blocks = cdiv(a->m, 256) * cdiv(a->n, 256);
-    const bool big = force == 256 || (force != 128 && big_blocks >= 192);
+    // the 256-wide tile only when it is not half empty (n = 64 / 128 layers of the keypoint encoder and GraphSAGE)
+    const bool big = force == 256 || (force != 128 && big_blocks >= 192 && (a->n % 256 == 0 || a->n > 512));
     if (force == 1283 || force == 1284 || force == 2563) {      // experimental ring geometries
       static bool attr2 = false;
       using T3 = X3P<256, 128, 4, 2, 3>;

@@ -191,12 +191,12 @@ class GMatcher(nn.Module):
             w, b = sd[f"kenc.encoder.{3 * i}.weight"][:, :, 0], sd[f"kenc.encoder.{3 * i}.bias"]
             if i < nk - 1:
                 w, b = fold(w, b, f"kenc.encoder.{3 * i + 1}")
-            P["kenc"].append(lin(w, b))
+            P["kenc"].append(lin(w, b, not ln))      # SPL32 operands (LDS-DMA GEMM); the LayerNorm variant keeps f32 activations
         # GraphSAGE: [W_self | W_neigh] on [h | mean(h)]  (gmatcher.py:149-151)
         P["sage"] = []
         for i in range(3):
             p = f"gnn_encoder.layers.{i}."
-            P["sage"].append(lin(torch.cat([sd[p + "fc_self.weight"], sd[p + "fc_neigh.weight"]], 1), sd[p + "fc_self.bias"]))
+            P["sage"].append(lin(torch.cat([sd[p + "fc_self.weight"], sd[p + "fc_neigh.weight"]], 1), sd[p + "fc_self.bias"], True))
         # attentional GNN.  Heads are interleaved in the reference (channel c = d*H + h, gmatcher.py:111);
         # permute q/k/v output rows and merge input columns to head-blocked order c' = h*64 + d.
         H, D = self._heads, self.config['descriptor_dim']
@@ -364,15 +364,29 @@ class GMatcher(nn.Module):
             g["n_kept"], g["n_edges"], g["info_host"] = int(inf[0]), int(inf[1]), inf
             g["rows"] = (ro, g["n_kept"])
         # ---- GraphSAGE over the merged CSR of all images (gmatcher.py:145-162, 268-269)
+        x3 = P["x3"]
         with St("sage"):
             h = feat
-            for i, e in enumerate(P["sage"]):
-                agg = torch.empty_like(h)
-                hip.sage_mean(h, indptr_all, indices_all, agg)
-                h = self._lin(e, h, a1=agg, act=hip.ACT_RELU if i < 2 else hip.ACT_NONE)
+            if x3:
+                # split-bf16 operands for the LDS-DMA GEMM: h and mean(h) as SPL32 planes (the producing GEMM writes the
+                # planes of the next layer's h itself; the aggregation reads h in f32)
+                h_spl = hip.split_spl32(h)
+                for i, e in enumerate(P["sage"]):
+                    agg = torch.empty_like(h)
+                    hip.sage_mean(h, indptr_all, indices_all, agg)
+                    agg_spl = hip.split_spl32(agg)
+                    last = i == len(P["sage"]) - 1
+                    h_next = torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev)
+                    h_spl_next = None if last else self._spl(n_tot, e["n"], dev)
+                    self._lin(e, h_spl, a1=agg_spl, act=hip.ACT_NONE if last else hip.ACT_RELU, out=h_next, out_split=h_spl_next)
+                    h, h_spl = h_next, h_spl_next
+            else:
+                for i, e in enumerate(P["sage"]):
+                    agg = torch.empty_like(h)
+                    hip.sage_mean(h, indptr_all, indices_all, agg)
+                    h = self._lin(e, h, a1=agg, act=hip.ACT_RELU if i < 2 else hip.ACT_NONE)
             sage = h
         # ---- keypoint encoder (gmatcher.py:26-33, 87-97) ; desc = sage + kenc (gmatcher.py:270-271)
-        x3 = P["x3"]
         with St("kenc"):
             ln = P["ln"]
             x = torch.empty((n_tot, P["kenc_w1"].shape[0]), dtype=torch.float32, device=dev)
@@ -380,13 +394,25 @@ class GMatcher(nn.Module):
             if ln:      # use_layernorm=True: conv -> LayerNorm -> ReLU (gmatcher.py:17-23), the norm as its own kernel
                 hip.layernorm_act(x, *P["kenc_ln"][0], out=x)
             dpl = self._spl(n_tot, D, dev) if x3 else None          # split-bf16 (SPL32) copy of the residual stream
-            for i, e in enumerate(P["kenc"]):
-                last = i == len(P["kenc"]) - 1
-                x = self._lin(e, x, act=hip.ACT_NONE if (last or ln) else hip.ACT_RELU, residual=sage if last else None,
-                              out=torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev),
-                              out_split=dpl if (last and x3) else None)
-                if ln and not last:
-                    hip.layernorm_act(x, *P["kenc_ln"][i + 1], out=x)
+            if x3 and not ln:
+                xs = hip.split_spl32(x)                              # the hidden activations only ever exist as SPL32 planes
+                for i, e in enumerate(P["kenc"]):
+                    last = i == len(P["kenc"]) - 1
+                    if last:
+                        x = torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev)
+                        self._lin(e, xs, residual=sage, out=x, out_split=dpl)
+                    else:
+                        nxt = self._spl(n_tot, e["n"], dev)
+                        self._lin(e, xs, act=hip.ACT_RELU, out_split=nxt)
+                        xs = nxt
+            else:
+                for i, e in enumerate(P["kenc"]):
+                    last = i == len(P["kenc"]) - 1
+                    x = self._lin(e, x, act=hip.ACT_NONE if (last or ln) else hip.ACT_RELU, residual=sage if last else None,
+                                  out=torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev),
+                                  out_split=dpl if (last and x3) else None)
+                    if ln and not last:
+                        hip.layernorm_act(x, *P["kenc_ln"][i + 1], out=x)
             desc = x
         # ---- attentional GNN (gmatcher.py:99-143): per layer QKV -> flash attention -> merge -> MLP -> residual
         pairs = [(images[2 * p]["rows"], images[2 * p + 1]["rows"]) for p in range(len(images) // 2)]
