@@ -658,7 +658,11 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   int rc = gims_linear_batch(dla, B, maxn, maxn, GIMS_PREC_F32, stream);
   if (rc != GIMS_OK) return rc;
   // K2
-  const int hgrid = maxn < 1024 ? maxn : 1024;
+  // ~4096 workgroups in total: each folds its LDS histogram into the global one with 256 atomics, so one workgroup per
+  // ROW (65 536 workgroups at 64 images x 1024 rows) spent most of the pass on those 16 M global atomics
+  int hgrid = 4096 / (B > 0 ? B : 1);
+  hgrid = hgrid < 16 ? 16 : (hgrid > 1024 ? 1024 : hgrid);
+  hgrid = hgrid < maxn ? hgrid : maxn;
   for (int pass = 0; pass < 4; ++pass) {
     hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, pass);
     hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, pass);
