@@ -14,6 +14,7 @@
 // the sequential fix-ups only flip bits and the CSR falls out of popcounts in ascending neighbour order.
 #include "common.h"
 
+#include <cstring>
 #include <vector>
 
 namespace gims {
@@ -21,7 +22,8 @@ namespace gims {
 constexpr int AGC_MAX_N = 16384;
 
 struct AgcWs {
-  float* dn;            // [n][d] normalised descriptors
+  float* dn;            // [n][d] normalised descriptors (f32 GEMM) -- or, as dn3, their SPL3 three-way bf16 split [n][3d]
+  uint16_t* dn3;        // non-null: the similarity GEMM runs as GIMS_PREC_BF16X6
   float* S;             // [n][lds]
   uint64_t* bits;       // [n][nw]
   uint32_t* hist;       // [256]
@@ -73,6 +75,18 @@ __global__ __launch_bounds__(256) void agc_normalize_kernel(const AgcWs* __restr
   for (int j = lane; j < d; j += 64) s = fmaf(x[j], x[j], s);
   s = wave_sum(s);
   const float nrm = fmaxf(sqrtf(s), 1e-12f);   // F.normalize: x / max(||x||, eps)
+  if (w.dn3) {     // exact three-way split of the f32 quotient (linear6.hip: SPL3 layout)
+    uint16_t* o = w.dn3 + (int64_t)row * 3 * d;
+    for (int j = lane; j < d; j += 64) {
+      const float v = x[j] / nrm;
+      const uint16_t h1 = f2bf(v);
+      const float r1 = v - bf2f(h1);
+      const uint16_t h2 = f2bf(r1);
+      uint16_t* q = o + (j >> 5) * 96 + (j & 31);
+      q[0] = h1; q[32] = h2; q[64] = f2bf(r1 - bf2f(h2));
+    }
+    return;
+  }
   for (int j = lane; j < d; j += 64) dn[(int64_t)row * d + j] = x[j] / nrm;
 }
 
@@ -558,12 +572,17 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 constexpr int AGC_CAP_PER_NODE = 64;  // scratch CSR capacity of the pre-removal graph: 64 directed edges per node
 
+static bool agc_sim_x6() {
+  static const int v = [] { const char* e = getenv("GIMS_SIM_PREC"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
+  return v != 0;
+}
+
 static size_t agc_layout(int n, int d, char* base, AgcWs* w) {
   const int lds = (n + 3) & ~3, nw = (n + 63) / 64, cap = n * AGC_CAP_PER_NODE;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return base ? base + o : (char*)nullptr; };
   char* p;
-  p = take((size_t)n * d * 4); if (w) w->dn = (float*)p;
+  p = take((size_t)n * d * 6); if (w) { w->dn = (float*)p; w->dn3 = (d % 32 == 0 && agc_sim_x6()) ? (uint16_t*)p : nullptr; }
   p = take((size_t)n * lds * 4); if (w) w->S = (float*)p;
   p = take((size_t)n * nw * 8); if (w) w->bits = (uint64_t*)p;
   p = take(256 * 4); if (w) w->hist = (uint32_t*)p;
@@ -612,6 +631,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   gims_linear_args* dla = (gims_linear_args*)((char*)work + al256(sizeof(AgcWs) * (size_t)n_images));
   char* base = (char*)work + agc_batch_header(n_images);
   int maxn = 0, maxnw = 0;
+  bool all_x6 = true;
   static bool attr_set = false;
   if (!attr_set) {
     GIMS_HIP(hipFuncSetAttribute((const void*)agc_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AGC_MAX_N * 8));
@@ -637,8 +657,12 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     w->krank = k;
     // K1 GEMM descriptor: S = Dn Dn^T in exact f32
     gims_linear_args la = {};
-    la.a0 = w->dn; la.lda0 = im.d; la.w = w->dn; la.ldw = im.d; la.out_f32 = w->S; la.ldc = w->lds;
-    la.m = im.n; la.n = im.n; la.k = im.d; la.k0 = im.d; la.act = GIMS_ACT_NONE; la.precision = GIMS_PREC_F32; la.scale = 1.f;
+    // (GIMS_PREC_BF16X6: three-way split operands, six bf16 MFMAs per product -- f32-GEMM accuracy at 6/16 of the exact-f32
+    // MFMA cost; GIMS_SIM_PREC=f32 in the environment selects the exact-f32 MFMA kernel)
+    const bool x6 = w->dn3 != nullptr;
+    all_x6 = all_x6 && x6;
+    la.a0 = x6 ? (const float*)w->dn3 : w->dn; la.lda0 = x6 ? 3 * im.d : im.d; la.w = la.a0; la.ldw = la.lda0; la.out_f32 = w->S; la.ldc = w->lds;
+    la.m = im.n; la.n = im.n; la.k = im.d; la.k0 = im.d; la.act = GIMS_ACT_NONE; la.precision = x6 ? GIMS_PREC_BF16X6 : GIMS_PREC_F32; la.scale = 1.f;
     la.flags = GIMS_LINEAR_UPPER;    // only S[i][j], i < j, is ever read (threshold select and edge test)
     hla[i] = la;
     maxn = im.n > maxn ? im.n : maxn;
@@ -655,7 +679,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   const dim3 gw(cdiv(maxn, 4), B), g1(1, B);
   // K1
   hipLaunchKernelGGL(agc_normalize_kernel, gw, dim3(256), 0, s, dws);
-  int rc = gims_linear_batch(dla, B, maxn, maxn, GIMS_PREC_F32, stream);
+  int rc = gims_linear_batch(dla, B, maxn, maxn, all_x6 ? GIMS_PREC_BF16X6 : GIMS_PREC_F32, stream);
   if (rc != GIMS_OK) return rc;
   // K2
   // ~4096 workgroups in total: each folds its LDS histogram into the global one with 256 atomics, so one workgroup per

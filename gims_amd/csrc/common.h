@@ -90,5 +90,8 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // Host descriptor table -> device memory through KERNEL ARGUMENTS (chunks of <= 3968 bytes per launch): asynchronous on
 // the stream, no staging buffer whose lifetime would need a synchronisation, no pageable-memory pinning by the runtime.
 int upload_table(const void* host, size_t bytes, void* dev, hipStream_t stream);
+// linear6.hip: exact-class bf16x6 GEMM on SPL3 operands (batched), and its operand split
+int linear_x6_batch_launch(const gims_linear_args* dev_args, int count, int max_m, int max_n, hipStream_t s);
+int split_spl3_launch(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int k, hipStream_t s);
 
 }  // namespace gims

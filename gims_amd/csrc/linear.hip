@@ -527,6 +527,16 @@ static int linear_validate(const gims_linear_args* a) {
   GIMS_CHECK_ARG(a->k0 == a->k || a->a1 != nullptr, "gims_linear: second A segment missing");
   GIMS_CHECK_ARG(a->out_f32 || a->out_bf16 || a->out_hi, "gims_linear: no output");
   GIMS_CHECK_ARG((a->out_hi == nullptr) == (a->out_lo == nullptr), "gims_linear: out_hi and out_lo come together");
+  if (a->precision == GIMS_PREC_BF16X6) {   // SPL3 operands, batched launches only: C = scale * A W^T, f32 out
+    GIMS_CHECK_ARG((a->k % 32) == 0 && a->k0 == a->k, "gims_linear(bf16x6): K=%d must be a multiple of 32, one A segment", a->k);
+    GIMS_CHECK_ARG(a->lda0 >= 3 * (int64_t)a->k && a->ldw >= 3 * (int64_t)a->k && (a->lda0 % 8) == 0 && (a->ldw % 8) == 0,
+                   "gims_linear(bf16x6): SPL3 operands have row pitch >= 3*K, a multiple of 8 elements");
+    GIMS_CHECK_ARG((((uintptr_t)a->a0 | (uintptr_t)a->w | (uintptr_t)a->out_f32) & 15) == 0 && a->out_f32 && (a->ldc % 4) == 0,
+                   "gims_linear(bf16x6): operands / output must be 16-byte aligned, f32 output with ldc %% 4 == 0");
+    GIMS_CHECK_ARG(!a->bias && !a->residual && !a->out_bf16 && !a->out_hi && a->act == GIMS_ACT_NONE,
+                   "gims_linear(bf16x6): plain scaled product only");
+    return GIMS_OK;
+  }
   if (a->a0_lo) {   // pre-split activations: bf16 hi/lo planes, LDS-DMA kernel
     GIMS_CHECK_ARG(a->precision == GIMS_PREC_BF16X3 && a->w_lo, "gims_linear: pre-split A needs GIMS_PREC_BF16X3 and w_lo");
     GIMS_CHECK_ARG(a->k0 == a->k || a->a1_lo, "gims_linear: second A segment needs its lo plane");
@@ -571,6 +581,7 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
   using namespace gims;
   int rc = linear_validate(a);
   if (rc != GIMS_OK) return rc;
+  GIMS_CHECK_ARG(a->precision != GIMS_PREC_BF16X6, "gims_linear: GIMS_PREC_BF16X6 runs through gims_linear_put_many + gims_linear_batch");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(a->n, BN), cdiv(a->m, BM));
   if (a->a0_lo) {
@@ -660,7 +671,9 @@ extern "C" int gims_linear_batch(const gims_linear_args* dev_args, int32_t count
   GIMS_CHECK_ARG(dev_args && count > 0 && max_m > 0 && max_n > 0, "gims_linear_batch: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(max_n, BN), cdiv(max_m, BM), count);
-  if (precision == GIMS_PREC_F32) {
+  if (precision == GIMS_PREC_BF16X6) {
+    return linear_x6_batch_launch(dev_args, count, max_m, max_n, s);
+  } else if (precision == GIMS_PREC_F32) {
     hipLaunchKernelGGL(linear_f32_batch_kernel, grid, dim3(256), 0, s, dev_args);
   } else if (precision == GIMS_PREC_BF16X3) {
     int rc = x3_attr();

@@ -1,0 +1,205 @@
+// Exact-class dense contraction on bf16 MFMA: C = scale * A W^T with both f32 operands split THREE ways,
+//     a = a1 + a2 + a3   (bf16 each; 8 + 8 + 8 significant bits: the split of an f32 value is exact)
+//     a . w ~ a1 w1 + (a1 w2 + a2 w1) + (a1 w3 + a2 w2 + a3 w1)            six v_mfma_f32_32x32x16_bf16 per product,
+// the dropped terms are <= 2^-24 relative -- the accuracy of an f32 GEMM (measured: 6e-8 against float64 on unit-norm
+// descriptors, an f32 BLAS GEMM 6e-7) at 6/16 of the cost of the exact-f32 MFMA (v_mfma_f32_32x32x2_f32 runs at 1/16 of
+// the bf16 rate).  Used for the two N x N contractions whose VALUES are compared or thresholded downstream: the cosine
+// similarity matrix of the adaptive graph (agc.py:390) and the score matrix (gmatcher.py:274).
+//
+// Operand layout "SPL3": logical [rows][K] f32 -> bf16 [rows][3K]; per 32-channel block 32 x a1, 32 x a2, 32 x a3
+// (192 bytes).  Kernel: 256 x 128 output tile, 8 waves (4 x 2, 64 x 64 each), 32-channel stages in a 2-stage LDS ring filled
+// by LDS-DMA; a stage row is 12 chunks of 16 bytes, stored ROTATED by (row >> 2) % 12 chunks (the rotation is applied to
+// the source chunk index of the DMA and again on the ds_read_b128: conflict-free for the b128 lane groups; 192-byte rows
+// without it are 4-way conflicted).  Epilogue: accumulators transposed through LDS so that stores cover whole lines.
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace gims {
+
+constexpr int X6_TM = 256, X6_TN = 128, X6_WM = 4, X6_WN = 2, X6_BK = 32;
+constexpr int X6_ROW = 96;                                   // bf16 elements per stage row (3 planes x 32 channels)
+constexpr int X6_STAGE = (X6_TM + X6_TN) * X6_ROW;           // elements per stage (73 728 bytes)
+constexpr int X6_PIECES = (X6_TM + X6_TN) * 12 / 64 / 8;     // 16-byte x 64-lane DMA instructions per wave per stage (9)
+constexpr int X6_EP_PITCH = X6_TN / X6_WN + 4;
+constexpr int X6_LDS_BYTES = 2 * X6_STAGE * 2;               // 147 456 bytes (the epilogue slices, 8 x 8.7 KB, reuse it)
+
+template <int N>
+__device__ __forceinline__ void x6_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ int x6_rot(int row) { return (row >> 2) % 12; }
+
+__global__ __launch_bounds__(512) void linear_x6_kernel(const gims_linear_args* __restrict__ args) {
+  const gims_linear_args p = args[blockIdx.z];
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / X6_WN, wn = wave % X6_WN;
+  const int m0 = blockIdx.y * X6_TM, n0 = blockIdx.x * X6_TN;
+  if (m0 >= p.m || n0 >= p.n) return;                          // batched launches are sized for the largest problem
+  if ((p.flags & GIMS_LINEAR_UPPER) && n0 + X6_TN <= m0) return;   // symmetric product: tile entirely below the diagonal
+  const int li = lane & 31, lh = lane >> 5;
+  const int nk = p.k / X6_BK;
+
+  // DMA duty of this lane: chunk c = (wave * 9 + i) * 64 + lane of the stage image; row = c / 12, position = c % 12 holds
+  // the source chunk (position - rot(row)) mod 12.  Element offsets relative to the k-block start are loop invariant.
+  int64_t goff[X6_PIECES];
+#pragma unroll
+  for (int i = 0; i < X6_PIECES; ++i) {
+    const int c = (wave * X6_PIECES + i) * 64 + lane;
+    const int row = c / 12, pos = c % 12;
+    int g = pos - x6_rot(row);
+    g = g < 0 ? g + 12 : g;
+    const bool is_a = row < X6_TM;
+    int gr = is_a ? m0 + row : n0 + row - X6_TM;
+    const int rmax = (is_a ? p.m : p.n) - 1;
+    gr = gr < rmax ? gr : rmax;
+    goff[i] = (is_a ? (int64_t)gr * p.lda0 : (int64_t)gr * p.ldw) + 8 * g;
+  }
+  const uint16_t* abase = (const uint16_t*)p.a0;
+  const uint16_t* wbase = (const uint16_t*)p.w;
+  auto issue = [&](int kt) {
+    uint16_t* dst = smem + (kt & 1) * X6_STAGE + wave * X6_PIECES * 512;
+#pragma unroll
+    for (int i = 0; i < X6_PIECES; ++i) {
+      const int c0 = (wave * X6_PIECES + i) * 64;            // wave-uniform: rows of one instruction are all A or all W
+      const uint16_t* g = ((c0 / 12) < X6_TM ? abase : wbase) + goff[i] + (int64_t)kt * X6_ROW;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(dst + i * 512), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];   // [n-block][m-block], D^T layout: column = row m (lane & 31), rows = output channels
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row r of the stage image, chunk (plane * 4 + 2 * s + lh + rot(r)) mod 12
+  int arow[2], wrow[2], arot[2], wrot[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    arow[i] = wm * 64 + i * 32 + li;
+    wrow[i] = X6_TM + wn * 64 + i * 32 + li;
+    arot[i] = x6_rot(arow[i]);
+    wrot[i] = x6_rot(wrow[i]);
+  }
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    x6_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1);
+    const uint16_t* st = smem + (kt & 1) * X6_STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[2][3], wf[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          int ca = pl * 4 + 2 * s + lh + arot[i];
+          ca = ca >= 12 ? ca - 12 : ca;
+          int cw = pl * 4 + 2 * s + lh + wrot[i];
+          cw = cw >= 12 ? cw - 12 : cw;
+          af[i][pl] = *(const bf16x8*)(st + arow[i] * X6_ROW + 8 * ca);
+          wf[i][pl] = *(const bf16x8*)(st + wrow[i] * X6_ROW + 8 * cw);
+        }
+      // six products per accumulator, smallest terms first; term-major so that consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int term = 0; term < 6; ++term) {
+        constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, AP[6] = {0, 2, 1, 0, 1, 0};   // (w3 a1) (w1 a3) (w2 a2) (w2 a1) (w1 a2) (w1 a1)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni][WP[term]], af[mi][AP[term]], acc[ni][mi], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: transpose through a wave-private LDS slice (32 rows x 64 columns at a time), row-contiguous stores
+  __builtin_amdgcn_s_barrier();
+  float* ep = (float*)smem + wave * (32 * X6_EP_PITCH);
+  constexpr int LPR = 64 / 8, RPI = 64 / LPR, ITERS = 32 / RPI;     // 8 lanes per row, 8 rows per access, 4 accesses
+  const int c8 = (lane % LPR) * 8, rsub = lane / LPR;
+  const int col = n0 + wn * 64 + c8;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(ep + li * X6_EP_PITCH + ni * 32 + 8 * g + 4 * lh) =
+            make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = m0 + wm * 64 + mi * 32 + rsub + it * RPI;
+      const float* src = ep + (rsub + it * RPI) * X6_EP_PITCH + c8;
+      const float4 a0 = *(const float4*)src, a1 = *(const float4*)(src + 4);
+      if (row < p.m) {
+        float* o = p.out_f32 + (int64_t)row * p.ldc + col;
+        if (col + 3 < p.n) *(float4*)o = make_float4(a0.x * p.scale, a0.y * p.scale, a0.z * p.scale, a0.w * p.scale);
+        else {
+          const float v[4] = {a0.x, a0.y, a0.z, a0.w};
+          for (int e = 0; e < 4; ++e)
+            if (col + e < p.n) o[e] = v[e] * p.scale;
+        }
+        if (col + 7 < p.n) *(float4*)(o + 4) = make_float4(a1.x * p.scale, a1.y * p.scale, a1.z * p.scale, a1.w * p.scale);
+        else {
+          const float v[4] = {a1.x, a1.y, a1.z, a1.w};
+          for (int e = 0; e < 4; ++e)
+            if (col + 4 + e < p.n) o[4 + e] = v[e] * p.scale;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// f32 [rows][k] -> SPL3 bf16 [rows][3k]: one thread per (row, channel)
+__global__ void split_spl3_kernel(const float* __restrict__ src, int64_t lds, uint16_t* __restrict__ dst, int64_t ldd, int64_t rows, int k) {
+  const int64_t total = rows * k;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / k;
+    const int c = (int)(idx - r * k);
+    const float x = src[r * lds + c];
+    const uint16_t h1 = f2bf(x);
+    const float r1 = x - bf2f(h1);
+    const uint16_t h2 = f2bf(r1);
+    const uint16_t h3 = f2bf(r1 - bf2f(h2));
+    uint16_t* d = dst + r * ldd + (c >> 5) * 96 + (c & 31);
+    d[0] = h1; d[32] = h2; d[64] = h3;
+  }
+}
+
+int linear_x6_batch_launch(const gims_linear_args* dev_args, int count, int max_m, int max_n, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    GIMS_HIP(hipFuncSetAttribute((const void*)linear_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES));
+    attr = true;
+  }
+  hipLaunchKernelGGL(linear_x6_kernel, dim3(cdiv(max_n, X6_TN), cdiv(max_m, X6_TM), count), dim3(512), X6_LDS_BYTES, s, dev_args);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+int split_spl3_launch(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int k, hipStream_t s) {
+  int64_t blocks = (rows * k + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_spl3_kernel, dim3((int)blocks), dim3(256), 0, s, src, lds, dst, ldd, rows, k);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+}  // namespace gims
+
+extern "C" int gims_split_spl3(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int32_t k, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(src && dst && rows >= 0 && k > 0 && (k % 32) == 0 && ldd >= 3 * (int64_t)k && (ldd % 8) == 0 && (((uintptr_t)dst) & 15) == 0,
+                 "gims_split_spl3: bad arguments (k %% 32 == 0, ldd >= 3k, 16-byte aligned rows)");
+  if (rows == 0) return GIMS_OK;
+  return split_spl3_launch(src, lds, dst, ldd, rows, k, (hipStream_t)stream);
+}

@@ -17,6 +17,7 @@ so that every linear layer is ONE launch for the whole batch.
 """
 from __future__ import annotations
 
+import os
 import math
 import time
 from typing import Dict, List
@@ -479,15 +480,19 @@ class GMatcher(nn.Module):
             s1_all = torch.empty(tot1, dtype=torch.float32, device=dev)
             uv_all = torch.empty(tot0 + tot1 + 3 * len(pairs), dtype=torch.float32, device=dev)
             c0 = c1 = cu = 0
+            # the score GEMM keeps f32 accuracy: three-way bf16 split operands (six MFMAs per product) unless
+            # GIMS_SCORE_PREC=f32 asks for the exact-f32 MFMA kernel
+            sprec = hip.PREC_BF16X6 if (D % 32 == 0 and os.environ.get("GIMS_SCORE_PREC", "x6") != "f32") else hip.PREC_F32
+            sdesc = hip.split_spl3(mdesc) if sprec == hip.PREC_BF16X6 else mdesc
             for (o0, n0), (o1, n1) in pairs:
                 ld = (n1 + 3) // 4 * 4
                 scores = torch.empty((n0, ld), dtype=torch.float32, device=dev)
-                largs.append(hip.linear_args(mdesc[o0:o0 + n0], mdesc[o1:o1 + n1], out=scores, precision=hip.PREC_F32,
+                largs.append(hip.linear_args(sdesc[o0:o0 + n0], sdesc[o1:o1 + n1], out=scores, precision=sprec,
                                              scale=1.0 / math.sqrt(D), n=n1))
                 items.append(dict(scores=scores, n=n0, m=n1, matches0=m0_all[c0:c0 + n0], matches1=m1_all[c1:c1 + n1],
                                   mscores0=s0_all[c0:c0 + n0], mscores1=s1_all[c1:c1 + n1], uv=uv_all[cu:cu + n0 + n1 + 3]))
                 c0, c1, cu = c0 + n0, c1 + n1, cu + n0 + n1 + 3
-            hip.linear_batch(largs, self._buf("score_args", 256 * len(largs)), hip.PREC_F32)
+            hip.linear_batch(largs, self._buf("score_args", 256 * len(largs)), sprec)
         with St("sinkhorn"):
             probs = hip.make_ot_problems(items)
             work = self._buf("ot", hip.sinkhorn_workspace_bytes(probs))

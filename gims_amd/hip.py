@@ -14,7 +14,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgims_hip.so")
 
-PREC_F32, PREC_BF16X3 = 0, 1
+PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
+LINEAR_UPPER = 1
 ACT_NONE, ACT_RELU = 0, 1
 
 
@@ -71,6 +72,7 @@ _SIGNATURES = {
     "gims_linear_put_many": (C.c_int, [C.POINTER(LinearArgs), C.c_int32, C.c_void_p, C.c_void_p]),
     "gims_linear_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_split_spl3": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_split_spl32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
@@ -174,7 +176,13 @@ def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None
     spl=True : a0/a1/w are SPL32 bf16 buffers [rows, 2*k] (see include/gims_hip.h), precision BF16X3.
     out_split: SPL32 bf16 buffer [m, >= 2n] receiving the result split into hi/lo."""
     m = a0.shape[0]
-    if spl:
+    if precision == PREC_BF16X6:
+        # a0 / w are SPL3 bf16 buffers [rows, 3k] (split_spl3); plain f32 output only
+        assert a0.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a1 is None and not spl
+        k0 = k = a0.shape[1] // 3
+        assert w.shape[1] == 3 * k, (w.shape, k)
+        a0_lo = a1_lo = w_lo = None
+    elif spl:
         assert a0.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and precision == PREC_BF16X3
         k0 = a0.shape[1] // 2
         k = k0 + (a1.shape[1] // 2 if a1 is not None else 0)
@@ -231,6 +239,18 @@ def split_spl32(x: torch.Tensor, out: torch.Tensor | None = None):
     if out is None:
         out = torch.empty((rows, 2 * k), dtype=torch.bfloat16, device=x.device)
     _check(lib.gims_split_spl32(_p(_dev(x, torch.float32)), x.stride(0), _p(out), out.stride(0), rows, k, _stream()), "gims_split_spl32")
+    return out
+
+
+def split_spl3(x: torch.Tensor, out: torch.Tensor | None = None):
+    """f32 [rows, k] -> SPL3 bf16 [rows, 3k]: the exact three-way split x = a1 + a2 + a3 (32 a1 | 32 a2 | 32 a3 per
+    32-channel block), the operand layout of PREC_BF16X6."""
+    lib = load()
+    rows, k = x.shape
+    assert x.stride(1) == 1 and k % 32 == 0
+    if out is None:
+        out = torch.empty((rows, 3 * k), dtype=torch.bfloat16, device=x.device)
+    _check(lib.gims_split_spl3(_p(_dev(x, torch.float32)), x.stride(0), _p(out), out.stride(0), rows, k, _stream()), "gims_split_spl3")
     return out
 
 

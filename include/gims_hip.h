@@ -59,6 +59,9 @@ int gims_upload_table(const void* host, int64_t bytes, void* dev, void* stream);
  */
 #define GIMS_PREC_F32 0
 #define GIMS_PREC_BF16X3 1
+#define GIMS_PREC_BF16X6 2   /* three-way split (a1+a2+a3, exact), six bf16 MFMAs per product: f32-GEMM accuracy at 6/16 of
+                              the exact-f32 MFMA cost.  Operands in the SPL3 layout (gims_split_spl3); batched launches only
+                              (gims_linear_put_many + gims_linear_batch), C = scale * A W^T into out_f32, GIMS_LINEAR_UPPER ok */
 #define GIMS_ACT_NONE 0
 #define GIMS_ACT_RELU 1
 
@@ -100,6 +103,9 @@ int gims_linear_batch(const gims_linear_args* dev_args, int32_t count, int32_t m
 /* Split an f32 array into bf16 hi/lo planes (hi = bf16_rne(x), lo = bf16_rne(x - hi)). */
 int gims_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
 /* f32 [rows][k] (pitch lds) -> SPL32 bf16 [rows][2k] (pitch ldd); k % 32 == 0. */
+/* f32 [rows][k] (row pitch lds) -> SPL3 bf16 [rows][3k] (row pitch ldd elements): per 32-channel block 32 x a1, 32 x a2,
+ * 32 x a3 with a = a1 + a2 + a3 exactly.  Operand format of GIMS_PREC_BF16X6. */
+int gims_split_spl3(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int32_t k, void* stream);
 int gims_split_spl32(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int32_t k, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -98,6 +98,51 @@ def test_linear_presplit(hip, m, n, k, k0):
     np.testing.assert_array_equal(ob.cpu().view(torch.int16).numpy(), torch.from_numpy(o).to(torch.bfloat16).view(torch.int16).numpy())
 
 
+def test_split_spl3_exact(hip):
+    """SPL3 = exact three-way bf16 split: the planes sum back to the f32 value bit for bit (24 significand bits)."""
+    r = _rng(5)
+    x = (r.normal(size=(41, 96)) * np.exp(r.normal(size=(41, 96)) * 4)).astype(np.float32)
+    buf = hip.split_spl3(_dev(x)).cpu().view(torch.int16).numpy().reshape(41, 3, 3, 32)      # [row][block][plane][32]
+    planes = (buf.astype(np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    rec = planes.sum(2).reshape(41, 96)
+    np.testing.assert_array_equal(rec.astype(np.float32), x)
+    np.testing.assert_array_equal(planes[:, :, 0, :].reshape(41, 96).astype(np.float32),
+                                  torch.from_numpy(x).to(torch.bfloat16).float().numpy())      # plane 1 = RNE bf16
+
+
+@pytest.mark.parametrize("upper", [False, True])
+@pytest.mark.parametrize("shapes,k", [([(128, 128)], 32), ([(300, 260), (77, 100), (1024, 1028)], 256),
+                                      ([(2048, 2048), (513, 129)], 64), ([(4096, 4096)], 256)])
+def test_linear_bf16x6(hip, shapes, k, upper):
+    """GIMS_PREC_BF16X6 (six bf16 MFMAs per product on three-way split operands): f32-GEMM error class against float64,
+    ragged problems in one launch; GIMS_LINEAR_UPPER only promises the strict upper triangle."""
+    r = _rng(k + len(shapes))
+    largs, keep = [], []
+    for (m, n) in shapes:
+        a = r.normal(size=(m, k)).astype(np.float32)
+        a[3, 5] = 1234.5
+        w = (r.normal(size=(n, k)) / np.sqrt(k)).astype(np.float32)
+        ld = (n + 3) // 4 * 4
+        out = torch.full((m, ld), float("nan"), dtype=torch.float32, device="cuda")
+        A3, W3 = hip.split_spl3(_dev(a)), hip.split_spl3(_dev(w))
+        la = hip.linear_args(A3, W3, out=out, precision=hip.PREC_BF16X6, scale=0.5, n=n)
+        if upper:
+            la.flags = hip.LINEAR_UPPER
+        largs.append(la)
+        keep.append((a, w, out, A3, W3))
+    buf = torch.empty(256 * len(largs), dtype=torch.uint8, device="cuda")
+    hip.linear_batch(largs, buf, hip.PREC_BF16X6)
+    torch.cuda.synchronize()
+    for (m, n), (a, w, out, _, _) in zip(shapes, keep):
+        ref = a.astype(np.float64) @ w.astype(np.float64).T * 0.5
+        scale_ref = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T * 0.5
+        o = out.cpu().numpy()[:, :n]
+        err = np.abs(o - ref) / scale_ref
+        if upper:
+            err = err[np.triu_indices(m, 1, n)]
+        assert np.isfinite(err).all() and err.max() < 2e-6, f"{m}x{n}: max scaled err {np.nanmax(err):.3e}"    # f32 roundoff class
+
+
 def test_split_spl32_layout(hip):
     x = _rng(2).normal(size=(37, 96)).astype(np.float32) * 5
     buf = hip.split_spl32(_dev(x))
