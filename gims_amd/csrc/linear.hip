@@ -360,11 +360,12 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   for (int kt = 0; kt < nk; ++kt) {
     // own pieces of stage kt landed: at most `newer` stages (PIECES each) may still be in flight
     const int newer = (nk - 1 - kt) < (D - 1) ? (nk - 1 - kt) : (D - 1);
-    if (newer >= 2) wait_vm<2 * T::PIECES>();
-    else if (newer == 1) wait_vm<T::PIECES>();
-    else wait_vm<0>();
+    if (newer == 0) wait_vm<0>();
+    else if (newer >= 2) wait_vm<2 * T::PIECES>();
+    else wait_vm<T::PIECES>();
     __builtin_amdgcn_s_barrier();
-    if (kt + D < nk) issue(kt + D);
+    if (kt + D < nk && !(p.flags & 0x400)) issue(kt + D);     // 0x400: no DMA after the prologue (probe)
+    if (p.flags & 0x800) continue;                             // 0x800: no LDS reads / MFMAs (probe)
     const uint16_t* st = smem + (kt % S) * T::STAGE;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {

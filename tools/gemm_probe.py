@@ -48,10 +48,11 @@ def main():
     print(f"rows={rows} reps={reps} GIMS_X3P_TILE={os.environ.get('GIMS_X3P_TILE', '(default)')}")
     for name, (mk, flops, byts) in cases.items():
         res = []
-        for fl in (0, 0x200, 0x100):
+        variants = [0, 0]          # repeats of the full kernel: the first timing of a case runs on a cold clock
+        for fl in [0, 0x200, 0x100, 0x200 | 0x400, 0x200 | 0x800] + variants:
             a = mk()
             a.flags = fl
-            for _ in range(3):
+            for _ in range(10):
                 lib.gims_linear(C.byref(a), st)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -62,7 +63,7 @@ def main():
             res.append(e0.elapsed_time(e1) / reps * 1e3)
         us = res[0]
         print(f"{name:30s} full {us:7.1f} us  ({flops / us * 1e-6:6.1f} TF/s alg, {byts / us * 1e-3:6.0f} GB/s alg) | "
-              f"main-only {res[1]:7.1f} us | epilogue-only {res[2]:7.1f} us | MFMA floor {3 * flops / 2.5e15 * 1e6:5.1f} us, HBM floor {byts / 8e12 * 1e6:5.1f} us")
+              f"main-only {res[1]:7.1f} us | epilogue-only {res[2]:7.1f} us | main w/o DMA {res[3]:7.1f} | main w/o MFMA {res[4]:7.1f} | variants(full) " + " ".join(f"{v:#x}:{r:.1f}" for v, r in zip(variants, res[5:])) + f" | MFMA floor {3 * flops / 2.5e15 * 1e6:5.1f} us, HBM floor {byts / 8e12 * 1e6:5.1f} us")
 
 
 if __name__ == "__main__":
