@@ -264,28 +264,35 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 //     phase 3:  A: O += V P of tile t, then tile t+1 into LDS, request tile t+2       B: softmax block 0 of tile t
 // K/V tiles are shared by 512 queries (half the staging traffic per query of the 4-wave kernel).
 constexpr int ATT8_WAVES = 8;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 template <bool PROF>
 __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
-    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, unsigned long long* prof) {
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, unsigned long long* prof,
+    int exact_only) {
   // diagnostics (GIMS_ATTN_PROF=1): cycles of wave 0 (group A) and wave 4 (group B) of workgroup 0 per phase, split into
   // work (phase start -> barrier reached) and wait (inside the barrier)
-  unsigned long long pt = 0, pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto stamp_work = [&](int ph) { if (PROF) { const unsigned long long n = __builtin_readcyclecounter(); pacc[2 * ph] += n - pt; pt = n; } };
-  auto stamp_wait = [&](int ph) { if (PROF) { const unsigned long long n = __builtin_readcyclecounter(); pacc[2 * ph + 1] += n - pt; pt = n; } };
+  unsigned long long pt = 0, pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp_work = [&](int ph) __attribute__((always_inline)) { if (PROF) { const unsigned long long n = __builtin_readcyclecounter(); pacc[2 * ph] += n - pt; pt = n; } };
+  // sub-stamps of the staging phase: [8] = its matrix segment, [9] = store_tile (the rest of the phase's work is load_tile)
+  auto stamp_sub = [&](int i) __attribute__((always_inline)) {
+    if (PROF) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n = __builtin_readcyclecounter(); pacc[i] += n - pt; pt = n; __builtin_amdgcn_sched_barrier(0); } };
+  auto stamp_wait = [&](int ph) __attribute__((always_inline)) { if (PROF) { const unsigned long long n = __builtin_readcyclecounter(); pacc[2 * ph + 1] += n - pt; pt = n; } };
   // Barriers inside the tile loop are RAW s_barrier + lgkmcnt(0): __syncthreads() also waits vmcnt(0), which would stall
   // every wave at the first barrier after load_tile until the global loads of the NEXT tile have landed.  The loads are
   // only needed by store_tile three phases later (register dependency).
-  auto raw_barrier = [&]() {
+  auto raw_barrier = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 #define ATT8_BAR(ph) do { stamp_work(ph); raw_barrier(); stamp_wait(ph); } while (0)
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KB * DH];
-  __shared__ __attribute__((aligned(16))) uint16_t Vt[2][DH * VT_LD];
+  // V tile row-major [key][d] with a 192-byte pitch (conflict-free for the transposing reads of seg_pv, see there)
+  constexpr int VROW = 96;
+  __shared__ __attribute__((aligned(16))) uint16_t Vs[2][KB * VROW];
   constexpr int QP = 2, QWV = QW * QP, QBK = QWV * ATT8_WAVES;   // 64 queries per wave, 512 per workgroup
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -314,49 +321,31 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   // were issued a moment earlier (measured: ~1100 of the 1575 cycles of that phase)
   __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) only
   f32x16 o[QP][2];
-#pragma unroll
-  for (int qi = 0; qi < QP; ++qi)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[qi][i][r] = 0.f;
   const float c = 0.125f * 1.4426950408889634f;
   constexpr float DEFER = 5.0f;
   const float defer_raw = DEFER / c;
   float m_run[QP], l_run[QP];
-#pragma unroll
-  for (int qi = 0; qi < QP; ++qi) { m_run[qi] = -1e30f; l_run[qi] = 0.f; }
 
-  // staging: K tile 64 rows x 8 chunks = 512 chunks, one per thread; V tile: key pair kp = t & 31, d-octet (t >> 5) & 7,
-  // element e = t >> 8 of the pair (threads 0-255 carry the even key, 256-511 the odd one)
+  // staging: K and V tiles are 64 rows x 8 chunks of 16 bytes = 512 chunks each, one of each per thread, same (row, chunk):
+  // eight lanes cover one 128-byte line of K and one of V, and the two addresses differ by a constant
   uint4 rk, rv;
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
-  const int vkp = t & 31, voct = (t >> 5) & 7, ve = t >> 8;
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt) __attribute__((always_inline)) {
     const int kbase = kt * KB;
-    {
-      const int row = t >> 3, ch = t & 7;
-      int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-      rk = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * ch);
-    }
-    {
-      int kr = kbase + 2 * vkp + ve; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-      rv = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * voct);
-    }
+    const int row = t >> 3, ch = t & 7;
+    int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+    const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + head * DH + 8 * ch;
+    rk = *(const uint4*)(src + k_col);
+    rv = *(const uint4*)(src + v_col);
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
     *(uint4*)(Ks[buf] + k_off(t >> 3, t & 7)) = rk;
-    const uint32_t a[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {   // d = 8*voct + 2j, 2j+1; this thread's key is 2*vkp + ve: 16-bit stores
-      Vt[buf][(8 * voct + 2 * j) * VT_LD + 2 * vkp + ve] = (uint16_t)(a[j] & 0xffffu);
-      Vt[buf][(8 * voct + 2 * j + 1) * VT_LD + 2 * vkp + ve] = (uint16_t)(a[j] >> 16);
-    }
+    *(uint4*)(Vs[buf] + (t >> 3) * VROW + 8 * (t & 7)) = rv;
   };
 
   f32x16 sacc[QP][2];
   bf16x8 pf[QP][4];
-  auto seg_qk = [&](int kt) {                 // S^T = K Q^T of tile kt (16 MFMAs)
+  auto seg_qk = [&](int kt) __attribute__((always_inline)) {                 // S^T = K Q^T of tile kt (16 MFMAs)
     const int buf = kt & 1;
 #pragma unroll
     for (int qi = 0; qi < QP; ++qi)
@@ -380,9 +369,8 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // 8 LDS reads ...
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);    // ... then the 16 MFMAs (the scheduler otherwise serialises read -> wait -> MFMA)
   };
-  auto seg_softmax = [&](int kt, int qi) {     // online softmax of query block qi on tile kt
+  auto seg_softmax = [&](int kt, int qi, bool exact) __attribute__((always_inline)) {     // online softmax of query block qi on tile kt
     const int kbase = kt * KB;
-    float tmax = -1e30f;
     if (kbase + KB > pr.n_kv) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
@@ -392,20 +380,28 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
           if (key >= pr.n_kv) sacc[qi][b][r] = -1e30f;
         }
     }
+    // Reference point of the exponentials.  softmax is invariant to it, so the OPTIMISTIC pass takes the row maximum of
+    // the first key tile and never looks at a maximum again (32 v_max + a cross-lane exchange + the rescale test per
+    // block and tile are a fifth of the VALU work that bounds this kernel): later scores above the reference just give
+    // p > 1.  Only a score more than ~100 octaves above it could overflow; the row sums are checked after the loop and the
+    // workgroup then repeats its tiles in the exact mode (running maximum, deferred rescale).
+    if (exact || kt == 0) {
+      float tmax = -1e30f;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    if (__any(tmax > m_run[qi] + defer_raw)) {          // wave-uniform, rare after the first tiles
-      const float m_new = fmaxf(m_run[qi], tmax);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
-      m_run[qi] = m_new;
-      l_run[qi] *= alpha;
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      if (__any(tmax > m_run[qi] + defer_raw)) {          // wave-uniform, rare after the first tiles
+        const float m_new = fmaxf(m_run[qi], tmax);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
+        m_run[qi] = m_new;
+        l_run[qi] *= alpha;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[qi][i][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[qi][i][r] *= alpha;
+      }
     }
     const float mc = m_run[qi] * c;
     float lsum = 0.f;
@@ -429,17 +425,24 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     }
     l_run[qi] += lsum;
   };
-  auto seg_pv = [&](int kt) {                  // O^T += V^T P^T of tile kt (16 MFMAs)
+  auto seg_pv = [&](int kt) __attribute__((always_inline)) {                  // O^T += V^T P^T of tile kt (16 MFMAs)
     const int buf = kt & 1;
+    // V^T fragments straight from the row-major tile with the transposing LDS read (ds_read_b64_tr_b16): within a
+    // 16-lane group, lane i receives as element j the element (i & 3) of the 8-byte chunk addressed by lane 4j + (i >> 2)
+    // (tools/probes/tr16_probe.hip).  A group addresses the block [4 keys][16 d] -- lane i: key i >> 2, d 4 (i & 3).. --
+    // and gets back column d = i with the 4 keys; MFMA s wants, in k-slots j = 0..7 of lane (d = li, lh), the keys
+    // 16 s + 8 (j >> 2) + 4 lh + (j & 3) (the order P already has): two such reads 8 keys apart.  One base address per
+    // lane, everything else is an immediate offset.  Pitch 192 B: the four key rows of a read land on disjoint quarters
+    // of the 64 banks.
     bf16x8 vf[4][2];                           // S is dead here: all 8 V fragments in flight before the first MFMA
+    const uint16_t* vb = Vs[buf] + (4 * lh + ((lane & 15) >> 2)) * VROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const uint16_t* vp = Vt[buf] + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
-        const uint2 v0 = *(const uint2*)(vp);
-        const uint2 v1 = *(const uint2*)(vp + 8);
-        vf[s][i] = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vb + 16 * s * VROW + 32 * i));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vb + (16 * s + 8) * VROW + 32 * i));
+        vf[s][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -447,10 +450,22 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int qi = 0; qi < QP; ++qi) o[qi][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s][i], pf[qi][s], o[qi][i], 0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);    // the V fragments are two 8-byte reads each (compiled to 8 ds_read2_b64)
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);    // the V fragments are two 8-byte transposing reads each
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
   };
 
+  // one optimistic pass; a second, exact one only if a row sum overflowed (see seg_softmax).  Two instantiations of the
+  // tile loop rather than a loop around it: the restart edge cost 34 spilled registers.
+  auto pass = [&](auto ex) __attribute__((always_inline)) -> bool {
+  constexpr bool exact = decltype(ex)::value;
+#pragma unroll
+  for (int qi = 0; qi < QP; ++qi) {
+    m_run[qi] = -1e30f; l_run[qi] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qi][i][r] = 0.f;
+  }
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -465,12 +480,14 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     for (int kt = 0; kt < n_tiles; ++kt) {
       seg_qk(kt);                             // phase 0
       ATT8_BAR(0);
-      seg_softmax(kt, 0);                     // phase 1
+      seg_softmax(kt, 0, exact);                     // phase 1
       ATT8_BAR(1);
-      seg_softmax(kt, 1);                     // phase 2
+      seg_softmax(kt, 1, exact);                     // phase 2
       ATT8_BAR(2);
       seg_pv(kt);                             // phase 3
+      stamp_sub(8);
       if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
+      stamp_sub(9);
       if (kt + 2 < n_tiles) load_tile(kt + 2);
       ATT8_BAR(3);
     }
@@ -483,28 +500,37 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
       if (1 < n_tiles) store_tile(1);
       if (2 < n_tiles) load_tile(2);
       raw_barrier();
-      seg_softmax(0, 0);                      // phase 3
+      seg_softmax(0, 0, exact);                      // phase 3
       raw_barrier();
     }
     if (PROF) pt = __builtin_readcyclecounter();
     for (int kt = 1; kt < n_tiles; ++kt) {
-      seg_softmax(kt - 1, 1);                 // phase 0
+      seg_softmax(kt - 1, 1, exact);                 // phase 0
       ATT8_BAR(0);
       seg_pv(kt - 1);                         // phase 1
       ATT8_BAR(1);
       seg_qk(kt);                             // phase 2
+      stamp_sub(8);
       if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
+      stamp_sub(9);
       if (kt + 2 < n_tiles) load_tile(kt + 2);
       ATT8_BAR(2);
-      seg_softmax(kt, 0);                     // phase 3
+      seg_softmax(kt, 0, exact);                     // phase 3
       ATT8_BAR(3);
     }
-    seg_softmax(n_tiles - 1, 1);              // drain round
+    seg_softmax(n_tiles - 1, 1, exact);              // drain round
     raw_barrier();
     seg_pv(n_tiles - 1);
   }
+  bool bad = false;
+#pragma unroll
+  for (int qi = 0; qi < QP; ++qi) bad = bad || !(l_run[qi] < 1e30f);      // inf / NaN / implausibly large
+  return bad;
+  };
+  // (__syncthreads_or is also the barrier that lets the second pass overwrite the last tiles in LDS)
+  if ((exact_only & 1) || __syncthreads_or(pass(std::false_type{}))) pass(std::true_type{});
   if (PROF && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
-    for (int i = 0; i < 8; ++i) prof[(wave >> 2) * 8 + i] = pacc[i];
+    for (int i = 0; i < 10; ++i) prof[(wave >> 2) * 10 + i] = pacc[i];
 
 #pragma unroll
   for (int qi = 0; qi < QP; ++qi) {
@@ -548,32 +574,35 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
   GIMS_CHECK_ARG((ld_out % 4) == 0, "gims_attention: ld_out must be a multiple of 4");
   const int n_groups = n_heads * n_problems;
   // 64 queries per wave (K/V fragments and barriers shared by two query blocks) when that still fills the chip
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("GIMS_ATTN_QP"); force = e ? atoi(e) : 0; }
+  // (environment read per call, not cached: the tests switch kernels with it)
+  int force = 0;
+  { const char* e = getenv("GIMS_ATTN_QP"); force = e ? atoi(e) : 0; }
   const int blocks2 = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB);
   const bool two = force == 2 || (force != 1 && blocks2 >= 512);
   const int n_qt8 = cdiv(max_n_q, 512);
   const bool eight = force == 8 || (force == 0 && 8 * cdiv(n_groups, 8) * n_qt8 >= 256);   // 8-wave workgroups of 512 queries
   if (eight) {
+    int exact_only = 0;                         // GIMS_ATTN_EXACT=1: running-maximum softmax only (no optimistic pass)
+    { const char* e = getenv("GIMS_ATTN_EXACT"); exact_only = e ? atoi(e) : 0; }
     static int prof = -1;
     if (prof < 0) { const char* e = getenv("GIMS_ATTN_PROF"); prof = e ? atoi(e) : 0; }
     if (prof) {                                 // diagnostics only: synchronous, prints the phase anatomy of workgroup 0
       static unsigned long long* dprof = nullptr;
-      if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 16 * sizeof(unsigned long long)));
+      if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 20 * sizeof(unsigned long long)));
       hipLaunchKernelGGL(attention8_bf16_kernel<true>, dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
-                         q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof);
+                         q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only);
       GIMS_HIP(hipStreamSynchronize((hipStream_t)stream));
-      unsigned long long h[16];
+      unsigned long long h[20];
       GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
       const char* nm[2][4] = {{"QK", "softmax0", "softmax1", "PV+store+load"}, {"softmax1", "PV", "QK+store+load", "softmax0"}};
       for (int g = 0; g < 2; ++g) {
         fprintf(stderr, "[attention8 group %c] cycles over the whole tile loop, work/wait per phase:", 'A' + g);
-        for (int ph = 0; ph < 4; ++ph) fprintf(stderr, "  %s %llu/%llu;", nm[g][ph], h[g * 8 + 2 * ph], h[g * 8 + 2 * ph + 1]);
-        fprintf(stderr, "\n");
+        for (int ph = 0; ph < 4; ++ph) fprintf(stderr, "  %s %llu/%llu;", nm[g][ph], h[g * 10 + 2 * ph], h[g * 10 + 2 * ph + 1]);
+        fprintf(stderr, "  [staging phase: matrix segment %llu, store_tile %llu, rest = load_tile]\n", h[g * 10 + 8], h[g * 10 + 9]);
       }
     } else {
       hipLaunchKernelGGL(attention8_bf16_kernel<false>, dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
-                         q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr);
+                         q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only);
     }
   } else if (two) {
     const int n_qt = cdiv(max_n_q, 2 * QB);

@@ -171,11 +171,15 @@ def _attn_ref(q, k, v):
     return np.einsum("hqk,khd->qhd", p, v)
 
 
+@pytest.mark.parametrize("kernel", ["auto", "8", "8exact"])     # launch-size heuristic / 8-wave kernel forced / its exact-only mode
 @pytest.mark.parametrize("sizes,sharp", [([(64, 64)], 1.0), ([(200, 333), (333, 200)], 1.0), ([(1, 5), (129, 64), (1000, 777)], 1.0),
                                          ([(256, 256)], 6.0)])
-def test_attention(hip, sizes, sharp):
+def test_attention(hip, monkeypatch, sizes, sharp, kernel):
     """bf16 flash attention vs float64 softmax attention on the SAME bf16-rounded Q/K/V.
     Tolerance 1.5e-2 of the value scale: P is rounded to bf16 (2^-9 relative) before the PV product."""
+    if kernel != "auto":
+        monkeypatch.setenv("GIMS_ATTN_QP", "8")
+        monkeypatch.setenv("GIMS_ATTN_EXACT", "1" if kernel == "8exact" else "0")
     r = _rng(len(sizes) * 100 + sizes[0][0])
     rows = sum(a + b for a, b in sizes)
     qkv = (r.normal(size=(rows, 768)) * np.r_[np.full(512, sharp), np.ones(256)]).astype(np.float32)
@@ -206,8 +210,12 @@ def test_attention(hip, sizes, sharp):
         assert (np.abs(rec[qo:qo + nq] - o[qo:qo + nq]) <= np.abs(o[qo:qo + nq]) * 2.0 ** -15 + 1e-30).all()
 
 
-def test_attention_online_rescale(hip):
+@pytest.mark.parametrize("kernel", ["auto", "8", "8exact"])
+def test_attention_online_rescale(hip, monkeypatch, kernel):
     """Force the running max to jump at a later key tile (guide rule: the rare rescale branch needs its own test)."""
+    if kernel != "auto":
+        monkeypatch.setenv("GIMS_ATTN_QP", "8")
+        monkeypatch.setenv("GIMS_ATTN_EXACT", "1" if kernel == "8exact" else "0")
     r = _rng(5)
     n = 300
     qkv = r.normal(size=(n, 768)).astype(np.float32) * 0.5
@@ -219,6 +227,30 @@ def test_attention_online_rescale(hip):
     hip.attention(qb.cuda(), torch.tensor([[0, n, 0, n]], dtype=torch.int32, device="cuda"), n, 4, out)
     ref = _attn_ref(f[:, :256].reshape(n, 4, 64), f[:, 256:512].reshape(n, 4, 64), f[:, 512:].reshape(n, 4, 64)).reshape(n, 256)
     assert np.abs(out.cpu().numpy() - ref).max() < 1.5e-2
+
+
+@pytest.mark.parametrize("kernel", ["8", "8exact"])
+def test_attention_optimistic_overflow_falls_back(hip, monkeypatch, kernel):
+    """The 8-wave kernel's optimistic pass references every exponential to the row maximum of the FIRST key tile.  Scores
+    more than ~100 octaves above it overflow the row sum; the workgroup must notice and redo its tiles with the running
+    maximum.  Queries 0-39 (head 0) see first-tile scores of 0 and a score of 80 * 64 / 8 = 640 at key 700."""
+    monkeypatch.setenv("GIMS_ATTN_QP", "8")
+    monkeypatch.setenv("GIMS_ATTN_EXACT", "1" if kernel == "8exact" else "0")
+    r = _rng(11)
+    n = 1100
+    qkv = r.normal(size=(n, 768)).astype(np.float32) * 0.5
+    qkv[:40, 0:64] = 10.0                       # queries 0..39, head 0
+    qkv[:64, 256:320] = 0.0                     # first key tile: scores 0 for everyone in head 0
+    qkv[700, 256:320] = 8.0                     # one key far above: 10 * 8 * 64 / 8 = 640 (923 octaves)
+    qb = torch.from_numpy(qkv).to(torch.bfloat16)
+    f = qb.float().numpy().astype(np.float64)
+    out = torch.full((n, 256), float("nan"), dtype=torch.float32, device="cuda")
+    hip.attention(qb.cuda(), torch.tensor([[0, n, 0, n]], dtype=torch.int32, device="cuda"), n, 4, out)
+    ref = _attn_ref(f[:, :256].reshape(n, 4, 64), f[:, 256:512].reshape(n, 4, 64), f[:, 512:].reshape(n, 4, 64)).reshape(n, 256)
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all()
+    assert np.abs(o - ref).max() < 1.5e-2
+    np.testing.assert_allclose(o[:40, :64], np.broadcast_to(f[700, 512:576], (40, 64)), atol=5e-3)   # one-hot rows: V[700]
 
 
 # --------------------------------------------------------------------------------------------- sinkhorn + selection
