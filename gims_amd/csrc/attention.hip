@@ -41,7 +41,7 @@ template <int QP>   // 32-query blocks per wave: 1 (32 queries/wave, 128/workgro
 __global__ __launch_bounds__(256) void attention_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
-    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split) {
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KB * DH];      // double-buffered: one barrier per key tile
   __shared__ __attribute__((aligned(16))) uint16_t Vt[2][DH * VT_LD];
   constexpr int QWV = QW * QP;            // queries per wave
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[qi][i][r] = 0.f;
-  const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+  // c = 1/sqrt(64) * log2(e), or 1 when the caller folded that factor into Q (GIMS_ATTN_Q_PRESCALED)
   // Deferred running max (rescale threshold): the accumulator is rescaled only when some row's tile max
   // exceeds its reference max by more than 2^DEFER in probability units; until then P is bounded by 2^DEFER
   // instead of 1, which bf16 (relative precision) and the f32 accumulators tolerate unchanged.
@@ -265,13 +265,14 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 // K/V tiles are shared by 512 queries (half the staging traffic per query of the 4-wave kernel).
 constexpr int ATT8_WAVES = 8;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool PROF>
+template <bool PROF, bool NOFMA>     // NOFMA: Q carries the softmax scale (c == 1): the optimistic pass is P = exp2(S), reference 0
 __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
     int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, unsigned long long* prof,
-    int exact_only) {
+    int exact_only, float c) {
   // diagnostics (GIMS_ATTN_PROF=1): cycles of wave 0 (group A) and wave 4 (group B) of workgroup 0 per phase, split into
   // work (phase start -> barrier reached) and wait (inside the barrier)
   unsigned long long pt = 0, pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   const int head = group % n_heads;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool groupB = wave >= 4;
+  const bool groupB = wave >= 4 && !(exact_only & 16);      // probe bit 16: every wave runs stream A (lockstep, no phase offset)
   const int li = lane & 31, lh = lane >> 5;
 
   bf16x8 qf[QP][4];
@@ -321,7 +322,6 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   // were issued a moment earlier (measured: ~1100 of the 1575 cycles of that phase)
   __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) only
   f32x16 o[QP][2];
-  const float c = 0.125f * 1.4426950408889634f;
   constexpr float DEFER = 5.0f;
   const float defer_raw = DEFER / c;
   float m_run[QP], l_run[QP];
@@ -385,7 +385,10 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     // block and tile are a fifth of the VALU work that bounds this kernel): later scores above the reference just give
     // p > 1.  Only a score more than ~100 octaves above it could overflow; the row sums are checked after the loop and the
     // workgroup then repeats its tiles in the exact mode (running maximum, deferred rescale).
-    if (exact || kt == 0) {
+    // With the scale folded into Q (NOFMA) the optimistic pass needs no reference at all: P = exp2(S) as the MFMA left it
+    // (row sums outside [1e-30, 1e30] send the workgroup to the exact pass) -- 64 fewer VALU per wave and tile again.
+    const bool track = exact || (!NOFMA && kt == 0);
+    if (track) {
       float tmax = -1e30f;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
@@ -404,15 +407,15 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
       }
     }
     const float mc = m_run[qi] * c;
-    float lsum = 0.f;
+    f32x2 lsum2 = {0.f, 0.f};                   // packed adds: one VALU issue per score pair
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       float pv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[qi][b][r], c, -mc));
-        lsum += pv[r];
-      }
+      for (int r = 0; r < 16; ++r)
+        pv[r] = (NOFMA && !exact) ? __builtin_amdgcn_exp2f(sacc[qi][b][r]) : __builtin_amdgcn_exp2f(fmaf(sacc[qi][b][r], c, -mc));
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) lsum2 += f32x2{pv[r], pv[r + 1]};
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
         uint4 pk;
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
         pf[qi][2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
       }
     }
+    const float lsum = lsum2.x + lsum2.y;
     l_run[qi] += lsum;
   };
   auto seg_pv = [&](int kt) __attribute__((always_inline)) {                  // O^T += V^T P^T of tile kt (16 MFMAs)
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   constexpr bool exact = decltype(ex)::value;
 #pragma unroll
   for (int qi = 0; qi < QP; ++qi) {
-    m_run[qi] = -1e30f; l_run[qi] = 0.f;
+    m_run[qi] = (NOFMA && !exact) ? 0.f : -1e30f; l_run[qi] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   }
   bool bad = false;
 #pragma unroll
-  for (int qi = 0; qi < QP; ++qi) bad = bad || !(l_run[qi] < 1e30f);      // inf / NaN / implausibly large
+  for (int qi = 0; qi < QP; ++qi) bad = bad || !(l_run[qi] < 1e30f) || (NOFMA && !(l_run[qi] > 1e-30f));      // inf / NaN / implausible
   return bad;
   };
   // (__syncthreads_or is also the barrier that lets the second pass overwrite the last tiles in LDS)
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
 extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
                               const gims_attn_problem* problems, int32_t n_problems, int32_t max_n_q,
                               int32_t n_heads, float* out, int64_t ld_out, uint16_t* out_hi, uint16_t* out_lo,
-                              int64_t ld_split, void* stream) {
+                              int64_t ld_split, int32_t flags, void* stream) {
   using namespace gims;
   GIMS_CHECK_ARG(qkv && problems && (out || out_hi), "gims_attention: null pointer");
   GIMS_CHECK_ARG((out_hi == nullptr) == (out_lo == nullptr) && (ld_split % 4) == 0, "gims_attention: out_hi/out_lo come together, ld_split %% 4 == 0");
@@ -573,6 +577,8 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
                  "gims_attention: qkv ld / column offsets must be multiples of 8 (16-byte loads)");
   GIMS_CHECK_ARG((ld_out % 4) == 0, "gims_attention: ld_out must be a multiple of 4");
   const int n_groups = n_heads * n_problems;
+  const bool prescaled = (flags & GIMS_ATTN_Q_PRESCALED) != 0;
+  const float c = prescaled ? 1.f : 0.125f * 1.4426950408889634f;      // 1/sqrt(64) * log2(e)
   // 64 queries per wave (K/V fragments and barriers shared by two query blocks) when that still fills the chip
   // (environment read per call, not cached: the tests switch kernels with it)
   int force = 0;
@@ -589,8 +595,12 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
     if (prof) {                                 // diagnostics only: synchronous, prints the phase anatomy of workgroup 0
       static unsigned long long* dprof = nullptr;
       if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 20 * sizeof(unsigned long long)));
-      hipLaunchKernelGGL(attention8_bf16_kernel<true>, dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
-                         q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only);
+      if (prescaled)
+        hipLaunchKernelGGL((attention8_bf16_kernel<true, true>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
+      else
+        hipLaunchKernelGGL((attention8_bf16_kernel<true, false>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
       GIMS_HIP(hipStreamSynchronize((hipStream_t)stream));
       unsigned long long h[20];
       GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
@@ -601,17 +611,21 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
         fprintf(stderr, "  [staging phase: matrix segment %llu, store_tile %llu, rest = load_tile]\n", h[g * 10 + 8], h[g * 10 + 9]);
       }
     } else {
-      hipLaunchKernelGGL(attention8_bf16_kernel<false>, dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
-                         q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only);
+      if (prescaled)
+        hipLaunchKernelGGL((attention8_bf16_kernel<false, true>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c);
+      else
+        hipLaunchKernelGGL((attention8_bf16_kernel<false, false>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c);
     }
   } else if (two) {
     const int n_qt = cdiv(max_n_q, 2 * QB);
     hipLaunchKernelGGL(attention_bf16_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split);
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
   } else {
     const int n_qt = cdiv(max_n_q, QB);
     hipLaunchKernelGGL(attention_bf16_kernel<1>, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split);
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
   }
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;

@@ -215,6 +215,10 @@ class GMatcher(nn.Module):
                 w0m = w0[:, D:].double()
                 w0f = torch.cat([w0[:, :D].double(), w0m @ wm.double()], 1).float()
                 b0f = (b0.double() + w0m @ sd[p + "attn.merge.bias"].double()).float()
+            # the softmax scale log2(e)/sqrt(dh) rides in the query projection (exact in f64, one rounding to f32): the
+            # attention kernel then exponentiates the MFMA result as it is (hip.attention(..., q_prescaled=True))
+            wq = (wq.double() * hip.ATTN_Q_SCALE).float()
+            bq = (bq.double() * hip.ATTN_Q_SCALE).float()
             P["layers"].append({
                 "mlp0_fused": lin(w0f, b0f, True) if w0f is not None else None,
                 "qkv": lin(torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0), True),
@@ -433,7 +437,7 @@ class GMatcher(nn.Module):
                 with St("qkv"):
                     self._lin(L["qkv"], dpl, out_bf16=qkv)
                 with St("attn_cross" if L["cross"] else "attn_self"):
-                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl)
+                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl, q_prescaled=True)
                 with St("mlp"):
                     if ln:        # LayerNorm between the two MLP convs: hidden activations in f32, normalised + split by the norm kernel
                         if hid_ln is None:
@@ -458,7 +462,7 @@ class GMatcher(nn.Module):
                 with St("qkv"):
                     self._lin(L["qkv"], desc, out_bf16=qkv)
                 with St("attn_cross" if L["cross"] else "attn_self"):
-                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D)
+                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D, q_prescaled=True)
                 with St("mlp"):
                     act0 = hip.ACT_NONE if ln else hip.ACT_RELU
                     if L["mlp0_fused"] is not None:

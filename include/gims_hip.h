@@ -118,13 +118,16 @@ int gims_split_spl32(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, 
  * out: f32 [rows][ld_out], head-blocked columns h*64 + d.       dh = 64, heads = n_heads.
  * out_hi/out_lo: the same result in the SPL32 split-bf16 layout (out_lo = out_hi + 32, ld_split = pitch >= 512) for
  * the pre-split linear that consumes the message.
+ * flags: GIMS_ATTN_Q_PRESCALED = the caller already multiplied Q by log2(e)/sqrt(dh) (e.g. folded into the rows of the
+ * query projection): the kernel then computes softmax as exp2(Q K^T) / sum, which saves it one multiply-add per score.
  */
+#define GIMS_ATTN_Q_PRESCALED 1
 typedef struct gims_attn_problem { int32_t q_off, n_q, kv_off, n_kv; } gims_attn_problem;
 
 int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
                    const gims_attn_problem* problems /* device */, int32_t n_problems, int32_t max_n_q,
                    int32_t n_heads, float* out /* may be NULL */, int64_t ld_out,
-                   uint16_t* out_hi /* may be NULL */, uint16_t* out_lo, int64_t ld_split, void* stream);
+                   uint16_t* out_hi /* may be NULL */, uint16_t* out_lo, int64_t ld_split, int32_t flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Keypoint encoder front end: normalize_keypoints (gmatcher.py:26-33, with the reference's NHWC-as-NCHW

@@ -171,10 +171,11 @@ def _attn_ref(q, k, v):
     return np.einsum("hqk,khd->qhd", p, v)
 
 
+@pytest.mark.parametrize("prescaled", [False, True])           # Q as is / Q carrying log2(e)/sqrt(dh) (GIMS_ATTN_Q_PRESCALED)
 @pytest.mark.parametrize("kernel", ["auto", "8", "8exact"])     # launch-size heuristic / 8-wave kernel forced / its exact-only mode
 @pytest.mark.parametrize("sizes,sharp", [([(64, 64)], 1.0), ([(200, 333), (333, 200)], 1.0), ([(1, 5), (129, 64), (1000, 777)], 1.0),
                                          ([(256, 256)], 6.0)])
-def test_attention(hip, monkeypatch, sizes, sharp, kernel):
+def test_attention(hip, monkeypatch, sizes, sharp, kernel, prescaled):
     """bf16 flash attention vs float64 softmax attention on the SAME bf16-rounded Q/K/V.
     Tolerance 1.5e-2 of the value scale: P is rounded to bf16 (2^-9 relative) before the PV product."""
     if kernel != "auto":
@@ -183,14 +184,18 @@ def test_attention(hip, monkeypatch, sizes, sharp, kernel):
     r = _rng(len(sizes) * 100 + sizes[0][0])
     rows = sum(a + b for a, b in sizes)
     qkv = (r.normal(size=(rows, 768)) * np.r_[np.full(512, sharp), np.ones(256)]).astype(np.float32)
+    if prescaled:
+        qkv[:, :256] *= np.float32(hip.ATTN_Q_SCALE)
     qkv_b = torch.from_numpy(qkv).to(torch.bfloat16)
     f = qkv_b.float().numpy().astype(np.float64)
+    if prescaled:
+        f[:, :256] /= hip.ATTN_Q_SCALE             # the reference below applies the scale itself
     probs, off = [], 0
     for nq, nk in sizes:
         probs.append((off, nq, off + nq, nk))
         off += nq + nk
     out = torch.full((rows, 256), float("nan"), dtype=torch.float32, device="cuda")
-    hip.attention(qkv_b.cuda(), torch.tensor(probs, dtype=torch.int32, device="cuda"), max(s[0] for s in sizes), 4, out)
+    hip.attention(qkv_b.cuda(), torch.tensor(probs, dtype=torch.int32, device="cuda"), max(s[0] for s in sizes), 4, out, q_prescaled=prescaled)
     o = out.cpu().numpy()
     for qo, nq, ko, nk in probs:
         q = f[qo:qo + nq, 0:256].reshape(nq, 4, 64)
@@ -203,7 +208,8 @@ def test_attention(hip, monkeypatch, sizes, sharp, kernel):
         assert np.isnan(o[ko:ko + nk]).all()      # rows that are not queries are untouched
     # split-plane output carries the same values
     osp = torch.zeros((rows, 512), dtype=torch.bfloat16, device="cuda")
-    hip.attention(qkv_b.cuda(), torch.tensor(probs, dtype=torch.int32, device="cuda"), max(s[0] for s in sizes), 4, None, out_split=osp)
+    hip.attention(qkv_b.cuda(), torch.tensor(probs, dtype=torch.int32, device="cuda"), max(s[0] for s in sizes), 4, None, out_split=osp,
+                  q_prescaled=prescaled)
     hi, lo = hip.spl32_planes(osp)
     rec = hi.float().cpu().numpy().astype(np.float64) + lo.float().cpu().numpy()
     for qo, nq, ko, nk in probs:
@@ -229,8 +235,9 @@ def test_attention_online_rescale(hip, monkeypatch, kernel):
     assert np.abs(out.cpu().numpy() - ref).max() < 1.5e-2
 
 
+@pytest.mark.parametrize("prescaled", [False, True])
 @pytest.mark.parametrize("kernel", ["8", "8exact"])
-def test_attention_optimistic_overflow_falls_back(hip, monkeypatch, kernel):
+def test_attention_optimistic_overflow_falls_back(hip, monkeypatch, kernel, prescaled):
     """The 8-wave kernel's optimistic pass references every exponential to the row maximum of the FIRST key tile.  Scores
     more than ~100 octaves above it overflow the row sum; the workgroup must notice and redo its tiles with the running
     maximum.  Queries 0-39 (head 0) see first-tile scores of 0 and a score of 80 * 64 / 8 = 640 at key 700."""
@@ -242,10 +249,16 @@ def test_attention_optimistic_overflow_falls_back(hip, monkeypatch, kernel):
     qkv[:40, 0:64] = 10.0                       # queries 0..39, head 0
     qkv[:64, 256:320] = 0.0                     # first key tile: scores 0 for everyone in head 0
     qkv[700, 256:320] = 8.0                     # one key far above: 10 * 8 * 64 / 8 = 640 (923 octaves)
+    qkv[40:80, 64:128] = -10.0                  # queries 40..79, head 1: every score hugely NEGATIVE except ...
+    qkv[:, 320:384] = 8.0                       # (all keys of head 1 equal: uniform attention; exp2 underflows without a reference)
+    if prescaled:
+        qkv[:, :256] *= np.float32(hip.ATTN_Q_SCALE)
     qb = torch.from_numpy(qkv).to(torch.bfloat16)
     f = qb.float().numpy().astype(np.float64)
+    if prescaled:
+        f[:, :256] /= hip.ATTN_Q_SCALE
     out = torch.full((n, 256), float("nan"), dtype=torch.float32, device="cuda")
-    hip.attention(qb.cuda(), torch.tensor([[0, n, 0, n]], dtype=torch.int32, device="cuda"), n, 4, out)
+    hip.attention(qb.cuda(), torch.tensor([[0, n, 0, n]], dtype=torch.int32, device="cuda"), n, 4, out, q_prescaled=prescaled)
     ref = _attn_ref(f[:, :256].reshape(n, 4, 64), f[:, 256:512].reshape(n, 4, 64), f[:, 512:].reshape(n, 4, 64)).reshape(n, 256)
     o = out.cpu().numpy()
     assert np.isfinite(o).all()
