@@ -305,9 +305,22 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   const int head = group % n_heads;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool groupB = wave >= 4 && !(exact_only & 16);      // probe bit 16: every wave runs stream A (lockstep, no phase offset)
   const int li = lane & 31, lh = lane >> 5;
 
+  // staging: K and V tiles are 64 rows x 8 chunks of 16 bytes = 512 chunks each, one of each per thread, same (row, chunk):
+  // eight lanes cover one 128-byte line of K and one of V, and the two addresses differ by a constant
+  uint4 rk, rv;
+  const int n_tiles = (pr.n_kv + KB - 1) / KB;
+  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+    const int kbase = kt * KB;
+    const int row = t >> 3, ch = t & 7;
+    int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+    const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + head * DH + 8 * ch;
+    rk = *(const uint4*)(src + k_col);
+    rv = *(const uint4*)(src + v_col);
+  };
+  load_tile(0);                                // in flight together with the Q fragments below
+  bool tile0_requested = true;
   bf16x8 qf[QP][4];
 #pragma unroll
   for (int qi = 0; qi < QP; ++qi) {
@@ -326,18 +339,6 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   const float defer_raw = DEFER / c;
   float m_run[QP], l_run[QP];
 
-  // staging: K and V tiles are 64 rows x 8 chunks of 16 bytes = 512 chunks each, one of each per thread, same (row, chunk):
-  // eight lanes cover one 128-byte line of K and one of V, and the two addresses differ by a constant
-  uint4 rk, rv;
-  const int n_tiles = (pr.n_kv + KB - 1) / KB;
-  auto load_tile = [&](int kt) __attribute__((always_inline)) {
-    const int kbase = kt * KB;
-    const int row = t >> 3, ch = t & 7;
-    int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-    const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + head * DH + 8 * ch;
-    rk = *(const uint4*)(src + k_col);
-    rv = *(const uint4*)(src + v_col);
-  };
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
     *(uint4*)(Ks[buf] + k_off(t >> 3, t & 7)) = rk;
     *(uint4*)(Vs[buf] + (t >> 3) * VROW + 8 * (t & 7)) = rv;
@@ -470,61 +471,29 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[qi][i][r] = 0.f;
   }
-  load_tile(0);
+  if (!tile0_requested) load_tile(0);           // (second, exact pass)
+  tile0_requested = false;
   store_tile(0);
-  __syncthreads();
   if (1 < n_tiles) load_tile(1);
-  // Two straight-line instruction streams (one per group, wave-uniform branch) with the SAME number of barriers:
-  // 4 per key tile + 1 in the drain round.  Group B trails group A by two phases.
-  // Staging: every thread stores its pieces of tile t+1 at the end of its group's SHORT phase of tile t (after the 16 MFMAs:
-  // group A in phase 3, group B in phase 2 -- the buffer's last readers finished in phase 1) and immediately requests its
-  // pieces of tile t+2, so the global loads have four phases to land and the long (softmax) phases carry no staging.
+  __syncthreads();
+  // One stream for all eight waves, ONE barrier per key tile (the double-buffered tile t+1 is stored after this wave's last
+  // read of tile t-1 -- the previous barrier -- and read after the next one).  The two waves of a SIMD drift freely inside a
+  // tile; the earlier design kept them half a tile apart with four barriers ("A multiplies while B exponentiates"), which
+  // the overlap probes showed to buy nothing (section 4.2 of DESIGN.md) and this order beats by 9 %.
   if (PROF) pt = __builtin_readcyclecounter();
-  if (!groupB) {
-    for (int kt = 0; kt < n_tiles; ++kt) {
-      seg_qk(kt);                             // phase 0
-      ATT8_BAR(0);
-      seg_softmax(kt, 0, exact);                     // phase 1
-      ATT8_BAR(1);
-      seg_softmax(kt, 1, exact);                     // phase 2
-      ATT8_BAR(2);
-      seg_pv(kt);                             // phase 3
-      stamp_sub(8);
-      if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
-      stamp_sub(9);
-      if (kt + 2 < n_tiles) load_tile(kt + 2);
-      ATT8_BAR(3);
-    }
-    raw_barrier();                            // drain round: group B finishes its last tile
-  } else {
-    {                                         // tile 0: phases 0 and 1 have nothing to trail yet
-      raw_barrier();
-      raw_barrier();
-      seg_qk(0);                              // phase 2
-      if (1 < n_tiles) store_tile(1);
-      if (2 < n_tiles) load_tile(2);
-      raw_barrier();
-      seg_softmax(0, 0, exact);                      // phase 3
-      raw_barrier();
-    }
-    if (PROF) pt = __builtin_readcyclecounter();
-    for (int kt = 1; kt < n_tiles; ++kt) {
-      seg_softmax(kt - 1, 1, exact);                 // phase 0
-      ATT8_BAR(0);
-      seg_pv(kt - 1);                         // phase 1
-      ATT8_BAR(1);
-      seg_qk(kt);                             // phase 2
-      stamp_sub(8);
-      if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
-      stamp_sub(9);
-      if (kt + 2 < n_tiles) load_tile(kt + 2);
-      ATT8_BAR(2);
-      seg_softmax(kt, 0, exact);                     // phase 3
-      ATT8_BAR(3);
-    }
-    seg_softmax(n_tiles - 1, 1, exact);              // drain round
-    raw_barrier();
-    seg_pv(n_tiles - 1);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    seg_qk(kt);
+    stamp_work(0);
+    seg_softmax(kt, 0, exact);
+    stamp_work(1);
+    seg_softmax(kt, 1, exact);
+    stamp_work(2);
+    seg_pv(kt);
+    stamp_sub(8);
+    if (kt + 1 < n_tiles) store_tile((kt + 1) & 1);
+    stamp_sub(9);
+    if (kt + 2 < n_tiles) load_tile(kt + 2);
+    ATT8_BAR(3);
   }
   bool bad = false;
 #pragma unroll
@@ -604,12 +573,10 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
       GIMS_HIP(hipStreamSynchronize((hipStream_t)stream));
       unsigned long long h[20];
       GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
-      const char* nm[2][4] = {{"QK", "softmax0", "softmax1", "PV+store+load"}, {"softmax1", "PV", "QK+store+load", "softmax0"}};
-      for (int g = 0; g < 2; ++g) {
-        fprintf(stderr, "[attention8 group %c] cycles over the whole tile loop, work/wait per phase:", 'A' + g);
-        for (int ph = 0; ph < 4; ++ph) fprintf(stderr, "  %s %llu/%llu;", nm[g][ph], h[g * 10 + 2 * ph], h[g * 10 + 2 * ph + 1]);
-        fprintf(stderr, "  [staging phase: matrix segment %llu, store_tile %llu, rest = load_tile]\n", h[g * 10 + 8], h[g * 10 + 9]);
-      }
+      for (int g = 0; g < 2; ++g)
+        fprintf(stderr, "[attention8 wave %d] cycles over the whole tile loop: QK %llu, softmax0 %llu, softmax1 %llu, PV %llu, store_tile %llu, "
+                "load_tile %llu, barrier wait %llu\n", 4 * g, h[g * 10 + 0], h[g * 10 + 2], h[g * 10 + 4], h[g * 10 + 8], h[g * 10 + 9], h[g * 10 + 6],
+                h[g * 10 + 7]);
     } else {
       if (prescaled)
         hipLaunchKernelGGL((attention8_bf16_kernel<false, true>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
