@@ -505,12 +505,43 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   if (PROF && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
     for (int i = 0; i < 10; ++i) prof[(wave >> 2) * 10 + i] = pacc[i];
 
+  // ---- normalise and store.  In the MFMA layout a lane owns 4 consecutive channels of ONE query, so direct stores scatter
+  // 8-byte pieces over 32 rows per instruction (store-issue-bound: ~10k cycles per workgroup, 15 % of the kernel at 1024
+  // keys).  For the split-bf16 output -- a head's 64 channels are 256 contiguous bytes of a row there, [32 hi|32 lo] x 2 --
+  // each wave transposes one 32-query block at a time through a private LDS slice (264-byte pitch: the 8-byte writes of 16
+  // lanes hit 32 distinct banks) and stores whole rows, 16 bytes per lane, 4 rows per instruction.
+  __shared__ __attribute__((aligned(16))) uint16_t Es[ATT8_WAVES][32 * 132];
+  const bool row_stores = out_hi && !out && out_lo == out_hi + 32;
 #pragma unroll
   for (int qi = 0; qi < QP; ++qi) {
     const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
     const float inv = 1.f / l_tot;
     const int qr = q0 + wave * QWV + qi * QW + li;
-    if (qr < pr.n_q) {
+    if (row_stores) {
+      uint16_t* es = Es[wave];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = make_float4(o[qi][i][4 * g] * inv, o[qi][i][4 * g + 1] * inv, o[qi][i][4 * g + 2] * inv, o[qi][i][4 * g + 3] * inv);
+          const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
+          const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+          const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+          uint16_t* e = es + li * 132 + 64 * i + 8 * g + 4 * lh;          // block i of the row: hi at +0, lo at +32
+          *(uint2*)e = make_uint2(h01, h23);
+          *(uint2*)(e + 32) = make_uint2(l01, l23);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // wave-private slice: no workgroup barrier
+      const int c = lane & 15, rs = lane >> 4;                            // 16-byte chunk of the row, row within the group of 4
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = 4 * it + rs;
+        const uint4 w = *(const uint4*)(es + r * 132 + 8 * c);
+        const int qrow = q0 + wave * QWV + qi * QW + r;
+        if (qrow < pr.n_q) *(uint4*)(out_hi + (int64_t)(pr.q_off + qrow) * ld_split + spl_col(head * DH) + 8 * c) = w;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // read-back done before the next block overwrites
+    } else if (qr < pr.n_q) {
       const int64_t grow = pr.q_off + qr;
       const int col0 = head * DH + 4 * lh;
 #pragma unroll
@@ -540,7 +571,8 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
                               int64_t ld_split, int32_t flags, void* stream) {
   using namespace gims;
   GIMS_CHECK_ARG(qkv && problems && (out || out_hi), "gims_attention: null pointer");
-  GIMS_CHECK_ARG((out_hi == nullptr) == (out_lo == nullptr) && (ld_split % 4) == 0, "gims_attention: out_hi/out_lo come together, ld_split %% 4 == 0");
+  GIMS_CHECK_ARG((out_hi == nullptr) == (out_lo == nullptr) && (ld_split % 8) == 0 && (((uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
+                 "gims_attention: out_hi/out_lo come together, 16-byte aligned, ld_split %% 8 == 0");
   GIMS_CHECK_ARG(n_problems > 0 && max_n_q > 0 && n_heads > 0, "gims_attention: empty launch");
   GIMS_CHECK_ARG((ld % 8) == 0 && (q_col % 8) == 0 && (k_col % 8) == 0 && (v_col % 8) == 0,
                  "gims_attention: qkv ld / column offsets must be multiples of 8 (16-byte loads)");
