@@ -301,7 +301,8 @@ struct X3P {
   __device__ static __forceinline__ int off(int row, int chunk) { return row * 64 + ((chunk ^ swz(row)) << 3); }
 };
 
-template <int TM, int TN, int WM, int WN, int S>
+// HI_ONLY: 1 = GIMS_LINEAR_HI_ONLY (one MFMA pass, hi planes), 2 = GIMS_LINEAR_A1_HI_ONLY (that for the second K segment only)
+template <int TM, int TN, int WM, int WN, int S, int HI_ONLY = 0>
 __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_args p) {
   using T = X3P<TM, TN, WM, WN, S>;
   constexpr int BK = T::BK;
@@ -384,14 +385,16 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
       }
       // term-major order: consecutive MFMAs hit DIFFERENT accumulators (no back-to-back dependent issue); per
       // accumulator the order stays lo*hi, hi*lo, hi*hi (small terms first)
+      if (HI_ONLY == 0 || (HI_ONLY == 2 && kt * BK < p.k0)) {
 #pragma unroll
-      for (int ni = 0; ni < T::NI; ++ni)
+        for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+          for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
 #pragma unroll
-      for (int ni = 0; ni < T::NI; ++ni)
+        for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
+          for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
+      }
 #pragma unroll
       for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
@@ -596,9 +599,17 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       force = e ? atoi(e) : 0;
       const void* fs = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2>;
       const void* fl = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2>;
+      const void* fs1 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2, 1>;
+      const void* fl1 = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2, 1>;
+      const void* fl2 = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2, 2>;
+      const void* fs2 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2, 2>;
       constexpr int ls = TS::LDS_BYTES, ll = TL::LDS_BYTES;
       GIMS_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
       GIMS_HIP(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
+      GIMS_HIP(hipFuncSetAttribute(fs1, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
+      GIMS_HIP(hipFuncSetAttribute(fl1, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
+      GIMS_HIP(hipFuncSetAttribute(fl2, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
+      GIMS_HIP(hipFuncSetAttribute(fs2, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
     }
     const int big_blocks = cdiv(a->m, 256) * cdiv(a->n, 256);
     // the 256-wide tile only when it is not half empty (n = 64 / 128 layers of the keypoint encoder and GraphSAGE)
@@ -630,10 +641,16 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       }
     } else if (big) {
       constexpr size_t lds = TL::LDS_BYTES;
-      hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256)), dim3(512), lds, s, *a);
+      const dim3 g(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256));
+      if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2, 1>), g, dim3(512), lds, s, *a);
+      else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2, 2>), g, dim3(512), lds, s, *a);
+      else hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), g, dim3(512), lds, s, *a);
     } else {
       constexpr size_t lds = TS::LDS_BYTES;
-      hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
+      const dim3 g(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128));
+      if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2, 1>), g, dim3(256), lds, s, *a);
+      else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2, 2>), g, dim3(256), lds, s, *a);
+      else hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2>), g, dim3(256), lds, s, *a);
     }
   } else if (a->precision == GIMS_PREC_F32) {
     hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, s, *a);

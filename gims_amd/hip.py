@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libgims_hip.so")
 
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
 LINEAR_UPPER = 1
+LINEAR_HI_ONLY = 2
+LINEAR_A1_HI_ONLY = 4
 ACT_NONE, ACT_RELU = 0, 1
 
 
@@ -170,7 +172,7 @@ def _dev(t: torch.Tensor, dtype=None):
 
 
 def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
-                precision=PREC_F32, scale=1.0, n=None, spl=False, out_split=None):
+                precision=PREC_F32, scale=1.0, n=None, spl=False, out_split=None, flags=0):
     """Build the C struct.
     spl=False: a0/a1 f32 [m,k*]; w f32 [n,K] (PREC_F32) or bf16 hi plane with w_lo (PREC_BF16X3).
     spl=True : a0/a1/w are SPL32 bf16 buffers [rows, 2*k] (see include/gims_hip.h), precision BF16X3.
@@ -205,7 +207,7 @@ def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None
                       out.stride(0) if out is not None else 0, _p(out_bf16),
                       out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale),
                       _p(a0_lo), _p(a1_lo), _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
-                      out_split.stride(0) if out_split is not None else 0, 0)
+                      out_split.stride(0) if out_split is not None else 0, int(flags))
 
 
 def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):

@@ -89,6 +89,12 @@ typedef struct gims_linear_args {
   int32_t flags;
 } gims_linear_args;
 #define GIMS_LINEAR_UPPER 1
+  /* GIMS_LINEAR_HI_ONLY (pre-split operands): multiply the hi planes only -- a plain bf16 product (2^-9 relative per
+   * operand) at a third of the matrix work, for results that are rounded to bf16 anyway (the Q/K/V projection) */
+#define GIMS_LINEAR_HI_ONLY 2
+  /* GIMS_LINEAR_A1_HI_ONLY: the same for the SECOND A segment (a1, columns k0..k) only -- for an operand that was computed
+   * from bf16 data and carries no information below bf16 precision (the attention message in MLP0) */
+#define GIMS_LINEAR_A1_HI_ONLY 4
 
 int gims_linear(const gims_linear_args* args, void* stream);
 /* Many independent problems in ONE launch (ragged batch: per-pair score matrices, per-image similarity

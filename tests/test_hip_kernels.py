@@ -98,6 +98,27 @@ def test_linear_presplit(hip, m, n, k, k0):
     np.testing.assert_array_equal(ob.cpu().view(torch.int16).numpy(), torch.from_numpy(o).to(torch.bfloat16).view(torch.int16).numpy())
 
 
+@pytest.mark.parametrize("m,n,k", [(300, 768, 256), (4096, 768, 256), (77, 100, 64)])
+def test_linear_presplit_hi_only(hip, m, n, k):
+    """GIMS_LINEAR_HI_ONLY: the pre-split kernel multiplies the hi planes only = a plain bf16 product with f32 accumulation."""
+    r = _rng(m + n)
+    a = r.normal(size=(m, k)).astype(np.float32)
+    w = (r.normal(size=(n, k)) / np.sqrt(k)).astype(np.float32)
+    bias = r.normal(size=n).astype(np.float32)
+    ah = torch.from_numpy(a).to(torch.bfloat16).float().numpy().astype(np.float64)
+    wh = torch.from_numpy(w).to(torch.bfloat16).float().numpy().astype(np.float64)
+    ref = ah @ wh.T + bias
+    A, W = hip.split_spl32(_dev(a)), hip.split_spl32(_dev(w))
+    ob = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    out = hip.linear(A, W, spl=True, bias=_dev(bias), precision=hip.PREC_BF16X3, flags=hip.LINEAR_HI_ONLY, out_bf16=ob,
+                     out=torch.empty((m, n), dtype=torch.float32, device="cuda"))
+    scale_ref = np.abs(ah) @ np.abs(wh).T + np.abs(bias)
+    err = np.abs(out.cpu().numpy() - ref) / scale_ref
+    assert err.max() < 2e-6, f"hi-only product: {err.max():.3e}"           # exact bf16 products, f32 accumulation
+    full = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    assert (np.abs(out.cpu().numpy() - full) / scale_ref).max() < 2.0 ** -7      # and it IS only a bf16 product
+
+
 def test_split_spl3_exact(hip):
     """SPL3 = exact three-way bf16 split: the planes sum back to the f32 value bit for bit (24 significand bits)."""
     r = _rng(5)
