@@ -284,27 +284,31 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 //   128x128, 2x2 waves (64x64 per wave),  64 KiB LDS, 2 workgroups/CU -- small problems (fills the chip sooner);
 //   256x256, 4x2 waves (64x128 per wave), 128 KiB LDS, 1 workgroup/CU -- half the operand bytes per MFMA, used when
 //   the launch still yields at least ~one workgroup per CU.
-template <int TM, int TN, int WM, int WN, int S>
+template <int TM, int TN, int WM, int WN, int S, bool HALF = false>     // HALF: the hi halves of the rows only (64-byte rows)
 struct X3P {
   static constexpr int BK = 32;
   static constexpr int WAVES = WM * WN;
   static constexpr int MI = TM / WM / 32, NI = TN / WN / 32;     // 32x32 tiles per wave
-  static constexpr int A_TILE = TM * 64, W_TILE = TN * 64;       // bf16 elements per stage (128-byte rows)
+  static constexpr int ROWE = HALF ? 32 : 64;                    // bf16 elements per row of a stage (64- / 128-byte rows)
+  static constexpr int RPP = 512 / ROWE;                          // rows per 1 KiB DMA piece (16 / 8)
+  static constexpr int A_TILE = TM * ROWE, W_TILE = TN * ROWE;   // bf16 elements per stage
   static constexpr int STAGE = A_TILE + W_TILE;
-  static constexpr int PA = TM / 8, PW = TN / 8;                 // 1 KiB pieces (8 rows) per operand per stage
+  static constexpr int PA = TM / RPP, PW = TN / RPP;             // 1 KiB pieces per operand per stage
   static constexpr int PIECES = (PA + PW) / WAVES;               // pieces per wave per stage
   static constexpr int EP_PITCH = TN / WN + 4;                    // epilogue transpose slice: 32 rows x EP_PITCH floats per wave
   static constexpr int RING_BYTES = S * STAGE * 2, EP_BYTES = WAVES * 32 * EP_PITCH * 4;
   static constexpr int LDS_BYTES = RING_BYTES > EP_BYTES ? RING_BYTES : EP_BYTES;
   static_assert((PA + PW) % WAVES == 0, "pieces divide evenly over the waves");
-  __device__ static __forceinline__ int swz(int row) { return (row >> 1) & 7; }
-  __device__ static __forceinline__ int off(int row, int chunk) { return row * 64 + ((chunk ^ swz(row)) << 3); }
+  // 16-byte chunk swizzles that make the fragment reads (32 rows x one chunk) conflict-free: 128-byte rows rotate by
+  // row/2 over 8 chunks, 64-byte rows by row/4 over 4 chunks (four consecutive rows already cover the 256-byte bank row)
+  __device__ static __forceinline__ int swz(int row) { return HALF ? (row >> 2) & 3 : (row >> 1) & 7; }
+  __device__ static __forceinline__ int off(int row, int chunk) { return row * ROWE + ((chunk ^ swz(row)) << 3); }
 };
 
 // HI_ONLY: 1 = GIMS_LINEAR_HI_ONLY (one MFMA pass, hi planes), 2 = GIMS_LINEAR_A1_HI_ONLY (that for the second K segment only)
 template <int TM, int TN, int WM, int WN, int S, int HI_ONLY = 0>
 __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_args p) {
-  using T = X3P<TM, TN, WM, WN, S>;
+  using T = X3P<TM, TN, WM, WN, S, HI_ONLY == 1>;
   constexpr int BK = T::BK;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -323,7 +327,8 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
 
   // this wave's LDS-DMA duty: PIECES consecutive 8-row pieces of the stage image [A rows | W rows]
   const int p0 = wave * T::PIECES;
-  const int drow = lane >> 3, dpos = lane & 7;
+  constexpr int CPR = T::ROWE / 8;                         // 16-byte chunks per stage row (8, or 4 for the hi-only rows)
+  const int drow = lane / CPR, dpos = lane % CPR;
   auto issue = [&](int kt) {
     const int k = kt * BK;
     const bool second = k >= p.k0;
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
     for (int i = 0; i < T::PIECES; ++i) {
       const int pp = p0 + i;                               // wave-uniform
       const bool is_a = pp < T::PA;
-      const int row = 8 * (is_a ? pp : pp - T::PA) + drow;
+      const int row = T::RPP * (is_a ? pp : pp - T::PA) + drow;
       int gr = (is_a ? m0 : n0) + row;
       const int rmax = (is_a ? p.m : p.n) - 1;
       gr = gr < rmax ? gr : rmax;
@@ -599,15 +604,18 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       force = e ? atoi(e) : 0;
       const void* fs = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2>;
       const void* fl = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2>;
-      const void* fs1 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2, 1>;
-      const void* fl1 = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2, 1>;
+      const void* fs1 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 4, 1>;
+      const void* fl1 = (const void*)linear_x3p_kernel<256, 256, 4, 2, 4, 1>;
       const void* fl2 = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2, 2>;
       const void* fs2 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2, 2>;
       constexpr int ls = TS::LDS_BYTES, ll = TL::LDS_BYTES;
       GIMS_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
       GIMS_HIP(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
-      GIMS_HIP(hipFuncSetAttribute(fs1, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
-      GIMS_HIP(hipFuncSetAttribute(fl1, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
+      using TSH0 = X3P<128, 128, 2, 2, 4, true>;
+      using TLH0 = X3P<256, 256, 4, 2, 4, true>;
+      constexpr int ls1 = TSH0::LDS_BYTES, ll1 = TLH0::LDS_BYTES;   // hi-only: 4-stage rings of half rows
+      GIMS_HIP(hipFuncSetAttribute(fs1, hipFuncAttributeMaxDynamicSharedMemorySize, ls1));
+      GIMS_HIP(hipFuncSetAttribute(fl1, hipFuncAttributeMaxDynamicSharedMemorySize, ll1));
       GIMS_HIP(hipFuncSetAttribute(fl2, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
       GIMS_HIP(hipFuncSetAttribute(fs2, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
     }
@@ -640,15 +648,17 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
         hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 3>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
       }
     } else if (big) {
-      constexpr size_t lds = TL::LDS_BYTES;
+      using TLH = X3P<256, 256, 4, 2, 4, true>;
+      constexpr size_t lds = TL::LDS_BYTES, lds_h = TLH::LDS_BYTES;
       const dim3 g(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256));
-      if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2, 1>), g, dim3(512), lds, s, *a);
+      if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 4, 1>), g, dim3(512), lds_h, s, *a);
       else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2, 2>), g, dim3(512), lds, s, *a);
       else hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), g, dim3(512), lds, s, *a);
     } else {
-      constexpr size_t lds = TS::LDS_BYTES;
+      using TSH = X3P<128, 128, 2, 2, 4, true>;
+      constexpr size_t lds = TS::LDS_BYTES, lds_h = TSH::LDS_BYTES;
       const dim3 g(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128));
-      if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2, 1>), g, dim3(256), lds, s, *a);
+      if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 4, 1>), g, dim3(256), lds_h, s, *a);
       else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2, 2>), g, dim3(256), lds, s, *a);
       else hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2>), g, dim3(256), lds, s, *a);
     }
