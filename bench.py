@@ -255,8 +255,10 @@ def main():
                         "VALU/transcendental issues (660 cycles) for the online softmax, so the softmax, not the matrix pipe, bounds it "
                         "(DESIGN.md 4.2); `achieved` counts 4*N*M*64 flops per head")
         else:
-            dom_note = ("linear_x3p_kernel issues 3 bf16 MFMA passes per algorithmic product (split-bf16 hi*hi+hi*lo+lo*hi, f32-class accuracy); "
-                        "`achieved` counts ALGORITHMIC flops 2MNK, so its ceiling against the 2.5 PF/s bf16 peak is 1/3")
+            dom_note = ("linear_x3p_kernel issues 3 bf16 MFMA passes per algorithmic product (split-bf16 hi*hi+hi*lo+lo*hi, f32-class accuracy) in "
+                        "the two MLP GEMMs of a layer and 1 pass (plain bf16, GIMS_LINEAR_HI_ONLY) in its Q/K/V projection, whose result is rounded "
+                        "to bf16 for the attention kernel anyway; `achieved` counts ALGORITHMIC flops 2MNK averaged over the three launches per "
+                        "layer, so its ceiling against the 2.5 PF/s bf16 peak is about 0.4")
         roofline = {"kernel": dom_kernel_name, "bound": bound, "achieved": rate(cand[dom]), "peak": peak, "unit": unit,
                     "frac": rate(cand[dom]) / peak, "traffic": traffic,
                     "avg_launch_ms": float(ms), "launches_per_step": n_launch, "algorithmic_work_per_launch": work,
