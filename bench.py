@@ -274,7 +274,7 @@ def main():
             "metric": f"image-pairs/sec at 2x{args.kpts} keypoints", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 MFMA attention + split-bf16x3 (f32-class) MFMA linears + f32 Sinkhorn" if args.linear_precision == "bf16x3"
+            "dtype": "bf16 MFMA attention and Q/K/V projection + split-bf16x3 (f32-class) MFMA linears + bf16x6 (f32-class) similarity and score GEMMs + f32 Sinkhorn" if args.linear_precision == "bf16x3"
                      else "bf16 MFMA attention + f32 MFMA linears + f32 Sinkhorn",
             "data": "synthetic",
             "config": {"workload": f"{args.pairs} pairs/step/GPU of 2x{args.kpts} synthetic keypoints (kept {problems[0][0]}/{problems[0][1]} after AGC r=15 p=2 m=7), "
