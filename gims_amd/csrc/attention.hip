@@ -13,8 +13,8 @@
 //     O^T += V^T P^T once the k-index of that MFMA is *defined* as the key order the lane holds
 //     (keys {0-3, 8-11} for lanes 0-31, {4-7, 12-15} for lanes 32-63 of each 16-key step) and V^T is
 //     read from LDS in the same order (two ds_read_b64 per fragment) -- no permlane / bpermute;
-//   * K tile in LDS row-major with XOR-swizzled 16-byte chunks (conflict-free ds_read_b128),
-//     V tile transposed on the way into LDS ([d][key], pitch 68 elements: conflict-free ds_read_b64);
+//   * K tile in LDS row-major with XOR-swizzled 16-byte chunks (conflict-free ds_read_b128); 4-wave kernel: V tile
+//     transposed on the way into LDS ([d][key], pitch 68 elements: conflict-free ds_read_b64); 8-wave kernel: see there;
 //   * global->register prefetch of the next K/V tile is issued before the MFMAs of the current one and written
 //     to the OTHER LDS buffer after them: one barrier per key tile;
 //   * the running max is deferred (rescale threshold): the O^T accumulator is only rescaled when a row's max
@@ -253,16 +253,17 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 
 // ---------------------------------------------------------------------------------------------- 8-wave variant
 // Same math and register layout as attention_bf16_kernel<2> (64 queries per wave), but a workgroup is EIGHT waves, two per
-// SIMD, and the two waves of a SIMD are kept half a key tile apart by the barriers: while group A (waves 0-3) runs a
-// matrix segment (QK^T or PV: 16 MFMAs) group B (waves 4-7) runs a softmax segment (one 32-query block: ~130 VALU +
-// 32 exp) on the same SIMD, and vice versa.  In the 4-wave kernel the two co-resident waves of a SIMD belong to different
-// workgroups and drift freely: knock-out experiments showed its tile time to be the SUM of its parts (MFMA, softmax,
-// staging each ~25 %), i.e. almost no overlap.  Per key tile, four phases, one barrier each:
-//     phase 0:  A: S = K Q^T of tile t          B: softmax block 1 of tile t-1
-//     phase 1:  A: softmax block 0 of tile t    B: O += V P of tile t-1
-//     phase 2:  A: softmax block 1 of tile t    B: S = K Q^T of tile t, then tile t+1 into LDS, request tile t+2
-//     phase 3:  A: O += V P of tile t, then tile t+1 into LDS, request tile t+2       B: softmax block 0 of tile t
-// K/V tiles are shared by 512 queries (half the staging traffic per query of the 4-wave kernel).
+// SIMD (K/V tiles shared by 512 queries: half the staging traffic per query of the 4-wave kernel), and the softmax is
+// stripped to what the measurements left standing:
+//   * gfx950 does not overlap one wave's MFMAs with its SIMD-mate's VALU (tools/probes/phase_overlap_probe.hip), and a
+//     wave issues one VALU instruction per ~4.9 cycles (valu_rate_probe.hip): a key tile costs its matrix cycles PLUS its
+//     VALU issues.  Hence ONE instruction stream for all waves and one barrier per key tile (an earlier version kept the
+//     two waves of a SIMD half a tile apart with four barriers -- 9 % slower), and as few VALU issues per score as possible:
+//   * the softmax scale log2(e)/sqrt(64) is folded into Q by the caller (GIMS_ATTN_Q_PRESCALED, NOFMA) and the first pass is
+//     "optimistic": P = exp2(S) with no running maximum at all (softmax is invariant to the reference point); row sums
+//     outside [1e-30, 1e30] send the workgroup through a second, exact pass (running maximum with deferred rescale);
+//   * row sums by v_pk_add_f32; V row-major in LDS, read transposed by ds_read_b64_tr_b16 (tr16_probe.hip);
+//   * the split-bf16 output leaves as whole 256-byte rows through a wave-private LDS transpose.
 constexpr int ATT8_WAVES = 8;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
