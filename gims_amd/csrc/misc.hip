@@ -231,6 +231,25 @@ extern "C" int gims_pack_graphs(const gims_pack_image* dev_images, int32_t n_ima
   return GIMS_OK;
 }
 
+extern "C" int gims_run_ops(const gims_op* ops, int32_t n_ops, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(ops && n_ops >= 0, "gims_run_ops: bad arguments");
+  for (int i = 0; i < n_ops; ++i) {
+    int rc;
+    if (ops[i].kind == GIMS_OP_LINEAR) {
+      rc = gims_linear(&ops[i].u.lin, stream);
+    } else if (ops[i].kind == GIMS_OP_ATTENTION) {
+      const gims_attn_args& a = ops[i].u.att;
+      rc = gims_attention(a.qkv, a.ld, a.q_col, a.k_col, a.v_col, a.problems, a.n_problems, a.max_n_q, a.n_heads, a.out, a.ld_out, a.out_hi, a.out_lo,
+                          a.ld_split, a.flags, stream);
+    } else {
+      GIMS_CHECK_ARG(false, "gims_run_ops: op %d has unknown kind %d", i, ops[i].kind);
+    }
+    if (rc != GIMS_OK) return rc;
+  }
+  return GIMS_OK;
+}
+
 extern "C" int gims_abi_version(void) { return GIMS_ABI_VERSION; }
 extern "C" const char* gims_last_error(void) { return gims::g_err; }
 extern "C" int gims_stream_sync(void* stream) {

@@ -249,6 +249,12 @@ class GMatcher(nn.Module):
         """SPL32 split-bf16 activation buffer for a logical [rows, cols] matrix (see include/gims_hip.h)."""
         return torch.empty((rows, 2 * cols), dtype=torch.bfloat16, device=dev)
 
+    def _act(self, name, rows, cols, dtype):
+        """Layer activation that never leaves this object ([rows, cols] of dtype): a view of a per-lane arena, so its
+        address is the same from call to call and the recorded launch sequence of the GNN layers can be replayed."""
+        nbytes = rows * cols * torch.empty((), dtype=dtype).element_size()
+        return self._buf("act_" + name, nbytes)[:nbytes].view(dtype).view(rows, cols)
+
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
     def enable_timing(self, on: bool = True):
         """Record a (start, end) HIP-event pair around every stage on the stream the kernels are launched on;
@@ -405,13 +411,13 @@ class GMatcher(nn.Module):
             hip.kenc_first(kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], x, relu=not ln)
             if ln:      # use_layernorm=True: conv -> LayerNorm -> ReLU (gmatcher.py:17-23), the norm as its own kernel
                 hip.layernorm_act(x, *P["kenc_ln"][0], out=x)
-            dpl = self._spl(n_tot, D, dev) if x3 else None          # split-bf16 (SPL32) copy of the residual stream
+            dpl = self._act("dpl", n_tot, 2 * D, torch.bfloat16) if x3 else None     # split-bf16 (SPL32) copy of the residual stream
             if x3 and not ln:
                 xs = hip.split_spl32(x)                              # the hidden activations only ever exist as SPL32 planes
                 for i, e in enumerate(P["kenc"]):
                     last = i == len(P["kenc"]) - 1
                     if last:
-                        x = torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev)
+                        x = self._act("desc", n_tot, e["n"], torch.float32)
                         self._lin(e, xs, residual=sage, out=x, out_split=dpl)
                     else:
                         nxt = self._spl(n_tot, e["n"], dev)
@@ -430,17 +436,43 @@ class GMatcher(nn.Module):
         pairs = [(images[2 * p]["rows"], images[2 * p + 1]["rows"]) for p in range(len(images) // 2)]
         # problem tables travel as kernel arguments (hip.upload): a pageable torch.tensor(..., device=) would block this
         # thread until the stream drains and stop the host from running ahead of the GPU
-        self_pr = hip.upload(np.asarray([[o, n, o, n] for pr in pairs for (o, n) in pr], dtype=np.int32), dev)
-        cross_pr = hip.upload(np.asarray([q for (o0, n0), (o1, n1) in pairs for q in ((o0, n0, o1, n1), (o1, n1, o0, n0))],
-                                         dtype=np.int32), dev)
+        # (problem tables and layer activations live in per-lane arenas: stable addresses let the launch sequence be replayed)
+        spr = np.asarray([[o, n, o, n] for pr in pairs for (o, n) in pr], dtype=np.int32)
+        cpr = np.asarray([q for (o0, n0), (o1, n1) in pairs for q in ((o0, n0, o1, n1), (o1, n1, o0, n0))], dtype=np.int32)
+        self_pr = hip.upload(spr, dev, out=self._buf("self_pr", spr.nbytes + 32))
+        cross_pr = hip.upload(cpr, dev, out=self._buf("cross_pr", cpr.nbytes + 32))
         max_nq = max(g["n_kept"] for g in images)
-        qkv = torch.empty((n_tot, 3 * D), dtype=torch.bfloat16, device=dev)
+        qkv = self._act("qkv", n_tot, 3 * D, torch.bfloat16)
         if x3:
             # all GEMM operands travel as split-bf16 SPL32 buffers written by the producing kernel's epilogue; only the
             # residual stream `desc` also exists in f32
-            mpl, gpl, hpl = self._spl(n_tot, D, dev), self._spl(n_tot, D, dev), self._spl(n_tot, 2 * D, dev)
+            mpl, gpl, hpl = (self._act("mpl", n_tot, 2 * D, torch.bfloat16), self._act("gpl", n_tot, 2 * D, torch.bfloat16),
+                             self._act("hpl", n_tot, 4 * D, torch.bfloat16))
             hid_ln = None
-            for L in P["layers"]:
+            replay = (self._timers is None and not ln and all(L["mlp0_fused"] is not None for L in P["layers"])
+                      and os.environ.get("GIMS_NO_REPLAY") is None)
+            if replay:
+                # the 72 launches of the 18 layers as ONE call into the library (gims_run_ops): their arguments depend only on
+                # the buffer addresses and the batch geometry, which repeat from call to call in steady state
+                key = (id(P), n_tot, max_nq, dpl.data_ptr(), mpl.data_ptr(), hpl.data_ptr(), desc.data_ptr(), qkv.data_ptr(),
+                       self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags)
+                cache = self.__dict__.setdefault("_ops_cache", {})
+                ops = cache.get(key)
+                if ops is None:
+                    def la(e, a0, **kw):
+                        return hip.op_linear(hip.linear_args(a0, e["w"], w_lo=e["w_lo"], bias=e["b"], precision=e["prec"], spl=e["spl"], **kw))
+                    lst = []
+                    for L in P["layers"]:
+                        lst.append(la(L["qkv"], dpl, out_bf16=qkv, flags=self._qkv_flags))
+                        lst.append(hip.op_attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D,
+                                                    out_split=mpl, q_prescaled=True))
+                        lst.append(la(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl, flags=self._msg_flags))
+                        lst.append(la(L["mlp1"], hpl, residual=desc, out=desc, out_split=dpl))
+                    if len(cache) > 8:
+                        cache.clear()
+                    ops = cache[key] = hip.make_ops(lst)
+                hip.run_ops(ops)
+            for L in (() if replay else P["layers"]):
                 with St("qkv"):
                     self._lin(L["qkv"], dpl, out_bf16=qkv, flags=self._qkv_flags)
                 with St("attn_cross" if L["cross"] else "attn_self"):

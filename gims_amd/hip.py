@@ -35,6 +35,21 @@ class LinearArgs(C.Structure):
                 ("out_lo", C.c_void_p), ("ld_split", C.c_int64), ("flags", C.c_int32)]
 
 
+class AttnArgs(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("ld", C.c_int64), ("q_col", C.c_int32), ("k_col", C.c_int32), ("v_col", C.c_int32),
+                ("problems", C.c_void_p), ("n_problems", C.c_int32), ("max_n_q", C.c_int32), ("n_heads", C.c_int32),
+                ("out", C.c_void_p), ("ld_out", C.c_int64), ("out_hi", C.c_void_p), ("out_lo", C.c_void_p),
+                ("ld_split", C.c_int64), ("flags", C.c_int32)]
+
+
+class _OpU(C.Union):
+    _fields_ = [("lin", LinearArgs), ("att", AttnArgs)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("u", _OpU)]
+
+
 class AgcImage(C.Structure):
     _fields_ = [("kpts", C.c_void_p), ("desc", C.c_void_p), ("ldd", C.c_int64), ("n", C.c_int32), ("d", C.c_int32),
                 ("kept", C.c_void_p), ("indptr", C.c_void_p), ("indices", C.c_void_p), ("max_edges_dir", C.c_int32),
@@ -74,6 +89,7 @@ _SIGNATURES = {
     "gims_linear_put_many": (C.c_int, [C.POINTER(LinearArgs), C.c_int32, C.c_void_p, C.c_void_p]),
     "gims_linear_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_run_ops": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "gims_split_spl3": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_split_spl32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
@@ -149,7 +165,7 @@ def _p(t) -> int | None:
 _NP2TORCH = {"float32": torch.float32, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8}
 
 
-def upload(arr, device="cuda") -> torch.Tensor:
+def upload(arr, device="cuda", out=None) -> torch.Tensor:
     """Small host table (numpy array) -> device tensor, asynchronously and in stream order (gims_upload_table): the
     bytes ride in kernel arguments, so unlike ``torch.tensor(..., device=...)`` / ``.to(device)`` from pageable memory
     the calling thread never waits for the stream to drain."""
@@ -157,7 +173,11 @@ def upload(arr, device="cuda") -> torch.Tensor:
     a = np.ascontiguousarray(arr)
     dt = _NP2TORCH[a.dtype.name]
     nbytes = a.nbytes
-    buf = torch.empty(((nbytes + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=device)   # caching allocator: 512-B aligned
+    if out is not None:      # caller-owned uint8 arena (stable address from call to call); stream order protects earlier readers
+        assert out.dtype == torch.uint8 and out.numel() >= nbytes + 16
+        buf = out
+    else:
+        buf = torch.empty(((nbytes + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=device)   # caching allocator: 512-B aligned
     if nbytes:
         _check(load().gims_upload_table(a.ctypes.data, nbytes, buf.data_ptr(), _stream()), "gims_upload_table")
     return buf[:nbytes].view(dt).view(a.shape)
@@ -242,6 +262,31 @@ def split_spl32(x: torch.Tensor, out: torch.Tensor | None = None):
         out = torch.empty((rows, 2 * k), dtype=torch.bfloat16, device=x.device)
     _check(lib.gims_split_spl32(_p(_dev(x, torch.float32)), x.stride(0), _p(out), out.stride(0), rows, k, _stream()), "gims_split_spl32")
     return out
+
+
+def op_linear(args: LinearArgs) -> Op:
+    o = Op()
+    o.kind = 0
+    o.u.lin = args
+    return o
+
+
+def op_attention(qkv, problems, max_n_q, n_heads, out=None, q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False) -> Op:
+    o = Op()
+    o.kind = 1
+    o.u.att = AttnArgs(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0], max_n_q, n_heads, _p(out),
+                       out.stride(0) if out is not None else 0, _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
+                       out_split.stride(0) if out_split is not None else 0, 1 if q_prescaled else 0)
+    return o
+
+
+def make_ops(ops):
+    """A replayable launch sequence (see gims_run_ops): returns the ctypes array; keep the tensors it points to alive."""
+    return (Op * len(ops))(*ops)
+
+
+def run_ops(op_array):
+    _check(load().gims_run_ops(op_array, len(op_array), _stream()), "gims_run_ops")
 
 
 def split_spl3(x: torch.Tensor, out: torch.Tensor | None = None):

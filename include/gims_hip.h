@@ -136,6 +136,22 @@ int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col
                    uint16_t* out_hi /* may be NULL */, uint16_t* out_lo, int64_t ld_split, int32_t flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A recorded sequence of launches replayed by ONE call: the 18 layers of AttentionalGNN.forward (gmatcher.py:127-143) are
+ * 72 launches whose arguments only change when the batch geometry does, and a caller in an interpreted language pays for
+ * every crossing of the ABI.  ops: HOST array; each op is exactly one gims_linear or gims_attention call, in order, on
+ * `stream`.  Stops at (and returns) the first error.
+ */
+typedef struct gims_attn_args {
+  const uint16_t* qkv; int64_t ld; int32_t q_col, k_col, v_col;
+  const gims_attn_problem* problems; int32_t n_problems, max_n_q, n_heads;
+  float* out; int64_t ld_out; uint16_t* out_hi; uint16_t* out_lo; int64_t ld_split; int32_t flags;
+} gims_attn_args;
+#define GIMS_OP_LINEAR 0
+#define GIMS_OP_ATTENTION 1
+typedef struct gims_op { int32_t kind; int32_t reserved; union { gims_linear_args lin; gims_attn_args att; } u; } gims_op;
+int gims_run_ops(const gims_op* ops /* HOST */, int32_t n_ops, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Keypoint encoder front end: normalize_keypoints (gmatcher.py:26-33, with the reference's NHWC-as-NCHW
  * quirk resolved by the caller into cx, cy, scale) fused with the first Conv1d(2->c1)+BN(eval)+ReLU of
  * KeypointEncoder (gmatcher.py:87-97).  w1: [c1][2] and b1: [c1] have BatchNorm already folded in.

@@ -171,6 +171,25 @@ def test_two_stream_lanes_equal_single_stream(synth_sd):
         np.testing.assert_allclose(a["matching_scores0"].cpu().numpy(), b["matching_scores0"].cpu().numpy(), atol=2e-6)
 
 
+def test_replayed_layers_equal_stepwise(synth_sd):
+    """The 18 GNN layers replayed through gims_run_ops (one ABI crossing, argument table cached across calls) give exactly
+    what the launch-by-launch path gives (the one that runs when stage timers are on)."""
+    pairs = [synth.make_pair(n, s) for n, s in ((256, 1002), (512, 1004), (256, 1003))]
+    m = GMatcher({}).eval()
+    m.load_state_dict(synth_sd)
+    res = []
+    for timed in (False, True, False):           # replay (cold cache), stepwise, replay (warm cache)
+        m.enable_timing(timed)
+        outs = m.match_pairs([pair_to_data(p, 15, 2, 7, device="cuda") for p in pairs])
+        torch.cuda.synchronize()
+        res.append([(o["matches0"].cpu().numpy(), o["matching_scores0"].cpu().numpy()) for o in outs])
+    assert m.__dict__.get("_ops_cache"), "the replay path did not run"
+    for other in res[1:]:
+        for (m0, s0), (m1, s1) in zip(res[0], other):
+            np.testing.assert_array_equal(m0, m1)
+            np.testing.assert_array_equal(s0, s1)
+
+
 def test_unequal_keypoint_counts_vs_oracle(models, synth_sd):
     """N0 != N1 (image 1 lost a third of its keypoints): HIP path vs the CPU oracle on the same inputs."""
     pair = synth.make_pair(384, 1010)
