@@ -250,6 +250,37 @@ extern "C" int gims_run_ops(const gims_op* ops, int32_t n_ops, void* stream) {
   return GIMS_OK;
 }
 
+extern "C" int gims_ops_graph_create(const gims_op* ops, int32_t n_ops, void* stream, void** graph_exec_out) {
+  using namespace gims;
+  GIMS_CHECK_ARG(ops && n_ops > 0 && graph_exec_out && stream, "gims_ops_graph_create: bad arguments (a non-default stream is required)");
+  hipStream_t s = (hipStream_t)stream;
+  GIMS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  const int rc = gims_run_ops(ops, n_ops, stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc != GIMS_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+  GIMS_HIP(e);
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  GIMS_HIP(e2);
+  *graph_exec_out = (void*)exec;
+  return GIMS_OK;
+}
+
+extern "C" int gims_ops_graph_launch(void* graph_exec, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(graph_exec, "gims_ops_graph_launch: null graph");
+  GIMS_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return GIMS_OK;
+}
+
+extern "C" int gims_ops_graph_destroy(void* graph_exec) {
+  using namespace gims;
+  if (graph_exec) GIMS_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return GIMS_OK;
+}
+
 extern "C" int gims_abi_version(void) { return GIMS_ABI_VERSION; }
 extern "C" const char* gims_last_error(void) { return gims::g_err; }
 extern "C" int gims_stream_sync(void* stream) {

@@ -240,6 +240,8 @@ class GMatcher(nn.Module):
 
     _msg_flags = hip.LINEAR_A1_HI_ONLY if os.environ.get("GIMS_MSG_PREC", "x3") == "bf16" else 0
 
+    _use_graph = os.environ.get("GIMS_OPS_GRAPH", "0") == "1"      # opt-in: measured gain <= 3 % (tools/graph_probe.py)
+
     @staticmethod
     def _lin(e, a0, **kw):
         return hip.linear(a0, e["w"], w_lo=e["w_lo"], bias=e["b"], precision=e["prec"], spl=e["spl"], **kw)
@@ -470,8 +472,16 @@ class GMatcher(nn.Module):
                         lst.append(la(L["mlp1"], hpl, residual=desc, out=desc, out_split=dpl))
                     if len(cache) > 8:
                         cache.clear()
-                    ops = cache[key] = hip.make_ops(lst)
-                hip.run_ops(ops)
+                    ops = cache[key] = [hip.make_ops(lst), None, 0]           # table, HIP graph, uses
+                # first use: plain replay (first-use initialisation inside the library); from the second use on a non-default
+                # stream, if GIMS_OPS_GRAPH=1: ONE graph launch
+                ops[2] += 1
+                if ops[1] is None and ops[2] >= 2 and self._use_graph and torch.cuda.current_stream().cuda_stream != 0:
+                    ops[1] = hip.OpsGraph(ops[0])
+                if ops[1] is not None:
+                    ops[1].launch()
+                else:
+                    hip.run_ops(ops[0])
             for L in (() if replay else P["layers"]):
                 with St("qkv"):
                     self._lin(L["qkv"], dpl, out_bf16=qkv, flags=self._qkv_flags)

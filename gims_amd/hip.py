@@ -90,6 +90,9 @@ _SIGNATURES = {
     "gims_linear_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_run_ops": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "gims_ops_graph_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gims_ops_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gims_ops_graph_destroy": (C.c_int, [C.c_void_p]),
     "gims_split_spl3": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_split_spl32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
@@ -287,6 +290,26 @@ def make_ops(ops):
 
 def run_ops(op_array):
     _check(load().gims_run_ops(op_array, len(op_array), _stream()), "gims_run_ops")
+
+
+class OpsGraph:
+    """The launch sequence as an instantiated HIP graph (gims_ops_graph_*); capture needs a non-default stream."""
+
+    def __init__(self, op_array):
+        self._ops = op_array          # keeps the host table alive
+        h = C.c_void_p()
+        _check(load().gims_ops_graph_create(op_array, len(op_array), _stream(), C.byref(h)), "gims_ops_graph_create")
+        self._h = h
+
+    def launch(self):
+        _check(load().gims_ops_graph_launch(self._h, _stream()), "gims_ops_graph_launch")
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().gims_ops_graph_destroy(self._h)
+        except Exception:
+            pass
 
 
 def split_spl3(x: torch.Tensor, out: torch.Tensor | None = None):

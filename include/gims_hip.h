@@ -150,6 +150,13 @@ typedef struct gims_attn_args {
 #define GIMS_OP_ATTENTION 1
 typedef struct gims_op { int32_t kind; int32_t reserved; union { gims_linear_args lin; gims_attn_args att; } u; } gims_op;
 int gims_run_ops(const gims_op* ops /* HOST */, int32_t n_ops, void* stream);
+/* The same sequence as a HIP graph: gims_ops_graph_create captures the launches of `ops` on `stream` (nothing executes),
+ * gims_ops_graph_launch replays them (one graph launch: no per-kernel launch gaps), gims_ops_graph_destroy frees the graph.
+ * Every op must have run once through gims_run_ops before (first-use initialisation cannot happen inside a capture), and
+ * every pointer in `ops` must stay valid for as long as the graph is launched. */
+int gims_ops_graph_create(const gims_op* ops /* HOST */, int32_t n_ops, void* stream, void** graph_exec_out);
+int gims_ops_graph_launch(void* graph_exec, void* stream);
+int gims_ops_graph_destroy(void* graph_exec);
 
 /* ------------------------------------------------------------------------------------------------
  * Keypoint encoder front end: normalize_keypoints (gmatcher.py:26-33, with the reference's NHWC-as-NCHW

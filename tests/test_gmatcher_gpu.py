@@ -190,6 +190,27 @@ def test_replayed_layers_equal_stepwise(synth_sd):
             np.testing.assert_array_equal(s0, s1)
 
 
+def test_graph_replay_equals_plain_replay(synth_sd):
+    """GIMS_OPS_GRAPH=1 on a non-default stream: the layer sequence captured into a HIP graph gives the same bits."""
+    pairs = [synth.make_pair(n, s) for n, s in ((256, 1002), (512, 1004))]
+    res = []
+    side = torch.cuda.Stream()
+    for graph in (False, True):
+        m = GMatcher({}).eval()
+        m.load_state_dict(synth_sd)
+        m._use_graph = graph
+        with torch.cuda.stream(side):
+            for _ in range(3):                     # the graph is built on the second use of a cached table
+                outs = m.match_pairs([pair_to_data(p, 15, 2, 7, device="cuda") for p in pairs])
+            torch.cuda.synchronize()
+        if graph:
+            assert any(v[1] is not None for v in m.__dict__["_ops_cache"].values()), "no graph was instantiated"
+        res.append([(o["matches0"].cpu().numpy(), o["matching_scores0"].cpu().numpy()) for o in outs])
+    for (m0, s0), (m1, s1) in zip(*res):
+        np.testing.assert_array_equal(m0, m1)
+        np.testing.assert_array_equal(s0, s1)
+
+
 def test_unequal_keypoint_counts_vs_oracle(models, synth_sd):
     """N0 != N1 (image 1 lost a third of its keypoints): HIP path vs the CPU oracle on the same inputs."""
     pair = synth.make_pair(384, 1010)
