@@ -256,6 +256,38 @@ def test_attention_online_rescale(hip, monkeypatch, kernel):
     assert np.abs(out.cpu().numpy() - ref).max() < 1.5e-2
 
 
+def test_attention_full_size_properties(hip, monkeypatch):
+    """BASELINE's full size (2 x 4096 keypoints, cross attention), where the float64 reference is too slow: properties that
+    hold for any size.  (1) The output is linear in V and a power-of-two scale is exact in bf16 and in the f32 accumulators:
+    attention(Q, K, 2V) == 2 attention(Q, K, V) bit for bit.  (2) Every output row is a convex combination of the value
+    rows: it lies inside the per-channel [min, max] of V (up to the bf16 rounding of P).  (3) Queries are independent:
+    attending a subset of the queries gives the same rows."""
+    monkeypatch.setenv("GIMS_ATTN_QP", "8")          # the 8-wave kernel for every launch below, whatever its size
+    r = _rng(77)
+    n = 4096
+    qkv = (r.normal(size=(2 * n, 768)) * 0.7).astype(np.float32)
+    qkv[:, :256] *= np.float32(hip.ATTN_Q_SCALE)
+    qb = torch.from_numpy(qkv).to(torch.bfloat16).cuda()
+    pr = torch.tensor([[0, n, n, n], [n, n, 0, n]], dtype=torch.int32, device="cuda")      # image 0 attends image 1 and back
+    out1 = torch.empty((2 * n, 256), dtype=torch.float32, device="cuda")
+    hip.attention(qb, pr, n, 4, out1, q_prescaled=True)
+    qb2 = qb.clone()
+    qb2[:, 512:] = qb[:, 512:] * 2
+    out2 = torch.empty_like(out1)
+    hip.attention(qb2, pr, n, 4, out2, q_prescaled=True)
+    assert torch.equal(out2, out1 * 2)
+    v = qb[:, 512:].float()
+    for (qo, nq, ko, nk) in pr.cpu().tolist():
+        lo, hi = v[ko:ko + nk].min(0).values, v[ko:ko + nk].max(0).values
+        o = out1[qo:qo + nq]
+        span = (hi - lo)
+        assert bool(((o >= lo - 0.01 * span) & (o <= hi + 0.01 * span)).all())
+    sub = torch.tensor([[100, 700, n, n]], dtype=torch.int32, device="cuda")                  # 700 queries of image 0
+    out3 = torch.full_like(out1, float("nan"))
+    hip.attention(qb, sub, 700, 4, out3, q_prescaled=True)
+    assert torch.equal(out3[100:800], out1[100:800])
+
+
 @pytest.mark.parametrize("prescaled", [False, True])
 @pytest.mark.parametrize("kernel", ["8", "8exact"])
 def test_attention_optimistic_overflow_falls_back(hip, monkeypatch, kernel, prescaled):
