@@ -268,3 +268,87 @@ def make_homography_pair(n: int, seed: int, canvas=None, pos_noise: float = 0.5,
     k1[gt[ok]] = (dst[ok] + jitter[ok]).astype(np.float32)
     pair["keypoints1"] = k1[None]
     return pair, H
+
+
+# ------------------------------------------------------------------------------------------------ CAR-HyNet
+def carhynet_state_dict_spec():
+    """(name, shape) of every tensor of the reference's CAR_HyNet().state_dict() (carhynet/models.py:311-362), in its order."""
+    spec = []
+
+    def frn(p, c):
+        spec.extend([(p + "weight", (1, c, 1, 1)), (p + "bias", (1, c, 1, 1)), (p + "eps", (1,))])
+
+    def bn(p, c, affine=True):
+        if affine:
+            spec.extend([(p + "weight", (c,)), (p + "bias", (c,))])
+        spec.extend([(p + "running_mean", (c,)), (p + "running_var", (c,)), (p + "num_batches_tracked", ())])
+
+    def coordatt(p, c, mip=8):
+        spec.extend([(p + "conv1.weight", (mip, c, 1, 1)), (p + "conv1.bias", (mip,))])
+        bn(p + "bn1.", mip)
+        spec.extend([(p + "conv_h.weight", (c, mip, 1, 1)), (p + "conv_h.bias", (c,)), (p + "conv_w.weight", (c, mip, 1, 1)), (p + "conv_w.bias", (c,))])
+
+    def sandglass(p, c, hidden=16):
+        spec.append((p + "conv.0.0.weight", (c, 1, 3, 3))); bn(p + "conv.0.1.", c)
+        coordatt(p + "conv.1.", c)
+        spec.append((p + "conv.2.weight", (hidden, c, 1, 1))); bn(p + "conv.3.", hidden)
+        spec.append((p + "conv.4.0.weight", (c, hidden, 1, 1))); bn(p + "conv.4.1.", c)
+        spec.append((p + "conv.5.weight", (c, 1, 3, 3))); bn(p + "conv.6.", c)
+
+    frn("layer1.0.", 3); spec.append(("layer1.1.tau", (1, 3, 1, 1)))
+    spec.extend([("layer1.2.weight", (32, 3, 3, 3)), ("layer1.2.bias", (32,))]); frn("layer1.3.", 32); coordatt("layer1.4.", 32)
+    spec.append(("layer1.5.tau", (1, 32, 1, 1)))
+    spec.extend([("layer2.0.weight", (32, 32, 3, 3)), ("layer2.0.bias", (32,))]); frn("layer2.1.", 32); coordatt("layer2.2.", 32)
+    spec.append(("layer2.3.tau", (1, 32, 1, 1)))
+    sandglass("layer2_5.", 32)
+    for name, cin, cout in (("layer3", 32, 64), ("layer4", 64, 64)):
+        spec.extend([(name + ".0.weight", (cout, cin, 3, 3)), (name + ".0.bias", (cout,))]); frn(name + ".1.", cout)
+        spec.append((name + ".2.tau", (1, cout, 1, 1)))
+        if name == "layer4":
+            sandglass("layer4_5.", 64)
+    for name, cin, cout in (("layer5", 64, 128), ("layer6", 128, 128)):
+        spec.extend([(name + ".0.weight", (cout, cin, 3, 3)), (name + ".0.bias", (cout,))]); frn(name + ".1.", cout)
+        spec.append((name + ".2.tau", (1, cout, 1, 1)))
+    spec.append(("layer7.1.weight", (128, 128, 8, 8))); bn("layer7.2.", 128, affine=False)
+    return spec
+
+
+def make_carhynet_state_dict(seed: int = 321, jitter: float = 0.2, bias_std: float = 0.05):
+    """Synthetic CAR-HyNet weights as {name: np.ndarray} (the reference's ./weights/car_hynet.pth is not in the repository).
+    Conv weights ~ N(0, 2 / fan_in) (activations keep their scale through the FRN / TLU stack), biases and BatchNorm / FRN
+    shifts ~ N(0, bias_std^2), scales and variances 1 +- jitter, TLU thresholds around the reference's init -1 (models.py:101),
+    FRN eps = 1e-6 (models.py:24)."""
+    out = {}
+    for i, (name, shape) in enumerate(carhynet_state_dict_spec()):
+        n = int(np.prod(shape)) if len(shape) else 1
+        stream = 5000 + i
+        if name.endswith("num_batches_tracked"):
+            a = np.array(0, dtype=np.int64)
+        elif name.endswith(".eps"):
+            a = np.array([1e-6], dtype=np.float32)
+        elif name.endswith(".tau"):
+            a = (-1.0 + 0.5 * (2.0 * uniform(seed, stream, n) - 1.0)).astype(np.float32).reshape(shape)
+        elif name.endswith("running_var") or (name.endswith("weight") and (len(shape) == 1 or shape[0] == 1)):
+            a = (1.0 + jitter * (2.0 * uniform(seed, stream, n) - 1.0)).astype(np.float32).reshape(shape)     # BN gamma / var, FRN scale
+        elif name.endswith("running_mean") or name.endswith("bias"):
+            a = (bias_std * normal(seed, stream, n)).astype(np.float32).reshape(shape)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            a = (normal(seed, stream, n) * np.sqrt(2.0 / fan_in)).astype(np.float32).reshape(shape)
+        out[name] = a
+    return out
+
+
+def make_patches(n: int, seed: int):
+    """n synthetic 32x32x3 patches in [0, 1] (NHWC float32, what HyNetnetFeature2D.compute_des_batches takes, models.py:655-666):
+    a smooth random field per patch (low-frequency sinusoids) plus noise, so neighbouring pixels correlate like image patches."""
+    yy, xx = np.meshgrid(np.arange(32, dtype=np.float32), np.arange(32, dtype=np.float32), indexing="ij")
+    u = uniform(seed, 77, n * 3 * 6).reshape(n, 3, 6).astype(np.float32)
+    noise = normal(seed, 78, n * 32 * 32 * 3).reshape(n, 32, 32, 3).astype(np.float32)
+    out = np.empty((n, 32, 32, 3), dtype=np.float32)
+    for c in range(3):
+        fx, fy, ph = 0.05 + 0.3 * u[:, c, 0], 0.05 + 0.3 * u[:, c, 1], 6.2831853 * u[:, c, 2]
+        amp, off = 0.2 + 0.25 * u[:, c, 3], 0.3 + 0.4 * u[:, c, 4]
+        field = off[:, None, None] + amp[:, None, None] * np.sin(fx[:, None, None] * xx[None] + fy[:, None, None] * yy[None] + ph[:, None, None])
+        out[..., c] = field
+    return np.clip(out + 0.03 * noise, 0.0, 1.0).astype(np.float32)
