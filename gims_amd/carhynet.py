@@ -1,0 +1,217 @@
+"""CAR-HyNet patch descriptor on MI355X -- host side.
+
+Mirrors the reference's interface for this stage (carhynet/models.py):
+  * ``CARHyNet`` is an ``nn.Module`` with the reference's 136 state tensors (``CAR_HyNet().state_dict()`` names and shapes,
+    models.py:311-362), so ``load_state_dict(torch.load('car_hynet.pth'))`` works unchanged; ``forward(x)`` takes the
+    reference's NCHW float input and returns L2-normalised [N, 128] descriptors (eval mode only, models.py:379-399);
+  * ``compute_des_batches(patches, color=True)`` takes NHWC patches in [0, 1] like ``HyNetnetFeature2D`` (models.py:655-666)
+    and returns a float32 NumPy array.
+All arithmetic runs in libgims_hip.so: activations are NHWC f32 in HBM, every 3x3 convolution is ``gims_ch_im2col3`` + the
+split-bf16x3 GEMM (``gims_linear``: f32-class accuracy), the 8x8 convolution is that GEMM on the flattened 8x8x128
+activation, 1x1 convolutions are ``gims_linear`` in f32, and FRN / TLU / CoordAtt / depthwise stages are the ``gims_ch_*``
+kernels.  BatchNorm (eval) is folded into the neighbouring weights.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .synth import carhynet_state_dict_spec
+
+BN_EPS = 1e-5
+EPS_L2_NORM = 1e-10
+
+
+class CARHyNet(nn.Module):
+    chunk = 2048                      # patches per pass (im2col of the 32->32 layer: 1.2 MB per patch)
+
+    def __init__(self):
+        super().__init__()
+        for name, shape in carhynet_state_dict_spec():
+            t = torch.zeros(shape, dtype=torch.int64 if name.endswith("num_batches_tracked") else torch.float32)
+            self.register_buffer(name.replace(".", "__"), t)
+        self._names = [n for n, _ in carhynet_state_dict_spec()]
+        self._pack = None
+
+    # state_dict with the reference's dotted names
+    def state_dict(self, *a, **k):
+        return {n: getattr(self, n.replace(".", "__")) for n in self._names}
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [n for n in self._names if n not in sd]
+        extra = [n for n in sd if n not in self._names]
+        if strict and (missing or extra):
+            raise RuntimeError(f"CARHyNet.load_state_dict: missing {missing[:3]}..., unexpected {extra[:3]}...")
+        for n in self._names:
+            if n in sd:
+                getattr(self, n.replace(".", "__")).copy_(torch.as_tensor(np.asarray(sd[n])) if not torch.is_tensor(sd[n]) else sd[n])
+        self._pack = None
+
+    # ------------------------------------------------------------------ weight preparation
+    def _prepare(self, dev):
+        if self._pack is not None and self._pack["dev"] == dev:
+            return self._pack
+        sd = {n: getattr(self, n.replace(".", "__")).detach().double().cpu() for n in self._names}
+        f32 = lambda t: t.float().contiguous().to(dev)       # noqa: E731
+
+        def bn_fold(p, affine=True):                # y = x * sc + sh
+            sc = 1.0 / torch.sqrt(sd[p + "running_var"] + BN_EPS)
+            if affine:
+                sc = sc * sd[p + "weight"]
+            sh = -sd[p + "running_mean"] * sc + (sd[p + "bias"] if affine else 0.0)
+            return sc, sh
+
+        def conv3(p, cin_pad=None):                 # [O][I][3][3] -> SPL32 [O][2 * kpad], column (ky*3+kx)*Ipad + i
+            w = sd[p + "weight"]
+            o, i = w.shape[0], w.shape[1]
+            ip = cin_pad or i
+            wk = torch.zeros(o, 3, 3, ip, dtype=torch.float64)
+            wk[..., :i] = w.permute(0, 2, 3, 1)
+            k = 9 * ip
+            kpad = (k + 31) // 32 * 32
+            full = torch.zeros(o, kpad, dtype=torch.float64)
+            full[:, :k] = wk.reshape(o, k)
+            return dict(w=hip.split_spl32(f32(full)), b=f32(sd[p + "bias"]), kpad=kpad, n=o)
+
+        def frn(p, cpad=None):
+            c = sd[p + "weight"].numel()
+            cp = cpad or c
+            w, b = torch.zeros(cp, dtype=torch.float64), torch.zeros(cp, dtype=torch.float64)
+            w[:c], b[:c] = sd[p + "weight"].reshape(-1), sd[p + "bias"].reshape(-1)
+            return dict(w=f32(w), b=f32(b), eps=float(sd[p + "eps"].abs()))
+
+        def tau(p, cpad=None):
+            c = sd[p + "tau"].numel()
+            t = torch.zeros(cpad or c, dtype=torch.float64)
+            t[:c] = sd[p + "tau"].reshape(-1)
+            return f32(t)
+
+        def coordatt(p):
+            sc, sh = bn_fold(p + "bn1.")
+            w1 = sd[p + "conv1.weight"][:, :, 0, 0] * sc[:, None]
+            b1 = sd[p + "conv1.bias"] * sc + sh
+            return dict(w1=f32(w1), b1=f32(b1), wh=f32(sd[p + "conv_h.weight"][:, :, 0, 0]), bh=f32(sd[p + "conv_h.bias"]),
+                        ww=f32(sd[p + "conv_w.weight"][:, :, 0, 0]), bw=f32(sd[p + "conv_w.bias"]))
+
+        def dw(pw, pbn):                            # depthwise [C][1][3][3] + BN -> wt [9][C], bias [C]
+            sc, sh = bn_fold(pbn)
+            w = sd[pw + "weight"][:, 0] * sc[:, None, None]
+            return dict(wt=f32(w.permute(1, 2, 0).reshape(9, -1)), b=f32(sh))
+
+        def pw(pconv, pbn, o_pad=None, i_pad=None):  # 1x1 conv (no bias) + BN -> f32 [O][I], bias [O]; zero-padded to the GEMM's K % 32
+            sc, sh = bn_fold(pbn)
+            w = sd[pconv + "weight"][:, :, 0, 0] * sc[:, None]
+            o, i = w.shape
+            wp, bp = torch.zeros(o_pad or o, i_pad or i, dtype=torch.float64), torch.zeros(o_pad or o, dtype=torch.float64)
+            wp[:o, :i], bp[:o] = w, sh
+            return dict(w=f32(wp), b=f32(bp))
+
+        def sandglass(p):
+            return dict(dw0=dw(p + "conv.0.0.", p + "conv.0.1."), ca=coordatt(p + "conv.1."), pw0=pw(p + "conv.2.", p + "conv.3.", o_pad=32),
+                        pw1=pw(p + "conv.4.0.", p + "conv.4.1.", i_pad=32), dw1=dw(p + "conv.5.", p + "conv.6."))
+
+        sc7, sh7 = bn_fold("layer7.2.", affine=False)
+        w7 = sd["layer7.1.weight"].permute(0, 2, 3, 1).reshape(128, 8 * 8 * 128) * sc7[:, None]      # column (y*8+x)*128 + c: NHWC flatten
+        P = dict(dev=dev,
+                 l1=dict(frn0=frn("layer1.0.", 4), tau0=tau("layer1.1.", 4), conv=conv3("layer1.2.", 4), frn=frn("layer1.3."), ca=coordatt("layer1.4."),
+                         tau=tau("layer1.5.")),
+                 l2=dict(conv=conv3("layer2.0."), frn=frn("layer2.1."), ca=coordatt("layer2.2."), tau=tau("layer2.3.")),
+                 sg2=sandglass("layer2_5."), sg4=sandglass("layer4_5."),
+                 l3=dict(conv=conv3("layer3.0."), frn=frn("layer3.1."), tau=tau("layer3.2.")),
+                 l4=dict(conv=conv3("layer4.0."), frn=frn("layer4.1."), tau=tau("layer4.2.")),
+                 l5=dict(conv=conv3("layer5.0."), frn=frn("layer5.1."), tau=tau("layer5.2.")),
+                 l6=dict(conv=conv3("layer6.0."), frn=frn("layer6.1."), tau=tau("layer6.2.")),
+                 l7=dict(w=hip.split_spl32(f32(w7)), b=f32(sh7)))
+        self._pack = P
+        return P
+
+    # ------------------------------------------------------------------ layers
+    @staticmethod
+    def _conv3(x, L, stride):
+        n, h, w, c = x.shape
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        cols = torch.empty((n * ho * wo, 2 * L["kpad"]), dtype=torch.bfloat16, device=x.device)
+        hip.ch_im2col3(x, stride, cols, L["kpad"])
+        out = torch.empty((n * ho * wo, L["n"]), dtype=torch.float32, device=x.device)
+        hip.linear(cols, L["w"], spl=True, bias=L["b"], precision=hip.PREC_BF16X3, out=out)
+        return out.view(n, ho, wo, L["n"])
+
+    @staticmethod
+    def _frn_scale(x, F):
+        n, h, w, c = x.shape
+        return hip.ch_frn_stats(x, F["w"], F["eps"], torch.empty((n, c), dtype=torch.float32, device=x.device))
+
+    @staticmethod
+    def _gates(x, s, b, G):
+        n, h, w, c = x.shape
+        ph = torch.empty((n, h, c), dtype=torch.float32, device=x.device)
+        pw = torch.empty((n, w, c), dtype=torch.float32, device=x.device)
+        hip.ch_pool_hw(x, s, b, ph, pw)
+        ah, aw = torch.empty_like(ph), torch.empty_like(pw)
+        hip.ch_gates(ph, pw, G, ah, aw)
+        return ah, aw
+
+    def _frn_tlu(self, x, F, tau, G=None):
+        s = self._frn_scale(x, F)
+        ah = aw = None
+        if G is not None:
+            ah, aw = self._gates(x, s, F["b"], G)
+        return hip.ch_apply(x, s, F["b"], ah, aw, tau, torch.empty_like(x))
+
+    def _sandglass_plus(self, x1, S):
+        """x1 + SandGlass(x1) = 2 x1 + conv-stack(x1)  (models.py:226-233 adds x1 inside, 383-385 / 387-389 add it again)."""
+        n, h, w, c = x1.shape
+        y = hip.ch_dwconv3(x1, S["dw0"]["wt"], S["dw0"]["b"], torch.empty_like(x1), relu6_out=True)
+        ah, aw = self._gates(y, None, None, S["ca"])
+        y = hip.ch_apply(y, None, None, ah, aw, None, y)
+        rows = n * h * w
+        z = hip.linear(y.view(rows, c), S["pw0"]["w"], bias=S["pw0"]["b"], precision=hip.PREC_F32)
+        z = hip.ch_relu6(hip.linear(z, S["pw1"]["w"], bias=S["pw1"]["b"], precision=hip.PREC_F32)).view(n, h, w, c)
+        return hip.ch_dwconv3(z, S["dw1"]["wt"], S["dw1"]["b"], torch.empty_like(x1), res=x1, res_scale=2.0)
+
+    @torch.no_grad()
+    def _forward_nhwc(self, patches):
+        """patches: [n, 32, 32, 3] f32 on the GPU -> (desc [n, 128], raw [n, 128])."""
+        if patches.device.type != "cuda":
+            raise hip.GimsHipError("CARHyNet runs on the GPU only (no CPU fallback): move the patches to 'cuda'")
+        P = self._prepare(patches.device)
+        n = patches.shape[0]
+        x = torch.zeros((n, 32, 32, 4), dtype=torch.float32, device=patches.device)      # channel 3 = padding (weights are zero there)
+        x[..., :3] = patches
+        L = P["l1"]
+        x = self._frn_tlu(x, L["frn0"], L["tau0"])
+        x = self._frn_tlu(self._conv3(x, L["conv"], 1), L["frn"], L["tau"], L["ca"])
+        L = P["l2"]
+        x1 = self._frn_tlu(self._conv3(x, L["conv"], 1), L["frn"], L["tau"], L["ca"])
+        x = self._sandglass_plus(x1, P["sg2"])
+        x = self._frn_tlu(self._conv3(x, P["l3"]["conv"], 2), P["l3"]["frn"], P["l3"]["tau"])
+        x1 = self._frn_tlu(self._conv3(x, P["l4"]["conv"], 1), P["l4"]["frn"], P["l4"]["tau"])
+        x = self._sandglass_plus(x1, P["sg4"])
+        x = self._frn_tlu(self._conv3(x, P["l5"]["conv"], 2), P["l5"]["frn"], P["l5"]["tau"])
+        x = self._frn_tlu(self._conv3(x, P["l6"]["conv"], 1), P["l6"]["frn"], P["l6"]["tau"])
+        flat = hip.split_spl32(x.reshape(n, 8 * 8 * 128))
+        raw = torch.empty((n, 128), dtype=torch.float32, device=patches.device)
+        hip.linear(flat, P["l7"]["w"], spl=True, bias=P["l7"]["b"], precision=hip.PREC_BF16X3, out=raw)
+        desc = hip.ch_l2norm(raw, EPS_L2_NORM, torch.empty_like(raw))
+        return desc, raw
+
+    def forward(self, x, mode="eval"):
+        """x: [N, 3, 32, 32] like the reference's CAR_HyNet.forward (models.py:379); eval mode only."""
+        if self.training:
+            raise NotImplementedError("CARHyNet: training mode (Dropout, batch statistics) is not on the HIP path")
+        outs = [self._forward_nhwc(x[i:i + self.chunk].permute(0, 2, 3, 1).float().contiguous()) for i in range(0, x.shape[0], self.chunk)]
+        desc, raw = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        return (desc, raw) if mode == "train" else desc
+
+    def compute_des_batches(self, patches, color=True):
+        """HyNetnetFeature2D.compute_des_batches (models.py:655-666): NHWC patches in [0, 1] -> float32 [N, 128] NumPy array."""
+        if not color:
+            raise NotImplementedError("CARHyNet: the grey-level variant (HyNet, 1 input channel) is not built")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        out = np.zeros((len(patches), 128), dtype=np.float32)
+        for i in range(0, len(patches), self.chunk):
+            p = torch.from_numpy(np.ascontiguousarray(patches[i:i + self.chunk], dtype=np.float32)).to(dev)
+            out[i:i + self.chunk] = self._forward_nhwc(p)[0].cpu().numpy()
+        return out

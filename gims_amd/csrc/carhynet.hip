@@ -1,0 +1,277 @@
+// CAR-HyNet patch descriptor: the layers of /root/reference/carhynet/models.py:311-399 that are not
+// plain GEMMs.  Activations are NHWC f32 in HBM ([patch][y][x][channel]: a pixel's channels are contiguous, so a 3x3
+// convolution is im2col + the split-bf16 GEMM of linear.hip with output rows = pixels, and the GEMM's output IS the next
+// NHWC activation).  First version of this row: correct and parity-checked; the kernels below are simple streaming kernels
+// (one thread per output element or per (pixel, channel quad)), HBM-bound by design, not yet fused.
+//
+//   gims_ch_frn_stats     FRN's per-(patch, channel) scale  weight * rsqrt(mean over H x W of x^2 + |eps|)        models.py:67-82
+//   gims_ch_pool_hw       CoordAtt's two average pools (over W and over H), optionally of the FRN output    models.py:141-143
+//   gims_ch_gates         CoordAtt's shared 1x1 conv + BN + h_swish and the two 1x1 convs + sigmoid         models.py:144-151
+//   gims_ch_apply         y = max((x * s + b) * a_w * a_h, tau): FRN scale, CoordAtt gates, TLU in one pass models.py:78-84,152,107
+//   gims_ch_im2col3       3x3 patches (pad 1, stride 1 or 2) written as SPL32 split-bf16 GEMM operand rows
+//   gims_ch_dwconv3       depthwise 3x3 + folded BatchNorm (+ReLU6 on input / output, + residual)          models.py:172-180, 207, 220-223
+//   gims_ch_l2norm        x / sqrt(sum x^2 + 1e-10) per row                                                 models.py:9-21
+#include "common.h"
+
+namespace gims {
+
+// one workgroup per (patch, 32-channel group): 256 threads = 8 pixel lanes x 32 channels
+__global__ __launch_bounds__(256) void ch_frn_stats_kernel(const float* __restrict__ x, int hw, int c, const float* __restrict__ wgt, float eps,
+                                                           float* __restrict__ scale) {
+  __shared__ float red[8][32];
+  const int p = blockIdx.x, cg = blockIdx.y, cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int ch = cg * 32 + cl;
+  float s = 0.f;
+  if (ch < c) {
+    const float* xp = x + (int64_t)p * hw * c + ch;
+    for (int i = pl; i < hw; i += 8) { const float v = xp[(int64_t)i * c]; s = fmaf(v, v, s); }
+  }
+  red[pl][cl] = s;
+  __syncthreads();
+  if (pl == 0 && ch < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][cl];
+    scale[(int64_t)p * c + ch] = wgt[ch] * rsqrtf(t / (float)hw + eps);      // x * rsqrt(nu2 + |eps|) * weight (models.py:67-82)
+  }
+}
+
+// pooled means over W (ph[p][y][c]) and over H (pw[p][x][c]) of  x * s[p][c] + b[c]  (s, b may be null: identity).
+// One workgroup per (patch, 32-channel group); the patch slice goes through LDS once.
+__global__ __launch_bounds__(256) void ch_pool_hw_kernel(const float* __restrict__ x, int h, int w, int c, const float* __restrict__ s,
+                                                         const float* __restrict__ b, float* __restrict__ ph, float* __restrict__ pw) {
+  extern __shared__ float tile[];                 // [h*w][33]
+  const int p = blockIdx.x, cg = blockIdx.y, cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int ch = cg * 32 + cl, hw = h * w;
+  const bool ok = ch < c;
+  const float sc = (ok && s) ? s[(int64_t)p * c + ch] : 1.f, sh = (ok && b) ? b[ch] : 0.f;
+  const float* xp = x + (int64_t)p * hw * c + ch;
+  for (int i = pl; i < hw; i += 8) tile[i * 33 + cl] = ok ? fmaf(xp[(int64_t)i * c], sc, sh) : 0.f;
+  __syncthreads();
+  for (int y = pl; y < h; y += 8) {               // mean over x
+    float t = 0.f;
+    for (int xx = 0; xx < w; ++xx) t += tile[(y * w + xx) * 33 + cl];
+    if (ok) ph[((int64_t)p * h + y) * c + ch] = t / (float)w;
+  }
+  for (int xx = pl; xx < w; xx += 8) {            // mean over y
+    float t = 0.f;
+    for (int y = 0; y < h; ++y) t += tile[(y * w + xx) * 33 + cl];
+    if (ok) pw[((int64_t)p * w + xx) * c + ch] = t / (float)h;
+  }
+}
+
+// CoordAtt gates for one patch per workgroup: rows r = 0..h-1 from ph, h..h+w-1 from pw.
+//   mid[r][m] = h_swish(bn(conv1(row r)))  (8 channels; BatchNorm folded into w1 / b1 by the caller)
+//   a_h[y][ch] = sigmoid(conv_h(mid[y])),  a_w[x][ch] = sigmoid(conv_w(mid[h + x]))
+__global__ __launch_bounds__(256) void ch_gates_kernel(const float* __restrict__ ph, const float* __restrict__ pw, int h, int w, int c,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,      // [8][c], [8]
+                                                       const float* __restrict__ wh, const float* __restrict__ bh,      // [c][8], [c]
+                                                       const float* __restrict__ ww, const float* __restrict__ bw,
+                                                       float* __restrict__ ah, float* __restrict__ aw) {
+  __shared__ float mid[64][8];
+  const int p = blockIdx.x, t = threadIdx.x, rows = h + w;
+  for (int i = t; i < rows * 8; i += 256) {
+    const int r = i >> 3, m = i & 7;
+    const float* src = r < h ? ph + ((int64_t)p * h + r) * c : pw + ((int64_t)p * w + (r - h)) * c;
+    float acc = b1[m];
+    for (int k = 0; k < c; ++k) acc = fmaf(src[k], w1[m * c + k], acc);
+    mid[r][m] = acc * (fminf(fmaxf(acc + 3.f, 0.f), 6.f) / 6.f);
+  }
+  __syncthreads();
+  for (int i = t; i < rows * c; i += 256) {
+    const int r = i / c, ch = i - r * c;
+    const bool is_h = r < h;
+    const float* wt = (is_h ? wh : ww) + ch * 8;
+    float acc = (is_h ? bh : bw)[ch];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc = fmaf(mid[r][m], wt[m], acc);
+    const float g = 1.f / (1.f + __expf(-acc));
+    if (is_h) ah[((int64_t)p * h + r) * c + ch] = g;
+    else aw[((int64_t)p * w + (r - h)) * c + ch] = g;
+  }
+}
+
+// y[p][y][x][ch] = max((x * s[p][ch] + b[ch]) * ah[p][y][ch] * aw[p][x][ch], tau[ch]);  any of s/b, ah/aw, tau may be null.
+__global__ __launch_bounds__(256) void ch_apply_kernel(const float* __restrict__ x, int64_t total, int h, int w, int c, const float* __restrict__ s,
+                                                       const float* __restrict__ b, const float* __restrict__ ah, const float* __restrict__ aw,
+                                                       const float* __restrict__ tau, float* __restrict__ y) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= total) return;
+  const int ch = (int)(i4 % c);
+  const int64_t pix = i4 / c;
+  const int xx = (int)(pix % w), yy = (int)((pix / w) % h);
+  const int64_t p = pix / ((int64_t)w * h);
+  float4 v = *(const float4*)(x + i4);
+  float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = r[j];
+    if (s) t = fmaf(t, s[p * c + ch + j], b ? b[ch + j] : 0.f);
+    if (ah) t = t * aw[(p * w + xx) * c + ch + j] * ah[(p * h + yy) * c + ch + j];
+    if (tau) t = fmaxf(t, tau[ch + j]);
+    r[j] = t;
+  }
+  *(float4*)(y + i4) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// 3x3 neighbourhoods (pad 1) of an NHWC activation as rows of a split-bf16 (SPL32) GEMM operand:
+// out row = output pixel (p, yo, xo), logical column k = (ky * 3 + kx) * c + ch, K = 9 c zero-padded to kpad (multiple of 32).
+__global__ __launch_bounds__(256) void ch_im2col3_kernel(const float* __restrict__ x, int64_t rows, int h, int w, int c, int stride, int ho, int wo,
+                                                         int kpad, uint16_t* __restrict__ out, int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int kq = kpad / 4;                                   // column quads per row
+  if (i >= rows * kq) return;
+  const int64_t row = i / kq;
+  const int k = (int)(i - row * kq) * 4;
+  const int xo = (int)(row % wo), yo = (int)((row / wo) % ho);
+  const int64_t p = row / ((int64_t)wo * ho);
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kk = k + j;
+    float t = 0.f;
+    if (kk < 9 * c) {
+      const int tap = kk / c, ch = kk - tap * c;
+      const int yy = yo * stride + tap / 3 - 1, xx = xo * stride + tap % 3 - 1;
+      if (yy >= 0 && yy < h && xx >= 0 && xx < w) t = x[((p * h + yy) * w + xx) * c + ch];
+    }
+    v[j] = t;
+  }
+  const uint32_t h01 = pack_bf2(v[0], v[1]), h23 = pack_bf2(v[2], v[3]);
+  const uint32_t l01 = pack_bf2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
+  const uint32_t l23 = pack_bf2(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
+  uint16_t* o = out + row * ld + spl_col(k);
+  *(uint2*)o = make_uint2(h01, h23);
+  *(uint2*)(o + 32) = make_uint2(l01, l23);
+}
+
+// depthwise 3x3 (pad 1, stride 1) with BatchNorm folded into wt [9][c] / bias [c]; optional ReLU6 on the output;
+// optional residual: y = res_scale * res + conv.
+__global__ __launch_bounds__(256) void ch_dwconv3_kernel(const float* __restrict__ x, int64_t total, int h, int w, int c, const float* __restrict__ wt,
+                                                         const float* __restrict__ bias, int relu6_out, const float* __restrict__ res, float res_scale,
+                                                         float* __restrict__ y) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= total) return;
+  const int ch = (int)(i4 % c);
+  const int64_t pix = i4 / c;
+  const int xx = (int)(pix % w), yy = (int)((pix / w) % h);
+  const int64_t p = pix / ((int64_t)w * h);
+  float acc[4] = {bias[ch], bias[ch + 1], bias[ch + 2], bias[ch + 3]};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int y2 = yy + ky - 1, x2 = xx + kx - 1;
+      if (y2 < 0 || y2 >= h || x2 < 0 || x2 >= w) continue;
+      const float4 v = *(const float4*)(x + ((p * h + y2) * w + x2) * c + ch);
+      const float4 k4 = *(const float4*)(wt + (ky * 3 + kx) * c + ch);
+      acc[0] = fmaf(v.x, k4.x, acc[0]); acc[1] = fmaf(v.y, k4.y, acc[1]); acc[2] = fmaf(v.z, k4.z, acc[2]); acc[3] = fmaf(v.w, k4.w, acc[3]);
+    }
+  if (relu6_out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = fminf(fmaxf(acc[j], 0.f), 6.f);
+  }
+  if (res) {
+    const float4 r = *(const float4*)(res + i4);
+    acc[0] = fmaf(r.x, res_scale, acc[0]); acc[1] = fmaf(r.y, res_scale, acc[1]); acc[2] = fmaf(r.z, res_scale, acc[2]); acc[3] = fmaf(r.w, res_scale, acc[3]);
+  }
+  *(float4*)(y + i4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// one wave per row of `c` (<= 256) values: y = x / sqrt(sum x^2 + eps)
+__global__ __launch_bounds__(256) void ch_l2norm_kernel(const float* __restrict__ x, int64_t rows, int c, float eps, float* __restrict__ y) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[4], s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int k = lane + 64 * j; v[j] = k < c ? x[row * c + k] : 0.f; s = fmaf(v[j], v[j], s); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float inv = 1.f / sqrtf(s + eps);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int k = lane + 64 * j; if (k < c) y[row * c + k] = v[j] * inv; }
+}
+
+// elementwise clamp to [0, 6] (ReLU6 after a pointwise GEMM) and  y = a + b
+__global__ __launch_bounds__(256) void ch_relu6_kernel(float* __restrict__ x, int64_t total) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= total) return;
+  float4 v = *(float4*)(x + i4);
+  v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f); v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+  *(float4*)(x + i4) = v;
+}
+
+}  // namespace gims
+
+using namespace gims;
+
+extern "C" int gims_ch_frn_stats(const float* x, int64_t patches, int32_t hw, int32_t c, const float* weight, float eps, float* scale, void* stream) {
+  GIMS_CHECK_ARG(x && weight && scale && patches > 0 && hw > 0 && c > 0 && eps >= 0.f, "gims_ch_frn_stats: bad arguments");
+  hipLaunchKernelGGL(ch_frn_stats_kernel, dim3((unsigned)patches, (c + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, hw, c, weight, eps, scale);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_pool_hw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, float* ph, float* pw,
+                               void* stream) {
+  GIMS_CHECK_ARG(x && ph && pw && patches > 0 && h > 0 && w > 0 && c > 0 && h * w <= 1024, "gims_ch_pool_hw: bad arguments (h*w <= 1024)");
+  const size_t lds = (size_t)h * w * 33 * sizeof(float);
+  static bool attr = false;
+  if (!attr) { GIMS_HIP(hipFuncSetAttribute((const void*)ch_pool_hw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 33 * 4)); attr = true; }
+  hipLaunchKernelGGL(ch_pool_hw_kernel, dim3((unsigned)patches, (c + 31) / 32), dim3(256), lds, (hipStream_t)stream, x, h, w, c, s, b, ph, pw);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_gates(const float* ph, const float* pw, int64_t patches, int32_t h, int32_t w, int32_t c, const float* w1, const float* b1,
+                             const float* wh, const float* bh, const float* ww, const float* bw, float* ah, float* aw, void* stream) {
+  GIMS_CHECK_ARG(ph && pw && w1 && b1 && wh && bh && ww && bw && ah && aw && patches > 0 && h + w <= 64, "gims_ch_gates: bad arguments (h + w <= 64)");
+  hipLaunchKernelGGL(ch_gates_kernel, dim3((unsigned)patches), dim3(256), 0, (hipStream_t)stream, ph, pw, h, w, c, w1, b1, wh, bh, ww, bw, ah, aw);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_apply(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, const float* ah,
+                             const float* aw, const float* tau, float* y, void* stream) {
+  GIMS_CHECK_ARG(x && y && patches > 0 && (c % 4) == 0 && ((ah == nullptr) == (aw == nullptr)), "gims_ch_apply: bad arguments (c %% 4 == 0)");
+  const int64_t total = patches * h * w * c;
+  hipLaunchKernelGGL(ch_apply_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, total, h, w, c, s, b, ah, aw, tau, y);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_im2col3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, int32_t stride, uint16_t* out, int64_t ld,
+                               int32_t kpad, void* stream) {
+  GIMS_CHECK_ARG(x && out && patches > 0 && (stride == 1 || stride == 2) && (kpad % 32) == 0 && kpad >= 9 * c && ld >= 2 * (int64_t)kpad && (ld % 64) == 0,
+                 "gims_ch_im2col3: bad arguments (kpad %% 32 == 0, kpad >= 9c, ld >= 2 kpad, ld %% 64 == 0)");
+  const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+  const int64_t rows = patches * ho * wo, n = rows * (kpad / 4);
+  hipLaunchKernelGGL(ch_im2col3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows, h, w, c, stride, ho, wo, kpad, out, ld);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_dwconv3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* wt, const float* bias, int32_t relu6_out,
+                               const float* res, float res_scale, float* y, void* stream) {
+  GIMS_CHECK_ARG(x && y && wt && bias && patches > 0 && (c % 4) == 0, "gims_ch_dwconv3: bad arguments (c %% 4 == 0)");
+  const int64_t total = patches * h * w * c;
+  hipLaunchKernelGGL(ch_dwconv3_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, total, h, w, c, wt, bias, relu6_out, res,
+                     res_scale, y);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_l2norm(const float* x, int64_t rows, int32_t c, float eps, float* y, void* stream) {
+  GIMS_CHECK_ARG(x && y && rows > 0 && c > 0 && c <= 256, "gims_ch_l2norm: bad arguments (c <= 256)");
+  hipLaunchKernelGGL(ch_l2norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, y);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_relu6(float* x, int64_t total, void* stream) {
+  GIMS_CHECK_ARG(x && total > 0 && (total % 4) == 0, "gims_ch_relu6: bad arguments (total %% 4 == 0)");
+  hipLaunchKernelGGL(ch_relu6_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, total);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}

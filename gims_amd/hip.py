@@ -89,6 +89,15 @@ _SIGNATURES = {
     "gims_linear_put_many": (C.c_int, [C.POINTER(LinearArgs), C.c_int32, C.c_void_p, C.c_void_p]),
     "gims_linear_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_ch_frn_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "gims_ch_pool_hw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gims_ch_gates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 9),
+    "gims_ch_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7),
+    "gims_ch_im2col3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "gims_ch_dwconv3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float,
+                                  C.c_void_p, C.c_void_p]),
+    "gims_ch_l2norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "gims_ch_relu6": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_run_ops": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "gims_ops_graph_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gims_ops_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -540,3 +549,52 @@ def eval_pairs(items, dist_thresh=3.0, n_iters=3, ransac_thresh=3.0, ransac_iter
                                int(seed) & 0xFFFFFFFFFFFFFFFF, _p(work), work.numel() * work.element_size(), _stream()),
            "gims_eval_pairs")
     return work
+
+
+# ------------------------------------------------------------------------------------------------ CAR-HyNet ops (NHWC f32)
+def ch_frn_stats(x, weight, eps, scale):
+    n, h, w, c = x.shape
+    _check(load().gims_ch_frn_stats(_p(_dev(x, torch.float32)), n, h * w, c, _p(weight), float(eps), _p(scale), _stream()), "gims_ch_frn_stats")
+    return scale
+
+
+def ch_pool_hw(x, s, b, ph, pw):
+    n, h, w, c = x.shape
+    _check(load().gims_ch_pool_hw(_p(_dev(x, torch.float32)), n, h, w, c, _p(s), _p(b), _p(ph), _p(pw), _stream()), "gims_ch_pool_hw")
+
+
+def ch_gates(ph, pw, g, ah, aw):
+    n, h, c = ph.shape
+    w = pw.shape[1]
+    _check(load().gims_ch_gates(_p(ph), _p(pw), n, h, w, c, _p(g["w1"]), _p(g["b1"]), _p(g["wh"]), _p(g["bh"]), _p(g["ww"]), _p(g["bw"]),
+                                _p(ah), _p(aw), _stream()), "gims_ch_gates")
+
+
+def ch_apply(x, s, b, ah, aw, tau, y):
+    n, h, w, c = x.shape
+    _check(load().gims_ch_apply(_p(_dev(x, torch.float32)), n, h, w, c, _p(s), _p(b), _p(ah), _p(aw), _p(tau), _p(y), _stream()), "gims_ch_apply")
+    return y
+
+
+def ch_im2col3(x, stride, out, kpad):
+    n, h, w, c = x.shape
+    _check(load().gims_ch_im2col3(_p(_dev(x, torch.float32)), n, h, w, c, stride, _p(out), out.stride(0), kpad, _stream()), "gims_ch_im2col3")
+    return out
+
+
+def ch_dwconv3(x, wt, bias, y, relu6_out=False, res=None, res_scale=1.0):
+    n, h, w, c = x.shape
+    _check(load().gims_ch_dwconv3(_p(_dev(x, torch.float32)), n, h, w, c, _p(wt), _p(bias), 1 if relu6_out else 0, _p(res), float(res_scale),
+                                  _p(y), _stream()), "gims_ch_dwconv3")
+    return y
+
+
+def ch_l2norm(x, eps, y):
+    rows, c = x.shape
+    _check(load().gims_ch_l2norm(_p(_dev(x, torch.float32)), rows, c, float(eps), _p(y), _stream()), "gims_ch_l2norm")
+    return y
+
+
+def ch_relu6(x):
+    _check(load().gims_ch_relu6(_p(_dev(x, torch.float32)), x.numel(), _stream()), "gims_ch_relu6")
+    return x

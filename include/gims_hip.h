@@ -323,6 +323,33 @@ int gims_eval_pairs(const gims_eval_pair* h_pairs /* HOST array */, int32_t n_pa
 int gims_ot_matrix(const float* scores, int64_t ld, int32_t n, int32_t m, float alpha, const float* uv,
                    float* out /* [(n+1)][(m+1)] */, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * CAR-HyNet patch descriptor: the non-GEMM layers of carhynet/models.py:311-399.  Activations are NHWC
+ * f32 ([patch][y][x][channel]); the 3x3 and 8x8 convolutions are gims_ch_im2col3 / a reshape + gims_linear (split-bf16x3),
+ * the 1x1 convolutions gims_linear directly.  BatchNorm (eval) is folded into weights / biases by the caller.
+ *   gims_ch_frn_stats: scale[p][c] = weight[c] * rsqrt(mean over the hw pixels of x^2 + eps)          (FRN, models.py:67-82)
+ *   gims_ch_pool_hw:   ph[p][y][c] = mean_x(x*s+b), pw[p][x][c] = mean_y(x*s+b); s [p][c], b [c] may be NULL  (CoordAtt 141-143)
+ *   gims_ch_gates:     CoordAtt's conv1(+BN folded)+h_swish over the h+w pooled rows, then conv_h / conv_w + sigmoid (144-151);
+ *                      w1 [8][c], b1 [8], wh / ww [c][8], bh / bw [c];  h + w <= 64
+ *   gims_ch_apply:     y = max((x*s[p][c] + b[c]) * ah[p][y][c] * aw[p][x][c], tau[c]); s/b, ah/aw, tau each optional (78-84,152,107)
+ *   gims_ch_im2col3:   3x3 neighbourhoods (pad 1, stride 1|2) as SPL32 rows: column (ky*3+kx)*c + ch, zero-padded to kpad
+ *   gims_ch_dwconv3:   depthwise 3x3 (pad 1) with wt [9][c], bias [c] (BatchNorm folded), optional ReLU6, optional
+ *                      y += res_scale * res                                                            (172-180, 207, 220-233)
+ *   gims_ch_l2norm:    y = x / sqrt(sum_c x^2 + eps) per row                                           (desc_l2norm, 9-21)
+ *   gims_ch_relu6:     in-place clamp to [0, 6]
+ */
+int gims_ch_frn_stats(const float* x, int64_t patches, int32_t hw, int32_t c, const float* weight, float eps, float* scale, void* stream);
+int gims_ch_pool_hw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, float* ph, float* pw, void* stream);
+int gims_ch_gates(const float* ph, const float* pw, int64_t patches, int32_t h, int32_t w, int32_t c, const float* w1, const float* b1,
+                  const float* wh, const float* bh, const float* ww, const float* bw, float* ah, float* aw, void* stream);
+int gims_ch_apply(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, const float* ah, const float* aw,
+                  const float* tau, float* y, void* stream);
+int gims_ch_im2col3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, int32_t stride, uint16_t* out, int64_t ld, int32_t kpad, void* stream);
+int gims_ch_dwconv3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* wt, const float* bias, int32_t relu6_out,
+                    const float* res, float res_scale, float* y, void* stream);
+int gims_ch_l2norm(const float* x, int64_t rows, int32_t c, float eps, float* y, void* stream);
+int gims_ch_relu6(float* x, int64_t total, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
