@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Measurement of the CAR-HyNet descriptor stage (BASELINE config 5: descriptors for 2 x 8192 keypoints).
+
+    python tools/carhynet_bench.py [--patches 16384] [--reps 5] [--no-cpu]
+
+Prints ONE JSON line: patches/s with the patches resident in HBM, the algorithmic flop rate against the bf16 MFMA peak
+(84.5 MFLOP per patch; the convolutions run as 3-pass split-bf16 GEMMs, so the ceiling is a third of the peak),
+and the CPU baseline (the restatement in oracle/carhynet_oracle.py, i.e. PyTorch CPU convolutions, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+FLOP_PER_PATCH = 84.5e6          # SURVEY 8f (torch flop counter on the reference module)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--patches", type=int, default=16384)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    import __graft_entry__
+    __graft_entry__.build()
+    from gims_amd import synth
+    from gims_amd.carhynet import CARHyNet
+    torch.set_grad_enabled(False)
+    m = CARHyNet().eval()
+    m.load_state_dict(synth.make_carhynet_state_dict(321))
+    base = synth.make_patches(256, 5)
+    patches = torch.from_numpy(np.tile(base, (a.patches // 256 + 1, 1, 1, 1))[:a.patches]).cuda()
+    x = patches.permute(0, 3, 1, 2)                     # the reference's NCHW view; forward() chunks internally
+    for _ in range(2):
+        d = m(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        d = m(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.reps
+    out = {"metric": "CAR-HyNet descriptors/sec (32x32x3 patches resident in HBM)", "value": a.patches / dt, "unit": "patches/s",
+           "patches": a.patches, "ms_per_batch": 1e3 * dt, "dtype": "split-bf16x3 MFMA convolutions (f32-class) + f32 FRN / CoordAtt / depthwise",
+           "roofline": {"bound": "mfma", "achieved": a.patches * FLOP_PER_PATCH / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": a.patches * FLOP_PER_PATCH / dt / 1e12 / 2500.0,
+                        "note": "algorithmic flops; first version of this row: im2col + GEMM per layer with NHWC f32 activations in HBM, not fused"},
+           "descriptor_norm_check": float(d.norm(dim=1).mean())}
+    if not a.no_cpu:
+        from oracle import carhynet_oracle as CO
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_carhynet_state_dict(321).items()}
+        sample = torch.from_numpy(base)
+        CO.car_hynet_forward(sd, sample[:64])
+        done, t_used = 0, 0.0
+        while t_used < 10.0 and done < 64:
+            t1 = time.perf_counter()
+            ref, _ = CO.car_hynet_forward(sd, sample)
+            t_used += time.perf_counter() - t1
+            done += 1
+        err = float((ref - d[:256].cpu()).abs().max())
+        out["cpu_baseline"] = {"value": done * 256 / t_used, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{done} batches of 256 patches, oracle/carhynet_oracle.py (torch CPU, {t_used:.1f} s)"}
+        out["max_abs_err_vs_cpu"] = err
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
