@@ -37,27 +37,25 @@ __global__ __launch_bounds__(256) void ch_frn_stats_kernel(const float* __restri
 }
 
 // pooled means over W (ph[p][y][c]) and over H (pw[p][x][c]) of  x * s[p][c] + b[c]  (s, b may be null: identity).
-// One workgroup per (patch, 32-channel group); the patch slice goes through LDS once.
-__global__ __launch_bounds__(256) void ch_pool_hw_kernel(const float* __restrict__ x, int h, int w, int c, const float* __restrict__ s,
+// One thread per output element: blockIdx.y = 0 -> ph (sum over x), 1 -> pw (sum over y); consecutive threads = consecutive
+// channels, so every load of the 32-step loop is a contiguous line across the wave.  The patch is read twice (once per
+// direction), from L2 the second time.
+__global__ __launch_bounds__(256) void ch_pool_hw_kernel(const float* __restrict__ x, int64_t patches, int h, int w, int c, const float* __restrict__ s,
                                                          const float* __restrict__ b, float* __restrict__ ph, float* __restrict__ pw) {
-  extern __shared__ float tile[];                 // [h*w][33]
-  const int p = blockIdx.x, cg = blockIdx.y, cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int ch = cg * 32 + cl, hw = h * w;
-  const bool ok = ch < c;
-  const float sc = (ok && s) ? s[(int64_t)p * c + ch] : 1.f, sh = (ok && b) ? b[ch] : 0.f;
-  const float* xp = x + (int64_t)p * hw * c + ch;
-  for (int i = pl; i < hw; i += 8) tile[i * 33 + cl] = ok ? fmaf(xp[(int64_t)i * c], sc, sh) : 0.f;
-  __syncthreads();
-  for (int y = pl; y < h; y += 8) {               // mean over x
-    float t = 0.f;
-    for (int xx = 0; xx < w; ++xx) t += tile[(y * w + xx) * 33 + cl];
-    if (ok) ph[((int64_t)p * h + y) * c + ch] = t / (float)w;
-  }
-  for (int xx = pl; xx < w; xx += 8) {            // mean over y
-    float t = 0.f;
-    for (int y = 0; y < h; ++y) t += tile[(y * w + xx) * 33 + cl];
-    if (ok) pw[((int64_t)p * w + xx) * c + ch] = t / (float)h;
-  }
+  const bool over_x = blockIdx.y == 0;
+  const int n_line = over_x ? h : w, n_sum = over_x ? w : h;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= patches * n_line * c) return;
+  const int ch = (int)(i % c);
+  const int line = (int)((i / c) % n_line);
+  const int64_t p = i / ((int64_t)c * n_line);
+  const float* xp = x + (p * h * w + (over_x ? (int64_t)line * w : line)) * c + ch;
+  const int64_t step = over_x ? c : (int64_t)w * c;
+  float t = 0.f;
+  for (int k = 0; k < n_sum; ++k) t += xp[k * step];
+  t /= (float)n_sum;
+  if (s) t = fmaf(t, s[p * c + ch], b ? b[ch] : 0.f);      // the mean of an affine map is the affine map of the mean
+  (over_x ? ph : pw)[i] = t;
 }
 
 // CoordAtt gates for one patch per workgroup: rows r = 0..h-1 from ph, h..h+w-1 from pw.
@@ -215,11 +213,9 @@ extern "C" int gims_ch_frn_stats(const float* x, int64_t patches, int32_t hw, in
 
 extern "C" int gims_ch_pool_hw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, float* ph, float* pw,
                                void* stream) {
-  GIMS_CHECK_ARG(x && ph && pw && patches > 0 && h > 0 && w > 0 && c > 0 && h * w <= 1024, "gims_ch_pool_hw: bad arguments (h*w <= 1024)");
-  const size_t lds = (size_t)h * w * 33 * sizeof(float);
-  static bool attr = false;
-  if (!attr) { GIMS_HIP(hipFuncSetAttribute((const void*)ch_pool_hw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 33 * 4)); attr = true; }
-  hipLaunchKernelGGL(ch_pool_hw_kernel, dim3((unsigned)patches, (c + 31) / 32), dim3(256), lds, (hipStream_t)stream, x, h, w, c, s, b, ph, pw);
+  GIMS_CHECK_ARG(x && ph && pw && patches > 0 && h > 0 && w > 0 && c > 0, "gims_ch_pool_hw: bad arguments");
+  const int64_t n = patches * (h > w ? h : w) * c;
+  hipLaunchKernelGGL(ch_pool_hw_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, x, patches, h, w, c, s, b, ph, pw);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

@@ -654,6 +654,24 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 4, 1>), g, dim3(512), lds_h, s, *a);
       else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2, 2>), g, dim3(512), lds, s, *a);
       else hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), g, dim3(512), lds, s, *a);
+    } else if (a->n <= 64 && !(a->flags & (GIMS_LINEAR_HI_ONLY | GIMS_LINEAR_A1_HI_ONLY)) && force == 0) {
+      // narrow outputs (the 32- and 64-channel convolutions of the descriptor network, millions of rows): 128 x 32 / 128 x 64
+      // tiles instead of wasting three quarters / half of a 128-wide one
+      using T32 = X3P<128, 32, 4, 1, 2>;
+      using T64 = X3P<128, 64, 2, 2, 2>;
+      static bool attr3 = false;
+      if (!attr3) {
+        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 32, 4, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T32::LDS_BYTES));
+        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 64, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T64::LDS_BYTES));
+        attr3 = true;
+      }
+      if (a->n <= 32) {
+        constexpr size_t lds = T32::LDS_BYTES;
+        hipLaunchKernelGGL((linear_x3p_kernel<128, 32, 4, 1, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 32)), dim3(256), lds, s, *a);
+      } else {
+        constexpr size_t lds = T64::LDS_BYTES;
+        hipLaunchKernelGGL((linear_x3p_kernel<128, 64, 2, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 64)), dim3(256), lds, s, *a);
+      }
     } else {
       using TSH = X3P<128, 128, 2, 2, 4, true>;
       constexpr size_t lds = TS::LDS_BYTES, lds_h = TSH::LDS_BYTES;

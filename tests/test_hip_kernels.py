@@ -71,7 +71,8 @@ def test_linear(hip, prec, m, n, k, k0):
 
 
 @pytest.mark.parametrize("m,n,k,k0", [(128, 128, 32, 32), (300, 768, 256, 256), (1000, 512, 512, 256), (77, 100, 128, 64),
-                                       (4096, 256, 512, 512), (513, 132, 64, 32), (60000, 256, 256, 256)])
+                                       (4096, 256, 512, 512), (513, 132, 64, 32), (60000, 256, 256, 256),
+                                       (5000, 32, 288, 288), (777, 64, 576, 576), (130, 28, 64, 32), (4100, 48, 96, 96)])    # narrow-N tiles
 def test_linear_presplit(hip, m, n, k, k0):
     """LDS-DMA kernel on pre-split bf16 planes: same contract as gims_linear, all three output kinds at once."""
     r = _rng(m * 3 + n)
