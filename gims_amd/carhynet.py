@@ -6,8 +6,9 @@ Mirrors the reference's interface for this stage (carhynet/models.py):
     reference's NCHW float input and returns L2-normalised [N, 128] descriptors (eval mode only, models.py:379-399);
   * ``compute_des_batches(patches, color=True)`` takes NHWC patches in [0, 1] like ``HyNetnetFeature2D`` (models.py:655-666)
     and returns a float32 NumPy array.
-All arithmetic runs in libgims_hip.so: activations are NHWC f32 in HBM, every 3x3 convolution is ``gims_ch_im2col3`` + the
-split-bf16x3 GEMM (``gims_linear``: f32-class accuracy), the 8x8 convolution is that GEMM on the flattened 8x8x128
+All arithmetic runs in libgims_hip.so: activations are NHWC f32 in HBM, every 3x3 convolution is the split-bf16x3 GEMM (``gims_linear``:
+f32-class accuracy) reading its operand rows straight from the 3x3 neighbourhood of the SPL32 pixel rows (GIMS_LINEAR_CONV3;
+only the 3-channel first layer materialises them with ``gims_ch_im2col3``), the 8x8 convolution is that GEMM on the flattened 8x8x128
 activation, 1x1 convolutions are ``gims_linear`` in f32, and FRN / TLU / CoordAtt / depthwise stages are the ``gims_ch_*``
 kernels.  BatchNorm (eval) is folded into the neighbouring weights.  No CPU fallback.
 """
@@ -124,18 +125,33 @@ class CARHyNet(nn.Module):
                  l5=dict(conv=conv3("layer5.0."), frn=frn("layer5.1."), tau=tau("layer5.2.")),
                  l6=dict(conv=conv3("layer6.0."), frn=frn("layer6.1."), tau=tau("layer6.2.")),
                  l7=dict(w=hip.split_spl32(f32(w7)), b=f32(sh7)))
+        self._zeros = torch.zeros(256, dtype=torch.bfloat16, device=dev)      # the out-of-image operand row of GIMS_LINEAR_CONV3
         self._pack = P
         return P
 
     # ------------------------------------------------------------------ layers
     @staticmethod
-    def _conv3(x, L, stride):
+    def _spl(rows, c, dev):
+        """SPL32 split-bf16 pixel rows of an NHWC activation: [rows, 2c]."""
+        return torch.empty((rows, 2 * c), dtype=torch.bfloat16, device=dev)
+
+    @staticmethod
+    def _conv3_im2col(x, L, stride):
+        """First layer only (4 input channels: not a multiple of 32): materialised 3x3 neighbourhoods + GEMM."""
         n, h, w, c = x.shape
         ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
         cols = torch.empty((n * ho * wo, 2 * L["kpad"]), dtype=torch.bfloat16, device=x.device)
         hip.ch_im2col3(x, stride, cols, L["kpad"])
         out = torch.empty((n * ho * wo, L["n"]), dtype=torch.float32, device=x.device)
         hip.linear(cols, L["w"], spl=True, bias=L["b"], precision=hip.PREC_BF16X3, out=out)
+        return out.view(n, ho, wo, L["n"])
+
+    def _conv3(self, xs, n, h, w, L, stride):
+        """3x3 convolution straight from the split-bf16 pixel rows xs [n*h*w, 2C] (GIMS_LINEAR_CONV3: no im2col buffer)."""
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        out = torch.empty((n * ho * wo, L["n"]), dtype=torch.float32, device=xs.device)
+        args = hip.linear_args(xs, L["w"], a1=self._zeros, bias=L["b"], out=out, precision=hip.PREC_BF16X3, spl=True, conv=(h, w, stride), m=n * ho * wo)
+        hip._check(hip.load().gims_linear(hip.C.byref(args), hip._stream()), "gims_linear(conv3)")
         return out.view(n, ho, wo, L["n"])
 
     @staticmethod
@@ -153,15 +169,20 @@ class CARHyNet(nn.Module):
         hip.ch_gates(ph, pw, G, ah, aw)
         return ah, aw
 
-    def _frn_tlu(self, x, F, tau, G=None):
+    def _frn_tlu(self, x, F, tau, G=None, split=False):
+        """FRN (+ CoordAtt) + TLU; split=True: the result as SPL32 pixel rows for the next convolution instead of f32."""
+        n, h, w, c = x.shape
         s = self._frn_scale(x, F)
         ah = aw = None
         if G is not None:
             ah, aw = self._gates(x, s, F["b"], G)
+        if split:
+            return hip.ch_apply(x, s, F["b"], ah, aw, tau, None, self._spl(n * h * w, c, x.device))
         return hip.ch_apply(x, s, F["b"], ah, aw, tau, torch.empty_like(x))
 
     def _sandglass_plus(self, x1, S):
-        """x1 + SandGlass(x1) = 2 x1 + conv-stack(x1)  (models.py:226-233 adds x1 inside, 383-385 / 387-389 add it again)."""
+        """x1 + SandGlass(x1) = 2 x1 + conv-stack(x1)  (models.py:226-233 adds x1 inside, 383-385 / 387-389 add it again);
+        returned as SPL32 pixel rows (it only feeds the next 3x3 convolution)."""
         n, h, w, c = x1.shape
         y = hip.ch_dwconv3(x1, S["dw0"]["wt"], S["dw0"]["b"], torch.empty_like(x1), relu6_out=True)
         ah, aw = self._gates(y, None, None, S["ca"])
@@ -169,7 +190,7 @@ class CARHyNet(nn.Module):
         rows = n * h * w
         z = hip.linear(y.view(rows, c), S["pw0"]["w"], bias=S["pw0"]["b"], precision=hip.PREC_F32)
         z = hip.ch_relu6(hip.linear(z, S["pw1"]["w"], bias=S["pw1"]["b"], precision=hip.PREC_F32)).view(n, h, w, c)
-        return hip.ch_dwconv3(z, S["dw1"]["wt"], S["dw1"]["b"], torch.empty_like(x1), res=x1, res_scale=2.0)
+        return hip.ch_dwconv3(z, S["dw1"]["wt"], S["dw1"]["b"], None, res=x1, res_scale=2.0, y_split=self._spl(rows, c, x1.device))
 
     @torch.no_grad()
     def _forward_nhwc(self, patches):
@@ -182,18 +203,19 @@ class CARHyNet(nn.Module):
         x[..., :3] = patches
         L = P["l1"]
         x = self._frn_tlu(x, L["frn0"], L["tau0"])
-        x = self._frn_tlu(self._conv3(x, L["conv"], 1), L["frn"], L["tau"], L["ca"])
+        xs = self._frn_tlu(self._conv3_im2col(x, L["conv"], 1), L["frn"], L["tau"], L["ca"], split=True)
         L = P["l2"]
-        x1 = self._frn_tlu(self._conv3(x, L["conv"], 1), L["frn"], L["tau"], L["ca"])
-        x = self._sandglass_plus(x1, P["sg2"])
-        x = self._frn_tlu(self._conv3(x, P["l3"]["conv"], 2), P["l3"]["frn"], P["l3"]["tau"])
-        x1 = self._frn_tlu(self._conv3(x, P["l4"]["conv"], 1), P["l4"]["frn"], P["l4"]["tau"])
-        x = self._sandglass_plus(x1, P["sg4"])
-        x = self._frn_tlu(self._conv3(x, P["l5"]["conv"], 2), P["l5"]["frn"], P["l5"]["tau"])
-        x = self._frn_tlu(self._conv3(x, P["l6"]["conv"], 1), P["l6"]["frn"], P["l6"]["tau"])
-        flat = hip.split_spl32(x.reshape(n, 8 * 8 * 128))
+        x1 = self._frn_tlu(self._conv3(xs, n, 32, 32, L["conv"], 1), L["frn"], L["tau"], L["ca"])
+        xs = self._sandglass_plus(x1, P["sg2"])
+        xs = self._frn_tlu(self._conv3(xs, n, 32, 32, P["l3"]["conv"], 2), P["l3"]["frn"], P["l3"]["tau"], split=True)
+        x1 = self._frn_tlu(self._conv3(xs, n, 16, 16, P["l4"]["conv"], 1), P["l4"]["frn"], P["l4"]["tau"])
+        xs = self._sandglass_plus(x1, P["sg4"])
+        xs = self._frn_tlu(self._conv3(xs, n, 16, 16, P["l5"]["conv"], 2), P["l5"]["frn"], P["l5"]["tau"], split=True)
+        xs = self._frn_tlu(self._conv3(xs, n, 8, 8, P["l6"]["conv"], 1), P["l6"]["frn"], P["l6"]["tau"], split=True)
+        # [n*64 pixels, 2*128] SPL32 rows ARE the SPL32 layout of the flattened [n, 8*8*128] activation (32-channel blocks never
+        # straddle a pixel): the 8x8 convolution is one GEMM on a view
         raw = torch.empty((n, 128), dtype=torch.float32, device=patches.device)
-        hip.linear(flat, P["l7"]["w"], spl=True, bias=P["l7"]["b"], precision=hip.PREC_BF16X3, out=raw)
+        hip.linear(xs.view(n, 64 * 256), P["l7"]["w"], spl=True, bias=P["l7"]["b"], precision=hip.PREC_BF16X3, out=raw)
         desc = hip.ch_l2norm(raw, EPS_L2_NORM, torch.empty_like(raw))
         return desc, raw
 

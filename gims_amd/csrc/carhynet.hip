@@ -89,10 +89,20 @@ __global__ __launch_bounds__(256) void ch_gates_kernel(const float* __restrict__
   }
 }
 
+// four consecutive channels of one pixel as split-bf16 (SPL32: hi at o, lo at o + 32)
+__device__ __forceinline__ void store_split4(uint16_t* o, const float (&v)[4]) {
+  const uint32_t h01 = pack_bf2(v[0], v[1]), h23 = pack_bf2(v[2], v[3]);
+  const uint32_t l01 = pack_bf2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
+  const uint32_t l23 = pack_bf2(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
+  *(uint2*)o = make_uint2(h01, h23);
+  *(uint2*)(o + 32) = make_uint2(l01, l23);
+}
+
 // y[p][y][x][ch] = max((x * s[p][ch] + b[ch]) * ah[p][y][ch] * aw[p][x][ch], tau[ch]);  any of s/b, ah/aw, tau may be null.
+// Output as f32 NHWC (y) and / or as SPL32 split-bf16 pixel rows (ysp, pitch ldsp): the operand of the next convolution.
 __global__ __launch_bounds__(256) void ch_apply_kernel(const float* __restrict__ x, int64_t total, int h, int w, int c, const float* __restrict__ s,
                                                        const float* __restrict__ b, const float* __restrict__ ah, const float* __restrict__ aw,
-                                                       const float* __restrict__ tau, float* __restrict__ y) {
+                                                       const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp, int64_t ldsp) {
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= total) return;
   const int ch = (int)(i4 % c);
@@ -109,7 +119,8 @@ __global__ __launch_bounds__(256) void ch_apply_kernel(const float* __restrict__
     if (tau) t = fmaxf(t, tau[ch + j]);
     r[j] = t;
   }
-  *(float4*)(y + i4) = make_float4(r[0], r[1], r[2], r[3]);
+  if (y) *(float4*)(y + i4) = make_float4(r[0], r[1], r[2], r[3]);
+  if (ysp) store_split4(ysp + pix * ldsp + spl_col(ch), r);
 }
 
 // 3x3 neighbourhoods (pad 1) of an NHWC activation as rows of a split-bf16 (SPL32) GEMM operand:
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) void ch_im2col3_kernel(const float* __restrict
 // optional residual: y = res_scale * res + conv.
 __global__ __launch_bounds__(256) void ch_dwconv3_kernel(const float* __restrict__ x, int64_t total, int h, int w, int c, const float* __restrict__ wt,
                                                          const float* __restrict__ bias, int relu6_out, const float* __restrict__ res, float res_scale,
-                                                         float* __restrict__ y) {
+                                                         float* __restrict__ y, uint16_t* __restrict__ ysp, int64_t ldsp) {
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= total) return;
   const int ch = (int)(i4 % c);
@@ -173,7 +184,8 @@ __global__ __launch_bounds__(256) void ch_dwconv3_kernel(const float* __restrict
     const float4 r = *(const float4*)(res + i4);
     acc[0] = fmaf(r.x, res_scale, acc[0]); acc[1] = fmaf(r.y, res_scale, acc[1]); acc[2] = fmaf(r.z, res_scale, acc[2]); acc[3] = fmaf(r.w, res_scale, acc[3]);
   }
-  *(float4*)(y + i4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  if (y) *(float4*)(y + i4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  if (ysp) store_split4(ysp + pix * ldsp + spl_col(ch), acc);
 }
 
 // one wave per row of `c` (<= 256) values: y = x / sqrt(sum x^2 + eps)
@@ -229,10 +241,12 @@ extern "C" int gims_ch_gates(const float* ph, const float* pw, int64_t patches, 
 }
 
 extern "C" int gims_ch_apply(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, const float* ah,
-                             const float* aw, const float* tau, float* y, void* stream) {
-  GIMS_CHECK_ARG(x && y && patches > 0 && (c % 4) == 0 && ((ah == nullptr) == (aw == nullptr)), "gims_ch_apply: bad arguments (c %% 4 == 0)");
+                             const float* aw, const float* tau, float* y, uint16_t* y_split, int64_t ld_split, void* stream) {
+  GIMS_CHECK_ARG(x && (y || y_split) && patches > 0 && (c % 4) == 0 && ((ah == nullptr) == (aw == nullptr)), "gims_ch_apply: bad arguments (c %% 4 == 0)");
+  GIMS_CHECK_ARG(!y_split || ((c % 32) == 0 && ld_split >= 2 * (int64_t)c && (ld_split % 4) == 0), "gims_ch_apply: split output needs c %% 32 == 0, pitch >= 2c");
   const int64_t total = patches * h * w * c;
-  hipLaunchKernelGGL(ch_apply_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, total, h, w, c, s, b, ah, aw, tau, y);
+  hipLaunchKernelGGL(ch_apply_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, total, h, w, c, s, b, ah, aw, tau, y,
+                     y_split, ld_split);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }
@@ -249,11 +263,12 @@ extern "C" int gims_ch_im2col3(const float* x, int64_t patches, int32_t h, int32
 }
 
 extern "C" int gims_ch_dwconv3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* wt, const float* bias, int32_t relu6_out,
-                               const float* res, float res_scale, float* y, void* stream) {
-  GIMS_CHECK_ARG(x && y && wt && bias && patches > 0 && (c % 4) == 0, "gims_ch_dwconv3: bad arguments (c %% 4 == 0)");
+                               const float* res, float res_scale, float* y, uint16_t* y_split, int64_t ld_split, void* stream) {
+  GIMS_CHECK_ARG(x && (y || y_split) && wt && bias && patches > 0 && (c % 4) == 0, "gims_ch_dwconv3: bad arguments (c %% 4 == 0)");
+  GIMS_CHECK_ARG(!y_split || ((c % 32) == 0 && ld_split >= 2 * (int64_t)c && (ld_split % 4) == 0), "gims_ch_dwconv3: split output needs c %% 32 == 0, pitch >= 2c");
   const int64_t total = patches * h * w * c;
   hipLaunchKernelGGL(ch_dwconv3_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, total, h, w, c, wt, bias, relu6_out, res,
-                     res_scale, y);
+                     res_scale, y, y_split, ld_split);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

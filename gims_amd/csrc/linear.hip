@@ -305,7 +305,8 @@ struct X3P {
   __device__ static __forceinline__ int off(int row, int chunk) { return row * ROWE + ((chunk ^ swz(row)) << 3); }
 };
 
-// HI_ONLY: 1 = GIMS_LINEAR_HI_ONLY (one MFMA pass, hi planes), 2 = GIMS_LINEAR_A1_HI_ONLY (that for the second K segment only)
+// HI_ONLY: 1 = GIMS_LINEAR_HI_ONLY (one MFMA pass, hi planes), 2 = GIMS_LINEAR_A1_HI_ONLY (that for the second K segment only),
+// 4 = GIMS_LINEAR_CONV3 (all three passes; the A rows are gathered from the 3x3 neighbourhood of an NHWC activation)
 template <int TM, int TN, int WM, int WN, int S, int HI_ONLY = 0>
 __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_args p) {
   using T = X3P<TM, TN, WM, WN, S, HI_ONLY == 1>;
@@ -329,6 +330,21 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   const int p0 = wave * T::PIECES;
   constexpr int CPR = T::ROWE / 8;                         // 16-byte chunks per stage row (8, or 4 for the hi-only rows)
   const int drow = lane / CPR, dpos = lane % CPR;
+  // conv mode: this lane's A rows are output pixels; their input coordinates are fixed over the K loop
+  constexpr bool CONV = HI_ONLY == 4;
+  int cy[T::PIECES], cx[T::PIECES];
+  int64_t cb[T::PIECES];
+  const int cC = CONV ? p.k / 9 : 1;
+  if (CONV) {
+    const int wo = (p.conv_w - 1) / p.conv_stride + 1, ho = (p.conv_h - 1) / p.conv_stride + 1;
+#pragma unroll
+    for (int i = 0; i < T::PIECES; ++i) {
+      int gr = m0 + T::RPP * (p0 + i) + drow;
+      gr = gr < p.m - 1 ? gr : p.m - 1;
+      const int t2 = gr / wo, xo = gr - t2 * wo, pi = t2 / ho, yo = t2 - pi * ho;
+      cy[i] = yo * p.conv_stride; cx[i] = xo * p.conv_stride; cb[i] = (int64_t)pi * p.conv_h * p.conv_w;
+    }
+  }
   auto issue = [&](int kt) {
     const int k = kt * BK;
     const bool second = k >= p.k0;
@@ -346,6 +362,13 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
       gr = gr < rmax ? gr : rmax;
       const uint16_t* g = (is_a ? abase + (int64_t)gr * alda + 2 * akk : (const uint16_t*)p.w + (int64_t)gr * p.ldw + 2 * k)
                           + 8 * (dpos ^ T::swz(row));   // SPL32: block k/32 starts at element 2*k
+      if (CONV && is_a) {                                  // tap (ky, kx) and channel block of this K step; zeros outside the image
+        const int tap = k / cC, c0 = k - tap * cC;
+        const int y = cy[i] + tap / 3 - 1, x = cx[i] + tap % 3 - 1;
+        const bool inb = y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w;
+        g = inb ? (const uint16_t*)p.a0 + (cb[i] + (int64_t)y * p.conv_w + x) * p.lda0 + 2 * c0 + 8 * (dpos ^ T::swz(row))
+                : (const uint16_t*)p.a1 + 8 * dpos;
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(dst + i * 512), 16, 0, 0);
     }
@@ -390,7 +413,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
       }
       // term-major order: consecutive MFMAs hit DIFFERENT accumulators (no back-to-back dependent issue); per
       // accumulator the order stays lo*hi, hi*lo, hi*hi (small terms first)
-      if (HI_ONLY == 0 || (HI_ONLY == 2 && kt * BK < p.k0)) {
+      if (HI_ONLY == 0 || HI_ONLY == 4 || (HI_ONLY == 2 && kt * BK < p.k0)) {
 #pragma unroll
         for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
@@ -546,11 +569,17 @@ static int linear_validate(const gims_linear_args* a) {
                    "gims_linear(bf16x6): plain scaled product only");
     return GIMS_OK;
   }
+  if (a->flags & GIMS_LINEAR_CONV3) {
+    GIMS_CHECK_ARG(a->a0_lo && a->a1 && a->k0 == a->k && (a->k % 9) == 0 && ((a->k / 9) % 32) == 0 && a->conv_h > 0 && a->conv_w > 0 &&
+                       (a->conv_stride == 1 || a->conv_stride == 2) &&
+                       (a->m % (((a->conv_h - 1) / a->conv_stride + 1) * ((a->conv_w - 1) / a->conv_stride + 1))) == 0,
+                   "gims_linear(conv3): pre-split NHWC input with C %% 32 == 0, k = 9 C, a1 = 128 zero bytes, m = patches * Ho * Wo");
+  }
   if (a->a0_lo) {   // pre-split activations: bf16 hi/lo planes, LDS-DMA kernel
     GIMS_CHECK_ARG(a->precision == GIMS_PREC_BF16X3 && a->w_lo, "gims_linear: pre-split A needs GIMS_PREC_BF16X3 and w_lo");
     GIMS_CHECK_ARG(a->k0 == a->k || a->a1_lo, "gims_linear: second A segment needs its lo plane");
     GIMS_CHECK_ARG((a->k % 32) == 0 && (a->k0 % 32) == 0, "gims_linear(pre-split): K=%d k0=%d must be multiples of 32", a->k, a->k0);
-    GIMS_CHECK_ARG((a->lda0 % 64) == 0 && (a->lda1 % 64) == 0 && (a->ldw % 64) == 0 && a->lda0 >= 2 * a->k0 && a->ldw >= 2 * a->k,
+    GIMS_CHECK_ARG((a->lda0 % 64) == 0 && (a->lda1 % 64) == 0 && (a->ldw % 64) == 0 && a->lda0 >= 2 * ((a->flags & GIMS_LINEAR_CONV3) ? a->k / 9 : a->k0) && a->ldw >= 2 * a->k,
                    "gims_linear(pre-split): SPL32 operands have row pitch >= 2*K, a multiple of 64 elements");
     GIMS_CHECK_ARG((((uintptr_t)a->a0 | (uintptr_t)a->w | (uintptr_t)a->a1) & 127) == 0, "gims_linear(pre-split): SPL32 operands must be 128-byte aligned");
     GIMS_CHECK_ARG((a->n % 4) == 0 && (a->ldc % 4) == 0 && (a->ldc_bf16 % 4) == 0 && (a->ld_split % 8) == 0,
@@ -654,6 +683,20 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 4, 1>), g, dim3(512), lds_h, s, *a);
       else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2, 2>), g, dim3(512), lds, s, *a);
       else hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), g, dim3(512), lds, s, *a);
+    } else if (a->flags & GIMS_LINEAR_CONV3) {
+      using T32 = X3P<128, 32, 4, 1, 2>;
+      using T64 = X3P<128, 64, 2, 2, 2>;
+      static bool attr4 = false;
+      if (!attr4) {
+        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 32, 4, 1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T32::LDS_BYTES));
+        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 64, 2, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T64::LDS_BYTES));
+        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 128, 2, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TS::LDS_BYTES));
+        attr4 = true;
+      }
+      const int mt = 8 * cdiv(cdiv(a->m, 128), 8);
+      if (a->n <= 32) { constexpr size_t lds = T32::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<128, 32, 4, 1, 2, 4>), dim3(mt * cdiv(a->n, 32)), dim3(256), lds, s, *a); }
+      else if (a->n <= 64) { constexpr size_t lds = T64::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<128, 64, 2, 2, 2, 4>), dim3(mt * cdiv(a->n, 64)), dim3(256), lds, s, *a); }
+      else { constexpr size_t lds = TS::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2, 4>), dim3(mt * cdiv(a->n, 128)), dim3(256), lds, s, *a); }
     } else if (a->n <= 64 && !(a->flags & (GIMS_LINEAR_HI_ONLY | GIMS_LINEAR_A1_HI_ONLY)) && force == 0) {
       // narrow outputs (the 32- and 64-channel convolutions of the descriptor network, millions of rows): 128 x 32 / 128 x 64
       // tiles instead of wasting three quarters / half of a 128-wide one

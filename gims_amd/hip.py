@@ -18,6 +18,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
 LINEAR_UPPER = 1
 LINEAR_HI_ONLY = 2
 LINEAR_A1_HI_ONLY = 4
+LINEAR_CONV3 = 8
 ACT_NONE, ACT_RELU = 0, 1
 
 
@@ -32,7 +33,8 @@ class LinearArgs(C.Structure):
                 ("out_bf16", C.c_void_p), ("ldc_bf16", C.c_int64), ("m", C.c_int32), ("n", C.c_int32),
                 ("k", C.c_int32), ("k0", C.c_int32), ("act", C.c_int32), ("precision", C.c_int32),
                 ("scale", C.c_float), ("a0_lo", C.c_void_p), ("a1_lo", C.c_void_p), ("out_hi", C.c_void_p),
-                ("out_lo", C.c_void_p), ("ld_split", C.c_int64), ("flags", C.c_int32)]
+                ("out_lo", C.c_void_p), ("ld_split", C.c_int64), ("flags", C.c_int32),
+                ("conv_h", C.c_int32), ("conv_w", C.c_int32), ("conv_stride", C.c_int32), ("conv_reserved", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -92,10 +94,10 @@ _SIGNATURES = {
     "gims_ch_frn_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_ch_pool_hw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gims_ch_gates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 9),
-    "gims_ch_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7),
+    "gims_ch_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_int64, C.c_void_p]),
     "gims_ch_im2col3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_ch_dwconv3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float,
-                                  C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_l2norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_ch_relu6": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_run_ops": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -204,12 +206,23 @@ def _dev(t: torch.Tensor, dtype=None):
 
 
 def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
-                precision=PREC_F32, scale=1.0, n=None, spl=False, out_split=None, flags=0):
+                precision=PREC_F32, scale=1.0, n=None, spl=False, out_split=None, flags=0, conv=None, m=None):
     """Build the C struct.
     spl=False: a0/a1 f32 [m,k*]; w f32 [n,K] (PREC_F32) or bf16 hi plane with w_lo (PREC_BF16X3).
     spl=True : a0/a1/w are SPL32 bf16 buffers [rows, 2*k] (see include/gims_hip.h), precision BF16X3.
     out_split: SPL32 bf16 buffer [m, >= 2n] receiving the result split into hi/lo."""
-    m = a0.shape[0]
+    m = a0.shape[0] if m is None else m
+    if conv is not None:
+        # 3x3 convolution read straight from an SPL32 NHWC activation: a0 = pixel rows [n*h*w, 2C], a1 = 128 zero bytes,
+        # w = SPL32 [n_out, 2*9C], conv = (h, w, stride), m = output pixels
+        assert spl and precision == PREC_BF16X3 and a1 is not None and m is not None
+        k0 = k = w.shape[1] // 2
+        assert k % 9 == 0 and a0.shape[1] == 2 * (k // 9)
+        a0_lo, a1_lo, w_lo = a0[:, 32:], None, w[:, 32:]
+        args = LinearArgs(_p(a0), a0.stride(0), _p(a1), 0, _p(w), _p(w_lo), w.stride(0), _p(bias), None, _p(out),
+                          out.stride(0) if out is not None else 0, None, 0, m, w.shape[0] if n is None else n, k, k0, act, precision, float(scale),
+                          _p(a0_lo), None, None, None, 0, int(flags) | LINEAR_CONV3, int(conv[0]), int(conv[1]), int(conv[2]), 0)
+        return args
     if precision == PREC_BF16X6:
         # a0 / w are SPL3 bf16 buffers [rows, 3k] (split_spl3); plain f32 output only
         assert a0.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a1 is None and not spl
@@ -239,7 +252,7 @@ def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None
                       out.stride(0) if out is not None else 0, _p(out_bf16),
                       out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale),
                       _p(a0_lo), _p(a1_lo), _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
-                      out_split.stride(0) if out_split is not None else 0, int(flags))
+                      out_split.stride(0) if out_split is not None else 0, int(flags), 0, 0, 0, 0)
 
 
 def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):
@@ -570,10 +583,12 @@ def ch_gates(ph, pw, g, ah, aw):
                                 _p(ah), _p(aw), _stream()), "gims_ch_gates")
 
 
-def ch_apply(x, s, b, ah, aw, tau, y):
+def ch_apply(x, s, b, ah, aw, tau, y=None, y_split=None):
+    """y: f32 NHWC and / or y_split: SPL32 bf16 [n*h*w, >= 2c] pixel rows (the operand layout of the next convolution)."""
     n, h, w, c = x.shape
-    _check(load().gims_ch_apply(_p(_dev(x, torch.float32)), n, h, w, c, _p(s), _p(b), _p(ah), _p(aw), _p(tau), _p(y), _stream()), "gims_ch_apply")
-    return y
+    _check(load().gims_ch_apply(_p(_dev(x, torch.float32)), n, h, w, c, _p(s), _p(b), _p(ah), _p(aw), _p(tau), _p(y), _p(y_split),
+                                y_split.stride(0) if y_split is not None else 0, _stream()), "gims_ch_apply")
+    return y if y is not None else y_split
 
 
 def ch_im2col3(x, stride, out, kpad):
@@ -582,11 +597,11 @@ def ch_im2col3(x, stride, out, kpad):
     return out
 
 
-def ch_dwconv3(x, wt, bias, y, relu6_out=False, res=None, res_scale=1.0):
+def ch_dwconv3(x, wt, bias, y=None, relu6_out=False, res=None, res_scale=1.0, y_split=None):
     n, h, w, c = x.shape
     _check(load().gims_ch_dwconv3(_p(_dev(x, torch.float32)), n, h, w, c, _p(wt), _p(bias), 1 if relu6_out else 0, _p(res), float(res_scale),
-                                  _p(y), _stream()), "gims_ch_dwconv3")
-    return y
+                                  _p(y), _p(y_split), y_split.stride(0) if y_split is not None else 0, _stream()), "gims_ch_dwconv3")
+    return y if y is not None else y_split
 
 
 def ch_l2norm(x, eps, y):

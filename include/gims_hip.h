@@ -87,6 +87,12 @@ typedef struct gims_linear_args {
   uint16_t* out_hi; uint16_t* out_lo; int64_t ld_split;
   /* GIMS_LINEAR_UPPER: symmetric product (A == W): skip output tiles that lie entirely below the diagonal */
   int32_t flags;
+  /* GIMS_LINEAR_CONV3 (pre-split operands only): the GEMM is a 3x3 convolution (pad 1) over an NHWC activation held in
+   * the SPL32 layout -- a0 = [patches * conv_h * conv_w][2C] with pitch lda0, C % 32 == 0, k = 9 C, W columns ordered
+   * (ky*3+kx)*C + c.  Output row r is output pixel (patch, yo, xo) of the [(conv_h-1)/stride+1] x [(conv_w-1)/stride+1]
+   * grid, and K block (tap, c0..c0+31) of its operand row is read straight from input pixel
+   * (yo*stride + ky - 1, xo*stride + kx - 1), or from the 128 zero bytes at a1 when that lies outside: no im2col buffer. */
+  int32_t conv_h, conv_w, conv_stride, conv_reserved;
 } gims_linear_args;
 #define GIMS_LINEAR_UPPER 1
   /* GIMS_LINEAR_HI_ONLY (pre-split operands): multiply the hi planes only -- a plain bf16 product (2^-9 relative per
@@ -95,6 +101,7 @@ typedef struct gims_linear_args {
   /* GIMS_LINEAR_A1_HI_ONLY: the same for the SECOND A segment (a1, columns k0..k) only -- for an operand that was computed
    * from bf16 data and carries no information below bf16 precision (the attention message in MLP0) */
 #define GIMS_LINEAR_A1_HI_ONLY 4
+#define GIMS_LINEAR_CONV3 8
 
 int gims_linear(const gims_linear_args* args, void* stream);
 /* Many independent problems in ONE launch (ragged batch: per-pair score matrices, per-image similarity
@@ -343,10 +350,10 @@ int gims_ch_pool_hw(const float* x, int64_t patches, int32_t h, int32_t w, int32
 int gims_ch_gates(const float* ph, const float* pw, int64_t patches, int32_t h, int32_t w, int32_t c, const float* w1, const float* b1,
                   const float* wh, const float* bh, const float* ww, const float* bw, float* ah, float* aw, void* stream);
 int gims_ch_apply(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, const float* ah, const float* aw,
-                  const float* tau, float* y, void* stream);
+                  const float* tau, float* y /* may be NULL */, uint16_t* y_split /* SPL32 pixel rows, may be NULL */, int64_t ld_split, void* stream);
 int gims_ch_im2col3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, int32_t stride, uint16_t* out, int64_t ld, int32_t kpad, void* stream);
 int gims_ch_dwconv3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* wt, const float* bias, int32_t relu6_out,
-                    const float* res, float res_scale, float* y, void* stream);
+                    const float* res, float res_scale, float* y /* may be NULL */, uint16_t* y_split /* may be NULL */, int64_t ld_split, void* stream);
 int gims_ch_l2norm(const float* x, int64_t rows, int32_t c, float eps, float* y, void* stream);
 int gims_ch_relu6(float* x, int64_t total, void* stream);
 

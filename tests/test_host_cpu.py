@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # sizes the C compiler produces for the structs in include/gims_hip.h (LP64)
-    assert ctypes.sizeof(hip.LinearArgs) == 13 * 8 + 6 * 4 + 4 + 4 + 5 * 8 + 8   # + 4 plane pointers + ld_split + flags (padded)
+    assert ctypes.sizeof(hip.LinearArgs) == 13 * 8 + 6 * 4 + 4 + 4 + 5 * 8 + 4 + 4 * 4 + 4   # + 4 plane pointers + ld_split + flags + conv geometry (padded)
     assert ctypes.sizeof(hip.OtProblem) == 8 + 8 + 4 + 4 + 5 * 8
     assert ctypes.sizeof(hip.AgcImage) == 3 * 8 + 2 * 4 + 3 * 8 + 8 + 8      # max_edges_dir is padded to 8
     assert ctypes.sizeof(hip.PackImage) == 7 * 8 + 4 * 4
