@@ -110,8 +110,8 @@ class CARHyNet(nn.Module):
             return dict(w=f32(wp), b=f32(bp))
 
         def sandglass(p):
-            return dict(dw0=dw(p + "conv.0.0.", p + "conv.0.1."), ca=coordatt(p + "conv.1."), pw0=pw(p + "conv.2.", p + "conv.3.", o_pad=32),
-                        pw1=pw(p + "conv.4.0.", p + "conv.4.1.", i_pad=32), dw1=dw(p + "conv.5.", p + "conv.6."))
+            p0, p1 = pw(p + "conv.2.", p + "conv.3."), pw(p + "conv.4.0.", p + "conv.4.1.")
+            return dict(dw0=dw(p + "conv.0.0.", p + "conv.0.1."), ca=coordatt(p + "conv.1."), mid=dict(w0=p0["w"], b0=p0["b"], w1=p1["w"], b1=p1["b"]), dw1=dw(p + "conv.5.", p + "conv.6."))
 
         sc7, sh7 = bn_fold("layer7.2.", affine=False)
         w7 = sd["layer7.1.weight"].permute(0, 2, 3, 1).reshape(128, 8 * 8 * 128) * sc7[:, None]      # column (y*8+x)*128 + c: NHWC flatten
@@ -186,10 +186,8 @@ class CARHyNet(nn.Module):
         n, h, w, c = x1.shape
         y = hip.ch_dwconv3(x1, S["dw0"]["wt"], S["dw0"]["b"], torch.empty_like(x1), relu6_out=True)
         ah, aw = self._gates(y, None, None, S["ca"])
-        y = hip.ch_apply(y, None, None, ah, aw, None, y)
         rows = n * h * w
-        z = hip.linear(y.view(rows, c), S["pw0"]["w"], bias=S["pw0"]["b"], precision=hip.PREC_F32)
-        z = hip.ch_relu6(hip.linear(z, S["pw1"]["w"], bias=S["pw1"]["b"], precision=hip.PREC_F32)).view(n, h, w, c)
+        z = hip.ch_gate_pw_pw(y, ah, aw, S["mid"], torch.empty_like(y))        # gates applied, 1x1 C->16 (+BN), 1x1 16->C (+BN, ReLU6)
         return hip.ch_dwconv3(z, S["dw1"]["wt"], S["dw1"]["b"], None, res=x1, res_scale=2.0, y_split=self._spl(rows, c, x1.device))
 
     @torch.no_grad()

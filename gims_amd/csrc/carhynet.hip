@@ -10,6 +10,7 @@
 //   gims_ch_apply         y = max((x * s + b) * a_w * a_h, tau): FRN scale, CoordAtt gates, TLU in one pass models.py:78-84,152,107
 //   gims_ch_im2col3       3x3 patches (pad 1, stride 1 or 2) written as SPL32 split-bf16 GEMM operand rows
 //   gims_ch_dwconv3       depthwise 3x3 + folded BatchNorm (+ReLU6 on input / output, + residual)          models.py:172-180, 207, 220-223
+//   gims_ch_gate_pw_pw    SandGlass middle in one pass: CoordAtt gates applied, 1x1 C->16 (+BN), 1x1 16->C (+BN, ReLU6)  models.py:152, 208-218
 //   gims_ch_l2norm        x / sqrt(sum x^2 + 1e-10) per row                                                 models.py:9-21
 #include "common.h"
 
@@ -188,6 +189,51 @@ __global__ __launch_bounds__(256) void ch_dwconv3_kernel(const float* __restrict
   if (ysp) store_split4(ysp + pix * ldsp + spl_col(ch), acc);
 }
 
+// SandGlass middle, one thread per pixel: z = ReLU6(W1 (W0 (x * a_w * a_h) + b0) + b1) with C -> 16 -> C channels (C = 32 or 64),
+// BatchNorm folded into W0/b0 and W1/b1 (models.py:208-218: CoordAtt output, pw-linear + BN, pw + BN + ReLU6).  The weights
+// (<= 2 x 64 x 16 floats) sit in LDS; x, a_h, a_w are read as float4.
+template <int C>
+__global__ __launch_bounds__(256) void ch_gate_pw_pw_kernel(const float* __restrict__ x, int64_t pixels, int h, int w, const float* __restrict__ ah,
+                                                            const float* __restrict__ aw, const float* __restrict__ w0, const float* __restrict__ b0,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ z) {
+  __shared__ float s0[16 * C], s1[C * 16], sb0[16], sb1[C];
+  for (int i = threadIdx.x; i < 16 * C; i += 256) { s0[i] = w0[i]; s1[i] = w1[i]; }
+  if (threadIdx.x < 16) sb0[threadIdx.x] = b0[threadIdx.x];
+  if (threadIdx.x < C) sb1[threadIdx.x] = b1[threadIdx.x];
+  __syncthreads();
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= pixels) return;
+  const int xx = (int)(pix % w), yy = (int)((pix / w) % h);
+  const int64_t p = pix / ((int64_t)w * h);
+  const float* xr = x + pix * C;
+  const float* hr = ah + (p * h + yy) * C;
+  const float* wr = aw + (p * w + xx) * C;
+  float hid[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) hid[m] = sb0[m];
+#pragma unroll
+  for (int k = 0; k < C; k += 4) {
+    const float4 v = *(const float4*)(xr + k), g1 = *(const float4*)(hr + k), g2 = *(const float4*)(wr + k);
+    const float t[4] = {v.x * g2.x * g1.x, v.y * g2.y * g1.y, v.z * g2.z * g1.z, v.w * g2.w * g1.w};      // x * a_w * a_h (models.py:152)
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hid[m] = fmaf(t[j], s0[m * C + k + j], hid[m]);
+  }
+#pragma unroll
+  for (int o = 0; o < C; o += 4) {
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = sb1[o + j];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) acc = fmaf(hid[m], s1[(o + j) * 16 + m], acc);
+      r[j] = fminf(fmaxf(acc, 0.f), 6.f);
+    }
+    *(float4*)(z + pix * C + o) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
 // one wave per row of `c` (<= 256) values: y = x / sqrt(sum x^2 + eps)
 __global__ __launch_bounds__(256) void ch_l2norm_kernel(const float* __restrict__ x, int64_t rows, int c, float eps, float* __restrict__ y) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -269,6 +315,17 @@ extern "C" int gims_ch_dwconv3(const float* x, int64_t patches, int32_t h, int32
   const int64_t total = patches * h * w * c;
   hipLaunchKernelGGL(ch_dwconv3_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, total, h, w, c, wt, bias, relu6_out, res,
                      res_scale, y, y_split, ld_split);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_gate_pw_pw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* ah, const float* aw, const float* w0,
+                                  const float* b0, const float* w1, const float* b1, float* z, void* stream) {
+  GIMS_CHECK_ARG(x && ah && aw && w0 && b0 && w1 && b1 && z && patches > 0 && (c == 32 || c == 64), "gims_ch_gate_pw_pw: bad arguments (c = 32 or 64, hidden 16)");
+  const int64_t pixels = patches * h * w;
+  const dim3 grid((unsigned)((pixels + 255) / 256));
+  if (c == 32) hipLaunchKernelGGL(ch_gate_pw_pw_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, pixels, h, w, ah, aw, w0, b0, w1, b1, z);
+  else hipLaunchKernelGGL(ch_gate_pw_pw_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x, pixels, h, w, ah, aw, w0, b0, w1, b1, z);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

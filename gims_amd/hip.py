@@ -98,6 +98,7 @@ _SIGNATURES = {
     "gims_ch_im2col3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_ch_dwconv3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_ch_gate_pw_pw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
     "gims_ch_l2norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_ch_relu6": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_run_ops": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -602,6 +603,13 @@ def ch_dwconv3(x, wt, bias, y=None, relu6_out=False, res=None, res_scale=1.0, y_
     _check(load().gims_ch_dwconv3(_p(_dev(x, torch.float32)), n, h, w, c, _p(wt), _p(bias), 1 if relu6_out else 0, _p(res), float(res_scale),
                                   _p(y), _p(y_split), y_split.stride(0) if y_split is not None else 0, _stream()), "gims_ch_dwconv3")
     return y if y is not None else y_split
+
+
+def ch_gate_pw_pw(x, ah, aw, S, z):
+    n, h, w, c = x.shape
+    _check(load().gims_ch_gate_pw_pw(_p(_dev(x, torch.float32)), n, h, w, c, _p(ah), _p(aw), _p(S["w0"]), _p(S["b0"]), _p(S["w1"]), _p(S["b1"]),
+                                     _p(z), _stream()), "gims_ch_gate_pw_pw")
+    return z
 
 
 def ch_l2norm(x, eps, y):

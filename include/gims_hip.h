@@ -354,6 +354,9 @@ int gims_ch_apply(const float* x, int64_t patches, int32_t h, int32_t w, int32_t
 int gims_ch_im2col3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, int32_t stride, uint16_t* out, int64_t ld, int32_t kpad, void* stream);
 int gims_ch_dwconv3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* wt, const float* bias, int32_t relu6_out,
                     const float* res, float res_scale, float* y /* may be NULL */, uint16_t* y_split /* may be NULL */, int64_t ld_split, void* stream);
+/* SandGlass middle in one pass per pixel: z = ReLU6(w1 (w0 (x * a_w * a_h) + b0) + b1); w0 [16][c], w1 [c][16] (BatchNorm folded), c = 32 | 64 */
+int gims_ch_gate_pw_pw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* ah, const float* aw, const float* w0,
+                       const float* b0, const float* w1, const float* b1, float* z, void* stream);
 int gims_ch_l2norm(const float* x, int64_t rows, int32_t c, float eps, float* y, void* stream);
 int gims_ch_relu6(float* x, int64_t total, void* stream);
 
