@@ -172,10 +172,19 @@ class CARHyNet(nn.Module):
     def _frn_tlu(self, x, F, tau, G=None, split=False):
         """FRN (+ CoordAtt) + TLU; split=True: the result as SPL32 pixel rows for the next convolution instead of f32."""
         n, h, w, c = x.shape
-        s = self._frn_scale(x, F)
         ah = aw = None
         if G is not None:
-            ah, aw = self._gates(x, s, F["b"], G)
+            # one pass over the raw convolution output serves FRN's statistics and CoordAtt's two pools; the FRN affine map is
+            # applied to the pooled values on their way into the gate MLP (the mean of an affine map is the affine map of the mean)
+            ph = torch.empty((n, h, c), dtype=torch.float32, device=x.device)
+            pw = torch.empty((n, w, c), dtype=torch.float32, device=x.device)
+            rowsq = torch.empty_like(ph)
+            hip.ch_pool_hw(x, None, None, ph, pw, rowsq)
+            s = hip.ch_frn_from_rows(rowsq, w, F["w"], F["eps"], torch.empty((n, c), dtype=torch.float32, device=x.device))
+            ah, aw = torch.empty_like(ph), torch.empty_like(pw)
+            hip.ch_gates(ph, pw, G, ah, aw, frn_scale=s, frn_bias=F["b"])
+        else:
+            s = self._frn_scale(x, F)
         if split:
             return hip.ch_apply(x, s, F["b"], ah, aw, tau, None, self._spl(n * h * w, c, x.device))
         return hip.ch_apply(x, s, F["b"], ah, aw, tau, torch.empty_like(x))

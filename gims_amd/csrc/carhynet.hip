@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void ch_frn_stats_kernel(const float* __restri
 // channels, so every load of the 32-step loop is a contiguous line across the wave.  The patch is read twice (once per
 // direction), from L2 the second time.
 __global__ __launch_bounds__(256) void ch_pool_hw_kernel(const float* __restrict__ x, int64_t patches, int h, int w, int c, const float* __restrict__ s,
-                                                         const float* __restrict__ b, float* __restrict__ ph, float* __restrict__ pw) {
+                                                         const float* __restrict__ b, float* __restrict__ ph, float* __restrict__ pw,
+                                                         float* __restrict__ rowsq) {
   const bool over_x = blockIdx.y == 0;
   const int n_line = over_x ? h : w, n_sum = over_x ? w : h;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -52,20 +53,35 @@ __global__ __launch_bounds__(256) void ch_pool_hw_kernel(const float* __restrict
   const int64_t p = i / ((int64_t)c * n_line);
   const float* xp = x + (p * h * w + (over_x ? (int64_t)line * w : line)) * c + ch;
   const int64_t step = over_x ? c : (int64_t)w * c;
-  float t = 0.f;
-  for (int k = 0; k < n_sum; ++k) t += xp[k * step];
+  float t = 0.f, q = 0.f;
+  for (int k = 0; k < n_sum; ++k) { const float v = xp[k * step]; t += v; q = fmaf(v, v, q); }
   t /= (float)n_sum;
   if (s) t = fmaf(t, s[p * c + ch], b ? b[ch] : 0.f);      // the mean of an affine map is the affine map of the mean
   (over_x ? ph : pw)[i] = t;
+  if (rowsq && over_x) rowsq[i] = q;                        // per-row sums of squares: FRN's statistics from the same pass
 }
 
-// CoordAtt gates for one patch per workgroup: rows r = 0..h-1 from ph, h..h+w-1 from pw.
+// FRN scale from the per-row sums of squares of gims_ch_pool_hw: scale[p][c] = weight[c] * rsqrt(sum_y rowsq[p][y][c] / (h w) + eps)
+__global__ __launch_bounds__(256) void ch_frn_from_rows_kernel(const float* __restrict__ rowsq, int64_t patches, int h, int w, int c, const float* __restrict__ wgt,
+                                                               float eps, float* __restrict__ scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= patches * c) return;
+  const int ch = (int)(i % c);
+  const int64_t p = i / c;
+  float t = 0.f;
+  for (int y = 0; y < h; ++y) t += rowsq[(p * h + y) * c + ch];
+  scale[i] = wgt[ch] * rsqrtf(t / (float)(h * w) + eps);
+}
+
+// CoordAtt gates for one patch per workgroup: rows r = 0..h-1 from ph, h..h+w-1 from pw (optionally the pools of the RAW
+// activation, mapped through FRN's per-(patch, channel) affine  v * s[p][k] + b[k]  on the way in).
 //   mid[r][m] = h_swish(bn(conv1(row r)))  (8 channels; BatchNorm folded into w1 / b1 by the caller)
 //   a_h[y][ch] = sigmoid(conv_h(mid[y])),  a_w[x][ch] = sigmoid(conv_w(mid[h + x]))
 __global__ __launch_bounds__(256) void ch_gates_kernel(const float* __restrict__ ph, const float* __restrict__ pw, int h, int w, int c,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,      // [8][c], [8]
                                                        const float* __restrict__ wh, const float* __restrict__ bh,      // [c][8], [c]
                                                        const float* __restrict__ ww, const float* __restrict__ bw,
+                                                       const float* __restrict__ fs, const float* __restrict__ fb,
                                                        float* __restrict__ ah, float* __restrict__ aw) {
   __shared__ float mid[64][8];
   const int p = blockIdx.x, t = threadIdx.x, rows = h + w;
@@ -73,7 +89,7 @@ __global__ __launch_bounds__(256) void ch_gates_kernel(const float* __restrict__
     const int r = i >> 3, m = i & 7;
     const float* src = r < h ? ph + ((int64_t)p * h + r) * c : pw + ((int64_t)p * w + (r - h)) * c;
     float acc = b1[m];
-    for (int k = 0; k < c; ++k) acc = fmaf(src[k], w1[m * c + k], acc);
+    for (int k = 0; k < c; ++k) acc = fmaf(fs ? fmaf(src[k], fs[(int64_t)p * c + k], fb[k]) : src[k], w1[m * c + k], acc);
     mid[r][m] = acc * (fminf(fmaxf(acc + 3.f, 0.f), 6.f) / 6.f);
   }
   __syncthreads();
@@ -270,18 +286,30 @@ extern "C" int gims_ch_frn_stats(const float* x, int64_t patches, int32_t hw, in
 }
 
 extern "C" int gims_ch_pool_hw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, float* ph, float* pw,
-                               void* stream) {
+                               float* rowsq, void* stream) {
   GIMS_CHECK_ARG(x && ph && pw && patches > 0 && h > 0 && w > 0 && c > 0, "gims_ch_pool_hw: bad arguments");
   const int64_t n = patches * (h > w ? h : w) * c;
-  hipLaunchKernelGGL(ch_pool_hw_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, x, patches, h, w, c, s, b, ph, pw);
+  hipLaunchKernelGGL(ch_pool_hw_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, x, patches, h, w, c, s, b, ph, pw, rowsq);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_frn_from_rows(const float* rowsq, int64_t patches, int32_t h, int32_t w, int32_t c, const float* weight, float eps, float* scale,
+                                     void* stream) {
+  GIMS_CHECK_ARG(rowsq && weight && scale && patches > 0 && h > 0 && w > 0 && c > 0 && eps >= 0.f, "gims_ch_frn_from_rows: bad arguments");
+  hipLaunchKernelGGL(ch_frn_from_rows_kernel, dim3((unsigned)((patches * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowsq, patches, h, w, c, weight,
+                     eps, scale);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }
 
 extern "C" int gims_ch_gates(const float* ph, const float* pw, int64_t patches, int32_t h, int32_t w, int32_t c, const float* w1, const float* b1,
-                             const float* wh, const float* bh, const float* ww, const float* bw, float* ah, float* aw, void* stream) {
-  GIMS_CHECK_ARG(ph && pw && w1 && b1 && wh && bh && ww && bw && ah && aw && patches > 0 && h + w <= 64, "gims_ch_gates: bad arguments (h + w <= 64)");
-  hipLaunchKernelGGL(ch_gates_kernel, dim3((unsigned)patches), dim3(256), 0, (hipStream_t)stream, ph, pw, h, w, c, w1, b1, wh, bh, ww, bw, ah, aw);
+                             const float* wh, const float* bh, const float* ww, const float* bw, const float* frn_scale, const float* frn_bias,
+                             float* ah, float* aw, void* stream) {
+  GIMS_CHECK_ARG(ph && pw && w1 && b1 && wh && bh && ww && bw && ah && aw && patches > 0 && h + w <= 64 && ((frn_scale == nullptr) == (frn_bias == nullptr)),
+                 "gims_ch_gates: bad arguments (h + w <= 64)");
+  hipLaunchKernelGGL(ch_gates_kernel, dim3((unsigned)patches), dim3(256), 0, (hipStream_t)stream, ph, pw, h, w, c, w1, b1, wh, bh, ww, bw, frn_scale, frn_bias,
+                     ah, aw);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

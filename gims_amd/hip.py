@@ -92,8 +92,9 @@ _SIGNATURES = {
     "gims_linear_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_frn_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
-    "gims_ch_pool_hw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gims_ch_gates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 9),
+    "gims_ch_pool_hw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gims_ch_frn_from_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "gims_ch_gates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11),
     "gims_ch_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_int64, C.c_void_p]),
     "gims_ch_im2col3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "gims_ch_dwconv3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float,
@@ -572,16 +573,22 @@ def ch_frn_stats(x, weight, eps, scale):
     return scale
 
 
-def ch_pool_hw(x, s, b, ph, pw):
+def ch_pool_hw(x, s, b, ph, pw, rowsq=None):
     n, h, w, c = x.shape
-    _check(load().gims_ch_pool_hw(_p(_dev(x, torch.float32)), n, h, w, c, _p(s), _p(b), _p(ph), _p(pw), _stream()), "gims_ch_pool_hw")
+    _check(load().gims_ch_pool_hw(_p(_dev(x, torch.float32)), n, h, w, c, _p(s), _p(b), _p(ph), _p(pw), _p(rowsq), _stream()), "gims_ch_pool_hw")
 
 
-def ch_gates(ph, pw, g, ah, aw):
+def ch_frn_from_rows(rowsq, w, weight, eps, scale):
+    n, h, c = rowsq.shape
+    _check(load().gims_ch_frn_from_rows(_p(rowsq), n, h, w, c, _p(weight), float(eps), _p(scale), _stream()), "gims_ch_frn_from_rows")
+    return scale
+
+
+def ch_gates(ph, pw, g, ah, aw, frn_scale=None, frn_bias=None):
     n, h, c = ph.shape
     w = pw.shape[1]
     _check(load().gims_ch_gates(_p(ph), _p(pw), n, h, w, c, _p(g["w1"]), _p(g["b1"]), _p(g["wh"]), _p(g["bh"]), _p(g["ww"]), _p(g["bw"]),
-                                _p(ah), _p(aw), _stream()), "gims_ch_gates")
+                                _p(frn_scale), _p(frn_bias), _p(ah), _p(aw), _stream()), "gims_ch_gates")
 
 
 def ch_apply(x, s, b, ah, aw, tau, y=None, y_split=None):

@@ -346,9 +346,14 @@ int gims_ot_matrix(const float* scores, int64_t ld, int32_t n, int32_t m, float 
  *   gims_ch_relu6:     in-place clamp to [0, 6]
  */
 int gims_ch_frn_stats(const float* x, int64_t patches, int32_t hw, int32_t c, const float* weight, float eps, float* scale, void* stream);
-int gims_ch_pool_hw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, float* ph, float* pw, void* stream);
+int gims_ch_pool_hw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, float* ph, float* pw,
+                    float* rowsq /* [p][y][c] sums of x^2 over x, may be NULL */, void* stream);
+/* FRN scale from those row sums (one pass over the activation serves the statistics and both pools) */
+int gims_ch_frn_from_rows(const float* rowsq, int64_t patches, int32_t h, int32_t w, int32_t c, const float* weight, float eps, float* scale, void* stream);
 int gims_ch_gates(const float* ph, const float* pw, int64_t patches, int32_t h, int32_t w, int32_t c, const float* w1, const float* b1,
-                  const float* wh, const float* bh, const float* ww, const float* bw, float* ah, float* aw, void* stream);
+                  const float* wh, const float* bh, const float* ww, const float* bw,
+                  const float* frn_scale /* [p][c] */, const float* frn_bias /* [c]; both NULL: the pools are used as they are */, float* ah, float* aw,
+                  void* stream);
 int gims_ch_apply(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* s, const float* b, const float* ah, const float* aw,
                   const float* tau, float* y /* may be NULL */, uint16_t* y_split /* SPL32 pixel rows, may be NULL */, int64_t ld_split, void* stream);
 int gims_ch_im2col3(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, int32_t stride, uint16_t* out, int64_t ld, int32_t kpad, void* stream);
