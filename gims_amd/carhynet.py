@@ -169,7 +169,7 @@ class CARHyNet(nn.Module):
         hip.ch_gates(ph, pw, G, ah, aw)
         return ah, aw
 
-    def _frn_tlu(self, x, F, tau, G=None, split=False):
+    def _frn_tlu(self, x, F, tau, G=None, split=False, split_out=None):
         """FRN (+ CoordAtt) + TLU; split=True: the result as SPL32 pixel rows for the next convolution instead of f32."""
         n, h, w, c = x.shape
         ah = aw = None
@@ -186,7 +186,7 @@ class CARHyNet(nn.Module):
         else:
             s = self._frn_scale(x, F)
         if split:
-            return hip.ch_apply(x, s, F["b"], ah, aw, tau, None, self._spl(n * h * w, c, x.device))
+            return hip.ch_apply(x, s, F["b"], ah, aw, tau, None, split_out if split_out is not None else self._spl(n * h * w, c, x.device))
         return hip.ch_apply(x, s, F["b"], ah, aw, tau, torch.empty_like(x))
 
     def _sandglass_plus(self, x1, S):
@@ -200,8 +200,8 @@ class CARHyNet(nn.Module):
         return hip.ch_dwconv3(z, S["dw1"]["wt"], S["dw1"]["b"], None, res=x1, res_scale=2.0, y_split=self._spl(rows, c, x1.device))
 
     @torch.no_grad()
-    def _forward_nhwc(self, patches):
-        """patches: [n, 32, 32, 3] f32 on the GPU -> (desc [n, 128], raw [n, 128])."""
+    def _features(self, patches, out):
+        """patches: [n, 32, 32, 3] f32 on the GPU -> layer 6 output (models.py:380-392) written into `out` [n*64, 256]."""
         if patches.device.type != "cuda":
             raise hip.GimsHipError("CARHyNet runs on the GPU only (no CPU fallback): move the patches to 'cuda'")
         P = self._prepare(patches.device)
@@ -218,20 +218,36 @@ class CARHyNet(nn.Module):
         x1 = self._frn_tlu(self._conv3(xs, n, 16, 16, P["l4"]["conv"], 1), P["l4"]["frn"], P["l4"]["tau"])
         xs = self._sandglass_plus(x1, P["sg4"])
         xs = self._frn_tlu(self._conv3(xs, n, 16, 16, P["l5"]["conv"], 2), P["l5"]["frn"], P["l5"]["tau"], split=True)
-        xs = self._frn_tlu(self._conv3(xs, n, 8, 8, P["l6"]["conv"], 1), P["l6"]["frn"], P["l6"]["tau"], split=True)
-        # [n*64 pixels, 2*128] SPL32 rows ARE the SPL32 layout of the flattened [n, 8*8*128] activation (32-channel blocks never
-        # straddle a pixel): the 8x8 convolution is one GEMM on a view
-        raw = torch.empty((n, 128), dtype=torch.float32, device=patches.device)
+        return self._frn_tlu(self._conv3(xs, n, 8, 8, P["l6"]["conv"], 1), P["l6"]["frn"], P["l6"]["tau"], split=True, split_out=out)
+
+    def _head(self, xs, n):
+        """layer7 + desc_l2norm over ALL patches at once.  The [n*64, 2*128] SPL32 pixel rows ARE the SPL32 layout of the
+        flattened [n, 8*8*128] activation (32-channel blocks never straddle a pixel): the 8x8 convolution is one GEMM on a
+        view (one launch for the whole batch: a chunk alone would fill 16 of the 256 CUs)."""
+        P = self._pack
+        raw = torch.empty((n, 128), dtype=torch.float32, device=xs.device)
         hip.linear(xs.view(n, 64 * 256), P["l7"]["w"], spl=True, bias=P["l7"]["b"], precision=hip.PREC_BF16X3, out=raw)
         desc = hip.ch_l2norm(raw, EPS_L2_NORM, torch.empty_like(raw))
         return desc, raw
+
+    def _forward_nhwc(self, patches):
+        """patches: [N, 32, 32, 3] f32 on the GPU -> (desc [N, 128], raw [N, 128]); the convolution stack runs in chunks."""
+        n = patches.shape[0]
+        if n == 0:
+            z = torch.zeros((0, 128), dtype=torch.float32, device=patches.device)
+            return z, z.clone()
+        feats = torch.empty((n * 64, 256), dtype=torch.bfloat16, device=patches.device)
+        for i in range(0, n, self.chunk):
+            m = min(self.chunk, n - i)
+            self._features(patches[i:i + m], feats[i * 64:(i + m) * 64])
+        return self._head(feats, n)
 
     def forward(self, x, mode="eval"):
         """x: [N, 3, 32, 32] like the reference's CAR_HyNet.forward (models.py:379); eval mode only."""
         if self.training:
             raise NotImplementedError("CARHyNet: training mode (Dropout, batch statistics) is not on the HIP path")
-        outs = [self._forward_nhwc(x[i:i + self.chunk].permute(0, 2, 3, 1).float().contiguous()) for i in range(0, x.shape[0], self.chunk)]
-        desc, raw = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        with torch.no_grad():
+            desc, raw = self._forward_nhwc(x.permute(0, 2, 3, 1).float().contiguous())
         return (desc, raw) if mode == "train" else desc
 
     def compute_des_batches(self, patches, color=True):
@@ -239,8 +255,6 @@ class CARHyNet(nn.Module):
         if not color:
             raise NotImplementedError("CARHyNet: the grey-level variant (HyNet, 1 input channel) is not built")
         dev = torch.device("cuda", torch.cuda.current_device())
-        out = np.zeros((len(patches), 128), dtype=np.float32)
-        for i in range(0, len(patches), self.chunk):
-            p = torch.from_numpy(np.ascontiguousarray(patches[i:i + self.chunk], dtype=np.float32)).to(dev)
-            out[i:i + self.chunk] = self._forward_nhwc(p)[0].cpu().numpy()
-        return out
+        with torch.no_grad():
+            p = torch.from_numpy(np.ascontiguousarray(patches, dtype=np.float32)).to(dev)
+            return self._forward_nhwc(p)[0].cpu().numpy()
