@@ -49,7 +49,7 @@ def main():
            "patches": a.patches, "ms_per_batch": 1e3 * dt, "dtype": "split-bf16x3 MFMA convolutions (f32-class) + f32 FRN / CoordAtt / depthwise",
            "roofline": {"bound": "mfma", "achieved": a.patches * FLOP_PER_PATCH / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": a.patches * FLOP_PER_PATCH / dt / 1e12 / 2500.0,
-                        "note": "algorithmic flops; first version of this row: im2col + GEMM per layer with NHWC f32 activations in HBM, not fused"},
+                        "note": "algorithmic flops; layer-by-layer version of this row: gather-mode split-bf16 GEMM per convolution, NHWC activations in HBM, not fused across layers"},
            "descriptor_norm_check": float(d.norm(dim=1).mean())}
     if not a.no_cpu:
         from oracle import carhynet_oracle as CO
