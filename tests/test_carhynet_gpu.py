@@ -48,6 +48,25 @@ def test_vs_oracle_ragged_batch():
     np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
 
 
+def test_full_size_properties():
+    """BASELINE config 5's size (descriptors for 2 x 8192 keypoints), where the CPU restatement is too slow: every patch is
+    processed independently, so (1) the result does not depend on how the batch is chunked -- bit for bit --, (2) a patch
+    gives the same descriptor wherever it sits in the batch, (3) all descriptors are unit vectors, (4) two runs agree bitwise."""
+    m = _model(321)
+    base = synth.make_patches(512, 21)
+    patches = np.tile(base, (32, 1, 1, 1))                      # 16384 patches, period 512
+    d1 = m.compute_des_batches(patches)
+    assert d1.shape == (16384, 128)
+    np.testing.assert_allclose(np.linalg.norm(d1, axis=1), 1.0, atol=1e-5)
+    np.testing.assert_array_equal(d1[:512], d1[512 * 17:512 * 18])
+    m.chunk = 1536                                              # does not divide the batch
+    d2 = m.compute_des_batches(patches)
+    np.testing.assert_array_equal(d1, d2)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_carhynet_state_dict(321).items()}
+    ref, _ = CO.car_hynet_forward(sd, torch.from_numpy(base[:32]))
+    np.testing.assert_allclose(d1[:32], ref.numpy(), atol=2e-5, rtol=0)
+
+
 def test_state_dict_roundtrip_and_errors():
     from gims_amd.carhynet import CARHyNet
     m = _model(321)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 end to end on one GPU: CAR-HyNet descriptors for both images of a pair (32x32x3 patches around 8192
+keypoints each) -> 128-d descriptors duplicated to 256-d (utils/common.py:891) -> the GIMS matcher.  Synthetic inputs:
+the keypoints / scores of gims_amd.synth.make_pair and synthetic patches (the second image's patches are the first's,
+permuted like its keypoints, plus noise), so the matcher sees correlated descriptors it can actually match.
+
+    python tools/pipeline_bench.py [--kpts 8192] [--pairs 2] [--reps 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kpts", type=int, default=8192)
+    ap.add_argument("--pairs", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    import __graft_entry__
+    __graft_entry__.build()
+    from gims_amd import GMatcher, synth
+    from gims_amd.carhynet import CARHyNet
+    torch.set_grad_enabled(False)
+    net = CARHyNet().eval()
+    net.load_state_dict(synth.make_carhynet_state_dict(321))
+    matcher = GMatcher({}).eval()
+    matcher.load_state_dict(synth.make_state_dict(123))
+    dev = "cuda"
+    work = []
+    for p in range(a.pairs):
+        pair = synth.make_pair(a.kpts, 1000 + p)
+        p0 = synth.make_patches(a.kpts, 50 + p)
+        perm = pair["gt_perm"]                                   # keypoint i of image 0 is keypoint perm[i] of image 1
+        p1 = np.empty_like(p0)
+        p1[perm] = np.clip(p0 + 0.01 * np.random.default_rng(p).normal(size=p0.shape).astype(np.float32), 0, 1)
+        d = {k: torch.from_numpy(v).to(dev) for k, v in pair.items() if k not in ("gt_perm", "image0", "image1", "descriptors0", "descriptors1")}
+        d["image0"], d["image1"] = pair["image0"], pair["image1"]
+        d.update(device=torch.device(dev), radius=15, percentile=2, min_size=7)
+        work.append((d, torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev), perm))
+
+    def descriptors():
+        return [[net._forward_nhwc(pt)[0] for pt in (p0, p1)] for _, p0, p1, _ in work]
+
+    def match(descs):
+        datas = []
+        for (d, _, _, _), (d0, d1) in zip(work, descs):
+            dd = dict(d)
+            dd["descriptors0"], dd["descriptors1"] = torch.cat([d0, d0], 1).t()[None], torch.cat([d1, d1], 1).t()[None]   # common.py:891
+            datas.append(dd)
+        return matcher.match_pairs(datas)
+
+    def timed(fn, *args):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = fn(*args)
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    for _ in range(2):
+        outs = match(descriptors())
+    t_desc = t_match = t_all = 0.0
+    for _ in range(a.reps):
+        descs, dt = timed(descriptors); t_desc += dt
+        outs, dt = timed(match, descs); t_match += dt
+        outs, dt = timed(lambda: match(descriptors())); t_all += dt
+    m0 = outs[0]["matches0"][0].cpu().numpy()
+    perm = work[0][3]
+    print(json.dumps({"metric": f"image-pairs/sec at 2x{a.kpts} keypoints INCLUDING CAR-HyNet descriptor extraction", "value": a.pairs * a.reps / t_all,
+                      "unit": "pairs/s", "pairs_per_step": a.pairs, "ms_per_pair": 1e3 * t_all / (a.pairs * a.reps),
+                      "ms_per_pair_descriptors_only": 1e3 * t_desc / (a.pairs * a.reps), "ms_per_pair_matcher_only": 1e3 * t_match / (a.pairs * a.reps),
+                      "matches_pair0": int((m0 >= 0).sum()), "correct_vs_planted_pair0": int(((m0 >= 0) & (m0 == perm[:len(m0)])).sum())}))
+
+
+if __name__ == "__main__":
+    main()
