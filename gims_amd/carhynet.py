@@ -26,7 +26,8 @@ EPS_L2_NORM = 1e-10
 
 
 class CARHyNet(nn.Module):
-    chunk = 2048                      # patches per pass (im2col of the 32->32 layer: 1.2 MB per patch)
+    chunk = 2048                      # patches per pass
+    fused_sandglass = True            # False: the layer-by-layer kernels (kept as the cross-check of the fused one)
 
     def __init__(self):
         super().__init__()
@@ -111,7 +112,9 @@ class CARHyNet(nn.Module):
 
         def sandglass(p):
             p0, p1 = pw(p + "conv.2.", p + "conv.3."), pw(p + "conv.4.0.", p + "conv.4.1.")
-            return dict(dw0=dw(p + "conv.0.0.", p + "conv.0.1."), ca=coordatt(p + "conv.1."), mid=dict(w0=p0["w"], b0=p0["b"], w1=p1["w"], b1=p1["b"]), dw1=dw(p + "conv.5.", p + "conv.6."))
+            d0, d1, ca = dw(p + "conv.0.0.", p + "conv.0.1."), dw(p + "conv.5.", p + "conv.6."), coordatt(p + "conv.1.")
+            ptrs = [d0["wt"], d0["b"], ca["w1"], ca["b1"], ca["wh"], ca["bh"], ca["ww"], ca["bw"], p0["w"], p0["b"], p1["w"], p1["b"], d1["wt"], d1["b"]]
+            return dict(ptrs=ptrs, dw0=d0, ca=ca, mid=dict(w0=p0["w"], b0=p0["b"], w1=p1["w"], b1=p1["b"]), dw1=dw(p + "conv.5.", p + "conv.6."))
 
         sc7, sh7 = bn_fold("layer7.2.", affine=False)
         w7 = sd["layer7.1.weight"].permute(0, 2, 3, 1).reshape(128, 8 * 8 * 128) * sc7[:, None]      # column (y*8+x)*128 + c: NHWC flatten
@@ -193,6 +196,8 @@ class CARHyNet(nn.Module):
         """x1 + SandGlass(x1) = 2 x1 + conv-stack(x1)  (models.py:226-233 adds x1 inside, 383-385 / 387-389 add it again);
         returned as SPL32 pixel rows (it only feeds the next 3x3 convolution)."""
         n, h, w, c = x1.shape
+        if self.fused_sandglass and (h, w, c) in ((32, 32, 32), (16, 16, 64)):
+            return hip.ch_sandglass(x1, S, self._spl(n * h * w, c, x1.device))       # one workgroup per patch, activation resident in LDS
         y = hip.ch_dwconv3(x1, S["dw0"]["wt"], S["dw0"]["b"], torch.empty_like(x1), relu6_out=True)
         ah, aw = self._gates(y, None, None, S["ca"])
         rows = n * h * w

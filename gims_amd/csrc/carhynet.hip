@@ -11,6 +11,7 @@
 //   gims_ch_im2col3       3x3 patches (pad 1, stride 1 or 2) written as SPL32 split-bf16 GEMM operand rows
 //   gims_ch_dwconv3       depthwise 3x3 + folded BatchNorm (+ReLU6 on input / output, + residual)          models.py:172-180, 207, 220-223
 //   gims_ch_gate_pw_pw    SandGlass middle in one pass: CoordAtt gates applied, 1x1 C->16 (+BN), 1x1 16->C (+BN, ReLU6)  models.py:152, 208-218
+//   gims_ch_sandglass     the whole SandGlass block + outer residual, one workgroup per patch, activation resident in LDS  models.py:182-235
 //   gims_ch_l2norm        x / sqrt(sum x^2 + 1e-10) per row                                                 models.py:9-21
 #include "common.h"
 
@@ -250,6 +251,157 @@ __global__ __launch_bounds__(256) void ch_gate_pw_pw_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------- fused SandGlass block
+// One workgroup per patch, the whole block of models.py:182-235 (+ the outer residual of 383-389) with the patch's activation
+// resident in LDS (H * W * C = 32768 floats = 128 KiB: 32x32x32 or 16x16x64):
+//   A  y = ReLU6(dw3x3(x) + BN)                       x from global (L2: every element is read by 9 neighbours), y -> LDS
+//   A2 pools of y over W and over H                   LDS -> LDS
+//   B  CoordAtt gate MLP: 8-channel bottleneck, sigmoid gates a_h, a_w (they overwrite the pools)
+//   C  z = ReLU6(W1 (W0 (y a_w a_h) + b0) + b1)      per pixel, in place
+//   D  out = 2 x + dw3x3(z) + BN                      z from LDS, x from global, out as SPL32 split-bf16 pixel rows
+// LDS image of y / z: [pixel][C] with the 16-byte quads of a pixel XOR-swizzled by the pixel index, so that both the
+// quad-per-lane passes (A, D) and the pixel-per-lane pass (C) are bank-conflict free without padding.
+struct ChSandglassW {          // all f32, BatchNorm folded
+  const float* dw0;   // [9][C]
+  const float* dw0b;  // [C]
+  const float* w1;    // [8][C]   CoordAtt conv1 (+bn1)
+  const float* b1;    // [8]
+  const float* wh;    // [C][8]
+  const float* bh;    // [C]
+  const float* ww;    // [C][8]
+  const float* bw;    // [C]
+  const float* p0;    // [16][C]  pw-linear (+BN)
+  const float* p0b;   // [16]
+  const float* p1;    // [C][16]  pw (+BN), ReLU6 after
+  const float* p1b;   // [C]
+  const float* dw1;   // [9][C]
+  const float* dw1b;  // [C]
+};
+
+template <int C, int HW>      // HW = H = W
+__global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restrict__ x, ChSandglassW wts, uint16_t* __restrict__ out, int64_t ldo) {
+  constexpr int NPIX = HW * HW, QPP = C / 4, MASK = QPP - 1;          // quads per pixel
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ybuf = lds;                        // [NPIX][C] swizzled
+  float* ph = ybuf + NPIX * C;              // [HW][C]  -> a_h
+  float* pw = ph + HW * C;                  // [HW][C]  -> a_w
+  float* mid = pw + HW * C;                 // [2 HW][8]
+  float* wl = mid + 2 * HW * 8;             // dw0 [9][C], dw0b [C], dw1 [9][C], dw1b [C], p0 [16][C], p0b [16], p1 [C][16], p1b [C]
+  float* l_dw0 = wl, *l_dw0b = l_dw0 + 9 * C, *l_dw1 = l_dw0b + C, *l_dw1b = l_dw1 + 9 * C, *l_p0 = l_dw1b + C, *l_p0b = l_p0 + 16 * C,
+        *l_p1 = l_p0b + 16, *l_p1b = l_p1 + 16 * C;
+  const int t = threadIdx.x;
+  const int64_t pbase = (int64_t)blockIdx.x * NPIX;
+  const float* xp = x + pbase * C;
+  for (int i = t; i < 9 * C; i += 512) { l_dw0[i] = wts.dw0[i]; l_dw1[i] = wts.dw1[i]; }
+  for (int i = t; i < 16 * C; i += 512) { l_p0[i] = wts.p0[i]; l_p1[i] = wts.p1[i]; }
+  if (t < C) { l_dw0b[t] = wts.dw0b[t]; l_dw1b[t] = wts.dw1b[t]; l_p1b[t] = wts.p1b[t]; }
+  if (t < 16) l_p0b[t] = wts.p0b[t];
+  __syncthreads();
+  auto slot = [&](int pix, int cq) { return pix * C + 4 * (cq ^ (pix & MASK)); };
+
+  // ---- A: depthwise 3x3 + BN + ReLU6 (x from global / L2: every element is read by its 9 neighbours; all 9 loads of a quad are
+  // issued before the first use)
+  for (int i = t; i < NPIX * QPP; i += 512) {
+    const int pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
+    float4 v[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+      const bool inb = y2 >= 0 && y2 < HW && x2 >= 0 && x2 < HW;
+      v[tap] = *(const float4*)(xp + ((inb ? y2 : yy) * HW + (inb ? x2 : xx)) * C + ch);
+      if (!inb) v[tap] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 acc = *(const float4*)(l_dw0b + ch);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float4 k4 = *(const float4*)(l_dw0 + tap * C + ch);
+      acc.x = fmaf(v[tap].x, k4.x, acc.x); acc.y = fmaf(v[tap].y, k4.y, acc.y); acc.z = fmaf(v[tap].z, k4.z, acc.z); acc.w = fmaf(v[tap].w, k4.w, acc.w);
+    }
+    acc.x = fminf(fmaxf(acc.x, 0.f), 6.f); acc.y = fminf(fmaxf(acc.y, 0.f), 6.f); acc.z = fminf(fmaxf(acc.z, 0.f), 6.f); acc.w = fminf(fmaxf(acc.w, 0.f), 6.f);
+    *(float4*)(ybuf + slot(pix, cq)) = acc;
+  }
+  __syncthreads();
+  // ---- A2: pools (mean over x for every row, mean over y for every column)
+  for (int i = t; i < 2 * HW * C; i += 512) {
+    const bool over_x = i < HW * C;
+    const int j = over_x ? i : i - HW * C, line = j / C, ch = j % C, cq = ch >> 2, e = ch & 3;
+    float s = 0.f;
+    for (int k = 0; k < HW; ++k) { const int pix = over_x ? line * HW + k : k * HW + line; s += ybuf[slot(pix, cq) + e]; }
+    (over_x ? ph : pw)[j] = s / (float)HW;
+  }
+  __syncthreads();
+  // ---- B: gate MLP
+  for (int i = t; i < 2 * HW * 8; i += 512) {
+    const int r = i >> 3, m = i & 7;
+    const float* src = r < HW ? ph + r * C : pw + (r - HW) * C;
+    float acc = wts.b1[m];
+    for (int k = 0; k < C; ++k) acc = fmaf(src[k], wts.w1[m * C + k], acc);
+    mid[i] = acc * (fminf(fmaxf(acc + 3.f, 0.f), 6.f) / 6.f);
+  }
+  __syncthreads();
+  for (int i = t; i < 2 * HW * C; i += 512) {
+    const bool is_h = i < HW * C;
+    const int j = is_h ? i : i - HW * C, r = j / C, ch = j % C;
+    const float* wt = (is_h ? wts.wh : wts.ww) + ch * 8;
+    const float* mr = mid + (is_h ? r : HW + r) * 8;
+    float acc = (is_h ? wts.bh : wts.bw)[ch];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc = fmaf(mr[m], wt[m], acc);
+    (is_h ? ph : pw)[j] = 1.f / (1.f + __expf(-acc));
+  }
+  __syncthreads();
+  // ---- C: per pixel  z = ReLU6(W1 (W0 (y a_w a_h) + b0) + b1), in place
+  for (int pix = t; pix < NPIX; pix += 512) {
+    const int yy = pix / HW, xx = pix % HW;
+    float hid[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) hid[m] = l_p0b[m];
+#pragma unroll
+    for (int cq = 0; cq < QPP; ++cq) {
+      const float4 v = *(const float4*)(ybuf + slot(pix, cq));
+      const float4 g1 = *(const float4*)(ph + yy * C + 4 * cq), g2 = *(const float4*)(pw + xx * C + 4 * cq);
+      const float tv[4] = {v.x * g2.x * g1.x, v.y * g2.y * g1.y, v.z * g2.z * g1.z, v.w * g2.w * g1.w};
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float4 k4 = *(const float4*)(l_p0 + m * C + 4 * cq);          // broadcast reads, 16 bytes at a time
+        hid[m] = fmaf(tv[0], k4.x, fmaf(tv[1], k4.y, fmaf(tv[2], k4.z, fmaf(tv[3], k4.w, hid[m]))));
+      }
+    }
+#pragma unroll
+    for (int cq = 0; cq < QPP; ++cq) {
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float acc = l_p1b[4 * cq + j];
+#pragma unroll
+        for (int m = 0; m < 16; m += 4) {
+          const float4 k4 = *(const float4*)(l_p1 + (4 * cq + j) * 16 + m);
+          acc = fmaf(hid[m], k4.x, fmaf(hid[m + 1], k4.y, fmaf(hid[m + 2], k4.z, fmaf(hid[m + 3], k4.w, acc))));
+        }
+        r[j] = fminf(fmaxf(acc, 0.f), 6.f);
+      }
+      *(float4*)(ybuf + slot(pix, cq)) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+  }
+  __syncthreads();
+  // ---- D: out = 2 x + dw3x3(z) + BN, as split-bf16 pixel rows
+  for (int i = t; i < NPIX * QPP; i += 512) {
+    const int pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
+    const float4 xr = *(const float4*)(xp + pix * C + ch);
+    float4 acc = *(const float4*)(l_dw1b + ch);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+      if (y2 < 0 || y2 >= HW || x2 < 0 || x2 >= HW) continue;
+      const float4 v = *(const float4*)(ybuf + slot(y2 * HW + x2, cq));
+      const float4 k4 = *(const float4*)(l_dw1 + tap * C + ch);
+      acc.x = fmaf(v.x, k4.x, acc.x); acc.y = fmaf(v.y, k4.y, acc.y); acc.z = fmaf(v.z, k4.z, acc.z); acc.w = fmaf(v.w, k4.w, acc.w);
+    }
+    const float r[4] = {fmaf(xr.x, 2.f, acc.x), fmaf(xr.y, 2.f, acc.y), fmaf(xr.z, 2.f, acc.z), fmaf(xr.w, 2.f, acc.w)};
+    store_split4(out + (pbase + pix) * ldo + spl_col(ch), r);
+  }
+}
+
 // one wave per row of `c` (<= 256) values: y = x / sqrt(sum x^2 + eps)
 __global__ __launch_bounds__(256) void ch_l2norm_kernel(const float* __restrict__ x, int64_t rows, int c, float eps, float* __restrict__ y) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -354,6 +506,26 @@ extern "C" int gims_ch_gate_pw_pw(const float* x, int64_t patches, int32_t h, in
   const dim3 grid((unsigned)((pixels + 255) / 256));
   if (c == 32) hipLaunchKernelGGL(ch_gate_pw_pw_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, pixels, h, w, ah, aw, w0, b0, w1, b1, z);
   else hipLaunchKernelGGL(ch_gate_pw_pw_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x, pixels, h, w, ah, aw, w0, b0, w1, b1, z);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, int32_t c, const float* const* w /* 14 device pointers, ChSandglassW order */,
+                                 uint16_t* out_split, int64_t ld_split, void* stream) {
+  GIMS_CHECK_ARG(x && w && out_split && patches > 0 && ((c == 32 && hw == 32) || (c == 64 && hw == 16)) && ld_split >= 2 * (int64_t)c && (ld_split % 4) == 0,
+                 "gims_ch_sandglass: bad arguments (32x32x32 or 16x16x64 activations)");
+  ChSandglassW W;
+  const float** dst = (const float**)&W;
+  for (int i = 0; i < 14; ++i) { GIMS_CHECK_ARG(w[i] != nullptr, "gims_ch_sandglass: weight pointer %d is null", i); dst[i] = w[i]; }
+  const size_t lds = ((size_t)hw * hw * c + 2 * (size_t)hw * c + 16 * (size_t)hw + (size_t)c * (9 + 1 + 9 + 1 + 16 + 16 + 1) + 16) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  if (c == 32) hipLaunchKernelGGL((ch_sandglass_kernel<32, 32>), dim3((unsigned)patches), dim3(512), lds, (hipStream_t)stream, x, W, out_split, ld_split);
+  else hipLaunchKernelGGL((ch_sandglass_kernel<64, 16>), dim3((unsigned)patches), dim3(512), lds, (hipStream_t)stream, x, W, out_split, ld_split);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

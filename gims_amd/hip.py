@@ -100,6 +100,7 @@ _SIGNATURES = {
     "gims_ch_dwconv3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_gate_pw_pw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
+    "gims_ch_sandglass": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_l2norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_ch_relu6": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_run_ops": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -617,6 +618,14 @@ def ch_gate_pw_pw(x, ah, aw, S, z):
     _check(load().gims_ch_gate_pw_pw(_p(_dev(x, torch.float32)), n, h, w, c, _p(ah), _p(aw), _p(S["w0"]), _p(S["b0"]), _p(S["w1"]), _p(S["b1"]),
                                      _p(z), _stream()), "gims_ch_gate_pw_pw")
     return z
+
+
+def ch_sandglass(x, S, out_split):
+    """S: dict with the 14 weight tensors of gims_ch_sandglass in order (key 'ptrs': list of tensors)."""
+    n, h, w, c = x.shape
+    arr = (C.c_void_p * 14)(*[t.data_ptr() for t in S["ptrs"]])
+    _check(load().gims_ch_sandglass(_p(_dev(x, torch.float32)), n, h, c, arr, _p(out_split), out_split.stride(0), _stream()), "gims_ch_sandglass")
+    return out_split
 
 
 def ch_l2norm(x, eps, y):

@@ -362,6 +362,11 @@ int gims_ch_dwconv3(const float* x, int64_t patches, int32_t h, int32_t w, int32
 /* SandGlass middle in one pass per pixel: z = ReLU6(w1 (w0 (x * a_w * a_h) + b0) + b1); w0 [16][c], w1 [c][16] (BatchNorm folded), c = 32 | 64 */
 int gims_ch_gate_pw_pw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* ah, const float* aw, const float* w0,
                        const float* b0, const float* w1, const float* b1, float* z, void* stream);
+/* x + SandGlass(x) (models.py:182-235 with the outer residual of 383-389: 2x + conv stack) for 32x32x32 or 16x16x64 activations,
+ * one workgroup per patch with the activation resident in LDS; w: HOST array of 14 device pointers (BatchNorm folded):
+ * dw0 [9][c], dw0 bias [c], CoordAtt w1 [8][c], b1 [8], wh [c][8], bh [c], ww [c][8], bw [c], pw0 [16][c], pw0 bias [16],
+ * pw1 [c][16], pw1 bias [c], dw1 [9][c], dw1 bias [c].  Output: SPL32 split-bf16 pixel rows. */
+int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, int32_t c, const float* const* w, uint16_t* out_split, int64_t ld_split, void* stream);
 int gims_ch_l2norm(const float* x, int64_t rows, int32_t c, float eps, float* y, void* stream);
 int gims_ch_relu6(float* x, int64_t total, void* stream);
 

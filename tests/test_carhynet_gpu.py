@@ -48,6 +48,19 @@ def test_vs_oracle_ragged_batch():
     np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
 
 
+def test_fused_sandglass_equals_layer_by_layer():
+    """gims_ch_sandglass (one workgroup per patch, activation resident in LDS) against the separate kernels it replaces."""
+    patches = synth.make_patches(70, 31)
+    outs = []
+    for fused in (True, False):
+        m = _model(321)
+        m.fused_sandglass = fused
+        d, raw = m(torch.from_numpy(patches).permute(0, 3, 1, 2).cuda(), mode="train")
+        outs.append((d.cpu().numpy(), raw.cpu().numpy()))
+    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=5e-5, rtol=1e-5)       # same f32 arithmetic, different summation orders
+    np.testing.assert_allclose(outs[0][0], outs[1][0], atol=5e-6, rtol=0)
+
+
 def test_full_size_properties():
     """BASELINE config 5's size (descriptors for 2 x 8192 keypoints), where the CPU restatement is too slow: every patch is
     processed independently, so (1) the result does not depend on how the batch is chunked -- bit for bit --, (2) a patch
