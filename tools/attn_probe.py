@@ -23,4 +23,4 @@ for n, imgs in ((4096, 16), (1022, 64)):
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 10
     fl = 4.0 * n * n * 64 * 4 * imgs
-    print(f"n={n} x{imgs} images: {ms*1e3:8.1f} us per layer  {fl/ms*1e-9:7.1f} TFLOP/s  (GIMS_ATTN_KNOCK={os.environ.get('GIMS_ATTN_KNOCK','0')})")
+    print(f"n={n} x{imgs} images: {ms*1e3:8.1f} us per layer  {fl/ms*1e-9:7.1f} TFLOP/s  (GIMS_ATTN_EXACT={os.environ.get('GIMS_ATTN_EXACT','0')} q_prescaled={PRE})")
