@@ -28,6 +28,7 @@ EPS_L2_NORM = 1e-10
 class CARHyNet(nn.Module):
     chunk = 2048                      # patches per pass
     fused_sandglass = True            # False: the layer-by-layer kernels (kept as the cross-check of the fused one)
+    fused_frn = True                  # likewise for the FRN (+ CoordAtt) + TLU block
 
     def __init__(self):
         super().__init__()
@@ -175,6 +176,11 @@ class CARHyNet(nn.Module):
     def _frn_tlu(self, x, F, tau, G=None, split=False, split_out=None):
         """FRN (+ CoordAtt) + TLU; split=True: the result as SPL32 pixel rows for the next convolution instead of f32."""
         n, h, w, c = x.shape
+        if self.fused_frn and (h, w, c) in ((32, 32, 32), (16, 16, 64), (8, 8, 128)):
+            # one workgroup per patch, the raw convolution output read once into LDS (gims_ch_frn_block)
+            if split:
+                return hip.ch_frn_block(x, F, tau, G, None, split_out if split_out is not None else self._spl(n * h * w, c, x.device))
+            return hip.ch_frn_block(x, F, tau, G, torch.empty_like(x), None)
         ah = aw = None
         if G is not None:
             # one pass over the raw convolution output serves FRN's statistics and CoordAtt's two pools; the FRN affine map is

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "gims_ch_dwconv3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_gate_pw_pw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
+    "gims_ch_frn_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_sandglass": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_l2norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_ch_relu6": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
@@ -618,6 +620,15 @@ def ch_gate_pw_pw(x, ah, aw, S, z):
     _check(load().gims_ch_gate_pw_pw(_p(_dev(x, torch.float32)), n, h, w, c, _p(ah), _p(aw), _p(S["w0"]), _p(S["b0"]), _p(S["w1"]), _p(S["b1"]),
                                      _p(z), _stream()), "gims_ch_gate_pw_pw")
     return z
+
+
+def ch_frn_block(x, F, tau, G=None, y=None, y_split=None):
+    """FRN (+ CoordAtt gates G) + TLU of one layer, one pass over the activation; F: dict(w, b, eps), G: dict(w1, b1, wh, bh, ww, bw)."""
+    n, h, w, c = x.shape
+    arr = (C.c_void_p * 6)(*[G[k].data_ptr() for k in ("w1", "b1", "wh", "bh", "ww", "bw")]) if G is not None else None
+    _check(load().gims_ch_frn_block(_p(_dev(x, torch.float32)), n, h, c, _p(F["w"]), _p(F["b"]), float(F["eps"]), arr, _p(tau), _p(y), _p(y_split),
+                                    y_split.stride(0) if y_split is not None else 0, _stream()), "gims_ch_frn_block")
+    return y if y is not None else y_split
 
 
 def ch_sandglass(x, S, out_split):

@@ -362,6 +362,12 @@ int gims_ch_dwconv3(const float* x, int64_t patches, int32_t h, int32_t w, int32
 /* SandGlass middle in one pass per pixel: z = ReLU6(w1 (w0 (x * a_w * a_h) + b0) + b1); w0 [16][c], w1 [c][16] (BatchNorm folded), c = 32 | 64 */
 int gims_ch_gate_pw_pw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* ah, const float* aw, const float* w0,
                        const float* b0, const float* w1, const float* b1, float* z, void* stream);
+/* FRN (+ CoordAtt) + TLU of one layer in one pass over the activation (32x32x32, 16x16x64 or 8x8x128), one workgroup per patch with
+ * the raw convolution output resident in LDS: y = max((x s + b) a_w a_h, tau), s = frn_weight * rsqrt(mean x^2 + eps) per (patch,
+ * channel), gates as in gims_ch_gates (gate_w: HOST array of 6 device pointers w1 [8][c] (+BN folded), b1, wh [c][8], bh, ww, bw; NULL: no
+ * CoordAtt).  Output f32 NHWC and / or SPL32 split-bf16 pixel rows. */
+int gims_ch_frn_block(const float* x, int64_t patches, int32_t hw, int32_t c, const float* frn_weight, const float* frn_bias, float eps,
+                      const float* const* gate_w, const float* tau, float* y, uint16_t* y_split, int64_t ld_split, void* stream);
 /* x + SandGlass(x) (models.py:182-235 with the outer residual of 383-389: 2x + conv stack) for 32x32x32 or 16x16x64 activations,
  * one workgroup per patch with the activation resident in LDS; w: HOST array of 14 device pointers (BatchNorm folded):
  * dw0 [9][c], dw0 bias [c], CoordAtt w1 [8][c], b1 [8], wh [c][8], bh [c], ww [c][8], bw [c], pw0 [16][c], pw0 bias [16],

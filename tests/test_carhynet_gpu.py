@@ -48,13 +48,13 @@ def test_vs_oracle_ragged_batch():
     np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
 
 
-def test_fused_sandglass_equals_layer_by_layer():
-    """gims_ch_sandglass (one workgroup per patch, activation resident in LDS) against the separate kernels it replaces."""
+def test_fused_blocks_equal_layer_by_layer():
+    """gims_ch_sandglass / gims_ch_frn_block (one workgroup per patch, activation resident in LDS) against the separate kernels they replace."""
     patches = synth.make_patches(70, 31)
     outs = []
     for fused in (True, False):
         m = _model(321)
-        m.fused_sandglass = fused
+        m.fused_sandglass = m.fused_frn = fused
         d, raw = m(torch.from_numpy(patches).permute(0, 3, 1, 2).cuda(), mode="train")
         outs.append((d.cpu().numpy(), raw.cpu().numpy()))
     np.testing.assert_allclose(outs[0][1], outs[1][1], atol=5e-5, rtol=1e-5)       # same f32 arithmetic, different summation orders
