@@ -346,11 +346,12 @@ __global__ __launch_bounds__(512) void ch_frn_block_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------- fused SandGlass block
 // One workgroup per patch, the whole block of models.py:182-235 (+ the outer residual of 383-389) with the patch's activation
 // resident in LDS (H * W * C = 32768 floats = 128 KiB: 32x32x32 or 16x16x64):
-//   A  y = ReLU6(dw3x3(x) + BN)                       x from global (L2: every element is read by 9 neighbours), y -> LDS
+//   0  x -> LDS (bulk, coalesced) and this thread's own quads -> registers (for the residual)
+//   A  y = ReLU6(dw3x3(x) + BN)                       from the LDS copy into registers, then over the copy
 //   A2 pools of y over W and over H                   LDS -> LDS
 //   B  CoordAtt gate MLP: 8-channel bottleneck, sigmoid gates a_h, a_w (they overwrite the pools)
 //   C  z = ReLU6(W1 (W0 (y a_w a_h) + b0) + b1)      per pixel, in place
-//   D  out = 2 x + dw3x3(z) + BN                      z from LDS, x from global, out as SPL32 split-bf16 pixel rows
+//   D  out = 2 x + dw3x3(z) + BN                      z from LDS, x from registers, out as SPL32 split-bf16 pixel rows
 // LDS image of y / z: [pixel][C] with the 16-byte quads of a pixel XOR-swizzled by the pixel index, so that both the
 // quad-per-lane passes (A, D) and the pixel-per-lane pass (C) are bank-conflict free without padding.
 struct ChSandglassW {          // all f32, BatchNorm folded
@@ -391,27 +392,39 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
   __syncthreads();
   auto slot = [&](int pix, int cq) { return pix * C + 4 * (cq ^ (pix & MASK)); };
 
-  // ---- A: depthwise 3x3 + BN + ReLU6 (x from global / L2: every element is read by its 9 neighbours; all 9 loads of a quad are
-  // issued before the first use)
-  for (int i = t; i < NPIX * QPP; i += 512) {
-    const int pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
-    float4 v[9];
+  // ---- 0: the patch into LDS and, for the final residual, this thread's own quads into registers: NQ independent, fully
+  // coalesced 16-byte loads in flight at once (with two waves per SIMD nothing else would hide a dependent load)
+  constexpr int NQ = NPIX * QPP / 512;
+  float4 xq[NQ];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
-      const bool inb = y2 >= 0 && y2 < HW && x2 >= 0 && x2 < HW;
-      v[tap] = *(const float4*)(xp + ((inb ? y2 : yy) * HW + (inb ? x2 : xx)) * C + ch);
-      if (!inb) v[tap] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+  for (int j = 0; j < NQ; ++j) xq[j] = *(const float4*)(xp + (int64_t)(t + 512 * j) * 4);
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) { const int i = t + 512 * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = xq[j]; }
+  __syncthreads();
+  // ---- A: depthwise 3x3 + BN + ReLU6 from the LDS copy into registers, then over the copy.  The loop is unrolled (register
+  // arrays), but the thread index is re-derived from an opaque copy every iteration: as loop invariants the compiler hoisted
+  // all NQ x 9 addresses and weights and spilled 900 registers.
+  float4 yq[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    const int i = tt + 512 * j, pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
     float4 acc = *(const float4*)(l_dw0b + ch);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+      const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+      if (y2 < 0 || y2 >= HW || x2 < 0 || x2 >= HW) continue;
+      const float4 v = *(const float4*)(ybuf + slot(y2 * HW + x2, cq));
       const float4 k4 = *(const float4*)(l_dw0 + tap * C + ch);
-      acc.x = fmaf(v[tap].x, k4.x, acc.x); acc.y = fmaf(v[tap].y, k4.y, acc.y); acc.z = fmaf(v[tap].z, k4.z, acc.z); acc.w = fmaf(v[tap].w, k4.w, acc.w);
+      acc.x = fmaf(v.x, k4.x, acc.x); acc.y = fmaf(v.y, k4.y, acc.y); acc.z = fmaf(v.z, k4.z, acc.z); acc.w = fmaf(v.w, k4.w, acc.w);
     }
     acc.x = fminf(fmaxf(acc.x, 0.f), 6.f); acc.y = fminf(fmaxf(acc.y, 0.f), 6.f); acc.z = fminf(fmaxf(acc.z, 0.f), 6.f); acc.w = fminf(fmaxf(acc.w, 0.f), 6.f);
-    *(float4*)(ybuf + slot(pix, cq)) = acc;
+    yq[j] = acc;
   }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) { const int i = t + 512 * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = yq[j]; }
   __syncthreads();
   // ---- A2: pools (mean over x for every row, mean over y for every column)
   for (int i = t; i < 2 * HW * C; i += 512) {
@@ -476,10 +489,12 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
     }
   }
   __syncthreads();
-  // ---- D: out = 2 x + dw3x3(z) + BN, as split-bf16 pixel rows
-  for (int i = t; i < NPIX * QPP; i += 512) {
-    const int pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
-    const float4 xr = *(const float4*)(xp + pix * C + ch);
+  // ---- D: out = 2 x + dw3x3(z) + BN, as split-bf16 pixel rows (x from the registers of step 0)
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    const int i = tt + 512 * j, pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
     float4 acc = *(const float4*)(l_dw1b + ch);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
       const float4 k4 = *(const float4*)(l_dw1 + tap * C + ch);
       acc.x = fmaf(v.x, k4.x, acc.x); acc.y = fmaf(v.y, k4.y, acc.y); acc.z = fmaf(v.z, k4.z, acc.z); acc.w = fmaf(v.w, k4.w, acc.w);
     }
-    const float r[4] = {fmaf(xr.x, 2.f, acc.x), fmaf(xr.y, 2.f, acc.y), fmaf(xr.z, 2.f, acc.z), fmaf(xr.w, 2.f, acc.w)};
+    const float r[4] = {fmaf(xq[j].x, 2.f, acc.x), fmaf(xq[j].y, 2.f, acc.y), fmaf(xq[j].z, 2.f, acc.z), fmaf(xq[j].w, 2.f, acc.w)};
     store_split4(out + (pbase + pix) * ldo + spl_col(ch), r);
   }
 }
