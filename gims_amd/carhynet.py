@@ -217,11 +217,19 @@ class CARHyNet(nn.Module):
             raise hip.GimsHipError("CARHyNet runs on the GPU only (no CPU fallback): move the patches to 'cuda'")
         P = self._prepare(patches.device)
         n = patches.shape[0]
-        x = torch.zeros((n, 32, 32, 4), dtype=torch.float32, device=patches.device)      # channel 3 = padding (weights are zero there)
-        x[..., :3] = patches
         L = P["l1"]
-        x = self._frn_tlu(x, L["frn0"], L["tau0"])
-        xs = self._frn_tlu(self._conv3_im2col(x, L["conv"], 1), L["frn"], L["tau"], L["ca"], split=True)
+        if self.fused_frn:
+            # FRN(3) + TLU(3) and the first convolution's operand rows in one per-patch kernel (gims_ch_input_block)
+            cols = hip.ch_input_block(patches.contiguous(), L["frn0"], L["tau0"], torch.empty((n * 1024, 2 * L["conv"]["kpad"]), dtype=torch.bfloat16, device=patches.device))
+            y1 = torch.empty((n * 1024, L["conv"]["n"]), dtype=torch.float32, device=patches.device)
+            hip.linear(cols, L["conv"]["w"], spl=True, bias=L["conv"]["b"], precision=hip.PREC_BF16X3, out=y1)
+            y1 = y1.view(n, 32, 32, L["conv"]["n"])
+        else:
+            x = torch.zeros((n, 32, 32, 4), dtype=torch.float32, device=patches.device)      # channel 3 = padding (weights are zero there)
+            x[..., :3] = patches
+            x = self._frn_tlu(x, L["frn0"], L["tau0"])
+            y1 = self._conv3_im2col(x, L["conv"], 1)
+        xs = self._frn_tlu(y1, L["frn"], L["tau"], L["ca"], split=True)
         L = P["l2"]
         x1 = self._frn_tlu(self._conv3(xs, n, 32, 32, L["conv"], 1), L["frn"], L["tau"], L["ca"])
         xs = self._sandglass_plus(x1, P["sg2"])

@@ -11,6 +11,7 @@
 //   gims_ch_im2col3       3x3 patches (pad 1, stride 1 or 2) written as SPL32 split-bf16 GEMM operand rows
 //   gims_ch_dwconv3       depthwise 3x3 + folded BatchNorm (+ReLU6 on input / output, + residual)          models.py:172-180, 207, 220-223
 //   gims_ch_gate_pw_pw    SandGlass middle in one pass: CoordAtt gates applied, 1x1 C->16 (+BN), 1x1 16->C (+BN, ReLU6)  models.py:152, 208-218
+//   gims_ch_input_block   FRN(3) + TLU(3) on the raw patches and the first convolution's split-bf16 operand rows, one workgroup per patch  models.py:316-317
 //   gims_ch_frn_block     FRN (+ CoordAtt) + TLU of one layer, one workgroup per patch: one read, one write of the activation   models.py:57-108, 139-153
 //   gims_ch_sandglass     the whole SandGlass block + outer residual, one workgroup per patch, activation resident in LDS  models.py:182-235
 //   gims_ch_l2norm        x / sqrt(sum x^2 + 1e-10) per row                                                 models.py:9-21
@@ -249,6 +250,58 @@ __global__ __launch_bounds__(256) void ch_gate_pw_pw_kernel(const float* __restr
       r[j] = fminf(fmaxf(acc, 0.f), 6.f);
     }
     *(float4*)(z + pix * C + o) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- input block
+// One workgroup per patch: FRN(3) + TLU(3) on the 32x32x3 input (models.py:316-317) and the 3x3 neighbourhoods of the result
+// written straight as the split-bf16 operand rows of the first convolution (K = 9 taps x 4 channels -- the 4th is zero --
+// padded to 64): 16 lanes write one 256-byte row, so a wave-wide store covers 1 KiB of consecutive bytes.
+__global__ __launch_bounds__(256) void ch_input_block_kernel(const float* __restrict__ patches, const float* __restrict__ fw, const float* __restrict__ fb,
+                                                             float eps, const float* __restrict__ tau, uint16_t* __restrict__ out, int64_t ldo) {
+  __shared__ float yb[1024 * 4];
+  __shared__ float red[64][4];
+  __shared__ float sc[4];
+  const int t = threadIdx.x;
+  const float* pp = patches + (int64_t)blockIdx.x * 1024 * 3;
+  float q[3] = {0.f, 0.f, 0.f};
+  for (int pix = t; pix < 1024; pix += 256) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float v = pp[pix * 3 + c]; yb[pix * 4 + c] = v; q[c] = fmaf(v, v, q[c]); }
+    yb[pix * 4 + 3] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q[c] += __shfl_xor(q[c], o, 64);
+  }
+  if ((t & 63) == 0) { red[t >> 6][0] = q[0]; red[t >> 6][1] = q[1]; red[t >> 6][2] = q[2]; }
+  __syncthreads();
+  if (t < 3) sc[t] = fw[t] * rsqrtf((red[0][t] + red[1][t] + red[2][t] + red[3][t]) / 1024.f + eps);
+  __syncthreads();
+  for (int i = t; i < 1024 * 3; i += 256) {
+    const int pix = i / 3, c = i - 3 * pix;
+    yb[pix * 4 + c] = fmaxf(fmaf(yb[pix * 4 + c], sc[c], fb[c]), tau[c]);
+  }
+  __syncthreads();
+  // rows: pixel = 16 * it + (t >> 4); lane part q16 = t & 15 writes elements [8 q16, 8 q16 + 8) of the 128-element SPL32 row
+  const int q16 = t & 15, blk = q16 >> 3, pos = (8 * q16) & 63, lo = pos >= 32, k0 = 32 * blk + (pos & 31);
+  for (int it = 0; it < 64; ++it) {
+    const int pix = 16 * it + (t >> 4), yy = pix >> 5, xx = pix & 31;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + e, tap = k >> 2, c = k & 3;
+      const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+      v[e] = (tap < 9 && y2 >= 0 && y2 < 32 && x2 >= 0 && x2 < 32) ? yb[(y2 * 32 + x2) * 4 + c] : 0.f;
+    }
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t h = pack_bf2(v[2 * e], v[2 * e + 1]);
+      w[e] = lo ? pack_bf2(v[2 * e] - __uint_as_float(h << 16), v[2 * e + 1] - __uint_as_float(h & 0xffff0000u)) : h;
+    }
+    *(uint4*)(out + ((int64_t)blockIdx.x * 1024 + pix) * ldo + 8 * q16) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 
@@ -613,6 +666,15 @@ extern "C" int gims_ch_gate_pw_pw(const float* x, int64_t patches, int32_t h, in
   const dim3 grid((unsigned)((pixels + 255) / 256));
   if (c == 32) hipLaunchKernelGGL(ch_gate_pw_pw_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, pixels, h, w, ah, aw, w0, b0, w1, b1, z);
   else hipLaunchKernelGGL(ch_gate_pw_pw_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x, pixels, h, w, ah, aw, w0, b0, w1, b1, z);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_input_block(const float* patches, int64_t n, const float* frn_weight, const float* frn_bias, float eps, const float* tau,
+                                   uint16_t* out, int64_t ld, void* stream) {
+  GIMS_CHECK_ARG(patches && frn_weight && frn_bias && tau && out && n > 0 && eps >= 0.f && ld >= 128 && (ld % 64) == 0 && (((uintptr_t)out) & 15) == 0,
+                 "gims_ch_input_block: bad arguments (SPL32 rows of K = 64: pitch >= 128, %% 64 == 0)");
+  hipLaunchKernelGGL(ch_input_block_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, patches, frn_weight, frn_bias, eps, tau, out, ld);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "gims_ch_dwconv3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_gate_pw_pw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
+    "gims_ch_input_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_frn_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_sandglass": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -620,6 +621,14 @@ def ch_gate_pw_pw(x, ah, aw, S, z):
     _check(load().gims_ch_gate_pw_pw(_p(_dev(x, torch.float32)), n, h, w, c, _p(ah), _p(aw), _p(S["w0"]), _p(S["b0"]), _p(S["w1"]), _p(S["b1"]),
                                      _p(z), _stream()), "gims_ch_gate_pw_pw")
     return z
+
+
+def ch_input_block(patches, F, tau, out):
+    """patches [n, 32, 32, 3] f32 -> FRN + TLU -> SPL32 im2col rows [n*1024, >= 128] of the first convolution."""
+    n = patches.shape[0]
+    _check(load().gims_ch_input_block(_p(_dev(patches, torch.float32)), n, _p(F["w"]), _p(F["b"]), float(F["eps"]), _p(tau), _p(out), out.stride(0),
+                                      _stream()), "gims_ch_input_block")
+    return out
 
 
 def ch_frn_block(x, F, tau, G=None, y=None, y_split=None):

@@ -362,6 +362,10 @@ int gims_ch_dwconv3(const float* x, int64_t patches, int32_t h, int32_t w, int32
 /* SandGlass middle in one pass per pixel: z = ReLU6(w1 (w0 (x * a_w * a_h) + b0) + b1); w0 [16][c], w1 [c][16] (BatchNorm folded), c = 32 | 64 */
 int gims_ch_gate_pw_pw(const float* x, int64_t patches, int32_t h, int32_t w, int32_t c, const float* ah, const float* aw, const float* w0,
                        const float* b0, const float* w1, const float* b1, float* z, void* stream);
+/* Input stage (models.py:316-317): patches [n][32][32][3] f32 -> FRN(3) + TLU(3) -> the 3x3 neighbourhoods as SPL32 rows
+ * [n*1024][pitch ld >= 128] for the first convolution's GEMM: column (ky*3+kx)*4 + c, K = 36 zero-padded to 64 (channel 3 is zero). */
+int gims_ch_input_block(const float* patches, int64_t n, const float* frn_weight /* [>=3] */, const float* frn_bias, float eps, const float* tau,
+                        uint16_t* out, int64_t ld, void* stream);
 /* FRN (+ CoordAtt) + TLU of one layer in one pass over the activation (32x32x32, 16x16x64 or 8x8x128), one workgroup per patch with
  * the raw convolution output resident in LDS: y = max((x s + b) a_w a_h, tau), s = frn_weight * rsqrt(mean x^2 + eps) per (patch,
  * channel), gates as in gims_ch_gates (gate_w: HOST array of 6 device pointers w1 [8][c] (+BN folded), b1, wh [c][8], bh, ww, bw; NULL: no
