@@ -312,11 +312,11 @@ __global__ __launch_bounds__(256) void ch_input_block_kernel(const float* __rest
 // pooling sweeps, apply pass).  models.py:57-85 (FRN), 139-153 (CoordAtt), 107-108 (TLU).
 struct ChGateW { const float* w1; const float* b1; const float* wh; const float* bh; const float* ww; const float* bw; };   // null w1: no CoordAtt
 
-template <int C, int HW>
-__global__ __launch_bounds__(512) void ch_frn_block_kernel(const float* __restrict__ x, const float* __restrict__ fw, const float* __restrict__ fb, float eps,
+template <int C, int HW, int NT>
+__global__ __launch_bounds__(NT) void ch_frn_block_kernel(const float* __restrict__ x, const float* __restrict__ fw, const float* __restrict__ fb, float eps,
                                                            ChGateW g, const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp,
                                                            int64_t ldsp) {
-  constexpr int NPIX = HW * HW, QPP = C / 4, NQ = NPIX * QPP / 512, GRP = 512 / C;
+  constexpr int NPIX = HW * HW, QPP = C / 4, NQ = NPIX * QPP / NT, GRP = NT / C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xb = lds;                          // [NPIX][C]
   float* red = xb + NPIX * C;               // [GRP][C]
@@ -330,9 +330,9 @@ __global__ __launch_bounds__(512) void ch_frn_block_kernel(const float* __restri
   {   // bulk load: NQ independent, fully coalesced 16-byte loads per thread
     float4 v[NQ];
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) v[j] = *(const float4*)(xp + (int64_t)(t + 512 * j) * 4);
+    for (int j = 0; j < NQ; ++j) v[j] = *(const float4*)(xp + (int64_t)(t + NT * j) * 4);
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) *(float4*)(xb + (t + 512 * j) * 4) = v[j];
+    for (int j = 0; j < NQ; ++j) *(float4*)(xb + (t + NT * j) * 4) = v[j];
   }
   __syncthreads();
   {   // FRN statistic: mean of x^2 over the pixels, per channel
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(512) void ch_frn_block_kernel(const float* __restri
   __syncthreads();
   const bool coord = g.w1 != nullptr;
   if (coord) {
-    for (int i = t; i < 2 * HW * C; i += 512) {        // pools of the FRN output = FRN affine map of the raw pools
+    for (int i = t; i < 2 * HW * C; i += NT) {        // pools of the FRN output = FRN affine map of the raw pools
       const bool over_x = i < HW * C;
       const int j = over_x ? i : i - HW * C, line = j / C, ch = j % C;
       float s = 0.f;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void ch_frn_block_kernel(const float* __restri
       (over_x ? ph : pw)[j] = fmaf(s / (float)HW, sc[ch], fb[ch]);
     }
     __syncthreads();
-    for (int i = t; i < 2 * HW * 8; i += 512) {
+    for (int i = t; i < 2 * HW * 8; i += NT) {
       const int r = i >> 3, m = i & 7;
       const float* src = r < HW ? ph + r * C : pw + (r - HW) * C;
       float acc = g.b1[m];
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512) void ch_frn_block_kernel(const float* __restri
       mid[i] = acc * (fminf(fmaxf(acc + 3.f, 0.f), 6.f) / 6.f);
     }
     __syncthreads();
-    for (int i = t; i < 2 * HW * C; i += 512) {
+    for (int i = t; i < 2 * HW * C; i += NT) {
       const bool is_h = i < HW * C;
       const int j = is_h ? i : i - HW * C, r = j / C, ch = j % C;
       const float* wt = (is_h ? g.wh : g.ww) + ch * 8;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(512) void ch_frn_block_kernel(const float* __restri
   }
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
-    const int i = t + 512 * j, pix = i / QPP, ch = 4 * (i % QPP), yy = pix / HW, xx = pix % HW;
+    const int i = t + NT * j, pix = i / QPP, ch = 4 * (i % QPP), yy = pix / HW, xx = pix % HW;
     const float4 v = *(const float4*)(xb + i * 4);
     const float4 s4 = *(const float4*)(sc + ch), b4 = *(const float4*)(fb + ch);
     float r[4] = {fmaf(v.x, s4.x, b4.x), fmaf(v.y, s4.y, b4.y), fmaf(v.z, s4.z, b4.z), fmaf(v.w, s4.w, b4.w)};
@@ -424,8 +424,8 @@ struct ChSandglassW {          // all f32, BatchNorm folded
   const float* dw1b;  // [C]
 };
 
-template <int C, int HW>      // HW = H = W
-__global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restrict__ x, ChSandglassW wts, uint16_t* __restrict__ out, int64_t ldo) {
+template <int C, int HW, int NT>      // HW = H = W, NT threads
+__global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restrict__ x, ChSandglassW wts, uint16_t* __restrict__ out, int64_t ldo) {
   constexpr int NPIX = HW * HW, QPP = C / 4, MASK = QPP - 1;          // quads per pixel
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ybuf = lds;                        // [NPIX][C] swizzled
@@ -438,8 +438,8 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
   const int t = threadIdx.x;
   const int64_t pbase = (int64_t)blockIdx.x * NPIX;
   const float* xp = x + pbase * C;
-  for (int i = t; i < 9 * C; i += 512) { l_dw0[i] = wts.dw0[i]; l_dw1[i] = wts.dw1[i]; }
-  for (int i = t; i < 16 * C; i += 512) { l_p0[i] = wts.p0[i]; l_p1[i] = wts.p1[i]; }
+  for (int i = t; i < 9 * C; i += NT) { l_dw0[i] = wts.dw0[i]; l_dw1[i] = wts.dw1[i]; }
+  for (int i = t; i < 16 * C; i += NT) { l_p0[i] = wts.p0[i]; l_p1[i] = wts.p1[i]; }
   if (t < C) { l_dw0b[t] = wts.dw0b[t]; l_dw1b[t] = wts.dw1b[t]; l_p1b[t] = wts.p1b[t]; }
   if (t < 16) l_p0b[t] = wts.p0b[t];
   __syncthreads();
@@ -447,12 +447,12 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
 
   // ---- 0: the patch into LDS and, for the final residual, this thread's own quads into registers: NQ independent, fully
   // coalesced 16-byte loads in flight at once (with two waves per SIMD nothing else would hide a dependent load)
-  constexpr int NQ = NPIX * QPP / 512;
+  constexpr int NQ = NPIX * QPP / NT;
   float4 xq[NQ];
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) xq[j] = *(const float4*)(xp + (int64_t)(t + 512 * j) * 4);
+  for (int j = 0; j < NQ; ++j) xq[j] = *(const float4*)(xp + (int64_t)(t + NT * j) * 4);
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) { const int i = t + 512 * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = xq[j]; }
+  for (int j = 0; j < NQ; ++j) { const int i = t + NT * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = xq[j]; }
   __syncthreads();
   // ---- A: depthwise 3x3 + BN + ReLU6 from the LDS copy into registers, then over the copy.  The loop is unrolled (register
   // arrays), but the thread index is re-derived from an opaque copy every iteration: as loop invariants the compiler hoisted
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
   for (int j = 0; j < NQ; ++j) {
     int tt = t;
     asm volatile("" : "+v"(tt));
-    const int i = tt + 512 * j, pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
+    const int i = tt + NT * j, pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
     float4 acc = *(const float4*)(l_dw0b + ch);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -477,10 +477,10 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) { const int i = t + 512 * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = yq[j]; }
+  for (int j = 0; j < NQ; ++j) { const int i = t + NT * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = yq[j]; }
   __syncthreads();
   // ---- A2: pools (mean over x for every row, mean over y for every column)
-  for (int i = t; i < 2 * HW * C; i += 512) {
+  for (int i = t; i < 2 * HW * C; i += NT) {
     const bool over_x = i < HW * C;
     const int j = over_x ? i : i - HW * C, line = j / C, ch = j % C, cq = ch >> 2, e = ch & 3;
     float s = 0.f;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
   }
   __syncthreads();
   // ---- B: gate MLP
-  for (int i = t; i < 2 * HW * 8; i += 512) {
+  for (int i = t; i < 2 * HW * 8; i += NT) {
     const int r = i >> 3, m = i & 7;
     const float* src = r < HW ? ph + r * C : pw + (r - HW) * C;
     float acc = wts.b1[m];
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
     mid[i] = acc * (fminf(fmaxf(acc + 3.f, 0.f), 6.f) / 6.f);
   }
   __syncthreads();
-  for (int i = t; i < 2 * HW * C; i += 512) {
+  for (int i = t; i < 2 * HW * C; i += NT) {
     const bool is_h = i < HW * C;
     const int j = is_h ? i : i - HW * C, r = j / C, ch = j % C;
     const float* wt = (is_h ? wts.wh : wts.ww) + ch * 8;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
   }
   __syncthreads();
   // ---- C: per pixel  z = ReLU6(W1 (W0 (y a_w a_h) + b0) + b1), in place
-  for (int pix = t; pix < NPIX; pix += 512) {
+  for (int pix = t; pix < NPIX; pix += NT) {
     const int yy = pix / HW, xx = pix % HW;
     float hid[16];
 #pragma unroll
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(512) void ch_sandglass_kernel(const float* __restri
   for (int j = 0; j < NQ; ++j) {
     int tt = t;
     asm volatile("" : "+v"(tt));
-    const int i = tt + 512 * j, pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
+    const int i = tt + NT * j, pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
     float4 acc = *(const float4*)(l_dw1b + ch);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -691,19 +691,20 @@ extern "C" int gims_ch_frn_block(const float* x, int64_t patches, int32_t hw, in
     for (int i = 0; i < 6; ++i) GIMS_CHECK_ARG(gate_w[i] != nullptr, "gims_ch_frn_block: gate weight pointer %d is null", i);
     G = ChGateW{gate_w[0], gate_w[1], gate_w[2], gate_w[3], gate_w[4], gate_w[5]};
   }
-  const size_t lds = ((size_t)hw * hw * c + (512 / c) * (size_t)c + c + 2 * (size_t)hw * c + 16 * (size_t)hw) * sizeof(float);
+  constexpr int FRN_NT = 1024;
+  const size_t lds = ((size_t)hw * hw * c + (FRN_NT / c) * (size_t)c + c + 2 * (size_t)hw * c + 16 * (size_t)hw) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_frn_block_kernel<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_frn_block_kernel<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_frn_block_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_frn_block_kernel<32, 32, FRN_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_frn_block_kernel<64, 16, FRN_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_frn_block_kernel<128, 8, FRN_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
   const dim3 grid((unsigned)patches);
   hipStream_t st = (hipStream_t)stream;
-  if (c == 32) hipLaunchKernelGGL((ch_frn_block_kernel<32, 32>), grid, dim3(512), lds, st, x, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split);
-  else if (c == 64) hipLaunchKernelGGL((ch_frn_block_kernel<64, 16>), grid, dim3(512), lds, st, x, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split);
-  else hipLaunchKernelGGL((ch_frn_block_kernel<128, 8>), grid, dim3(512), lds, st, x, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split);
+  if (c == 32) hipLaunchKernelGGL((ch_frn_block_kernel<32, 32, FRN_NT>), grid, dim3(FRN_NT), lds, st, x, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split);
+  else if (c == 64) hipLaunchKernelGGL((ch_frn_block_kernel<64, 16, FRN_NT>), grid, dim3(FRN_NT), lds, st, x, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split);
+  else hipLaunchKernelGGL((ch_frn_block_kernel<128, 8, FRN_NT>), grid, dim3(FRN_NT), lds, st, x, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }
@@ -715,15 +716,16 @@ extern "C" int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, in
   ChSandglassW W;
   const float** dst = (const float**)&W;
   for (int i = 0; i < 14; ++i) { GIMS_CHECK_ARG(w[i] != nullptr, "gims_ch_sandglass: weight pointer %d is null", i); dst[i] = w[i]; }
+  constexpr int SG_NT = 1024;
   const size_t lds = ((size_t)hw * hw * c + 2 * (size_t)hw * c + 16 * (size_t)hw + (size_t)c * (9 + 1 + 9 + 1 + 16 + 16 + 1) + 16) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<32, 32, SG_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<64, 16, SG_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  if (c == 32) hipLaunchKernelGGL((ch_sandglass_kernel<32, 32>), dim3((unsigned)patches), dim3(512), lds, (hipStream_t)stream, x, W, out_split, ld_split);
-  else hipLaunchKernelGGL((ch_sandglass_kernel<64, 16>), dim3((unsigned)patches), dim3(512), lds, (hipStream_t)stream, x, W, out_split, ld_split);
+  if (c == 32) hipLaunchKernelGGL((ch_sandglass_kernel<32, 32, SG_NT>), dim3((unsigned)patches), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split);
+  else hipLaunchKernelGGL((ch_sandglass_kernel<64, 16, SG_NT>), dim3((unsigned)patches), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }
