@@ -120,6 +120,30 @@ def test_linear_presplit_hi_only(hip, m, n, k):
     assert (np.abs(out.cpu().numpy() - full) / scale_ref).max() < 2.0 ** -7      # and it IS only a bf16 product
 
 
+@pytest.mark.parametrize("n,h,c,cout,stride", [(5, 32, 32, 32, 1), (3, 32, 32, 64, 2), (7, 16, 64, 64, 1), (2, 16, 64, 128, 2), (9, 8, 128, 128, 1)])
+def test_linear_conv3_gather(hip, n, h, c, cout, stride):
+    """GIMS_LINEAR_CONV3: the split-bf16 GEMM reads its operand rows straight from the 3x3 neighbourhoods of SPL32 NHWC pixel
+    rows (zero padding from a zero row) -- against torch's conv2d in float64."""
+    r = _rng(n * 100 + c)
+    x = r.normal(size=(n, h, h, c)).astype(np.float32)
+    w = (r.normal(size=(cout, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32)
+    bias = r.normal(size=cout).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(w).double(), torch.from_numpy(bias).double(),
+                                     stride=stride, padding=1).permute(0, 2, 3, 1).numpy()
+    ho = (h - 1) // stride + 1
+    xs = hip.split_spl32(_dev(x.reshape(n * h * h, c)))
+    wk = hip.split_spl32(_dev(np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(cout, 9 * c))))      # column (ky*3+kx)*c + ch
+    zeros = torch.zeros(256, dtype=torch.bfloat16, device="cuda")
+    out = torch.full((n * ho * ho, cout), float("nan"), dtype=torch.float32, device="cuda")
+    args = hip.linear_args(xs, wk, a1=zeros, bias=_dev(bias), out=out, precision=hip.PREC_BF16X3, spl=True, conv=(h, h, stride), m=n * ho * ho)
+    hip._check(hip.load().gims_linear(hip.C.byref(args), hip._stream()), "gims_linear(conv3)")
+    o = out.cpu().numpy().reshape(n, ho, ho, cout)
+    scale = torch.nn.functional.conv2d(torch.from_numpy(np.abs(x)).double().permute(0, 3, 1, 2), torch.from_numpy(np.abs(w)).double(), None,
+                                       stride=stride, padding=1).permute(0, 2, 3, 1).numpy() + np.abs(bias)
+    err = np.abs(o - ref) / scale
+    assert np.isfinite(o).all() and err.max() < 4e-5, f"conv3 gather: max scaled err {err.max():.3e}"      # split-bf16x3 class
+
+
 def test_split_spl3_exact(hip):
     """SPL3 = exact three-way bf16 split: the planes sum back to the f32 value bit for bit (24 significand bits)."""
     r = _rng(5)
