@@ -627,10 +627,12 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
     // else 128x128.  GIMS_X3P_TILE=128|256 forces one (experiments).
     using TS = X3P<128, 128, 2, 2, 2>;
     using TL = X3P<256, 256, 4, 2, 2>;
-    static int force = -1;
+    static int force = -1, qkv_tile = 3;
     if (force < 0) {
       const char* e = getenv("GIMS_X3P_TILE");
       force = e ? atoi(e) : 0;
+      const char* eq = getenv("GIMS_X3P_QKV");
+      qkv_tile = eq ? atoi(eq) : 3;          // 0: 256 x 256 tiles for the one-pass GEMMs too; 2 / 3: 256 x 128, that many stages
       const void* fs = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2>;
       const void* fl = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2>;
       const void* fs1 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 4, 1>;
@@ -676,6 +678,20 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
         constexpr size_t lds = T5::LDS_BYTES;
         hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 3>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
       }
+    } else if (big && (a->flags & GIMS_LINEAR_HI_ONLY) && qkv_tile > 0) {
+      // one-pass GEMMs with a short K (the Q/K/V projection: K = 256, 8 stages) are all prologue and epilogue: 256 x 128
+      // tiles with 64 accumulator registers per wave let TWO workgroups share a CU, one's epilogue under the other's loads
+      using TQ2 = X3P<256, 128, 4, 2, 2, true>;
+      using TQ3 = X3P<256, 128, 4, 2, 3, true>;
+      static bool attr5 = false;
+      if (!attr5) {
+        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<256, 128, 4, 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TQ2::LDS_BYTES));
+        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<256, 128, 4, 2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TQ3::LDS_BYTES));
+        attr5 = true;
+      }
+      const dim3 g(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 128));
+      if (qkv_tile == 2) { constexpr size_t lds = TQ2::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<256, 128, 4, 2, 2, 1>), g, dim3(512), lds, s, *a); }
+      else { constexpr size_t lds = TQ3::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<256, 128, 4, 2, 3, 1>), g, dim3(512), lds, s, *a); }
     } else if (big) {
       using TLH = X3P<256, 256, 4, 2, 4, true>;
       constexpr size_t lds = TL::LDS_BYTES, lds_h = TLH::LDS_BYTES;

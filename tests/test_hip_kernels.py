@@ -99,7 +99,7 @@ def test_linear_presplit(hip, m, n, k, k0):
     np.testing.assert_array_equal(ob.cpu().view(torch.int16).numpy(), torch.from_numpy(o).to(torch.bfloat16).view(torch.int16).numpy())
 
 
-@pytest.mark.parametrize("m,n,k", [(300, 768, 256), (4096, 768, 256), (77, 100, 64)])
+@pytest.mark.parametrize("m,n,k", [(300, 768, 256), (4096, 768, 256), (77, 100, 64), (16500, 768, 256)])      # the last: 256 x 128 tiles, two workgroups per CU
 def test_linear_presplit_hi_only(hip, m, n, k):
     """GIMS_LINEAR_HI_ONLY: the pre-split kernel multiplies the hi planes only = a plain bf16 product with f32 accumulation."""
     r = _rng(m + n)

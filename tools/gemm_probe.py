@@ -33,6 +33,8 @@ def main():
     out_h = torch.empty_like(hpl)
     out_d = torch.empty_like(dpl)
     cases = {
+        "qkv1 K256 N768 ->bf16 hi-only": (lambda: hip.linear_args(dpl, w_qkv, bias=b3, out_bf16=qkv, precision=hip.PREC_BF16X3, spl=True, flags=hip.LINEAR_HI_ONLY),
+                                          2.0 * rows * 256 * 768, rows * (256 * 2 + 768 * 2)),
         "qkv  K256 N768 ->bf16": (lambda: hip.linear_args(dpl, w_qkv, bias=b3, out_bf16=qkv, precision=hip.PREC_BF16X3, spl=True),
                                   2.0 * rows * 256 * 768, rows * (256 * 4 + 768 * 2)),
         "mlp0 K512 N512 relu->spl": (lambda: hip.linear_args(dpl, w_m0, a1=mpl, bias=b2, act=hip.ACT_RELU, out_split=out_h,
@@ -51,7 +53,7 @@ def main():
         variants = [0, 0]          # repeats of the full kernel: the first timing of a case runs on a cold clock
         for fl in [0, 0x200, 0x100, 0x200 | 0x400, 0x200 | 0x800] + variants:
             a = mk()
-            a.flags = fl
+            a.flags |= fl
             for _ in range(10):
                 lib.gims_linear(C.byref(a), st)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
