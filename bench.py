@@ -259,12 +259,23 @@ def main():
                         "the two MLP GEMMs of a layer and 1 pass (plain bf16, GIMS_LINEAR_HI_ONLY) in its Q/K/V projection, whose result is rounded "
                         "to bf16 for the attention kernel anyway; `achieved` counts ALGORITHMIC flops 2MNK averaged over the three launches per "
                         "layer, so its ceiling against the 2.5 PF/s bf16 peak is about 0.4")
+        # second view of the GEMM launches: they are short-K products (K = 256 / 512) over 4-byte-per-element operands and
+        # results, so per launch they also move a lot of HBM: algorithmic bytes = rows x (Q/K/V 256x2 in + 768x2 out, MLP0
+        # 512x4 in + 512x4 out, MLP1 512x4 in + 256x4 residual + 256x4 f32 out + 256x4 split out) / launches per layer
+        lin_bytes_launch = n_rows * (256 * 2 + 768 * 2 + 512 * 4 + 512 * 4 + 512 * 4 + 3 * 256 * 4) / (lpl * nl) if fused else None
         roofline = {"kernel": dom_kernel_name, "bound": bound, "achieved": rate(cand[dom]), "peak": peak, "unit": unit,
                     "frac": rate(cand[dom]) / peak, "traffic": traffic,
                     "avg_launch_ms": float(ms), "launches_per_step": n_launch, "algorithmic_work_per_launch": work,
                     "note": dom_note + dom_note_extra,
                     "all": {k: {"bound": v[0], "avg_launch_ms": float(v[2]), "launches_per_step": v[5], "achieved": rate(v), "unit": v[4],
                                 "peak": v[3], "frac": rate(v) / v[3]} for k, v in cand.items()}}
+        if lin_bytes_launch and "linear_x3p_kernel" in cand:
+            lms = cand["linear_x3p_kernel"][2]
+            roofline["all"]["linear_x3p_kernel"]["hbm_view"] = {
+                "algorithmic_bytes_per_launch": lin_bytes_launch, "achieved": lin_bytes_launch / (lms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": lin_bytes_launch / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "note": "SURVEY 8(d) prices the linears against the MFMA peak (the `frac` above); with K = 256 / 512 the same launches sit at this "
+                        "fraction of the HBM peak as well -- neither roof is reached, prologue / epilogue phases do not overlap (DESIGN.md 4.3)"}
         k0 = host_t["datas"][0]["kept_kpts0_indices"][0].cpu().numpy()
         k1 = host_t["datas"][0]["kept_kpts1_indices"][0].cpu().numpy()
         v = m0 >= 0
