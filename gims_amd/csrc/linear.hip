@@ -345,29 +345,41 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
       cy[i] = yo * p.conv_stride; cx[i] = xo * p.conv_stride; cb[i] = (int64_t)pi * p.conv_h * p.conv_w;
     }
   }
+  // Loop-invariant part of every DMA source address: the byte offset of this lane's 16-byte chunk inside the tile's row
+  // panel (rows clamped to the last valid one), one per K segment.  The K-dependent part is a wave-uniform base pointer
+  // (scalar ALU), so issuing a stage costs no vector ALU work -- VALU issue of one wave stalls the MFMAs of its SIMD mate,
+  // and the 64-bit row x pitch multiplies this replaces were 17 % of the K loop.
+  uint32_t voff0[T::PIECES], voff1[T::PIECES];
+#pragma unroll
+  for (int i = 0; i < T::PIECES; ++i) {
+    const int pp = p0 + i;
+    const bool is_a = pp < T::PA;
+    const int row = T::RPP * (is_a ? pp : pp - T::PA) + drow;
+    const int rmax = (is_a ? p.m - m0 : p.n - n0) - 1;
+    const uint32_t rl = (uint32_t)(row < rmax ? row : rmax), ch = 16u * (uint32_t)(dpos ^ T::swz(row));
+    voff0[i] = rl * (uint32_t)(is_a ? p.lda0 : p.ldw) * 2u + ch;
+    voff1[i] = is_a ? rl * (uint32_t)p.lda1 * 2u + ch : voff0[i];
+  }
   auto issue = [&](int kt) {
     const int k = kt * BK;
     const bool second = k >= p.k0;
-    const uint16_t* abase = (const uint16_t*)(second ? p.a1 : p.a0);
-    const int64_t alda = second ? p.lda1 : p.lda0;
     const int akk = second ? k - p.k0 : k;
+    // SPL32: block k/32 starts at element 2*k
+    const char* ab = (const char*)(second ? p.a1 : p.a0) + ((int64_t)m0 * (second ? p.lda1 : p.lda0) + 2 * akk) * 2;
+    const char* wb = (const char*)p.w + ((int64_t)n0 * p.ldw + 2 * k) * 2;
     uint16_t* dst = smem + (kt % S) * T::STAGE + p0 * 512;
 #pragma unroll
     for (int i = 0; i < T::PIECES; ++i) {
       const int pp = p0 + i;                               // wave-uniform
       const bool is_a = pp < T::PA;
-      const int row = T::RPP * (is_a ? pp : pp - T::PA) + drow;
-      int gr = (is_a ? m0 : n0) + row;
-      const int rmax = (is_a ? p.m : p.n) - 1;
-      gr = gr < rmax ? gr : rmax;
-      const uint16_t* g = (is_a ? abase + (int64_t)gr * alda + 2 * akk : (const uint16_t*)p.w + (int64_t)gr * p.ldw + 2 * k)
-                          + 8 * (dpos ^ T::swz(row));   // SPL32: block k/32 starts at element 2*k
+      const char* g = (is_a ? ab : wb) + (second ? voff1[i] : voff0[i]);
       if (CONV && is_a) {                                  // tap (ky, kx) and channel block of this K step; zeros outside the image
+        const int row = T::RPP * pp + drow;
         const int tap = k / cC, c0 = k - tap * cC;
         const int y = cy[i] + tap / 3 - 1, x = cx[i] + tap % 3 - 1;
         const bool inb = y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w;
-        g = inb ? (const uint16_t*)p.a0 + (cb[i] + (int64_t)y * p.conv_w + x) * p.lda0 + 2 * c0 + 8 * (dpos ^ T::swz(row))
-                : (const uint16_t*)p.a1 + 8 * dpos;
+        g = (const char*)(inb ? (const uint16_t*)p.a0 + (cb[i] + (int64_t)y * p.conv_w + x) * p.lda0 + 2 * c0 + 8 * (dpos ^ T::swz(row))
+                              : (const uint16_t*)p.a1 + 8 * dpos);
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(dst + i * 512), 16, 0, 0);
