@@ -278,7 +278,6 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_batch_kernel(const gims_
 // residual are vector loads.
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 // Geometry: TM x TN output tile per workgroup, WM x WN waves, each wave (TM/WM) x (TN/WN) as 32x32 MFMA tiles,
 // 32-channel stages in an S-stage LDS ring.  Two instantiations are used:
 //   128x128, 2x2 waves (64x64 per wave),  64 KiB LDS, 2 workgroups/CU -- small problems (fills the chip sooner);
@@ -295,7 +294,8 @@ struct X3P {
   static constexpr int STAGE = A_TILE + W_TILE;
   static constexpr int PA = TM / RPP, PW = TN / RPP;             // 1 KiB pieces per operand per stage
   static constexpr int PIECES = (PA + PW) / WAVES;               // pieces per wave per stage
-  static constexpr int EP_PITCH = TN / WN + 4;                    // epilogue transpose slice: 32 rows x EP_PITCH floats per wave
+  static constexpr int EPW = TN / WN > 128 ? 128 : TN / WN;       // columns of a wave tile that go through the epilogue transpose at a time
+  static constexpr int EP_PITCH = EPW + 4;                        // epilogue transpose slice: 32 rows x EP_PITCH floats per wave
   static constexpr int RING_BYTES = S * STAGE * 2, EP_BYTES = WAVES * 32 * EP_PITCH * 4;
   static constexpr int LDS_BYTES = RING_BYTES > EP_BYTES ? RING_BYTES : EP_BYTES;
   static_assert((PA + PW) % WAVES == 0, "pieces divide evenly over the waves");
@@ -408,38 +408,56 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
     if (kt + D < nk && !(p.flags & 0x400)) issue(kt + D);     // 0x400: no DMA after the prologue (probe)
     if (p.flags & 0x800) continue;                             // 0x800: no LDS reads / MFMAs (probe)
     const uint16_t* st = smem + (kt % S) * T::STAGE;
+    // Fragment reads are grouped and pinned ahead of the MFMAs that consume them (in consumption order: LDS returns in
+    // order, so the waits count down): reads of K step 0 -> its lo*hi and hi*lo products -> reads of step 1 -> hi*hi of
+    // step 0 -> step 1.  Left alone the compiler emits read-a-few / wait-for-ALL / multiply-a-few, eight exposed LDS round
+    // trips per stage; more than 15 reads in flight cannot be counted by lgkmcnt either, hence two groups.
+    constexpr bool LO = HI_ONLY != 1;
+    const bool lo_pass = HI_ONLY == 0 || HI_ONLY == 4 || (HI_ONLY == 2 && kt * BK < p.k0);
+    bf16x8 ah[2][T::MI], al[2][T::MI], wh[2][T::NI], wl[2][T::NI];
+    auto rd = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 ah[T::MI], al[T::MI], wh[T::NI], wl[T::NI];
+      for (int i = 0; i < T::MI; ++i) ah[s][i] = *(const bf16x8*)(st + T::off(wm * (TM / WM) + i * 32 + li, 2 * s + lh));       // chunks 0-3: hi of channels 0-31
+      if (LO) {
 #pragma unroll
-      for (int i = 0; i < T::MI; ++i) {
-        const int ar = wm * (TM / WM) + i * 32 + li;
-        ah[i] = *(const bf16x8*)(st + T::off(ar, 2 * s + lh));         // chunks 0-3: hi of channels 0-31
-        al[i] = *(const bf16x8*)(st + T::off(ar, 4 + 2 * s + lh));     // chunks 4-7: lo
+        for (int i = 0; i < T::NI; ++i) wl[s][i] = *(const bf16x8*)(st + T::A_TILE + T::off(wn * (TN / WN) + i * 32 + li, 4 + 2 * s + lh));
+#pragma unroll
+        for (int i = 0; i < T::MI; ++i) al[s][i] = *(const bf16x8*)(st + T::off(wm * (TM / WM) + i * 32 + li, 4 + 2 * s + lh));   // chunks 4-7: lo
       }
 #pragma unroll
-      for (int i = 0; i < T::NI; ++i) {
-        const int wr = wn * (TN / WN) + i * 32 + li;
-        wh[i] = *(const bf16x8*)(st + T::A_TILE + T::off(wr, 2 * s + lh));
-        wl[i] = *(const bf16x8*)(st + T::A_TILE + T::off(wr, 4 + 2 * s + lh));
-      }
-      // term-major order: consecutive MFMAs hit DIFFERENT accumulators (no back-to-back dependent issue); per
-      // accumulator the order stays lo*hi, hi*lo, hi*hi (small terms first)
-      if (HI_ONLY == 0 || HI_ONLY == 4 || (HI_ONLY == 2 && kt * BK < p.k0)) {
+      for (int i = 0; i < T::NI; ++i) wh[s][i] = *(const bf16x8*)(st + T::A_TILE + T::off(wn * (TN / WN) + i * 32 + li, 2 * s + lh));
+    };
+    // term-major order: consecutive MFMAs hit DIFFERENT accumulators (no back-to-back dependent issue); per
+    // accumulator the order stays lo*hi, hi*lo, hi*hi (small terms first)
+    auto lo_terms = [&](int s) __attribute__((always_inline)) {
+      if (LO && lo_pass) {
 #pragma unroll
         for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
-          for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+          for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s][ni], ah[s][mi], acc[ni][mi], 0, 0, 0);
 #pragma unroll
         for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
-          for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
+          for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s][ni], al[s][mi], acc[ni][mi], 0, 0, 0);
       }
+    };
+    auto hi_term = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
       for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
-    }
+        for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s][ni], ah[s][mi], acc[ni][mi], 0, 0, 0);
+    };
+    static_assert(BK == 32, "two 16-deep K steps per stage");
+    rd(0);
+    if (!LO) rd(1);
+    __builtin_amdgcn_sched_barrier(0);
+    lo_terms(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (LO) rd(1);
+    __builtin_amdgcn_sched_barrier(0);
+    hi_term(0);
+    lo_terms(1);
+    hi_term(1);
   }
 
   // ---- epilogue.  In the MFMA (D^T) layout a lane owns 4 consecutive channels of ONE row, so a wave-wide store would
@@ -450,26 +468,29 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   if ((p.flags & 0x200) && acc[0][0][0] != 12345.678f) return;
   __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
   constexpr int WCOLS = TN / WN;                      // columns of the wave tile
+  constexpr int EPW = T::EPW, NG = WCOLS / EPW, NIG = EPW / 32;   // ... transposed EPW columns (NIG 32-column blocks) at a time
   constexpr int PITCH = T::EP_PITCH;                  // floats; +4 keeps the 16-byte LDS writes of 16 lanes on distinct banks
-  constexpr int LPR = WCOLS / 8;                      // lanes per row in the read-back (8 consecutive channels per lane)
+  constexpr int LPR = EPW / 8;                        // lanes per row in the read-back (8 consecutive channels per lane)
   constexpr int RPI = 64 / LPR;                       // rows per wave-wide access
   constexpr int ITERS = 32 / RPI;
   float* ep = (float*)smem + wave * (32 * PITCH);
   const int c8 = (lane % LPR) * 8, rsub = lane / LPR;
-  const int col = n0 + wn * WCOLS + c8;
-  const bool cok = col < p.n, full = col + 4 < p.n;   // n % 4 == 0: a lane's 8 channels are all, half or not in range
-  float4 b4[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) b4[h] = (p.bias && col + 4 * h < p.n) ? *(const float4*)(p.bias + col + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int scol = spl_col(col);
 #pragma unroll
   for (int mi = 0; mi < T::MI; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < T::NI; ++ni)
+   for (int cg = 0; cg < NG; ++cg) {
+    const int col = n0 + wn * WCOLS + cg * EPW + c8;
+    const bool cok = col < p.n, full = col + 4 < p.n;   // n % 4 == 0: a lane's 8 channels are all, half or not in range
+    float4 b4[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) b4[h] = (p.bias && col + 4 * h < p.n) ? *(const float4*)(p.bias + col + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int scol = spl_col(col);
+#pragma unroll
+    for (int ni = 0; ni < NIG; ++ni)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *(float4*)(ep + li * PITCH + ni * 32 + 8 * g + 4 * lh) =
-            make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+            make_float4(acc[cg * NIG + ni][mi][4 * g], acc[cg * NIG + ni][mi][4 * g + 1], acc[cg * NIG + ni][mi][4 * g + 2], acc[cg * NIG + ni][mi][4 * g + 3]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no workgroup barrier needed
     const int rbase = m0 + wm * (TM / WM) + mi * 32 + rsub;
     constexpr int CH = ITERS < 4 ? ITERS : 4;            // residual loads of a chunk are all in flight before the first use
@@ -527,6 +548,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read-back complete before the slice is overwritten
+   }
   }
 }
 
