@@ -143,28 +143,35 @@ __global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------- K3 adjacency bits
-// one wave per (row i, 64-column word): bit j set iff j != i, ||xi-xj||^2 <= r^2 in float64 (inclusive),
-// and S[min(i,j)][max(i,j)] >= thr  (the reference tests sim_matrix[i,j] with i<j, agc.py:445-446)
+// one wave per row i, walking its 64-column words: bit j set iff j != i, ||xi-xj||^2 <= r^2 in float64 (inclusive),
+// and S[min(i,j)][max(i,j)] >= thr  (the reference tests sim_matrix[i,j] with i<j, agc.py:445-446).  (One wave per WORD
+// was 4 M one-shot waves per batch at 4096 keypoints: wave launch and index arithmetic, not memory, bounded it.)
 __global__ __launch_bounds__(256) void agc_adj_kernel(const AgcWs* __restrict__ ws, double r2) {
   const AgcWs& w = ws[blockIdx.y];
   const float* __restrict__ kpts = w.kpts;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-  const int i = (int)(wid / w.nw), wj = (int)(wid % w.nw);
+  const int i = blockIdx.x * 4 + wave;
   if (i >= w.n) return;
   const float thr = key_f32(w.sel[0]);
-  const int j = wj * 64 + lane;
-  bool pred = false;
-  if (j < w.n && j != i) {
-    const double dx = (double)kpts[2 * i] - (double)kpts[2 * j];
-    const double dy = (double)kpts[2 * i + 1] - (double)kpts[2 * j + 1];
-    if (dx * dx + dy * dy <= r2) {
-      const int a = i < j ? i : j, b = i < j ? j : i;
-      pred = w.S[(int64_t)a * w.lds + b] >= thr;
+  const double xi = (double)kpts[2 * i], yi = (double)kpts[2 * i + 1];
+  for (int w0 = 0; w0 < w.nw; w0 += 64) {
+    const int wend = w.nw - w0 < 64 ? w.nw - w0 : 64;
+    uint64_t mine = 0;                          // lane q keeps word w0 + q: one coalesced store per 64 words
+    for (int q = 0; q < wend; ++q) {
+      const int j = (w0 + q) * 64 + lane;
+      bool pred = false;
+      if (j < w.n && j != i) {
+        const double dx = xi - (double)kpts[2 * j], dy = yi - (double)kpts[2 * j + 1];
+        if (dx * dx + dy * dy <= r2) {
+          const int a = i < j ? i : j, b = i < j ? j : i;
+          pred = w.S[(int64_t)a * w.lds + b] >= thr;
+        }
+      }
+      const uint64_t mask = __ballot(pred);
+      if (lane == q) mine = mask;
     }
+    if (lane < wend) w.bits[(int64_t)i * w.nw + w0 + lane] = mine;
   }
-  const uint64_t mask = __ballot(pred);
-  if (lane == 0) w.bits[(int64_t)i * w.nw + wj] = mask;
 }
 
 __global__ __launch_bounds__(256) void agc_deg_kernel(const AgcWs* __restrict__ ws, int count_total) {
@@ -692,7 +699,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, pass);
   }
   // K3
-  hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv((int64_t)maxn * maxnw, 4), B), dim3(256), 0, s, dws, radius * radius);
+  hipLaunchKernelGGL(agc_adj_kernel, gw, dim3(256), 0, s, dws, radius * radius);
   hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 1);
   // K4
   hipLaunchKernelGGL(agc_iso_nn_kernel, gw, dim3(256), 0, s, dws);
