@@ -39,7 +39,8 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const gims_linear_args* 
   if (m0 >= p.m || n0 >= p.n) return;                          // batched launches are sized for the largest problem
   if ((p.flags & GIMS_LINEAR_UPPER) && n0 + X6_TN <= m0) return;   // symmetric product: tile entirely below the diagonal
   const int li = lane & 31, lh = lane >> 5;
-  const int nk = p.k / X6_BK;
+  // diagnostic bits (tools/x6_probe.py only): 0x100 no K loop, 0x200 no epilogue, 0x400 no DMA after the first stage, 0x800 no MFMA
+  const int nk = (p.flags & 0x100) ? 0 : p.k / X6_BK;
 
   // DMA duty of this lane: chunk c = (wave * 9 + i) * 64 + lane of the stage image; row = c / 12, position = c % 12 holds
   // the source chunk (position - rot(row)) mod 12.  Element offsets relative to the k-block start are loop invariant.
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const gims_linear_args* 
   for (int kt = 0; kt < nk; ++kt) {
     x6_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) issue(kt + 1);
+    if (kt + 1 < nk && !(p.flags & 0x400)) issue(kt + 1);
+    if (p.flags & 0x800) continue;
     const uint16_t* st = smem + (kt & 1) * X6_STAGE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const gims_linear_args* 
   }
 
   // ---- epilogue: transpose through a wave-private LDS slice (32 rows x 64 columns at a time), row-contiguous stores
+  if ((p.flags & 0x200) && acc[0][0][0] != 12345.678f) return;
   __builtin_amdgcn_s_barrier();
   float* ep = (float*)smem + wave * (32 * X6_EP_PITCH);
   constexpr int LPR = 64 / 8, RPI = 64 / LPR, ITERS = 32 / RPI;     // 8 lanes per row, 8 rows per access, 4 accesses
