@@ -7,7 +7,7 @@
 // similarity matrix of the adaptive graph (agc.py:390) and the score matrix (gmatcher.py:274).
 //
 // Operand layout "SPL3": logical [rows][K] f32 -> bf16 [rows][3K]; per 32-channel block 32 x a1, 32 x a2, 32 x a3
-// (192 bytes).  Kernel: 256 x 128 output tile, 8 waves (4 x 2, 64 x 64 each), 32-channel stages in a 2-stage LDS ring filled
+// (192 bytes).  Kernel: PERSISTENT over the tile list of the batch; 256 x 128 output tile, 8 waves (4 x 2, 64 x 64 each), 32-channel stages in a 2-stage LDS ring filled
 // by LDS-DMA; a stage row is 12 chunks of 16 bytes, stored ROTATED by (row >> 2) % 12 chunks (the rotation is applied to
 // the source chunk index of the DMA and again on the ds_read_b128: conflict-free for the b128 lane groups; 192-byte rows
 // without it are 4-way conflicted).  Epilogue: accumulators transposed through LDS so that stores cover whole lines.
@@ -23,22 +23,58 @@ constexpr int X6_STAGE = (X6_TM + X6_TN) * X6_ROW;           // elements per sta
 constexpr int X6_PIECES = (X6_TM + X6_TN) * 12 / 64 / 8;     // 16-byte x 64-lane DMA instructions per wave per stage (9)
 constexpr int X6_EP_PITCH = X6_TN / X6_WN + 4;
 constexpr int X6_LDS_BYTES = 2 * X6_STAGE * 2;               // 147 456 bytes (the epilogue slices, 8 x 8.7 KB, reuse it)
+constexpr int X6_MAX_PROBLEMS = 1024, X6_TABLE_BYTES = (X6_MAX_PROBLEMS + 1) * 4;   // tile table behind the ring
 
 template <int N>
 __device__ __forceinline__ void x6_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ int x6_rot(int row) { return (row >> 2) % 12; }
 
-__global__ __launch_bounds__(512) void linear_x6_kernel(const gims_linear_args* __restrict__ args) {
-  const gims_linear_args p = args[blockIdx.z];
+// tiles of problem (m, n): all of them, or for a symmetric product (GIMS_LINEAR_UPPER) those not entirely below the
+// diagonal -- row by of 256-row tiles keeps the 128-column tiles bx >= 2 by
+__device__ __forceinline__ int x6_rows_kept(int ntm, int ntn) { const int r = (ntn + 1) / 2; return ntm < r ? ntm : r; }
+__device__ __forceinline__ int x6_upper_before(int by, int ntn) { return by * ntn - by * (by - 1); }   // tiles in rows < by
+
+// PERSISTENT: one workgroup per CU walks the tile list of the whole batch (tile t -> workgroup t mod gridDim.x).  With
+// K = 256 a tile is only eight stages; as one-shot workgroups (147 KB of LDS each, so strictly one after the other on a
+// CU) the launch, the argument fetch and the un-overlapped first stage cost as much as the K loop, and the workgroups
+// of a symmetric product that lie below the diagonal still queued for a CU each just to exit.
+__global__ __launch_bounds__(512) void linear_x6_kernel(const gims_linear_args* __restrict__ args, int count) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  int* tstart = (int*)(smem + 2 * X6_STAGE);                    // [count + 1] first tile of every problem
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / X6_WN, wn = wave % X6_WN;
-  const int m0 = blockIdx.y * X6_TM, n0 = blockIdx.x * X6_TN;
-  if (m0 >= p.m || n0 >= p.n) return;                          // batched launches are sized for the largest problem
-  if ((p.flags & GIMS_LINEAR_UPPER) && n0 + X6_TN <= m0) return;   // symmetric product: tile entirely below the diagonal
   const int li = lane & 31, lh = lane >> 5;
+  for (int i = t; i < count; i += 512) {
+    const int ntm = (args[i].m + X6_TM - 1) / X6_TM, ntn = (args[i].n + X6_TN - 1) / X6_TN;
+    tstart[i + 1] = (args[i].flags & GIMS_LINEAR_UPPER) ? x6_upper_before(x6_rows_kept(ntm, ntn), ntn) : ntm * ntn;
+  }
+  __syncthreads();
+  if (t == 0) {
+    tstart[0] = 0;
+    for (int i = 1; i <= count; ++i) tstart[i] += tstart[i - 1];
+  }
+  __syncthreads();
+  const int total = __builtin_amdgcn_readfirstlane(tstart[count]);
+  int z = 0;
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+  while (tile >= __builtin_amdgcn_readfirstlane(tstart[z + 1])) ++z;
+  const gims_linear_args p = args[z];
+  int by, bx;
+  {
+    const int u = tile - __builtin_amdgcn_readfirstlane(tstart[z]);
+    const int ntn = (p.n + X6_TN - 1) / X6_TN;
+    if (p.flags & GIMS_LINEAR_UPPER) {
+      by = 0;
+      while (u >= x6_upper_before(by + 1, ntn)) ++by;
+      bx = 2 * by + (u - x6_upper_before(by, ntn));
+    } else {
+      by = u / ntn;
+      bx = u - by * ntn;
+    }
+  }
+  const int m0 = by * X6_TM, n0 = bx * X6_TN;
   // diagnostic bits (tools/x6_probe.py only): 0x100 no K loop, 0x200 no epilogue, 0x400 no DMA after the first stage, 0x800 no MFMA
   const int nk = (p.flags & 0x100) ? 0 : p.k / X6_BK;
 
@@ -122,8 +158,8 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const gims_linear_args* 
   }
 
   // ---- epilogue: transpose through a wave-private LDS slice (32 rows x 64 columns at a time), row-contiguous stores
-  if ((p.flags & 0x200) && acc[0][0][0] != 12345.678f) return;
   __builtin_amdgcn_s_barrier();
+  if (!((p.flags & 0x200) && acc[0][0][0] != 12345.678f)) {
   float* ep = (float*)smem + wave * (32 * X6_EP_PITCH);
   constexpr int LPR = 64 / 8, RPI = 64 / LPR, ITERS = 32 / RPI;     // 8 lanes per row, 8 rows per access, 4 accesses
   const int c8 = (lane % LPR) * 8, rsub = lane / LPR;
@@ -160,6 +196,9 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const gims_linear_args* 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  }
+  __builtin_amdgcn_s_barrier();          // the next tile's first stage overwrites the epilogue slices of other waves
+  }
 }
 
 // f32 [rows][k] -> SPL3 bf16 [rows][3k]: one thread per (row, channel)
@@ -181,10 +220,12 @@ __global__ void split_spl3_kernel(const float* __restrict__ src, int64_t lds, ui
 int linear_x6_batch_launch(const gims_linear_args* dev_args, int count, int max_m, int max_n, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)linear_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES));
+    GIMS_HIP(hipFuncSetAttribute((const void*)linear_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES + X6_TABLE_BYTES));
     attr = true;
   }
-  hipLaunchKernelGGL(linear_x6_kernel, dim3(cdiv(max_n, X6_TN), cdiv(max_m, X6_TM), count), dim3(512), X6_LDS_BYTES, s, dev_args);
+  GIMS_CHECK_ARG(count >= 1 && count <= X6_MAX_PROBLEMS, "gims_linear_batch(bf16x6): at most %d problems per launch", X6_MAX_PROBLEMS);
+  const int64_t bound = (int64_t)cdiv(max_n, X6_TN) * cdiv(max_m, X6_TM) * count;      // workgroups beyond the tile list exit at once
+  hipLaunchKernelGGL(linear_x6_kernel, dim3((int)(bound < 256 ? bound : 256)), dim3(512), X6_LDS_BYTES + X6_TABLE_BYTES, s, dev_args, count);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }
