@@ -119,27 +119,33 @@ __global__ __launch_bounds__(256) void agc_hist_kernel(const AgcWs* __restrict__
   if (h[threadIdx.x]) atomicAdd(&w.hist[threadIdx.x], h[threadIdx.x]);
 }
 
+// the bin holding rank k: parallel inclusive scan of the 256 counts (a single lane walking them through LDS took 16-19 us)
 __global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__ ws, int pass) {
   const AgcWs& w = ws[blockIdx.y];
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = w.hist[threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint64_t k = (uint64_t)w.sel[1] | ((uint64_t)w.sel[2] << 32);
-    uint64_t cum = 0;
-    int b = 0;
-    for (; b < 255; ++b) {
-      if (cum + h[b] > k) break;
-      cum += h[b];
-    }
-    k -= cum;
-    const int shift = 24 - 8 * pass;
-    w.sel[0] |= ((uint32_t)b) << shift;
-    w.sel[1] = (uint32_t)k;
-    w.sel[2] = (uint32_t)(k >> 32);
+  __shared__ uint64_t wsum[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint64_t v = w.hist[t];
+  uint64_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
+  if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  w.hist[threadIdx.x] = 0;
+  for (int q = 0; q < wave; ++q) incl += wsum[q];
+  const uint64_t k = (uint64_t)w.sel[1] | ((uint64_t)w.sel[2] << 32);
+  const uint64_t excl = incl - v;
+  // first bin b < 255 with cum(b) + h[b] > k, else 255 (the reference walk)
+  const bool hit = t < 255 ? (excl <= k && k < incl) : excl <= k;
+  __syncthreads();                      // every thread has read sel[1..2]
+  if (hit) {
+    const uint64_t r = k - excl;
+    w.sel[0] |= ((uint32_t)t) << (24 - 8 * pass);
+    w.sel[1] = (uint32_t)r;
+    w.sel[2] = (uint32_t)(r >> 32);
+  }
+  w.hist[t] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------- K3 adjacency bits
@@ -180,14 +186,20 @@ __global__ __launch_bounds__(256) void agc_deg_kernel(const AgcWs* __restrict__ 
   int32_t* total = count_total ? w.counters + 0 : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
-  if (i >= w.n) return;
   int c = 0;
-  for (int k = lane; k < w.nw; k += 64) c += __popcll(w.bits[(int64_t)i * w.nw + k]);
+  if (i < w.n)
+    for (int k = lane; k < w.nw; k += 64) c += __popcll(w.bits[(int64_t)i * w.nw + k]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if (lane == 0) {
-    deg[i] = c;
-    if (total && c) atomicAdd(total, c);
+  if (lane == 0 && i < w.n) deg[i] = c;
+  if (total) {                          // one atomic per workgroup, not per row
+    __shared__ int part[4];
+    if (lane == 0) part[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int sum = part[0] + part[1] + part[2] + part[3];
+      if (sum) atomicAdd(total, sum);
+    }
   }
 }
 
