@@ -151,32 +151,66 @@ __global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__
 // ---------------------------------------------------------------------------------------------- K3 adjacency bits
 // one wave per row i, walking its 64-column words: bit j set iff j != i, ||xi-xj||^2 <= r^2 in float64 (inclusive),
 // and S[min(i,j)][max(i,j)] >= thr  (the reference tests sim_matrix[i,j] with i<j, agc.py:445-446).  (One wave per WORD
-// was 4 M one-shot waves per batch at 4096 keypoints: wave launch and index arithmetic, not memory, bounded it.)
+// was 4 M one-shot waves per batch at 4096 keypoints; with the S read inside the column loop every in-radius pair cost the
+// wave a full memory round trip, ~9 per row.)
+constexpr int ADJ_R = 4;      // rows per wave: one load of point j serves four row tests (the loop is issue bound)
 __global__ __launch_bounds__(256) void agc_adj_kernel(const AgcWs* __restrict__ ws, double r2) {
   const AgcWs& w = ws[blockIdx.y];
   const float* __restrict__ kpts = w.kpts;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wave;
-  if (i >= w.n) return;
+  const int i0 = (blockIdx.x * 4 + wave) * ADJ_R;
+  if (i0 >= w.n) return;
   const float thr = key_f32(w.sel[0]);
-  const double xi = (double)kpts[2 * i], yi = (double)kpts[2 * i + 1];
+  float xif[ADJ_R], yif[ADJ_R];
+#pragma unroll
+  for (int r = 0; r < ADJ_R; ++r) {
+    const int i = i0 + r < w.n ? i0 + r : w.n - 1;
+    xif[r] = kpts[2 * i];
+    yif[r] = kpts[2 * i + 1];
+  }
+  const float r2f = (float)(r2 * 1.00002);
+  const bool al8 = ((uintptr_t)kpts & 7) == 0;
   for (int w0 = 0; w0 < w.nw; w0 += 64) {
     const int wend = w.nw - w0 < 64 ? w.nw - w0 : 64;
-    uint64_t mine = 0;                          // lane q keeps word w0 + q: one coalesced store per 64 words
+    uint64_t mine[ADJ_R];                       // lane q keeps word w0 + q of each row: one coalesced store per 64 words
+#pragma unroll
+    for (int r = 0; r < ADJ_R; ++r) mine[r] = 0;
     for (int q = 0; q < wend; ++q) {
       const int j = (w0 + q) * 64 + lane;
-      bool pred = false;
-      if (j < w.n && j != i) {
-        const double dx = xi - (double)kpts[2 * j], dy = yi - (double)kpts[2 * j + 1];
-        if (dx * dx + dy * dy <= r2) {
-          const int a = i < j ? i : j, b = i < j ? j : i;
-          pred = w.S[(int64_t)a * w.lds + b] >= thr;
+      const int jc = j < w.n ? j : w.n - 1;
+      float xj, yj;                             // one 8-byte load per lane when the table allows it
+      if (al8) { const float2 pj = *(const float2*)(kpts + 2 * jc); xj = pj.x; yj = pj.y; }
+      else { xj = kpts[2 * jc]; yj = kpts[2 * jc + 1]; }
+#pragma unroll
+      for (int r = 0; r < ADJ_R; ++r) {
+        // f32 screen first (relative error of dxf^2 + dyf^2 <= 3e-7, margin 2e-5): only the pairs it cannot rule out take
+        // the float64 test that decides -- ~99 % of the pairs are far outside the radius
+        const float dxf = xif[r] - xj, dyf = yif[r] - yj;
+        bool pred = false;
+        if (j < w.n && j != i0 + r && !(dxf * dxf + dyf * dyf > r2f)) {
+          const double dx = (double)xif[r] - (double)xj, dy = (double)yif[r] - (double)yj;
+          pred = dx * dx + dy * dy <= r2;
         }
+        const uint64_t mask = __ballot(pred);
+        if (lane == q) mine[r] = mask;
       }
-      const uint64_t mask = __ballot(pred);
-      if (lane == q) mine = mask;
     }
-    if (lane < wend) w.bits[(int64_t)i * w.nw + w0 + lane] = mine;
+    // similarity test of the (few) pairs inside the radius: lane q walks the candidates of ITS word, so the dependent,
+    // scattered reads of S of a row are in flight together instead of one after the other inside the loop above
+#pragma unroll
+    for (int r = 0; r < ADJ_R; ++r) {
+      const int i = i0 + r;
+      if (i >= w.n) break;
+      uint64_t cand = mine[r];
+      while (cand) {
+        const int bit = __ffsll((unsigned long long)cand) - 1;
+        cand &= cand - 1;
+        const int j = (w0 + lane) * 64 + bit;
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        if (!(w.S[(int64_t)a * w.lds + b] >= thr)) mine[r] &= ~(1ull << bit);
+      }
+      if (lane < wend) w.bits[(int64_t)i * w.nw + w0 + lane] = mine[r];
+    }
   }
 }
 
@@ -711,7 +745,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, pass);
   }
   // K3
-  hipLaunchKernelGGL(agc_adj_kernel, gw, dim3(256), 0, s, dws, radius * radius);
+  hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv(maxn, 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
   hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 1);
   // K4
   hipLaunchKernelGGL(agc_iso_nn_kernel, gw, dim3(256), 0, s, dws);
