@@ -616,6 +616,7 @@ static int linear_validate(const gims_linear_args* a) {
     GIMS_CHECK_ARG((a->lda0 % 64) == 0 && (a->lda1 % 64) == 0 && (a->ldw % 64) == 0 && a->lda0 >= 2 * ((a->flags & GIMS_LINEAR_CONV3) ? a->k / 9 : a->k0) && a->ldw >= 2 * a->k,
                    "gims_linear(pre-split): SPL32 operands have row pitch >= 2*K, a multiple of 64 elements");
     GIMS_CHECK_ARG((((uintptr_t)a->a0 | (uintptr_t)a->w | (uintptr_t)a->a1) & 127) == 0, "gims_linear(pre-split): SPL32 operands must be 128-byte aligned");
+    GIMS_CHECK_ARG(a->lda0 < (1 << 22) && a->lda1 < (1 << 22) && a->ldw < (1 << 22), "gims_linear(pre-split): row pitch too large (32-bit tile-relative offsets)");
     GIMS_CHECK_ARG((a->n % 4) == 0 && (a->ldc % 4) == 0 && (a->ldc_bf16 % 4) == 0 && (a->ld_split % 8) == 0,
                    "gims_linear(pre-split): n, ldc and ldc_bf16 must be multiples of 4, ld_split of 8");
     GIMS_CHECK_ARG((((uintptr_t)a->out_f32 | (uintptr_t)a->out_hi | (uintptr_t)a->residual | (uintptr_t)a->bias) & 15) == 0 &&
