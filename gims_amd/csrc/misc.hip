@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(const float* __restr
 __global__ __launch_bounds__(256) void sage_mean_kernel(const float* __restrict__ h, int64_t ldh,
                                                         const int32_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ indices, int n, int c,
-                                                        float* __restrict__ out, int64_t ldo) {
+                                                        float* __restrict__ out, int64_t ldo,
+                                                        uint16_t* __restrict__ out_spl, int64_t ld_spl) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int node = blockIdx.x * 4 + wave;
   if (node >= n) return;
@@ -124,7 +125,15 @@ __global__ __launch_bounds__(256) void sage_mean_kernel(const float* __restrict_
       const float d = (float)(end - beg);
       s.x /= d; s.y /= d; s.z /= d; s.w /= d;
     }
-    *(float4*)(out + (int64_t)node * ldo + 4 * q) = s;
+    if (out) *(float4*)(out + (int64_t)node * ldo + 4 * q) = s;
+    if (out_spl) {      // SPL32 planes for the split-bf16 GEMM that consumes the mean (a quad never straddles a 32-channel block)
+      const uint32_t h01 = pack_bf2(s.x, s.y), h23 = pack_bf2(s.z, s.w);
+      const uint32_t l01 = pack_bf2(s.x - __uint_as_float(h01 << 16), s.y - __uint_as_float(h01 & 0xffff0000u));
+      const uint32_t l23 = pack_bf2(s.z - __uint_as_float(h23 << 16), s.w - __uint_as_float(h23 & 0xffff0000u));
+      uint16_t* o = out_spl + (int64_t)node * ld_spl + spl_col(4 * q);
+      *(uint2*)o = make_uint2(h01, h23);
+      *(uint2*)(o + 32) = make_uint2(l01, l23);
+    }
   }
 }
 
@@ -331,7 +340,20 @@ extern "C" int gims_sage_mean(const float* h, int64_t ldh, const int32_t* indptr
   GIMS_CHECK_ARG((c % 4) == 0 && (ldh % 4) == 0 && (ldo % 4) == 0, "gims_sage_mean: c / ld must be multiples of 4");
   if (n == 0) return GIMS_OK;
   hipLaunchKernelGGL(sage_mean_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, h, ldh, indptr, indices, n, c,
-                     out, ldo);
+                     out, ldo, (uint16_t*)nullptr, (int64_t)0);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_sage_mean_split(const float* h, int64_t ldh, const int32_t* indptr, const int32_t* indices, int32_t n,
+                                    int32_t c, uint16_t* out_spl, int64_t ld_spl, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(h && indptr && indices && out_spl && n >= 0, "gims_sage_mean_split: bad arguments");
+  GIMS_CHECK_ARG((c % 4) == 0 && (ldh % 4) == 0 && (ld_spl % 4) == 0 && ld_spl >= 2 * (int64_t)((c + 31) / 32 * 32) && ((uintptr_t)out_spl & 7) == 0,
+                 "gims_sage_mean_split: c / ldh multiples of 4, SPL32 output pitch >= 2 * c rounded up to 32 channels");
+  if (n == 0) return GIMS_OK;
+  hipLaunchKernelGGL(sage_mean_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, h, ldh, indptr, indices, n, c,
+                     (float*)nullptr, (int64_t)0, out_spl, ld_spl);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

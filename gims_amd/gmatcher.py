@@ -392,9 +392,7 @@ class GMatcher(nn.Module):
                 # planes of the next layer's h itself; the aggregation reads h in f32)
                 h_spl = hip.split_spl32(h)
                 for i, e in enumerate(P["sage"]):
-                    agg = torch.empty_like(h)
-                    hip.sage_mean(h, indptr_all, indices_all, agg)
-                    agg_spl = hip.split_spl32(agg)
+                    agg_spl = hip.sage_mean_split(h, indptr_all, indices_all, self._spl(n_tot, h.shape[1], dev))
                     last = i == len(P["sage"]) - 1
                     h_next = torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev)
                     h_spl_next = None if last else self._spl(n_tot, e["n"], dev)

@@ -123,6 +123,8 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_sage_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_sage_mean_split": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
     "gims_agc_workspace_bytes": (C.c_size_t, [C.POINTER(AgcImage), C.c_int32]),
@@ -405,6 +407,16 @@ def layernorm_act(x, a2, b2, out=None, out_split=None, act=ACT_RELU, eps=1e-6):
                                   (out_split.data_ptr() + 64) if out_split is not None else None,
                                   out_split.stride(0) if out_split is not None else 0, _stream()), "gims_layernorm_act")
     return out if out is not None else out_split
+
+
+def sage_mean_split(h, indptr, indices, out_spl, n=None, c=None):
+    """mean over CSR neighbours, written as SPL32 split-bf16 planes (out_spl: bf16 [rows, 2 * c])."""
+    lib = load()
+    n = h.shape[0] if n is None else n
+    c = h.shape[1] if c is None else c
+    _check(lib.gims_sage_mean_split(_p(_dev(h, torch.float32)), h.stride(0), _p(indptr), _p(indices), n, c, _p(out_spl),
+                                    out_spl.stride(0), _stream()), "gims_sage_mean_split")
+    return out_spl
 
 
 def sage_mean(h, indptr, indices, out, n=None, c=None):

@@ -196,6 +196,10 @@ int gims_layernorm_act(const float* x, int64_t ldx, int64_t rows, int32_t c, con
  */
 int gims_sage_mean(const float* h, int64_t ldh, const int32_t* indptr, const int32_t* indices,
                    int32_t n, int32_t c, float* out, int64_t ldo, void* stream);
+/* The same mean written directly as SPL32 split-bf16 planes (the A-operand layout of GIMS_PREC_BF16X3 pre-split GEMMs,
+ * see gims_split_spl32): hi + lo of every f32 mean, no f32 copy.  ld_spl in bf16 elements, >= 2 * c (c rounded up to 32). */
+int gims_sage_mean_split(const float* h, int64_t ldh, const int32_t* indptr, const int32_t* indices,
+                         int32_t n, int32_t c, uint16_t* out_spl, int64_t ld_spl, void* stream);
 
 /* Gather rows: dst[i, :] = src[idx[i], :]  (kept-keypoint compaction, gmatcher.py:244-249). */
 int gims_gather_rows(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t c,

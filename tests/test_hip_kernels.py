@@ -456,6 +456,10 @@ def test_sage_mean_and_gather(hip):
         if deg[i]:
             ref[i] = h[indices[indptr[i]:indptr[i + 1]]].astype(np.float64).mean(0)
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-5)
+    # the split-bf16 (SPL32) variant writes exactly the planes gims_split_spl32 makes of the f32 mean
+    spl = torch.zeros((n, 2 * c), dtype=torch.bfloat16, device="cuda")
+    hip.sage_mean_split(_dev(h), _dev(indptr), _dev(indices), spl)
+    np.testing.assert_array_equal(spl.cpu().view(torch.int16).numpy(), hip.split_spl32(out).cpu().view(torch.int16).numpy())
     idx = r.permutation(n)[:123].astype(np.int32)
     g = torch.empty((123, c), device="cuda")
     hip.gather_rows(_dev(h), _dev(idx), g)
