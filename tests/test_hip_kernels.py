@@ -577,6 +577,21 @@ def test_agc_vs_oracle_random(hip):
     assert int(inf[5]) == len(ref["link_edges"]) and int(inf[5]) > 0 and int(inf[3]) > 0
 
 
+@pytest.mark.parametrize("n", [61, 333, 1023])
+def test_agc_odd_sizes_vs_oracle(hip, n):
+    """Keypoint counts that are not multiples of 4 / 16 / 64 (the adjacency kernel walks four rows per wave and 64-column
+    words; the bit rows end in a partial word): graph equal to the oracle's."""
+    r = _rng(100 + n)
+    centers = r.random(size=(8, 2)) * 300
+    kp = (centers[r.integers(0, 8, size=n)] + r.normal(size=(n, 2)) * 10).astype(np.float32)
+    de = r.normal(size=(n, 256)).astype(np.float32)
+    ref = O.agc_build(kp, de, 15, 10, 3)
+    kept, indptr, indices, inf = _run_agc(hip, kp, de, 15, 10, 3)
+    np.testing.assert_array_equal(kept, ref["kept"])
+    np.testing.assert_array_equal(indptr, ref["indptr"])
+    np.testing.assert_array_equal(indices, ref["indices"])
+
+
 @pytest.mark.parametrize("resident", ["0", "2"])
 def test_sinkhorn_full_size_marginals(hip, monkeypatch, resident):
     """BASELINE size (4096 x 4096, 100 iterations), too large for the CPU oracle in a test: size-independent property of the
