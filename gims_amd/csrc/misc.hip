@@ -358,6 +358,41 @@ extern "C" int gims_sage_mean_split(const float* h, int64_t ldh, const int32_t* 
   return GIMS_OK;
 }
 
+// per-pair match statistics: one workgroup per pair, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void pair_stats_kernel(const int64_t* __restrict__ matches0, const float* __restrict__ scores0,
+                                                         const int32_t* __restrict__ tab, float* __restrict__ out) {
+  const int p = blockIdx.x, t = threadIdx.x;
+  const int n0 = tab[4 * p + 1], off = tab[4 * p + 3];
+  __shared__ float ssum[256];
+  __shared__ int scnt[256];
+  float s = 0.f;
+  int c = 0;
+  for (int i = t; i < n0; i += 256)
+    if (matches0[off + i] >= 0) { s += scores0[off + i]; ++c; }
+  ssum[t] = s;
+  scnt[t] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { ssum[t] += ssum[t + o]; scnt[t] += scnt[t + o]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    float* r = out + 5 * p;
+    r[0] = (float)tab[4 * p]; r[1] = (float)n0; r[2] = (float)tab[4 * p + 2];
+    r[3] = (float)scnt[0]; r[4] = ssum[0] / fmaxf((float)scnt[0], 1.f);
+  }
+}
+
+extern "C" int gims_pair_stats(const int64_t* matches0, const float* scores0, const int32_t* table, int32_t n_pairs, float* out,
+                               void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(matches0 && scores0 && table && out && n_pairs >= 0, "gims_pair_stats: bad arguments");
+  if (n_pairs == 0) return GIMS_OK;
+  hipLaunchKernelGGL(pair_stats_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, matches0, scores0, table, out);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
 extern "C" int gims_gather_rows(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t c, float* dst,
                                 int64_t ldd, void* stream) {
   using namespace gims;

@@ -125,6 +125,7 @@ _SIGNATURES = {
                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_sage_mean_split": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_pair_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gims_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
     "gims_agc_workspace_bytes": (C.c_size_t, [C.POINTER(AgcImage), C.c_int32]),
@@ -425,6 +426,17 @@ def sage_mean(h, indptr, indices, out, n=None, c=None):
     c = h.shape[1] if c is None else c
     _check(lib.gims_sage_mean(_p(_dev(h, torch.float32)), h.stride(0), _p(indptr), _p(indices), n, c, _p(out),
                               out.stride(0), _stream()), "gims_sage_mean")
+    return out
+
+
+def pair_stats(matches0, scores0, table):
+    """[n_pairs, 5] f32 records {pair_id, n0, n1, n_matches, mean_score} from batch-concatenated outputs; table: int32
+    [n_pairs, 4] = {pair_id, n0, n1, row offset} on the device (gims_pair_stats)."""
+    lib = load()
+    n = table.shape[0]
+    out = torch.empty((n, 5), dtype=torch.float32, device=matches0.device)
+    _check(lib.gims_pair_stats(_p(_dev(matches0, torch.int64)), _p(_dev(scores0, torch.float32)), _p(_dev(table, torch.int32)), n, _p(out),
+                               _stream()), "gims_pair_stats")
     return out
 
 

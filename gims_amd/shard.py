@@ -48,6 +48,13 @@ def pair_stats(pair_ids: Sequence[int], outs: Sequence[dict], device) -> torch.T
         n1 = [int(o["matches1"].numel()) for o in outs]
         m0 = torch.cat([o["matches0"].reshape(-1) for o in outs])
         s0 = torch.cat([o["matching_scores0"].reshape(-1) for o in outs])
+    if torch.device(device).type == "cuda" and m0.is_contiguous() and s0.is_contiguous():
+        # one table upload + one kernel (gims_pair_stats) instead of ~20 small tensor ops
+        import numpy as np
+        from . import hip
+        offs = np.concatenate([[0], np.cumsum(n0)[:-1]])
+        table = hip.upload(np.stack([np.asarray(pair_ids), np.asarray(n0), np.asarray(n1), offs], axis=1).astype(np.int32), device)
+        return hip.pair_stats(m0, s0, table)
     # only two tiny (<= a few hundred bytes) host->device copies: larger pageable copies make the HIP runtime pin and
     # unpin the source pages on the fly, which stalls the submitting thread for tens of milliseconds
     host = _to_device([[float(p), float(a), float(b)] for p, a, b in zip(pair_ids, n0, n1)], "float32", device)

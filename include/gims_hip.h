@@ -201,6 +201,13 @@ int gims_sage_mean(const float* h, int64_t ldh, const int32_t* indptr, const int
 int gims_sage_mean_split(const float* h, int64_t ldh, const int32_t* indptr, const int32_t* indices,
                          int32_t n, int32_t c, uint16_t* out_spl, int64_t ld_spl, void* stream);
 
+/* Per-pair match statistics of a batch whose outputs are concatenated (the record the multi-GPU harness all-gathers,
+ * SURVEY 8(e); the reference's eval loop keeps the same numbers per pair on the host, eval_homography.py:186-236):
+ *   table[p] = {pair_id, n0, n1, offset of the pair's rows in matches0 / scores0}  (int32 x 4, device memory)
+ *   out[p]   = {pair_id, n0, n1, #matches (matches0 >= 0), mean matching score over the matches (0 if none)}  (f32 x 5)
+ * Fixed summation order: the result is deterministic. */
+int gims_pair_stats(const int64_t* matches0, const float* scores0, const int32_t* table, int32_t n_pairs, float* out, void* stream);
+
 /* Gather rows: dst[i, :] = src[idx[i], :]  (kept-keypoint compaction, gmatcher.py:244-249). */
 int gims_gather_rows(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t c,
                      float* dst, int64_t ldd, void* stream);

@@ -466,6 +466,26 @@ def test_sage_mean_and_gather(hip):
     np.testing.assert_array_equal(g.cpu().numpy(), h[idx])
 
 
+def test_pair_stats(hip):
+    """gims_pair_stats against the plain formulation: per pair id / sizes / number of matches / mean score of the matches,
+    including a pair without any match and an empty pair."""
+    r = _rng(21)
+    n0 = [300, 0, 1023, 64, 17]
+    n1 = [280, 5, 1000, 64, 20]
+    ids = [7, 3, 11, 2, 5]
+    m0 = np.concatenate([r.integers(-1, 50, size=n).astype(np.int64) for n in n0])
+    m0[sum(n0[:3]):sum(n0[:4])] = -1                      # pair 3: no match at all
+    s0 = r.random(size=m0.size).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(n0)[:-1]])
+    table = hip.upload(np.stack([ids, n0, n1, offs], axis=1).astype(np.int32))
+    out = hip.pair_stats(_dev(m0), _dev(s0), table).cpu().numpy()
+    for p in range(len(n0)):
+        sl = slice(offs[p], offs[p] + n0[p])
+        v = m0[sl] >= 0
+        ref = [ids[p], n0[p], n1[p], v.sum(), s0[sl][v].astype(np.float64).mean() if v.any() else 0.0]
+        np.testing.assert_allclose(out[p], ref, rtol=1e-6, atol=1e-7)
+
+
 def test_kenc_first(hip):
     r = _rng(4)
     n = 1000
