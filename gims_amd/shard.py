@@ -96,12 +96,16 @@ def eval_summary(gathered: torch.Tensor, min_matches: int = 12) -> dict:
     return evalh.summarize(rec, min_matches=min_matches)
 
 
-def gather_stats(stats: torch.Tensor, world: int | None = None, counts: Sequence[int] | None = None) -> torch.Tensor:
+def gather_stats(stats: torch.Tensor, world: int | None = None, counts: Sequence[int] | None = None,
+                 presorted: bool = False) -> torch.Tensor:
     """All-gather the per-pair records of every rank (ragged counts are padded with pair_id = -1 rows and
     dropped again); returns the records of the whole job sorted by pair id, identical on every rank.
     counts: records per rank when the caller knows them (shard_indices is deterministic) -- then no count exchange and
-    no host sync happens here, so the host keeps running ahead of the GPU."""
+    no host sync happens here, so the host keeps running ahead of the GPU.  presorted: the caller's records are already
+    in ascending pair id (shard_indices yields them so); only used to skip the sort of a single-process run."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        if presorted:        # single process and the caller built the records in ascending pair id: nothing to do
+            return stats
         return stats[torch.argsort(stats[:, 0])] if stats.numel() else stats
     world = dist.get_world_size() if world is None else world
     if counts is None:
