@@ -108,6 +108,10 @@ def main():
     torch.set_grad_enabled(False)
 
     import __graft_entry__
+    if world > 1:            # one rank per node (re)builds a stale library, the others wait: no concurrent hipcc runs on one tree
+        if local_rank == 0:
+            __graft_entry__.build()
+        dist.barrier()
     __graft_entry__.build()
     from gims_amd import GMatcher, shard, synth
 
