@@ -74,8 +74,8 @@ def cpu_baseline(kpts, iters, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kpts", type=int, default=1024)
     ap.add_argument("--pairs", type=int, default=32, help="image pairs per step per GPU")
     ap.add_argument("--sinkhorn-iters", type=int, default=100)
