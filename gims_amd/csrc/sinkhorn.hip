@@ -560,6 +560,7 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
   auto mk = [](float x, float y) -> E { if constexpr (C >= 2) return E{x, y}; else return x; };
   auto lo = [](E v) -> float { if constexpr (C >= 2) return v[0]; else return v; };
   auto hi = [](E v) -> float { if constexpr (C >= 2) return v[1]; else return 0.f; };
+  auto fmaE = [](E x, E y, E z) -> E { return __builtin_elementwise_fma(x, y, z); };   // explicit: contraction is off in here
   E P[RR][H];
   // LDS rows: a thread's C values as 16-byte quads (C >= 4), one pair (C == 2) or one float, element q of thread t at
   // [(row * NQ + q) * 512 + t]: consecutive lanes are adjacent, so ds_read/write_b128 (b64, b32) are conflict-free
@@ -586,8 +587,12 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
       ((E*)plds)[r * 512 + t] = x[0];
     }
   };
-  // g: column factors of the last column step, applied lazily in the next row pass.  Ahead of a fresh iteration the
-  // same registers carry v instead (P is re-derived from Z, u, v there and needs no g); v0 = 0.
+  // LAZY SCALING: the stored matrix is K = exp(Z + u + v) of the last fresh iteration and is never rewritten; the row
+  // and column factors since then live as cumulative vectors F (fac[], per slab row) and G (g[], per column), the
+  // transport matrix being diag(F) K diag(G).  A sweep is then one fma per entry and no write-back -- row sums
+  // F_i sum_j K_ij G_j, column sums G_j sum_i F_i K_ij -- instead of a multiply, an add and a store.
+  // g: cumulative column factors.  Ahead of a fresh iteration the same registers carry v instead (K is re-derived from
+  // Z, u, v there); v0 = 0.
   float g[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) g[k] = 0.f;
@@ -601,6 +606,7 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
   const int G4 = p.cpb >> 2;
   const int S = 512 / G4 < p.nblk ? 512 / G4 : p.nblk;
   float vfold = 0.f;                                      // v of that column, carried across iterations
+  float gcf = 1.f;                                        // its cumulative factor G since the last fresh iteration
   __syncthreads();
 
   // P = exp(Z + u + v) for one row held in registers / LDS
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
     const int fg4 = t % G4, fss = t / G4, fcol = bk.slab * p.cpb + t;
     const bool fresh = it == 0 || it == a.iters - 1 || (a.refresh > 0 && it % a.refresh == 0);   // the last one: exact P behind the final u, v
     const bool publish_v = it + 1 < a.iters && (it + 2 == a.iters || (a.refresh > 0 && (it + 1) % a.refresh == 0));
-    // ---------------- row pass: P *= g (P re-derived from Z, u, v first on a fresh iteration), row sums
+    // ---------------- row pass: row sums sum_j K_ij G_j (K re-derived from Z, u, v first on a fresh iteration)
     stamp(-1);
     if (fresh) {
       int row0_o = row0, c0_o = c0;
@@ -672,12 +678,11 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
         for (int h = 0; h < H; ++h) y[h] = mk(x[2 * h], x[(2 * h + 1) % C]);
         lds_store(r, y);
       }
-      for (int r = t; r < nrows; r += 512) pb[r] = __expf((alpha + us[r]) + gbin);
+      for (int r = t; r < nrows; r += 512) { pb[r] = __expf((alpha + us[r]) + gbin); fac[r] = 1.f; }
 #pragma unroll
       for (int k = 0; k < C; ++k) g[k] = 1.f;
       gbin = 1.f;
-    } else {
-      for (int r = t; r < nrows; r += 512) pb[r] *= gbin;
+      gcf = 1.f;
     }
     E g2[H];
 #pragma unroll
@@ -689,9 +694,8 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
       for (int r8 = 0; r8 < 8; ++r8) {
         const int r = rb + r8;
         E s2 = P[r][0] * g2[0];
-        P[r][0] = s2;
 #pragma unroll
-        for (int h = 1; h < H; ++h) { P[r][h] *= g2[h]; s2 += P[r][h]; }
+        for (int h = 1; h < H; ++h) s2 = fmaE(P[r][h], g2[h], s2);
         rs[r8] = lo(s2) + hi(s2);
       }
       float t0, t1;
@@ -709,11 +713,9 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
         if (r < nl) {
           E x[H];
           lds_load(r, x);
-          x[0] *= g2[0];
-          E s2 = x[0];
+          E s2 = x[0] * g2[0];
 #pragma unroll
-          for (int h = 1; h < H; ++h) { x[h] *= g2[h]; s2 += x[h]; }
-          lds_store(r, x);
+          for (int h = 1; h < H; ++h) s2 = fmaE(x[h], g2[h], s2);
           s = lo(s2) + hi(s2);
         }
         rs[r8] = s;
@@ -736,18 +738,16 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
       float tot = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) tot += red[w * RMAX + r];
-      const float pbi = pb[r];
-      tot += pbi;
+      const float fc = fac[r];
+      tot = fc * (tot + pb[r] * gbin);                      // true row sum: F_i (sum_j K_ij G_j + K_i,bin G_bin)
       if (!(tot > 0.f) || !(tot < 3.0e38f)) p.status[0] = 1.f;
       const float du = (row0 + r < p.n ? p.norm : p.log_mu_bin) - logf(tot);
       us[r] += du;
-      const float f = __expf(du);
-      fac[r] = f;
-      pb[r] = pbi * f;
+      fac[r] = fc * __expf(du);
     }
     __syncthreads();
     stamp(1);
-    // ---------------- column pass: P *= f, partial column sums of this slab
+    // ---------------- column pass: partial column sums sum_i F_i K_ij of this slab (G_j is applied by the folding workgroup)
     E cs2[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) cs2[h] = mk(0.f, 0.f);
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
       for (int r8 = 0; r8 < 8; ++r8) {
         const E f2 = mk(f8[r8], f8[r8]);
 #pragma unroll
-        for (int h = 0; h < H; ++h) { P[rb + r8][h] *= f2; cs2[h] += P[rb + r8][h]; }
+        for (int h = 0; h < H; ++h) cs2[h] = fmaE(P[rb + r8][h], f2, cs2[h]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -770,8 +770,7 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
       E x[H];
       lds_load(r, x);
 #pragma unroll
-      for (int h = 0; h < H; ++h) { x[h] *= f2; cs2[h] += x[h]; }
-      lds_store(r, x);
+      for (int h = 0; h < H; ++h) cs2[h] = fmaE(x[h], f2, cs2[h]);
     }
     float cs[C];
 #pragma unroll
@@ -803,7 +802,7 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
     }
     if (wave == 0) {                                    // dustbin column: sum of pb over the slab rows
       float s = 0.f;
-      for (int r = lane; r < nrows; r += 64) s += pb[r];
+      for (int r = lane; r < nrows; r += 64) s += pb[r] * fac[r];
       s = wave_sum(s);
       if (lane == 0) st_agent(mine + p.m, tg(s));
     }
@@ -852,14 +851,16 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
       float tot = 0.f;
       const int j4 = t >> 2, jc = t & 3;
       for (int s = 0; s < S; ++s) tot += colred[(s * G4 + j4) * 4 + jc];
+      tot *= gcf;                                          // true column sum
       if (!(tot > 0.f) || !(tot < 3.0e38f)) p.status[0] = 1.f;
       const float dv = (fcol < p.m ? p.norm : p.log_nu_bin) - logf(tot);
       vfold += dv;
+      gcf *= __expf(dv);
       if (publish_v) {                                    // v first, acknowledged, then the tagged g that readers wait on
         st_agent(p.gbuf + p.mpad + fcol, vfold);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      st_agent(p.gbuf + fcol, tg(__expf(dv)));
+      st_agent(p.gbuf + fcol, tg(gcf));
     }
     stamp(4);
     if (it + 1 < a.iters) {
