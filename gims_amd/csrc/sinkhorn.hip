@@ -1052,7 +1052,7 @@ static int ot_res_run(const OtResPlan& P, const std::vector<OtDev>& hprob, float
   GIMS_HIP(hipMemsetAsync(base + al256r(sizeof(OtResProb) * (size_t)np), 0xFF, off - al256r(sizeof(OtResProb) * (size_t)np), s));
   int rc = upload_table(hp.data(), sizeof(OtResProb) * (size_t)np, dprob, s);
   if (rc != GIMS_OK) return rc;
-  const int refresh = ot_env("GIMS_OT_REFRESH", 33);
+  const int refresh = ot_env("GIMS_OT_REFRESH", 50);
   for (int gi = 0; gi < P.ngroups; ++gi) {
     OtResBlock* dblk = (OtResBlock*)(base + off); off += al256r(sizeof(OtResBlock) * 256);
     OtResBlock hb[256];

@@ -279,7 +279,7 @@ int gims_pack_graphs(const gims_pack_image* dev_images /* DEVICE array */, int32
  * Two implementations of the iteration loop (same recurrence, results agree to f32 rounding):
  *   streamed  -- one launch per iteration, Z read from HBM once per iteration (any size);
  *   resident  -- ONE launch for all iterations of a group of problems: exp(Z + u + v) is held in the registers and LDS
- *                of the 256 CUs and updated multiplicatively (re-derived from Z every 33 iterations and on the last),
+ *                of the 256 CUs and scaled lazily by cumulative row / column factors (re-derived from Z every 50 iterations and on the last),
  *                no HBM traffic inside the loop.  Used when the matrices fit on chip (m <= 4096, about 134 MB of
  *                matrix per launch) and are large enough to pay (>= 6 M entries); GIMS_OT_RESIDENT=0 / 2 in the
  *                environment forces streamed / resident.  gims_sinkhorn_plan() tells which one a call will take.
