@@ -146,6 +146,7 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    gc.disable()           # and no collection at all inside the K timed steps (re-enabled right after them)
     model.enable_timing(os.environ.get("GIMS_BENCH_NO_STAGE_TIMERS") is None)
     if world > 1:
         dist.barrier()
@@ -157,6 +158,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
