@@ -259,6 +259,58 @@ extern "C" int gims_run_ops(const gims_op* ops, int32_t n_ops, void* stream) {
   return GIMS_OK;
 }
 
+// The same replay with a HIP event recorded on `stream` before the first op and after every op (events[0 .. n_ops]): the
+// per-kernel durations of the production path, measured on the stream the kernels are launched on.
+extern "C" int gims_run_ops_timed(const gims_op* ops, int32_t n_ops, void* stream, void* const* events) {
+  using namespace gims;
+  GIMS_CHECK_ARG(ops && n_ops >= 0 && events, "gims_run_ops_timed: bad arguments");
+  GIMS_HIP(hipEventRecord((hipEvent_t)events[0], (hipStream_t)stream));
+  for (int i = 0; i < n_ops; ++i) {
+    const int rc = gims_run_ops(ops + i, 1, stream);
+    if (rc != GIMS_OK) return rc;
+    GIMS_HIP(hipEventRecord((hipEvent_t)events[i + 1], (hipStream_t)stream));
+  }
+  return GIMS_OK;
+}
+
+extern "C" int gims_events_create(int32_t n, void** events_out) {
+  using namespace gims;
+  GIMS_CHECK_ARG(n > 0 && events_out, "gims_events_create: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) {
+      for (int j = 0; j < i; ++j) hipEventDestroy((hipEvent_t)events_out[j]);
+      GIMS_HIP(rc);
+    }
+    events_out[i] = (void*)e;
+  }
+  return GIMS_OK;
+}
+
+extern "C" int gims_events_record(void* event, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(event, "gims_events_record: null event");
+  GIMS_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return GIMS_OK;
+}
+
+// ms_out[i] = time between events[i] and events[i+1], i < n - 1; every event must have completed (synchronise first).
+extern "C" int gims_events_elapsed(void* const* events, int32_t n, float* ms_out) {
+  using namespace gims;
+  GIMS_CHECK_ARG(events && n > 1 && ms_out, "gims_events_elapsed: bad arguments");
+  for (int i = 0; i + 1 < n; ++i) GIMS_HIP(hipEventElapsedTime(&ms_out[i], (hipEvent_t)events[i], (hipEvent_t)events[i + 1]));
+  return GIMS_OK;
+}
+
+extern "C" int gims_events_destroy(void* const* events, int32_t n) {
+  using namespace gims;
+  GIMS_CHECK_ARG(events && n >= 0, "gims_events_destroy: bad arguments");
+  for (int i = 0; i < n; ++i)
+    if (events[i]) GIMS_HIP(hipEventDestroy((hipEvent_t)events[i]));
+  return GIMS_OK;
+}
+
 extern "C" int gims_ops_graph_create(const gims_op* ops, int32_t n_ops, void* stream, void** graph_exec_out) {
   using namespace gims;
   GIMS_CHECK_ARG(ops && n_ops > 0 && graph_exec_out && stream, "gims_ops_graph_create: bad arguments (a non-default stream is required)");

@@ -143,6 +143,7 @@ class GMatcher(nn.Module):
                 k = k[:-len("bias")] + "fc_self.bias"
             sd[k] = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
         self._pack = None
+        self.__dict__.pop("_ops_cache", None)
         return super().load_state_dict(sd, strict=strict, **kw)
 
     # ------------------------------------------------------------------ weight packing
@@ -231,6 +232,11 @@ class GMatcher(nn.Module):
         P["final"] = lin(sd["final_proj.weight"][:, :, 0], sd["final_proj.bias"], True)
         P["alpha"] = float(sd["bin_score"])
         self._pack, self._pack_key = P, key
+        # replay tables bake raw device pointers of the OLD pack's tensors: drop them with it, and identify packs by a
+        # monotonically increasing generation (id() of a freed dict is readily reused by CPython)
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1
+        P["gen"] = self._pack_gen
+        self.__dict__.pop("_ops_cache", None)
         return P
 
     # The Q/K/V projection feeds the bf16 attention kernel and is rounded to bf16 on the way out, so it runs as a plain bf16
@@ -258,16 +264,24 @@ class GMatcher(nn.Module):
         return self._buf("act_" + name, nbytes)[:nbytes].view(dtype).view(rows, cols)
 
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
-    def enable_timing(self, on: bool = True):
+    def enable_timing(self, on: bool = True, stepwise: bool = False):
         """Record a (start, end) HIP-event pair around every stage on the stream the kernels are launched on;
-        read them back with ``stage_times_ms()`` after a synchronize."""
+        read them back with ``stage_times_ms()`` after a synchronize.  The GNN layers keep running through the replayed
+        launch table (the production path): the library records an event after each of its launches
+        (gims_run_ops_timed).  ``stepwise=True`` launches the layers one by one from Python instead."""
         self._timers = {} if on else None
+        self._stepwise = bool(stepwise)
+
+    _stepwise = False
 
     def stage_times_ms(self):
         out = {}
         for name, evs in (self._timers or {}).items():
             if not name.startswith("_"):
                 out[name] = [a.elapsed_time(b) for a, b, _ in evs]
+        for pool, labels in (self._timers or {}).get("_ops", []):       # per-op events of the replayed layers
+            for lab, ms in zip(labels, pool.elapsed_ms()):
+                out.setdefault(lab, []).append(ms)
         return out
 
     def stage_host_ms(self):
@@ -449,12 +463,12 @@ class GMatcher(nn.Module):
             mpl, gpl, hpl = (self._act("mpl", n_tot, 2 * D, torch.bfloat16), self._act("gpl", n_tot, 2 * D, torch.bfloat16),
                              self._act("hpl", n_tot, 4 * D, torch.bfloat16))
             hid_ln = None
-            replay = (self._timers is None and not ln and all(L["mlp0_fused"] is not None for L in P["layers"])
+            replay = (not self._stepwise and not ln and all(L["mlp0_fused"] is not None for L in P["layers"])
                       and os.environ.get("GIMS_NO_REPLAY") is None)
             if replay:
                 # the 72 launches of the 18 layers as ONE call into the library (gims_run_ops): their arguments depend only on
                 # the buffer addresses and the batch geometry, which repeat from call to call in steady state
-                key = (id(P), n_tot, max_nq, dpl.data_ptr(), mpl.data_ptr(), hpl.data_ptr(), desc.data_ptr(), qkv.data_ptr(),
+                key = (P["gen"], n_tot, max_nq, dpl.data_ptr(), mpl.data_ptr(), hpl.data_ptr(), desc.data_ptr(), qkv.data_ptr(),
                        self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags)
                 cache = self.__dict__.setdefault("_ops_cache", {})
                 ops = cache.get(key)
@@ -470,13 +484,19 @@ class GMatcher(nn.Module):
                         lst.append(la(L["mlp1"], hpl, residual=desc, out=desc, out_split=dpl))
                     if len(cache) > 8:
                         cache.clear()
-                    ops = cache[key] = [hip.make_ops(lst), None, 0]           # table, HIP graph, uses
+                    # table, HIP graph, uses, and references to every tensor whose address is baked into the table
+                    ops = cache[key] = [hip.make_ops(lst), None, 0, (P, dpl, mpl, hpl, desc, qkv, self_pr, cross_pr),
+                                        [lab for L in P["layers"] for lab in ("qkv", "attn_cross" if L["cross"] else "attn_self", "mlp", "mlp")]]
                 # first use: plain replay (first-use initialisation inside the library); from the second use on a non-default
                 # stream, if GIMS_OPS_GRAPH=1: ONE graph launch
                 ops[2] += 1
                 if ops[1] is None and ops[2] >= 2 and self._use_graph and torch.cuda.current_stream().cuda_stream != 0:
                     ops[1] = hip.OpsGraph(ops[0])
-                if ops[1] is not None:
+                if self._timers is not None:
+                    pool = hip.EventPool(len(ops[0]) + 1)
+                    hip.run_ops_timed(ops[0], pool)
+                    self._timers.setdefault("_ops", []).append((pool, ops[4]))
+                elif ops[1] is not None:
                     ops[1].launch()
                 else:
                     hip.run_ops(ops[0])

@@ -107,6 +107,11 @@ _SIGNATURES = {
     "gims_ch_l2norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_ch_relu6": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_run_ops": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "gims_run_ops_timed": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gims_events_create": (C.c_int, [C.c_int32, C.c_void_p]),
+    "gims_events_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gims_events_elapsed": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "gims_events_destroy": (C.c_int, [C.c_void_p, C.c_int32]),
     "gims_ops_graph_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gims_ops_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gims_ops_graph_destroy": (C.c_int, [C.c_void_p]),
@@ -321,6 +326,32 @@ def make_ops(ops):
 
 def run_ops(op_array):
     _check(load().gims_run_ops(op_array, len(op_array), _stream()), "gims_run_ops")
+
+
+class EventPool:
+    """n HIP events owned by the library (gims_events_*): per-op timing of a replayed launch sequence."""
+
+    def __init__(self, n):
+        self.n = n
+        self._ev = (C.c_void_p * n)()
+        _check(load().gims_events_create(n, self._ev), "gims_events_create")
+
+    def elapsed_ms(self):
+        """The n - 1 intervals between consecutive events (ms); synchronise the stream first."""
+        out = (C.c_float * (self.n - 1))()
+        _check(load().gims_events_elapsed(self._ev, self.n, out), "gims_events_elapsed")
+        return list(out)
+
+    def __del__(self):
+        try:
+            load().gims_events_destroy(self._ev, self.n)
+        except Exception:
+            pass
+
+
+def run_ops_timed(op_array, pool: EventPool):
+    assert pool.n == len(op_array) + 1
+    _check(load().gims_run_ops_timed(op_array, len(op_array), _stream(), pool._ev), "gims_run_ops_timed")
 
 
 class OpsGraph:

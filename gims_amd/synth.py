@@ -135,10 +135,16 @@ def make_pair(n: int, seed: int, canvas=None, pos_noise=0.5, desc_noise=0.03, ou
 GAINS = {"kenc": 0.5, "gnn_encoder": 3.0, "gnn": 0.3, "final_proj": 1.0}
 
 
-def _gain_for(name: str) -> float:
+def _gain_for(name: str, gains=None) -> float:
+    """Gain of a weight tensor.  ``gains`` may override the module gains (keys of GAINS) and may add substring keys such as
+    ``"attn.proj.0"`` (query projection): the longest matching substring key wins over the module gain."""
+    g = {**GAINS, **(gains or {})}
+    sub = [k for k in g if k not in GAINS and k in name]
+    if sub:
+        return g[max(sub, key=len)]
     for k in ("gnn_encoder", "kenc", "final_proj", "gnn"):
         if name.startswith(k + "."):
-            return GAINS[k]
+            return g[k]
     return 1.0
 
 
@@ -189,12 +195,13 @@ def state_dict_spec(descriptor_dim=256, keypoint_encoder=(32, 64, 128, 256), n_l
     return spec
 
 
-def make_state_dict(seed: int = 123, bias_std: float = 0.02, bn_jitter: float = 0.2, **kw):
+def make_state_dict(seed: int = 123, bias_std: float = 0.02, bn_jitter: float = 0.2, gains=None, **kw):
     """Synthetic GMatcher weights as {name: np.ndarray}.
 
     Conv/linear weights ~ N(0, g^2/fan_in); biases ~ N(0, bias_std^2) (non-zero so the bias
     paths are exercised); BatchNorm gamma/var ~ 1 +- bn_jitter, beta/mean small -- so the
-    BN-folding path is exercised as well.  ``bin_score`` = 1 (gmatcher.py:206).
+    BN-folding path is exercised as well.  ``bin_score`` = 1 (gmatcher.py:206).  ``gains`` overrides / extends GAINS (see
+    ``_gain_for``): e.g. ``{"attn.proj.0": 1.2, "attn.proj.1": 1.2}`` sharpens the attention of every layer.
     """
     out = {}
     for i, (name, shape) in enumerate(state_dict_spec(**kw)):
@@ -223,7 +230,7 @@ def make_state_dict(seed: int = 123, bias_std: float = 0.02, bn_jitter: float = 
             a = (bias_std * normal(seed, stream, n)).astype(np.float32).reshape(shape)
         else:
             fan_in = shape[1]
-            g = _gain_for(name)
+            g = _gain_for(name, gains)
             a = (normal(seed, stream, n) * (g / np.sqrt(float(fan_in)))).astype(np.float32).reshape(shape)
         out[name] = a
     return out

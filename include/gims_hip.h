@@ -157,6 +157,15 @@ typedef struct gims_attn_args {
 #define GIMS_OP_ATTENTION 1
 typedef struct gims_op { int32_t kind; int32_t reserved; union { gims_linear_args lin; gims_attn_args att; } u; } gims_op;
 int gims_run_ops(const gims_op* ops /* HOST */, int32_t n_ops, void* stream);
+/* The same replay with a HIP event recorded on `stream` before the first op and after every op: events is a HOST array of
+ * n_ops + 1 event handles from gims_events_create.  gims_events_elapsed (after the stream has been synchronised) returns the
+ * n - 1 intervals between n consecutive events in milliseconds: per-kernel durations of the production path, taken on the
+ * stream the kernels run on.  (Instrumentation of this build; the reference prints wall-clock stage times, gmatcher.py:226-243.) */
+int gims_run_ops_timed(const gims_op* ops /* HOST */, int32_t n_ops, void* stream, void* const* events /* HOST, n_ops + 1 */);
+int gims_events_create(int32_t n, void** events_out /* HOST array of n handles */);
+int gims_events_record(void* event, void* stream);
+int gims_events_elapsed(void* const* events /* HOST */, int32_t n, float* h_ms_out /* HOST, n - 1 */);
+int gims_events_destroy(void* const* events /* HOST */, int32_t n);
 /* The same sequence as a HIP graph: gims_ops_graph_create captures the launches of `ops` on `stream` (nothing executes),
  * gims_ops_graph_launch replays them (one graph launch: no per-kernel launch gaps), gims_ops_graph_destroy frees the graph.
  * Every op must have run once through gims_run_ops before (first-use initialisation cannot happen inside a capture), and

@@ -24,3 +24,20 @@ def pair_to_data(pair, radius, percentile, min_size, device="cpu"):
     d["image0"], d["image1"] = pair["image0"], pair["image1"]
     d.update(device=torch.device(device), radius=radius, percentile=percentile, min_size=min_size)
     return d
+
+
+def safe_rows(ot, thr, ref_matches0, ref_scores0, eps=1e-3):
+    """Rows of the reference's (n+1, m+1) log-OT matrix whose match decision is well conditioned: top-1/top-2 gap of the
+    row above `eps`, score further than `eps` from the threshold, and (for matched rows) a well-conditioned argmax in the
+    partner's column.  Index parity is asserted on exactly these rows; everywhere else a last-ulp difference in the
+    potentials may legitimately flip the reference's own decision."""
+    inner = np.asarray(ot)[:-1, :-1]
+    part = np.partition(inner, -2, axis=1)
+    gap0 = part[:, -1] - part[:, -2]
+    partc = np.partition(inner, -2, axis=0)
+    gap1 = partc[-1] - partc[-2]
+    safe = (gap0 > eps) & (np.abs(np.asarray(ref_scores0) - thr) > eps)
+    r0 = np.asarray(ref_matches0)
+    partner = np.where(r0 >= 0, r0, 0)
+    safe &= (gap1[partner] > eps) | (r0 < 0)
+    return safe

@@ -9,7 +9,7 @@ import torch
 
 from gims_amd import GMatcher, synth
 from oracle import gims_oracle as O
-from tests.helpers import golden_names, load_golden, pair_to_data
+from tests.helpers import golden_names, load_golden, pair_to_data, safe_rows
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -45,10 +45,13 @@ def _compare(out, data, g, thr):
     same = m0 == r0
     err = np.abs(s0 - rs0)[same & (r0 >= 0)].max()
     assert err < 1e-4, f"matching_scores0 max err {err:.3e}"
-    if (m0 == r0).all():
-        np.testing.assert_array_equal(m1, r1)
-        assert np.abs(s1 - rs1).max() < 1e-4
-    return dict(n=len(m0), mismatched_unsafe=int((m0 != r0).sum()), score_err=float(err))
+    # ... and in practice EVERY row agrees, ill-conditioned ones included: asserted, so that a regression on those rows is
+    # seen (a failure here with zero well-conditioned mismatches means a reference decision flipped on a sub-1e-3 margin)
+    mismatched_unsafe = int((m0 != r0).sum())
+    assert mismatched_unsafe == 0, f"{mismatched_unsafe} ill-conditioned rows differ from the reference: {np.nonzero(m0 != r0)[0][:8]}"
+    np.testing.assert_array_equal(m1, r1)
+    assert np.abs(s1 - rs1).max() < 1e-4
+    return dict(n=len(m0), mismatched_unsafe=mismatched_unsafe, score_err=float(err))
 
 
 @pytest.mark.parametrize("sinkhorn", ["streamed", "resident"])     # both Sinkhorn implementations against the reference
@@ -72,6 +75,24 @@ def test_e2e_vs_reference_golden(models, monkeypatch, name, prec, sinkhorn):
     a = np.stack([src.cpu().numpy(), dst.cpu().numpy()], 1)
     b = np.stack([g["out/dgl_src1"], g["out/dgl_dst1"]], 1)
     np.testing.assert_array_equal(a[np.lexsort((a[:, 1], a[:, 0]))], b[np.lexsort((b[:, 1], b[:, 0]))])
+
+
+@pytest.mark.parametrize("sinkhorn", ["streamed", "resident"])
+@pytest.mark.parametrize("name", golden_names("sharpe2e_") + golden_names("peakede2e_"))
+def test_e2e_sharp_attention_vs_reference_golden(monkeypatch, name, sinkhorn):
+    """Trained-like, PEAKED attention (query / key projections of every layer scaled up: mean row maximum of the softmax
+    0.21 for the 'sharp' fixtures and 0.76 for the 'peaked' ones, against 0.007 with the default synthetic weights).  The
+    reference produced the goldens with the same weights; bars as everywhere: indices exact, scores within 1e-4."""
+    monkeypatch.setenv("GIMS_OT_RESIDENT", "0" if sinkhorn == "streamed" else "2")
+    g = load_golden(name)
+    n, seed, rad, pct, ms, iters = [int(x) for x in g["meta"]]
+    gq = float(g["gain_qk"])
+    m = GMatcher({"sinkhorn_iterations": iters, "match_threshold": float(g["match_threshold"])}).eval()
+    m.load_state_dict(synth.make_state_dict(123, gains={"attn.proj.0": gq, "attn.proj.1": gq}))
+    data = pair_to_data(synth.make_pair(n, seed), rad, pct, ms, device="cuda")
+    out = m(data)
+    stats = _compare(out, data, g, float(g["match_threshold"]))
+    print(name, sinkhorn, stats)
 
 
 @pytest.mark.parametrize("name", golden_names("full_"))
@@ -179,7 +200,7 @@ def test_replayed_layers_equal_stepwise(synth_sd):
     m.load_state_dict(synth_sd)
     res = []
     for timed in (False, True, False):           # replay (cold cache), stepwise, replay (warm cache)
-        m.enable_timing(timed)
+        m.enable_timing(timed, stepwise=timed)
         outs = m.match_pairs([pair_to_data(p, 15, 2, 7, device="cuda") for p in pairs])
         torch.cuda.synchronize()
         res.append([(o["matches0"].cpu().numpy(), o["matching_scores0"].cpu().numpy()) for o in outs])
@@ -259,14 +280,17 @@ def test_sparse_graph_few_kept_vs_oracle(models, synth_sd):
     d_gpu = pair_to_data(pair, 15, 2, 7, device="cuda")
     out = m(d_gpu)
     d_cpu = pair_to_data(pair, 15, 2, 7, device="cpu")
-    ref = O.gmatcher_forward(synth_sd, d_cpu, {})
+    st = {}
+    ref = O.gmatcher_forward(synth_sd, d_cpu, {}, stages=st)
     assert d_gpu["kept_kpts0_indices"] == d_cpu["kept_kpts0_indices"] and d_gpu["kept_kpts1_indices"] == d_cpu["kept_kpts1_indices"]
     n0, n1 = len(d_cpu["kept_kpts0_indices"][0]), len(d_cpu["kept_kpts1_indices"][0])
     assert 0 < n0 < 200 and 0 < n1 < 200
     assert out["matches0"].shape == (1, n0) and out["matches1"].shape == (1, n1)
     np.testing.assert_allclose(out["matching_scores0"][0].cpu().numpy(), ref["matching_scores0"][0].numpy(), atol=1e-4)
-    agree = (out["matches0"][0].cpu().numpy() == ref["matches0"][0].numpy()).mean()
-    assert agree > 0.95
+    r0 = ref["matches0"][0].numpy()
+    safe = safe_rows(st["ot"][0].numpy(), 0.2, r0, ref["matching_scores0"][0].numpy())
+    assert safe.mean() > 0.8
+    np.testing.assert_array_equal(out["matches0"][0].cpu().numpy()[safe], r0[safe])          # every well-conditioned row: exact
 
 
 def test_everything_removed_raises_like_reference(models):

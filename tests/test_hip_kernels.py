@@ -9,7 +9,7 @@ import torch
 
 from gims_amd import synth
 from oracle import gims_oracle as O
-from tests.helpers import golden_names, load_golden
+from tests.helpers import golden_names, load_golden, safe_rows
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -405,9 +405,10 @@ def test_sinkhorn_batched_ragged(hip, monkeypatch, resident, shapes):
     for it, ref in zip(items, refs):
         full = hip.ot_matrix(it["scores"], it["n"], it["m"], 0.7, it["uv"]).cpu().numpy()
         np.testing.assert_allclose(full, ref[0].numpy(), atol=1e-3, rtol=0)
-        i0, _, _, _ = O.select_matches(ref, 0.2)
-        agree = (it["matches0"].cpu().numpy() == i0[0].numpy()).mean()
-        assert agree > 0.99
+        i0, _, sc0, _ = O.select_matches(ref, 0.2)
+        safe = safe_rows(ref[0].numpy(), 0.2, i0[0].numpy(), sc0[0].numpy())
+        assert safe.mean() > 0.9
+        np.testing.assert_array_equal(it["matches0"].cpu().numpy()[safe], i0[0].numpy()[safe])     # every well-conditioned row: exact
         assert float(it["uv"][-1]) == 0.0
 
 
@@ -533,7 +534,8 @@ def _csr_edges(indptr, indices):
     return e[np.lexsort((e[:, 1], e[:, 0]))]
 
 
-@pytest.mark.parametrize("name", golden_names("agc_") + golden_names("e2e_n256") + golden_names("e2e_n1024_s1000"))
+@pytest.mark.parametrize("name", golden_names("agc_") + golden_names("e2e_n256") + golden_names("e2e_n1024_s1000") + golden_names("e2e_n4096")
+                         + golden_names("e2e_n8192"))
 def test_agc_vs_reference_golden(hip, name):
     """kept indices and the final edge set must equal the REFERENCE's (golden) bit for bit; the threshold may
     differ in the last ulps (BLAS summation order), so conditioning is asserted first (margin of the closest
@@ -550,7 +552,17 @@ def test_agc_vs_reference_golden(hip, name):
         thr = np.array([inf[6]], dtype=np.int32).view(np.float32)[0]
         assert abs(float(thr) - float(g[f"agc{s}/thr"])) < 1e-6, (thr, g[f"agc{s}/thr"])
         if float(g[f"agc{s}/margin"]) < 2e-6:
-            pytest.skip("fixture is ill-conditioned: a candidate similarity sits within 2e-6 of the threshold")
+            # ill-conditioned fixture: a radius candidate's similarity sits within 2e-6 of the percentile threshold, so the
+            # reference's own edge decision hangs on its BLAS summation order.  Not skipped: the comparison is made in
+            # ORIGINAL node ids and reported; at most the near-threshold edges (and what hangs on them) may differ.
+            mine = kept[_csr_edges(indptr, indices)]
+            a = {tuple(e) for e in mine.tolist()}
+            b = {tuple(e) for e in g[f"agc{s}/final"].tolist()}
+            kd = len(set(kept.tolist()) ^ set(g[f"agc{s}/kept"].tolist()))
+            print(f"{name} image {s}: margin {float(g[f'agc{s}/margin']):.2e} (ill-conditioned): coarse edges {int(inf[2])} vs "
+                  f"{len(g[f'agc{s}/coarse'])}, final edge symmetric difference {len(a ^ b)}, kept-id symmetric difference {kd}")
+            assert abs(int(inf[2]) - len(g[f"agc{s}/coarse"])) <= 2 and len(a ^ b) <= 4 and kd <= 2 * ms
+            continue
         assert int(inf[2]) == len(g[f"agc{s}/coarse"])
         np.testing.assert_array_equal(kept, g[f"agc{s}/kept"])
         relabel = -np.ones(n, dtype=np.int64)
