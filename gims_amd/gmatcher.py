@@ -86,6 +86,10 @@ class GMatcher(nn.Module):
         'num_heads': 4,
         # --- additions (defaults keep the reference behaviour) ---
         'linear_precision': 'bf16x3',   # 'bf16x3' (split-bf16 MFMA, ~2^-17) or 'f32' (exact-f32 MFMA)
+        # 'bf16': plain bf16 MFMA attention (north_star's choice; meets the 1e-4 score bar for diffuse to moderately peaked
+        # softmaxes -- mean row maximum up to ~0.2 measured).  'bf16x3': Q, K, V and P as split-bf16 pairs, three MFMAs
+        # per product (GIMS_ATTN_X3) -- for sharply peaked attention (mean row maximum ~0.8: the 'peaked' goldens need it)
+        'attention_precision': 'bf16',
         'verbose': False,               # the reference prints '>> ...' timing lines; off by default here
         # fold the attention 'merge' conv into the first MLP conv at load time:
         #   W0 [x ; Wm o + bm] + b0  ==  W0x x + (W0m Wm) o + (W0m bm + b0)        (gmatcher.py:114,125)
@@ -456,7 +460,14 @@ class GMatcher(nn.Module):
         self_pr = hip.upload(spr, dev, out=self._buf("self_pr", spr.nbytes + 32))
         cross_pr = hip.upload(cpr, dev, out=self._buf("cross_pr", cpr.nbytes + 32))
         max_nq = max(g["n_kept"] for g in images)
-        qkv = self._act("qkv", n_tot, 3 * D, torch.bfloat16)
+        if cfg['attention_precision'] not in ('bf16', 'bf16x3'):
+            raise ValueError("attention_precision must be 'bf16' or 'bf16x3'")
+        ax3 = cfg['attention_precision'] == 'bf16x3' and x3
+        if cfg['attention_precision'] == 'bf16x3' and not x3:
+            raise ValueError("attention_precision='bf16x3' needs linear_precision='bf16x3' (the split Q/K/V projection)")
+        # bf16 attention: Q|K|V as one bf16 buffer [rows][768]; x3 attention: the same three matrices as SPL32 hi/lo planes
+        qkv = self._act("qkv", n_tot, (6 if ax3 else 3) * D, torch.bfloat16)
+        qkv_out = dict(out_split=qkv) if ax3 else dict(out_bf16=qkv, flags=self._qkv_flags)
         if x3:
             # all GEMM operands travel as split-bf16 SPL32 buffers written by the producing kernel's epilogue; only the
             # residual stream `desc` also exists in f32
@@ -469,7 +480,7 @@ class GMatcher(nn.Module):
                 # the 72 launches of the 18 layers as ONE call into the library (gims_run_ops): their arguments depend only on
                 # the buffer addresses and the batch geometry, which repeat from call to call in steady state
                 key = (P["gen"], n_tot, max_nq, dpl.data_ptr(), mpl.data_ptr(), hpl.data_ptr(), desc.data_ptr(), qkv.data_ptr(),
-                       self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags)
+                       self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags, ax3)
                 cache = self.__dict__.setdefault("_ops_cache", {})
                 ops = cache.get(key)
                 if ops is None:
@@ -477,9 +488,9 @@ class GMatcher(nn.Module):
                         return hip.op_linear(hip.linear_args(a0, e["w"], w_lo=e["w_lo"], bias=e["b"], precision=e["prec"], spl=e["spl"], **kw))
                     lst = []
                     for L in P["layers"]:
-                        lst.append(la(L["qkv"], dpl, out_bf16=qkv, flags=self._qkv_flags))
+                        lst.append(la(L["qkv"], dpl, **qkv_out))
                         lst.append(hip.op_attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D,
-                                                    out_split=mpl, q_prescaled=True))
+                                                    out_split=mpl, q_prescaled=True, x3=ax3))
                         lst.append(la(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl, flags=self._msg_flags))
                         lst.append(la(L["mlp1"], hpl, residual=desc, out=desc, out_split=dpl))
                     if len(cache) > 8:
@@ -502,9 +513,9 @@ class GMatcher(nn.Module):
                     hip.run_ops(ops[0])
             for L in (() if replay else P["layers"]):
                 with St("qkv"):
-                    self._lin(L["qkv"], dpl, out_bf16=qkv, flags=self._qkv_flags)
+                    self._lin(L["qkv"], dpl, **qkv_out)
                 with St("attn_cross" if L["cross"] else "attn_self"):
-                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl, q_prescaled=True)
+                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl, q_prescaled=True, x3=ax3)
                 with St("mlp"):
                     if ln:        # LayerNorm between the two MLP convs: hidden activations in f32, normalised + split by the norm kernel
                         if hid_ln is None:

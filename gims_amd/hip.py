@@ -310,12 +310,12 @@ def op_linear(args: LinearArgs) -> Op:
     return o
 
 
-def op_attention(qkv, problems, max_n_q, n_heads, out=None, q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False) -> Op:
+def op_attention(qkv, problems, max_n_q, n_heads, out=None, q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False) -> Op:
     o = Op()
     o.kind = 1
     o.u.att = AttnArgs(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0], max_n_q, n_heads, _p(out),
                        out.stride(0) if out is not None else 0, _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
-                       out_split.stride(0) if out_split is not None else 0, 1 if q_prescaled else 0)
+                       out_split.stride(0) if out_split is not None else 0, (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0))
     return o
 
 
@@ -405,16 +405,21 @@ def split_bf16(x: torch.Tensor):
 ATTN_Q_SCALE = 0.125 * 1.4426950408889634      # log2(e) / sqrt(64): what q_prescaled=True expects folded into Q
 
 
+ATTN_X3 = 2
+
+
 def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: int, out=None,
-              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False):
+              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False):
     """qkv bf16 [rows, ld]; problems int32 [P,4] (q_off, n_q, kv_off, n_kv) on device; out f32 [rows, ld_out]
-    and/or out_split = SPL32 bf16 buffer [rows, >= 512].  q_prescaled: Q already carries ATTN_Q_SCALE."""
+    and/or out_split = SPL32 bf16 buffer [rows, >= 512].  q_prescaled: Q already carries ATTN_Q_SCALE.
+    x3: qkv is the SPL32 split-bf16 buffer [rows, >= 1536] of the 3-pass projection (GIMS_ATTN_X3)."""
     lib = load()
     assert qkv.dtype == torch.bfloat16 and problems.dtype == torch.int32 and problems.is_cuda
     _check(lib.gims_attention(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0],
                               max_n_q, n_heads, _p(out), out.stride(0) if out is not None else 0, _p(out_split),
                               (out_split.data_ptr() + 64) if out_split is not None else None,
-                              out_split.stride(0) if out_split is not None else 0, 1 if q_prescaled else 0, _stream()),
+                              out_split.stride(0) if out_split is not None else 0,
+                              (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0), _stream()),
            "gims_attention")
     return out if out is not None else out_split
 

@@ -135,6 +135,11 @@ int gims_split_spl32(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, 
  * query projection): the kernel then computes softmax as exp2(Q K^T) / sum, which saves it one multiply-add per score.
  */
 #define GIMS_ATTN_Q_PRESCALED 1
+/* GIMS_ATTN_X3: f32-class accuracy for sharply peaked softmaxes.  qkv is then the SPL32 split-bf16 buffer the 3-pass Q/K/V
+ * projection writes (gims_linear out_hi/out_lo; pitch ld >= 2 * 768, see gims_linear_args), q_col/k_col/v_col stay LOGICAL
+ * channel offsets (multiples of 32), and every product of the kernel (Q K^T and P V) is three bf16 MFMAs on hi/lo pairs
+ * (hi*hi + hi*lo + lo*hi); P is split in registers.  About three times the matrix work of the plain bf16 kernel. */
+#define GIMS_ATTN_X3 2
 typedef struct gims_attn_problem { int32_t q_off, n_q, kv_off, n_kv; } gims_attn_problem;
 
 int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,

@@ -87,7 +87,10 @@ def test_e2e_sharp_attention_vs_reference_golden(monkeypatch, name, sinkhorn):
     g = load_golden(name)
     n, seed, rad, pct, ms, iters = [int(x) for x in g["meta"]]
     gq = float(g["gain_qk"])
-    m = GMatcher({"sinkhorn_iterations": iters, "match_threshold": float(g["match_threshold"])}).eval()
+    # plain bf16 attention holds the bar up to the 'sharp' weights (measured); the 'peaked' ones need the split-bf16 mode
+    # (with bf16 attention their score error is 3.1e-4: indices still exact, scores over the 1e-4 bar)
+    m = GMatcher({"sinkhorn_iterations": iters, "match_threshold": float(g["match_threshold"]),
+                  "attention_precision": "bf16x3" if name.startswith("peaked") else "bf16"}).eval()
     m.load_state_dict(synth.make_state_dict(123, gains={"attn.proj.0": gq, "attn.proj.1": gq}))
     data = pair_to_data(synth.make_pair(n, seed), rad, pct, ms, device="cuda")
     out = m(data)

@@ -262,6 +262,54 @@ def test_attention(hip, monkeypatch, sizes, sharp, kernel, prescaled):
         assert (np.abs(rec[qo:qo + nq] - o[qo:qo + nq]) <= np.abs(o[qo:qo + nq]) * 2.0 ** -15 + 1e-30).all()
 
 
+@pytest.mark.parametrize("prescaled", [False, True])
+@pytest.mark.parametrize("sizes,sharp", [([(64, 64)], 1.0), ([(200, 333), (333, 200)], 1.0), ([(1, 5), (129, 64), (1000, 777)], 1.0),
+                                         ([(256, 256)], 6.0), ([(500, 300)], 12.0)])
+def test_attention_x3(hip, sizes, sharp, prescaled):
+    """Split-bf16 attention (GIMS_ATTN_X3): f32 Q/K/V given as SPL32 hi/lo planes, three MFMAs per product, against the
+    float64 softmax attention of the SAME f32 values -- f32-class agreement (1e-4 of the value scale; the plain bf16 kernel
+    is held to 1.5e-2), also for sharply peaked softmaxes (sharp = 6, 12: logits of magnitude 50-150)."""
+    r = _rng(len(sizes) * 100 + sizes[0][0] + 1)
+    rows = sum(a + b for a, b in sizes)
+    qkv = (r.normal(size=(rows, 768)) * np.r_[np.full(512, sharp), np.ones(256)]).astype(np.float32)
+    f = qkv.astype(np.float64)
+    if prescaled:
+        qkv = qkv.copy()
+        qkv[:, :256] *= np.float32(hip.ATTN_Q_SCALE)
+        f = qkv.astype(np.float64)
+        f[:, :256] /= hip.ATTN_Q_SCALE
+    spl = hip.split_spl32(_dev(qkv))                     # [rows][1536]
+    # the kernel sees hi + lo, not the f32 value: the reference uses exactly that
+    hi, lo = hip.spl32_planes(spl)
+    seen = hi.float().cpu().numpy().astype(np.float64) + lo.float().cpu().numpy()
+    if prescaled:
+        seen[:, :256] /= hip.ATTN_Q_SCALE
+    probs, off = [], 0
+    for nq, nk in sizes:
+        probs.append((off, nq, off + nq, nk))
+        off += nq + nk
+    out = torch.full((rows, 256), float("nan"), dtype=torch.float32, device="cuda")
+    pr = torch.tensor(probs, dtype=torch.int32, device="cuda")
+    hip.attention(spl, pr, max(s[0] for s in sizes), 4, out, q_prescaled=prescaled, x3=True)
+    o = out.cpu().numpy()
+    for qo, nq, ko, nk in probs:
+        q = seen[qo:qo + nq, 0:256].reshape(nq, 4, 64)
+        k = seen[ko:ko + nk, 256:512].reshape(nk, 4, 64)
+        v = seen[ko:ko + nk, 512:768].reshape(nk, 4, 64)
+        ref = _attn_ref(q, k, v).reshape(nq, 256)
+        err = np.abs(o[qo:qo + nq] - ref).max()
+        assert np.isfinite(o[qo:qo + nq]).all()
+        # logits carry |S| * 2^-17 of split error plus the f32 accumulation of 64 terms; probabilities inherit it
+        assert err < 1e-4 * max(1.0, sharp * sharp / 8) * max(1.0, np.abs(v).max() / 4), f"x3 attention err {err:.3e} (nq={nq}, nk={nk}, sharp={sharp})"
+        assert np.isnan(o[ko:ko + nk]).all()
+    osp = torch.zeros((rows, 512), dtype=torch.bfloat16, device="cuda")
+    hip.attention(spl, pr, max(s[0] for s in sizes), 4, None, out_split=osp, q_prescaled=prescaled, x3=True)
+    h2, l2 = hip.spl32_planes(osp)
+    rec = h2.float().cpu().numpy().astype(np.float64) + l2.float().cpu().numpy()
+    for qo, nq, ko, nk in probs:
+        assert (np.abs(rec[qo:qo + nq] - o[qo:qo + nq]) <= np.abs(o[qo:qo + nq]) * 2.0 ** -15 + 1e-30).all()
+
+
 @pytest.mark.parametrize("kernel", ["auto", "8", "8exact"])
 def test_attention_online_rescale(hip, monkeypatch, kernel):
     """Force the running max to jump at a later key tile (guide rule: the rare rescale branch needs its own test)."""
