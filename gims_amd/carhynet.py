@@ -277,3 +277,10 @@ class CARHyNet(nn.Module):
         with torch.no_grad():
             p = torch.from_numpy(np.ascontiguousarray(patches, dtype=np.float32)).to(dev)
             return self._forward_nhwc(p)[0].cpu().numpy()
+
+    def compute_sift(self, patches, kps, color=True):
+        """HyNetnetFeature2D.compute_sift (models.py:668-671): what utils.common.sift_forward calls on ``data['carhynet']``
+        (common.py:886) -- so an instance of this class can be handed to the reference's front end as its ``carhynet``."""
+        if len(kps) == 0:
+            return kps, []
+        return kps, self.compute_des_batches(patches, color).astype(np.float32)

@@ -280,7 +280,7 @@ extern "C" int gims_events_create(int32_t n, void** events_out) {
     hipEvent_t e = nullptr;
     const hipError_t rc = hipEventCreate(&e);
     if (rc != hipSuccess) {
-      for (int j = 0; j < i; ++j) hipEventDestroy((hipEvent_t)events_out[j]);
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy((hipEvent_t)events_out[j]);
       GIMS_HIP(rc);
     }
     events_out[i] = (void*)e;
@@ -319,11 +319,11 @@ extern "C" int gims_ops_graph_create(const gims_op* ops, int32_t n_ops, void* st
   const int rc = gims_run_ops(ops, n_ops, stream);
   hipGraph_t graph = nullptr;
   const hipError_t e = hipStreamEndCapture(s, &graph);
-  if (rc != GIMS_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+  if (rc != GIMS_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
   GIMS_HIP(e);
   hipGraphExec_t exec = nullptr;
   const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   GIMS_HIP(e2);
   *graph_exec_out = (void*)exec;
   return GIMS_OK;

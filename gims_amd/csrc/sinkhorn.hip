@@ -432,6 +432,71 @@ __global__ void ot_matrix_kernel(const float* __restrict__ z, int64_t ld, int n,
   out[(int64_t)i * (m + 1) + j] = ((zz + uv[i]) + uv[n + 1 + j]) - norm;
 }
 
+// ---------------------------------------------------------------------------------------------- training loss (forward)
+// forward_train's loss on top of the solved potentials (gmatcher.py:333-386): the (N+1)x(M+1) OT matrix is not materialised,
+// the ground-truth cells are gathered as (Z_ij + u_i) + v_j - norm.
+//   phase 1 (one thread per ground-truth row (b, i0, i1), ORIGINAL keypoint ids): remap through the sorted kept lists
+//   (gmatcher.py:340-367; binary search instead of the reference's dicts), a row whose i0 / i1 is -1 or was dropped by the
+//   adaptive graph becomes (b, -1, -1) -- which the reference's indexing reads as the CORNER cell scores[b, -1, -1] = OT[N, M]
+//   (gmatcher.py:372) -- and is a negative; clamp to [-100, 0], negate (373-376).
+//   phase 2 (one wave per batch element, fixed order): scatter_mean of the positive / negative losses by batch element
+//   (380), then the batch means times the weights (383-385).
+__device__ __forceinline__ int kept_find(const int32_t* kept, int n, int64_t orig) {
+  int lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int v = kept[mid];
+    if (v == orig) return mid;
+    if (v < orig) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+
+__global__ void train_loss_gather_kernel(const gims_loss_pair* __restrict__ pairs, int n_pairs, const int64_t* __restrict__ gt, int K,
+                                         float alpha, float* __restrict__ loss_vec, int32_t* __restrict__ tag) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int64_t b = gt[3 * k], i0 = gt[3 * k + 1], i1 = gt[3 * k + 2];
+  if (b < 0 || b >= n_pairs) { tag[k] = -1; loss_vec[k] = 0.f; return; }      // the reference would raise IndexError; ignored here
+  const gims_loss_pair p = pairs[b];
+  int r0 = -1, r1 = -1;
+  if (i0 != -1 && i1 != -1) {
+    r0 = kept_find(p.kept0, p.n, i0);
+    r1 = kept_find(p.kept1, p.m, i1);
+  }
+  const bool neg = r0 < 0 || r1 < 0;
+  const float norm = -logf((float)p.n + (float)p.m);
+  const float* u = p.uv;
+  const float* v = p.uv + p.n + 1;
+  float x = neg ? ((alpha + u[p.n]) + v[p.m]) - norm : ((p.scores[(int64_t)r0 * p.ld + r1] + u[r0]) + v[r1]) - norm;
+  x = fminf(fmaxf(x, -100.f), 0.f);
+  loss_vec[k] = -x;
+  tag[k] = (int32_t)b | (neg ? (int32_t)0x40000000 : 0);
+}
+
+__global__ __launch_bounds__(1024) void train_loss_reduce_kernel(const float* __restrict__ loss_vec, const int32_t* __restrict__ tag, int K,
+                                                                 int n_pairs, float pos_w, float neg_w, float* __restrict__ out3) {
+  __shared__ float pos_mean[1024], neg_mean[1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = wave; b < n_pairs; b += 16) {
+    float ps = 0.f, ns = 0.f, pc = 0.f, nc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const int32_t t = tag[k];
+      if (t < 0 || (t & 0x3fffffff) != b) continue;
+      if (t & 0x40000000) { ns += loss_vec[k]; nc += 1.f; } else { ps += loss_vec[k]; pc += 1.f; }
+    }
+    ps = wave_sum(ps); ns = wave_sum(ns); pc = wave_sum(pc); nc = wave_sum(nc);
+    if (lane == 0) { pos_mean[b] = ps / fmaxf(pc, 1.f); neg_mean[b] = ns / fmaxf(nc, 1.f); }   // scatter_mean: empty groups give 0
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ps = 0.f, ns = 0.f;
+    for (int b = 0; b < n_pairs; ++b) { ps += pos_mean[b]; ns += neg_mean[b]; }
+    const float pl = pos_w * (ps / (float)n_pairs), nl = neg_w * (ns / (float)n_pairs);
+    out3[0] = pl + nl; out3[1] = pl; out3[2] = nl;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- resident Sinkhorn
 // All iterations in ONE launch with the transport matrix held ON CHIP.  The streamed kernels above are pinned to the HBM
 // rate (one 4-byte read per matrix entry per iteration); here every workgroup (one per CU) keeps a slab of rows of
@@ -926,9 +991,100 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
     stamp(6);
   }
   if (PROF && blockIdx.x == 0 && threadIdx.x < 8) a.prof[threadIdx.x] = prof_acc[threadIdx.x];
+  // a bounded wait that ran out in the LAST iteration (or with iters == 1) falls out of the loop without passing the test
+  // at its top: test again before any potential is written, so that a timed-out solve can never leave with status 0
+  __syncthreads();
+  if (fail_flag) {
+    if (threadIdx.x == 0) p.status[0] = 2.f;
+    return;
+  }
   // ---------------- potentials out (the selection kernels read Z, u, v)
   for (int r = t; r < nrows; r += 512) p.u[row0 + r] = us[r];
   if (t < p.cpb && bk.slab * p.cpb + t <= p.m) p.v[bk.slab * p.cpb + t] = vfold;
+}
+
+// ---------------------------------------------------------------------------------------------- rescue
+// The on-chip kernel needs its 256 workgroups co-resident; when a bounded wait runs out (another process's kernels on the
+// GPU, a straggling workgroup) it leaves status 2 and no potentials.  This kernel is enqueued right after the resident
+// launches of every call and costs one empty launch when nothing happened: a workgroup looks at its problem's status word
+// and returns unless it is 2.  Otherwise it re-solves THAT problem, alone, with no cross-workgroup dependency at all
+// (one workgroup per problem walks the matrix twice per iteration: slow -- ~0.25 s for a 4096^2 problem -- but it cannot
+// stall, and the batch leaves with valid matches instead of -1s).  Same recurrence as the streamed kernels
+// (u = log mu - LSE_j(Z + v); v = log nu - LSE_i(Z + u), gmatcher.py:41-47), fixed summation order.
+__global__ __launch_bounds__(1024) void ot_rescue_kernel(const OtDev* __restrict__ probs, float alpha, int iters, int force) {
+  const OtDev p = probs[blockIdx.x];
+  if (!force && p.status[0] != 2.f) return;
+  __shared__ float wsum[16];
+  __shared__ int bad;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) bad = 0;
+  // start potentials like ot_init_kernel: u = -max(alpha, row max), v = 0
+  for (int j = t; j <= p.m; j += 1024) p.v[j] = 0.f;
+  for (int i = wave; i < p.n; i += 16) {
+    const float* zr = p.z + (int64_t)i * p.ld;
+    float mx = alpha;
+    for (int j = lane; j < p.m; j += 64) mx = fmaxf(mx, zr[j]);
+    mx = wave_max(mx);
+    if (lane == 0) p.u[i] = -mx;
+  }
+  if (t == 0) p.u[p.n] = -alpha;
+  __threadfence_block();
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    // ---- rows: one wave per row (coalesced along the row); the dustbin row is row n
+    const float vbin = p.v[p.m];
+    for (int i = wave; i <= p.n; i += 16) {
+      const float ui = p.u[i];
+      float sacc = 0.f;
+      if (i < p.n) {
+        const float* zr = p.z + (int64_t)i * p.ld;
+        for (int j = lane; j < p.m; j += 64) sacc += __expf(zr[j] + ui + p.v[j]);
+      } else {
+        for (int j = lane; j < p.m; j += 64) sacc += __expf(alpha + ui + p.v[j]);
+      }
+      sacc = wave_sum(sacc) + __expf(alpha + ui + vbin);
+      if (lane == 0) {
+        if (!(sacc > 0.f) || !(sacc < 3.0e38f)) bad = 1;
+        p.u[i] = ui + (i < p.n ? p.norm : p.log_mu_bin) - logf(sacc);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- columns: one thread per column (coalesced across the threads of a row visit); the dustbin column by wave 0 last
+    const float ubin = p.u[p.n];
+    for (int j = t; j < p.m; j += 1024) {
+      const float vj = p.v[j];
+      float sacc = 0.f;
+      for (int i = 0; i < p.n; ++i) sacc += __expf(p.z[(int64_t)i * p.ld + j] + p.u[i] + vj);
+      sacc += __expf(alpha + ubin + vj);
+      if (!(sacc > 0.f) || !(sacc < 3.0e38f)) bad = 1;
+      p.v[j] = vj + p.norm - logf(sacc);
+    }
+    {
+      float sacc = 0.f;
+      for (int i = t; i <= p.n; i += 1024) sacc += __expf(alpha + p.u[i] + vbin);
+      sacc = wave_sum(sacc);
+      if (lane == 0) wsum[wave] = sacc;
+      __syncthreads();
+      if (t == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        if (!(tot > 0.f) || !(tot < 3.0e38f)) bad = 1;
+        p.v[p.m] = vbin + p.log_nu_bin - logf(tot);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (t == 0) p.status[0] = bad ? 1.f : 0.f;
+}
+
+// test hook (GIMS_OT_FORCE_FAIL=1): what a timed-out resident solve leaves behind -- status 2 and garbage potentials
+__global__ void ot_poison_kernel(const OtDev* __restrict__ probs) {
+  const OtDev p = probs[blockIdx.x];
+  for (int i = threadIdx.x; i <= p.n; i += blockDim.x) p.u[i] = __uint_as_float(0x7fc00000u);
+  for (int j = threadIdx.x; j <= p.m; j += blockDim.x) p.v[j] = __uint_as_float(0x7fc00000u);
+  if (threadIdx.x == 0) p.status[0] = 2.f;
 }
 
 // ---- host side of the resident path: geometry, workspace, launches
@@ -1026,6 +1182,16 @@ static int ot_res_launch(OtResArgs a, hipStream_t s) {
     for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.0f;", names[i], (double)h[i] / a.iters);
     fprintf(stderr, "\n");
     return GIMS_OK;
+  }
+  // The kernel's workgroups wait on each other: a COOPERATIVE launch makes the runtime check that the whole grid fits in
+  // resident workgroup slots and dispatch it as one gang (a plain launch only assumes it).  GIMS_OT_COOP=0: plain launch.
+  if (ot_env("GIMS_OT_COOP", 1)) {
+    void* kargs[] = {(void*)&a};
+    const hipError_t e = hipLaunchCooperativeKernel((const void*)ot_resident_kernel<C, false>, dim3(256), dim3(512), kargs, (unsigned)lds, s);
+    if (e == hipSuccess) return GIMS_OK;
+    (void)hipGetLastError();
+    set_error("cooperative launch of the on-chip Sinkhorn kernel failed: %s", hipGetErrorString(e));
+    return GIMS_EHIP;
   }
   hipLaunchKernelGGL((ot_resident_kernel<C, false>), dim3(256), dim3(512), lds, s, a);
   GIMS_LAUNCH_CHECK();
@@ -1172,6 +1338,11 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   if (plan.ok) {      // whole iteration loop on chip (one launch per group of problems)
     const int rc = ot_res_run(plan, hprob, alpha, iters, base + off, s);
     if (rc != GIMS_OK) return rc;
+    const int force_fail = ot_env("GIMS_OT_FORCE_FAIL", 0);       // test hook: pretend every resident solve timed out
+    if (force_fail) hipLaunchKernelGGL(ot_poison_kernel, dim3(np), dim3(256), 0, s, dp);
+    // problems whose on-chip solve gave up (status 2) are re-solved here, before the selection kernels read u and v:
+    // an empty launch otherwise (see ot_rescue_kernel)
+    hipLaunchKernelGGL(ot_rescue_kernel, dim3(np), dim3(1024), 0, s, dp, alpha, iters, 0);
   }
   for (int it = 0; it < (plan.ok ? 0 : iters); ++it) {
     if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha);
@@ -1195,6 +1366,18 @@ extern "C" int gims_ot_matrix(const float* scores, int64_t ld, int32_t n, int32_
   GIMS_CHECK_ARG(scores && uv && out && n > 0 && m > 0, "gims_ot_matrix: bad arguments");
   hipLaunchKernelGGL(ot_matrix_kernel, dim3(cdiv(m + 1, 256), n + 1), dim3(256), 0, (hipStream_t)stream, scores, ld, n, m,
                      alpha, uv, out);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_train_loss(const gims_loss_pair* dev_pairs, int32_t n_pairs, const int64_t* gt, int32_t n_gt, float alpha,
+                               float pos_weight, float neg_weight, float* loss_vec, int32_t* tag, float* out3, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(dev_pairs && n_pairs > 0 && n_pairs <= 1024 && out3 && n_gt >= 0 && (n_gt == 0 || (gt && loss_vec && tag)),
+                 "gims_train_loss: bad arguments (1 <= n_pairs <= 1024)");
+  if (n_gt > 0) hipLaunchKernelGGL(train_loss_gather_kernel, dim3(cdiv(n_gt, 256)), dim3(256), 0, (hipStream_t)stream, dev_pairs, n_pairs, gt, n_gt, alpha,
+                                   loss_vec, tag);
+  hipLaunchKernelGGL(train_loss_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, loss_vec, tag, n_gt, n_pairs, pos_weight, neg_weight, out3);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

@@ -380,7 +380,6 @@ class GMatcher(nn.Module):
         ts0 = time.perf_counter()
         infos = info_all.cpu().numpy()                                                    # the one host sync of the build
         self._sync_ms = 1e3 * (time.perf_counter() - ts0)
-        self._check_pending_status()          # the previous batch's Sinkhorn status words are on the host side of this sync
         if infos[:, 7].any():
             raise hip.GimsHipError("adaptive graph exceeded the edge capacity (64 directed edges per node)")
         if (infos[:, 0] == 0).any():
@@ -579,13 +578,12 @@ class GMatcher(nn.Module):
             probs = hip.make_ot_problems(items)
             work = self._buf("ot", hip.sinkhorn_workspace_bytes(probs))
             self.sinkhorn_plan_last = hip.sinkhorn_plan(probs, cfg['sinkhorn_iterations'])   # 0 streamed / k resident launches
+            # (a resident solve that gives up -- status 2: its 256 workgroups were not co-resident, e.g. next to another
+            # process's kernels -- is re-solved inside this call by a dependency-free kernel before the selection runs, so the
+            # matches of THIS batch are valid when the call returns; see ot_rescue_kernel.  The status words stay readable:
+            # `sinkhorn_status()` after a synchronise.)
             hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
-            if self.sinkhorn_plan_last > 0:
-                # the on-chip kernel gives up (status 2, all matches -1) when it cannot get its 256 workgroups resident, e.g.
-                # next to another process's kernels; that must not pass silently: the worst status word of this batch is read
-                # at the next host sync (no extra sync here) and raises there
-                offs = np.cumsum([it["n"] + it["m"] + 3 for it in items]) - 1
-                self._pending_status = uv_all[hip.upload(offs.astype(np.int64), dev)].max()
+            self._status_offs = np.cumsum([it["n"] + it["m"] + 3 for it in items]) - 1
         # per-image views and graph handles: host-only bookkeeping, done after everything is enqueued
         for g in images:
             ro, nk = g["rows"]
@@ -625,20 +623,19 @@ class GMatcher(nn.Module):
         images[0]["_keep"] = keep
         return images
 
-    _pending_status = None
-
-    def _check_pending_status(self):
-        """Raises if the previous batch's resident Sinkhorn gave up; call only right after a host sync."""
-        st, self._pending_status = self._pending_status, None
-        if st is not None and float(st) == 2.0:
-            raise hip.GimsHipError("the on-chip Sinkhorn kernel could not get all its workgroups resident (is another process "
-                                   "using this GPU?): the matches of the previous batch are invalid; set GIMS_OT_RESIDENT=0")
+    def sinkhorn_status(self):
+        """Status word of every pair of the LAST batch of this lane (0 ok, 1 a marginal left the finite range -> that pair's
+        matches are all -1); synchronises.  Status 2 (on-chip solve gave up) never survives a call: it is rescued inside."""
+        uv = self._last["outputs"][4]
+        return uv[torch.from_numpy(self._status_offs).to(uv.device)].cpu().numpy()
 
     def _check_call(self, data, kwargs):
         if data.get('delaunay', False):
             raise NotImplementedError("delaunay=True is broken in the reference snapshot (UnboundLocalError, gmatcher.py:250)")
-        if kwargs.get('mode', 'test') == "train":
-            raise NotImplementedError("forward_train (gmatcher.py:309-386) is not on the HIP path yet")
+        if kwargs.get('mode', 'test') == "train" and self.training and not self.config['use_layernorm']:
+            raise NotImplementedError("mode='train' on a module in training mode needs batch-statistics BatchNorm and a backward "
+                                      "pass, which are not on the HIP path: the FORWARD loss (gmatcher.py:309-386) is available "
+                                      "with the module in eval() mode (running statistics)")
         if data['keypoints0'].device.type != "cuda":
             raise hip.GimsHipError("GMatcher runs on the GPU only (no CPU fallback): move the inputs to 'cuda'")
 
@@ -659,7 +656,10 @@ class GMatcher(nn.Module):
             data['scores' + side] = torch.stack([h.ndata['score'] for h in gs])
             data['kept_kpts%s_indices' % side] = [images[2 * b + s]["kept"].tolist() for b in range(B)]
             data['graph' + side] = gs
-        self._check_pending_status()          # .tolist() above synchronised: this batch's own status is readable now
+        if (self.sinkhorn_status() == 2.0).any():        # cannot happen (rescued inside gims_sinkhorn_match); never return silently wrong
+            raise hip.GimsHipError("the Sinkhorn solve of this batch gave up and was not rescued")
+        if kwargs.get('mode', 'test') == "train":        # gmatcher.py:254
+            return self._forward_train(data, images, items)
         md0 = torch.stack([mdesc[o0:o0 + n0] for (o0, n0), _ in pairs])
         md1 = torch.stack([mdesc[o1:o1 + n1] for _, (o1, n1) in pairs])
         return {
@@ -671,6 +671,20 @@ class GMatcher(nn.Module):
             'matching_scores1': torch.stack([it["mscores1"] for it in items]),
             'mdesc0': md0.squeeze(), 'mdesc1': md1.squeeze(),
         }
+
+    def _forward_train(self, data, images, items):
+        """Forward value of the reference's training loss (gmatcher.py:309-386) on the potentials the Sinkhorn kernels just
+        produced: kept-index remap of data['matches'] (340-367), gather of the OT log-scores at the ground-truth cells --
+        negatives read the corner cell OT[N, M], the reference's scores[b, -1, -1] (368-372) --, clamp, scatter_mean per
+        batch element, weights (373-385).  Returns (loss, pos_loss, neg_loss) as 0-dim tensors.  No autograd graph is
+        attached (no backward on the HIP path yet): calling .backward() on the result raises, it does not silently no-op."""
+        gt = data['matches']
+        dev = images[0]["kp"].device
+        gt = gt.to(device=dev, dtype=torch.int64).contiguous()
+        B = len(items)
+        out3, _ = hip.train_loss(items, [images[2 * b]["kept"] for b in range(B)], [images[2 * b + 1]["kept"] for b in range(B)], gt,
+                                 self._packed(dev)["alpha"], self.config['pos_loss_weight'], self.config['neg_loss_weight'])
+        return out3[0], out3[1], out3[2]
 
     # ------------------------------------------------------------------ ragged batch of independent pairs
     @torch.no_grad()

@@ -75,6 +75,11 @@ class OtProblem(C.Structure):
                 ("mscores1", C.c_void_p), ("uv", C.c_void_p)]
 
 
+class LossPair(C.Structure):
+    _fields_ = [("scores", C.c_void_p), ("ld", C.c_int64), ("n", C.c_int32), ("m", C.c_int32), ("uv", C.c_void_p),
+                ("kept0", C.c_void_p), ("kept1", C.c_void_p)]
+
+
 class EvalPair(C.Structure):
     _fields_ = [("kpts0", C.c_void_p), ("kpts1", C.c_void_p), ("matches0", C.c_void_p), ("mscores0", C.c_void_p),
                 ("n0", C.c_int32), ("n1", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("h_gt", C.c_float * 9),
@@ -148,6 +153,8 @@ _SIGNATURES = {
     "gims_eval_workspace_bytes": (C.c_size_t, [C.POINTER(EvalPair), C.c_int32, C.c_int32]),
     "gims_eval_pairs": (C.c_int, [C.POINTER(EvalPair), C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_uint64,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gims_train_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     "gims_ot_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
 }
@@ -717,3 +724,25 @@ def ch_l2norm(x, eps, y):
 def ch_relu6(x):
     _check(load().gims_ch_relu6(_p(_dev(x, torch.float32)), x.numel(), _stream()), "gims_ch_relu6")
     return x
+
+
+def train_loss(items, kept0, kept1, gt: torch.Tensor, alpha: float, pos_weight: float, neg_weight: float):
+    """forward_train's loss from the solved potentials (gims_train_loss).  items: the per-pair dicts given to make_ot_problems
+    (scores, n, m, uv); kept0 / kept1: per pair the int32 device tensors of kept original ids; gt: [K, 3] int64 device tensor
+    (b, i0, i1).  Returns (out3 f32 [3] = loss, pos, neg; per-row loss vector [K])."""
+    import numpy as np
+    dev = gt.device
+    assert gt.dtype == torch.int64 and gt.is_contiguous() and (gt.numel() == 0 or gt.shape[1] == 3)
+    B = len(items)
+    arr = (LossPair * B)()
+    for i, (it, k0, k1) in enumerate(zip(items, kept0, kept1)):
+        assert k0.dtype == torch.int32 and k1.dtype == torch.int32 and k0.numel() == it["n"] and k1.numel() == it["m"]
+        arr[i] = LossPair(_p(it["scores"]), it["scores"].stride(0), it["n"], it["m"], _p(it["uv"]), _p(k0), _p(k1))
+    tab = upload(np.frombuffer(bytes(arr), dtype=np.uint8), dev)
+    K = int(gt.shape[0])
+    loss_vec = torch.empty(max(K, 1), dtype=torch.float32, device=dev)
+    tag = torch.empty(max(K, 1), dtype=torch.int32, device=dev)
+    out3 = torch.empty(3, dtype=torch.float32, device=dev)
+    _check(load().gims_train_loss(_p(tab), B, _p(gt), K, float(alpha), float(pos_weight), float(neg_weight), _p(loss_vec), _p(tag), _p(out3),
+                                  _stream()), "gims_train_loss")
+    return out3, loss_vec[:K]

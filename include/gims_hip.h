@@ -288,8 +288,9 @@ int gims_pack_graphs(const gims_pack_image* dev_images /* DEVICE array */, int32
  * (one per image pair); `work` needs gims_sinkhorn_workspace_bytes(...) bytes.
  * Outputs per problem (device): matches0 [n] int64, matches1 [m] int64, mscores0 [n] f32, mscores1 [m]
  * f32, uv: u [n+1] then v [m+1] (log-potentials, so that OT = Z + u + v - norm can be rebuilt) then one
- * status word (0 = ok, 1 = a marginal left the finite range, 2 = the on-chip kernel could not get all its
- * workgroups resident and gave up: matches are then all -1).
+ * status word (0 = ok, 1 = a marginal left the finite range: matches are then all -1; 2 is transient: the on-chip
+ * kernel could not get all its workgroups resident and gave up -- the call then re-solves THAT problem with a
+ * dependency-free kernel before the selection runs (slow, rare), so a caller never sees 2 nor -1s caused by it).
  * Two implementations of the iteration loop (same recurrence, results agree to f32 rounding):
  *   streamed  -- one launch per iteration, Z read from HBM once per iteration (any size);
  *   resident  -- ONE launch for all iterations of a group of problems: exp(Z + u + v) is held in the registers and LDS
@@ -354,6 +355,22 @@ int gims_eval_pairs(const gims_eval_pair* h_pairs /* HOST array */, int32_t n_pa
 /* Rebuild the full (n+1)x(m+1) OT matrix Z + u + v - norm (gmatcher.py:47,68) -- for forward_train and tests. */
 int gims_ot_matrix(const float* scores, int64_t ld, int32_t n, int32_t m, float alpha, const float* uv,
                    float* out /* [(n+1)][(m+1)] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training loss of GMatcher.forward_train, forward value (gmatcher.py:333-386), from the solved potentials of
+ * gims_sinkhorn_match -- the OT matrix is not materialised.  Per batch element b: scores / ld / n / m / uv as in
+ * gims_ot_problem, kept0 / kept1 = the sorted ORIGINAL ids of the keypoints the adaptive graph kept (data['kept_kpts*_indices']).
+ * gt: [n_gt][3] int64 rows (b, i0, i1) in ORIGINAL keypoint ids, -1 = no partner (train.py:113-125).  A row is remapped
+ * through the kept lists (gmatcher.py:340-367); rows with a -1 or a dropped keypoint become (b, -1, -1), which the
+ * reference's tensor indexing reads as the corner cell OT[N, M] (gmatcher.py:372), and count as negatives.  Each gathered
+ * log-score is clamped to [-100, 0] and negated; positives and negatives are averaged per batch element (scatter_mean,
+ * empty groups give 0), then over the batch, and weighted: out3 = {loss, pos_weight * pos, neg_weight * neg}.
+ * loss_vec [n_gt] f32 and tag [n_gt] int32 are scratch (loss_vec holds the per-row losses afterwards).  Deterministic. */
+typedef struct gims_loss_pair {
+  const float* scores; int64_t ld; int32_t n, m; const float* uv; const int32_t* kept0; const int32_t* kept1;
+} gims_loss_pair;
+int gims_train_loss(const gims_loss_pair* dev_pairs /* DEVICE array */, int32_t n_pairs, const int64_t* gt, int32_t n_gt, float alpha,
+                    float pos_weight, float neg_weight, float* loss_vec, int32_t* tag, float* out3, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CAR-HyNet patch descriptor: the non-GEMM layers of carhynet/models.py:311-399.  Activations are NHWC

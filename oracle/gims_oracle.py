@@ -419,8 +419,37 @@ def select_matches(scores: torch.Tensor, match_threshold: float):
 
 # ============================================================================ GMatcher.forward
 
-def gmatcher_forward(sd, data: dict, config: dict | None = None, stages: dict | None = None) -> dict:
-    """gmatcher.py:219-307 (test mode, B == 1) on a state dict ``sd`` (NumPy arrays or tensors).
+def train_loss(ot: torch.Tensor, matches: torch.Tensor, kept0, kept1, batch_size: int, pos_w: float, neg_w: float):
+    """gmatcher.py:333-386 (forward_train after the Sinkhorn solve): ``ot`` (B, N+1, M+1) log-OT matrix, ``matches`` (K, 3)
+    int64 rows (b, i0, i1) in ORIGINAL keypoint ids, kept0/kept1 per batch element the sorted kept ids.  Restates the
+    remap (340-367), the negative-index gather that reads the corner cell for (b, -1, -1) rows (372), the clamp (374), and
+    ``torch_scatter.scatter_mean`` (380; third-party, absent from /root/reference and not installed: restated from its
+    documented semantics -- mean per index, 0 for empty groups -- PARITY UNPINNED for that call)."""
+    remap0 = [{int(o): i for i, o in enumerate(k)} for k in kept0]
+    remap1 = [{int(o): i for i, o in enumerate(k)} for k in kept1]
+    rows = []
+    for b, i0, i1 in matches.tolist():
+        if i0 == -1 or i1 == -1 or i0 not in remap0[b] or i1 not in remap1[b]:
+            rows.append([b, -1, -1])
+        else:
+            rows.append([b, remap0[b][i0], remap1[b][i1]])
+    gt = torch.tensor(rows, dtype=torch.long).reshape(-1, 3)
+    neg = (gt[:, 1] == -1) | (gt[:, 2] == -1)
+    vec = -torch.clamp(ot[gt[:, 0], gt[:, 1], gt[:, 2]], min=-100, max=0.0)
+
+    def scatter_mean(src, index):
+        out = torch.zeros(batch_size, dtype=src.dtype).index_add_(0, index, src)
+        cnt = torch.zeros(batch_size, dtype=src.dtype).index_add_(0, index, torch.ones_like(src))
+        return out / cnt.clamp(min=1)
+
+    pos_loss = pos_w * scatter_mean(vec[~neg], gt[:, 0][~neg]).mean()
+    neg_loss = neg_w * scatter_mean(vec[neg], gt[:, 0][neg]).mean()
+    return pos_loss + neg_loss, pos_loss, neg_loss
+
+
+def gmatcher_forward(sd, data: dict, config: dict | None = None, stages: dict | None = None, mode: str = "test"):
+    """gmatcher.py:219-307 (test mode) on a state dict ``sd`` (NumPy arrays or tensors); ``mode='train'`` returns the
+    forward value of forward_train's loss instead (gmatcher.py:254, 309-386; eval-mode BatchNorm).
 
     ``data`` holds torch tensors in the reference layout and is mutated in place exactly
     like the reference does (gmatcher.py:244-252).  ``stages`` (optional dict) receives intermediates.
@@ -472,6 +501,9 @@ def gmatcher_forward(sd, data: dict, config: dict | None = None, stages: dict | 
     scores = torch.einsum("bdn,bdm->bnm", mdesc0, mdesc1)
     scores = scores / cfg["descriptor_dim"] ** 0.5
     ot = log_optimal_transport(scores, _t(sd, "bin_score").float(), iters=cfg["sinkhorn_iterations"])
+    if mode == "train":
+        return train_loss(ot, data["matches"], data["kept_kpts0_indices"], data["kept_kpts1_indices"], data["image0"].shape[0],
+                          cfg["pos_loss_weight"], cfg["neg_loss_weight"])
     i0, i1, s0, s1 = select_matches(ot, cfg["match_threshold"])
     if stages is not None:
         stages.update(kn0=kn0, kn1=kn1, sage0=sage0, sage1=sage1, kenc0=ke0, kenc1=ke1, desc0_in=desc0,

@@ -41,3 +41,22 @@ def safe_rows(ot, thr, ref_matches0, ref_scores0, eps=1e-3):
     partner = np.where(r0 >= 0, r0, 0)
     safe &= (gap1[partner] > eps) | (r0 < 0)
     return safe
+
+
+def train_pairs(name, g):
+    """The synthetic pairs of a trainloss_* fixture (regenerated from seeds; the fixture stores only outputs)."""
+    from gims_amd import synth
+    return {"trainloss_n256_s1002_i100": lambda: [synth.make_pair(256, 1002)],
+            "trainloss_n1024_s1000_i100": lambda: [synth.make_pair(1024, 1000)],
+            "trainloss_n1024sparse_s2001_i20": lambda: [synth.make_pair(1024, 2001, canvas=(800, 600))],
+            "trainloss_b2_n64_s1000_i100": lambda: [synth.make_pair(64, 1000), synth.make_pair(64, 1000, desc_noise=0.2)]}[name]()
+
+
+def train_data(pairs, g, device="cpu"):
+    """Batch dict for mode='train' exactly as tools/gen_golden_train.py built it for the reference."""
+    datas = [pair_to_data(p, int(g["meta"][1]), int(g["meta"][2]), int(g["meta"][3]), device=device) for p in pairs]
+    data = {k: (torch.cat([d[k] for d in datas]) if torch.is_tensor(datas[0][k]) else datas[0][k]) for k in datas[0]}
+    data["image0"] = np.concatenate([p["image0"] for p in pairs])
+    data["image1"] = np.concatenate([p["image1"] for p in pairs])
+    data["matches"] = torch.from_numpy(g["matches"]).to(device)
+    return data

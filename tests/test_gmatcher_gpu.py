@@ -7,9 +7,9 @@ import numpy as np
 import pytest
 import torch
 
-from gims_amd import GMatcher, synth
+from gims_amd import GMatcher, Matching, synth
 from oracle import gims_oracle as O
-from tests.helpers import golden_names, load_golden, pair_to_data, safe_rows
+from tests.helpers import golden_names, load_golden, pair_to_data, safe_rows, train_data, train_pairs
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -346,3 +346,58 @@ def test_layernorm_kernel(models):
         hi, lo = hip.spl32_planes(osp)
         rec = hi.float().cpu().numpy().astype(np.float64) + lo.float().cpu().numpy()
         assert (np.abs(rec - out.cpu().numpy()) <= np.abs(out.cpu().numpy()) * 2.0 ** -15 + 1e-30).all()
+
+
+def test_matching_without_keypoints_through_a_front_end(synth_sd):
+    """The call eval_homography.py:177 makes -- image0 / image1 / carhynet / device and NO keypoints: Matching runs its front
+    end per image (here a stand-in for utils.common.sift_forward that returns the synthetic pair's tensors as one-element
+    lists, like sift_forward does) and returns {**front-end outputs, **GMatcher outputs} (models/matching.py:15-30):
+    the same matches as the call with keypoints."""
+    pair = synth.make_pair(256, 1002)
+    order = []
+
+    def front_end(d, device):
+        s = str(len(order))
+        order.append(d["image"].shape)
+        assert d["max_keypoints"] == -1 and d["carhynet"] == "the-net"
+        return {"keypoints": [torch.from_numpy(pair["keypoints" + s][0]).to(device)], "scores": [torch.from_numpy(pair["scores" + s][0]).to(device)],
+                "descriptors": [torch.from_numpy(pair["descriptors" + s][0]).to(device)]}
+
+    m = Matching({"front_end": front_end}).eval()
+    m.gmodel.load_state_dict(synth_sd)
+    dev = torch.device("cuda")
+    out = m({"image0": pair["image0"], "image1": pair["image1"], "carhynet": "the-net", "device": dev, "radius": 15, "percentile": 2, "min_size": 7})
+    assert len(order) == 2
+    ref = m(pair_to_data(pair, 15, 2, 7, device="cuda"))        # keypoints given: the front end is not called
+    assert len(order) == 2
+    for k in ("matches0", "matches1", "matching_scores0", "keypoints0", "descriptors1"):
+        assert torch.equal(out[k], ref[k]), k
+    assert isinstance(out["scores0"], list) and out["scores0"][0].shape == (256,)      # the front end's own entries are merged in
+    assert "scores0" not in ref
+
+
+@pytest.mark.parametrize("sinkhorn", ["streamed", "resident"])
+@pytest.mark.parametrize("name", golden_names("trainloss_"))
+def test_train_loss_forward_vs_reference_golden(synth_sd, monkeypatch, name, sinkhorn):
+    """mode='train' (train.py:136 -> gmatcher.py:254, 309-386), forward value: (loss, pos_loss, neg_loss) within 1e-4 of what the
+    reference returned for the same pairs / ground-truth rows / weights (module in eval mode: running-statistics BatchNorm)."""
+    monkeypatch.setenv("GIMS_OT_RESIDENT", "0" if sinkhorn == "streamed" else "2")
+    g = load_golden(name)
+    pairs = train_pairs(name, g)
+    m = GMatcher({"sinkhorn_iterations": int(g["meta"][4]), "pos_loss_weight": float(g["pos_loss_weight"]),
+                  "neg_loss_weight": float(g["neg_loss_weight"])}).eval()
+    m.load_state_dict(synth_sd)
+    data = train_data(pairs, g, device="cuda")
+    loss, pos, neg = m(data, mode="train")
+    assert loss.dim() == 0 and loss.dtype == torch.float32
+    for b in range(len(pairs)):
+        np.testing.assert_array_equal(np.asarray(data["kept_kpts0_indices"][b]), g[f"kept0_{b}"])
+    got = [float(loss), float(pos), float(neg)]
+    print(name, sinkhorn, got, [float(g["loss"]), float(g["pos"]), float(g["neg"])])
+    np.testing.assert_allclose(got, [g["loss"], g["pos"], g["neg"]], atol=1e-4, rtol=0)
+    m2 = GMatcher({"sinkhorn_iterations": 5}).eval()
+    m2.load_state_dict(synth_sd)
+    with pytest.raises(KeyError):                     # like the reference: the loss weights have no default (gmatcher.py:383)
+        m2(train_data(pairs, g, device="cuda"), mode="train")
+    with pytest.raises(NotImplementedError):          # training-mode BatchNorm (batch statistics) is not on the HIP path
+        m.train()(train_data(pairs, g, device="cuda"), mode="train")

@@ -489,6 +489,42 @@ def test_sinkhorn_resident_matches_streamed(hip, monkeypatch):
         assert float((a["mscores0"] - b["mscores0"]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("coop", ["1", "0"])
+def test_sinkhorn_resident_giveup_is_rescued(hip, monkeypatch, coop):
+    """A resident solve that gives up (status 2, garbage potentials -- forced here by GIMS_OT_FORCE_FAIL=1, which poisons
+    u, v and the status word after the on-chip launches) is re-solved INSIDE the same call by the dependency-free rescue
+    kernel: the caller gets status 0, the streamed path's potentials (f32 rounding) and exactly its matches -- never -1s."""
+    gg = torch.Generator(device="cpu").manual_seed(11)
+    zs = []
+    for n, m in ((700, 650), (300, 333), (1022, 1024), (64, 31)):
+        z = torch.zeros((n, (m + 3) // 4 * 4))
+        z[:, :m] = torch.randn(n, m, generator=gg) * 4
+        k = min(n, m)
+        z[torch.arange(k), torch.randperm(m, generator=gg)[:k]] += 15.0
+        zs.append((n, m, z))
+    outs = {}
+    for mode, fail in (("0", "0"), ("2", "1")):
+        monkeypatch.setenv("GIMS_OT_RESIDENT", mode)
+        monkeypatch.setenv("GIMS_OT_FORCE_FAIL", fail)
+        monkeypatch.setenv("GIMS_OT_COOP", coop)
+        items = [dict(scores=z.cuda(), n=n, m=m, matches0=torch.empty(n, dtype=torch.int64, device="cuda"),
+                      matches1=torch.empty(m, dtype=torch.int64, device="cuda"), mscores0=torch.empty(n, device="cuda"),
+                      mscores1=torch.empty(m, device="cuda"), uv=torch.empty(n + m + 3, device="cuda")) for n, m, z in zs]
+        probs = hip.make_ot_problems(items)
+        if mode == "2":
+            assert hip.sinkhorn_plan(probs, 30) > 0
+        work = torch.empty(hip.sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device="cuda")
+        hip.sinkhorn_match(probs, 1.0, 30, 0.2, work)
+        outs[mode] = items
+    for a, b in zip(outs["0"], outs["2"]):
+        assert float(b["uv"][-1]) == 0.0
+        assert torch.isfinite(b["uv"]).all()
+        assert float((a["uv"][:-1] - b["uv"][:-1]).abs().max()) < 1e-4
+        assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches1"], b["matches1"])
+        assert int((b["matches0"] >= 0).sum()) > 0
+        assert float((a["mscores0"] - b["mscores0"]).abs().max()) < 1e-5
+
+
 # --------------------------------------------------------------------------------------------- small kernels
 def test_sage_mean_and_gather(hip):
     r = _rng(3)

@@ -80,6 +80,27 @@ def test_no_cpu_fallback_and_matching_shell():
         m({"image0": pair["image0"], "image1": pair["image1"]})
 
 
+def test_matching_front_end_hook_is_called_like_sift_forward():
+    """Without keypoints, Matching calls its front end once per image with the reference's argument dict
+    (models/matching.py:17-24) and feeds the stacked lists to GMatcher (which then refuses CPU tensors: no fallback)."""
+    pair = synth.make_pair(64, 1000)
+    calls = []
+
+    def fake_front_end(d, device):
+        calls.append((d["image"].shape, d["max_keypoints"], d["carhynet"], device))
+        s = "0" if len(calls) == 1 else "1"
+        return {"keypoints": [torch.from_numpy(pair["keypoints" + s][0])], "scores": [torch.from_numpy(pair["scores" + s][0])],
+                "descriptors": [torch.from_numpy(pair["descriptors" + s][0])]}
+
+    m = Matching({"front_end": fake_front_end, "max_keypoints": 77})
+    with pytest.raises(hip.GimsHipError):
+        m({"image0": pair["image0"], "image1": pair["image1"], "carhynet": "net", "device": "cpu"})
+    assert calls == [(pair["image0"].shape, 77, "net", "cpu"), (pair["image1"].shape, 77, "net", "cpu")]
+    assert "front_end" not in m.gmodel.config
+    with pytest.raises(TypeError):
+        Matching({"front_end": 3})
+
+
 def test_product_code_never_imports_the_oracle():
     for root, _, files in os.walk(os.path.join(ROOT, "gims_amd")):
         for f in files:

@@ -6,7 +6,7 @@ import torch
 
 from gims_amd import synth
 from oracle import gims_oracle as O
-from tests.helpers import golden_names, load_golden, pair_to_data
+from tests.helpers import golden_names, load_golden, pair_to_data, train_data, train_pairs
 
 torch.set_grad_enabled(False)
 
@@ -129,3 +129,16 @@ def test_e2e_layernorm(name):
     np.testing.assert_array_equal(out["matches1"][0].numpy(), g["out/matches1"])
     np.testing.assert_allclose(out["matching_scores0"][0].numpy(), g["out/matching_scores0"], atol=5e-5)
     np.testing.assert_allclose(out["matching_scores1"][0].numpy(), g["out/matching_scores1"], atol=5e-5)
+
+
+@pytest.mark.parametrize("name", golden_names("trainloss_"))
+def test_train_loss_forward_vs_reference(synth_sd, name):
+    """Forward value of forward_train's loss (gmatcher.py:309-386, module in eval mode): oracle == reference."""
+    g = load_golden(name)
+    pairs = train_pairs(name, g)
+    data = train_data(pairs, g)
+    cfg = {"sinkhorn_iterations": int(g["meta"][4]), "pos_loss_weight": float(g["pos_loss_weight"]), "neg_loss_weight": float(g["neg_loss_weight"])}
+    loss, pos, neg = O.gmatcher_forward(synth_sd, data, cfg, mode="train")
+    for b in range(len(pairs)):
+        np.testing.assert_array_equal(np.asarray(data["kept_kpts0_indices"][b]), g[f"kept0_{b}"])
+    np.testing.assert_allclose([float(loss), float(pos), float(neg)], [g["loss"], g["pos"], g["neg"]], atol=2e-5, rtol=1e-5)
