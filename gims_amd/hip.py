@@ -75,6 +75,10 @@ class OtProblem(C.Structure):
                 ("mscores1", C.c_void_p), ("uv", C.c_void_p)]
 
 
+class PyrLevel(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("h", C.c_int32), ("w", C.c_int32)]
+
+
 class LossPair(C.Structure):
     _fields_ = [("scores", C.c_void_p), ("ld", C.c_int64), ("n", C.c_int32), ("m", C.c_int32), ("uv", C.c_void_p),
                 ("kept0", C.c_void_p), ("kept1", C.c_void_p)]
@@ -153,6 +157,10 @@ _SIGNATURES = {
     "gims_eval_workspace_bytes": (C.c_size_t, [C.POINTER(EvalPair), C.c_int32, C.c_int32]),
     "gims_eval_pairs": (C.c_int, [C.POINTER(EvalPair), C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_uint64,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gims_pyramid_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_size_t)]),
+    "gims_pyramid_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gims_patch_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gims_train_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "gims_ot_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
@@ -746,3 +754,35 @@ def train_loss(items, kept0, kept1, gt: torch.Tensor, alpha: float, pos_weight: 
     _check(load().gims_train_loss(_p(tab), B, _p(gt), K, float(alpha), float(pos_weight), float(neg_weight), _p(loss_vec), _p(tag), _p(out3),
                                   _stream()), "gims_train_loss")
     return out3, loss_vec[:K]
+
+
+def pyramid_layout(h: int, w: int, c: int = 3):
+    """(levels [(offset, h, w)], pyramid bytes, scratch bytes) of gims_pyramid_layout."""
+    n, pb, sb = C.c_int32(), C.c_size_t(), C.c_size_t()
+    _check(load().gims_pyramid_layout(h, w, c, None, 0, C.byref(n), C.byref(pb), C.byref(sb)), "gims_pyramid_layout")
+    arr = (PyrLevel * n.value)()
+    _check(load().gims_pyramid_layout(h, w, c, arr, n.value, C.byref(n), C.byref(pb), C.byref(sb)), "gims_pyramid_layout")
+    return arr, int(pb.value), int(sb.value)
+
+
+def pyramid_build(img: torch.Tensor):
+    """img uint8 [H, W, 3] on the device -> (pyramid buffer uint8, ctypes level table, device level table)."""
+    import numpy as np
+    assert img.dtype == torch.uint8 and img.is_cuda and img.dim() == 3 and img.is_contiguous()
+    h, w, c = img.shape
+    levels, pb, sb = pyramid_layout(h, w, c)
+    pyr = torch.empty(pb, dtype=torch.uint8, device=img.device)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=img.device)
+    _check(load().gims_pyramid_build(_p(img), h, w, c, _p(pyr), _p(scratch), _stream()), "gims_pyramid_build")
+    dev_levels = upload(np.frombuffer(bytes(levels), dtype=np.uint8), img.device)
+    return pyr, levels, dev_levels
+
+
+def patch_extract(pyr: torch.Tensor, dev_levels: torch.Tensor, n_levels: int, kp4: torch.Tensor, kp_octave: torch.Tensor):
+    """kp4 f32 [N, 4] (x, y, size, angle), kp_octave int32 [N] on the device -> (patches f32 [N, 32, 32, 3], bad-count tensor)."""
+    assert kp4.dtype == torch.float32 and kp_octave.dtype == torch.int32 and kp4.is_contiguous() and kp4.is_cuda and kp_octave.is_cuda
+    n = int(kp4.shape[0])
+    out = torch.empty((n, 32, 32, 3), dtype=torch.float32, device=pyr.device)
+    bad = torch.empty(1, dtype=torch.int32, device=pyr.device)
+    _check(load().gims_patch_extract(_p(pyr), _p(dev_levels), n_levels, _p(kp4), _p(kp_octave), n, _p(out), _p(bad), _stream()), "gims_patch_extract")
+    return out, bad

@@ -422,6 +422,29 @@ int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, int32_t c, co
 int gims_ch_l2norm(const float* x, int64_t rows, int32_t c, float eps, float* y, void* stream);
 int gims_ch_relu6(float* x, int64_t total, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Patch extraction: the front-end stage between keypoint detection and CAR-HyNet,
+ *   buildGaussianPyramid(img, 6, graydesc=False)  (utils/library.py:234-271)
+ *   ComputePatches(k, pyramid, radius_size=64)    (utils/library.py:84-110)
+ *   cv2.resize(p, (32, 32), INTER_AREA) / 255.0   (utils/common.py:884)
+ * on uint8 HWC images, in OpenCV's uint8 fixed-point arithmetic as restated in gims_amd/csrc/patches.hip (PARITY UNPINNED
+ * against OpenCV itself, which is not available here; bit-identical to oracle/patch_oracle.py).
+ * gims_pyramid_layout: number of levels (nOctaves * 6), per-level {byte offset, h, w} inside ONE buffer of *pyr_bytes, and
+ *   the scratch bytes gims_pyramid_build needs.  h_levels may be NULL to query the sizes only.
+ * gims_pyramid_build: img [h][w][c] uint8 (device) -> pyr (device).  Level o*6+i: octave o, layer i; level 0 is the 2x
+ *   INTER_LINEAR_EXACT upsampling of img, layer 0 of octave o > 0 the INTER_NEAREST halving of level (o-1)*6+3, every other
+ *   level the uint8 GaussianBlur of its predecessor.
+ * gims_patch_extract: kp4 [n][4] f32 = (x, y, size, angle) and kp_octave [n] int32 = cv2.KeyPoint.octave (packed octave /
+ *   layer, utils/library.py:16-35), all on the device.  out [n][32][32][3] f32 in [0, 1] (NHWC: the input layout of the
+ *   CAR-HyNet kernels).  *bad_count (device int32) = keypoints whose octave / layer lie outside the pyramid (zero patches;
+ *   the reference would raise IndexError).  c must be 3. */
+typedef struct gims_pyr_level { int64_t offset; int32_t h, w; } gims_pyr_level;
+int gims_pyramid_layout(int32_t h, int32_t w, int32_t c, gims_pyr_level* h_levels /* HOST, may be NULL */, int32_t capacity, int32_t* n_levels,
+                        size_t* pyr_bytes, size_t* scratch_bytes);
+int gims_pyramid_build(const uint8_t* img, int32_t h, int32_t w, int32_t c, uint8_t* pyr, void* scratch, void* stream);
+int gims_patch_extract(const uint8_t* pyr, const gims_pyr_level* dev_levels, int32_t n_levels, const float* kp4, const int32_t* kp_octave,
+                       int32_t n_kp, float* out, int32_t* bad_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
