@@ -127,13 +127,12 @@ def test_patches_descriptors_matcher_chain_vs_chained_oracles(synth_sd):
         data[f"keypoints{s}"] = torch.tensor([[k.pt for k in kps]], dtype=torch.float32)
         data[f"scores{s}"] = torch.tensor([[k.response for k in kps]], dtype=torch.float32)
         data[f"descriptors{s}"] = torch.cat([d, d], 1).permute(1, 0)[None].contiguous()
-        got = out[f"descriptors{s}"] if False else None
     # descriptors of the HIP chain (before the adaptive graph filtered them) against the oracle chain: same bar as f1
     hip_d0 = frontend.sift_forward_device({"image": img0[None], "carhynet": net, "max_keypoints": -1}, dev, detector=lambda img: kps0)["descriptors"][0]
     np.testing.assert_allclose(hip_d0[:128].t().cpu().numpy(), descs[0].numpy(), atol=3e-5, rtol=0)
     st = {}
     ref = O.gmatcher_forward(synth_sd, data, {}, stages=st)
-    assert out["keypoints0"].shape[1] == ref["keypoints0"].shape[1] and out["keypoints1"].shape[1] == ref["keypoints1"].shape[1], \\
+    assert out["keypoints0"].shape[1] == ref["keypoints0"].shape[1] and out["keypoints1"].shape[1] == ref["keypoints1"].shape[1], \
         "the adaptive graph kept different keypoints (descriptor drift moved an edge across the percentile threshold)"
     np.testing.assert_array_equal(out["keypoints0"].cpu().numpy(), ref["keypoints0"].numpy())
     r0 = ref["matches0"][0].numpy()
