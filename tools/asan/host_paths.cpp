@@ -1,0 +1,90 @@
+// Host-side AddressSanitizer harness ("compile-time -fsanitize=address for host C++").  CPU container
+// only -- never on the GPU pool.  The library's HOST code (argument validation, workspace / plan / layout arithmetic, table
+// builders, error strings, the replay loop) is compiled with -fsanitize=address (device code untouched: -fno-gpu-sanitize)
+// and driven through every entry point that can run without a GPU: calls either return before touching HIP (GIMS_EINVAL,
+// size queries) or fail cleanly inside the runtime (GIMS_EHIP: no device here).  ASan aborts on any heap / stack / global
+// overflow, use-after-free or leak it sees on the way.    Build + run: tools/asan/run.sh
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/gims_hip.h"
+
+static int checks = 0;
+#define EXPECT(cond) do { ++checks; if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s  (last error: %s)\n", __FILE__, __LINE__, #cond, gims_last_error()); exit(1); } } while (0)
+
+int main() {
+  EXPECT(gims_abi_version() == GIMS_ABI_VERSION);
+  // ---- Sinkhorn: size / plan arithmetic over ragged problem lists (host vectors, per-problem loops)
+  std::vector<gims_ot_problem> pr;
+  for (int i = 0; i < 40; ++i) {
+    gims_ot_problem q; memset(&q, 0, sizeof(q));
+    q.n = 600 + 7 * i; q.m = 640 - 5 * i; q.ld = (q.m + 3) / 4 * 4;
+    pr.push_back(q);
+  }
+  EXPECT(gims_sinkhorn_workspace_bytes(pr.data(), (int)pr.size()) > 0);
+  EXPECT(gims_sinkhorn_workspace_bytes(nullptr, 3) == 0);
+  EXPECT(gims_sinkhorn_plan(pr.data(), (int)pr.size(), 100) >= 0);
+  for (int n : {1, 31, 1024, 4096, 5000, 16384}) {
+    gims_ot_problem q; memset(&q, 0, sizeof(q)); q.n = n; q.m = n; q.ld = (n + 3) / 4 * 4;
+    EXPECT(gims_sinkhorn_workspace_bytes(&q, 1) > 0);
+    EXPECT(gims_sinkhorn_plan(&q, 1, 100) >= 0);
+  }
+  EXPECT(gims_sinkhorn_match(nullptr, 1, 1.f, 10, 0.2f, nullptr, 0, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_sinkhorn_match(pr.data(), (int)pr.size(), 1.f, -1, 0.2f, (void*)0x1000, 1 << 20, nullptr) == GIMS_EINVAL);
+  EXPECT(strlen(gims_last_error()) > 0);
+  // ---- adaptive graph: workspace arithmetic, validation
+  std::vector<gims_agc_image> im(5);
+  for (size_t i = 0; i < im.size(); ++i) { memset(&im[i], 0, sizeof(im[i])); im[i].n = 100 + 900 * (int)i; im[i].d = 256; im[i].ldd = 256; im[i].max_edges_dir = 64 * im[i].n; }
+  EXPECT(gims_agc_workspace_bytes(im.data(), (int)im.size()) > 0);
+  EXPECT(gims_agc_build(nullptr, 0, 15.0, 2.0, 7, nullptr, 0, nullptr) != GIMS_OK);
+  // ---- evaluation: workspace arithmetic
+  std::vector<gims_eval_pair> ep(3);
+  for (size_t i = 0; i < ep.size(); ++i) { memset(&ep[i], 0, sizeof(ep[i])); ep[i].n0 = 500 + (int)i; ep[i].n1 = 400; ep[i].height = 480; ep[i].width = 640; }
+  EXPECT(gims_eval_workspace_bytes(ep.data(), (int)ep.size(), 2000) > 0);
+  EXPECT(gims_eval_pairs(nullptr, 0, 3.f, 3, 3.f, 100, 1, nullptr, 0, nullptr) != GIMS_OK);
+  // ---- pyramid layout (host loops over octaves / levels, caller-provided table with exact and short capacity)
+  int32_t nl = 0; size_t pb = 0, sb = 0;
+  EXPECT(gims_pyramid_layout(480, 640, 3, nullptr, 0, &nl, &pb, &sb) == GIMS_OK && nl > 0 && nl % 6 == 0 && pb > 0 && sb > 0);
+  std::vector<gims_pyr_level> lv(nl);
+  EXPECT(gims_pyramid_layout(480, 640, 3, lv.data(), nl, &nl, &pb, &sb) == GIMS_OK);
+  EXPECT(lv[0].h == 960 && lv[0].w == 1280 && lv[6].h == 480 && (size_t)lv[nl - 1].offset < pb);
+  EXPECT(gims_pyramid_layout(480, 640, 3, lv.data(), nl - 1, &nl, &pb, &sb) == GIMS_EINVAL);
+  EXPECT(gims_pyramid_layout(0, 640, 3, nullptr, 0, &nl, &pb, &sb) == GIMS_EINVAL);
+  for (int h : {1, 2, 3, 7, 33, 75, 1201}) {          // tiny images have no octave at all: a clean GIMS_EINVAL
+    const int rc = gims_pyramid_layout(h, 2 * h + 1, 3, nullptr, 0, &nl, &pb, &sb);
+    EXPECT(rc == GIMS_OK || (h < 3 && rc == GIMS_EINVAL));
+  }
+  EXPECT(gims_pyramid_build(nullptr, 10, 10, 3, nullptr, nullptr, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_patch_extract(nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr) == GIMS_EINVAL);
+  // ---- replay loop: empty table, unknown op kind, a linear op that fails validation
+  EXPECT(gims_run_ops(nullptr, 0, nullptr) == GIMS_EINVAL);
+  std::vector<gims_op> ops(3);
+  memset(ops.data(), 0, sizeof(gims_op) * ops.size());
+  EXPECT(gims_run_ops(ops.data(), 0, nullptr) == GIMS_OK);
+  ops[0].kind = 7;
+  EXPECT(gims_run_ops(ops.data(), 1, nullptr) == GIMS_EINVAL);
+  ops[0].kind = GIMS_OP_LINEAR;                       // all-null linear arguments
+  EXPECT(gims_run_ops(ops.data(), 3, nullptr) != GIMS_OK);
+  ops[0].kind = GIMS_OP_ATTENTION;
+  EXPECT(gims_run_ops(ops.data(), 3, nullptr) != GIMS_OK);
+  EXPECT(gims_run_ops_timed(ops.data(), 1, nullptr, nullptr) == GIMS_EINVAL);
+  // ---- validation of the remaining entry points (every call returns before touching memory it was not given)
+  gims_linear_args la; memset(&la, 0, sizeof(la));
+  EXPECT(gims_linear(&la, nullptr) != GIMS_OK);
+  EXPECT(gims_linear(nullptr, nullptr) != GIMS_OK);
+  EXPECT(gims_linear_batch(nullptr, 0, 0, 0, GIMS_PREC_F32, nullptr) != GIMS_OK);
+  EXPECT(gims_attention(nullptr, 0, 0, 0, 0, nullptr, 0, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_train_loss(nullptr, 0, nullptr, 0, 1.f, 0.45f, 1.f, nullptr, nullptr, nullptr, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_ingest_images(nullptr, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_pack_graphs(nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_events_create(0, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_ops_graph_create(nullptr, 0, nullptr, nullptr) == GIMS_EINVAL);
+  // ---- a call that reaches the HIP runtime: no device in this container -> a clean GIMS_EHIP / error string, no crash
+  char host_table[64] = {0};
+  const int rc = gims_upload_table(host_table, sizeof(host_table), (void*)0x1000, nullptr);
+  EXPECT(rc == GIMS_OK || rc == GIMS_EHIP || rc == GIMS_EINVAL);
+  printf("asan host harness: %d checks passed\n", checks);
+  return 0;
+}
