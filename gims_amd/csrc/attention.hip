@@ -775,6 +775,217 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------- split-key variant (small launches)
+// One image pair through the reference-shaped forward() (B = 1) gives a launch of 2 problems x 4 heads: with 32 queries per
+// wave that is ONE wave per SIMD at 4096 keypoints (and a quarter of the chip at 1024) -- every wave then sits out its own
+// LDS and global latencies.  Here a workgroup is eight waves over the same 128 queries: waves 0-3 walk the even half of the
+// key tiles, waves 4-7 the other half (own K / V^T staging buffers), and the two partial results (unnormalised O, running
+// maximum, row sum) are merged through LDS at the end -- the flash-decoding split, inside one workgroup: no workspace, no
+// second launch.  Same math and layouts as attention_bf16_kernel<1>.
+__global__ __launch_bounds__(512) void attention_split_kernel(
+    const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
+    const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t sp_lds[];
+  // [half][buffer]: K tiles, then V^T tiles
+  auto Ks = [&](int hf, int buf) __attribute__((always_inline)) { return sp_lds + (hf * 2 + buf) * (KB * DH); };
+  auto Vt = [&](int hf, int buf) __attribute__((always_inline)) { return sp_lds + 4 * (KB * DH) + (hf * 2 + buf) * (DH * VT_LD); };
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int group = (slot / n_qt) * 8 + xcd;
+  if (group >= n_groups) return;
+  const gims_attn_problem pr = problems[group / n_heads];
+  const int q0 = (slot % n_qt) * QB;
+  if (q0 >= pr.n_q) return;
+  const int head = group % n_heads;
+  const int tt = threadIdx.x, lane = tt & 63;
+  const int half = __builtin_amdgcn_readfirstlane(tt >> 8), wave = (tt >> 6) & 3, t = tt & 255;
+  const int li = lane & 31, lh = lane >> 5;
+
+  bf16x8 qf[4];
+  {
+    int qr = q0 + wave * QW + li;
+    qr = qr < pr.n_q ? qr : pr.n_q - 1;
+    const uint16_t* qp = qkv + (int64_t)(pr.q_off + qr) * ld + q_col + head * DH + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  constexpr float DEFER = 5.0f;
+  const float defer_raw = DEFER / c;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int n_tiles = (pr.n_kv + KB - 1) / KB;
+  const int n_mine = (n_tiles - half + 1) / 2;            // tiles half, half + 2, ...
+  const int n_iter = (n_tiles + 1) / 2;                   // both halves pass the same number of barriers
+  uint4 rk[2], rv[2];
+  const int vkp = t & 31, voct = t >> 5;
+  auto load_tile = [&](int it) __attribute__((always_inline)) {
+    const int kbase = (2 * it + half) * KB;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int f = t + 256 * e, row = f >> 3, ch = f & 7;
+      int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      rk[e] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * ch);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      rv[e] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * voct);
+    }
+  };
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int f = t + 256 * e, row = f >> 3, ch = f & 7;
+      *(uint4*)(Ks(half, buf) + k_off(row, ch)) = rk[e];
+    }
+    const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
+    const uint32_t b[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
+      const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
+      *(uint32_t*)(Vt(half, buf) + (8 * voct + 2 * j) * VT_LD + 2 * vkp) = lo;
+      *(uint32_t*)(Vt(half, buf) + (8 * voct + 2 * j + 1) * VT_LD + 2 * vkp) = hi;
+    }
+  };
+
+  if (n_mine > 0) { load_tile(0); store_tile(0); }
+  __syncthreads();
+  for (int it = 0; it < n_iter; ++it) {
+    const int buf = it & 1;
+    const bool live = it < n_mine;
+    if (it + 1 < n_mine) load_tile(it + 1);
+    if (live) {
+      f32x16 sacc[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 kf = *(const bf16x8*)(Ks(half, buf) + k_off(b * 32 + li, 2 * s + lh));
+          sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[b], 0, 0, 0);
+        }
+      const int kbase = (2 * it + half) * KB;
+      if (kbase + KB > pr.n_kv) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kbase + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (key >= pr.n_kv) sacc[b][r] = -1e30f;
+          }
+      }
+      float tmax = -1e30f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      if (__any(tmax > m_run + defer_raw)) {
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
+      const float mc = m_run * c;
+      bf16x8 pf[4];
+      float lsum = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[b][r], c, -mc));
+          lsum += pv[r];
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          uint4 pk;
+          pk.x = pack_bf2(pv[8 * h2 + 0], pv[8 * h2 + 1]);
+          pk.y = pack_bf2(pv[8 * h2 + 2], pv[8 * h2 + 3]);
+          pk.z = pack_bf2(pv[8 * h2 + 4], pv[8 * h2 + 5]);
+          pk.w = pack_bf2(pv[8 * h2 + 6], pv[8 * h2 + 7]);
+          pf[2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
+        }
+      }
+      l_run += lsum;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint16_t* vp = Vt(half, buf) + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
+          const uint2 v0 = *(const uint2*)(vp);
+          const uint2 v1 = *(const uint2*)(vp + 8);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o[i], 0, 0, 0);
+        }
+    }
+    if (it + 1 < n_mine) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- merge the two halves: half 1 hands (O, m, l) to half 0 through LDS (the staging buffers are idle now)
+  float* xo = (float*)sp_lds;                            // [4 waves][32 regs][64 lanes]
+  float* xm = xo + 4 * 32 * 64;                          // [4 waves][2][64 lanes]
+  if (half == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xo[(wave * 32 + i * 16 + r) * 64 + lane] = o[i][r];
+    xm[(wave * 2 + 0) * 64 + lane] = m_run;
+    xm[(wave * 2 + 1) * 64 + lane] = l_run;
+  }
+  __syncthreads();
+  if (half == 1) return;
+  {
+    const float m1 = xm[(wave * 2 + 0) * 64 + lane], l1 = xm[(wave * 2 + 1) * 64 + lane];
+    // m_run is wave-uniform per query COLUMN only up to the lane^32 partner (both lanes of a column hold the same value)
+    const float m_new = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f((m_run - m_new) * c), a1 = __builtin_amdgcn_exp2f((m1 - m_new) * c);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + xo[(wave * 32 + i * 16 + r) * 64 + lane] * a1;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  const int qr = q0 + wave * QW + li;
+  if (qr < pr.n_q) {
+    const int64_t grow = pr.q_off + qr;
+    const int col0 = head * DH + 4 * lh;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = make_float4(o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+        const int col = col0 + 32 * i + 8 * g;
+        if (out) *(float4*)(out + grow * ld_out + col) = v;
+        if (out_hi) {
+          const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
+          const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+          const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+          *(uint2*)(out_hi + grow * ld_split + spl_col(col)) = make_uint2(h01, h23);
+          *(uint2*)(out_lo + grow * ld_split + spl_col(col)) = make_uint2(l01, l23);
+        }
+      }
+  }
+}
+constexpr int SPLIT_LDS_BYTES = 2 * 2 * (KB * DH + DH * VT_LD) * 2;     // >= the 34 KB of the merge exchange
+
 }  // namespace gims
 
 extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
@@ -814,7 +1025,18 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
   const bool two = force == 2 || (force != 1 && blocks2 >= 512);
   const int n_qt8 = cdiv(max_n_q, 512);
   const bool eight = force == 8 || (force == 0 && 8 * cdiv(n_groups, 8) * n_qt8 >= 256);   // 8-wave workgroups of 512 queries
-  if (eight) {
+  // a small launch (one pair through forward()): split the keys of every query block over two wave groups (GIMS_ATTN_QP=3: always)
+  const bool split = force == 3 || (force == 0 && !eight && !two && 8 * cdiv(n_groups, 8) * cdiv(max_n_q, QB) <= 512 && max_n_q >= 512);
+  if (split) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      GIMS_HIP(hipFuncSetAttribute((const void*)attention_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES));
+      attr_set = true;
+    }
+    const int n_qt = cdiv(max_n_q, QB);
+    hipLaunchKernelGGL(attention_split_kernel, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(512), SPLIT_LDS_BYTES, (hipStream_t)stream, qkv, ld,
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
+  } else if (eight) {
     int exact_only = 0;                         // GIMS_ATTN_EXACT=1: running-maximum softmax only (no optimistic pass)
     { const char* e = getenv("GIMS_ATTN_EXACT"); exact_only = e ? atoi(e) : 0; }
     static int prof = -1;
