@@ -623,15 +623,18 @@ __global__ __launch_bounds__(256) void agc_kept_deg_kernel(const AgcWs* __restri
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-constexpr int AGC_CAP_PER_NODE = 64;  // scratch CSR capacity of the pre-removal graph: 64 directed edges per node
+// The scratch CSR of the pre-removal graph gets the capacity the caller gives the final one (gims_agc_image::max_edges_dir,
+// at least 64 directed edges per node): a caller that sees the overflow flag repeats the build with larger output buffers.
+constexpr int AGC_MIN_CAP_PER_NODE = 64;
 
 static bool agc_sim_x6() {
   static const int v = [] { const char* e = getenv("GIMS_SIM_PREC"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
   return v != 0;
 }
 
-static size_t agc_layout(int n, int d, char* base, AgcWs* w) {
-  const int lds = (n + 3) & ~3, nw = (n + 63) / 64, cap = n * AGC_CAP_PER_NODE;
+static size_t agc_layout(int n, int d, int max_edges_dir, char* base, AgcWs* w) {
+  const int lds = (n + 3) & ~3, nw = (n + 63) / 64;
+  const int cap = max_edges_dir > n * AGC_MIN_CAP_PER_NODE ? max_edges_dir : n * AGC_MIN_CAP_PER_NODE;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return base ? base + o : (char*)nullptr; };
   char* p;
@@ -670,7 +673,7 @@ extern "C" size_t gims_agc_workspace_bytes(const gims_agc_image* images, int32_t
   using namespace gims;
   if (!images || n_images <= 0) return 0;
   size_t b = agc_batch_header(n_images);
-  for (int i = 0; i < n_images; ++i) b += agc_layout(images[i].n, images[i].d, nullptr, nullptr);
+  for (int i = 0; i < n_images; ++i) b += agc_layout(images[i].n, images[i].d, images[i].max_edges_dir, nullptr, nullptr);
   return b;
 }
 
@@ -699,7 +702,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     GIMS_CHECK_ARG(im.n >= 2 && im.n <= AGC_MAX_N, "gims_agc_build: image %d: n=%d out of range [2, %d]", i, im.n, AGC_MAX_N);
     GIMS_CHECK_ARG(im.d > 0 && (im.d % 32) == 0 && (im.ldd % 4) == 0, "gims_agc_build: image %d: d=%d must be a multiple of 32 (ldd %% 4 == 0)", i, im.d);
     AgcWs* w = &hws[i];
-    base += agc_layout(im.n, im.d, base, w);
+    base += agc_layout(im.n, im.d, im.max_edges_dir, base, w);
     w->kpts = im.kpts; w->desc = im.desc; w->ldd = im.ldd; w->kept = im.kept; w->indptr = im.indptr; w->indices = im.indices;
     w->info = im.info; w->max_edges_dir = im.max_edges_dir;
     // K2 rank: k = int(L * p / 100), clamped (agc.py:378-379)

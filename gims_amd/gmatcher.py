@@ -342,11 +342,15 @@ class GMatcher(nn.Module):
             ns = [g["kp"].shape[0] for g in images]
             if min(ns) < 2:
                 raise ValueError("need at least one array to concatenate")               # what the reference raises (agc.py:701)
-            pool = torch.empty(sum(66 * n + 4 for n in ns), dtype=torch.int32, device=dev)   # kept | indptr | indices per image
+            # capacity of the adaptive graph in directed edges per node (the reference has no limit: its percentile keeps
+            # (100 - p) % of the radius pairs, agc.py:378-380, 445-447; dense keypoints at radius 25 can exceed any fixed guess):
+            # starts at 64 and grows for good when a build reports an overflow (see _run_rest)
+            ec = self._edge_cap
+            pool = torch.empty(sum((ec + 2) * n + 4 for n in ns), dtype=torch.int32, device=dev)   # kept | indptr | indices per image
             o = 0
             for g, n in zip(images, ns):
-                g["kept"], g["indptr"], g["indices"] = pool[o:o + n], pool[o + n:o + 2 * n + 1], pool[o + 2 * n + 4:o + 66 * n + 4]
-                o += 66 * n + 4
+                g["kept"], g["indptr"], g["indices"] = pool[o:o + n], pool[o + n:o + 2 * n + 1], pool[o + 2 * n + 4:o + (ec + 2) * n + 4]
+                o += (ec + 2) * n + 4
             info_all = torch.empty((len(images), 8), dtype=torch.int32, device=dev)
             agc_imgs = hip.make_agc_images([dict(kpts=g["kp"], desc=g["de"], kept=g["kept"], indptr=g["indptr"],
                                                  indices=g["indices"], info=info_all[i]) for i, g in enumerate(images)])
@@ -360,14 +364,16 @@ class GMatcher(nn.Module):
             hw = np.asarray([[g["shape"][3], g["shape"][2]] for g in images], dtype=np.float32)   # size = [width, height]
             norm3 = np.concatenate([hw / np.float32(2), (hw.max(axis=1, keepdims=True) * np.float32(0.7))], axis=1).astype(np.float32)
             norm3 = hip.upload(norm3, dev)
-            n_up = sum(ns)                                  # upper bounds: kept <= n, edges <= 64 n
+            n_up = sum(ns)                                  # upper bounds: kept <= n, edges <= capacity * n
             bufs = dict(feat=torch.empty((n_up, D), dtype=torch.float32, device=dev),
                         kpts=torch.empty((n_up, 2), dtype=torch.float32, device=dev),
                         score=torch.empty((n_up,), dtype=torch.float32, device=dev),
                         seg=torch.empty((n_up,), dtype=torch.int32, device=dev),
                         indptr=torch.empty((n_up + 1,), dtype=torch.int32, device=dev),
-                        indices=torch.empty((64 * n_up + 1,), dtype=torch.int32, device=dev))
-        return dict(images=images, info_all=info_all, pool=pool, ptab=ptab, norm3=norm3, bufs=bufs)
+                        indices=torch.empty((ec * n_up + 1,), dtype=torch.int32, device=dev))
+        return dict(images=images, info_all=info_all, pool=pool, ptab=ptab, norm3=norm3, bufs=bufs, params=(radius, percentile, min_size))
+
+    _edge_cap = 64
 
     def _run_rest(self, ctx):
         """Phase 2: read the kept counts (the one host sync), then enqueue everything else."""
@@ -381,7 +387,18 @@ class GMatcher(nn.Module):
         infos = info_all.cpu().numpy()                                                    # the one host sync of the build
         self._sync_ms = 1e3 * (time.perf_counter() - ts0)
         if infos[:, 7].any():
-            raise hip.GimsHipError("adaptive graph exceeded the edge capacity (64 directed edges per node)")
+            # more edges than the buffers hold: repeat the graph build of this batch with room for what it reported (the
+            # directed-edge total of the densest image, rounded up to a power of two per node), and keep the larger capacity
+            ns = np.asarray([g["kp"].shape[0] for g in images], dtype=np.float64)
+            # info[1]: directed edges of the final graph, info[2]: undirected edges of the coarse graph (both counted in full
+            # even when they did not fit); the isolated-node fix-up adds at most one edge per node
+            tot = np.maximum(infos[:, 1].astype(np.float64), 2.0 * infos[:, 2] + 2.0 * ns)
+            need = int(np.ceil(max(2.0 * self._edge_cap, float((tot / ns).max()) * 1.1)))
+            cap = 1 << (need - 1).bit_length()
+            if cap > 16384 or cap <= self._edge_cap:
+                raise hip.GimsHipError(f"adaptive graph exceeded the edge capacity ({self._edge_cap} directed edges per node) and cannot grow further")
+            self._edge_cap = cap
+            return self._run_rest(self._run_build(images, *ctx["params"]))
         if (infos[:, 0] == 0).any():
             raise ValueError("need at least one array to concatenate")               # np.vstack([]) in agc.py:701
 

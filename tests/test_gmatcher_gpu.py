@@ -401,3 +401,31 @@ def test_train_loss_forward_vs_reference_golden(synth_sd, monkeypatch, name, sin
         m2(train_data(pairs, g, device="cuda"), mode="train")
     with pytest.raises(NotImplementedError):          # training-mode BatchNorm (batch statistics) is not on the HIP path
         m.train()(train_data(pairs, g, device="cuda"), mode="train")
+
+
+def test_dense_keypoints_grow_the_graph_capacity(synth_sd):
+    """Densely packed keypoints at the GMatcher DEFAULT radius / percentile (25 / 7: what train.py runs with, gmatcher.py:220-222)
+    give ~100 neighbours per node -- more than the 64 directed edges per node the buffers start with.  The reference has no
+    such limit; here the overflow flag makes the build repeat with larger buffers (kept for later calls) and the result
+    equals the oracle's."""
+    pair = synth.make_pair(600, 4242, canvas=(120, 90))
+    m = GMatcher({}).eval()
+    m.load_state_dict(synth_sd)
+    assert m._edge_cap == 64
+    d_gpu = pair_to_data(pair, 25, 7, 8, device="cuda")
+    out = m(d_gpu)
+    assert m._edge_cap > 64
+    g0 = d_gpu["graph0"][0]
+    assert g0.num_edges() > 64 * g0.num_nodes()
+    d_cpu = pair_to_data(pair, 25, 7, 8, device="cpu")
+    st = {}
+    ref = O.gmatcher_forward(synth_sd, d_cpu, {}, stages=st)
+    assert d_gpu["kept_kpts0_indices"] == d_cpu["kept_kpts0_indices"] and d_gpu["kept_kpts1_indices"] == d_cpu["kept_kpts1_indices"]
+    assert g0.num_edges() == len(d_cpu["graph0"][0]["indices"])
+    r0 = ref["matches0"][0].numpy()
+    safe = safe_rows(st["ot"][0].numpy(), 0.2, r0, ref["matching_scores0"][0].numpy())
+    np.testing.assert_array_equal(out["matches0"][0].cpu().numpy()[safe], r0[safe])
+    np.testing.assert_allclose(out["matching_scores0"][0].cpu().numpy(), ref["matching_scores0"][0].numpy(), atol=1e-4)
+    # the next call starts with the grown capacity: no second build
+    out2 = m(pair_to_data(pair, 25, 7, 8, device="cuda"))
+    np.testing.assert_array_equal(out2["matches0"].cpu().numpy(), out["matches0"].cpu().numpy())
