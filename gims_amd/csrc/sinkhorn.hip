@@ -1183,9 +1183,23 @@ static int ot_res_launch(OtResArgs a, hipStream_t s) {
     fprintf(stderr, "\n");
     return GIMS_OK;
   }
-  // The kernel's workgroups wait on each other: a COOPERATIVE launch makes the runtime check that the whole grid fits in
-  // resident workgroup slots and dispatch it as one gang (a plain launch only assumes it).  GIMS_OT_COOP=0: plain launch.
-  if (ot_env("GIMS_OT_COOP", 1)) {
+  // The kernel's workgroups wait on each other, so the whole grid (256 workgroups) must be resident at once.  Checked here
+  // against the occupancy query (once per instantiation): workgroups per CU x CUs >= 256, else the call fails loudly.
+  // What a cooperative launch adds is only that same check at launch time (same residency as a plain launch, +15-19 us of
+  // host time per launch); it is available as GIMS_OT_COOP=1 but not the default: under rocprofv3 a process that issued
+  // cooperative launches segfaults at exit, after the tool has written its output (measured on this image, ROCm 7.2).
+  // A solve that still gives up (another process's kernels on the GPU) is re-solved by ot_rescue_kernel in the same call.
+  static int resident_ok = -1;
+  if (resident_ok < 0) {
+    int per_cu = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ot_resident_kernel<C, false>, 512, lds);
+    resident_ok = (e == hipSuccess && per_cu * ot_res_cus() >= 256) ? 1 : 0;
+  }
+  if (!resident_ok) {
+    set_error("the on-chip Sinkhorn kernel does not fit: 256 workgroups of 512 threads with %zu bytes of LDS are not co-resident on this device", lds);
+    return GIMS_EHIP;
+  }
+  if (ot_env("GIMS_OT_COOP", 0)) {
     void* kargs[] = {(void*)&a};
     const hipError_t e = hipLaunchCooperativeKernel((const void*)ot_resident_kernel<C, false>, dim3(256), dim3(512), kargs, (unsigned)lds, s);
     if (e == hipSuccess) return GIMS_OK;
