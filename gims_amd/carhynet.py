@@ -29,6 +29,7 @@ class CARHyNet(nn.Module):
     chunk = 2048                      # patches per pass
     fused_sandglass = True            # False: the layer-by-layer kernels (kept as the cross-check of the fused one)
     fused_frn = True                  # likewise for the FRN (+ CoordAtt) + TLU block
+    fused_conv = True                 # 3x3 convolution + FRN block of layers 2-6 as ONE per-patch kernel (gims_ch_conv_block); False: GEMM + FRN block
 
     def __init__(self):
         super().__init__()
@@ -76,7 +77,8 @@ class CARHyNet(nn.Module):
             kpad = (k + 31) // 32 * 32
             full = torch.zeros(o, kpad, dtype=torch.float64)
             full[:, :k] = wk.reshape(o, k)
-            return dict(w=hip.split_spl32(f32(full)), b=f32(sd[p + "bias"]), kpad=kpad, n=o)
+            wp = hip.pack_conv3_fragments(w).to(dev) if (i % 16 == 0 and o % 32 == 0) else None   # fragment order of gims_ch_conv_block
+            return dict(w=hip.split_spl32(f32(full)), b=f32(sd[p + "bias"]), kpad=kpad, n=o, wp=wp)
 
         def frn(p, cpad=None):
             c = sd[p + "weight"].numel()
@@ -231,6 +233,16 @@ class CARHyNet(nn.Module):
             y1 = self._conv3_im2col(x, L["conv"], 1)
         xs = self._frn_tlu(y1, L["frn"], L["tau"], L["ca"], split=True)
         L = P["l2"]
+        dev = patches.device
+        if self.fused_conv and self.fused_frn and self.fused_sandglass:
+            # layers 2-6: convolution + FRN (+ CoordAtt) + TLU in one per-patch kernel each; the raw convolution outputs never reach HBM
+            x1 = hip.ch_conv_block(xs, n, 32, 32, 32, 1, L["conv"], L["frn"], L["tau"], L["ca"], y=torch.empty((n, 32, 32, 32), dtype=torch.float32, device=dev))
+            xs = self._sandglass_plus(x1, P["sg2"])
+            xs = hip.ch_conv_block(xs, n, 32, 32, 64, 2, P["l3"]["conv"], P["l3"]["frn"], P["l3"]["tau"], y_split=self._spl(n * 256, 64, dev))
+            x1 = hip.ch_conv_block(xs, n, 16, 64, 64, 1, P["l4"]["conv"], P["l4"]["frn"], P["l4"]["tau"], y=torch.empty((n, 16, 16, 64), dtype=torch.float32, device=dev))
+            xs = self._sandglass_plus(x1, P["sg4"])
+            xs = hip.ch_conv_block(xs, n, 16, 64, 128, 2, P["l5"]["conv"], P["l5"]["frn"], P["l5"]["tau"], y_split=self._spl(n * 64, 128, dev))
+            return hip.ch_conv_block(xs, n, 8, 128, 128, 1, P["l6"]["conv"], P["l6"]["frn"], P["l6"]["tau"], y_split=out)
         x1 = self._frn_tlu(self._conv3(xs, n, 32, 32, L["conv"], 1), L["frn"], L["tau"], L["ca"])
         xs = self._sandglass_plus(x1, P["sg2"])
         xs = self._frn_tlu(self._conv3(xs, n, 32, 32, P["l3"]["conv"], 2), P["l3"]["frn"], P["l3"]["tau"], split=True)

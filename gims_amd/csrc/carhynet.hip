@@ -312,12 +312,12 @@ __global__ __launch_bounds__(256) void ch_input_block_kernel(const float* __rest
 // pooling sweeps, apply pass).  models.py:57-85 (FRN), 139-153 (CoordAtt), 107-108 (TLU).
 struct ChGateW { const float* w1; const float* b1; const float* wh; const float* bh; const float* ww; const float* bw; };   // null w1: no CoordAtt
 
+// body shared by ch_frn_block_kernel and ch_conv_block_kernel: the raw convolution output of ONE patch is in LDS (xb [NPIX][C],
+// followed by the scratch arrays); pbase = index of the patch's first pixel row in the outputs
 template <int C, int HW, int NT>
-__global__ __launch_bounds__(NT) void ch_frn_block_kernel(const float* __restrict__ x, const float* __restrict__ fw, const float* __restrict__ fb, float eps,
-                                                           ChGateW g, const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp,
-                                                           int64_t ldsp) {
+__device__ __forceinline__ void frn_block_body(float* lds, const float* __restrict__ fw, const float* __restrict__ fb, float eps, const ChGateW& g,
+                                               const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp, int64_t ldsp, int64_t pbase) {
   constexpr int NPIX = HW * HW, QPP = C / 4, NQ = NPIX * QPP / NT, GRP = NT / C;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xb = lds;                          // [NPIX][C]
   float* red = xb + NPIX * C;               // [GRP][C]
   float* sc = red + GRP * C;                // [C]   FRN scale of this patch
@@ -325,16 +325,6 @@ __global__ __launch_bounds__(NT) void ch_frn_block_kernel(const float* __restric
   float* pw = ph + HW * C;                  // [HW][C] -> a_w
   float* mid = pw + HW * C;                 // [2 HW][8]
   const int t = threadIdx.x;
-  const int64_t pbase = (int64_t)blockIdx.x * NPIX;
-  const float* xp = x + pbase * C;
-  {   // bulk load: NQ independent, fully coalesced 16-byte loads per thread
-    float4 v[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) v[j] = *(const float4*)(xp + (int64_t)(t + NT * j) * 4);
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) *(float4*)(xb + (t + NT * j) * 4) = v[j];
-  }
-  __syncthreads();
   {   // FRN statistic: mean of x^2 over the pixels, per channel
     const int c = t % C, gq = t / C;
     float s = 0.f;
@@ -394,6 +384,175 @@ __global__ __launch_bounds__(NT) void ch_frn_block_kernel(const float* __restric
     if (y) *(float4*)(y + (pbase * C) + (int64_t)i * 4) = make_float4(r[0], r[1], r[2], r[3]);
     if (ysp) store_split4(ysp + (pbase + pix) * ldsp + spl_col(ch), r);
   }
+}
+
+template <int C, int HW, int NT>
+__global__ __launch_bounds__(NT) void ch_frn_block_kernel(const float* __restrict__ x, const float* __restrict__ fw, const float* __restrict__ fb, float eps,
+                                                           ChGateW g, const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp,
+                                                           int64_t ldsp) {
+  constexpr int NPIX = HW * HW, QPP = C / 4, NQ = NPIX * QPP / NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int t = threadIdx.x;
+  const int64_t pbase = (int64_t)blockIdx.x * NPIX;
+  const float* xp = x + pbase * C;
+  {   // bulk load: NQ independent, fully coalesced 16-byte loads per thread
+    float4 v[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) v[j] = *(const float4*)(xp + (int64_t)(t + NT * j) * 4);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) *(float4*)(lds + (t + NT * j) * 4) = v[j];
+  }
+  __syncthreads();
+  frn_block_body<C, HW, NT>(lds, fw, fb, eps, g, tau, y, ysp, ldsp, pbase);
+}
+
+// ---------------------------------------------------------------------------------------------- fused 3x3 convolution + FRN (+CoordAtt) + TLU
+// One workgroup (8 waves) per patch.  The split-bf16 input activation of the patch ([HIN*HIN][2 CIN] SPL32 pixel rows) is
+// read ONCE into LDS with a one-pixel zero border, and the 3x3 convolution runs there as an implicit GEMM on the matrix
+// cores: rows = output pixels, K = 9 taps x CIN channels, three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, like the
+// GEMMs it replaces).  A tap is a shifted view of the LDS image -- where the gather-mode GEMM (GIMS_LINEAR_CONV3) DMA-ed every
+// pixel row nine times from L2.  The weights come pre-packed in MFMA fragment order (one contiguous KiB per fragment),
+// straight from L1 / L2 into registers, one K step ahead.  The accumulators (+ bias) then go to LDS over the dead input image
+// and the FRN (+ CoordAtt) + TLU block runs on them as in ch_frn_block_kernel: the raw convolution output never reaches HBM.
+// 16-byte chunks of a pixel record are XOR-swizzled by the pixel index so that the fragment reads of 16 consecutive pixels
+// hit distinct banks.
+template <int CIN, int COUT, int HIN, int STRIDE>
+struct ConvGeom {
+  static constexpr int NT = 512, WAVES = 8;
+  static constexpr int HOUT = (HIN - 1) / STRIDE + 1, NPIX = HOUT * HOUT, WP = HIN + 2;
+  static constexpr int PXB = CIN * 4, CPP = PXB / 16;                 // bytes / 16-byte chunks per pixel record (hi + lo planes)
+  static constexpr int MB = NPIX / 32, NB = COUT / 32, KS = CIN / 16;
+  // wave tiling: MBW m-blocks x NBW n-blocks per wave
+  static constexpr int NBW = (MB >= WAVES) ? NB : (MB * NB) / WAVES;   // L2: 1, L3/L4: 2, L5/L6: 1
+  static constexpr int MBW = (MB >= WAVES) ? MB / WAVES : 1;
+  static constexpr int IN_BYTES = WP * WP * PXB;
+  static constexpr int FRN_FLOATS = NPIX * COUT + (NT / COUT) * COUT + COUT + 2 * HOUT * COUT + 16 * HOUT;
+  static constexpr int LDS_BYTES = IN_BYTES > FRN_FLOATS * 4 ? IN_BYTES : FRN_FLOATS * 4;
+  static_assert(MB * NB == WAVES * MBW * NBW, "blocks divide over the waves");
+  __device__ static __forceinline__ int swz(int q) { return CIN == 32 ? ((q >> 1) & 7) : (q & 15); }
+};
+
+template <int CIN, int COUT, int HIN, int STRIDE>
+__global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __restrict__ xin, int64_t ldx, const uint16_t* __restrict__ wpk,
+                                                            const float* __restrict__ bias, const float* __restrict__ fw, const float* __restrict__ fb, float eps,
+                                                            ChGateW g, const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp,
+                                                            int64_t ldsp) {
+  using G = ConvGeom<CIN, COUT, HIN, STRIDE>;
+  constexpr int NT = G::NT, WP = G::WP, PXB = G::PXB, CPP = G::CPP, HOUT = G::HOUT, MBW = G::MBW, NBW = G::NBW, KS = G::KS, NB = G::NB;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* img = (char*)lds;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t patch = blockIdx.x;
+
+  // ---- input patch -> LDS (zero border, swizzled chunks)
+  {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = t; i < (4 * WP - 4) * CPP; i += NT) {          // border pixels: rows 0 and WP-1, columns 0 and WP-1
+      const int b = i / CPP, ch = i % CPP;
+      int q;
+      if (b < WP) q = b;                                         // top row
+      else if (b < 2 * WP) q = (WP - 1) * WP + (b - WP);         // bottom row
+      else if (b < 3 * WP - 2) q = (b - 2 * WP + 1) * WP;        // left column
+      else q = (b - (3 * WP - 2) + 1) * WP + WP - 1;             // right column
+      *(uint4*)(img + q * PXB + ch * 16) = z;
+    }
+    const uint16_t* src = xin + patch * (HIN * HIN) * ldx;
+    constexpr int TOT = HIN * HIN * CPP;
+    static_assert(TOT % (4 * NT) == 0, "whole trips of four loads per thread");
+    for (int i0 = t; i0 < TOT; i0 += 4 * NT) {                   // four independent 16-byte loads in flight per thread
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NT;
+        v[u] = *(const uint4*)(src + (int64_t)(i / CPP) * ldx + (i % CPP) * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NT;
+        const int pix = i / CPP, ch = i % CPP, q = (pix / HIN + 1) * WP + (pix % HIN) + 1;
+        *(uint4*)(img + q * PXB + ((ch ^ G::swz(q)) * 16)) = v[u];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- implicit GEMM: this wave's (m-block, n-block) tiles
+  const int mb0 = (G::MB >= G::WAVES) ? wave * MBW : wave % G::MB;
+  const int nb0 = (G::MB >= G::WAVES) ? 0 : (wave / G::MB) * NBW;
+  int qbase[MBW];
+#pragma unroll
+  for (int m = 0; m < MBW; ++m) {
+    const int p = (mb0 + m) * 32 + li, yy = p / HOUT, xx = p % HOUT;
+    qbase[m] = (yy * STRIDE) * WP + xx * STRIDE;                 // tap (ky, kx) adds ky * WP + kx (border offset and pad cancel)
+  }
+  f32x16 acc[MBW][NBW];
+#pragma unroll
+  for (int m = 0; m < MBW; ++m)
+#pragma unroll
+    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  // weight fragments: [step = tap * KS + ks][nb][plane][lane][8]
+  const uint16_t* wl = wpk + lane * 8;
+  auto wfrag = [&](int step, int nb, int plane) __attribute__((always_inline)) {
+    return *(const bf16x8*)(wl + (((int64_t)step * NB + nb) * 2 + plane) * 512);
+  };
+  constexpr int STEPS = 9 * KS;                                  // even (KS = 2, 4, 8)
+  auto load_w = [&](int step, bf16x8 (&h)[NBW], bf16x8 (&l)[NBW]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) { h[n] = wfrag(step, nb0 + n, 0); l[n] = wfrag(step, nb0 + n, 1); }
+  };
+  auto compute = [&](int step, const bf16x8 (&h)[NBW], const bf16x8 (&l)[NBW]) __attribute__((always_inline)) {
+    const int tap = step / KS, ks = step % KS;
+    const int toff = (tap / 3) * WP + (tap % 3);
+    const int chunk = (ks >> 1) * 8 + 2 * (ks & 1) + lh;          // hi chunk of channels [16 ks + 8 lh, +8); lo = chunk + 4
+    bf16x8 ah[MBW], al[MBW];
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) {
+      const int q = qbase[m] + toff, sw = G::swz(q);
+      ah[m] = *(const bf16x8*)(img + q * PXB + ((chunk ^ sw) * 16));
+      al[m] = *(const bf16x8*)(img + q * PXB + (((chunk + 4) ^ sw) * 16));
+    }
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+      for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l[n], ah[m], acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+      for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h[n], al[m], acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+      for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h[n], ah[m], acc[m][n], 0, 0, 0);
+  };
+  bf16x8 wh0[NBW], wl0[NBW], wh1[NBW], wl1[NBW];               // two named buffers: the weights of the next K step are in flight
+  load_w(0, wh0, wl0);
+  for (int step = 0; step < STEPS; step += 2) {
+    load_w(step + 1, wh1, wl1);
+    compute(step, wh0, wl0);
+    if (step + 2 < STEPS) load_w(step + 2, wh0, wl0);
+    compute(step + 1, wh1, wl1);
+  }
+  __syncthreads();                                                // every wave is done with the input image
+
+  // ---- raw convolution output (+ bias) -> LDS [pixel][COUT], then the FRN block
+#pragma unroll
+  for (int m = 0; m < MBW; ++m)
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+      const int pix = (mb0 + m) * 32 + li, c0 = (nb0 + n) * 32 + 4 * lh;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 b4 = *(const float4*)(bias + c0 + 8 * gq);
+        *(float4*)(lds + pix * COUT + c0 + 8 * gq) =
+            make_float4(acc[m][n][4 * gq] + b4.x, acc[m][n][4 * gq + 1] + b4.y, acc[m][n][4 * gq + 2] + b4.z, acc[m][n][4 * gq + 3] + b4.w);
+      }
+    }
+  __syncthreads();
+  frn_block_body<COUT, HOUT, NT>(lds, fw, fb, eps, g, tau, y, ysp, ldsp, patch * G::NPIX);
 }
 
 // ---------------------------------------------------------------------------------------------- fused SandGlass block
@@ -707,6 +866,48 @@ extern "C" int gims_ch_frn_block(const float* x, int64_t patches, int32_t hw, in
   else hipLaunchKernelGGL((ch_frn_block_kernel<128, 8, FRN_NT>), grid, dim3(FRN_NT), lds, st, x, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
+}
+
+template <int CIN, int COUT, int HIN, int STRIDE>
+static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, const uint16_t* w, const float* bias, const float* fw, const float* fb, float eps,
+                             gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st) {
+  using namespace gims;
+  using Geo = ConvGeom<CIN, COUT, HIN, STRIDE>;
+  static bool attr = false;
+  if (!attr) {
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES));
+    attr = true;
+  }
+  hipLaunchKernelGGL((ch_conv_block_kernel<CIN, COUT, HIN, STRIDE>), dim3((unsigned)patches), dim3(512), Geo::LDS_BYTES, st, x, ldx, w, bias, fw, fb, eps, G, tau,
+                     y, ysp, ldsp);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_ch_conv_block(const uint16_t* x_split, int64_t ldx, int64_t patches, int32_t hin, int32_t cin, int32_t cout, int32_t stride,
+                                  const uint16_t* w_packed, const float* bias, const float* frn_weight, const float* frn_bias, float eps,
+                                  const float* const* gate_w, const float* tau, float* y, uint16_t* y_split, int64_t ld_split, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(x_split && w_packed && bias && frn_weight && frn_bias && tau && (y || y_split) && patches > 0 && eps >= 0.f,
+                 "gims_ch_conv_block: null pointer / empty batch");
+  GIMS_CHECK_ARG(ldx >= 2 * (int64_t)cin && (ldx % 8) == 0 && (((uintptr_t)x_split) & 15) == 0, "gims_ch_conv_block: input pitch >= 2 cin, 16-byte aligned rows");
+  GIMS_CHECK_ARG(!y_split || (ld_split >= 2 * (int64_t)cout && (ld_split % 4) == 0), "gims_ch_conv_block: split output pitch >= 2 cout");
+  ChGateW G = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (gate_w) {
+    for (int i = 0; i < 6; ++i) GIMS_CHECK_ARG(gate_w[i] != nullptr, "gims_ch_conv_block: gate weight pointer %d is null", i);
+    G = ChGateW{gate_w[0], gate_w[1], gate_w[2], gate_w[3], gate_w[4], gate_w[5]};
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int key = hin * 1000000 + cin * 10000 + cout * 10 + stride;
+  switch (key) {
+    case 32 * 1000000 + 32 * 10000 + 32 * 10 + 1: return conv_block_launch<32, 32, 32, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+    case 32 * 1000000 + 32 * 10000 + 64 * 10 + 2: return conv_block_launch<32, 64, 32, 2>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+    case 16 * 1000000 + 64 * 10000 + 64 * 10 + 1: return conv_block_launch<64, 64, 16, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+    case 16 * 1000000 + 64 * 10000 + 128 * 10 + 2: return conv_block_launch<64, 128, 16, 2>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+    case 8 * 1000000 + 128 * 10000 + 128 * 10 + 1: return conv_block_launch<128, 128, 8, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+    default: break;
+  }
+  GIMS_CHECK_ARG(false, "gims_ch_conv_block: unsupported geometry hin=%d cin=%d cout=%d stride=%d (the five 3x3 layers of CAR-HyNet after the first)", hin, cin, cout, stride);
 }
 
 extern "C" int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, int32_t c, const float* const* w /* 14 device pointers, ChSandglassW order */,

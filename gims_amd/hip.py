@@ -112,6 +112,8 @@ _SIGNATURES = {
     "gims_ch_input_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_frn_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_ch_conv_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_sandglass": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_l2norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_ch_relu6": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
@@ -712,6 +714,27 @@ def ch_frn_block(x, F, tau, G=None, y=None, y_split=None):
     arr = (C.c_void_p * 6)(*[G[k].data_ptr() for k in ("w1", "b1", "wh", "bh", "ww", "bw")]) if G is not None else None
     _check(load().gims_ch_frn_block(_p(_dev(x, torch.float32)), n, h, c, _p(F["w"]), _p(F["b"]), float(F["eps"]), arr, _p(tau), _p(y), _p(y_split),
                                     y_split.stride(0) if y_split is not None else 0, _stream()), "gims_ch_frn_block")
+    return y if y is not None else y_split
+
+
+def pack_conv3_fragments(w: torch.Tensor) -> torch.Tensor:
+    """[cout][cin][3][3] float64/float32 (CPU) -> the bf16 fragment layout of gims_ch_conv_block:
+    [step = (ky*3+kx) * cin/16 + ks][nb][plane hi|lo][lane = lh*32 + li][8]."""
+    o, i = w.shape[0], w.shape[1]
+    assert o % 32 == 0 and i % 16 == 0 and w.shape[2:] == (3, 3)
+    x = w.double().permute(2, 3, 1, 0).reshape(9, i // 16, 2, 8, o // 32, 32)         # [tap][ks][lh][e][nb][li]
+    x = x.permute(0, 1, 4, 2, 5, 3).reshape(9 * (i // 16), o // 32, 64, 8).float()     # [step][nb][lane][e]
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], dim=2).contiguous()                                   # [step][nb][plane][lane][8]
+
+
+def ch_conv_block(xs, n, hin, cin, cout, stride, L, F, tau, G=None, y=None, y_split=None):
+    """Fused 3x3 convolution + FRN (+ CoordAtt gates G) + TLU, one workgroup per patch (gims_ch_conv_block).
+    xs: SPL32 pixel rows [n*hin*hin, >= 2 cin]; L: dict(wp=packed fragments on the device, b=bias)."""
+    arr = (C.c_void_p * 6)(*[G[k].data_ptr() for k in ("w1", "b1", "wh", "bh", "ww", "bw")]) if G is not None else None
+    _check(load().gims_ch_conv_block(_p(xs), xs.stride(0), n, hin, cin, cout, stride, _p(L["wp"]), _p(L["b"]), _p(F["w"]), _p(F["b"]), float(F["eps"]), arr,
+                                     _p(tau), _p(y), _p(y_split), y_split.stride(0) if y_split is not None else 0, _stream()), "gims_ch_conv_block")
     return y if y is not None else y_split
 
 

@@ -419,6 +419,17 @@ int gims_ch_frn_block(const float* x, int64_t patches, int32_t hw, int32_t c, co
  * dw0 [9][c], dw0 bias [c], CoordAtt w1 [8][c], b1 [8], wh [c][8], bh [c], ww [c][8], bw [c], pw0 [16][c], pw0 bias [16],
  * pw1 [c][16], pw1 bias [c], dw1 [9][c], dw1 bias [c].  Output: SPL32 split-bf16 pixel rows. */
 int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, int32_t c, const float* const* w, uint16_t* out_split, int64_t ld_split, void* stream);
+/* 3x3 convolution (pad 1, stride 1 | 2) + bias + FRN (+ CoordAtt) + TLU of one CAR-HyNet layer in ONE kernel, one workgroup per patch
+ * (models.py:325-360: layer2 .. layer6).  x_split: the layer's input as SPL32 split-bf16 pixel rows [patches * hin * hin][pitch ldx >= 2 cin];
+ * it is read once into LDS (zero border) and the convolution runs there as an implicit GEMM on the matrix cores (split-bf16x3: hi*hi +
+ * hi*lo + lo*hi, like gims_linear); the raw output never leaves the chip: FRN statistic, CoordAtt gates (gate_w as in gims_ch_frn_block,
+ * NULL: none) and TLU are applied to the accumulators and the result leaves as f32 NHWC (y) and / or SPL32 pixel rows (y_split).
+ * w_packed: the weights [cout][cin][3][3] in MFMA fragment order, bf16: [step = (ky*3+kx) * cin/16 + ks][nb = cout/32][plane hi|lo][lane 64][8]
+ * with lane = lh*32 + li holding out channel nb*32 + li, input channels 16 ks + 8 lh + (0..7) of tap (ky, kx).
+ * Geometries: (hin, cin, cout, stride) = (32,32,32,1), (32,32,64,2), (16,64,64,1), (16,64,128,2), (8,128,128,1). */
+int gims_ch_conv_block(const uint16_t* x_split, int64_t ldx, int64_t patches, int32_t hin, int32_t cin, int32_t cout, int32_t stride,
+                       const uint16_t* w_packed, const float* bias, const float* frn_weight, const float* frn_bias, float eps,
+                       const float* const* gate_w, const float* tau, float* y, uint16_t* y_split, int64_t ld_split, void* stream);
 int gims_ch_l2norm(const float* x, int64_t rows, int32_t c, float eps, float* y, void* stream);
 int gims_ch_relu6(float* x, int64_t total, void* stream);
 

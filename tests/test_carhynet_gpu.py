@@ -62,6 +62,51 @@ def test_fused_blocks_equal_layer_by_layer():
     np.testing.assert_allclose(outs[0][0], outs[1][0], atol=5e-6, rtol=0)
 
 
+def test_fused_conv_blocks_equal_gemm_plus_frn_block():
+    """gims_ch_conv_block (3x3 convolution as an implicit GEMM on the LDS-resident patch + FRN (+CoordAtt) + TLU in one kernel, layers
+    2-6) against the gather-mode GEMM followed by gims_ch_frn_block: the same split-bf16x3 products, summed in a different order."""
+    patches = synth.make_patches(70, 33)
+    outs = []
+    for fused in (True, False):
+        m = _model(321)
+        m.fused_conv = fused
+        d, raw = m(torch.from_numpy(patches).permute(0, 3, 1, 2).cuda(), mode="train")
+        outs.append((d.cpu().numpy(), raw.cpu().numpy()))
+    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], atol=1e-5, rtol=0)
+
+
+def test_conv_block_layer_vs_conv2d():
+    """One layer in isolation, every geometry: gims_ch_conv_block against torch's float64 conv2d + the FRN / TLU formulas on the
+    SAME split-bf16 input (hi + lo) and split weights."""
+    from gims_amd import hip
+    r = np.random.default_rng(5)
+    for hin, cin, cout, stride in ((32, 32, 32, 1), (32, 32, 64, 2), (16, 64, 64, 1), (16, 64, 128, 2), (8, 128, 128, 1)):
+        n = 5
+        x = r.normal(size=(n, hin, hin, cin)).astype(np.float32)
+        w = (r.normal(size=(cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+        b = r.normal(size=cout).astype(np.float32) * 0.1
+        fw, fb = (1 + 0.2 * r.normal(size=cout)).astype(np.float32), (0.1 * r.normal(size=cout)).astype(np.float32)
+        tau = (-1 + 0.3 * r.normal(size=cout)).astype(np.float32)
+        xs = hip.split_spl32(torch.from_numpy(x.reshape(-1, cin)).cuda())
+        xh, xl = hip.spl32_planes(xs)
+        x_seen = (xh.double() + xl.double()).cpu().reshape(n, hin, hin, cin)
+        wp = hip.pack_conv3_fragments(torch.from_numpy(w))
+        w_seen = (wp[:, :, 0].double() + wp[:, :, 1].double())            # [step][nb][lane][8] -> back to [cout][cin][3][3]
+        w_seen = w_seen.reshape(9, cin // 16, cout // 32, 2, 32, 8).permute(2, 4, 1, 3, 5, 0).reshape(cout, cin, 3, 3)
+        L = dict(wp=wp.cuda(), b=torch.from_numpy(b).cuda())
+        F = dict(w=torch.from_numpy(fw).cuda(), b=torch.from_numpy(fb).cuda(), eps=1e-6)
+        ho = (hin - 1) // stride + 1
+        y = torch.empty((n, ho, ho, cout), dtype=torch.float32, device="cuda")
+        hip.ch_conv_block(xs, n, hin, cin, cout, stride, L, F, torch.from_numpy(tau).cuda(), None, y=y)
+        conv = torch.nn.functional.conv2d(x_seen.permute(0, 3, 1, 2), w_seen, torch.from_numpy(b).double(), stride=stride, padding=1)
+        nu2 = (conv * conv).mean(dim=(2, 3), keepdim=True)
+        ref = torch.maximum(conv * torch.rsqrt(nu2 + 1e-6) * torch.from_numpy(fw).double()[None, :, None, None]
+                            + torch.from_numpy(fb).double()[None, :, None, None], torch.from_numpy(tau).double()[None, :, None, None])
+        err = (y.cpu().double() - ref.permute(0, 2, 3, 1)).abs().max().item()
+        assert err < 2e-5, (hin, cin, cout, stride, err)
+
+
 def test_full_size_properties():
     """BASELINE config 5's size (descriptors for 2 x 8192 keypoints), where the CPU restatement is too slow: every patch is
     processed independently, so (1) the result does not depend on how the batch is chunked -- bit for bit --, (2) a patch
