@@ -419,13 +419,15 @@ __global__ __launch_bounds__(NT) void ch_frn_block_kernel(const float* __restric
 template <int CIN, int COUT, int HIN, int STRIDE>
 struct ConvGeom {
   static constexpr int NT = 512, WAVES = 8;
-  static constexpr int HOUT = (HIN - 1) / STRIDE + 1, NPIX = HOUT * HOUT, WP = HIN + 2;
+  static constexpr int HOUT = (HIN - 1) / STRIDE + 1, NPIX = HOUT * HOUT, ZQ = HIN * HIN;   // ZQ: index of the all-zero pixel record
   static constexpr int PXB = CIN * 4, CPP = PXB / 16;                 // bytes / 16-byte chunks per pixel record (hi + lo planes)
   static constexpr int MB = NPIX / 32, NB = COUT / 32, KS = CIN / 16;
-  // wave tiling: MBW m-blocks x NBW n-blocks per wave
-  static constexpr int NBW = (MB >= WAVES) ? NB : (MB * NB) / WAVES;   // L2: 1, L3/L4: 2, L5/L6: 1
-  static constexpr int MBW = (MB >= WAVES) ? MB / WAVES : 1;
-  static constexpr int IN_BYTES = WP * WP * PXB;
+  // wave tiling: MBW m-blocks x ONE n-block per wave (the weight fragments come from global memory through L1: a wave that
+  // owns several pixel blocks of one channel block loads each weight fragment once for all of them; the pixel fragments
+  // come from LDS, where re-reads are cheap)
+  static constexpr int NBW = 1;
+  static constexpr int MBW = MB * NB / WAVES;                          // L2: 4, L3/L4: 2, L5/L6: 1
+  static constexpr int IN_BYTES = (HIN * HIN + 1) * PXB;
   static constexpr int FRN_FLOATS = NPIX * COUT + (NT / COUT) * COUT + COUT + 2 * HOUT * COUT + 16 * HOUT;
   static constexpr int LDS_BYTES = IN_BYTES > FRN_FLOATS * 4 ? IN_BYTES : FRN_FLOATS * 4;
   static_assert(MB * NB == WAVES * MBW * NBW, "blocks divide over the waves");
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
                                                             ChGateW g, const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp,
                                                             int64_t ldsp) {
   using G = ConvGeom<CIN, COUT, HIN, STRIDE>;
-  constexpr int NT = G::NT, WP = G::WP, PXB = G::PXB, CPP = G::CPP, HOUT = G::HOUT, MBW = G::MBW, NBW = G::NBW, KS = G::KS, NB = G::NB;
+  constexpr int NT = G::NT, ZQ = G::ZQ, PXB = G::PXB, CPP = G::CPP, HOUT = G::HOUT, MBW = G::MBW, NBW = G::NBW, KS = G::KS, NB = G::NB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* img = (char*)lds;
   const int t = threadIdx.x, lane = t & 63;
@@ -446,18 +448,10 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   const int li = lane & 31, lh = lane >> 5;
   const int64_t patch = blockIdx.x;
 
-  // ---- input patch -> LDS (zero border, swizzled chunks)
+  // ---- input patch -> LDS (swizzled chunks) + ONE all-zero pixel record that every out-of-image tap reads (no border in LDS:
+  // the 16x16x64 and 8x8x128 layers then fit two / three workgroups per CU)
   {
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = t; i < (4 * WP - 4) * CPP; i += NT) {          // border pixels: rows 0 and WP-1, columns 0 and WP-1
-      const int b = i / CPP, ch = i % CPP;
-      int q;
-      if (b < WP) q = b;                                         // top row
-      else if (b < 2 * WP) q = (WP - 1) * WP + (b - WP);         // bottom row
-      else if (b < 3 * WP - 2) q = (b - 2 * WP + 1) * WP;        // left column
-      else q = (b - (3 * WP - 2) + 1) * WP + WP - 1;             // right column
-      *(uint4*)(img + q * PXB + ch * 16) = z;
-    }
+    if (t < CPP) *(uint4*)(img + ZQ * PXB + t * 16) = make_uint4(0u, 0u, 0u, 0u);
     const uint16_t* src = xin + patch * (HIN * HIN) * ldx;
     constexpr int TOT = HIN * HIN * CPP;
     static_assert(TOT % (4 * NT) == 0, "whole trips of four loads per thread");
@@ -471,7 +465,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * NT;
-        const int pix = i / CPP, ch = i % CPP, q = (pix / HIN + 1) * WP + (pix % HIN) + 1;
+        const int q = i / CPP, ch = i % CPP;
         *(uint4*)(img + q * PXB + ((ch ^ G::swz(q)) * 16)) = v[u];
       }
     }
@@ -479,13 +473,13 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   __syncthreads();
 
   // ---- implicit GEMM: this wave's (m-block, n-block) tiles
-  const int mb0 = (G::MB >= G::WAVES) ? wave * MBW : wave % G::MB;
-  const int nb0 = (G::MB >= G::WAVES) ? 0 : (wave / G::MB) * NBW;
-  int qbase[MBW];
+  const int nb0 = wave % NB, mb0 = (wave / NB) * MBW;            // waves with the same n-block walk consecutive pixel blocks
+  int y0[MBW], x0[MBW];                                          // input coordinates of tap (0, 0) of this lane's output pixels (may be -1)
 #pragma unroll
   for (int m = 0; m < MBW; ++m) {
-    const int p = (mb0 + m) * 32 + li, yy = p / HOUT, xx = p % HOUT;
-    qbase[m] = (yy * STRIDE) * WP + xx * STRIDE;                 // tap (ky, kx) adds ky * WP + kx (border offset and pad cancel)
+    const int p = (mb0 + m) * 32 + li;
+    y0[m] = (p / HOUT) * STRIDE - 1;
+    x0[m] = (p % HOUT) * STRIDE - 1;
   }
   f32x16 acc[MBW][NBW];
 #pragma unroll
@@ -506,12 +500,14 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   };
   auto compute = [&](int step, const bf16x8 (&h)[NBW], const bf16x8 (&l)[NBW]) __attribute__((always_inline)) {
     const int tap = step / KS, ks = step % KS;
-    const int toff = (tap / 3) * WP + (tap % 3);
+    const int ky = tap / 3, kx = tap % 3;
     const int chunk = (ks >> 1) * 8 + 2 * (ks & 1) + lh;          // hi chunk of channels [16 ks + 8 lh, +8); lo = chunk + 4
     bf16x8 ah[MBW], al[MBW];
 #pragma unroll
     for (int m = 0; m < MBW; ++m) {
-      const int q = qbase[m] + toff, sw = G::swz(q);
+      const int iy = y0[m] + ky, ix = x0[m] + kx;
+      const int q = ((unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN) ? iy * HIN + ix : ZQ;
+      const int sw = G::swz(q);
       ah[m] = *(const bf16x8*)(img + q * PXB + ((chunk ^ sw) * 16));
       al[m] = *(const bf16x8*)(img + q * PXB + (((chunk + 4) ^ sw) * 16));
     }
@@ -528,13 +524,22 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
 #pragma unroll
       for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h[n], ah[m], acc[m][n], 0, 0, 0);
   };
-  bf16x8 wh0[NBW], wl0[NBW], wh1[NBW], wl1[NBW];               // two named buffers: the weights of the next K step are in flight
-  load_w(0, wh0, wl0);
-  for (int step = 0; step < STEPS; step += 2) {
-    load_w(step + 1, wh1, wl1);
-    compute(step, wh0, wl0);
-    if (step + 2 < STEPS) load_w(step + 2, wh0, wl0);
-    compute(step + 1, wh1, wl1);
+  // register ring of weight fragments, WD K steps deep: the loads of step + WD - 1 are issued before the MFMAs of step.  The
+  // loop body covers UNR steps (a multiple of WD, so the ring indices are compile-time constants: registers, not scratch)
+  // and is NOT unrolled further: 72 unrolled steps of the 128-channel layer overflow the instruction cache.
+  constexpr int WD = KS == 2 ? 3 : 4, UNR = KS == 2 ? 6 : KS;
+  static_assert(STEPS % UNR == 0 && UNR % WD == 0, "ring geometry");
+  bf16x8 rh[WD][NBW], rl[WD][NBW];
+#pragma unroll
+  for (int s0 = 0; s0 < WD - 1; ++s0) load_w(s0, rh[s0], rl[s0]);
+#pragma unroll 1
+  for (int s0 = 0; s0 < STEPS; s0 += UNR) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int step = s0 + u;
+      if (step + WD - 1 < STEPS) load_w(step + WD - 1, rh[(u + WD - 1) % WD], rl[(u + WD - 1) % WD]);
+      compute(step, rh[u % WD], rl[u % WD]);
+    }
   }
   __syncthreads();                                                // every wave is done with the input image
 
