@@ -675,9 +675,14 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   // ---- C: per pixel  z = ReLU6(W1 (W0 (y a_w a_h) + b0) + b1), in place
   for (int pix = t; pix < NPIX; pix += NT) {
     const int yy = pix / HW, xx = pix % HW;
+    // the pointwise weights are read with UNIFORM (compile-time) indices straight from global memory: the compiler turns
+    // them into scalar loads (SGPR operands of the fmas) -- as LDS broadcast reads they were 256 of the ~300 LDS reads per
+    // pixel of this phase, which is LDS-bandwidth bound
+    typedef const __attribute__((address_space(4))) float* cfp;      // constant address space: uniform loads become s_load
+    const cfp gp0 = (cfp)wts.p0, gp1 = (cfp)wts.p1, gb0 = (cfp)wts.p0b, gb1 = (cfp)wts.p1b;
     float hid[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) hid[m] = l_p0b[m];
+    for (int m = 0; m < 16; ++m) hid[m] = gb0[m];
 #pragma unroll
     for (int cq = 0; cq < QPP; ++cq) {
       const float4 v = *(const float4*)(ybuf + slot(pix, cq));
@@ -685,8 +690,8 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
       const float tv[4] = {v.x * g2.x * g1.x, v.y * g2.y * g1.y, v.z * g2.z * g1.z, v.w * g2.w * g1.w};
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
-        const float4 k4 = *(const float4*)(l_p0 + m * C + 4 * cq);          // broadcast reads, 16 bytes at a time
-        hid[m] = fmaf(tv[0], k4.x, fmaf(tv[1], k4.y, fmaf(tv[2], k4.z, fmaf(tv[3], k4.w, hid[m]))));
+        const cfp k4 = gp0 + m * C + 4 * cq;
+        hid[m] = fmaf(tv[0], k4[0], fmaf(tv[1], k4[1], fmaf(tv[2], k4[2], fmaf(tv[3], k4[3], hid[m]))));
       }
     }
 #pragma unroll
@@ -694,11 +699,11 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
       float r[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float acc = l_p1b[4 * cq + j];
+        float acc = gb1[4 * cq + j];
 #pragma unroll
         for (int m = 0; m < 16; m += 4) {
-          const float4 k4 = *(const float4*)(l_p1 + (4 * cq + j) * 16 + m);
-          acc = fmaf(hid[m], k4.x, fmaf(hid[m + 1], k4.y, fmaf(hid[m + 2], k4.z, fmaf(hid[m + 3], k4.w, acc))));
+          const cfp k4 = gp1 + (4 * cq + j) * 16 + m;
+          acc = fmaf(hid[m], k4[0], fmaf(hid[m + 1], k4[1], fmaf(hid[m + 2], k4[2], fmaf(hid[m + 3], k4[3], acc))));
         }
         r[j] = fminf(fmaxf(acc, 0.f), 6.f);
       }
