@@ -78,7 +78,12 @@ class CARHyNet(nn.Module):
             full = torch.zeros(o, kpad, dtype=torch.float64)
             full[:, :k] = wk.reshape(o, k)
             wp = hip.pack_conv3_fragments(w).to(dev) if (i % 16 == 0 and o % 32 == 0) else None   # fragment order of gims_ch_conv_block
-            return dict(w=hip.split_spl32(f32(full)), b=f32(sd[p + "bias"]), kpad=kpad, n=o, wp=wp)
+            wp16 = None
+            if i < 16 and o % 32 == 0:                # the first layer: input channels zero-padded to one 16-channel K step
+                w16 = torch.zeros(o, 16, 3, 3, dtype=torch.float64)
+                w16[:, :i] = w
+                wp16 = hip.pack_conv3_fragments(w16).to(dev)
+            return dict(w=hip.split_spl32(f32(full)), b=f32(sd[p + "bias"]), kpad=kpad, n=o, wp=wp, wp16=wp16)
 
         def frn(p, cpad=None):
             c = sd[p + "weight"].numel()
@@ -220,7 +225,12 @@ class CARHyNet(nn.Module):
         P = self._prepare(patches.device)
         n = patches.shape[0]
         L = P["l1"]
-        if self.fused_frn:
+        if self.fused_conv and self.fused_frn and self.fused_sandglass:
+            # the whole first layer in one per-patch kernel (gims_ch_conv_block_first)
+            xs = hip.ch_conv_block_first(patches.contiguous(), L["frn0"], L["tau0"], L["conv"], L["frn"], L["tau"], L["ca"],
+                                         self._spl(n * 1024, 32, patches.device))
+            y1 = None
+        elif self.fused_frn:
             # FRN(3) + TLU(3) and the first convolution's operand rows in one per-patch kernel (gims_ch_input_block)
             cols = hip.ch_input_block(patches.contiguous(), L["frn0"], L["tau0"], torch.empty((n * 1024, 2 * L["conv"]["kpad"]), dtype=torch.bfloat16, device=patches.device))
             y1 = torch.empty((n * 1024, L["conv"]["n"]), dtype=torch.float32, device=patches.device)
@@ -231,7 +241,8 @@ class CARHyNet(nn.Module):
             x[..., :3] = patches
             x = self._frn_tlu(x, L["frn0"], L["tau0"])
             y1 = self._conv3_im2col(x, L["conv"], 1)
-        xs = self._frn_tlu(y1, L["frn"], L["tau"], L["ca"], split=True)
+        if y1 is not None:
+            xs = self._frn_tlu(y1, L["frn"], L["tau"], L["ca"], split=True)
         L = P["l2"]
         dev = patches.device
         if self.fused_conv and self.fused_frn and self.fused_sandglass:

@@ -431,15 +431,22 @@ struct ConvGeom {
   static constexpr int FRN_FLOATS = NPIX * COUT + (NT / COUT) * COUT + COUT + 2 * HOUT * COUT + 16 * HOUT;
   static constexpr int LDS_BYTES = IN_BYTES > FRN_FLOATS * 4 ? IN_BYTES : FRN_FLOATS * 4;
   static_assert(MB * NB == WAVES * MBW * NBW, "blocks divide over the waves");
-  __device__ static __forceinline__ int swz(int q) { return CIN == 32 ? ((q >> 1) & 7) : (q & 15); }
+  static constexpr int HB = (CIN < 32 ? CIN : 32) / 8;                 // 16-byte chunks per plane of a channel block (32-channel blocks; 16 for the first layer)
+  __device__ static __forceinline__ int swz(int q) { return CIN == 16 ? ((q >> 2) & 3) : (CIN == 32 ? ((q >> 1) & 7) : (q & 15)); }
+  // hi chunk of channels [16 ks + 8 lh, +8) inside the pixel record; the lo chunk is HB further
+  __device__ static __forceinline__ int chunk(int ks, int lh) { return (ks / (HB / 2)) * (2 * HB) + 2 * (ks % (HB / 2)) + lh; }
 };
+struct ChFirst { const float* fw0; const float* fb0; const float* tau0; float eps0; };   // FRN(3) + TLU(3) in front of the first convolution
 
-template <int CIN, int COUT, int HIN, int STRIDE>
+// FIRST (layer 1, models.py:316-323): xin is the raw f32 patch [32*32][3]; FRN(3) + TLU(3) run here and the result is written
+// into the LDS image as 16-channel split-bf16 pixel records (channels 3-15 zero) -- no operand rows through HBM at all.
+template <int CIN, int COUT, int HIN, int STRIDE, bool FIRST = false>
 __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __restrict__ xin, int64_t ldx, const uint16_t* __restrict__ wpk,
                                                             const float* __restrict__ bias, const float* __restrict__ fw, const float* __restrict__ fb, float eps,
                                                             ChGateW g, const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp,
-                                                            int64_t ldsp) {
+                                                            int64_t ldsp, ChFirst first) {
   using G = ConvGeom<CIN, COUT, HIN, STRIDE>;
+  static_assert(!FIRST || (CIN == 16 && HIN == 32 && STRIDE == 1), "the first layer is 32x32x3 -> 16-channel records");
   constexpr int NT = G::NT, ZQ = G::ZQ, PXB = G::PXB, CPP = G::CPP, HOUT = G::HOUT, MBW = G::MBW, NBW = G::NBW, KS = G::KS, NB = G::NB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* img = (char*)lds;
@@ -450,7 +457,47 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
 
   // ---- input patch -> LDS (swizzled chunks) + ONE all-zero pixel record that every out-of-image tap reads (no border in LDS:
   // the 16x16x64 and 8x8x128 layers then fit two / three workgroups per CU)
-  {
+  if (FIRST) {
+    float* yb = lds + (G::IN_BYTES + 255) / 256 * 64;            // raw patch [1024][4] behind the image (the LDS block is sized for the FRN stage)
+    float* red = yb + 4096;                                       // [8 waves][4]
+    float* sc0 = red + 32;
+    if (t < CPP) *(uint4*)(img + ZQ * PXB + t * 16) = make_uint4(0u, 0u, 0u, 0u);
+    const float* pp = (const float*)xin + patch * 3072;
+    float q3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pix = t + NT * u;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { const float v = pp[pix * 3 + c]; yb[pix * 4 + c] = v; q3[c] = fmaf(v, v, q3[c]); }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q3[c] = wave_sum(q3[c]);
+    if (lane == 0) { red[wave * 4] = q3[0]; red[wave * 4 + 1] = q3[1]; red[wave * 4 + 2] = q3[2]; }
+    __syncthreads();
+    if (t < 3) {
+      float sq = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) sq += red[w8 * 4 + t];
+      sc0[t] = first.fw0[t] * rsqrtf(sq / 1024.f + first.eps0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = t + NT * u, sw = G::swz(q);
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = fmaxf(fmaf(yb[q * 4 + c], sc0[c], first.fb0[c]), first.tau0[c]);
+      v[3] = 0.f;
+      const uint32_t h01 = pack_bf2(v[0], v[1]), h23 = pack_bf2(v[2], 0.f);
+      const uint32_t l01 = pack_bf2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
+      const uint32_t l23 = pack_bf2(v[2] - __uint_as_float(h23 << 16), 0.f);
+      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+      *(uint4*)(img + q * PXB + ((0 ^ sw) * 16)) = make_uint4(h01, h23, 0u, 0u);      // hi, channels 0-7
+      *(uint4*)(img + q * PXB + ((1 ^ sw) * 16)) = z;                                  // hi, channels 8-15
+      *(uint4*)(img + q * PXB + ((2 ^ sw) * 16)) = make_uint4(l01, l23, 0u, 0u);      // lo, channels 0-7
+      *(uint4*)(img + q * PXB + ((3 ^ sw) * 16)) = z;
+    }
+  } else {
     if (t < CPP) *(uint4*)(img + ZQ * PXB + t * 16) = make_uint4(0u, 0u, 0u, 0u);
     const uint16_t* src = xin + patch * (HIN * HIN) * ldx;
     constexpr int TOT = HIN * HIN * CPP;
@@ -501,7 +548,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   auto compute = [&](int step, const bf16x8 (&h)[NBW], const bf16x8 (&l)[NBW]) __attribute__((always_inline)) {
     const int tap = step / KS, ks = step % KS;
     const int ky = tap / 3, kx = tap % 3;
-    const int chunk = (ks >> 1) * 8 + 2 * (ks & 1) + lh;          // hi chunk of channels [16 ks + 8 lh, +8); lo = chunk + 4
+    const int chunk = G::chunk(ks, lh);                           // hi chunk of channels [16 ks + 8 lh, +8); lo = chunk + HB
     bf16x8 ah[MBW], al[MBW];
 #pragma unroll
     for (int m = 0; m < MBW; ++m) {
@@ -509,7 +556,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
       const int q = ((unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN) ? iy * HIN + ix : ZQ;
       const int sw = G::swz(q);
       ah[m] = *(const bf16x8*)(img + q * PXB + ((chunk ^ sw) * 16));
-      al[m] = *(const bf16x8*)(img + q * PXB + (((chunk + 4) ^ sw) * 16));
+      al[m] = *(const bf16x8*)(img + q * PXB + (((chunk + G::HB) ^ sw) * 16));
     }
 #pragma unroll
     for (int m = 0; m < MBW; ++m)
@@ -527,7 +574,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   // register ring of weight fragments, WD K steps deep: the loads of step + WD - 1 are issued before the MFMAs of step.  The
   // loop body covers UNR steps (a multiple of WD, so the ring indices are compile-time constants: registers, not scratch)
   // and is NOT unrolled further: 72 unrolled steps of the 128-channel layer overflow the instruction cache.
-  constexpr int WD = KS == 2 ? 3 : 4, UNR = KS == 2 ? 6 : KS;
+  constexpr int WD = KS <= 2 ? 3 : 4, UNR = KS == 1 ? 9 : (KS == 2 ? 6 : KS);
   static_assert(STEPS % UNR == 0 && UNR % WD == 0, "ring geometry");
   bf16x8 rh[WD][NBW], rl[WD][NBW];
 #pragma unroll
@@ -878,20 +925,36 @@ extern "C" int gims_ch_frn_block(const float* x, int64_t patches, int32_t hw, in
   return GIMS_OK;
 }
 
-template <int CIN, int COUT, int HIN, int STRIDE>
+template <int CIN, int COUT, int HIN, int STRIDE, bool FIRST = false>
 static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, const uint16_t* w, const float* bias, const float* fw, const float* fb, float eps,
-                             gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st) {
+                             gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st, gims::ChFirst first = {nullptr, nullptr, nullptr, 0.f}) {
   using namespace gims;
   using Geo = ConvGeom<CIN, COUT, HIN, STRIDE>;
   static bool attr = false;
   if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES));
     attr = true;
   }
-  hipLaunchKernelGGL((ch_conv_block_kernel<CIN, COUT, HIN, STRIDE>), dim3((unsigned)patches), dim3(512), Geo::LDS_BYTES, st, x, ldx, w, bias, fw, fb, eps, G, tau,
-                     y, ysp, ldsp);
+  hipLaunchKernelGGL((ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>), dim3((unsigned)patches), dim3(512), Geo::LDS_BYTES, st, x, ldx, w, bias, fw, fb, eps, G,
+                     tau, y, ysp, ldsp, first);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
+}
+
+extern "C" int gims_ch_conv_block_first(const float* patches, int64_t n, const float* frn0_weight, const float* frn0_bias, float eps0, const float* tau0,
+                                        const uint16_t* w_packed, const float* bias, const float* frn_weight, const float* frn_bias, float eps,
+                                        const float* const* gate_w, const float* tau, float* y, uint16_t* y_split, int64_t ld_split, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(patches && frn0_weight && frn0_bias && tau0 && w_packed && bias && frn_weight && frn_bias && tau && (y || y_split) && n > 0 && eps >= 0.f &&
+                     eps0 >= 0.f, "gims_ch_conv_block_first: null pointer / empty batch");
+  GIMS_CHECK_ARG(!y_split || (ld_split >= 64 && (ld_split % 4) == 0), "gims_ch_conv_block_first: split output pitch >= 64");
+  ChGateW G = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (gate_w) {
+    for (int i = 0; i < 6; ++i) GIMS_CHECK_ARG(gate_w[i] != nullptr, "gims_ch_conv_block_first: gate weight pointer %d is null", i);
+    G = ChGateW{gate_w[0], gate_w[1], gate_w[2], gate_w[3], gate_w[4], gate_w[5]};
+  }
+  return conv_block_launch<16, 32, 32, 1, true>((const uint16_t*)patches, 0, n, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split,
+                                                 (hipStream_t)stream, ChFirst{frn0_weight, frn0_bias, tau0, eps0});
 }
 
 extern "C" int gims_ch_conv_block(const uint16_t* x_split, int64_t ldx, int64_t patches, int32_t hin, int32_t cin, int32_t cout, int32_t stride,

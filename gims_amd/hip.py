@@ -114,6 +114,8 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_conv_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_ch_conv_block_first": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_sandglass": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_ch_l2norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_ch_relu6": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
@@ -736,6 +738,16 @@ def ch_conv_block(xs, n, hin, cin, cout, stride, L, F, tau, G=None, y=None, y_sp
     _check(load().gims_ch_conv_block(_p(xs), xs.stride(0), n, hin, cin, cout, stride, _p(L["wp"]), _p(L["b"]), _p(F["w"]), _p(F["b"]), float(F["eps"]), arr,
                                      _p(tau), _p(y), _p(y_split), y_split.stride(0) if y_split is not None else 0, _stream()), "gims_ch_conv_block")
     return y if y is not None else y_split
+
+
+def ch_conv_block_first(patches, F0, tau0, L, F, tau, G, y_split):
+    """Layer 1 in one kernel: patches [n, 32, 32, 3] f32 -> FRN(3) + TLU(3) -> conv 3->32 -> FRN + CoordAtt + TLU -> SPL32 rows."""
+    n = patches.shape[0]
+    arr = (C.c_void_p * 6)(*[G[k].data_ptr() for k in ("w1", "b1", "wh", "bh", "ww", "bw")]) if G is not None else None
+    _check(load().gims_ch_conv_block_first(_p(_dev(patches, torch.float32)), n, _p(F0["w"]), _p(F0["b"]), float(F0["eps"]), _p(tau0), _p(L["wp16"]), _p(L["b"]),
+                                           _p(F["w"]), _p(F["b"]), float(F["eps"]), arr, _p(tau), None, _p(y_split), y_split.stride(0), _stream()),
+           "gims_ch_conv_block_first")
+    return y_split
 
 
 def ch_sandglass(x, S, out_split):

@@ -430,6 +430,12 @@ int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, int32_t c, co
 int gims_ch_conv_block(const uint16_t* x_split, int64_t ldx, int64_t patches, int32_t hin, int32_t cin, int32_t cout, int32_t stride,
                        const uint16_t* w_packed, const float* bias, const float* frn_weight, const float* frn_bias, float eps,
                        const float* const* gate_w, const float* tau, float* y, uint16_t* y_split, int64_t ld_split, void* stream);
+/* The FIRST layer the same way (models.py:316-323): patches [n][32][32][3] f32 -> FRN(3) + TLU(3) -> 3x3 convolution 3 -> 32 (weights packed like
+ * above with the input channels zero-padded to 16) -> FRN(32) + CoordAtt + TLU, one workgroup per patch, nothing but the patch read and the result
+ * written.  Replaces gims_ch_input_block + gims_linear + gims_ch_frn_block for this layer. */
+int gims_ch_conv_block_first(const float* patches, int64_t n, const float* frn0_weight, const float* frn0_bias, float eps0, const float* tau0,
+                             const uint16_t* w_packed, const float* bias, const float* frn_weight, const float* frn_bias, float eps,
+                             const float* const* gate_w, const float* tau, float* y, uint16_t* y_split, int64_t ld_split, void* stream);
 int gims_ch_l2norm(const float* x, int64_t rows, int32_t c, float eps, float* y, void* stream);
 int gims_ch_relu6(float* x, int64_t total, void* stream);
 

@@ -56,6 +56,7 @@ def test_fused_blocks_equal_layer_by_layer():
     for fused in (True, False):
         m = _model(321)
         m.fused_sandglass = m.fused_frn = fused
+        m.fused_conv = False                        # same convolution GEMMs on both sides: this test isolates the two f32 blocks
         d, raw = m(torch.from_numpy(patches).permute(0, 3, 1, 2).cuda(), mode="train")
         outs.append((d.cpu().numpy(), raw.cpu().numpy()))
     np.testing.assert_allclose(outs[0][1], outs[1][1], atol=5e-5, rtol=1e-5)       # same f32 arithmetic, different summation orders

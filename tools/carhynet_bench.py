@@ -49,7 +49,8 @@ def main():
            "patches": a.patches, "ms_per_batch": 1e3 * dt, "dtype": "split-bf16x3 MFMA convolutions (f32-class) + f32 FRN / CoordAtt / depthwise",
            "roofline": {"bound": "mfma", "achieved": a.patches * FLOP_PER_PATCH / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": a.patches * FLOP_PER_PATCH / dt / 1e12 / 2500.0,
-                        "note": "algorithmic flops; layer-by-layer version of this row: gather-mode split-bf16 GEMM per convolution, NHWC activations in HBM, not fused across layers"},
+                        "note": "algorithmic flops (x3 MFMA passes per product: ceiling 1/3); every 3x3 convolution + its FRN (+CoordAtt) + TLU block is ONE per-patch kernel "
+                                "(implicit GEMM on the LDS-resident patch, gims_ch_conv_block); the per-patch kernels are latency-bound between their phases (one 128-148 KB workgroup per CU on the 32x32 layers)"},
            "descriptor_norm_check": float(d.norm(dim=1).mean())}
     if not a.no_cpu:
         from oracle import carhynet_oracle as CO
