@@ -668,19 +668,26 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   // ---- A: depthwise 3x3 + BN + ReLU6 from the LDS copy into registers, then over the copy.  The loop is unrolled (register
   // arrays), but the thread index is re-derived from an opaque copy every iteration: as loop invariants the compiler hoisted
   // all NQ x 9 addresses and weights and spilled 900 registers.
+  // a thread's quads all belong to ONE channel quad (NT % QPP == 0): its nine tap weights stay in registers (they were half of
+  // the LDS reads of this LDS-bandwidth-bound pass)
+  static_assert(NT % QPP == 0, "a thread keeps its channel quad");
+  float4 kw[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) kw[tap] = *(const float4*)(l_dw0 + tap * C + 4 * (t % QPP));
+  const float4 kb0 = *(const float4*)(l_dw0b + 4 * (t % QPP));
   float4 yq[NQ];
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
     int tt = t;
     asm volatile("" : "+v"(tt));
-    const int i = tt + NT * j, pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
-    float4 acc = *(const float4*)(l_dw0b + ch);
+    const int i = tt + NT * j, pix = i / QPP, cq = i % QPP, yy = pix / HW, xx = pix % HW;
+    float4 acc = kb0;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
       if (y2 < 0 || y2 >= HW || x2 < 0 || x2 >= HW) continue;
       const float4 v = *(const float4*)(ybuf + slot(y2 * HW + x2, cq));
-      const float4 k4 = *(const float4*)(l_dw0 + tap * C + ch);
+      const float4 k4 = kw[tap];
       acc.x = fmaf(v.x, k4.x, acc.x); acc.y = fmaf(v.y, k4.y, acc.y); acc.z = fmaf(v.z, k4.z, acc.z); acc.w = fmaf(v.w, k4.w, acc.w);
     }
     acc.x = fminf(fmaxf(acc.x, 0.f), 6.f); acc.y = fminf(fmaxf(acc.y, 0.f), 6.f); acc.z = fminf(fmaxf(acc.z, 0.f), 6.f); acc.w = fminf(fmaxf(acc.w, 0.f), 6.f);
@@ -760,17 +767,20 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   __syncthreads();
   // ---- D: out = 2 x + dw3x3(z) + BN, as split-bf16 pixel rows (x from the registers of step 0)
 #pragma unroll
+  for (int tap = 0; tap < 9; ++tap) kw[tap] = *(const float4*)(l_dw1 + tap * C + 4 * (t % QPP));
+  const float4 kb0d = *(const float4*)(l_dw1b + 4 * (t % QPP));
+#pragma unroll
   for (int j = 0; j < NQ; ++j) {
     int tt = t;
     asm volatile("" : "+v"(tt));
     const int i = tt + NT * j, pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
-    float4 acc = *(const float4*)(l_dw1b + ch);
+    float4 acc = kb0d;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
       if (y2 < 0 || y2 >= HW || x2 < 0 || x2 >= HW) continue;
       const float4 v = *(const float4*)(ybuf + slot(y2 * HW + x2, cq));
-      const float4 k4 = *(const float4*)(l_dw1 + tap * C + ch);
+      const float4 k4 = kw[tap];
       acc.x = fmaf(v.x, k4.x, acc.x); acc.y = fmaf(v.y, k4.y, acc.y); acc.z = fmaf(v.z, k4.z, acc.z); acc.w = fmaf(v.w, k4.w, acc.w);
     }
     const float r[4] = {fmaf(xq[j].x, 2.f, acc.x), fmaf(xq[j].y, 2.f, acc.y), fmaf(xq[j].z, 2.f, acc.z), fmaf(xq[j].w, 2.f, acc.w)};
