@@ -6,7 +6,7 @@
 // which the reference runs on one CPU core through OpenCV (README.md:151,155: 3.2-3.9 s per image at 15 k keypoints).
 //
 // The arithmetic is OpenCV's uint8 fixed-point arithmetic, restated (PARITY UNPINNED against the library itself, which is
-// absent here; bit-identical to oracle/patch_oracle.py, which restates the same published algorithms in NumPy):
+// absent here; bit-identical to the NumPy restatement of the same published algorithms that the tests hold):
 //   * 2x upsampling, INTER_LINEAR_EXACT: weights 1/4, 3/4 per direction, one rounding (half up) of the 16ths;
 //   * Gaussian blur on uint8: Q8.8 kernel with error diffusion (host), row pass Q8.8, column pass Q16.16, one rounding,
 //     BORDER_REFLECT_101;
