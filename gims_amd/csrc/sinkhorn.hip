@@ -39,6 +39,15 @@ struct OtDev {
   float norm, log_mu_bin, log_nu_bin;  // norm = -log(n+m); log(m)+norm; log(n)+norm
 };
 
+struct OtBwd {                    // one problem of the backward sweep
+  const float* z; int64_t ld; int n, m;
+  const float* hist; int64_t hstride;     // potentials after iteration k at hist + k * hstride: u [n+1] then v [m+1]; k = 0 .. iters (slot 0 unused)
+  float* dz;                               // [(n+1)][(m+1)], holds G on entry, dL/dZc on exit
+  float* gu; float* gv; float* gv2;        // [n+1], [m+1], [m+1]
+  float* dalpha;
+  float norm, log_mu_bin, log_nu_bin;
+};
+
 // Reduce R (= 8, 4 or 2) per-lane values over the 64 lanes of a wave with a reduce-scatter butterfly:
 // log2(R) exchange steps halve the number of live values, the rest fold the single survivor -- R-1 + (6-log2 R)
 // cross-lane moves instead of 6*R.  On return lane l holds the total of row
@@ -495,6 +504,121 @@ __global__ __launch_bounds__(1024) void train_loss_reduce_kernel(const float* __
     const float pl = pos_w * (ps / (float)n_pairs), nl = neg_w * (ns / (float)n_pairs);
     out3[0] = pl + nl; out3[1] = pl; out3[2] = nl;
   }
+}
+
+// ---------------------------------------------------------------------------------------------- backward through the Sinkhorn iterations
+// d loss / d scores and d loss / d bin_score for forward_train: reverse mode through the UNROLLED iterations of
+// log_sinkhorn_iterations (gmatcher.py:41-47), which is what autograd does in the reference.  With Zc the (n+1) x (m+1)
+// couplings (scores + the alpha border), out = Zc + u_I + v_I - norm and
+//     u_k = log mu - LSE_j(Zc + v_{k-1}),      v_k = log nu - LSE_i(Zc + u_k),      u_0 = v_0 = 0,
+// the softmax weights of the two LSEs are  R^k_ij = exp(Zc_ij + u_k[i] + v_{k-1}[j] - log mu_i)  and
+// C^k_ij = exp(Zc_ij + u_k[i] + v_k[j] - log nu_j).  Reverse sweep, k = I .. 1, with gu = dL/du_k, gv = dL/dv_k:
+//     dZc -= gv[j] C^k_ij ;  gu[i] -= sum_j gv[j] C^k_ij ;   then   dZc -= gu[i] R^k_ij ;  gv'[j] = - sum_i gu[i] R^k_ij
+// starting from dZc = G = dL/dout, gu = row sums of G, gv = column sums of G.  The potentials of every iteration come from
+// a recorded forward solve (gims_sinkhorn_history).  Correct-first kernels: one sweep of the matrix per half step, rows
+// by waves (column step) or columns by threads (row step); fixed summation order.
+__global__ __launch_bounds__(256) void ot_bwd_init_kernel(const OtBwd* __restrict__ probs) {
+  const OtBwd p = probs[blockIdx.y];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int ldz = p.m + 1;
+  if (t <= p.n) {                 // row sums -> gu
+    float s = 0.f;
+    for (int j = 0; j <= p.m; ++j) s += p.dz[(int64_t)t * ldz + j];
+    p.gu[t] = s;
+  }
+  if (t <= p.m) {                 // column sums -> gv
+    float s = 0.f;
+    for (int i = 0; i <= p.n; ++i) s += p.dz[(int64_t)i * ldz + t];
+    p.gv[t] = s;
+  }
+}
+
+// column step of iteration k: uses u_k, v_k.  One wave per row.
+__global__ __launch_bounds__(256) void ot_bwd_col_kernel(const OtBwd* __restrict__ probs, float alpha, int k) {
+  const OtBwd p = probs[blockIdx.y];
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row > p.n) return;
+  const float* uk = p.hist + (int64_t)k * p.hstride;
+  const float* vk = uk + p.n + 1;
+  const float ui = uk[row];
+  const int ldz = p.m + 1;
+  float acc = 0.f;
+  for (int j = lane; j <= p.m; j += 64) {
+    const float z = (row < p.n && j < p.m) ? p.z[(int64_t)row * p.ld + j] : alpha;
+    const float lognu = j < p.m ? p.norm : p.log_nu_bin;
+    const float t = p.gv[j] * __expf(z + ui + vk[j] - lognu);
+    p.dz[(int64_t)row * ldz + j] -= t;
+    acc += t;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) p.gu[row] -= acc;
+}
+
+// row step of iteration k: uses u_k, v_{k-1} (v_0 = 0).  One thread per column; writes gv' (the gradient w.r.t. v_{k-1}).
+__global__ __launch_bounds__(256) void ot_bwd_row_kernel(const OtBwd* __restrict__ probs, float alpha, int k) {
+  const OtBwd p = probs[blockIdx.y];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > p.m) return;
+  const float* uk = p.hist + (int64_t)k * p.hstride;
+  const float* vprev = p.hist + (int64_t)(k - 1) * p.hstride + p.n + 1;
+  const float vj = k > 1 ? vprev[j] : 0.f;
+  const int ldz = p.m + 1;
+  float acc = 0.f;
+  for (int i = 0; i <= p.n; ++i) {
+    const float z = (i < p.n && j < p.m) ? p.z[(int64_t)i * p.ld + j] : alpha;
+    const float logmu = i < p.n ? p.norm : p.log_mu_bin;
+    const float t = p.gu[i] * __expf(z + uk[i] + vj - logmu);
+    p.dz[(int64_t)i * ldz + j] -= t;
+    acc += t;
+  }
+  p.gv2[j] = -acc;
+}
+
+// after a row step: gv <- gv', gu <- 0   (and after a column step gv is dead: it is overwritten here)
+__global__ __launch_bounds__(256) void ot_bwd_swap_kernel(const OtBwd* __restrict__ probs) {
+  const OtBwd p = probs[blockIdx.y];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t <= p.m) p.gv[t] = p.gv2[t];
+  if (t <= p.n) p.gu[t] = 0.f;
+}
+
+// d alpha = sum of dZc over the border cells (dustbin row, dustbin column, corner once)
+__global__ __launch_bounds__(256) void ot_bwd_alpha_kernel(const OtBwd* __restrict__ probs) {
+  const OtBwd p = probs[blockIdx.x];
+  __shared__ float red[4];
+  const int ldz = p.m + 1;
+  float s = 0.f;
+  for (int j = threadIdx.x; j <= p.m; j += 256) s += p.dz[(int64_t)p.n * ldz + j];
+  for (int i = threadIdx.x; i < p.n; i += 256) s += p.dz[(int64_t)i * ldz + p.m];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) p.dalpha[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// G = dL/dout scattered into the zeroed dZc: the loss is  sum_b [ w_pos/(B cnt_pos_b) sum_pos (-x) + w_neg/(B cnt_neg_b) sum_neg (-x) ]
+// with x = clamp(out, -100, 0): d/d out = -w / (B cnt) inside the clamp, 0 outside (gmatcher.py:372-385).
+__global__ void train_loss_grad_kernel(const gims_loss_pair* __restrict__ pairs, int n_pairs, const int64_t* __restrict__ gt, int K, float alpha,
+                                       const int32_t* __restrict__ tag, float pos_w, float neg_w, float* const* __restrict__ dz_ptrs) {
+  // one thread per ground-truth row; counts per (batch element, sign) are recomputed by a loop over the tags (K <= a few thousand)
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int32_t t = tag[k];
+  if (t < 0) return;
+  const int b = t & 0x3fffffff;
+  const bool neg = (t & 0x40000000) != 0;
+  int cnt = 0;
+  for (int q = 0; q < K; ++q) cnt += (tag[q] == t) ? 1 : 0;
+  const gims_loss_pair p = pairs[b];
+  int r0 = p.n, r1 = p.m;                                   // negatives: the corner cell
+  if (!neg) { r0 = kept_find(p.kept0, p.n, gt[3 * k + 1]); r1 = kept_find(p.kept1, p.m, gt[3 * k + 2]); }
+  const float norm = -logf((float)p.n + (float)p.m);
+  const float* u = p.uv;
+  const float* v = p.uv + p.n + 1;
+  const float x = neg ? ((alpha + u[p.n]) + v[p.m]) - norm : ((p.scores[(int64_t)r0 * p.ld + r1] + u[r0]) + v[r1]) - norm;
+  if (!(x > -100.f && x < 0.f)) return;                      // clamped: zero gradient (torch.clamp passes the gradient only inside)
+  const float g = -(neg ? neg_w : pos_w) / ((float)n_pairs * (float)cnt);
+  atomicAdd(dz_ptrs[b] + (int64_t)r0 * (p.m + 1) + r1, g);   // equal addends per cell group: the sum does not depend on the order
 }
 
 // ---------------------------------------------------------------------------------------------- resident Sinkhorn
@@ -1392,6 +1516,127 @@ extern "C" int gims_train_loss(const gims_loss_pair* dev_pairs, int32_t n_pairs,
   if (n_gt > 0) hipLaunchKernelGGL(train_loss_gather_kernel, dim3(cdiv(n_gt, 256)), dim3(256), 0, (hipStream_t)stream, dev_pairs, n_pairs, gt, n_gt, alpha,
                                    loss_vec, tag);
   hipLaunchKernelGGL(train_loss_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, loss_vec, tag, n_gt, n_pairs, pos_weight, neg_weight, out3);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+// ---- recorded forward solve + backward sweep (forward_train gradients w.r.t. scores and bin_score)
+namespace gims {
+static int ot_fill_common(const gims_ot_problem& q, float& norm, float& log_mu_bin, float& log_nu_bin) {
+  const float ms = (float)q.n, ns = (float)q.m;
+  norm = -logf(ms + ns);
+  log_mu_bin = logf(ns) + norm;
+  log_nu_bin = logf(ms) + norm;
+  return 0;
+}
+}  // namespace gims
+
+extern "C" size_t gims_sinkhorn_history_floats(int32_t n, int32_t m, int32_t iters) {
+  return (size_t)(iters + 1) * (size_t)(n + m + 2);
+}
+
+extern "C" int gims_sinkhorn_history(const gims_ot_problem* pr, int32_t np, float alpha, int32_t iters, float* const* h_hist, void* work,
+                                     size_t work_bytes, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(pr && np > 0 && work && h_hist && iters >= 1, "gims_sinkhorn_history: null / empty arguments");
+  GIMS_CHECK_ARG(work_bytes >= gims_sinkhorn_workspace_bytes(pr, np), "gims_sinkhorn_history: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int threads, cpt, maxn, maxm;
+  ot_launch_shape(pr, np, threads, cpt, maxn, maxm);
+  GIMS_CHECK_ARG(cpt <= 4, "gims_sinkhorn_history: m=%d too large (max 16384)", maxm);
+  std::vector<OtDev> hprob(np);
+  char* base = (char*)work;
+  size_t off = al256(sizeof(OtDev) * (size_t)np);
+  int maxG = 0;
+  for (int i = 0; i < np; ++i) {
+    const gims_ot_problem& q = pr[i];
+    GIMS_CHECK_ARG(q.n > 0 && q.m > 0 && q.scores && q.uv && h_hist[i], "gims_sinkhorn_history: problem %d has empty shape or null pointer", i);
+    GIMS_CHECK_ARG((q.ld % 4) == 0 && (((uintptr_t)q.scores) & 15) == 0, "gims_sinkhorn_history: scores must be 16-byte aligned with ld %% 4 == 0");
+    OtDev d{};
+    d.z = q.scores; d.ld = q.ld; d.n = q.n; d.m = q.m;
+    d.u = q.uv; d.v = q.uv + q.n + 1; d.status = q.uv + q.n + 1 + q.m + 1;
+    d.G = ot_G(q.n, np, threads, cpt);
+    maxG = d.G > maxG ? d.G : maxG;
+    d.partial = (float*)(base + off); off += al256((size_t)d.G * (q.m + 1) * 4);
+    d.cbest_val = nullptr; d.cbest_idx = nullptr; d.max0 = nullptr; d.idx0 = nullptr; d.max1 = nullptr; d.idx1 = nullptr;
+    d.matches0 = nullptr; d.matches1 = nullptr; d.mscores0 = nullptr; d.mscores1 = nullptr;
+    ot_fill_common(q, d.norm, d.log_mu_bin, d.log_nu_bin);
+    hprob[i] = d;
+  }
+  const int rc = upload_table(hprob.data(), sizeof(OtDev) * (size_t)np, work, s);
+  if (rc != GIMS_OK) return rc;
+  const OtDev* dp = (const OtDev*)work;
+  hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, 0);
+  dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
+  for (int it = 0; it < iters; ++it) {        // the streamed kernels, one iteration at a time, potentials copied out after each
+    if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha);
+    else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha);
+    else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha);
+    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp);
+    for (int i = 0; i < np; ++i) {
+      const size_t hs = (size_t)(pr[i].n + pr[i].m + 2);
+      GIMS_HIP(hipMemcpyAsync(h_hist[i] + (size_t)(it + 1) * hs, pr[i].uv, hs * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+  }
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" size_t gims_sinkhorn_backward_workspace_bytes(const gims_ot_problem* pr, int32_t np) {
+  using namespace gims;
+  if (!pr || np <= 0) return 0;
+  size_t b = al256(sizeof(OtBwd) * (size_t)np);
+  for (int i = 0; i < np; ++i) b += al256((size_t)(pr[i].n + 1) * 4) + 2 * al256((size_t)(pr[i].m + 1) * 4);
+  return b;
+}
+
+extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, float alpha, int32_t iters, const float* const* h_hist,
+                                      float* const* h_dz, float* dalpha /* device [np] */, void* work, size_t work_bytes, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(pr && np > 0 && h_hist && h_dz && dalpha && work && iters >= 1, "gims_sinkhorn_backward: null / empty arguments");
+  GIMS_CHECK_ARG(work_bytes >= gims_sinkhorn_backward_workspace_bytes(pr, np), "gims_sinkhorn_backward: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<OtBwd> hp(np);
+  char* base = (char*)work;
+  size_t off = al256(sizeof(OtBwd) * (size_t)np);
+  int maxn = 0, maxm = 0;
+  for (int i = 0; i < np; ++i) {
+    const gims_ot_problem& q = pr[i];
+    GIMS_CHECK_ARG(q.n > 0 && q.m > 0 && q.scores && h_hist[i] && h_dz[i], "gims_sinkhorn_backward: problem %d has empty shape or null pointer", i);
+    OtBwd b{};
+    b.z = q.scores; b.ld = q.ld; b.n = q.n; b.m = q.m;
+    b.hist = h_hist[i]; b.hstride = q.n + q.m + 2;
+    b.dz = h_dz[i];
+    b.gu = (float*)(base + off); off += al256((size_t)(q.n + 1) * 4);
+    b.gv = (float*)(base + off); off += al256((size_t)(q.m + 1) * 4);
+    b.gv2 = (float*)(base + off); off += al256((size_t)(q.m + 1) * 4);
+    b.dalpha = dalpha + i;
+    ot_fill_common(q, b.norm, b.log_mu_bin, b.log_nu_bin);
+    hp[i] = b;
+    maxn = q.n > maxn ? q.n : maxn; maxm = q.m > maxm ? q.m : maxm;
+  }
+  const int rc = upload_table(hp.data(), sizeof(OtBwd) * (size_t)np, work, s);
+  if (rc != GIMS_OK) return rc;
+  const OtBwd* dp = (const OtBwd*)work;
+  const int mx = maxn > maxm ? maxn : maxm;
+  hipLaunchKernelGGL(ot_bwd_init_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
+  for (int k = iters; k >= 1; --k) {
+    hipLaunchKernelGGL(ot_bwd_col_kernel, dim3(cdiv(maxn + 1, 4), np), dim3(256), 0, s, dp, alpha, k);
+    hipLaunchKernelGGL(ot_bwd_row_kernel, dim3(cdiv(maxm + 1, 256), np), dim3(256), 0, s, dp, alpha, k);
+    hipLaunchKernelGGL(ot_bwd_swap_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
+  }
+  hipLaunchKernelGGL(ot_bwd_alpha_kernel, dim3(np), dim3(256), 0, s, dp);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_train_loss_grad(const gims_loss_pair* dev_pairs, int32_t n_pairs, const int64_t* gt, int32_t n_gt, float alpha, const int32_t* tag,
+                                    float pos_weight, float neg_weight, float* const* dev_dz_ptrs, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(dev_pairs && n_pairs > 0 && dev_dz_ptrs && n_gt >= 0 && (n_gt == 0 || (gt && tag)), "gims_train_loss_grad: bad arguments");
+  if (n_gt > 0)
+    hipLaunchKernelGGL(train_loss_grad_kernel, dim3(cdiv(n_gt, 256)), dim3(256), 0, (hipStream_t)stream, dev_pairs, n_pairs, gt, n_gt, alpha, tag, pos_weight,
+                       neg_weight, dev_dz_ptrs);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

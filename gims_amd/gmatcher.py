@@ -703,6 +703,19 @@ class GMatcher(nn.Module):
                                  self._packed(dev)["alpha"], self.config['pos_loss_weight'], self.config['neg_loss_weight'])
         return out3[0], out3[1], out3[2]
 
+    @torch.no_grad()
+    def loss_and_score_gradients(self, data):
+        """``forward(data, mode='train')`` plus the first stage of its backward pass: the gradient of the loss
+        with respect to the score matrix of every pair and to ``bin_score``, by reverse mode through the unrolled Sinkhorn
+        iterations (what autograd does in the reference, gmatcher.py:41-69, 372-385).  Returns
+        ``{'loss', 'pos_loss', 'neg_loss', 'dscores': [per pair, (n_kept0, n_kept1)], 'dbin_score'}``.  The rest of the backward
+        pass (final projection, attention layers, encoders) is not built."""
+        loss, pos, neg = self.forward(data, mode="train")
+        items = self._last["items"]
+        dscores, dalpha = hip.sinkhorn_score_gradients(items, self._packed(items[0]["scores"].device)["alpha"], self.config['sinkhorn_iterations'],
+                                                       self.config['pos_loss_weight'], self.config['neg_loss_weight'], hip.train_loss.last)
+        return {"loss": loss, "pos_loss": pos, "neg_loss": neg, "dscores": dscores, "dbin_score": dalpha}
+
     # ------------------------------------------------------------------ ragged batch of independent pairs
     @torch.no_grad()
     def match_pairs(self, datas: List[dict], **kwargs):

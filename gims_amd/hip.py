@@ -165,6 +165,12 @@ _SIGNATURES = {
                                       C.POINTER(C.c_size_t)]),
     "gims_pyramid_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gims_patch_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gims_sinkhorn_history_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "gims_sinkhorn_history": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gims_sinkhorn_backward_workspace_bytes": (C.c_size_t, [C.POINTER(OtProblem), C.c_int32]),
+    "gims_sinkhorn_backward": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
+    "gims_train_loss_grad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_train_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "gims_ot_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
@@ -788,7 +794,34 @@ def train_loss(items, kept0, kept1, gt: torch.Tensor, alpha: float, pos_weight: 
     out3 = torch.empty(3, dtype=torch.float32, device=dev)
     _check(load().gims_train_loss(_p(tab), B, _p(gt), K, float(alpha), float(pos_weight), float(neg_weight), _p(loss_vec), _p(tag), _p(out3),
                                   _stream()), "gims_train_loss")
+    train_loss.last = dict(table=tab, tag=tag, gt=gt, K=K, B=B)          # what the gradient entry points need again
     return out3, loss_vec[:K]
+
+
+def sinkhorn_score_gradients(items, alpha: float, iters: int, pos_weight: float, neg_weight: float, loss_state):
+    """d loss / d scores (list of [n, m] views with pitch m + 1) and d loss / d bin_score (0-dim tensor) for the loss of
+    ``train_loss`` (whose ``last`` state is passed in): a recorded streamed forward solve (gims_sinkhorn_history), the loss
+    gradient scattered into zeroed (n+1) x (m+1) buffers (gims_train_loss_grad), the reverse sweep through the unrolled
+    iterations (gims_sinkhorn_backward)."""
+    lib = load()
+    dev = items[0]["scores"].device
+    probs = make_ot_problems(items)
+    work = torch.empty(sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device=dev)
+    hists = [torch.zeros(int(lib.gims_sinkhorn_history_floats(it["n"], it["m"], iters)), dtype=torch.float32, device=dev) for it in items]
+    hp = (C.c_void_p * len(items))(*[h.data_ptr() for h in hists])
+    _check(lib.gims_sinkhorn_history(probs, len(items), float(alpha), int(iters), hp, _p(work), work.numel(), _stream()), "gims_sinkhorn_history")
+    dzs = [torch.zeros((it["n"] + 1, it["m"] + 1), dtype=torch.float32, device=dev) for it in items]
+    import numpy as np
+    dz_tab = upload(np.asarray([d.data_ptr() for d in dzs], dtype=np.int64), dev)
+    st = loss_state
+    _check(lib.gims_train_loss_grad(_p(st["table"]), st["B"], _p(st["gt"]), st["K"], float(alpha), _p(st["tag"]), float(pos_weight), float(neg_weight),
+                                    _p(dz_tab), _stream()), "gims_train_loss_grad")
+    bw = torch.empty(int(lib.gims_sinkhorn_backward_workspace_bytes(probs, len(items))), dtype=torch.uint8, device=dev)
+    dalpha = torch.empty(len(items), dtype=torch.float32, device=dev)
+    dp = (C.c_void_p * len(items))(*[d.data_ptr() for d in dzs])
+    _check(lib.gims_sinkhorn_backward(probs, len(items), float(alpha), int(iters), hp, dp, _p(dalpha), _p(bw), bw.numel(), _stream()),
+           "gims_sinkhorn_backward")
+    return [d[:it["n"], :it["m"]] for d, it in zip(dzs, items)], dalpha.sum()
 
 
 def pyramid_layout(h: int, w: int, c: int = 3):

@@ -372,6 +372,25 @@ typedef struct gims_loss_pair {
 int gims_train_loss(const gims_loss_pair* dev_pairs /* DEVICE array */, int32_t n_pairs, const int64_t* gt, int32_t n_gt, float alpha,
                     float pos_weight, float neg_weight, float* loss_vec, int32_t* tag, float* out3, void* stream);
 
+/* Backward of that loss through the Sinkhorn iterations (first differentiable kernel): d loss / d scores and
+ * d loss / d bin_score, by reverse mode through the UNROLLED iterations of log_sinkhorn_iterations (gmatcher.py:41-47) -- what
+ * autograd does in the reference.
+ *   gims_sinkhorn_history: a forward solve with the streamed kernels that records the potentials after every iteration:
+ *     h_hist[p] (HOST array of device pointers) receives (iters + 1) slots of n + m + 2 floats (u [n+1] then v [m+1]); slot 0 is
+ *     unused (u_0 = v_0 = 0), slot k holds u_k, v_k.  problems[p].uv ends with the final potentials as in gims_sinkhorn_match.
+ *   gims_train_loss_grad: scatters G = d loss / d out (out = Zc + u + v - norm at the gathered cells; zero where the clamp was
+ *     active, gmatcher.py:374) into ZEROED per-problem buffers dz[p] [(n+1)][(m+1)]; `tag` is gims_train_loss's scratch output.
+ *   gims_sinkhorn_backward: dz[p] holds G on entry and d loss / d Zc on exit (rows 0..n-1, columns 0..m-1 = d loss / d scores,
+ *     pitch m + 1); dalpha[p] = the sum over the dustbin border = that problem's share of d loss / d bin_score. */
+size_t gims_sinkhorn_history_floats(int32_t n, int32_t m, int32_t iters);
+int gims_sinkhorn_history(const gims_ot_problem* h_problems, int32_t n_problems, float alpha, int32_t iters, float* const* h_hist /* HOST array */,
+                          void* work /* gims_sinkhorn_workspace_bytes */, size_t work_bytes, void* stream);
+size_t gims_sinkhorn_backward_workspace_bytes(const gims_ot_problem* h_problems, int32_t n_problems);
+int gims_sinkhorn_backward(const gims_ot_problem* h_problems, int32_t n_problems, float alpha, int32_t iters, const float* const* h_hist /* HOST array */,
+                           float* const* h_dz /* HOST array */, float* dalpha /* device [n_problems] */, void* work, size_t work_bytes, void* stream);
+int gims_train_loss_grad(const gims_loss_pair* dev_pairs, int32_t n_pairs, const int64_t* gt, int32_t n_gt, float alpha, const int32_t* tag,
+                         float pos_weight, float neg_weight, float* const* dev_dz_ptrs /* DEVICE array */, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * CAR-HyNet patch descriptor: the non-GEMM layers of carhynet/models.py:311-399.  Activations are NHWC
  * f32 ([patch][y][x][channel]); the 3x3 and 8x8 convolutions are gims_ch_im2col3 / a reshape + gims_linear (split-bf16x3),

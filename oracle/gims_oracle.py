@@ -500,7 +500,12 @@ def gmatcher_forward(sd, data: dict, config: dict | None = None, stages: dict | 
     mdesc0, mdesc1 = F.conv1d(gd0, fw, fb), F.conv1d(gd1, fw, fb)
     scores = torch.einsum("bdn,bdm->bnm", mdesc0, mdesc1)
     scores = scores / cfg["descriptor_dim"] ** 0.5
-    ot = log_optimal_transport(scores, _t(sd, "bin_score").float(), iters=cfg["sinkhorn_iterations"])
+    alpha = _t(sd, "bin_score").float()
+    if stages is not None and stages.get("grad_scores"):        # leaves for autograd: d loss / d scores, d loss / d bin_score
+        scores = scores.detach().requires_grad_(True)
+        alpha = alpha.detach().clone().requires_grad_(True)
+        stages["scores_leaf"], stages["alpha_leaf"] = scores, alpha
+    ot = log_optimal_transport(scores, alpha, iters=cfg["sinkhorn_iterations"])
     if mode == "train":
         return train_loss(ot, data["matches"], data["kept_kpts0_indices"], data["kept_kpts1_indices"], data["image0"].shape[0],
                           cfg["pos_loss_weight"], cfg["neg_loss_weight"])

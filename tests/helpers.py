@@ -60,3 +60,22 @@ def train_data(pairs, g, device="cpu"):
     data["image1"] = np.concatenate([p["image1"] for p in pairs])
     data["matches"] = torch.from_numpy(g["matches"]).to(device)
     return data
+
+
+def check_score_gradients(g, dscores, dbin, n_pairs, rtol):
+    """d loss / d scores and d loss / d bin_score against what the reference's autograd produced (trainloss_* fixtures):
+    dense matrices where the fixture holds them, a fixed sample of cells + row / column sums otherwise.  rtol is relative
+    to the largest gradient entry of the pair."""
+    for b in range(n_pairs):
+        d = np.asarray(dscores[b], dtype=np.float64)
+        scale = float(g[f"dscores_absmax_{b}"])
+        assert scale > 0
+        if f"dscores_{b}" in g:
+            assert d.shape == g[f"dscores_{b}"].shape
+            err = np.abs(d - g[f"dscores_{b}"]).max()
+        else:
+            err = np.abs(d.reshape(-1)[g[f"dscores_sample_idx_{b}"]] - g[f"dscores_sample_{b}"]).max()
+        assert err <= rtol * scale, (b, err, scale)
+        np.testing.assert_allclose(d.sum(1), g[f"dscores_rowsum_{b}"], atol=8 * rtol * scale, rtol=0)
+        np.testing.assert_allclose(d.sum(0), g[f"dscores_colsum_{b}"], atol=8 * rtol * scale, rtol=0)
+    assert abs(float(dbin) - float(g["dbin_score"])) <= rtol * max(abs(float(g["dbin_score"])), 1e-3), (float(dbin), float(g["dbin_score"]))

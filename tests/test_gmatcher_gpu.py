@@ -9,7 +9,7 @@ import torch
 
 from gims_amd import GMatcher, Matching, synth
 from oracle import gims_oracle as O
-from tests.helpers import golden_names, load_golden, pair_to_data, safe_rows, train_data, train_pairs
+from tests.helpers import check_score_gradients, golden_names, load_golden, pair_to_data, safe_rows, train_data, train_pairs
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -429,3 +429,24 @@ def test_dense_keypoints_grow_the_graph_capacity(synth_sd):
     # the next call starts with the grown capacity: no second build
     out2 = m(pair_to_data(pair, 25, 7, 8, device="cuda"))
     np.testing.assert_array_equal(out2["matches0"].cpu().numpy(), out["matches0"].cpu().numpy())
+
+
+@pytest.mark.parametrize("name", golden_names("trainloss_"))
+def test_train_loss_score_gradients_vs_reference_golden(synth_sd, name):
+    """First stage of the backward pass: d loss / d scores and d loss / d bin_score from gims_sinkhorn_backward
+    (reverse mode through the unrolled Sinkhorn iterations) against the reference's own autograd."""
+    g = load_golden(name)
+    pairs = train_pairs(name, g)
+    m = GMatcher({"sinkhorn_iterations": int(g["meta"][4]), "pos_loss_weight": float(g["pos_loss_weight"]),
+                  "neg_loss_weight": float(g["neg_loss_weight"])}).eval()
+    m.load_state_dict(synth_sd)
+    out = m.loss_and_score_gradients(train_data(pairs, g, device="cuda"))
+    np.testing.assert_allclose(float(out["loss"]), float(g["loss"]), atol=1e-4, rtol=0)
+    ds = [d.cpu().numpy() for d in out["dscores"]]
+    errs = []
+    for b in range(len(pairs)):
+        ref = g[f"dscores_{b}"] if f"dscores_{b}" in g else None
+        if ref is not None:
+            errs.append(float(np.abs(ds[b] - ref).max() / g[f"dscores_absmax_{b}"]))
+    print(name, "relative gradient errors", errs, "dbin", float(out["dbin_score"]), float(g["dbin_score"]))
+    check_score_gradients(g, ds, out["dbin_score"].cpu(), len(pairs), rtol=2e-3)

@@ -6,7 +6,7 @@ import torch
 
 from gims_amd import synth
 from oracle import gims_oracle as O
-from tests.helpers import golden_names, load_golden, pair_to_data, train_data, train_pairs
+from tests.helpers import check_score_gradients, golden_names, load_golden, pair_to_data, train_data, train_pairs
 
 torch.set_grad_enabled(False)
 
@@ -142,3 +142,17 @@ def test_train_loss_forward_vs_reference(synth_sd, name):
     for b in range(len(pairs)):
         np.testing.assert_array_equal(np.asarray(data["kept_kpts0_indices"][b]), g[f"kept0_{b}"])
     np.testing.assert_allclose([float(loss), float(pos), float(neg)], [g["loss"], g["pos"], g["neg"]], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("trainloss_") if "n1024_s1000" not in n])
+def test_train_loss_score_gradients_vs_reference(synth_sd, name):
+    """d loss / d scores and d loss / d bin_score by autograd through the oracle's unrolled Sinkhorn == the reference's autograd."""
+    g = load_golden(name)
+    pairs = train_pairs(name, g)
+    data = train_data(pairs, g)
+    cfg = {"sinkhorn_iterations": int(g["meta"][4]), "pos_loss_weight": float(g["pos_loss_weight"]), "neg_loss_weight": float(g["neg_loss_weight"])}
+    st = {"grad_scores": True}
+    with torch.enable_grad():
+        loss, _, _ = O.gmatcher_forward(synth_sd, data, cfg, stages=st, mode="train")
+        loss.backward()
+    check_score_gradients(g, [st["scores_leaf"].grad[b].numpy() for b in range(len(pairs))], st["alpha_leaf"].grad, len(pairs), rtol=2e-3)

@@ -42,12 +42,40 @@ def one(name, model, pairs, rad, pct, ms, iters):
     data["image1"] = np.concatenate([p["image1"] for p in pairs])
     matches = np.concatenate([matches_of(b, p["gt_perm"], p["keypoints1"].shape[1]) for b, p in enumerate(pairs)])
     data["matches"] = torch.from_numpy(matches)
-    with G.quiet():
-        loss, pos, neg = model(data, mode="train")
+    # the gradient of the loss w.r.t. the score matrix and bin_score, by the reference's own autograd through its unrolled
+    # Sinkhorn iterations: log_optimal_transport's input is tapped and keeps its gradient
+    cap = {}
+    orig = G.RG.log_optimal_transport
+
+    def spy(scores, alpha, iters):
+        scores.retain_grad()
+        cap["scores"] = scores
+        return orig(scores, alpha, iters)
+    G.RG.log_optimal_transport = spy
+    try:
+        with G.quiet(), torch.enable_grad():
+            model.zero_grad()
+            loss, pos, neg = model(data, mode="train")
+            loss.backward()
+    finally:
+        G.RG.log_optimal_transport = orig
+    loss, pos, neg = loss.detach(), pos.detach(), neg.detach()
+    dsc = cap["scores"].grad.numpy()                     # (B, n_kept0, n_kept1)
+    dbin = float(model.bin_score.grad)
+    grads = {"dbin_score": np.float64(dbin)}
+    for b in range(len(pairs)):
+        d = dsc[b]
+        grads[f"dscores_rowsum_{b}"], grads[f"dscores_colsum_{b}"] = d.sum(1).astype(np.float64), d.sum(0).astype(np.float64)
+        grads[f"dscores_absmax_{b}"] = np.float64(np.abs(d).max())
+        if d.size <= 400 * 400:
+            grads[f"dscores_{b}"] = d.astype(np.float32)
+        else:                                             # large pairs: a fixed sample of cells instead of the dense matrix
+            idx = np.random.default_rng(b).choice(d.size, 8192, replace=False)
+            grads[f"dscores_sample_idx_{b}"], grads[f"dscores_sample_{b}"] = idx.astype(np.int64), d.reshape(-1)[idx].astype(np.float32)
     kept = {f"kept{s}_{b}": np.asarray(data[f"kept_kpts{s}_indices"][b], dtype=np.int64) for s in "01" for b in range(len(pairs))}
     G.save(name, matches=matches, loss=np.float64(loss), pos=np.float64(pos), neg=np.float64(neg),
            meta=np.asarray([pairs[0]["keypoints0"].shape[1], rad, pct, ms, iters, len(pairs)], dtype=np.int64),
-           pos_loss_weight=np.float64(WEIGHTS["pos_loss_weight"]), neg_loss_weight=np.float64(WEIGHTS["neg_loss_weight"]), **kept)
+           pos_loss_weight=np.float64(WEIGHTS["pos_loss_weight"]), neg_loss_weight=np.float64(WEIGHTS["neg_loss_weight"]), **kept, **grads)
     print(f"  loss {float(loss):.6f} pos {float(pos):.6f} neg {float(neg):.6f}; kept {[len(v) for v in kept.values()]}", flush=True)
 
 
