@@ -688,7 +688,16 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
     const int big_blocks = cdiv(a->m, 256) * cdiv(a->n, 256);
     // the 256-wide tile only when it is not half empty (n = 64 / 128 layers of the keypoint encoder and GraphSAGE)
     const bool big = force == 256 || (force != 128 && big_blocks >= 192 && (a->n % 256 == 0 || a->n > 512));
-    if (force == 1283 || force == 1284 || force == 2563) {      // experimental ring geometries
+    if (force == 1288) {      // experiment: 128 x 128 tiles on EIGHT waves (two per SIMD) for small, latency-bound launches
+      using T8 = X3P<128, 128, 4, 2, 2>;
+      static bool attr8 = false;
+      if (!attr8) {
+        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 128, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T8::LDS_BYTES));
+        attr8 = true;
+      }
+      constexpr size_t lds = T8::LDS_BYTES;
+      hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 4, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(512), lds, s, *a);
+    } else if (force == 1283 || force == 1284 || force == 2563) {      // experimental ring geometries
       static bool attr2 = false;
       using T3 = X3P<256, 128, 4, 2, 3>;
       using T4 = X3P<128, 128, 2, 2, 4>;
@@ -772,7 +781,20 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       const dim3 g(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128));
       if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 4, 1>), g, dim3(256), lds_h, s, *a);
       else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2, 2>), g, dim3(256), lds, s, *a);
-      else hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2>), g, dim3(256), lds, s, *a);
+      else if (force == 128 || cdiv(a->m, 128) * cdiv(a->n, 128) > 256)      // more than one tile per CU (or GIMS_X3P_TILE=128): the 4-wave tile, two workgroups per CU
+        hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2>), g, dim3(256), lds, s, *a);
+      else {
+        // small launches are latency-bound (one tile per CU, ~1 us per K step at one wave per SIMD): the same 128 x 128 tile on
+        // EIGHT waves (two per SIMD, 64 x 32 ... per wave) hides the LDS and MFMA-chain latencies: 23 -> 18 us at 8192 rows,
+        // 21 -> 15 us at 2048 rows (tools/gemm_probe.py); same K order per output element: bit-identical results
+        static bool attr8 = false;
+        if (!attr8) {
+          GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 128, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3P<128, 128, 4, 2, 2>::LDS_BYTES));
+          attr8 = true;
+        }
+        constexpr size_t lds8 = X3P<128, 128, 4, 2, 2>::LDS_BYTES;
+        hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 4, 2, 2>), g, dim3(512), lds8, s, *a);
+      }
     }
   } else if (a->precision == GIMS_PREC_F32) {
     hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, s, *a);
