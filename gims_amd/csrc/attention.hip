@@ -782,14 +782,15 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
 // key tiles, waves 4-7 the other half (own K / V^T staging buffers), and the two partial results (unnormalised O, running
 // maximum, row sum) are merged through LDS at the end -- the flash-decoding split, inside one workgroup: no workspace, no
 // second launch.  Same math and layouts as attention_bf16_kernel<1>.
-__global__ __launch_bounds__(512) void attention_split_kernel(
+template <int NS>      // key parts per query block: 2 (eight waves) or 4 (sixteen waves)
+__global__ __launch_bounds__(256 * NS) void attention_split_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
     int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c) {
   extern __shared__ __attribute__((aligned(16))) uint16_t sp_lds[];
   // [half][buffer]: K tiles, then V^T tiles
   auto Ks = [&](int hf, int buf) __attribute__((always_inline)) { return sp_lds + (hf * 2 + buf) * (KB * DH); };
-  auto Vt = [&](int hf, int buf) __attribute__((always_inline)) { return sp_lds + 4 * (KB * DH) + (hf * 2 + buf) * (DH * VT_LD); };
+  auto Vt = [&](int hf, int buf) __attribute__((always_inline)) { return sp_lds + 2 * NS * (KB * DH) + (hf * 2 + buf) * (DH * VT_LD); };
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int group = (slot / n_qt) * 8 + xcd;
@@ -820,12 +821,12 @@ __global__ __launch_bounds__(512) void attention_split_kernel(
   float m_run = -1e30f, l_run = 0.f;
 
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
-  const int n_mine = (n_tiles - half + 1) / 2;            // tiles half, half + 2, ...
-  const int n_iter = (n_tiles + 1) / 2;                   // both halves pass the same number of barriers
+  const int n_mine = (n_tiles - half + NS - 1) / NS;      // tiles half, half + NS, ...
+  const int n_iter = (n_tiles + NS - 1) / NS;             // every part passes the same number of barriers
   uint4 rk[2], rv[2];
   const int vkp = t & 31, voct = t >> 5;
   auto load_tile = [&](int it) __attribute__((always_inline)) {
-    const int kbase = (2 * it + half) * KB;
+    const int kbase = (NS * it + half) * KB;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int f = t + 256 * e, row = f >> 3, ch = f & 7;
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(
           const bf16x8 kf = *(const bf16x8*)(Ks(half, buf) + k_off(b * 32 + li, 2 * s + lh));
           sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[b], 0, 0, 0);
         }
-      const int kbase = (2 * it + half) * KB;
+      const int kbase = (NS * it + half) * KB;
       if (kbase + KB > pr.n_kv) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -937,29 +938,31 @@ __global__ __launch_bounds__(512) void attention_split_kernel(
     __syncthreads();
   }
 
-  // ---- merge the two halves: half 1 hands (O, m, l) to half 0 through LDS (the staging buffers are idle now)
-  float* xo = (float*)sp_lds;                            // [4 waves][32 regs][64 lanes]
-  float* xm = xo + 4 * 32 * 64;                          // [4 waves][2][64 lanes]
-  if (half == 1) {
+  // ---- merge the parts: parts 1 .. NS-1 hand (O, m, l) to part 0 through LDS (the staging buffers are idle now)
+  float* xo = (float*)sp_lds;                            // [NS - 1][4 waves][34][64 lanes]: 32 accumulator registers, m, l
+  if (half > 0) {
+    float* dst = xo + (((half - 1) * 4 + wave) * 34) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xo[(wave * 32 + i * 16 + r) * 64 + lane] = o[i][r];
-    xm[(wave * 2 + 0) * 64 + lane] = m_run;
-    xm[(wave * 2 + 1) * 64 + lane] = l_run;
+      for (int r = 0; r < 16; ++r) dst[(i * 16 + r) * 64] = o[i][r];
+    dst[32 * 64] = m_run;
+    dst[33 * 64] = l_run;
   }
   __syncthreads();
-  if (half == 1) return;
-  {
-    const float m1 = xm[(wave * 2 + 0) * 64 + lane], l1 = xm[(wave * 2 + 1) * 64 + lane];
-    // m_run is wave-uniform per query COLUMN only up to the lane^32 partner (both lanes of a column hold the same value)
+  if (half > 0) return;
+#pragma unroll
+  for (int pt = 1; pt < NS; ++pt) {                      // fixed merge order
+    const float* src = xo + (((pt - 1) * 4 + wave) * 34) * 64 + lane;
+    const float m1 = src[32 * 64], l1 = src[33 * 64];
     const float m_new = fmaxf(m_run, m1);
     const float a0 = __builtin_amdgcn_exp2f((m_run - m_new) * c), a1 = __builtin_amdgcn_exp2f((m1 - m_new) * c);
+    m_run = m_new;
     l_run = l_run * a0 + l1 * a1;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + xo[(wave * 32 + i * 16 + r) * 64 + lane] * a1;
+      for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + src[(i * 16 + r) * 64] * a1;
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(
       }
   }
 }
-constexpr int SPLIT_LDS_BYTES = 2 * 2 * (KB * DH + DH * VT_LD) * 2;     // >= the 34 KB of the merge exchange
+template <int NS> constexpr int SPLIT_LDS_BYTES = NS * 2 * (KB * DH + DH * VT_LD) * 2;     // >= the (NS - 1) x 34 KB of the merge exchange
 
 }  // namespace gims
 
@@ -1030,12 +1033,22 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
   if (split) {
     static bool attr_set = false;
     if (!attr_set) {
-      GIMS_HIP(hipFuncSetAttribute((const void*)attention_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES));
+      GIMS_HIP(hipFuncSetAttribute((const void*)attention_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES<2>));
+      GIMS_HIP(hipFuncSetAttribute((const void*)attention_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES<4>));
       attr_set = true;
     }
     const int n_qt = cdiv(max_n_q, QB);
-    hipLaunchKernelGGL(attention_split_kernel, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(512), SPLIT_LDS_BYTES, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
+    const int wgs = 8 * cdiv(n_groups, 8) * n_qt;
+    int ns_env = 0;                                  // read per call: the tests switch between the two variants
+    { const char* e = getenv("GIMS_ATTN_SPLIT"); ns_env = e ? atoi(e) : 0; }
+    // four key parts (sixteen waves) when the launch is at most one workgroup per CU and the keys are many
+    const bool four = ns_env == 4 || (ns_env != 2 && wgs <= 256 && max_n_q >= 2048);
+    if (four)
+      hipLaunchKernelGGL(attention_split_kernel<4>, dim3(wgs), dim3(1024), SPLIT_LDS_BYTES<4>, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col, problems,
+                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
+    else
+      hipLaunchKernelGGL(attention_split_kernel<2>, dim3(wgs), dim3(512), SPLIT_LDS_BYTES<2>, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col, problems,
+                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
   } else if (eight) {
     int exact_only = 0;                         // GIMS_ATTN_EXACT=1: running-maximum softmax only (no optimistic pass)
     { const char* e = getenv("GIMS_ATTN_EXACT"); exact_only = e ? atoi(e) : 0; }

@@ -1269,7 +1269,14 @@ static OtResPlan ot_res_plan(const gims_ot_problem* pr, int np, int iters) {
     int ppg = 256 / need;
     ppg = np < ppg ? np : ppg;
     P.ppg = ppg;
-    P.nbu = 256 / ppg;
+    // as FEW workgroups per problem as its rows need (rounded up to whole groups of 8): every fold spans all slabs of the
+    // problem, so spreading one 4096^2 problem over all 256 CUs (16 rows each) made its iteration slower than two such
+    // problems side by side -- measured 1.60 -> 1.29 ms per solve with 128 instead of 256 slabs (tools/ot_probe.py 4096x1)
+    int nbu = (need + 7) & ~7;
+    nbu = nbu < 256 / ppg ? nbu : 256 / ppg;
+    const int cap_nbu = ot_env("GIMS_OT_MAXNBU", 0);            // experiments: force a (larger) number of slabs per problem
+    if (cap_nbu >= need && cap_nbu <= 256 / ppg) nbu = cap_nbu;
+    P.nbu = nbu;
   }
   P.ngroups = cdiv(np, P.ppg);
   if (P.ngroups > 16) return P;

@@ -148,12 +148,23 @@ class GMatcher(nn.Module):
             sd[k] = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
         self._pack = None
         self.__dict__.pop("_ops_cache", None)
+        self.__dict__.pop("_plist", None)
         return super().load_state_dict(sd, strict=strict, **kw)
+
+    def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .half() replace the parameter tensors
+        self.__dict__.pop("_plist", None)
+        self._pack = None
+        return super()._apply(fn, *a, **kw)
 
     # ------------------------------------------------------------------ weight packing
     def _packed(self, device):
+        # (the parameter list is cached: walking the module tree for 348 parameters cost ~0.25 ms per call, twice per forward,
+        # both times on the host's critical path in front of a launch; in-place updates are still seen through _version)
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self.__dict__["_plist"] = list(self.parameters())
         key = (str(device), self.config['linear_precision'], bool(self.config['fuse_merge']),
-               sum(int(p._version) for p in self.parameters()))
+               sum([p._version for p in plist]))
         if self._pack is not None and self._pack_key == key:
             return self._pack
         sd = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
@@ -384,7 +395,14 @@ class GMatcher(nn.Module):
         D = cfg['descriptor_dim']
         St = lambda name: GMatcher._Stage(self, name)   # noqa: E731
         ts0 = time.perf_counter()
-        infos = info_all.cpu().numpy()                                                    # the one host sync of the build
+        # the one host sync of the build: into a pinned staging buffer (a pageable .cpu() goes through the runtime's own
+        # pin / copy / unpin path and costs ~0.1 ms more per call, which a single pair through forward() feels)
+        pin = self.__dict__.get("_info_pin")
+        if pin is None or pin.shape[0] < info_all.shape[0]:
+            pin = self.__dict__["_info_pin"] = torch.empty((max(64, info_all.shape[0]), 8), dtype=torch.int32, pin_memory=True)
+        pin[:info_all.shape[0]].copy_(info_all, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        infos = pin[:info_all.shape[0]].numpy().copy()
         self._sync_ms = 1e3 * (time.perf_counter() - ts0)
         if infos[:, 7].any():
             # more edges than the buffers hold: repeat the graph build of this batch with room for what it reported (the

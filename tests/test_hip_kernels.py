@@ -218,14 +218,15 @@ def _attn_ref(q, k, v):
 
 
 @pytest.mark.parametrize("prescaled", [False, True])           # Q as is / Q carrying log2(e)/sqrt(dh) (GIMS_ATTN_Q_PRESCALED)
-@pytest.mark.parametrize("kernel", ["auto", "8", "8exact", "split"])     # launch-size heuristic / 8-wave kernel forced / its exact-only mode / split-key kernel
+@pytest.mark.parametrize("kernel", ["auto", "8", "8exact", "split", "split4"])     # launch-size heuristic / 8-wave kernel forced / its exact-only mode / split-key kernels (2 and 4 parts)
 @pytest.mark.parametrize("sizes,sharp", [([(64, 64)], 1.0), ([(200, 333), (333, 200)], 1.0), ([(1, 5), (129, 64), (1000, 777)], 1.0),
                                          ([(256, 256)], 6.0)])
 def test_attention(hip, monkeypatch, sizes, sharp, kernel, prescaled):
     """bf16 flash attention vs float64 softmax attention on the SAME bf16-rounded Q/K/V.
     Tolerance 1.5e-2 of the value scale: P is rounded to bf16 (2^-9 relative) before the PV product."""
-    if kernel == "split":
+    if kernel.startswith("split"):
         monkeypatch.setenv("GIMS_ATTN_QP", "3")
+        monkeypatch.setenv("GIMS_ATTN_SPLIT", "4" if kernel == "split4" else "2")
     elif kernel != "auto":
         monkeypatch.setenv("GIMS_ATTN_QP", "8")
         monkeypatch.setenv("GIMS_ATTN_EXACT", "1" if kernel == "8exact" else "0")
@@ -312,11 +313,12 @@ def test_attention_x3(hip, sizes, sharp, prescaled):
         assert (np.abs(rec[qo:qo + nq] - o[qo:qo + nq]) <= np.abs(o[qo:qo + nq]) * 2.0 ** -15 + 1e-30).all()
 
 
-@pytest.mark.parametrize("kernel", ["auto", "8", "8exact", "split"])
+@pytest.mark.parametrize("kernel", ["auto", "8", "8exact", "split", "split4"])
 def test_attention_online_rescale(hip, monkeypatch, kernel):
     """Force the running max to jump at a later key tile (guide rule: the rare rescale branch needs its own test)."""
-    if kernel == "split":
+    if kernel.startswith("split"):
         monkeypatch.setenv("GIMS_ATTN_QP", "3")
+        monkeypatch.setenv("GIMS_ATTN_SPLIT", "4" if kernel == "split4" else "2")
     elif kernel != "auto":
         monkeypatch.setenv("GIMS_ATTN_QP", "8")
         monkeypatch.setenv("GIMS_ATTN_EXACT", "1" if kernel == "8exact" else "0")
