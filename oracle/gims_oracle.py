@@ -313,9 +313,11 @@ def normalize_keypoints(kpts: torch.Tensor, image_shape) -> torch.Tensor:
     return (kpts - center[:, None, :]) / scaling[:, None, :]
 
 
-def _mlp(sd, prefix: str, n_convs: int, x: torch.Tensor) -> torch.Tensor:
-    """gmatcher.py:11-24 -- Conv1d(k=1) [+ BatchNorm1d(eval) | LayerNorm + ReLU] stack; Sequential indices 0,1,2 / 3,4,5 ...
-    Which norm a checkpoint uses is read off its keys (LayerNorm stores a_2 / b_2, gmatcher.py:78-79)."""
+def _mlp(sd, prefix: str, n_convs: int, x: torch.Tensor, bn_training: bool = False) -> torch.Tensor:
+    """gmatcher.py:11-24 -- Conv1d(k=1) [+ BatchNorm1d | LayerNorm + ReLU] stack; Sequential indices 0,1,2 / 3,4,5 ...
+    Which norm a checkpoint uses is read off its keys (LayerNorm stores a_2 / b_2, gmatcher.py:78-79).  ``bn_training``:
+    nn.BatchNorm1d in train() mode -- statistics of THIS call over (B, N), running statistics (torch tensors in ``sd``) updated
+    in place with momentum 0.1 and the unbiased variance, num_batches_tracked incremented when present."""
     idx = 0
     for i in range(n_convs):
         x = F.conv1d(x, _t(sd, f"{prefix}.{idx}.weight"), _t(sd, f"{prefix}.{idx}.bias"))
@@ -329,15 +331,17 @@ def _mlp(sd, prefix: str, n_convs: int, x: torch.Tensor) -> torch.Tensor:
             else:
                 x = F.batch_norm(x, _t(sd, f"{prefix}.{idx}.running_mean"), _t(sd, f"{prefix}.{idx}.running_var"),
                                  _t(sd, f"{prefix}.{idx}.weight"), _t(sd, f"{prefix}.{idx}.bias"),
-                                 training=False, eps=BN_EPS)
+                                 training=bn_training, momentum=0.1, eps=BN_EPS)
+                if bn_training and isinstance(sd.get(f"{prefix}.{idx}.num_batches_tracked"), torch.Tensor):
+                    sd[f"{prefix}.{idx}.num_batches_tracked"] += 1
             x = F.relu(x)
             idx += 2
     return x
 
 
-def keypoint_encoder(sd, kpts_norm: torch.Tensor, n_convs: int = 5) -> torch.Tensor:
+def keypoint_encoder(sd, kpts_norm: torch.Tensor, n_convs: int = 5, bn_training: bool = False) -> torch.Tensor:
     """gmatcher.py:87-97 with score=False: encoder(kpts^T) -> (B,256,N)."""
-    return _mlp(sd, "kenc.encoder", n_convs, kpts_norm.transpose(1, 2))
+    return _mlp(sd, "kenc.encoder", n_convs, kpts_norm.transpose(1, 2), bn_training)
 
 
 def attention(q, k, v):
@@ -348,7 +352,7 @@ def attention(q, k, v):
     return torch.einsum("bhnm,bdhm->bdhn", prob, v)
 
 
-def attentional_propagation(sd, l: int, x: torch.Tensor, source: torch.Tensor, heads: int = 4) -> torch.Tensor:
+def attentional_propagation(sd, l: int, x: torch.Tensor, source: torch.Tensor, heads: int = 4, bn_training: bool = False) -> torch.Tensor:
     """gmatcher.py:99-125 -- MultiHeadedAttention (heads interleaved: view(B, dh, H, N)) + MLP([2D,2D,D])."""
     p = f"gnn.layers.{l}."
     b, d, _ = x.shape
@@ -356,17 +360,18 @@ def attentional_propagation(sd, l: int, x: torch.Tensor, source: torch.Tensor, h
                .view(b, d // heads, heads, -1) for j, t in enumerate((x, source, source))]
     msg = attention(q, k, v).contiguous().view(b, d, -1)
     msg = F.conv1d(msg, _t(sd, p + "attn.merge.weight"), _t(sd, p + "attn.merge.bias"))
-    return _mlp(sd, p + "mlp", 2, torch.cat([x, msg], dim=1))
+    return _mlp(sd, p + "mlp", 2, torch.cat([x, msg], dim=1), bn_training)
 
 
-def attentional_gnn(sd, desc0, desc1, names, taps=None):
-    """gmatcher.py:127-143."""
+def attentional_gnn(sd, desc0, desc1, names, taps=None, bn_training: bool = False):
+    """gmatcher.py:127-143 (image 0 before image 1 in every layer: the order of the two running-statistics updates)."""
     for l, name in enumerate(names):
         if name == "cross":
             src0, src1 = desc1, desc0
         else:
             src0, src1 = desc0, desc1
-        delta0, delta1 = attentional_propagation(sd, l, desc0, src0), attentional_propagation(sd, l, desc1, src1)
+        delta0 = attentional_propagation(sd, l, desc0, src0, bn_training=bn_training)
+        delta1 = attentional_propagation(sd, l, desc1, src1, bn_training=bn_training)
         desc0, desc1 = desc0 + delta0, desc1 + delta1
         if taps is not None:
             taps.append((desc0.clone(), desc1.clone()))
@@ -449,7 +454,8 @@ def train_loss(ot: torch.Tensor, matches: torch.Tensor, kept0, kept1, batch_size
 
 def gmatcher_forward(sd, data: dict, config: dict | None = None, stages: dict | None = None, mode: str = "test"):
     """gmatcher.py:219-307 (test mode) on a state dict ``sd`` (NumPy arrays or tensors); ``mode='train'`` returns the
-    forward value of forward_train's loss instead (gmatcher.py:254, 309-386; eval-mode BatchNorm).
+    forward value of forward_train's loss instead (gmatcher.py:254, 309-386; eval-mode BatchNorm unless
+    ``config['bn_training']``).
 
     ``data`` holds torch tensors in the reference layout and is mutated in place exactly
     like the reference does (gmatcher.py:244-252).  ``stages`` (optional dict) receives intermediates.
@@ -492,10 +498,11 @@ def gmatcher_forward(sd, data: dict, config: dict | None = None, stages: dict | 
     sage0 = torch.stack([graph_sage(sd, g["indptr"], g["indices"], g["feat"]) for g in g0s]).permute(0, 2, 1)
     sage1 = torch.stack([graph_sage(sd, g["indptr"], g["indices"], g["feat"]) for g in g1s]).permute(0, 2, 1)
     n_kenc = len(cfg["keypoint_encoder"]) + 1
-    ke0, ke1 = keypoint_encoder(sd, kn0, n_kenc), keypoint_encoder(sd, kn1, n_kenc)
+    bn_tr = bool(cfg.get("bn_training", False))          # nn.Module.train(): BatchNorm on batch statistics (train.py:100)
+    ke0, ke1 = keypoint_encoder(sd, kn0, n_kenc, bn_tr), keypoint_encoder(sd, kn1, n_kenc, bn_tr)
     desc0, desc1 = sage0 + ke0, sage1 + ke1
     taps = [] if stages is not None else None
-    gd0, gd1 = attentional_gnn(sd, desc0, desc1, cfg["transformer_layers"], taps)
+    gd0, gd1 = attentional_gnn(sd, desc0, desc1, cfg["transformer_layers"], taps, bn_tr)
     fw, fb = _t(sd, "final_proj.weight"), _t(sd, "final_proj.bias")
     mdesc0, mdesc1 = F.conv1d(gd0, fw, fb), F.conv1d(gd1, fw, fb)
     scores = torch.einsum("bdn,bdm->bnm", mdesc0, mdesc1)
@@ -517,3 +524,20 @@ def gmatcher_forward(sd, data: dict, config: dict | None = None, stages: dict | 
             "descriptors0": data["descriptors0"], "descriptors1": data["descriptors1"],
             "matches0": i0, "matches1": i1, "matching_scores0": s0, "matching_scores1": s1,
             "mdesc0": mdesc0.permute(0, 2, 1).squeeze(), "mdesc1": mdesc1.permute(0, 2, 1).squeeze()}
+
+
+def train_step(sd_np: dict, data: dict, config: dict | None = None):
+    """One step of train.py:100, 136-137 on the CPU: ``model.train()``, forward(mode='train'), ``loss.backward()`` -- torch
+    autograd through this file's restatement.  Returns (loss, pos, neg) as floats, the gradient of every floating-point
+    parameter (NumPy, keyed like the state dict) and the state dict's BatchNorm buffers after the step."""
+    sd = {}
+    for k, v in sd_np.items():
+        t = torch.from_numpy(np.array(v, copy=True))
+        is_buf = k.endswith(("running_mean", "running_var", "num_batches_tracked"))
+        sd[k] = t if is_buf else t.requires_grad_(True)
+    with torch.enable_grad():
+        loss, pos, neg = gmatcher_forward(sd, data, {**(config or {}), "bn_training": True}, mode="train")
+        loss.backward()
+    grads = {k: v.grad.numpy() for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    bufs = {k: v.detach().numpy() for k, v in sd.items() if not v.requires_grad}
+    return (float(loss.detach()), float(pos.detach()), float(neg.detach())), grads, bufs

@@ -49,7 +49,11 @@ def train_pairs(name, g):
     return {"trainloss_n256_s1002_i100": lambda: [synth.make_pair(256, 1002)],
             "trainloss_n1024_s1000_i100": lambda: [synth.make_pair(1024, 1000)],
             "trainloss_n1024sparse_s2001_i20": lambda: [synth.make_pair(1024, 2001, canvas=(800, 600))],
-            "trainloss_b2_n64_s1000_i100": lambda: [synth.make_pair(64, 1000), synth.make_pair(64, 1000, desc_noise=0.2)]}[name]()
+            "trainloss_b2_n64_s1000_i100": lambda: [synth.make_pair(64, 1000), synth.make_pair(64, 1000, desc_noise=0.2)],
+            "trainstep_n256_s1002_i100": lambda: [synth.make_pair(256, 1002)],
+            "trainstep_n512_s1003_i20": lambda: [synth.make_pair(512, 1003)],
+            "trainstep_b2_n64_s1000_i100": lambda: [synth.make_pair(64, 1000), synth.make_pair(64, 1000, desc_noise=0.2)],
+            "trainstep_n2048_s1004_i100": lambda: [synth.make_pair(2048, 1004)]}[name]()
 
 
 def train_data(pairs, g, device="cpu"):
@@ -79,3 +83,43 @@ def check_score_gradients(g, dscores, dbin, n_pairs, rtol):
         np.testing.assert_allclose(d.sum(1), g[f"dscores_rowsum_{b}"], atol=8 * rtol * scale, rtol=0)
         np.testing.assert_allclose(d.sum(0), g[f"dscores_colsum_{b}"], atol=8 * rtol * scale, rtol=0)
     assert abs(float(dbin) - float(g["dbin_score"])) <= rtol * max(abs(float(g["dbin_score"])), 1e-3), (float(dbin), float(g["dbin_score"]))
+
+
+def grad_sample_index(name: str, numel: int) -> np.ndarray:
+    """The stored entries of a large gradient in the trainstep_* fixtures (same rule as tools/gen_golden_grads.py)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    return np.sort(rng.choice(numel, 256, replace=False)).astype(np.int64)
+
+
+def check_step_gradients(g, grads, rtol, rtol_p95=None, atol_frac=1e-3):
+    """``grads``: parameter name -> gradient (NumPy) of one training step; compared with a trainstep_* fixture of the
+    reference's own autograd.  Every stored gradient must be present.  Per tensor the error is the largest entry difference
+    relative to the largest reference entry of THAT tensor (floor: atol_frac of the largest gradient entry anywhere -- the
+    gradients of the key bias, of a bias in front of a BatchNorm and of bin_score are mathematically zero or rounding noise).
+    Bars: every tensor within ``rtol``; 95 % of the tensors within ``rtol_p95`` (two f32 evaluations of the same step differ
+    by a few 1e-4 on most tensors and by up to a few 1e-3 where one ReLU of a near-zero pre-activation falls the other way:
+    measured between the reference and the oracle, tests/test_train_oracle_cpu.py).  Returns (worst, where, p95)."""
+    keys = [k[2:] for k in g if k.startswith("g:") or k.startswith("s:")]
+    assert keys and all(k in grads for k in keys), [k for k in keys if k not in grads][:5]
+    big = max(float(np.abs(g[("g:" if "g:" + k in g else "s:") + k]).max()) for k in keys)
+    errs = []
+    for k in keys:
+        mine = np.asarray(grads[k], dtype=np.float64).reshape(-1)
+        assert np.isfinite(mine).all(), k
+        if "g:" + k in g:
+            ref = g["g:" + k].astype(np.float64)
+        else:
+            ref = g["s:" + k].astype(np.float64)
+            tot, nrm, amax = g["n:" + k]
+            den = max(nrm, atol_frac * big * np.sqrt(mine.size))
+            assert abs(np.sqrt((mine ** 2).sum()) - nrm) <= rtol * den, (k, np.sqrt((mine ** 2).sum()), nrm)
+            mine = mine[grad_sample_index(k, mine.size)]
+        den = max(float(np.abs(ref).max()), atol_frac * big)
+        errs.append((float(np.abs(mine - ref).max()) / den, k))
+    errs.sort()
+    worst, p95 = errs[-1], errs[int(0.95 * (len(errs) - 1))][0]
+    assert worst[0] <= rtol, errs[-5:]
+    if rtol_p95 is not None:
+        assert p95 <= rtol_p95, (p95, errs[-20:])
+    return worst[0], worst[1], p95
