@@ -1,0 +1,673 @@
+// Training-step kernels (forward_train + backward, models/gmatcher.py:309-386, train.py:136-137).
+//
+// The training step runs in f32-class arithmetic end to end, on ROW-MAJOR f32 activations [keypoint rows][channels]:
+//   * gemm_x3_kernel      -- one general batched GEMM  C = alpha * op(A) op(B)^T + beta * C (+ bias, + residual, ReLU)
+//                            for every product of the step (linear layers forward / input gradient / weight gradient, the
+//                            attention products Q K^T, P V and their five gradients, the score matrix and its gradients).
+//                            f32 operands are split into bf16 hi + lo on the way into LDS and multiplied with three bf16 MFMA
+//                            passes (hi*hi + hi*lo + lo*hi, v_mfma_f32_32x32x16_bf16): ~2^-17 relative, the accuracy class of the
+//                            reference's f32 matmuls.  Either operand may be stored transposed ([k][rows]).
+//   * BatchNorm1d in train() mode (gmatcher.py:17-22 under nn.Module.train()): batch statistics per call = per SIDE of the
+//                            batch (the reference calls every layer once for image 0 and once for image 1), running
+//                            statistics updated in call order with the unbiased variance, and its backward pass.
+//   * softmax over attention rows and its backward, column sums (bias gradients), the transposed mean aggregation of
+//                            GraphSAGE, a strided 3-D copy (head interleave of gmatcher.py:108-113 <-> contiguous heads).
+// All reductions have a fixed order: a training step is bitwise reproducible.
+#include "common.h"
+
+namespace gims {
+
+// ------------------------------------------------------------------------------------------------ general GEMM, bf16x3
+// LDS tile: [rows][64 bf16] = per row 4 chunks of 8 hi values (k 0..31) then 4 chunks of 8 lo values; 16-byte chunk c of
+// row r lives at chunk position c ^ (r & 7) (conflict-free ds_read_b128 of MFMA fragments: 8 consecutive rows cover
+// all 32 banks).
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
+
+struct TileItem {
+  f32x4 v;     // four consecutive k of one tile row
+};
+
+// R rows x 32 k of an operand into registers.  T = false: stored [rows][k] (k contiguous); T = true: stored [k][rows].
+// item i of thread t covers (row_of(i), k4_of()) -- see tile_store.
+template <bool T, int R>
+__device__ __forceinline__ void tile_load(f32x4 (&v)[4], const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int K,
+                                          bool vec, int t) {
+  if constexpr (!T) {
+#pragma unroll
+    for (int i = 0; i < R / 32; ++i) {
+      const int gr = row0 + (t >> 3) + 32 * i, k = k0 + (t & 7) * 4;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (gr < nrows && k < K) {
+        const float* p = base + (int64_t)gr * ld + k;
+        if (vec) {
+          x = *(const f32x4*)p;
+          if (k + 3 >= K) {
+            if (k + 1 >= K) x[1] = 0.f;
+            if (k + 2 >= K) x[2] = 0.f;
+            x[3] = 0.f;
+          }
+        } else {
+          x[0] = p[0];
+          if (k + 1 < K) x[1] = p[1];
+          if (k + 2 < K) x[2] = p[2];
+          if (k + 3 < K) x[3] = p[3];
+        }
+      }
+      v[i] = x;
+    }
+  } else {
+    const int rq = (t % (R / 4)) * 4, kb = t / (R / 4);
+    f32x4 w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + kb * 4 + j, gr = row0 + rq;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (kb < 8 && k < K && gr < nrows) {
+        const float* p = base + (int64_t)k * ld + gr;
+        if (vec) {
+          x = *(const f32x4*)p;
+          if (gr + 3 >= nrows) {
+            if (gr + 1 >= nrows) x[1] = 0.f;
+            if (gr + 2 >= nrows) x[2] = 0.f;
+            x[3] = 0.f;
+          }
+        } else {
+          x[0] = p[0];
+          if (gr + 1 < nrows) x[1] = p[1];
+          if (gr + 2 < nrows) x[2] = p[2];
+          if (gr + 3 < nrows) x[3] = p[3];
+        }
+      }
+      w[j] = x;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = f32x4{w[0][r], w[1][r], w[2][r], w[3][r]};
+  }
+}
+
+__device__ __forceinline__ void item_store(uint16_t* __restrict__ tile, int row, int k4, f32x4 x) {
+  const uint32_t h01 = pack_bf2(x[0], x[1]), h23 = pack_bf2(x[2], x[3]);
+  const uint32_t l01 = pack_bf2(x[0] - __uint_as_float(h01 << 16), x[1] - __uint_as_float(h01 & 0xffff0000u));
+  const uint32_t l23 = pack_bf2(x[2] - __uint_as_float(h23 << 16), x[3] - __uint_as_float(h23 & 0xffff0000u));
+  const int c = k4 >> 3, half = k4 & 4;
+  *(uint2*)(tile + tile_off(row, c) + half) = make_uint2(h01, h23);
+  *(uint2*)(tile + tile_off(row, c + 4) + half) = make_uint2(l01, l23);
+}
+
+template <bool T, int R>
+__device__ __forceinline__ void tile_store(const f32x4 (&v)[4], uint16_t* __restrict__ tile, int t) {
+  if constexpr (!T) {
+#pragma unroll
+    for (int i = 0; i < R / 32; ++i) item_store(tile, (t >> 3) + 32 * i, (t & 7) * 4, v[i]);
+  } else {
+    const int rq = (t % (R / 4)) * 4, kb = t / (R / 4);
+    if (kb < 8) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) item_store(tile, rq + r, kb * 4, v[r]);
+    }
+  }
+}
+
+template <bool TA, bool TB, int BN>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(gims_gemm g) {
+  constexpr int BM = 128, MT = BN == 128 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * 64];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN * 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+  const int wm = BN == 128 ? (wave >> 1) * 64 : wave * 32, wn = BN == 128 ? (wave & 1) * 64 : 0;
+  const float* __restrict__ A = g.a + (int64_t)z * g.sa;
+  const float* __restrict__ B = g.b + (int64_t)z * g.sb;
+  const bool va = (g.flags & 1) != 0, vb = (g.flags & 2) != 0;
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  const int nk = (g.k + 31) / 32;
+  tile_load<TA, BM>(ra, A, g.lda, m0, g.m, 0, g.k, va, t);
+  tile_load<TB, BN>(rb, B, g.ldb, n0, g.n, 0, g.k, vb, t);
+  tile_store<TA, BM>(ra, As[0], t);
+  tile_store<TB, BN>(rb, Bs[0], t);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      tile_load<TA, BM>(ra, A, g.lda, m0, g.m, (kt + 1) * 32, g.k, va, t);
+      tile_load<TB, BN>(rb, B, g.ldb, n0, g.n, (kt + 1) * 32, g.k, vb, t);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[MT], al[MT], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm + i * 32 + li;
+        ah[i] = *(const bf16x8*)(As[buf] + tile_off(row, ks * 2 + lh));
+        al[i] = *(const bf16x8*)(As[buf] + tile_off(row, ks * 2 + lh + 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wn + j * 32 + li;
+        bh[j] = *(const bf16x8*)(Bs[buf] + tile_off(row, ks * 2 + lh));
+        bl[j] = *(const bf16x8*)(Bs[buf] + tile_off(row, ks * 2 + lh + 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);      // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) {
+      tile_store<TA, BM>(ra, As[buf ^ 1], t);
+      tile_store<TB, BN>(rb, Bs[buf ^ 1], t);
+    }
+    __syncthreads();
+  }
+
+  float* __restrict__ Cz = g.c + (int64_t)z * g.sc;
+  const float* __restrict__ Rz = g.residual ? g.residual + (int64_t)z * g.sr : nullptr;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn + j * 32 + li;
+      if (n >= g.n) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.m) continue;
+        float v = g.alpha * acc[i][j][r] + bv;
+        if (Rz) v += Rz[(int64_t)m * g.ldr + n];
+        float* cp = Cz + (int64_t)m * g.ldc + n;
+        if (g.beta != 0.f) v += g.beta * *cp;
+        if (g.act == GIMS_ACT_RELU) v = fmaxf(v, 0.f);
+        *cp = v;
+      }
+    }
+}
+
+template <bool TA, bool TB>
+static void gemm_launch(const gims_gemm& g, hipStream_t s) {
+  if (g.n <= 64)
+    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, 64>), dim3(cdiv(g.n, 64), cdiv(g.m, 128), g.batch), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, 128>), dim3(cdiv(g.n, 128), cdiv(g.m, 128), g.batch), dim3(256), 0, s, g);
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm1d, train mode
+// Rows are grouped in up to 8 SEGMENTS (one per call of the module in the reference: image 0 of the batch, image 1 of the
+// batch); statistics are per (segment, channel).  A block covers 256 rows x 32 channels.
+constexpr int BN_RB = 256;
+
+__device__ __forceinline__ bool seg_of_block(const gims_segments& sg, int blk, int& seg, int& r0, int& nr) {
+  for (int s = 0; s < sg.n; ++s) {
+    const int nb = (sg.rows[s] + BN_RB - 1) / BN_RB;
+    if (blk < nb) {
+      seg = s;
+      r0 = sg.off[s] + blk * BN_RB;
+      nr = min(BN_RB, sg.rows[s] - blk * BN_RB);
+      return true;
+    }
+    blk -= nb;
+  }
+  return false;
+}
+static int seg_blocks(const gims_segments& sg) {
+  int nb = 0;
+  for (int s = 0; s < sg.n; ++s) nb += (sg.rows[s] + BN_RB - 1) / BN_RB;
+  return nb;
+}
+__device__ __forceinline__ int seg_first_block(const gims_segments& sg, int seg) {
+  int nb = 0;
+  for (int s = 0; s < seg; ++s) nb += (sg.rows[s] + BN_RB - 1) / BN_RB;
+  return nb;
+}
+
+// partial[blk][c] = (mean, M2) of the block's rows
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t ld, int c, gims_segments sg, float* __restrict__ partial) {
+  __shared__ float red[8][32];
+  int seg, r0, nr;
+  if (!seg_of_block(sg, blockIdx.y, seg, r0, nr)) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, ch = blockIdx.x * 32 + tx;
+  const bool on = ch < c;
+  float s = 0.f;
+  if (on)
+    for (int r = ty; r < nr; r += 8) s += x[(int64_t)(r0 + r) * ld + ch];
+  red[ty][tx] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) tot += red[i][tx];
+  const float mean = tot / (float)nr;
+  __syncthreads();
+  float q = 0.f;
+  if (on)
+    for (int r = ty; r < nr; r += 8) {
+      const float d = x[(int64_t)(r0 + r) * ld + ch] - mean;
+      q = fmaf(d, d, q);
+    }
+  red[ty][tx] = q;
+  __syncthreads();
+  if (ty == 0 && on) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m2 += red[i][tx];
+    partial[((int64_t)blockIdx.y * c + ch) * 2] = mean;
+    partial[((int64_t)blockIdx.y * c + ch) * 2 + 1] = m2;
+  }
+}
+
+// Chan's combination of the block partials of one segment, in block order
+__device__ __forceinline__ void bn_combine(const float* __restrict__ partial, int c, int ch, const gims_segments& sg, int seg, float& mean, float& m2) {
+  const int b0 = seg_first_block(sg, seg), nb = (sg.rows[seg] + BN_RB - 1) / BN_RB;
+  float n = 0.f;
+  mean = 0.f;
+  m2 = 0.f;
+  for (int b = 0; b < nb; ++b) {
+    const float nb_rows = (float)min(BN_RB, sg.rows[seg] - b * BN_RB);
+    const float mb = partial[((int64_t)(b0 + b) * c + ch) * 2], qb = partial[((int64_t)(b0 + b) * c + ch) * 2 + 1];
+    const float d = mb - mean, nn = n + nb_rows;
+    mean += d * (nb_rows / nn);
+    m2 += qb + d * d * (n * nb_rows / nn);
+    n = nn;
+  }
+}
+
+// y = [relu](gamma * (x - mean) / sqrt(var + eps) + beta); saves mean / invstd per (segment, channel); block 0 updates the running
+// statistics segment by segment (momentum, unbiased variance: torch.nn.BatchNorm1d)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t ld, int c, gims_segments sg, const float* __restrict__ partial,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ save,
+                                                       float* __restrict__ y, int64_t ldy, int relu) {
+  __shared__ float sm[32], si[32];
+  int seg, r0, nr;
+  if (!seg_of_block(sg, blockIdx.y, seg, r0, nr)) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, ch = blockIdx.x * 32 + tx;
+  const bool on = ch < c;
+  if (ty == 0 && on) {
+    float mean, m2;
+    bn_combine(partial, c, ch, sg, seg, mean, m2);
+    const float var = m2 / (float)sg.rows[seg];
+    sm[tx] = mean;
+    si[tx] = 1.f / sqrtf(var + eps);
+  }
+  if (blockIdx.y == 0 && ty == 1 && on) {
+    float rm = run_mean ? run_mean[ch] : 0.f, rv = run_var ? run_var[ch] : 0.f;
+    for (int s = 0; s < sg.n; ++s) {
+      float mean, m2;
+      bn_combine(partial, c, ch, sg, s, mean, m2);
+      const float n = (float)sg.rows[s];
+      save[((int64_t)s * c + ch) * 2] = mean;
+      save[((int64_t)s * c + ch) * 2 + 1] = 1.f / sqrtf(m2 / n + eps);
+      rm = (1.f - momentum) * rm + momentum * mean;
+      rv = (1.f - momentum) * rv + momentum * (m2 / fmaxf(n - 1.f, 1.f));
+    }
+    if (run_mean) run_mean[ch] = rm;
+    if (run_var) run_var[ch] = rv;
+  }
+  __syncthreads();
+  if (!on) return;
+  const float mean = sm[tx], inv = si[tx], gm = gamma[ch], bt = beta[ch];
+  for (int r = ty; r < nr; r += 8) {
+    const float xh = (x[(int64_t)(r0 + r) * ld + ch] - mean) * inv;
+    float v = fmaf(xh, gm, bt);
+    if (relu) v = fmaxf(v, 0.f);
+    y[(int64_t)(r0 + r) * ldy + ch] = v;
+  }
+}
+
+// backward: partial[blk][c] = (sum dyr, sum dyr * xhat), dyr = dy masked by the ReLU that followed the norm
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, int64_t ld, const float* __restrict__ dy, int64_t ldd, int c,
+                                                             gims_segments sg, const float* __restrict__ save, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int relu, float* __restrict__ partial) {
+  __shared__ float red[2][8][32];
+  int seg, r0, nr;
+  if (!seg_of_block(sg, blockIdx.y, seg, r0, nr)) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, ch = blockIdx.x * 32 + tx;
+  const bool on = ch < c;
+  float s1 = 0.f, s2 = 0.f;
+  if (on) {
+    const float mean = save[((int64_t)seg * c + ch) * 2], inv = save[((int64_t)seg * c + ch) * 2 + 1], gm = gamma[ch], bt = beta[ch];
+    for (int r = ty; r < nr; r += 8) {
+      const float xh = (x[(int64_t)(r0 + r) * ld + ch] - mean) * inv;
+      float d = dy[(int64_t)(r0 + r) * ldd + ch];
+      if (relu && !(fmaf(xh, gm, bt) > 0.f)) d = 0.f;
+      s1 += d;
+      s2 = fmaf(d, xh, s2);
+    }
+  }
+  red[0][ty][tx] = s1;
+  red[1][ty][tx] = s2;
+  __syncthreads();
+  if (ty == 0 && on) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      a += red[0][i][tx];
+      b += red[1][i][tx];
+    }
+    partial[((int64_t)blockIdx.y * c + ch) * 2] = a;
+    partial[((int64_t)blockIdx.y * c + ch) * 2 + 1] = b;
+  }
+}
+
+__device__ __forceinline__ void bn_sum2(const float* __restrict__ partial, int c, int ch, const gims_segments& sg, int seg, float& s1, float& s2) {
+  const int b0 = seg_first_block(sg, seg), nb = (sg.rows[seg] + BN_RB - 1) / BN_RB;
+  s1 = 0.f;
+  s2 = 0.f;
+  for (int b = 0; b < nb; ++b) {
+    s1 += partial[((int64_t)(b0 + b) * c + ch) * 2];
+    s2 += partial[((int64_t)(b0 + b) * c + ch) * 2 + 1];
+  }
+}
+
+// dx = gamma * invstd * (dyr - mean(dyr) - xhat * mean(dyr * xhat)); block 0: dgamma = sum dyr * xhat, dbeta = sum dyr over all segments
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int64_t ld, const float* __restrict__ dy, int64_t ldd, int c,
+                                                           gims_segments sg, const float* __restrict__ save, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int relu, const float* __restrict__ partial,
+                                                           float* __restrict__ dx, int64_t ldx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float a1[32], a2[32];
+  int seg, r0, nr;
+  if (!seg_of_block(sg, blockIdx.y, seg, r0, nr)) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, ch = blockIdx.x * 32 + tx;
+  const bool on = ch < c;
+  if (ty == 0 && on) {
+    float s1, s2;
+    bn_sum2(partial, c, ch, sg, seg, s1, s2);
+    a1[tx] = s1 / (float)sg.rows[seg];
+    a2[tx] = s2 / (float)sg.rows[seg];
+  }
+  if (blockIdx.y == 0 && ty == 1 && on) {
+    float g1 = 0.f, g2 = 0.f;
+    for (int s = 0; s < sg.n; ++s) {
+      float s1, s2;
+      bn_sum2(partial, c, ch, sg, s, s1, s2);
+      g1 += s1;
+      g2 += s2;
+    }
+    dbeta[ch] = g1;
+    dgamma[ch] = g2;
+  }
+  __syncthreads();
+  if (!on) return;
+  const float mean = save[((int64_t)seg * c + ch) * 2], inv = save[((int64_t)seg * c + ch) * 2 + 1], gm = gamma[ch], bt = beta[ch];
+  const float m1 = a1[tx], m2 = a2[tx];
+  for (int r = ty; r < nr; r += 8) {
+    const float xh = (x[(int64_t)(r0 + r) * ld + ch] - mean) * inv;
+    float d = dy[(int64_t)(r0 + r) * ldd + ch];
+    if (relu && !(fmaf(xh, gm, bt) > 0.f)) d = 0.f;
+    dx[(int64_t)(r0 + r) * ldx + ch] = gm * inv * (d - m1 - xh * m2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ softmax rows
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  return r;
+}
+
+// in place: s[row][0..cols) <- softmax (gmatcher.py:37); one block per row, blockIdx.y = batch
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int64_t ld, int64_t stride, int cols) {
+  __shared__ float sh[4];
+  float* p = s + (int64_t)blockIdx.y * stride + (int64_t)blockIdx.x * ld;
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < cols; j += 256) mx = fmaxf(mx, p[j]);
+  mx = block_reduce(mx, true, sh);
+  float sum = 0.f;
+  for (int j = threadIdx.x; j < cols; j += 256) {
+    const float e = __expf(p[j] - mx);
+    p[j] = e;
+    sum += e;
+  }
+  sum = block_reduce(sum, false, sh);
+  const float inv = 1.f / sum;
+  for (int j = threadIdx.x; j < cols; j += 256) p[j] *= inv;
+}
+
+// in place on dp: dS = P * (dP - sum_j dP_j P_j)
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ prob, float* __restrict__ dp, int64_t ld, int64_t stride, int cols) {
+  __shared__ float sh[4];
+  const float* p = prob + (int64_t)blockIdx.y * stride + (int64_t)blockIdx.x * ld;
+  float* d = dp + (int64_t)blockIdx.y * stride + (int64_t)blockIdx.x * ld;
+  float dot = 0.f;
+  for (int j = threadIdx.x; j < cols; j += 256) dot = fmaf(p[j], d[j], dot);
+  dot = block_reduce(dot, false, sh);
+  for (int j = threadIdx.x; j < cols; j += 256) d[j] = p[j] * (d[j] - dot);
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// out[ch] = beta * out[ch] + sum_rows x[row][ch]; blocks of 256 rows write partials, the last block of a channel group to
+// finish adds them in block order (deterministic); counters: zero on entry, zero on exit
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int c, float beta, float* __restrict__ out,
+                                                     float* __restrict__ work, unsigned* __restrict__ counters) {
+  __shared__ float red[8][32];
+  __shared__ bool last;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, ch = blockIdx.x * 32 + tx;
+  const bool on = ch < c;
+  const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = min(rows, r0 + 256);
+  float s = 0.f;
+  if (on)
+    for (int64_t r = r0 + ty; r < r1; r += 8) s += x[r * ld + ch];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && on) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += red[i][tx];
+    __hip_atomic_store(work + (int64_t)blockIdx.y * c + ch, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(counters + blockIdx.x, 1u) == gridDim.y - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (ty == 0 && on) {
+    float tot = 0.f;
+    for (unsigned b = 0; b < gridDim.y; ++b) tot += __hip_atomic_load(work + (int64_t)b * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[ch] = beta != 0.f ? fmaf(beta, out[ch], tot) : tot;
+  }
+  if (threadIdx.x == 0) counters[blockIdx.x] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ small element-wise kernels
+__global__ __launch_bounds__(256) void ew_kernel(int op, float* __restrict__ out, int64_t ldo, const float* __restrict__ a, int64_t lda,
+                                                 const float* __restrict__ b, int64_t ldb, int64_t rows, int cols, float alpha) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t r = i / cols;
+  const int cc = (int)(i - r * cols);
+  const float av = a[r * lda + cc];
+  float v;
+  switch (op) {
+    case GIMS_EW_ADD: v = av + alpha * b[r * ldb + cc]; break;
+    case GIMS_EW_RELU_MASK: v = b[r * ldb + cc] > 0.f ? av : 0.f; break;
+    case GIMS_EW_RELU: v = fmaxf(av, 0.f); break;
+    case GIMS_EW_ACC: v = out[r * ldo + cc] + alpha * av; break;
+    default: v = alpha * av; break;
+  }
+  out[r * ldo + cc] = v;
+}
+
+// dst[i0*d0 + i1*d1 + i2*d2] (=|+=) src[i0*s0 + i1*s1 + i2*s2]
+__global__ __launch_bounds__(256) void permute3_kernel(float* __restrict__ dst, const float* __restrict__ src, int n0, int n1, int n2, int64_t d0, int64_t d1,
+                                                       int64_t d2, int64_t s0, int64_t s1, int64_t s2, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)n0 * n1 * n2) return;
+  const int i2 = (int)(i % n2), i1 = (int)((i / n2) % n1), i0 = (int)(i / ((int64_t)n1 * n2));
+  const float v = src[i0 * s0 + i1 * s1 + i2 * s2];
+  float* o = dst + i0 * d0 + i1 * d1 + i2 * d2;
+  *o = accumulate ? *o + v : v;
+}
+
+// transposed mean aggregation: out_j = sum over in-neighbours i of j (symmetric CSR) of g_i / deg_i  -- the gradient of
+// mean_{j in N(i)} h_j with respect to h (SAGEConv 'mean', gmatcher.py:149-158)
+__global__ __launch_bounds__(256) void sage_mean_t_kernel(const float* __restrict__ g, int64_t ldg, const int32_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices, int n, int c, float* __restrict__ out, int64_t ldo) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int node = blockIdx.x * 4 + wave;
+  if (node >= n) return;
+  const int beg = indptr[node], end = indptr[node + 1];
+  for (int q = lane; 4 * q < c; q += 64) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = beg; e < end; ++e) {
+      const int i = indices[e];
+      const float d = (float)(indptr[i + 1] - indptr[i]);
+      const float4 x = *(const float4*)(g + (int64_t)i * ldg + 4 * q);
+      s.x += x.x / d; s.y += x.y / d; s.z += x.z / d; s.w += x.w / d;
+    }
+    *(float4*)(out + (int64_t)node * ldo + 4 * q) = s;
+  }
+}
+
+// normalize_keypoints (gmatcher.py:26-33) as its own tensor: (k - centre) / scale per image
+__global__ __launch_bounds__(256) void normalize_kpts_kernel(const float* __restrict__ kpts, const float* __restrict__ norm3, const int32_t* __restrict__ seg,
+                                                             int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * n) return;
+  const float* nm = norm3 + 3 * seg[i >> 1];
+  out[i] = (kpts[i] - nm[i & 1]) / nm[2];
+}
+
+}  // namespace gims
+
+// ================================================================================================ C ABI
+using namespace gims;
+
+extern "C" int gims_gemm_f32(const gims_gemm* gp, void* stream) {
+  GIMS_CHECK_ARG(gp && gp->a && gp->b && gp->c && gp->m >= 0 && gp->n >= 0 && gp->k >= 0 && gp->batch >= 1 && gp->batch <= 65535,
+                 "gims_gemm_f32: bad arguments");
+  gims_gemm g = *gp;
+  if (g.m == 0 || g.n == 0) return GIMS_OK;
+  GIMS_CHECK_ARG(g.lda >= (g.ta ? g.m : g.k) && g.ldb >= (g.tb ? g.n : g.k) && g.ldc >= g.n && (!g.residual || g.ldr >= g.n),
+                 "gims_gemm_f32: leading dimension smaller than the row it strides");
+  auto vec_ok = [&](const float* p, int64_t ld, int64_t st) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0 && (g.batch == 1 || (st & 3) == 0); };
+  g.flags = (vec_ok(g.a, g.lda, g.sa) ? 1 : 0) | (vec_ok(g.b, g.ldb, g.sb) ? 2 : 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (!g.ta && !g.tb) gemm_launch<false, false>(g, s);
+  else if (!g.ta && g.tb) gemm_launch<false, true>(g, s);
+  else if (g.ta && !g.tb) gemm_launch<true, false>(g, s);
+  else gemm_launch<true, true>(g, s);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+static int check_segments(const gims_segments* sg, const char* who) {
+  GIMS_CHECK_ARG(sg && sg->n >= 1 && sg->n <= 8, "%s: 1..8 row segments", who);
+  for (int s = 0; s < sg->n; ++s) GIMS_CHECK_ARG(sg->rows[s] >= 1 && sg->off[s] >= 0, "%s: empty or negative row segment", who);
+  return GIMS_OK;
+}
+
+extern "C" size_t gims_batchnorm_workspace_floats(const gims_segments* sg, int32_t c) {
+  if (!sg || sg->n < 1 || sg->n > 8 || c <= 0) return 0;
+  return (size_t)seg_blocks(*sg) * (size_t)c * 2;
+}
+
+extern "C" int gims_batchnorm_train_forward(const float* x, int64_t ld, int32_t c, const gims_segments* sg, const float* gamma, const float* beta, float eps,
+                                            float momentum, float* running_mean, float* running_var, float* save, float* y, int64_t ldy, int32_t relu,
+                                            float* work, void* stream) {
+  GIMS_CHECK_ARG(x && gamma && beta && save && y && work && c > 0 && ld >= c && ldy >= c, "gims_batchnorm_train_forward: bad arguments");
+  if (int rc = check_segments(sg, "gims_batchnorm_train_forward")) return rc;
+  const dim3 grid(cdiv(c, 32), seg_blocks(*sg));
+  hipLaunchKernelGGL(bn_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ld, c, *sg, work);
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ld, c, *sg, (const float*)work, gamma, beta, eps, momentum,
+                     running_mean, running_var, save, y, ldy, relu);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_batchnorm_train_backward(const float* x, int64_t ld, const float* dy, int64_t ldd, int32_t c, const gims_segments* sg, const float* save,
+                                             const float* gamma, const float* beta, int32_t relu, float* dx, int64_t ldx, float* dgamma, float* dbeta,
+                                             float* work, void* stream) {
+  GIMS_CHECK_ARG(x && dy && save && gamma && beta && dx && dgamma && dbeta && work && c > 0 && ld >= c && ldd >= c && ldx >= c,
+                 "gims_batchnorm_train_backward: bad arguments");
+  if (int rc = check_segments(sg, "gims_batchnorm_train_backward")) return rc;
+  const dim3 grid(cdiv(c, 32), seg_blocks(*sg));
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ld, dy, ldd, c, *sg, save, gamma, beta, relu, work);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ld, dy, ldd, c, *sg, save, gamma, beta, relu, (const float*)work, dx,
+                     ldx, dgamma, dbeta);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_softmax_rows(float* s, int64_t ld, int64_t rows, int32_t cols, int32_t batch, int64_t stride, void* stream) {
+  GIMS_CHECK_ARG(s && ld >= cols && rows >= 0 && cols >= 1 && batch >= 1 && batch <= 65535, "gims_softmax_rows: bad arguments");
+  if (rows == 0) return GIMS_OK;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows, batch), dim3(256), 0, (hipStream_t)stream, s, ld, stride, cols);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_softmax_rows_backward(const float* prob, float* dp, int64_t ld, int64_t rows, int32_t cols, int32_t batch, int64_t stride, void* stream) {
+  GIMS_CHECK_ARG(prob && dp && ld >= cols && rows >= 0 && cols >= 1 && batch >= 1 && batch <= 65535, "gims_softmax_rows_backward: bad arguments");
+  if (rows == 0) return GIMS_OK;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows, batch), dim3(256), 0, (hipStream_t)stream, prob, dp, ld, stride, cols);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" size_t gims_colsum_workspace_floats(int64_t rows, int32_t c) {
+  if (rows <= 0 || c <= 0) return 0;
+  return 64 + (size_t)cdiv(rows, 256) * (size_t)c;          // [64 counters (fixed place, zero between calls)][row blocks][c] partials
+}
+
+extern "C" int gims_colsum(const float* x, int64_t ld, int64_t rows, int32_t c, float beta, float* out, float* work, void* stream) {
+  GIMS_CHECK_ARG(x && out && work && rows >= 1 && c >= 1 && c <= 2048 && ld >= c, "gims_colsum: bad arguments (c <= 2048)");
+  const int nrb = cdiv(rows, 256);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 32), nrb), dim3(256), 0, (hipStream_t)stream, x, ld, rows, c, beta, out, work + 64, (unsigned*)work);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_elementwise(int32_t op, float* out, int64_t ldo, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t cols,
+                                float alpha, void* stream) {
+  GIMS_CHECK_ARG(out && a && rows >= 0 && cols >= 1 && ldo >= cols && lda >= cols, "gims_elementwise: bad arguments");
+  GIMS_CHECK_ARG(op >= GIMS_EW_SCALE && op <= GIMS_EW_ACC, "gims_elementwise: unknown operation %d", op);
+  GIMS_CHECK_ARG((op != GIMS_EW_ADD && op != GIMS_EW_RELU_MASK) || (b && ldb >= cols), "gims_elementwise: this operation needs a second operand");
+  if (rows == 0) return GIMS_OK;
+  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, op, out, ldo, a, lda, b, ldb, rows, cols, alpha);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_permute3(float* dst, const float* src, int32_t n0, int32_t n1, int32_t n2, int64_t d0, int64_t d1, int64_t d2, int64_t s0, int64_t s1,
+                             int64_t s2, int32_t accumulate, void* stream) {
+  GIMS_CHECK_ARG(dst && src && n0 >= 1 && n1 >= 1 && n2 >= 1, "gims_permute3: bad arguments");
+  hipLaunchKernelGGL(permute3_kernel, dim3((unsigned)cdiv((int64_t)n0 * n1 * n2, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n0, n1, n2, d0, d1, d2,
+                     s0, s1, s2, accumulate);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_sage_mean_transposed(const float* g, int64_t ldg, const int32_t* indptr, const int32_t* indices, int32_t n, int32_t c, float* out,
+                                         int64_t ldo, void* stream) {
+  GIMS_CHECK_ARG(g && indptr && indices && out && n >= 0 && c >= 4 && (c % 4) == 0 && (ldg % 4) == 0 && (ldo % 4) == 0,
+                 "gims_sage_mean_transposed: bad arguments (c, pitches multiples of 4)");
+  if (n == 0) return GIMS_OK;
+  hipLaunchKernelGGL(sage_mean_t_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, g, ldg, indptr, indices, n, c, out, ldo);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_normalize_keypoints(const float* kpts, const float* norm3, const int32_t* seg_of_row, int64_t n, float* out, void* stream) {
+  GIMS_CHECK_ARG(kpts && norm3 && seg_of_row && out && n >= 0, "gims_normalize_keypoints: bad arguments");
+  if (n == 0) return GIMS_OK;
+  hipLaunchKernelGGL(normalize_kpts_kernel, dim3((unsigned)cdiv(2 * n, 256)), dim3(256), 0, (hipStream_t)stream, kpts, norm3, seg_of_row, n, out);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}

@@ -84,6 +84,19 @@ class LossPair(C.Structure):
                 ("kept0", C.c_void_p), ("kept1", C.c_void_p)]
 
 
+class Gemm(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64),
+                ("sa", C.c_int64), ("sb", C.c_int64), ("sc", C.c_int64), ("sr", C.c_int64),
+                ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("batch", C.c_int32),
+                ("ta", C.c_int32), ("tb", C.c_int32), ("act", C.c_int32), ("flags", C.c_int32),
+                ("alpha", C.c_float), ("beta", C.c_float)]
+
+
+class Segments(C.Structure):
+    _fields_ = [("n", C.c_int32), ("off", C.c_int32 * 8), ("rows", C.c_int32 * 8)]
+
+
 class EvalPair(C.Structure):
     _fields_ = [("kpts0", C.c_void_p), ("kpts1", C.c_void_p), ("matches0", C.c_void_p), ("mscores0", C.c_void_p),
                 ("n0", C.c_int32), ("n1", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("h_gt", C.c_float * 9),
@@ -173,6 +186,21 @@ _SIGNATURES = {
     "gims_train_loss_grad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "gims_train_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    "gims_gemm_f32": (C.c_int, [C.POINTER(Gemm), C.c_void_p]),
+    "gims_batchnorm_workspace_floats": (C.c_size_t, [C.POINTER(Segments), C.c_int32]),
+    "gims_batchnorm_train_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(Segments), C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gims_batchnorm_train_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(Segments), C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gims_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "gims_softmax_rows_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "gims_colsum_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "gims_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gims_elementwise": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float,
+                                   C.c_void_p]),
+    "gims_permute3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_int64] * 6 + [C.c_int32, C.c_void_p]),
+    "gims_sage_mean_transposed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gims_normalize_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gims_ot_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
 }
@@ -854,3 +882,133 @@ def patch_extract(pyr: torch.Tensor, dev_levels: torch.Tensor, n_levels: int, kp
     bad = torch.empty(1, dtype=torch.int32, device=pyr.device)
     _check(load().gims_patch_extract(_p(pyr), _p(dev_levels), n_levels, _p(kp4), _p(kp_octave), n, _p(out), _p(bad), _stream()), "gims_patch_extract")
     return out, bad
+
+
+# ------------------------------------------------------------------------------------------------ training step
+EW_SCALE, EW_ADD, EW_RELU_MASK, EW_RELU, EW_ACC = 0, 1, 2, 3, 4
+
+
+def _operand(x: torch.Tensor):
+    """A 2-D (or batched 3-D) f32 tensor VIEW as a GEMM operand [rows][k]: (transposed flag, pitch, batch stride).  The view
+    must be contiguous along one of its last two dimensions -- `w.t()`, column slices and head slices all qualify."""
+    if x.dtype != torch.float32 or not x.is_cuda or x.dim() not in (2, 3):
+        raise GimsHipError("gemm operands are 2-D / 3-D f32 device tensors")
+    st = x.stride(0) if x.dim() == 3 else 0
+    r, k = x.shape[-2], x.shape[-1]
+    if x.stride(-1) == 1 or k == 1:
+        return 0, (x.stride(-2) if r > 1 else max(k, x.stride(-2))), st
+    if x.stride(-2) == 1 or r == 1:
+        return 1, (x.stride(-1) if k > 1 else max(r, x.stride(-1))), st
+    raise GimsHipError("gemm operand is contiguous along neither of its last two dimensions")
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, *, alpha=1.0, beta=0.0, bias=None, residual=None, act=ACT_NONE):
+    """out = alpha * a @ b^T + beta * out (+ bias over the last dimension) (+ residual), then act (gims_gemm_f32, f32-class
+    split-bf16x3 MFMA).  a: [.., m, k], b: [.., n, k] views (either may be a transposed view), out: [.., m, n] with unit
+    stride along n.  Batched when the tensors are 3-D."""
+    ta, lda, sa = _operand(a)
+    tb, ldb, sb = _operand(b)
+    m, k, n = a.shape[-2], a.shape[-1], b.shape[-2]
+    if b.shape[-1] != k or a.dim() != b.dim():
+        raise GimsHipError(f"gemm: shapes {tuple(a.shape)} x {tuple(b.shape)}^T do not agree")
+    batch = a.shape[0] if a.dim() == 3 else 1
+    if out is None:
+        out = torch.empty((batch, m, n) if a.dim() == 3 else (m, n), dtype=torch.float32, device=a.device)
+    if out.shape[-2:] != (m, n) or (out.stride(-1) != 1 and n > 1) or out.dtype != torch.float32:
+        raise GimsHipError("gemm: bad output tensor")
+    g = Gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), lda, ldb, out.stride(-2) if m > 1 else max(n, out.stride(-2)),
+             (residual.stride(-2) if residual is not None else 0), sa, sb, out.stride(0) if out.dim() == 3 else 0,
+             (residual.stride(0) if (residual is not None and residual.dim() == 3) else 0), m, n, k, batch, ta, tb, int(act), 0, float(alpha), float(beta))
+    _check(load().gims_gemm_f32(C.byref(g), _stream()), "gims_gemm_f32")
+    return out
+
+
+def segments(ranges) -> Segments:
+    """ranges: [(first row, rows)] -- the rows every call of a module covers in the reference (image 0 of the batch, image 1)."""
+    sg = Segments()
+    sg.n = len(ranges)
+    for i, (o, r) in enumerate(ranges):
+        sg.off[i], sg.rows[i] = int(o), int(r)
+    return sg
+
+
+def batchnorm_train_forward(x, sg: Segments, gamma, beta, eps, momentum, running_mean, running_var, relu: bool, y=None):
+    """nn.BatchNorm1d in train() mode (+ ReLU) on x [rows, c]; returns (y, save).  Running statistics are updated in place."""
+    c = x.shape[1]
+    y = torch.empty_like(x) if y is None else y
+    save = torch.empty((sg.n, c, 2), dtype=torch.float32, device=x.device)
+    work = torch.empty(int(load().gims_batchnorm_workspace_floats(C.byref(sg), c)), dtype=torch.float32, device=x.device)
+    _check(load().gims_batchnorm_train_forward(_p(x), x.stride(0), c, C.byref(sg), _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
+                                               _p(running_var), _p(save), _p(y), y.stride(0), int(relu), _p(work), _stream()), "gims_batchnorm_train_forward")
+    return y, save
+
+
+def batchnorm_train_backward(x, dy, sg: Segments, save, gamma, beta, relu: bool, dx=None):
+    """Returns (dx, dgamma, dbeta) for the module of batchnorm_train_forward; dy: gradient of its (post-ReLU) output."""
+    c = x.shape[1]
+    dx = torch.empty_like(x) if dx is None else dx
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    work = torch.empty(int(load().gims_batchnorm_workspace_floats(C.byref(sg), c)), dtype=torch.float32, device=x.device)
+    _check(load().gims_batchnorm_train_backward(_p(x), x.stride(0), _p(dy), dy.stride(0), c, C.byref(sg), _p(save), _p(gamma), _p(beta), int(relu),
+                                                _p(dx), dx.stride(0), _p(dg), _p(db), _p(work), _stream()), "gims_batchnorm_train_backward")
+    return dx, dg, db
+
+
+def softmax_rows_(s: torch.Tensor, cols: int):
+    """In-place softmax over the first `cols` entries of every row of s [batch, rows, ld]."""
+    assert s.dim() == 3 and s.stride(2) == 1
+    _check(load().gims_softmax_rows(_p(s), s.stride(1), s.shape[1], int(cols), s.shape[0], s.stride(0), _stream()), "gims_softmax_rows")
+    return s
+
+
+def softmax_rows_backward_(prob: torch.Tensor, dp: torch.Tensor, cols: int):
+    assert prob.shape == dp.shape and prob.stride() == dp.stride() and prob.dim() == 3
+    _check(load().gims_softmax_rows_backward(_p(prob), _p(dp), prob.stride(1), prob.shape[1], int(cols), prob.shape[0], prob.stride(0), _stream()),
+           "gims_softmax_rows_backward")
+    return dp
+
+
+_colsum_work = {}
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor | None = None, beta=0.0):
+    """out[c] = beta * out[c] + sum_rows x[row, c] (fixed summation order)."""
+    rows, c = x.shape
+    if out is None:
+        out = torch.empty(c, dtype=torch.float32, device=x.device)
+    need = int(load().gims_colsum_workspace_floats(rows, c))
+    key = (x.device, _stream())
+    w = _colsum_work.get(key)
+    if w is None or w.numel() < need:
+        w = _colsum_work[key] = torch.zeros(max(need, 1 << 16), dtype=torch.float32, device=x.device)
+    # (the kernel leaves its counters -- the first 64 words -- zeroed; partials are overwritten before they are read)
+    _check(load().gims_colsum(_p(x), x.stride(0), rows, c, float(beta), _p(out), _p(w), _stream()), "gims_colsum")
+    return out
+
+
+def elementwise(op: int, out, a, b=None, alpha=1.0):
+    rows, cols = a.shape
+    _check(load().gims_elementwise(int(op), _p(out), out.stride(0), _p(a), a.stride(0), _p(b), (b.stride(0) if b is not None else 0), rows, cols,
+                                   float(alpha), _stream()), "gims_elementwise")
+    return out
+
+
+def permute3(dst, src, shape, dstrides, sstrides, accumulate=False):
+    _check(load().gims_permute3(_p(dst), _p(src), *[int(v) for v in shape], *[int(v) for v in dstrides], *[int(v) for v in sstrides], int(accumulate),
+                                _stream()), "gims_permute3")
+    return dst
+
+
+def sage_mean_transposed(g, indptr, indices, out=None):
+    n, c = g.shape
+    out = torch.empty_like(g) if out is None else out
+    _check(load().gims_sage_mean_transposed(_p(g), g.stride(0), _p(indptr), _p(indices), n, c, _p(out), out.stride(0), _stream()),
+           "gims_sage_mean_transposed")
+    return out
+
+
+def normalize_keypoints(kpts, norm3, seg):
+    out = torch.empty_like(kpts)
+    _check(load().gims_normalize_keypoints(_p(kpts), _p(norm3), _p(seg), kpts.shape[0], _p(out), _stream()), "gims_normalize_keypoints")
+    return out

@@ -481,6 +481,74 @@ int gims_pyramid_build(const uint8_t* img, int32_t h, int32_t w, int32_t c, uint
 int gims_patch_extract(const uint8_t* pyr, const gims_pyr_level* dev_levels, int32_t n_levels, const float* kp4, const int32_t* kp_octave,
                        int32_t n_kp, float* out, int32_t* bad_count, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training step (SURVEY 8f, row f3 = a25): GMatcher.forward(data, mode='train') on a module in train() mode followed by
+ * loss.backward() (models/gmatcher.py:309-386 under train.py:100, 136-137).  gims_amd/trainstep.py composes the entry points
+ * below (with gims_agc_build, gims_sage_mean, gims_sinkhorn_match, gims_train_loss, gims_sinkhorn_history,
+ * gims_train_loss_grad and gims_sinkhorn_backward) into the forward and the reverse pass behind a torch.autograd.Function
+ * whose inputs are the module's parameters; activations are row-major f32 [keypoint rows][channels].
+ *
+ * gims_gemm_f32: for z < batch   C_z = alpha * op(A_z) op(B_z)^T + beta * C_z (+ bias[n]) (+ residual_z), then act.
+ *   op(A)(m, k) = ta ? A[k * lda + m] : A[m * lda + k];  op(B)(n, k) = tb ? B[k * ldb + n] : B[n * ldb + k].
+ *   X_z = X + z * s{a,b,c,r} elements.  Arithmetic: f32 operands split into bf16 hi + lo, three bf16 MFMA passes, f32
+ *   accumulation (the f32-class mode of gims_linear).  Replaces every torch matmul / conv1d(k=1) / einsum of the step and of
+ *   its autograd: nn.Conv1d forward, grad_input, grad_weight (gmatcher.py:11-24, 99-125, 202-205), attention (35-39), the
+ *   score einsum (273-275).  Any m, n, k >= 0; 16-byte aligned operands with pitches that are multiples of 4 take the
+ *   vector path, anything else is read element by element.  `flags` is set by the library. */
+typedef struct gims_gemm {
+  const float* a; const float* b; float* c;
+  const float* bias;          /* [n] or NULL */
+  const float* residual;      /* [m][ldr] or NULL */
+  int64_t lda, ldb, ldc, ldr;
+  int64_t sa, sb, sc, sr;
+  int32_t m, n, k, batch;
+  int32_t ta, tb;
+  int32_t act;                /* GIMS_ACT_* */
+  int32_t flags;
+  float alpha, beta;
+} gims_gemm;
+int gims_gemm_f32(const gims_gemm* g, void* stream);
+
+/* Row segments of a batch: one segment per call of the module in the reference (all image-0 rows, all image-1 rows). */
+typedef struct gims_segments { int32_t n; int32_t off[8]; int32_t rows[8]; } gims_segments;
+/* nn.BatchNorm1d in train() mode after a Conv1d (gmatcher.py:17-22), optionally with the ReLU that follows it:
+ * statistics per (segment, channel) over the segment's rows, biased variance for the normalisation; running_mean /
+ * running_var (may be NULL) are updated segment by segment with `momentum` and the unbiased variance, exactly the sequence
+ * of updates the reference's two calls per layer make.  save [segments][c][2] = (mean, 1/sqrt(var + eps)) for the backward
+ * pass; work: gims_batchnorm_workspace_floats floats.  Backward: dy is the gradient of the (post-ReLU) output; the ReLU mask
+ * is recomputed from x; dgamma / dbeta are the sums over all segments. */
+size_t gims_batchnorm_workspace_floats(const gims_segments* sg, int32_t c);
+int gims_batchnorm_train_forward(const float* x, int64_t ld, int32_t c, const gims_segments* sg, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* save, float* y, int64_t ldy, int32_t relu,
+                                 float* work, void* stream);
+int gims_batchnorm_train_backward(const float* x, int64_t ld, const float* dy, int64_t ldd, int32_t c, const gims_segments* sg, const float* save,
+                                  const float* gamma, const float* beta, int32_t relu, float* dx, int64_t ldx, float* dgamma, float* dbeta,
+                                  float* work, void* stream);
+/* softmax over the last dimension of `batch` matrices [rows][cols] (pitch ld, matrix stride `stride`), in place
+ * (gmatcher.py:37), and its backward: dp <- prob * (dp - rowsum(dp * prob)), in place on dp. */
+int gims_softmax_rows(float* s, int64_t ld, int64_t rows, int32_t cols, int32_t batch, int64_t stride, void* stream);
+int gims_softmax_rows_backward(const float* prob, float* dp, int64_t ld, int64_t rows, int32_t cols, int32_t batch, int64_t stride, void* stream);
+/* out[ch] = beta * out[ch] + sum over rows of x[row][ch] (bias gradients), fixed summation order.  work: zero-initialised
+ * once by the caller (gims_colsum_workspace_floats floats), left zeroed where it must be. */
+size_t gims_colsum_workspace_floats(int64_t rows, int32_t c);
+int gims_colsum(const float* x, int64_t ld, int64_t rows, int32_t c, float beta, float* out, float* work, void* stream);
+#define GIMS_EW_SCALE 0      /* out = alpha * a */
+#define GIMS_EW_ADD 1        /* out = a + alpha * b */
+#define GIMS_EW_RELU_MASK 2  /* out = b > 0 ? a : 0   (gradient of ReLU, b = the ReLU's output) */
+#define GIMS_EW_RELU 3       /* out = max(a, 0) */
+#define GIMS_EW_ACC 4        /* out += alpha * a */
+int gims_elementwise(int32_t op, float* out, int64_t ldo, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t cols,
+                     float alpha, void* stream);
+/* dst[i0*d0 + i1*d1 + i2*d2] (= | +=) src[i0*s0 + i1*s1 + i2*s2] over [n0][n1][n2]: the reference's interleaved heads
+ * (channel = d * heads + h, gmatcher.py:108-113) <-> contiguous heads, for weights on the way in and gradients on the way out. */
+int gims_permute3(float* dst, const float* src, int32_t n0, int32_t n1, int32_t n2, int64_t d0, int64_t d1, int64_t d2, int64_t s0, int64_t s1,
+                  int64_t s2, int32_t accumulate, void* stream);
+/* gradient of gims_sage_mean with respect to its input: out_j = sum over neighbours i of j of g_i / deg_i (symmetric CSR). */
+int gims_sage_mean_transposed(const float* g, int64_t ldg, const int32_t* indptr, const int32_t* indices, int32_t n, int32_t c, float* out,
+                              int64_t ldo, void* stream);
+/* normalize_keypoints (gmatcher.py:26-33) as a tensor: out [n][2] = (kpts - norm3[seg][0..1]) / norm3[seg][2]. */
+int gims_normalize_keypoints(const float* kpts, const float* norm3, const int32_t* seg_of_row, int64_t n, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

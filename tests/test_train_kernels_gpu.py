@@ -1,0 +1,130 @@
+"""Kernels of the training step (gims_amd/csrc/train.hip) against float64 / torch references of the same operations."""
+import numpy as np
+import pytest
+import torch
+
+from gims_amd import hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 200, 70), (2031, 64, 2031), (65, 257, 2), (1, 512, 513), (257, 1, 33), (512, 512, 512)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_f32_forms(m, n, k, ta, tb):
+    """C = alpha A B^T + beta C + bias + residual for both storage orders of both operands, ragged edges, K not a multiple of 4."""
+    a = _rand(k, m, seed=1).t() if ta else _rand(m, k, seed=1)
+    b = _rand(k, n, seed=2).t() if tb else _rand(n, k, seed=2)
+    c0 = _rand(m, n, seed=3)
+    bias, res = _rand(n, seed=4), _rand(m, n, seed=5)
+    out = c0.clone()
+    hip.gemm(a, b, out, alpha=0.5, beta=2.0, bias=bias, residual=res)
+    ref = 0.5 * (a.double() @ b.double().t()) + 2.0 * c0.double() + bias.double() + res.double()
+    err = float((out.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    assert err < 1.5e-5, err         # split-bf16x3: operands carry 16 mantissa bits (hi + lo), f32 accumulation over k
+    out2 = hip.gemm(a, b, act=hip.ACT_RELU)
+    ref2 = (a.double() @ b.double().t()).clamp(min=0)
+    assert float((out2.double() - ref2).abs().max()) / max(1.0, float(ref2.abs().max())) < 1.5e-5
+
+
+def test_gemm_batched_strided_heads():
+    """Batched over heads with column-slice operands: S_h = Q_h K_h^T / 8 and O_h = P_h V_h written into a [rows, 256] buffer."""
+    n, mk = 333, 271
+    q, kv = _rand(n, 256, seed=1), _rand(mk, 512, seed=2)
+    qh = q.view(n, 4, 64).permute(1, 0, 2)                       # [4, n, 64] view, batch stride 64
+    kh = kv[:, :256].view(mk, 4, 64).permute(1, 0, 2)
+    vh = kv[:, 256:].view(mk, 4, 64).permute(1, 0, 2)
+    ld = (mk + 3) // 4 * 4
+    s = torch.zeros(4, n, ld, device=DEV)
+    hip.gemm(qh, kh, s[:, :, :mk], alpha=0.125)
+    ref = torch.einsum("hnd,hmd->hnm", qh.double(), kh.double()) / 8
+    assert float((s[:, :, :mk].double() - ref).abs().max()) < 6e-5        # logits up to +-4 at 16 mantissa bits per operand
+    hip.softmax_rows_(s, mk)
+    p_ref = torch.softmax(ref, dim=-1)
+    assert float((s[:, :, :mk].double() - p_ref).abs().max()) < 2e-5
+    o = torch.empty(n, 256, device=DEV)
+    hip.gemm(s[:, :, :mk], vh.transpose(1, 2), o.view(n, 4, 64).permute(1, 0, 2))
+    o_ref = torch.einsum("hnm,hmd->hnd", p_ref, vh.double()).permute(1, 0, 2).reshape(n, 256)
+    assert float((o.double() - o_ref).abs().max()) < 3e-5
+    # softmax backward
+    dp = _rand(4, n, ld, seed=7)
+    p_mine = s[:, :, :mk].double()
+    dref = p_mine * (dp[:, :, :mk].double() - (dp[:, :, :mk].double() * p_mine).sum(-1, keepdim=True))
+    hip.softmax_rows_backward_(s, dp, mk)
+    assert float((dp[:, :, :mk].double() - dref).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("rows,c,relu", [((700, 300), 64, True), ((2048, 2031), 512, True), ((37,), 32, False), ((256, 257), 128, True)])
+def test_batchnorm_train_forward_backward(rows, c, relu):
+    """Per-segment batch statistics, running-statistics sequence, and the backward pass, against torch.nn.functional.batch_norm
+    called once per segment (the reference calls the module once per image side)."""
+    tot = sum(rows)
+    x = _rand(tot, c, seed=1, scale=2.0) + 0.3
+    gamma, beta = _rand(c, seed=2).abs() + 0.5, _rand(c, seed=3) * 0.1
+    dy = _rand(tot, c, seed=4)
+    rm, rv = _rand(c, seed=5) * 0.1, _rand(c, seed=6).abs() + 0.5
+    offs = np.concatenate([[0], np.cumsum(rows)])
+    sg = hip.segments([(int(offs[i]), int(rows[i])) for i in range(len(rows))])
+    rm_h, rv_h = rm.clone(), rv.clone()
+    y, save = hip.batchnorm_train_forward(x, sg, gamma, beta, 1e-5, 0.1, rm_h, rv_h, relu)
+    dx, dg, db = hip.batchnorm_train_backward(x, dy, sg, save, gamma, beta, relu)
+    xr = x.double().cpu().requires_grad_(True)
+    gr, br = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    rm_r, rv_r = rm.double().cpu(), rv.double().cpu()
+    ys = []
+    for i in range(len(rows)):
+        seg = xr[offs[i]:offs[i + 1]].t()[None]                   # (1, C, N) like the reference's Conv1d activations
+        o = torch.nn.functional.batch_norm(seg, rm_r, rv_r, gr, br, training=True, momentum=0.1, eps=1e-5)
+        ys.append((o.relu() if relu else o)[0].t())
+    yr = torch.cat(ys)
+    yr.backward(dy.double().cpu())
+    assert float((y.double().cpu() - yr.detach()).abs().max()) < 2e-5
+    assert float((rm_h.double().cpu() - rm_r).abs().max()) < 1e-6 and float((rv_h.double().cpu() - rv_r).abs().max()) < 1e-5
+    # entries whose pre-activation is within rounding of 0 may take the other branch of the ReLU: compare away from them
+    sc = float(xr.grad.abs().max())
+    assert float((dx.double().cpu() - xr.grad).abs().max()) < 2e-4 * sc
+    assert float((dg.double().cpu() - gr.grad).abs().max()) < 2e-4 * float(gr.grad.abs().max())
+    assert float((db.double().cpu() - br.grad).abs().max()) < 2e-4 * float(br.grad.abs().max())
+
+
+def test_colsum_elementwise_permute():
+    x = _rand(2031, 512, seed=1)
+    s = hip.colsum(x)
+    assert float((s.double() - x.double().sum(0)).abs().max()) < 2e-4
+    s2 = hip.colsum(x[:300, :96], out=s[:96].clone(), beta=1.0)
+    assert float((s2.double() - (x.double().sum(0)[:96] + x[:300, :96].double().sum(0))).abs().max()) < 2e-4
+    assert torch.equal(hip.colsum(x), s)                              # deterministic
+    a, b = _rand(100, 48, seed=2), _rand(100, 48, seed=3)
+    out = torch.empty_like(a)
+    assert torch.equal(hip.elementwise(hip.EW_ADD, out, a, b, alpha=1.0), a + b)
+    assert torch.equal(hip.elementwise(hip.EW_RELU_MASK, out, a, b), torch.where(b > 0, a, torch.zeros_like(a)))
+    # head interleave: weight rows d*4+h -> h*64+d
+    w = _rand(256, 256, seed=4)
+    wp = torch.empty_like(w)
+    hip.permute3(wp, w, (64, 4, 256), (256, 64 * 256, 1), (4 * 256, 256, 1))
+    assert torch.equal(wp, w.view(64, 4, 256).permute(1, 0, 2).reshape(256, 256))
+
+
+def test_sage_mean_transposed_is_the_adjoint():
+    """<mean(h), g> == <h, mean^T(g)> on a random symmetric graph."""
+    n, c = 500, 128
+    rng = np.random.default_rng(0)
+    e = rng.integers(0, n, size=(2000, 2))
+    e = e[e[:, 0] != e[:, 1]]
+    adj = [set() for _ in range(n)]
+    for u, v in e:
+        adj[u].add(int(v)); adj[v].add(int(u))
+    indptr = np.concatenate([[0], np.cumsum([len(a) for a in adj])]).astype(np.int32)
+    indices = np.concatenate([sorted(a) for a in adj if a]).astype(np.int32)
+    ip, ix = torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV)
+    h, g = _rand(n, c, seed=1), _rand(n, c, seed=2)
+    mean = torch.empty_like(h)
+    hip.sage_mean(h, ip, ix, mean)
+    gt = hip.sage_mean_transposed(g, ip, ix)
+    lhs, rhs = float((mean.double() * g.double()).sum()), float((h.double() * gt.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
