@@ -44,6 +44,7 @@ struct OtBwd {                    // one problem of the backward sweep
   const float* hist; int64_t hstride;     // potentials after iteration k at hist + k * hstride: u [n+1] then v [m+1]; k = 0 .. iters (slot 0 unused)
   float* dz;                               // [(n+1)][(m+1)], holds G on entry, dL/dZc on exit
   float* gu; float* gv; float* gv2;        // [n+1], [m+1], [m+1]
+  float* colpart;                          // [ceil((n+1)/8)][m+1] per-slab column partials of the fused sweep
   float* dalpha;
   float norm, log_mu_bin, log_nu_bin;
 };
@@ -572,6 +573,100 @@ __global__ __launch_bounds__(256) void ot_bwd_row_kernel(const OtBwd* __restrict
     acc += t;
   }
   p.gv2[j] = -acc;
+}
+
+// The sweep as it runs (the three kernels above are the unfused statement of the same arithmetic, kept for the small-problem
+// cross-check in tests): ONE pass over Z and one read-modify-write of dZc per iteration.  A workgroup owns a slab of 8 rows, a
+// thread the columns j = t, t + 256, ...: phase 1 reduces sum_j gv[j] C_ij per row over the workgroup (gu_k[i] is final right
+// after its own row's reduction); phase 2 recomputes C, adds the row-step term gu_k[i] R_ij, updates dZc once and keeps the
+// column sums of the row-step terms of its 8 rows -> colpart[slab][j]; ot_bwd_colsum_kernel folds the slabs in order -> gv_{k-1}.
+constexpr int BW_ROWS = 8;
+template <bool INIT>
+__global__ __launch_bounds__(256) void ot_bwd_fused_kernel(const OtBwd* __restrict__ probs, float alpha, int k, int first) {
+  const OtBwd p = probs[blockIdx.y];
+  const int r0 = blockIdx.x * BW_ROWS;
+  if (r0 > p.n) return;
+  const int nr = min(BW_ROWS, p.n + 1 - r0);
+  const int ldz = p.m + 1, tid = threadIdx.x;
+  __shared__ float red[4][BW_ROWS];
+  __shared__ float gnew[BW_ROWS];
+  float acc[BW_ROWS];
+#pragma unroll
+  for (int r = 0; r < BW_ROWS; ++r) acc[r] = 0.f;
+  if constexpr (INIT) {           // gu = row sums of G, colpart = per-slab column sums of G
+    for (int j = tid; j <= p.m; j += 256) {
+      float cs = 0.f;
+#pragma unroll
+      for (int r = 0; r < BW_ROWS; ++r)
+        if (r < nr) {
+          const float g = p.dz[(int64_t)(r0 + r) * ldz + j];
+          acc[r] += g;
+          cs += g;
+        }
+      p.colpart[(int64_t)blockIdx.x * ldz + j] = cs;
+    }
+  } else {
+    const float* uk = p.hist + (int64_t)k * p.hstride;
+    const float* vk = uk + p.n + 1;
+    const float* vprev = p.hist + (int64_t)(k - 1) * p.hstride + p.n + 1;
+    float ui[BW_ROWS];
+#pragma unroll
+    for (int r = 0; r < BW_ROWS; ++r) ui[r] = r < nr ? uk[r0 + r] : 0.f;
+    for (int j = tid; j <= p.m; j += 256) {
+      const float w = vk[j] - (j < p.m ? p.norm : p.log_nu_bin), gvj = p.gv[j];
+#pragma unroll
+      for (int r = 0; r < BW_ROWS; ++r)
+        if (r < nr) {
+          const int i = r0 + r;
+          const float z = (i < p.n && j < p.m) ? p.z[(int64_t)i * p.ld + j] : alpha;
+          acc[r] += gvj * __expf(z + ui[r] + w);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < BW_ROWS; ++r) acc[r] = wave_sum(acc[r]);
+    if ((tid & 63) == 0)
+#pragma unroll
+      for (int r = 0; r < BW_ROWS; ++r) red[tid >> 6][r] = acc[r];
+    __syncthreads();
+    if (tid < BW_ROWS) gnew[tid] = ((first && tid < nr) ? p.gu[r0 + tid] : 0.f) - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    __syncthreads();
+    for (int j = tid; j <= p.m; j += 256) {
+      const float w = vk[j] - (j < p.m ? p.norm : p.log_nu_bin), gvj = p.gv[j];
+      const float vp = k > 1 ? vprev[j] : 0.f;
+      float cs = 0.f;
+#pragma unroll
+      for (int r = 0; r < BW_ROWS; ++r)
+        if (r < nr) {
+          const int i = r0 + r;
+          const float z = (i < p.n && j < p.m) ? p.z[(int64_t)i * p.ld + j] : alpha;
+          const float t = gvj * __expf(z + ui[r] + w);
+          const float t2 = gnew[r] * __expf(z + ui[r] + vp - (i < p.n ? p.norm : p.log_mu_bin));
+          p.dz[(int64_t)i * ldz + j] -= t + t2;
+          cs += t2;
+        }
+      p.colpart[(int64_t)blockIdx.x * ldz + j] = cs;
+    }
+    return;
+  }
+  // INIT: row sums -> gu
+#pragma unroll
+  for (int r = 0; r < BW_ROWS; ++r) acc[r] = wave_sum(acc[r]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int r = 0; r < BW_ROWS; ++r) red[tid >> 6][r] = acc[r];
+  __syncthreads();
+  if (tid < nr) p.gu[r0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// gv[j] = sign * sum over slabs of colpart[slab][j], slabs in order
+__global__ __launch_bounds__(256) void ot_bwd_colsum_kernel(const OtBwd* __restrict__ probs, float sign) {
+  const OtBwd p = probs[blockIdx.y];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > p.m) return;
+  const int ns = (p.n + BW_ROWS) / BW_ROWS, ldz = p.m + 1;
+  float s = 0.f;
+  for (int b = 0; b < ns; ++b) s += p.colpart[(int64_t)b * ldz + j];
+  p.gv[j] = sign * s;
 }
 
 // after a row step: gv <- gv', gu <- 0   (and after a column step gv is dead: it is overwritten here)
@@ -1593,7 +1688,8 @@ extern "C" size_t gims_sinkhorn_backward_workspace_bytes(const gims_ot_problem* 
   using namespace gims;
   if (!pr || np <= 0) return 0;
   size_t b = al256(sizeof(OtBwd) * (size_t)np);
-  for (int i = 0; i < np; ++i) b += al256((size_t)(pr[i].n + 1) * 4) + 2 * al256((size_t)(pr[i].m + 1) * 4);
+  for (int i = 0; i < np; ++i)
+    b += al256((size_t)(pr[i].n + 1) * 4) + 2 * al256((size_t)(pr[i].m + 1) * 4) + al256((size_t)((pr[i].n + 8) / 8) * (size_t)(pr[i].m + 1) * 4);
   return b;
 }
 
@@ -1617,6 +1713,7 @@ extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, flo
     b.gu = (float*)(base + off); off += al256((size_t)(q.n + 1) * 4);
     b.gv = (float*)(base + off); off += al256((size_t)(q.m + 1) * 4);
     b.gv2 = (float*)(base + off); off += al256((size_t)(q.m + 1) * 4);
+    b.colpart = (float*)(base + off); off += al256((size_t)((q.n + 8) / 8) * (size_t)(q.m + 1) * 4);
     b.dalpha = dalpha + i;
     ot_fill_common(q, b.norm, b.log_mu_bin, b.log_nu_bin);
     hp[i] = b;
@@ -1626,11 +1723,21 @@ extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, flo
   if (rc != GIMS_OK) return rc;
   const OtBwd* dp = (const OtBwd*)work;
   const int mx = maxn > maxm ? maxn : maxm;
-  hipLaunchKernelGGL(ot_bwd_init_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
-  for (int k = iters; k >= 1; --k) {
-    hipLaunchKernelGGL(ot_bwd_col_kernel, dim3(cdiv(maxn + 1, 4), np), dim3(256), 0, s, dp, alpha, k);
-    hipLaunchKernelGGL(ot_bwd_row_kernel, dim3(cdiv(maxm + 1, 256), np), dim3(256), 0, s, dp, alpha, k);
-    hipLaunchKernelGGL(ot_bwd_swap_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
+  if (ot_env("GIMS_OT_BWD_UNFUSED", 0)) {          // the unfused statement of the sweep (cross-check)
+    hipLaunchKernelGGL(ot_bwd_init_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
+    for (int k = iters; k >= 1; --k) {
+      hipLaunchKernelGGL(ot_bwd_col_kernel, dim3(cdiv(maxn + 1, 4), np), dim3(256), 0, s, dp, alpha, k);
+      hipLaunchKernelGGL(ot_bwd_row_kernel, dim3(cdiv(maxm + 1, 256), np), dim3(256), 0, s, dp, alpha, k);
+      hipLaunchKernelGGL(ot_bwd_swap_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
+    }
+  } else {
+    const dim3 gs(cdiv(maxn + 1, BW_ROWS), np), gc(cdiv(maxm + 1, 256), np);
+    hipLaunchKernelGGL(ot_bwd_fused_kernel<true>, gs, dim3(256), 0, s, dp, alpha, 0, 0);
+    hipLaunchKernelGGL(ot_bwd_colsum_kernel, gc, dim3(256), 0, s, dp, 1.f);
+    for (int k = iters; k >= 1; --k) {
+      hipLaunchKernelGGL((ot_bwd_fused_kernel<false>), gs, dim3(256), 0, s, dp, alpha, k, k == iters ? 1 : 0);
+      hipLaunchKernelGGL(ot_bwd_colsum_kernel, gc, dim3(256), 0, s, dp, -1.f);
+    }
   }
   hipLaunchKernelGGL(ot_bwd_alpha_kernel, dim3(np), dim3(256), 0, s, dp);
   GIMS_LAUNCH_CHECK();

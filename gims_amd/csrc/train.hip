@@ -114,7 +114,13 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(gims_gemm g) {
   __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * 64];
   __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN * 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int nsplit = g.splits > 1 ? g.splits : 1;
+  const int z = blockIdx.z / nsplit, split = blockIdx.z - z * nsplit;
+  // split-K: this workgroup covers k in [kbeg, kend) and leaves its raw partial sums in the workspace (fixed-order reduction
+  // and the epilogue follow in splitk_reduce_kernel)
+  const int kchunk = ((g.k + nsplit - 1) / nsplit + 31) & ~31;
+  const int kbeg = split * kchunk, kend = min(g.k, kbeg + kchunk);
   const int wm = BN == 128 ? (wave >> 1) * 64 : wave * 32, wn = BN == 128 ? (wave & 1) * 64 : 0;
   const float* __restrict__ A = g.a + (int64_t)z * g.sa;
   const float* __restrict__ B = g.b + (int64_t)z * g.sb;
@@ -129,17 +135,17 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(gims_gemm g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[4], rb[4];
-  const int nk = (g.k + 31) / 32;
-  tile_load<TA, BM>(ra, A, g.lda, m0, g.m, 0, g.k, va, t);
-  tile_load<TB, BN>(rb, B, g.ldb, n0, g.n, 0, g.k, vb, t);
+  const int nk = kend > kbeg ? (kend - kbeg + 31) / 32 : 0;
+  tile_load<TA, BM>(ra, A, g.lda, m0, g.m, kbeg, kend, va, t);
+  tile_load<TB, BN>(rb, B, g.ldb, n0, g.n, kbeg, kend, vb, t);
   tile_store<TA, BM>(ra, As[0], t);
   tile_store<TB, BN>(rb, Bs[0], t);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) {
-      tile_load<TA, BM>(ra, A, g.lda, m0, g.m, (kt + 1) * 32, g.k, va, t);
-      tile_load<TB, BN>(rb, B, g.ldb, n0, g.n, (kt + 1) * 32, g.k, vb, t);
+      tile_load<TA, BM>(ra, A, g.lda, m0, g.m, kbeg + (kt + 1) * 32, kend, va, t);
+      tile_load<TB, BN>(rb, B, g.ldb, n0, g.n, kbeg + (kt + 1) * 32, kend, vb, t);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -172,6 +178,22 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(gims_gemm g) {
     __syncthreads();
   }
 
+  if (nsplit > 1) {
+    float* __restrict__ W = g.work + ((int64_t)split * g.batch + z) * (int64_t)g.m * g.n;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + j * 32 + li;
+        if (n >= g.n) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < g.m) W[(int64_t)m * g.n + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   float* __restrict__ Cz = g.c + (int64_t)z * g.sc;
   const float* __restrict__ Rz = g.residual ? g.residual + (int64_t)z * g.sr : nullptr;
 #pragma unroll
@@ -195,12 +217,30 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(gims_gemm g) {
     }
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(gims_gemm g) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, per = (int64_t)g.m * g.n;
+  if (idx >= per * g.batch) return;
+  const int z = (int)(idx / per);
+  const int64_t e = idx - (int64_t)z * per;
+  const int m = (int)(e / g.n), n = (int)(e - (int64_t)m * g.n);
+  float acc = 0.f;
+  for (int sp = 0; sp < g.splits; ++sp) acc += g.work[((int64_t)sp * g.batch + z) * per + e];
+  float v = g.alpha * acc + (g.bias ? g.bias[n] : 0.f);
+  if (g.residual) v += g.residual[(int64_t)z * g.sr + (int64_t)m * g.ldr + n];
+  float* cp = g.c + (int64_t)z * g.sc + (int64_t)m * g.ldc + n;
+  if (g.beta != 0.f) v += g.beta * *cp;
+  if (g.act == GIMS_ACT_RELU) v = fmaxf(v, 0.f);
+  *cp = v;
+}
+
 template <bool TA, bool TB>
 static void gemm_launch(const gims_gemm& g, hipStream_t s) {
+  const int sp = g.splits > 1 ? g.splits : 1;
   if (g.n <= 64)
-    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, 64>), dim3(cdiv(g.n, 64), cdiv(g.m, 128), g.batch), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, 64>), dim3(cdiv(g.n, 64), cdiv(g.m, 128), g.batch * sp), dim3(256), 0, s, g);
   else
-    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, 128>), dim3(cdiv(g.n, 128), cdiv(g.m, 128), g.batch), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, 128>), dim3(cdiv(g.n, 128), cdiv(g.m, 128), g.batch * sp), dim3(256), 0, s, g);
+  if (sp > 1) hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv((int64_t)g.m * g.n * g.batch, 256)), dim3(256), 0, s, g);
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm1d, train mode
@@ -558,6 +598,19 @@ extern "C" int gims_gemm_f32(const gims_gemm* gp, void* stream) {
                  "gims_gemm_f32: leading dimension smaller than the row it strides");
   auto vec_ok = [&](const float* p, int64_t ld, int64_t st) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0 && (g.batch == 1 || (st & 3) == 0); };
   g.flags = (vec_ok(g.a, g.lda, g.sa) ? 1 : 0) | (vec_ok(g.b, g.ldb, g.sb) ? 2 : 0);
+  // split-K when the output has too few tiles to fill the chip and k is long (the weight gradients: k = keypoint rows):
+  // every split covers >= 128 k, partial sums go through the caller's workspace and are added in split order
+  g.splits = 1;
+  if (g.work && g.k >= 512) {
+    const int64_t tiles = (int64_t)cdiv(g.n, g.n <= 64 ? 64 : 128) * cdiv(g.m, 128) * g.batch;
+    if (tiles < 128) {
+      int sp = (int)((384 + tiles - 1) / tiles);
+      sp = sp < g.k / 128 ? sp : g.k / 128;
+      const int64_t cap = g.work_floats / ((int64_t)g.m * g.n * g.batch);
+      sp = sp < cap ? sp : (int)cap;
+      if (sp > 1) g.splits = sp;
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   if (!g.ta && !g.tb) gemm_launch<false, false>(g, s);
   else if (!g.ta && g.tb) gemm_launch<false, true>(g, s);

@@ -45,7 +45,7 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool):
     if buffer:
         mod.register_buffer(parts[-1], tensor)
     else:
-        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
 
 
 class PairResults(list):
@@ -113,7 +113,20 @@ class GMatcher(nn.Module):
         self.n_layers = len(cfg['transformer_layers'])
         self._heads = 4   # AttentionalGNN hard-codes 4 heads (gmatcher.py:131); config['num_heads'] is ignored there too
         from .synth import state_dict_spec
-        for name, shape in state_dict_spec(D, tuple(cfg['keypoint_encoder']), self.n_layers, use_layernorm=bool(cfg['use_layernorm'])):
+        spec = list(state_dict_spec(D, tuple(cfg['keypoint_encoder']), self.n_layers, use_layernorm=bool(cfg['use_layernorm'])))
+        # the BatchNorm layers are real nn.BatchNorm1d modules (never called -- the kernels read their tensors by name): what
+        # train.py:43-51 sorts into optimizer groups by isinstance, and what SyncBatchNorm conversion looks for
+        bn_prefixes = {n[:-len(".running_mean")]: shape for n, shape in spec if n.endswith(".running_mean")}
+        for prefix, shape in bn_prefixes.items():
+            mod, parts = self, prefix.split(".")
+            for q in parts[:-1]:
+                if not hasattr(mod, q):
+                    mod.add_module(q, _Node())
+                mod = getattr(mod, q)
+            mod.add_module(parts[-1], nn.BatchNorm1d(shape[0]))
+        for name, shape in spec:
+            if name.rsplit(".", 1)[0] in bn_prefixes:
+                continue
             if name.endswith("num_batches_tracked"):
                 _register(self, name, torch.zeros((), dtype=torch.int64), buffer=True)
             elif name.endswith("running_mean"):
@@ -344,7 +357,6 @@ class GMatcher(nn.Module):
         """Phase 1: enqueue the adaptive graph construction (asynchronous; no host sync)."""
         cfg = self.config
         dev = images[0]["kp"].device
-        P = self._packed(dev)
         D = cfg['descriptor_dim']
         St = lambda name: GMatcher._Stage(self, name)   # noqa: E731
 
@@ -386,12 +398,13 @@ class GMatcher(nn.Module):
 
     _edge_cap = 64
 
-    def _run_rest(self, ctx):
-        """Phase 2: read the kept counts (the one host sync), then enqueue everything else."""
+    def _gather(self, ctx):
+        """Read the kept counts (the one host sync of a batch) and compact the kept keypoints of all images into merged
+        row-major arrays + one merged CSR (gmatcher.py:244-249).  Returns None after growing the edge capacity (the caller
+        repeats the build), else a dict of the merged arrays."""
         images, info_all = ctx["images"], ctx["info_all"]
         cfg = self.config
         dev = images[0]["kp"].device
-        P = self._packed(dev)
         D = cfg['descriptor_dim']
         St = lambda name: GMatcher._Stage(self, name)   # noqa: E731
         ts0 = time.perf_counter()
@@ -416,7 +429,7 @@ class GMatcher(nn.Module):
             if cap > 16384 or cap <= self._edge_cap:
                 raise hip.GimsHipError(f"adaptive graph exceeded the edge capacity ({self._edge_cap} directed edges per node) and cannot grow further")
             self._edge_cap = cap
-            return self._run_rest(self._run_build(images, *ctx["params"]))
+            return None
         if (infos[:, 0] == 0).any():
             raise ValueError("need at least one array to concatenate")               # np.vstack([]) in agc.py:701
 
@@ -429,12 +442,38 @@ class GMatcher(nn.Module):
             ptab["n_kept"], ptab["n_edges"], ptab["row_off"], ptab["edge_off"] = infos[:, 0], infos[:, 1], row_off[:-1], e_off[:-1]
             feat, kpts_all, score_all, seg = b["feat"][:n_tot], b["kpts"][:n_tot], b["score"][:n_tot], b["seg"][:n_tot]
             indptr_all, indices_all = b["indptr"][:n_tot + 1], b["indices"][:max(e_tot, 1)]
-            g_keep = hip.pack_graphs_table(ptab, D, feat, kpts_all, score_all, seg, indptr_all, indices_all, n_tot, e_tot)
-            norm3 = ctx["norm3"]
+            hip.pack_graphs_table(ptab, D, feat, kpts_all, score_all, seg, indptr_all, indices_all, n_tot, e_tot)
         row_off, e_off = row_off.tolist(), e_off.tolist()
         for g, inf, ro in zip(images, infos, row_off):
             g["n_kept"], g["n_edges"], g["info_host"] = int(inf[0]), int(inf[1]), inf
             g["rows"] = (ro, g["n_kept"])
+        return dict(feat=feat, kpts_all=kpts_all, score_all=score_all, seg=seg, indptr_all=indptr_all, indices_all=indices_all,
+                    norm3=ctx["norm3"], n_tot=n_tot, e_tot=e_tot)
+
+    @staticmethod
+    def _finish_graphs(images, G):
+        """Per-image views and graph handles (host-only bookkeeping, done after everything is enqueued)."""
+        for g in images:
+            ro, nk = g["rows"]
+            g["kept"] = g["kept"][:nk]
+            g["indptr"] = g["indptr"][:nk + 1]
+            g["indices"] = g["indices"][:g["n_edges"]]
+            g["graph"] = GraphHandle(g["indptr"], g["indices"],
+                                     {"point": G["kpts_all"][ro:ro + nk], "feat": G["feat"][ro:ro + nk], "score": G["score_all"][ro:ro + nk]})
+
+    def _run_rest(self, ctx):
+        """Phase 2: read the kept counts (the one host sync), then enqueue everything else."""
+        images = ctx["images"]
+        cfg = self.config
+        dev = images[0]["kp"].device
+        P = self._packed(dev)
+        D = cfg['descriptor_dim']
+        St = lambda name: GMatcher._Stage(self, name)   # noqa: E731
+        G = self._gather(ctx)
+        if G is None:
+            return self._run_rest(self._run_build(images, *ctx["params"]))
+        feat, kpts_all, score_all, seg = G["feat"], G["kpts_all"], G["score_all"], G["seg"]
+        indptr_all, indices_all, norm3, n_tot = G["indptr_all"], G["indices_all"], G["norm3"], G["n_tot"]
         # ---- GraphSAGE over the merged CSR of all images (gmatcher.py:145-162, 268-269)
         x3 = P["x3"]
         with St("sage"):
@@ -619,14 +658,7 @@ class GMatcher(nn.Module):
             # `sinkhorn_status()` after a synchronise.)
             hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
             self._status_offs = np.cumsum([it["n"] + it["m"] + 3 for it in items]) - 1
-        # per-image views and graph handles: host-only bookkeeping, done after everything is enqueued
-        for g in images:
-            ro, nk = g["rows"]
-            g["kept"] = g["kept"][:nk]
-            g["indptr"] = g["indptr"][:nk + 1]
-            g["indices"] = g["indices"][:g["n_edges"]]
-            g["graph"] = GraphHandle(g["indptr"], g["indices"],
-                                     {"point": kpts_all[ro:ro + nk], "feat": feat[ro:ro + nk], "score": score_all[ro:ro + nk]})
+        self._finish_graphs(images, G)
         self._last = dict(items=items, pairs=pairs, mdesc=mdesc, desc=desc, sage=sage, images=images,
                           flat=dict(matches0=m0_all, scores0=s0_all, n0=[n0 for (_, n0), _ in pairs], n1=[n1 for _, (_, n1) in pairs]),
                           outputs=[m0_all, m1_all, s0_all, s1_all, uv_all, mdesc, feat, kpts_all, score_all, ctx["pool"]])
@@ -667,17 +699,23 @@ class GMatcher(nn.Module):
     def _check_call(self, data, kwargs):
         if data.get('delaunay', False):
             raise NotImplementedError("delaunay=True is broken in the reference snapshot (UnboundLocalError, gmatcher.py:250)")
-        if kwargs.get('mode', 'test') == "train" and self.training and not self.config['use_layernorm']:
-            raise NotImplementedError("mode='train' on a module in training mode needs batch-statistics BatchNorm and a backward "
-                                      "pass, which are not on the HIP path: the FORWARD loss (gmatcher.py:309-386) is available "
-                                      "with the module in eval() mode (running statistics)")
         if data['keypoints0'].device.type != "cuda":
             raise hip.GimsHipError("GMatcher runs on the GPU only (no CPU fallback): move the inputs to 'cuda'")
 
     # ------------------------------------------------------------------ reference-shaped forward (gmatcher.py:219-307)
-    @torch.no_grad()
     def forward(self, data, **kwargs):
+        """gmatcher.py:219-307.  ``mode='train'`` on a module in train() mode is one differentiable training step (train.py:136:
+        batch-statistics BatchNorm, running statistics updated, ``loss.backward()`` fills every parameter's .grad --
+        gims_amd/trainstep.py); ``mode='train'`` on a module in eval() mode returns the forward value of the loss on running
+        statistics, without a graph."""
         self._check_call(data, kwargs)
+        if kwargs.get('mode', 'test') == "train" and self.training:
+            from . import trainstep
+            return trainstep.train_forward(self, data)
+        return self._forward_eval(data, **kwargs)
+
+    @torch.no_grad()
+    def _forward_eval(self, data, **kwargs):
         radius, percentile, min_size = data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)
         B = data['keypoints0'].shape[0]
         images = self._ingest([(data['keypoints' + side][b], data['descriptors' + side][b], data['scores' + side][b],
@@ -728,7 +766,7 @@ class GMatcher(nn.Module):
         iterations (what autograd does in the reference, gmatcher.py:41-69, 372-385).  Returns
         ``{'loss', 'pos_loss', 'neg_loss', 'dscores': [per pair, (n_kept0, n_kept1)], 'dbin_score'}``.  The rest of the backward
         pass (final projection, attention layers, encoders) is not built."""
-        loss, pos, neg = self.forward(data, mode="train")
+        loss, pos, neg = self._forward_eval(data, mode="train")
         items = self._last["items"]
         dscores, dalpha = hip.sinkhorn_score_gradients(items, self._packed(items[0]["scores"].device)["alpha"], self.config['sinkhorn_iterations'],
                                                        self.config['pos_loss_weight'], self.config['neg_loss_weight'], hip.train_loss.last)

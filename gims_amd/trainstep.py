@@ -1,0 +1,370 @@
+"""One training step of GMatcher on the HIP path (SURVEY row f3 = a25): the forward pass of ``forward_train``
+(models/gmatcher.py:309-386) with the module in train() mode -- BatchNorm on batch statistics, running statistics updated --
+and the reverse pass through every stage of it, so that ``loss.backward()`` of train.py:136-137 fills ``.grad`` of all 282
+parameters.  Host orchestration only: every product runs in gims_gemm_f32 (split-bf16x3 MFMA), the norms, softmaxes, sums
+and graph aggregations in the kernels of csrc/train.hip, the Sinkhorn solve and its reverse sweep in csrc/sinkhorn.hip.
+
+Layout: rows of all images SIDE-major ([image 0 of every batch element | image 1 of every batch element]), activations
+row-major f32 [rows][channels].  The linear layers of a GNN layer run once over all rows (both sides share the weights,
+gmatcher.py:139-141); BatchNorm statistics are per side (= per call of the module in the reference); attention runs per
+image with the probabilities P kept for the reverse pass (4 x n x m f32 per image and layer: 2.4 GB at 2 x 2048 keypoints
+-- HBM is 288 GB; nothing is recomputed).  Heads are made contiguous by permuting the projection weights on the way in
+(reference: channel = d * heads + h, gmatcher.py:108-113) and the weight gradients on the way out.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import hip
+
+HEADS = 4
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1        # nn.BatchNorm1d defaults (gmatcher.py:20)
+
+
+# ------------------------------------------------------------------------------------------------ head interleave <-> contiguous heads
+def _rows_in(w):
+    """Projection weight [D, k] / bias [D]: output channel d * H + h -> h * dh + d."""
+    D = w.shape[0]
+    k = w.numel() // D
+    out = torch.empty_like(w)
+    return hip.permute3(out, w, (D // HEADS, HEADS, k), (k, (D // HEADS) * k, 1), (HEADS * k, k, 1))
+
+
+def _rows_out(gp, like):
+    D = gp.shape[0]
+    k = gp.numel() // D
+    out = torch.empty_like(like)
+    return hip.permute3(out, gp, (D // HEADS, HEADS, k), (HEADS * k, k, 1), (k, (D // HEADS) * k, 1))
+
+
+def _cols_in(w):
+    """Merge weight [n, D]: input channel d * H + h -> h * dh + d."""
+    n, D = w.shape
+    out = torch.empty_like(w)
+    return hip.permute3(out, w, (n, D // HEADS, HEADS), (D, 1, D // HEADS), (D, HEADS, 1))
+
+
+def _cols_out(gp, like):
+    n, D = gp.shape
+    out = torch.empty_like(like)
+    return hip.permute3(out, gp, (n, D // HEADS, HEADS), (D, HEADS, 1), (D, 1, D // HEADS))
+
+
+def _w2(p):
+    """Conv1d(k=1) weight [out, in, 1] (or Linear [out, in]) as a 2-D matrix."""
+    return p.detach().view(p.shape[0], -1)
+
+
+class _Step:
+    """Everything the reverse pass needs from the forward pass of one step."""
+
+
+def _sage_bias(P, i):
+    k = f"gnn_encoder.layers.{i}.fc_self.bias"
+    return k if k in P else f"gnn_encoder.layers.{i}.bias"
+
+
+# ------------------------------------------------------------------------------------------------ forward
+def forward(model, data):
+    """Returns (out3 = [loss, pos_loss, neg_loss] device tensor, _Step).  Mutates ``data`` like the reference's forward does
+    (gmatcher.py:244-252) and updates the BatchNorm buffers of ``model``."""
+    cfg = model.config
+    if cfg['use_layernorm']:
+        raise NotImplementedError("training with use_layernorm=True is not on the HIP path (the reference default is BatchNorm)")
+    radius, percentile, min_size = data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)
+    B = data['keypoints0'].shape[0]
+    D = cfg['descriptor_dim']
+    # side-major image order: [b0 s0, b1 s0, ..., b0 s1, b1 s1, ...]
+    images = model._ingest([(data['keypoints' + side][b], data['descriptors' + side][b], data['scores' + side][b], data['image' + side].shape)
+                            for side in ("0", "1") for b in range(B)])
+    G = None
+    while G is None:
+        ctx = model._run_build(images, radius, percentile, min_size)
+        G = model._gather(ctx)
+    model._finish_graphs(images, G)
+    dev = G["feat"].device
+    for s in range(2):
+        if len({images[s * B + b]["n_kept"] for b in range(B)}) != 1:
+            raise RuntimeError("stack expects each tensor to be equal size: the batch elements keep different numbers of keypoints "
+                               "(torch.stack in models/gmatcher.py:244-249 needs equal counts)")
+    for s, side in enumerate(("0", "1")):
+        gs = [images[s * B + b]["graph"] for b in range(B)]
+        data['keypoints' + side] = torch.stack([h.ndata['point'] for h in gs])
+        data['descriptors' + side] = torch.stack([h.ndata['feat'] for h in gs]).permute(0, 2, 1)
+        data['scores' + side] = torch.stack([h.ndata['score'] for h in gs])
+        data['kept_kpts%s_indices' % side] = [images[s * B + b]["kept"].tolist() for b in range(B)]
+        data['graph' + side] = gs
+
+    P = {k: v.detach() for k, v in model.named_parameters()}
+    Bf = dict(model.named_buffers())
+    n_tot = G["n_tot"]
+    rows = [[images[s * B + b]["rows"] for s in range(2)] for b in range(B)]          # rows[b][s] = (offset, n)
+    side_rows = [(images[s * B]["rows"][0], sum(images[s * B + b]["n_kept"] for b in range(B))) for s in range(2)]
+    sg = hip.segments(side_rows)
+    S = _Step()
+    S.images, S.G, S.rows, S.sg, S.B, S.n_tot, S.D = images, G, rows, sg, B, n_tot, D
+
+    def bn(prefix, x, relu=True):
+        y, save = hip.batchnorm_train_forward(x, sg, P[prefix + ".weight"], P[prefix + ".bias"], BN_EPS, BN_MOMENTUM,
+                                              Bf.get(prefix + ".running_mean"), Bf.get(prefix + ".running_var"), relu)
+        nbt = Bf.get(prefix + ".num_batches_tracked")
+        if nbt is not None:
+            nbt += sg.n                       # one forward call per side in the reference
+        return y, save
+
+    # ---- GraphSAGE (gmatcher.py:145-162; SAGEConv 'mean': fc_neigh before the aggregation iff in > out)
+    h = G["feat"]
+    S.sage = []
+    for i in range(3):
+        pre = f"gnn_encoder.layers.{i}."
+        ws, wn, bs = P[pre + "fc_self.weight"], P[pre + "fc_neigh.weight"], P[_sage_bias(P, i)]
+        act = hip.ACT_RELU if i < 2 else hip.ACT_NONE
+        if ws.shape[1] > ws.shape[0]:
+            xn = hip.gemm(h, wn)
+            agg = torch.empty_like(xn)
+            hip.sage_mean(xn, G["indptr_all"], G["indices_all"], agg)
+            out = hip.gemm(h, ws, bias=bs, residual=agg, act=act)
+            S.sage.append(dict(h=h, before=True, out=out))
+        else:
+            agg = torch.empty_like(h)
+            hip.sage_mean(h, G["indptr_all"], G["indices_all"], agg)
+            out = hip.gemm(h, ws, bias=bs)
+            hip.gemm(agg, wn, out, beta=1.0, act=act)
+            S.sage.append(dict(h=h, before=False, agg=agg, out=out))
+        h = out
+    sage = h
+
+    # ---- keypoint encoder (gmatcher.py:26-33, 87-97): conv -> BN(train) -> ReLU ..., last conv + sage
+    x = hip.normalize_keypoints(G["kpts_all"], G["norm3"], G["seg"])
+    S.kenc = []
+    n_convs = len(cfg['keypoint_encoder']) + 1
+    idx = 0
+    for i in range(n_convs):
+        w, bia = _w2(P[f"kenc.encoder.{idx}.weight"]), P[f"kenc.encoder.{idx}.bias"]
+        if i == n_convs - 1:
+            y = hip.gemm(x, w, bias=bia, residual=sage)
+            S.kenc.append(dict(x=x, conv=idx))
+        else:
+            pre = hip.gemm(x, w, bias=bia)
+            y, save = bn(f"kenc.encoder.{idx + 1}", pre)
+            S.kenc.append(dict(x=x, conv=idx, pre=pre, save=save))
+            idx += 3
+        x = y
+    desc = x
+
+    # ---- attentional GNN (gmatcher.py:99-143)
+    S.layers = []
+    for l, name in enumerate(cfg['transformer_layers']):
+        pre = f"gnn.layers.{l}."
+        wqkv = torch.cat([_rows_in(_w2(P[pre + f"attn.proj.{j}.weight"])) for j in range(3)])
+        bqkv = torch.cat([_rows_in(P[pre + f"attn.proj.{j}.bias"]) for j in range(3)])
+        wm = _cols_in(_w2(P[pre + "attn.merge.weight"]))
+        qkv = hip.gemm(desc, wqkv, bias=bqkv)
+        o = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
+        probs = []
+        for b in range(B):
+            for s in range(2):
+                (oq, nq), (os_, ns) = rows[b][s], rows[b][s if name != 'cross' else 1 - s]
+                ld = (ns + 3) // 4 * 4
+                pm = torch.empty((HEADS, nq, ld), dtype=torch.float32, device=dev)
+                qh = qkv[oq:oq + nq, 0:D].view(nq, HEADS, D // HEADS).permute(1, 0, 2)
+                kh = qkv[os_:os_ + ns, D:2 * D].view(ns, HEADS, D // HEADS).permute(1, 0, 2)
+                vh = qkv[os_:os_ + ns, 2 * D:3 * D].view(ns, HEADS, D // HEADS).permute(1, 0, 2)
+                hip.gemm(qh, kh, pm[:, :, :ns], alpha=1.0 / math.sqrt(D // HEADS))
+                hip.softmax_rows_(pm, ns)
+                hip.gemm(pm[:, :, :ns], vh.transpose(1, 2), o[oq:oq + nq].view(nq, HEADS, D // HEADS).permute(1, 0, 2))
+                probs.append(pm)
+        msg = hip.gemm(o, wm, bias=P[pre + "attn.merge.bias"])
+        w0, w3 = _w2(P[pre + "mlp.0.weight"]), _w2(P[pre + "mlp.3.weight"])
+        hpre = hip.gemm(desc, w0[:, :D], bias=P[pre + "mlp.0.bias"])
+        hip.gemm(msg, w0[:, D:], hpre, beta=1.0)
+        hid, save = bn(pre + "mlp.1", hpre)
+        nxt = hip.gemm(hid, w3, bias=P[pre + "mlp.3.bias"], residual=desc)       # desc + delta (gmatcher.py:142)
+        S.layers.append(dict(x=desc, wqkv=wqkv, wm=wm, qkv=qkv, o=o, probs=probs, msg=msg, hpre=hpre, save=save, hid=hid, cross=name == 'cross'))
+        desc = nxt
+    S.desc = desc
+
+    # ---- final projection, scores, Sinkhorn, loss (gmatcher.py:330-385)
+    mdesc = hip.gemm(desc, _w2(P["final_proj.weight"]), bias=P["final_proj.bias"])
+    S.mdesc = mdesc
+    items = []
+    for b in range(B):
+        (o0, n0), (o1, n1) = rows[b]
+        ld = (n1 + 3) // 4 * 4
+        scores = torch.empty((n0, ld), dtype=torch.float32, device=dev)
+        hip.gemm(mdesc[o0:o0 + n0], mdesc[o1:o1 + n1], scores[:, :n1], alpha=1.0 / math.sqrt(D))
+        items.append(dict(scores=scores, n=n0, m=n1, matches0=torch.empty(n0, dtype=torch.int64, device=dev),
+                          matches1=torch.empty(n1, dtype=torch.int64, device=dev), mscores0=torch.empty(n0, dtype=torch.float32, device=dev),
+                          mscores1=torch.empty(n1, dtype=torch.float32, device=dev), uv=torch.empty(n0 + n1 + 3, dtype=torch.float32, device=dev)))
+    S.items = items
+    S.alpha = float(P["bin_score"])
+    probs_ot = hip.make_ot_problems(items)
+    work = torch.empty(hip.sinkhorn_workspace_bytes(probs_ot), dtype=torch.uint8, device=dev)
+    hip.sinkhorn_match(probs_ot, S.alpha, cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
+    gt = data['matches'].to(device=dev, dtype=torch.int64).contiguous()
+    out3, _ = hip.train_loss(items, [images[b]["kept"] for b in range(B)], [images[B + b]["kept"] for b in range(B)], gt, S.alpha,
+                             cfg['pos_loss_weight'], cfg['neg_loss_weight'])
+    S.loss_state = hip.train_loss.last
+    return out3, S
+
+
+# ------------------------------------------------------------------------------------------------ backward
+def backward(model, S, w_pos: float, w_neg: float):
+    """Gradients of  w_pos * (pos_loss / pos_loss_weight) + w_neg * (neg_loss / neg_loss_weight)  -- i.e. with w_pos / w_neg the
+    effective weights of the two loss terms -- with respect to every parameter: dict name -> tensor shaped like the parameter."""
+    cfg = model.config
+    P = {k: v.detach() for k, v in model.named_parameters()}
+    D, B, n_tot, rows, sg, G = S.D, S.B, S.n_tot, S.rows, S.sg, S.G
+    dev = S.mdesc.device
+    grads = {}
+
+    def put(name, g):
+        grads[name] = g.view(P[name].shape)
+
+    # ---- loss -> scores (reverse sweep through the unrolled Sinkhorn iterations) -> matching descriptors
+    dscores, dalpha = hip.sinkhorn_score_gradients(S.items, S.alpha, cfg['sinkhorn_iterations'], w_pos, w_neg, S.loss_state)
+    put("bin_score", dalpha)
+    dm = torch.empty_like(S.mdesc)
+    inv = 1.0 / math.sqrt(D)
+    for b in range(B):
+        (o0, n0), (o1, n1) = rows[b]
+        hip.gemm(dscores[b], S.mdesc[o1:o1 + n1].t(), dm[o0:o0 + n0], alpha=inv)
+        hip.gemm(dscores[b].t(), S.mdesc[o0:o0 + n0].t(), dm[o1:o1 + n1], alpha=inv)
+    wf = _w2(P["final_proj.weight"])
+    put("final_proj.weight", hip.gemm(dm.t(), S.desc.t()))
+    put("final_proj.bias", hip.colsum(dm))
+    dx = hip.gemm(dm, wf.t())                                     # gradient w.r.t. the residual stream after the last layer
+
+    # ---- GNN layers in reverse
+    dqkv = torch.empty((n_tot, 3 * D), dtype=torch.float32, device=dev)
+    max_p = max(p.numel() for L in S.layers for p in L["probs"])
+    dp_buf = torch.empty(max_p, dtype=torch.float32, device=dev)
+    dh = D // HEADS
+    for l in range(len(S.layers) - 1, -1, -1):
+        L = S.layers[l]
+        pre = f"gnn.layers.{l}."
+        w0, w3 = _w2(P[pre + "mlp.0.weight"]), _w2(P[pre + "mlp.3.weight"])
+        # delta = mlp(cat[x, msg]); x_next = x + delta: dx is d/dx_next = d/ddelta
+        put(pre + "mlp.3.weight", hip.gemm(dx.t(), L["hid"].t()))
+        put(pre + "mlp.3.bias", hip.colsum(dx))
+        dhid = hip.gemm(dx, w3.t())
+        dhpre, dgam, dbet = hip.batchnorm_train_backward(L["hpre"], dhid, sg, L["save"], P[pre + "mlp.1.weight"], P[pre + "mlp.1.bias"], True)
+        put(pre + "mlp.1.weight", dgam)
+        put(pre + "mlp.1.bias", dbet)
+        dw0 = torch.empty_like(w0)
+        hip.gemm(dhpre.t(), L["x"].t(), dw0[:, :D])
+        hip.gemm(dhpre.t(), L["msg"].t(), dw0[:, D:])
+        put(pre + "mlp.0.weight", dw0)
+        put(pre + "mlp.0.bias", hip.colsum(dhpre))
+        hip.gemm(dhpre, w0[:, :D].t(), dx, beta=1.0)              # dx += dhpre W0[:, :D]   (x enters the MLP directly)
+        dmsg = hip.gemm(dhpre, w0[:, D:].t())
+        # merge
+        put(pre + "attn.merge.weight", _cols_out(hip.gemm(dmsg.t(), L["o"].t()), _w2(P[pre + "attn.merge.weight"])))
+        put(pre + "attn.merge.bias", hip.colsum(dmsg))
+        do = hip.gemm(dmsg, L["wm"].t())
+        # attention, image by image (every image's rows are queries once and sources once per layer: dqkv is written exactly once)
+        qkv = L["qkv"]
+        pi = 0
+        for b in range(B):
+            for s in range(2):
+                (oq, nq), (os_, ns) = rows[b][s], rows[b][1 - s if L["cross"] else s]
+                pm = L["probs"][pi]
+                pi += 1
+                ld = pm.shape[2]
+                dp = dp_buf[:pm.numel()].view(HEADS, nq, ld)
+                qh = qkv[oq:oq + nq, 0:D].view(nq, HEADS, dh).permute(1, 0, 2)
+                kh = qkv[os_:os_ + ns, D:2 * D].view(ns, HEADS, dh).permute(1, 0, 2)
+                vh = qkv[os_:os_ + ns, 2 * D:3 * D].view(ns, HEADS, dh).permute(1, 0, 2)
+                doh = do[oq:oq + nq].view(nq, HEADS, dh).permute(1, 0, 2)
+                dqh = dqkv[oq:oq + nq, 0:D].view(nq, HEADS, dh).permute(1, 0, 2)
+                dkh = dqkv[os_:os_ + ns, D:2 * D].view(ns, HEADS, dh).permute(1, 0, 2)
+                dvh = dqkv[os_:os_ + ns, 2 * D:3 * D].view(ns, HEADS, dh).permute(1, 0, 2)
+                hip.gemm(pm[:, :, :ns].transpose(1, 2), doh.transpose(1, 2), dvh)                    # dV = P^T dO
+                hip.gemm(doh, vh, dp[:, :, :ns])                                                     # dP = dO V^T
+                hip.softmax_rows_backward_(pm, dp, ns)                                               # dS
+                hip.gemm(dp[:, :, :ns], kh.transpose(1, 2), dqh, alpha=1.0 / math.sqrt(dh))          # dQ = dS K / sqrt(dh)
+                hip.gemm(dp[:, :, :ns].transpose(1, 2), qh.transpose(1, 2), dkh, alpha=1.0 / math.sqrt(dh))   # dK = dS^T Q / sqrt(dh)
+        dwqkv = hip.gemm(dqkv.t(), L["x"].t())
+        dbqkv = hip.colsum(dqkv)
+        for j in range(3):
+            put(pre + f"attn.proj.{j}.weight", _rows_out(dwqkv[j * D:(j + 1) * D], _w2(P[pre + f"attn.proj.{j}.weight"])))
+            put(pre + f"attn.proj.{j}.bias", _rows_out(dbqkv[j * D:(j + 1) * D], P[pre + f"attn.proj.{j}.bias"]))
+        hip.gemm(dqkv, L["wqkv"].t(), dx, beta=1.0)               # dx += dQKV Wqkv
+        S.layers[l] = None                                        # this layer's activations are no longer needed
+
+    # ---- keypoint encoder (dx is now d/d(sage + kenc))
+    ddesc = dx
+    g = ddesc
+    for i in range(len(S.kenc) - 1, -1, -1):
+        K = S.kenc[i]
+        idx = K["conv"]
+        if "pre" in K:           # conv idx -> BN idx+1 -> ReLU: g is the gradient of the ReLU output
+            g, dgam, dbet = hip.batchnorm_train_backward(K["pre"], g, sg, K["save"], P[f"kenc.encoder.{idx + 1}.weight"], P[f"kenc.encoder.{idx + 1}.bias"], True)
+            put(f"kenc.encoder.{idx + 1}.weight", dgam)
+            put(f"kenc.encoder.{idx + 1}.bias", dbet)
+        put(f"kenc.encoder.{idx}.weight", hip.gemm(g.t(), K["x"].t()))
+        put(f"kenc.encoder.{idx}.bias", hip.colsum(g))
+        if i > 0:
+            g = hip.gemm(g, _w2(P[f"kenc.encoder.{idx}.weight"]).t())
+
+    # ---- GraphSAGE
+    g = ddesc
+    for i in range(2, -1, -1):
+        L = S.sage[i]
+        pre = f"gnn_encoder.layers.{i}."
+        ws, wn = P[pre + "fc_self.weight"], P[pre + "fc_neigh.weight"]
+        if i < 2:                 # ReLU after layers 0 and 1
+            g = hip.elementwise(hip.EW_RELU_MASK, torch.empty_like(g), g, L["out"])
+        put(pre + "fc_self.weight", hip.gemm(g.t(), L["h"].t()))
+        put(_sage_bias(P, i), hip.colsum(g))
+        if L["before"]:           # out = h Ws^T + b + mean(h Wn^T)
+            dxn = hip.sage_mean_transposed(g, G["indptr_all"], G["indices_all"])
+            put(pre + "fc_neigh.weight", hip.gemm(dxn.t(), L["h"].t()))
+            if i > 0:
+                gh = hip.gemm(g, ws.t())
+                hip.gemm(dxn, wn.t(), gh, beta=1.0)
+                g = gh
+        else:                     # out = h Ws^T + b + mean(h) Wn^T
+            put(pre + "fc_neigh.weight", hip.gemm(g.t(), L["agg"].t()))
+            if i > 0:
+                dagg = hip.gemm(g, wn.t())
+                gh = hip.gemm(g, ws.t())
+                hip.elementwise(hip.EW_ACC, gh, hip.sage_mean_transposed(dagg, G["indptr_all"], G["indices_all"]), alpha=1.0)
+                g = gh
+    return grads
+
+
+# ------------------------------------------------------------------------------------------------ autograd boundary
+class _TrainStepFn(torch.autograd.Function):
+    """(loss, pos_loss, neg_loss) as differentiable functions of the module's parameters: forward and backward are the HIP
+    passes above; the parameters are the inputs so that .grad, optimizers, DDP hooks and GradScaler see an ordinary graph."""
+
+    @staticmethod
+    def forward(ctx, model, data, names, *params):
+        out3, S = forward(model, data)
+        ctx.model, ctx.S, ctx.names = model, S, names
+        return out3[0].clone(), out3[1].clone(), out3[2].clone()
+
+    @staticmethod
+    def backward(ctx, g_loss, g_pos, g_neg):
+        model, S = ctx.model, ctx.S
+        if S is None:
+            raise RuntimeError("the activations of this training step were already released (backward called twice)")
+        zero = torch.zeros((), dtype=torch.float32, device=S.mdesc.device)
+        gl, gp, gn = torch.stack([zero if g is None else g.float().reshape(()) for g in (g_loss, g_pos, g_neg)]).tolist()
+        cfg = model.config
+        # loss = pos_loss + neg_loss, pos_loss = pos_weight * mean-of-means, neg_loss likewise (gmatcher.py:383-385)
+        grads = backward(model, S, cfg['pos_loss_weight'] * (gl + gp), cfg['neg_loss_weight'] * (gl + gn))
+        ctx.S = None
+        return (None, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
+def train_forward(model, data):
+    """``GMatcher.forward(data, mode='train')`` for a module in train() mode: returns (loss, pos_loss, neg_loss), 0-dim tensors
+    attached to the autograd graph of the module's parameters."""
+    named = [(n, p) for n, p in model.named_parameters()]
+    names = tuple(n for n, _ in named)
+    return _TrainStepFn.apply(model, data, names, *[p for _, p in named])

@@ -494,7 +494,7 @@ int gims_patch_extract(const uint8_t* pyr, const gims_pyr_level* dev_levels, int
  *   accumulation (the f32-class mode of gims_linear).  Replaces every torch matmul / conv1d(k=1) / einsum of the step and of
  *   its autograd: nn.Conv1d forward, grad_input, grad_weight (gmatcher.py:11-24, 99-125, 202-205), attention (35-39), the
  *   score einsum (273-275).  Any m, n, k >= 0; 16-byte aligned operands with pitches that are multiples of 4 take the
- *   vector path, anything else is read element by element.  `flags` is set by the library. */
+ *   vector path, anything else is read element by element.  `flags` and `splits` are set by the library. */
 typedef struct gims_gemm {
   const float* a; const float* b; float* c;
   const float* bias;          /* [n] or NULL */
@@ -506,6 +506,9 @@ typedef struct gims_gemm {
   int32_t act;                /* GIMS_ACT_* */
   int32_t flags;
   float alpha, beta;
+  float* work;                /* optional split-K workspace (device), work_floats floats: used when the output has too few tiles */
+  int64_t work_floats;        /* to fill the chip and k >= 512; partial sums are added in a fixed order.  NULL: never split */
+  int32_t splits, reserved;   /* set by the library */
 } gims_gemm;
 int gims_gemm_f32(const gims_gemm* g, void* stream);
 

@@ -1,0 +1,97 @@
+"""One training step on the HIP path (gims_amd/trainstep.py): model.train(); loss, pos, neg = model(data, mode='train');
+loss.backward() -- against the reference's own training step (tests/golden/trainstep_*: train.py:100, 136-137 run on the
+reference) and, on other seeds, against the oracle's autograd (oracle/gims_oracle.py: train_step, pinned to the same
+goldens by tests/test_train_oracle_cpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from gims_amd import GMatcher, synth
+from oracle import gims_oracle as O
+from tests.helpers import check_step_gradients, golden_names, load_golden, train_data, train_pairs
+
+pytestmark = pytest.mark.gpu
+
+# Bars (relative to the largest entry of each gradient tensor, floor 1e-3 of the largest gradient entry anywhere): the
+# reference and the oracle -- two f32 evaluations of the same step -- differ by 6e-4 worst / 1.2e-4 p95 on these fixtures
+# (4e-3 worst where one ReLU flips); the HIP step computes its products at 16 mantissa bits per operand (split-bf16x3).
+RTOL_WORST, RTOL_P95, LOSS_ATOL = 2e-2, 3e-3, 1e-4
+
+
+def _model(sd, g):
+    m = GMatcher({"sinkhorn_iterations": int(g["meta"][4]), "pos_loss_weight": float(g["pos_loss_weight"]),
+                  "neg_loss_weight": float(g["neg_loss_weight"])})
+    m.load_state_dict(sd)
+    return m.cuda().train()
+
+
+@pytest.mark.parametrize("name", golden_names("trainstep_"))
+def test_train_step_vs_reference_golden(name):
+    g = load_golden(name)
+    sd = synth.make_state_dict(123)
+    m = _model(sd, g)
+    data = train_data(train_pairs(name, g), g, device="cuda")
+    m.zero_grad()
+    loss, pos, neg = m(data, mode="train")
+    assert loss.requires_grad and loss.dim() == 0
+    loss.backward()
+    got = [float(loss), float(pos), float(neg)]
+    np.testing.assert_allclose(got, [g["loss"], g["pos"], g["neg"]], atol=LOSS_ATOL, rtol=0)
+    for s in "01":
+        for b in range(int(g["meta"][5])):
+            assert data[f"kept_kpts{s}_indices"][b] == g[f"kept{s}_{b}"].tolist()
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
+    worst, where, p95 = check_step_gradients(g, grads, rtol=RTOL_WORST, rtol_p95=RTOL_P95)
+    print(name, "loss", got, "gradients: worst", worst, where, "p95", p95)
+    bufs = dict(m.named_buffers())
+    for k in g:
+        if k.startswith("b:"):
+            mine, ref = bufs[k[2:]].cpu().numpy(), g[k]
+            if k.endswith("num_batches_tracked"):
+                assert int(mine) == int(ref), k
+            else:
+                np.testing.assert_allclose(mine, ref, rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_train_step_vs_oracle_and_optimizer_step():
+    """A seed without a fixture, compared with the oracle's autograd; then two optimizer steps lower the loss on the same batch
+    (the gradients point downhill) and a second backward on released activations raises."""
+    g = load_golden("trainstep_n256_s1002_i100")
+    sd = synth.make_state_dict(7)
+    pairs = [synth.make_pair(200, 77)]
+    m = _model(sd, g)
+    cfg = dict(sinkhorn_iterations=int(g["meta"][4]), pos_loss_weight=float(g["pos_loss_weight"]), neg_loss_weight=float(g["neg_loss_weight"]))
+    (l_ref, p_ref, n_ref), g_ref, _ = O.train_step(sd, train_data(pairs, g), cfg)
+    loss, pos, neg = m(train_data(pairs, g, device="cuda"), mode="train")
+    (2.0 * loss + 0.5 * pos).backward()                   # upstream weights other than (1, 0, 0)
+    assert abs(float(loss) - l_ref) < LOSS_ATOL and abs(float(pos) - p_ref) < LOSS_ATOL
+    big = max(float(np.abs(v).max()) for v in g_ref.values())
+    errs = []
+    for k, p in m.named_parameters():
+        ref = 2.5 * g_ref[k] if True else None            # d(2 loss + 0.5 pos) = 2.5 d pos + 2 d neg; neg has no gradient here (clamped corner cell)
+        den = max(float(np.abs(ref).max()), 1e-3 * 2.5 * big)
+        errs.append((float(np.abs(p.grad.cpu().numpy() - ref).max()) / den, k))
+    errs.sort()
+    assert errs[-1][0] < RTOL_WORST and errs[int(0.95 * (len(errs) - 1))][0] < RTOL_P95, errs[-5:]
+    with pytest.raises(RuntimeError):
+        loss.backward()
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    first = None
+    for _ in range(3):
+        opt.zero_grad()
+        loss, _, _ = m(train_data(pairs, g, device="cuda"), mode="train")
+        loss.backward()
+        opt.step()
+        first = float(loss) if first is None else first
+    assert float(loss) < first, (first, float(loss))
+
+
+def test_train_mode_under_no_grad_and_eval_mode_are_graph_free():
+    g = load_golden("trainstep_n256_s1002_i100")
+    m = _model(synth.make_state_dict(123), g)
+    pairs = train_pairs("trainstep_n256_s1002_i100", g)
+    with torch.no_grad():
+        loss, _, _ = m(train_data(pairs, g, device="cuda"), mode="train")
+    assert not loss.requires_grad
+    loss2, _, _ = m.eval()(train_data(pairs, g, device="cuda"), mode="train")     # running statistics, forward value only
+    assert not loss2.requires_grad

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Training-step throughput of the HIP path: model.train(); loss = model(data, mode='train')[0];
+loss.backward(); optimizer.step() on one synthetic pair of 2 x N keypoints (the reference trains with batch_size 1 and
+max_keypoints 2048: configs/coco_config.yaml, train.py:107), next to the oracle's CPU training step on the same input.
+
+    python tools/train_bench.py [--keypoints 2048] [--steps 10] [--no-cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gims_amd import GMatcher, synth  # noqa: E402
+from tools.gen_pairs import matches_of  # noqa: E402
+
+
+def batch(n, seed, device):
+    pair = synth.make_pair(n, seed)
+    d = {k: torch.from_numpy(np.asarray(v)).to(device) for k, v in pair.items() if k not in ("gt_perm", "image0", "image1")}
+    d["image0"], d["image1"] = pair["image0"], pair["image1"]
+    d.update(device=torch.device(device), radius=15, percentile=2, min_size=7)
+    d["matches"] = torch.from_numpy(matches_of(0, pair["gt_perm"], pair["keypoints1"].shape[1])).to(device)
+    return d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--keypoints", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    cfg = {"sinkhorn_iterations": 100, "pos_loss_weight": 0.45, "neg_loss_weight": 1.0}
+    sd = synth.make_state_dict(123)
+    m = GMatcher(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    fw, bw, st, losses = [], [], [], []
+    for i in range(a.warmup + a.steps):
+        d = batch(a.keypoints, 1000 + i % 4, "cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss, pos, neg = m(d, mode="train")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        opt.step()
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        if i >= a.warmup:
+            fw.append(t1 - t0), bw.append(t2 - t1), st.append(t3 - t0), losses.append(float(loss.detach()))
+    out = {"metric": "training steps/sec at 2x%d keypoints, batch 1" % a.keypoints, "value": 1.0 / float(np.median(st)), "unit": "steps/s",
+           "ms_per_step": 1e3 * float(np.median(st)), "forward_ms": 1e3 * float(np.median(fw)), "backward_ms": 1e3 * float(np.median(bw)),
+           "optimizer_ms": 1e3 * float(np.median(st) - np.median(fw) - np.median(bw)), "steps": a.steps, "loss_first_last": [losses[0], losses[-1]],
+           "dtype": "split-bf16x3 MFMA products, f32 everything else", "data": "synthetic",
+           "config": {"workload": "1 pair/step of 2x%d synthetic keypoints, 18 layers, 100 Sinkhorn iterations, Adam" % a.keypoints}}
+    if not a.no_cpu:
+        from oracle import gims_oracle as O
+        torch.set_num_threads(os.cpu_count())
+        d = batch(a.keypoints, 1000, "cpu")
+        t0 = time.perf_counter()
+        O.train_step(sd, d, cfg)
+        out["cpu_baseline"] = {"value": 1.0 / (time.perf_counter() - t0), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "1 training step (forward + autograd backward, no optimizer) of oracle/gims_oracle.py on the same pair"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
