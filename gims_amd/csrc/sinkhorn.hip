@@ -658,15 +658,87 @@ __global__ __launch_bounds__(256) void ot_bwd_fused_kernel(const OtBwd* __restri
   if (tid < nr) p.gu[r0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
-// gv[j] = sign * sum over slabs of colpart[slab][j], slabs in order
+// gv[j] = sign * sum over slabs of colpart[slab][j]: 32 columns x 8 slab groups per workgroup, fixed order
 __global__ __launch_bounds__(256) void ot_bwd_colsum_kernel(const OtBwd* __restrict__ probs, float sign) {
   const OtBwd p = probs[blockIdx.y];
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j > p.m) return;
+  __shared__ float red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, j = blockIdx.x * 32 + tx;
   const int ns = (p.n + BW_ROWS) / BW_ROWS, ldz = p.m + 1;
   float s = 0.f;
-  for (int b = 0; b < ns; ++b) s += p.colpart[(int64_t)b * ldz + j];
-  p.gv[j] = sign * s;
+  if (j <= p.m)
+    for (int b = ty; b < ns; b += 8) s += p.colpart[(int64_t)b * ldz + j];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j <= p.m) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][tx];
+    p.gv[j] = sign * t;
+  }
+}
+
+// The same sweep for m + 1 <= 256 * CPT columns with the slab's Z values held in registers between the two phases (one read of Z).
+template <int CPT>
+__global__ __launch_bounds__(256) void ot_bwd_fused_reg_kernel(const OtBwd* __restrict__ probs, float alpha, int k, int first) {
+  const OtBwd p = probs[blockIdx.y];
+  const int r0 = blockIdx.x * BW_ROWS;
+  if (r0 > p.n) return;
+  const int nr = min(BW_ROWS, p.n + 1 - r0);
+  const int ldz = p.m + 1, tid = threadIdx.x;
+  __shared__ float red[4][BW_ROWS];
+  __shared__ float gnew[BW_ROWS];
+  const float* uk = p.hist + (int64_t)k * p.hstride;
+  const float* vk = uk + p.n + 1;
+  const float* vprev = p.hist + (int64_t)(k - 1) * p.hstride + p.n + 1;
+  float ui[BW_ROWS], acc[BW_ROWS], zc[CPT][BW_ROWS], w[CPT], gvj[CPT];
+#pragma unroll
+  for (int r = 0; r < BW_ROWS; ++r) {
+    ui[r] = r < nr ? uk[r0 + r] : 0.f;
+    acc[r] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int j = tid + 256 * c;
+    const bool on = j <= p.m;
+    w[c] = on ? vk[j] - (j < p.m ? p.norm : p.log_nu_bin) : 0.f;
+    gvj[c] = on ? p.gv[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < BW_ROWS; ++r) {
+      const int i = r0 + r;
+      float z = alpha;
+      if (on && r < nr && i < p.n && j < p.m) z = p.z[(int64_t)i * p.ld + j];
+      zc[c][r] = z;
+      if (on && r < nr) acc[r] += gvj[c] * __expf(z + ui[r] + w[c]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < BW_ROWS; ++r) acc[r] = wave_sum(acc[r]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int r = 0; r < BW_ROWS; ++r) red[tid >> 6][r] = acc[r];
+  __syncthreads();
+  if (tid < BW_ROWS) gnew[tid] = ((first && tid < nr) ? p.gu[r0 + tid] : 0.f) - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+  __syncthreads();
+  float gn[BW_ROWS];
+#pragma unroll
+  for (int r = 0; r < BW_ROWS; ++r) gn[r] = gnew[r];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int j = tid + 256 * c;
+    if (j > p.m) continue;
+    const float vp = k > 1 ? vprev[j] : 0.f;
+    float cs = 0.f;
+#pragma unroll
+    for (int r = 0; r < BW_ROWS; ++r)
+      if (r < nr) {
+        const int i = r0 + r;
+        const float t = gvj[c] * __expf(zc[c][r] + ui[r] + w[c]);
+        const float t2 = gn[r] * __expf(zc[c][r] + ui[r] + vp - (i < p.n ? p.norm : p.log_mu_bin));
+        p.dz[(int64_t)i * ldz + j] -= t + t2;
+        cs += t2;
+      }
+    p.colpart[(int64_t)blockIdx.x * ldz + j] = cs;
+  }
 }
 
 // after a row step: gv <- gv', gu <- 0   (and after a column step gv is dead: it is overwritten here)
@@ -1731,11 +1803,16 @@ extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, flo
       hipLaunchKernelGGL(ot_bwd_swap_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
     }
   } else {
-    const dim3 gs(cdiv(maxn + 1, BW_ROWS), np), gc(cdiv(maxm + 1, 256), np);
+    const dim3 gs(cdiv(maxn + 1, BW_ROWS), np), gc(cdiv(maxm + 1, 32), np);
+    const int cpt = cdiv(maxm + 1, 256);
     hipLaunchKernelGGL(ot_bwd_fused_kernel<true>, gs, dim3(256), 0, s, dp, alpha, 0, 0);
     hipLaunchKernelGGL(ot_bwd_colsum_kernel, gc, dim3(256), 0, s, dp, 1.f);
     for (int k = iters; k >= 1; --k) {
-      hipLaunchKernelGGL((ot_bwd_fused_kernel<false>), gs, dim3(256), 0, s, dp, alpha, k, k == iters ? 1 : 0);
+      const int first = k == iters ? 1 : 0;
+      if (cpt <= 2) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<2>), gs, dim3(256), 0, s, dp, alpha, k, first);
+      else if (cpt <= 5) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<5>), gs, dim3(256), 0, s, dp, alpha, k, first);
+      else if (cpt <= 9) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<9>), gs, dim3(256), 0, s, dp, alpha, k, first);
+      else hipLaunchKernelGGL((ot_bwd_fused_kernel<false>), gs, dim3(256), 0, s, dp, alpha, k, first);
       hipLaunchKernelGGL(ot_bwd_colsum_kernel, gc, dim3(256), 0, s, dp, -1.f);
     }
   }

@@ -1,7 +1,7 @@
 // Training-step kernels (forward_train + backward, models/gmatcher.py:309-386, train.py:136-137).
 //
 // The training step runs in f32-class arithmetic end to end, on ROW-MAJOR f32 activations [keypoint rows][channels]:
-//   * gemm_x3_kernel      -- one general batched GEMM  C = alpha * op(A) op(B)^T + beta * C (+ bias, + residual, ReLU)
+//   * gemm_split_kernel   -- one general batched GEMM  C = alpha * op(A) op(B)^T + beta * C (+ bias, + residual, ReLU)
 //                            for every product of the step (linear layers forward / input gradient / weight gradient, the
 //                            attention products Q K^T, P V and their five gradients, the score matrix and its gradients).
 //                            f32 operands are split into bf16 hi + lo on the way into LDS and multiplied with three bf16 MFMA
@@ -18,14 +18,9 @@
 namespace gims {
 
 // ------------------------------------------------------------------------------------------------ general GEMM, bf16x3
-// LDS tile: [rows][64 bf16] = per row 4 chunks of 8 hi values (k 0..31) then 4 chunks of 8 lo values; 16-byte chunk c of
-// row r lives at chunk position c ^ (r & 7) (conflict-free ds_read_b128 of MFMA fragments: 8 consecutive rows cover
-// all 32 banks).
-__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
-
-struct TileItem {
-  f32x4 v;     // four consecutive k of one tile row
-};
+// LDS tile: NS planes (bf16 hi, mid[, lo] of the f32 value) of [rows][32 k]; 16-byte chunk c (8 k) of row r lives at chunk
+// position c ^ ((r >> 1) & 3) (conflict-free ds_read_b128 of MFMA fragments: 8 consecutive rows cover all 32 banks).
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 3)) << 3); }
 
 // R rows x 32 k of an operand into registers.  T = false: stored [rows][k] (k contiguous); T = true: stored [k][rows].
 // item i of thread t covers (row_of(i), k4_of()) -- see tile_store.
@@ -85,34 +80,41 @@ __device__ __forceinline__ void tile_load(f32x4 (&v)[4], const float* __restrict
   }
 }
 
+template <int NS, int R>
 __device__ __forceinline__ void item_store(uint16_t* __restrict__ tile, int row, int k4, f32x4 x) {
-  const uint32_t h01 = pack_bf2(x[0], x[1]), h23 = pack_bf2(x[2], x[3]);
-  const uint32_t l01 = pack_bf2(x[0] - __uint_as_float(h01 << 16), x[1] - __uint_as_float(h01 & 0xffff0000u));
-  const uint32_t l23 = pack_bf2(x[2] - __uint_as_float(h23 << 16), x[3] - __uint_as_float(h23 & 0xffff0000u));
-  const int c = k4 >> 3, half = k4 & 4;
-  *(uint2*)(tile + tile_off(row, c) + half) = make_uint2(h01, h23);
-  *(uint2*)(tile + tile_off(row, c + 4) + half) = make_uint2(l01, l23);
+  const int o = tile_off(row, k4 >> 3) + (k4 & 4);
+#pragma unroll
+  for (int pl = 0; pl < NS; ++pl) {
+    const uint32_t h01 = pack_bf2(x[0], x[1]), h23 = pack_bf2(x[2], x[3]);
+    *(uint2*)(tile + pl * (R * 32) + o) = make_uint2(h01, h23);
+    x[0] -= __uint_as_float(h01 << 16);
+    x[1] -= __uint_as_float(h01 & 0xffff0000u);
+    x[2] -= __uint_as_float(h23 << 16);
+    x[3] -= __uint_as_float(h23 & 0xffff0000u);
+  }
 }
 
-template <bool T, int R>
+template <bool T, int R, int NS>
 __device__ __forceinline__ void tile_store(const f32x4 (&v)[4], uint16_t* __restrict__ tile, int t) {
   if constexpr (!T) {
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) item_store(tile, (t >> 3) + 32 * i, (t & 7) * 4, v[i]);
+    for (int i = 0; i < R / 32; ++i) item_store<NS, R>(tile, (t >> 3) + 32 * i, (t & 7) * 4, v[i]);
   } else {
     const int rq = (t % (R / 4)) * 4, kb = t / (R / 4);
     if (kb < 8) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) item_store(tile, rq + r, kb * 4, v[r]);
+      for (int r = 0; r < 4; ++r) item_store<NS, R>(tile, rq + r, kb * 4, v[r]);
     }
   }
 }
 
-template <bool TA, bool TB, int BN>
-__global__ __launch_bounds__(256) void gemm_x3_kernel(gims_gemm g) {
+// NS = 2: split-bf16x3 (hi*hi + hi*mid + mid*hi, 16 mantissa bits per operand); NS = 3: split-bf16x6 (+ mid*mid + hi*lo + lo*hi,
+// 24 bits: the f32 class)
+template <bool TA, bool TB, int BN, int NS>
+__global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
   constexpr int BM = 128, MT = BN == 128 ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * 64];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN * 64];
+  __shared__ __attribute__((aligned(16))) uint16_t As[2][NS * BM * 32];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NS * BN * 32];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int nsplit = g.splits > 1 ? g.splits : 1;
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(gims_gemm g) {
   const int nk = kend > kbeg ? (kend - kbeg + 31) / 32 : 0;
   tile_load<TA, BM>(ra, A, g.lda, m0, g.m, kbeg, kend, va, t);
   tile_load<TB, BN>(rb, B, g.ldb, n0, g.n, kbeg, kend, vb, t);
-  tile_store<TA, BM>(ra, As[0], t);
-  tile_store<TB, BN>(rb, Bs[0], t);
+  tile_store<TA, BM, NS>(ra, As[0], t);
+  tile_store<TB, BN, NS>(rb, Bs[0], t);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -149,31 +151,32 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(gims_gemm g) {
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[MT], al[MT], bh[2], bl[2];
+      bf16x8 af[NS][MT], bfr[NS][2];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm + i * 32 + li;
-        ah[i] = *(const bf16x8*)(As[buf] + tile_off(row, ks * 2 + lh));
-        al[i] = *(const bf16x8*)(As[buf] + tile_off(row, ks * 2 + lh + 4));
-      }
+      for (int pl = 0; pl < NS; ++pl) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = wn + j * 32 + li;
-        bh[j] = *(const bf16x8*)(Bs[buf] + tile_off(row, ks * 2 + lh));
-        bl[j] = *(const bf16x8*)(Bs[buf] + tile_off(row, ks * 2 + lh + 4));
+        for (int i = 0; i < MT; ++i) af[pl][i] = *(const bf16x8*)(As[buf] + pl * (BM * 32) + tile_off(wm + i * 32 + li, ks * 2 + lh));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[pl][j] = *(const bf16x8*)(Bs[buf] + pl * (BN * 32) + tile_off(wn + j * 32 + li, ks * 2 + lh));
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);      // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          // small terms first
+          if constexpr (NS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
         }
     }
     if (kt + 1 < nk) {
-      tile_store<TA, BM>(ra, As[buf ^ 1], t);
-      tile_store<TB, BN>(rb, Bs[buf ^ 1], t);
+      tile_store<TA, BM, NS>(ra, As[buf ^ 1], t);
+      tile_store<TB, BN, NS>(rb, Bs[buf ^ 1], t);
     }
     __syncthreads();
   }
@@ -236,10 +239,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(gims_gemm g) {
 template <bool TA, bool TB>
 static void gemm_launch(const gims_gemm& g, hipStream_t s) {
   const int sp = g.splits > 1 ? g.splits : 1;
-  if (g.n <= 64)
-    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, 64>), dim3(cdiv(g.n, 64), cdiv(g.m, 128), g.batch * sp), dim3(256), 0, s, g);
-  else
-    hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, 128>), dim3(cdiv(g.n, 128), cdiv(g.m, 128), g.batch * sp), dim3(256), 0, s, g);
+  const dim3 g64(cdiv(g.n, 64), cdiv(g.m, 128), g.batch * sp), g128(cdiv(g.n, 128), cdiv(g.m, 128), g.batch * sp);
+  if (g.precision == GIMS_PREC_BF16X6) {
+    if (g.n <= 64) hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 64, 3>), g64, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 128, 3>), g128, dim3(256), 0, s, g);
+  } else {
+    if (g.n <= 64) hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 64, 2>), g64, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 128, 2>), g128, dim3(256), 0, s, g);
+  }
   if (sp > 1) hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv((int64_t)g.m * g.n * g.batch, 256)), dim3(256), 0, s, g);
 }
 
@@ -491,25 +498,28 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-// out[ch] = beta * out[ch] + sum_rows x[row][ch]; blocks of 256 rows write partials, the last block of a channel group to
-// finish adds them in block order (deterministic); counters: zero on entry, zero on exit
+// out[ch] = beta * out[ch] + sum_rows x[row][ch].  A workgroup covers 128 rows x 64 channels (16 row lanes x 16 float4 column
+// groups), writes its partial sums, and the last workgroup of a channel group to finish adds the partials in block order
+// (deterministic); counters: zero on entry, zero on exit.  c and the pitch must be multiples of 4 (vector loads).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int c, float beta, float* __restrict__ out,
                                                      float* __restrict__ work, unsigned* __restrict__ counters) {
-  __shared__ float red[8][32];
+  __shared__ f32x4 red[16][16];
   __shared__ bool last;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, ch = blockIdx.x * 32 + tx;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, ch = blockIdx.x * 64 + tx * 4;
   const bool on = ch < c;
-  const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = min(rows, r0 + 256);
-  float s = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.y * 128, r1 = min(rows, r0 + 128);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (on)
-    for (int64_t r = r0 + ty; r < r1; r += 8) s += x[r * ld + ch];
+    for (int64_t r = r0 + ty; r < r1; r += 16) s += *(const f32x4*)(x + r * ld + ch);
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && on) {
-    float tot = 0.f;
+    f32x4 tot = red[0][tx];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tot += red[i][tx];
-    __hip_atomic_store(work + (int64_t)blockIdx.y * c + ch, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 1; i < 16; ++i) tot += red[i][tx];
+    float* w = work + (int64_t)blockIdx.y * c + ch;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) __hip_atomic_store(w + q, tot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __threadfence();
   __syncthreads();
@@ -517,10 +527,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   __syncthreads();
   if (!last) return;
   __threadfence();
-  if (ty == 0 && on) {
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < c) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
     float tot = 0.f;
-    for (unsigned b = 0; b < gridDim.y; ++b) tot += __hip_atomic_load(work + (int64_t)b * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[ch] = beta != 0.f ? fmaf(beta, out[ch], tot) : tot;
+    for (unsigned b = 0; b < gridDim.y; ++b) tot += __hip_atomic_load(work + (int64_t)b * c + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[cc] = beta != 0.f ? fmaf(beta, out[cc], tot) : tot;
   }
   if (threadIdx.x == 0) counters[blockIdx.x] = 0;
 }
@@ -592,6 +603,7 @@ using namespace gims;
 extern "C" int gims_gemm_f32(const gims_gemm* gp, void* stream) {
   GIMS_CHECK_ARG(gp && gp->a && gp->b && gp->c && gp->m >= 0 && gp->n >= 0 && gp->k >= 0 && gp->batch >= 1 && gp->batch <= 65535,
                  "gims_gemm_f32: bad arguments");
+  GIMS_CHECK_ARG(gp->precision == GIMS_PREC_BF16X3 || gp->precision == GIMS_PREC_BF16X6, "gims_gemm_f32: precision is GIMS_PREC_BF16X3 or GIMS_PREC_BF16X6");
   gims_gemm g = *gp;
   if (g.m == 0 || g.n == 0) return GIMS_OK;
   GIMS_CHECK_ARG(g.lda >= (g.ta ? g.m : g.k) && g.ldb >= (g.tb ? g.n : g.k) && g.ldc >= g.n && (!g.residual || g.ldr >= g.n),
@@ -676,13 +688,14 @@ extern "C" int gims_softmax_rows_backward(const float* prob, float* dp, int64_t 
 
 extern "C" size_t gims_colsum_workspace_floats(int64_t rows, int32_t c) {
   if (rows <= 0 || c <= 0) return 0;
-  return 64 + (size_t)cdiv(rows, 256) * (size_t)c;          // [64 counters (fixed place, zero between calls)][row blocks][c] partials
+  return 64 + (size_t)cdiv(rows, 128) * (size_t)c;          // [64 counters (fixed place, zero between calls)][row blocks][c] partials
 }
 
 extern "C" int gims_colsum(const float* x, int64_t ld, int64_t rows, int32_t c, float beta, float* out, float* work, void* stream) {
-  GIMS_CHECK_ARG(x && out && work && rows >= 1 && c >= 1 && c <= 2048 && ld >= c, "gims_colsum: bad arguments (c <= 2048)");
-  const int nrb = cdiv(rows, 256);
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 32), nrb), dim3(256), 0, (hipStream_t)stream, x, ld, rows, c, beta, out, work + 64, (unsigned*)work);
+  GIMS_CHECK_ARG(x && out && work && rows >= 1 && c >= 4 && c <= 4096 && ld >= c && (c & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0,
+                 "gims_colsum: bad arguments (c <= 4096; c, pitch multiples of 4, 16-byte aligned)");
+  const int nrb = cdiv(rows, 128);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 64), nrb), dim3(256), 0, (hipStream_t)stream, x, ld, rows, c, beta, out, work + 64, (unsigned*)work);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

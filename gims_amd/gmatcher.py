@@ -90,6 +90,7 @@ class GMatcher(nn.Module):
         # softmaxes -- mean row maximum up to ~0.2 measured).  'bf16x3': Q, K, V and P as split-bf16 pairs, three MFMAs
         # per product (GIMS_ATTN_X3) -- for sharply peaked attention (mean row maximum ~0.8: the 'peaked' goldens need it)
         'attention_precision': 'bf16',
+        'train_precision': 'bf16x6',      # products of the training step (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
         'verbose': False,               # the reference prints '>> ...' timing lines; off by default here
         # fold the attention 'merge' conv into the first MLP conv at load time:
         #   W0 [x ; Wm o + bm] + b0  ==  W0x x + (W0m Wm) o + (W0m bm + b0)        (gmatcher.py:114,125)

@@ -90,7 +90,7 @@ class Gemm(C.Structure):
                 ("sa", C.c_int64), ("sb", C.c_int64), ("sc", C.c_int64), ("sr", C.c_int64),
                 ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("batch", C.c_int32),
                 ("ta", C.c_int32), ("tb", C.c_int32), ("act", C.c_int32), ("flags", C.c_int32),
-                ("alpha", C.c_float), ("beta", C.c_float), ("work", C.c_void_p), ("work_floats", C.c_int64), ("splits", C.c_int32), ("reserved", C.c_int32)]
+                ("alpha", C.c_float), ("beta", C.c_float), ("work", C.c_void_p), ("work_floats", C.c_int64), ("splits", C.c_int32), ("precision", C.c_int32)]
 
 
 class Segments(C.Structure):
@@ -905,7 +905,11 @@ def _operand(x: torch.Tensor):
 _gemm_work = {}
 
 
-def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, *, alpha=1.0, beta=0.0, bias=None, residual=None, act=ACT_NONE):
+GEMM_PRECISION = PREC_BF16X6          # default of gemm(): gims_amd.trainstep sets it per step from config['train_precision']
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, *, alpha=1.0, beta=0.0, bias=None, residual=None, act=ACT_NONE,
+         precision=None):
     """out = alpha * a @ b^T + beta * out (+ bias over the last dimension) (+ residual), then act (gims_gemm_f32, f32-class
     split-bf16x3 MFMA).  a: [.., m, k], b: [.., n, k] views (either may be a transposed view), out: [.., m, n] with unit
     stride along n.  Batched when the tensors are 3-D."""
@@ -922,6 +926,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, *, a
     g = Gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), lda, ldb, out.stride(-2) if m > 1 else max(n, out.stride(-2)),
              (residual.stride(-2) if residual is not None else 0), sa, sb, out.stride(0) if out.dim() == 3 else 0,
              (residual.stride(0) if (residual is not None and residual.dim() == 3) else 0), m, n, k, batch, ta, tb, int(act), 0, float(alpha), float(beta))
+    g.precision = GEMM_PRECISION if precision is None else int(precision)
     if k >= 512:                                  # split-K workspace (one arena per device and stream; stream order protects it)
         key = (a.device, _stream())
         w = _gemm_work.get(key)

@@ -1,7 +1,7 @@
 """One training step of GMatcher on the HIP path (SURVEY row f3 = a25): the forward pass of ``forward_train``
 (models/gmatcher.py:309-386) with the module in train() mode -- BatchNorm on batch statistics, running statistics updated --
 and the reverse pass through every stage of it, so that ``loss.backward()`` of train.py:136-137 fills ``.grad`` of all 282
-parameters.  Host orchestration only: every product runs in gims_gemm_f32 (split-bf16x3 MFMA), the norms, softmaxes, sums
+parameters.  Host orchestration only: every product runs in gims_gemm_f32 (split-bf16 MFMA, f32 class by default), the norms, softmaxes, sums
 and graph aggregations in the kernels of csrc/train.hip, the Sinkhorn solve and its reverse sweep in csrc/sinkhorn.hip.
 
 Layout: rows of all images SIDE-major ([image 0 of every batch element | image 1 of every batch element]), activations
@@ -58,6 +58,16 @@ def _w2(p):
     return p.detach().view(p.shape[0], -1)
 
 
+def _precision(cfg):
+    """config['train_precision']: 'bf16x6' (default: three bf16 parts per f32 operand, six MFMA passes -- the accuracy class of the
+    reference's f32 matmuls, which the reverse pass needs: bias-like gradients are sums with heavy cancellation and a ReLU
+    of a near-zero pre-activation falls the other way ~100x more often at 16 bits) or 'bf16x3' (two parts, three passes)."""
+    p = cfg.get('train_precision', 'bf16x6')
+    if p not in ('bf16x6', 'bf16x3'):
+        raise ValueError("train_precision must be 'bf16x6' or 'bf16x3'")
+    return hip.PREC_BF16X6 if p == 'bf16x6' else hip.PREC_BF16X3
+
+
 class _Step:
     """Everything the reverse pass needs from the forward pass of one step."""
 
@@ -72,6 +82,7 @@ def forward(model, data):
     """Returns (out3 = [loss, pos_loss, neg_loss] device tensor, _Step).  Mutates ``data`` like the reference's forward does
     (gmatcher.py:244-252) and updates the BatchNorm buffers of ``model``."""
     cfg = model.config
+    hip.GEMM_PRECISION = _precision(cfg)
     if cfg['use_layernorm']:
         raise NotImplementedError("training with use_layernorm=True is not on the HIP path (the reference default is BatchNorm)")
     radius, percentile, min_size = data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)
@@ -216,6 +227,7 @@ def backward(model, S, w_pos: float, w_neg: float):
     """Gradients of  w_pos * (pos_loss / pos_loss_weight) + w_neg * (neg_loss / neg_loss_weight)  -- i.e. with w_pos / w_neg the
     effective weights of the two loss terms -- with respect to every parameter: dict name -> tensor shaped like the parameter."""
     cfg = model.config
+    hip.GEMM_PRECISION = _precision(cfg)
     P = {k: v.detach() for k, v in model.named_parameters()}
     D, B, n_tot, rows, sg, G = S.D, S.B, S.n_tot, S.rows, S.sg, S.G
     dev = S.mdesc.device

@@ -490,8 +490,8 @@ int gims_patch_extract(const uint8_t* pyr, const gims_pyr_level* dev_levels, int
  *
  * gims_gemm_f32: for z < batch   C_z = alpha * op(A_z) op(B_z)^T + beta * C_z (+ bias[n]) (+ residual_z), then act.
  *   op(A)(m, k) = ta ? A[k * lda + m] : A[m * lda + k];  op(B)(n, k) = tb ? B[k * ldb + n] : B[n * ldb + k].
- *   X_z = X + z * s{a,b,c,r} elements.  Arithmetic: f32 operands split into bf16 hi + lo, three bf16 MFMA passes, f32
- *   accumulation (the f32-class mode of gims_linear).  Replaces every torch matmul / conv1d(k=1) / einsum of the step and of
+ *   X_z = X + z * s{a,b,c,r} elements.  Arithmetic: f32 operands split on the fly into two (three) bf16 parts, three (six)
+ *   bf16 MFMA passes per product, f32 accumulation (`precision`).  Replaces every torch matmul / conv1d(k=1) / einsum of the step and of
  *   its autograd: nn.Conv1d forward, grad_input, grad_weight (gmatcher.py:11-24, 99-125, 202-205), attention (35-39), the
  *   score einsum (273-275).  Any m, n, k >= 0; 16-byte aligned operands with pitches that are multiples of 4 take the
  *   vector path, anything else is read element by element.  `flags` and `splits` are set by the library. */
@@ -508,7 +508,8 @@ typedef struct gims_gemm {
   float alpha, beta;
   float* work;                /* optional split-K workspace (device), work_floats floats: used when the output has too few tiles */
   int64_t work_floats;        /* to fill the chip and k >= 512; partial sums are added in a fixed order.  NULL: never split */
-  int32_t splits, reserved;   /* set by the library */
+  int32_t splits;             /* set by the library */
+  int32_t precision;          /* GIMS_PREC_BF16X3 (16 mantissa bits per operand) or GIMS_PREC_BF16X6 (24 bits: the f32 class) */
 } gims_gemm;
 int gims_gemm_f32(const gims_gemm* g, void* stream);
 

@@ -16,20 +16,21 @@ def _rand(*shape, seed=0, scale=1.0):
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 200, 70), (2031, 64, 2031), (65, 257, 2), (1, 512, 513), (257, 1, 33), (512, 512, 512)])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_gemm_f32_forms(m, n, k, ta, tb):
+@pytest.mark.parametrize("prec,tol", [(hip.PREC_BF16X3, 1.5e-5), (hip.PREC_BF16X6, 4e-7)])
+def test_gemm_f32_forms(m, n, k, ta, tb, prec, tol):
     """C = alpha A B^T + beta C + bias + residual for both storage orders of both operands, ragged edges, K not a multiple of 4."""
     a = _rand(k, m, seed=1).t() if ta else _rand(m, k, seed=1)
     b = _rand(k, n, seed=2).t() if tb else _rand(n, k, seed=2)
     c0 = _rand(m, n, seed=3)
     bias, res = _rand(n, seed=4), _rand(m, n, seed=5)
     out = c0.clone()
-    hip.gemm(a, b, out, alpha=0.5, beta=2.0, bias=bias, residual=res)
+    hip.gemm(a, b, out, alpha=0.5, beta=2.0, bias=bias, residual=res, precision=prec)
     ref = 0.5 * (a.double() @ b.double().t()) + 2.0 * c0.double() + bias.double() + res.double()
     err = float((out.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
-    assert err < 1.5e-5, err         # split-bf16x3: operands carry 16 mantissa bits (hi + lo), f32 accumulation over k
-    out2 = hip.gemm(a, b, act=hip.ACT_RELU)
+    assert err < tol, err            # x3: operands carry 16 mantissa bits; x6: 24 (f32 accumulation over k either way)
+    out2 = hip.gemm(a, b, act=hip.ACT_RELU, precision=prec)
     ref2 = (a.double() @ b.double().t()).clamp(min=0)
-    assert float((out2.double() - ref2).abs().max()) / max(1.0, float(ref2.abs().max())) < 1.5e-5
+    assert float((out2.double() - ref2).abs().max()) / max(1.0, float(ref2.abs().max())) < tol
 
 
 def test_gemm_batched_strided_heads():

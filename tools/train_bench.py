@@ -34,8 +34,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "bf16x3"])
     a = ap.parse_args()
-    cfg = {"sinkhorn_iterations": 100, "pos_loss_weight": 0.45, "neg_loss_weight": 1.0}
+    cfg = {"sinkhorn_iterations": 100, "pos_loss_weight": 0.45, "neg_loss_weight": 1.0, "train_precision": a.precision}
     sd = synth.make_state_dict(123)
     m = GMatcher(cfg)
     m.load_state_dict(sd)
@@ -61,7 +62,7 @@ def main():
     out = {"metric": "training steps/sec at 2x%d keypoints, batch 1" % a.keypoints, "value": 1.0 / float(np.median(st)), "unit": "steps/s",
            "ms_per_step": 1e3 * float(np.median(st)), "forward_ms": 1e3 * float(np.median(fw)), "backward_ms": 1e3 * float(np.median(bw)),
            "optimizer_ms": 1e3 * float(np.median(st) - np.median(fw) - np.median(bw)), "steps": a.steps, "loss_first_last": [losses[0], losses[-1]],
-           "dtype": "split-bf16x3 MFMA products, f32 everything else", "data": "synthetic",
+           "dtype": "split-%s MFMA products, f32 everything else" % a.precision, "data": "synthetic",
            "config": {"workload": "1 pair/step of 2x%d synthetic keypoints, 18 layers, 100 Sinkhorn iterations, Adam" % a.keypoints}}
     if not a.no_cpu:
         from oracle import gims_oracle as O

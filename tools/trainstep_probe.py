@@ -11,9 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gims_amd import GMatcher, synth  # noqa: E402
 from tests.helpers import golden_names, grad_sample_index, load_golden, train_data, train_pairs  # noqa: E402
 
+PREC = sys.argv[1] if len(sys.argv) > 1 else "bf16x6"
 for name in golden_names("trainstep_"):
     g = load_golden(name)
-    m = GMatcher({"sinkhorn_iterations": int(g["meta"][4]), "pos_loss_weight": float(g["pos_loss_weight"]), "neg_loss_weight": float(g["neg_loss_weight"])})
+    m = GMatcher({"train_precision": PREC, "sinkhorn_iterations": int(g["meta"][4]), "pos_loss_weight": float(g["pos_loss_weight"]), "neg_loss_weight": float(g["neg_loss_weight"])})
     m.load_state_dict(synth.make_state_dict(123))
     m = m.cuda().train()
     pairs = train_pairs(name, g)
