@@ -677,15 +677,16 @@ __global__ __launch_bounds__(256) void ot_bwd_colsum_kernel(const OtBwd* __restr
   }
 }
 
-// The same sweep for m + 1 <= 256 * CPT columns with the slab's Z values held in registers between the two phases (one read of Z).
+// The same sweep for m + 1 <= 512 * CPT columns with the slab's Z values held in registers between the two phases (one read of Z);
+// 512 threads: two workgroups fit on a CU, so the one-row slab of the dustbin row does not cost a second round.
 template <int CPT>
-__global__ __launch_bounds__(256) void ot_bwd_fused_reg_kernel(const OtBwd* __restrict__ probs, float alpha, int k, int first) {
+__global__ __launch_bounds__(512) void ot_bwd_fused_reg_kernel(const OtBwd* __restrict__ probs, float alpha, int k, int first) {
   const OtBwd p = probs[blockIdx.y];
   const int r0 = blockIdx.x * BW_ROWS;
   if (r0 > p.n) return;
   const int nr = min(BW_ROWS, p.n + 1 - r0);
   const int ldz = p.m + 1, tid = threadIdx.x;
-  __shared__ float red[4][BW_ROWS];
+  __shared__ float red[8][BW_ROWS];
   __shared__ float gnew[BW_ROWS];
   const float* uk = p.hist + (int64_t)k * p.hstride;
   const float* vk = uk + p.n + 1;
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(256) void ot_bwd_fused_reg_kernel(const OtBwd* __re
   }
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
-    const int j = tid + 256 * c;
+    const int j = tid + 512 * c;
     const bool on = j <= p.m;
     w[c] = on ? vk[j] - (j < p.m ? p.norm : p.log_nu_bin) : 0.f;
     gvj[c] = on ? p.gv[j] : 0.f;
@@ -717,14 +718,16 @@ __global__ __launch_bounds__(256) void ot_bwd_fused_reg_kernel(const OtBwd* __re
 #pragma unroll
     for (int r = 0; r < BW_ROWS; ++r) red[tid >> 6][r] = acc[r];
   __syncthreads();
-  if (tid < BW_ROWS) gnew[tid] = ((first && tid < nr) ? p.gu[r0 + tid] : 0.f) - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+  if (tid < BW_ROWS)
+    gnew[tid] = ((first && tid < nr) ? p.gu[r0 + tid] : 0.f) -
+                (((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid])));
   __syncthreads();
   float gn[BW_ROWS];
 #pragma unroll
   for (int r = 0; r < BW_ROWS; ++r) gn[r] = gnew[r];
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
-    const int j = tid + 256 * c;
+    const int j = tid + 512 * c;
     if (j > p.m) continue;
     const float vp = k > 1 ? vprev[j] : 0.f;
     float cs = 0.f;
@@ -1804,14 +1807,15 @@ extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, flo
     }
   } else {
     const dim3 gs(cdiv(maxn + 1, BW_ROWS), np), gc(cdiv(maxm + 1, 32), np);
-    const int cpt = cdiv(maxm + 1, 256);
+    const int cpt = cdiv(maxm + 1, 512);
     hipLaunchKernelGGL(ot_bwd_fused_kernel<true>, gs, dim3(256), 0, s, dp, alpha, 0, 0);
     hipLaunchKernelGGL(ot_bwd_colsum_kernel, gc, dim3(256), 0, s, dp, 1.f);
     for (int k = iters; k >= 1; --k) {
       const int first = k == iters ? 1 : 0;
-      if (cpt <= 2) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<2>), gs, dim3(256), 0, s, dp, alpha, k, first);
-      else if (cpt <= 5) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<5>), gs, dim3(256), 0, s, dp, alpha, k, first);
-      else if (cpt <= 9) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<9>), gs, dim3(256), 0, s, dp, alpha, k, first);
+      if (cpt <= 1) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<1>), gs, dim3(512), 0, s, dp, alpha, k, first);
+      else if (cpt <= 3) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<3>), gs, dim3(512), 0, s, dp, alpha, k, first);
+      else if (cpt <= 5) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<5>), gs, dim3(512), 0, s, dp, alpha, k, first);
+      else if (cpt <= 9) hipLaunchKernelGGL((ot_bwd_fused_reg_kernel<9>), gs, dim3(512), 0, s, dp, alpha, k, first);
       else hipLaunchKernelGGL((ot_bwd_fused_kernel<false>), gs, dim3(256), 0, s, dp, alpha, k, first);
       hipLaunchKernelGGL(ot_bwd_colsum_kernel, gc, dim3(256), 0, s, dp, -1.f);
     }

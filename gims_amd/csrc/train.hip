@@ -527,11 +527,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   __syncthreads();
   if (!last) return;
   __threadfence();
-  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < c) {
-    const int cc = blockIdx.x * 64 + threadIdx.x;
+  {
+    // 64 channels x 4 lanes over the row blocks; each lane keeps 8 loads in flight (a serial chain of device-scope loads costs
+    // ~0.7 us per partial); lanes are folded in order, so the sum is still a fixed sequence
+    float* fr = (float*)red;
+    const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6, cc = blockIdx.x * 64 + cl;
     float tot = 0.f;
-    for (unsigned b = 0; b < gridDim.y; ++b) tot += __hip_atomic_load(work + (int64_t)b * c + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[cc] = beta != 0.f ? fmaf(beta, out[cc], tot) : tot;
+    if (cc < c)
+      for (unsigned b0 = lane4 * 8; b0 < gridDim.y; b0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          v[q] = b0 + q < gridDim.y ? __hip_atomic_load(work + (int64_t)(b0 + q) * c + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tot += v[q];
+      }
+    __syncthreads();
+    fr[lane4 * 64 + cl] = tot;
+    __syncthreads();
+    if (lane4 == 0 && cc < c) {
+      const float t = (fr[cl] + fr[64 + cl]) + (fr[128 + cl] + fr[192 + cl]);
+      out[cc] = beta != 0.f ? fmaf(beta, out[cc], t) : t;
+    }
   }
   if (threadIdx.x == 0) counters[blockIdx.x] = 0;
 }
