@@ -74,16 +74,17 @@ def test_batchnorm_train_forward_backward(rows, c, relu):
     rm_h, rv_h = rm.clone(), rv.clone()
     y, save = hip.batchnorm_train_forward(x, sg, gamma, beta, 1e-5, 0.1, rm_h, rv_h, relu)
     dx, dg, db = hip.batchnorm_train_backward(x, dy, sg, save, gamma, beta, relu)
-    xr = x.double().cpu().requires_grad_(True)
-    gr, br = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
-    rm_r, rv_r = rm.double().cpu(), rv.double().cpu()
-    ys = []
-    for i in range(len(rows)):
-        seg = xr[offs[i]:offs[i + 1]].t()[None]                   # (1, C, N) like the reference's Conv1d activations
-        o = torch.nn.functional.batch_norm(seg, rm_r, rv_r, gr, br, training=True, momentum=0.1, eps=1e-5)
-        ys.append((o.relu() if relu else o)[0].t())
-    yr = torch.cat(ys)
-    yr.backward(dy.double().cpu())
+    with torch.enable_grad():           # (some test modules switch autograd off process-wide)
+        xr = x.double().cpu().requires_grad_(True)
+        gr, br = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+        rm_r, rv_r = rm.double().cpu(), rv.double().cpu()
+        ys = []
+        for i in range(len(rows)):
+            seg = xr[offs[i]:offs[i + 1]].t()[None]                   # (1, C, N) like the reference's Conv1d activations
+            o = torch.nn.functional.batch_norm(seg, rm_r, rv_r, gr, br, training=True, momentum=0.1, eps=1e-5)
+            ys.append((o.relu() if relu else o)[0].t())
+        yr = torch.cat(ys)
+        yr.backward(dy.double().cpu())
     assert float((y.double().cpu() - yr.detach()).abs().max()) < 2e-5
     assert float((rm_h.double().cpu() - rm_r).abs().max()) < 1e-6 and float((rv_h.double().cpu() - rv_r).abs().max()) < 1e-5
     # entries whose pre-activation is within rounding of 0 may take the other branch of the ReLU: compare away from them

@@ -12,6 +12,13 @@ from tests.helpers import check_step_gradients, golden_names, load_golden, train
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _autograd_on():
+    """Other test modules switch autograd off process-wide at import; a training step needs it."""
+    with torch.enable_grad():
+        yield
+
 # Bars (relative to the largest entry of each gradient tensor, floor 1e-3 of the largest gradient entry anywhere).  The
 # reference and the oracle -- two f32 evaluations of the same step -- differ by 6e-4 worst / 1.2e-4 p95 on these fixtures
 # (4e-3 worst on the batch-of-two fixture, where one ReLU of a near-zero pre-activation falls the other way).  The default
