@@ -376,6 +376,11 @@ def main():
             res["also"] = {f"2x{k}": r for (k, _), r in zip(loads[1:], results[1:])}
         if world == 1 and (args.latency or args.kpts is None):
             res["latency_ms_b1"] = latency_b1(model, [k for k, _ in loads], dev)
+        if world == 1 and args.kpts is None:
+            # one training step (train() mode forward, backward, Adam) per pair of 2x2048 keypoints, the
+            # reference's training configuration; its CPU leg (one oracle step, ~5 s) only next to the main CPU baseline
+            from tools.train_bench import measure as train_measure
+            res["train_step"] = train_measure(2048, 6, 2, "bf16x6", with_cpu=base)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -28,6 +28,49 @@ def batch(n, seed, device):
     return d
 
 
+def measure(keypoints=2048, steps=10, warmup=2, precision="bf16x6", with_cpu=True):
+    """The JSON block of one measurement (also embedded in bench.py's line as `train_step`)."""
+    cfg = {"sinkhorn_iterations": 100, "pos_loss_weight": 0.45, "neg_loss_weight": 1.0, "train_precision": precision}
+    sd = synth.make_state_dict(123)
+    m = GMatcher(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    fw, bw, st, losses = [], [], [], []
+    with torch.enable_grad():
+        for i in range(warmup + steps):
+            d = batch(keypoints, 1000 + i % 4, "cuda")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss, pos, neg = m(d, mode="train")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            loss.backward()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            opt.step()
+            opt.zero_grad()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            if i >= warmup:
+                fw.append(t1 - t0), bw.append(t2 - t1), st.append(t3 - t0), losses.append(float(loss.detach()))
+    out = {"metric": "training steps/sec at 2x%d keypoints, batch 1" % keypoints, "value": 1.0 / float(np.median(st)), "unit": "steps/s",
+           "ms_per_step": 1e3 * float(np.median(st)), "forward_ms": 1e3 * float(np.median(fw)), "backward_ms": 1e3 * float(np.median(bw)),
+           "optimizer_ms": 1e3 * float(np.median(st) - np.median(fw) - np.median(bw)), "steps": steps, "loss_first_last": [losses[0], losses[-1]],
+           "dtype": "split-%s MFMA products, f32 everything else" % precision, "data": "synthetic",
+           "config": {"workload": "1 pair/step of 2x%d synthetic keypoints, 18 layers, 100 Sinkhorn iterations, train() mode forward + backward + Adam" % keypoints}}
+    if with_cpu:
+        from oracle import gims_oracle as O
+        cores = min(os.cpu_count() or 1, 16)            # more threads than that make torch's CPU autograd crawl on many-core hosts
+        torch.set_num_threads(cores)
+        d = batch(keypoints, 1000, "cpu")
+        t0 = time.perf_counter()
+        O.train_step(sd, d, cfg)
+        out["cpu_baseline"] = {"value": 1.0 / (time.perf_counter() - t0), "unit": "steps/s", "cores": cores, "kind": "port",
+                               "sample": "1 training step (forward + autograd backward, no optimizer) of oracle/gims_oracle.py on the same pair"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--keypoints", type=int, default=2048)
@@ -36,44 +79,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "bf16x3"])
     a = ap.parse_args()
-    cfg = {"sinkhorn_iterations": 100, "pos_loss_weight": 0.45, "neg_loss_weight": 1.0, "train_precision": a.precision}
-    sd = synth.make_state_dict(123)
-    m = GMatcher(cfg)
-    m.load_state_dict(sd)
-    m = m.cuda().train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
-    fw, bw, st, losses = [], [], [], []
-    for i in range(a.warmup + a.steps):
-        d = batch(a.keypoints, 1000 + i % 4, "cuda")
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        loss, pos, neg = m(d, mode="train")
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        loss.backward()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        opt.step()
-        opt.zero_grad()
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        if i >= a.warmup:
-            fw.append(t1 - t0), bw.append(t2 - t1), st.append(t3 - t0), losses.append(float(loss.detach()))
-    out = {"metric": "training steps/sec at 2x%d keypoints, batch 1" % a.keypoints, "value": 1.0 / float(np.median(st)), "unit": "steps/s",
-           "ms_per_step": 1e3 * float(np.median(st)), "forward_ms": 1e3 * float(np.median(fw)), "backward_ms": 1e3 * float(np.median(bw)),
-           "optimizer_ms": 1e3 * float(np.median(st) - np.median(fw) - np.median(bw)), "steps": a.steps, "loss_first_last": [losses[0], losses[-1]],
-           "dtype": "split-%s MFMA products, f32 everything else" % a.precision, "data": "synthetic",
-           "config": {"workload": "1 pair/step of 2x%d synthetic keypoints, 18 layers, 100 Sinkhorn iterations, Adam" % a.keypoints}}
-    if not a.no_cpu:
-        from oracle import gims_oracle as O
-        cores = min(os.cpu_count() or 1, 16)            # more threads than that make torch's CPU autograd crawl on many-core hosts
-        torch.set_num_threads(cores)
-        d = batch(a.keypoints, 1000, "cpu")
-        t0 = time.perf_counter()
-        O.train_step(sd, d, cfg)
-        out["cpu_baseline"] = {"value": 1.0 / (time.perf_counter() - t0), "unit": "steps/s", "cores": cores, "kind": "port",
-                               "sample": "1 training step (forward + autograd backward, no optimizer) of oracle/gims_oracle.py on the same pair"}
-    print(json.dumps(out))
+    print(json.dumps(measure(a.keypoints, a.steps, a.warmup, a.precision, not a.no_cpu)))
 
 
 if __name__ == "__main__":
