@@ -13,6 +13,8 @@
 //   * softmax over attention rows and its backward, column sums (bias gradients), the transposed mean aggregation of
 //                            GraphSAGE, a strided 3-D copy (head interleave of gmatcher.py:108-113 <-> contiguous heads).
 // All reductions have a fixed order: a training step is bitwise reproducible.
+#include <type_traits>
+
 #include "common.h"
 
 namespace gims {
@@ -23,60 +25,34 @@ namespace gims {
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 3)) << 3); }
 
 // R rows x 32 k of an operand into registers.  T = false: stored [rows][k] (k contiguous); T = true: stored [k][rows].
-// item i of thread t covers (row_of(i), k4_of()) -- see tile_store.
-template <bool T, int R>
-__device__ __forceinline__ void tile_load(f32x4 (&v)[4], const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int K,
-                                          bool vec, int t) {
+// The loads are UNCONDITIONAL (indices clamped into the operand) and nothing consumes them here: masking of the ragged edges
+// happens in tile_store, two compute phases later -- a select right behind a load would make every load wait for its own data
+// and serialise the eight round trips of a tile.
+template <bool T, int R, bool VEC>
+__device__ __forceinline__ void tile_load(f32x4 (&v)[4], const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int K, int t) {
   if constexpr (!T) {
+    const int k = k0 + (t & 7) * 4;
 #pragma unroll
     for (int i = 0; i < R / 32; ++i) {
-      const int gr = row0 + (t >> 3) + 32 * i, k = k0 + (t & 7) * 4;
-      f32x4 x = {0.f, 0.f, 0.f, 0.f};
-      if (gr < nrows && k < K) {
-        const float* p = base + (int64_t)gr * ld + k;
-        if (vec) {
-          x = *(const f32x4*)p;
-          if (k + 3 >= K) {
-            if (k + 1 >= K) x[1] = 0.f;
-            if (k + 2 >= K) x[2] = 0.f;
-            x[3] = 0.f;
-          }
-        } else {
-          x[0] = p[0];
-          if (k + 1 < K) x[1] = p[1];
-          if (k + 2 < K) x[2] = p[2];
-          if (k + 3 < K) x[3] = p[3];
-        }
+      const int gr = min(row0 + (t >> 3) + 32 * i, nrows - 1);
+      const float* p = base + (int64_t)gr * ld;
+      if constexpr (VEC) {
+        v[i] = *(const f32x4*)(p + min(k, (K - 1) & ~3));
+      } else {
+        v[i] = f32x4{p[min(k, K - 1)], p[min(k + 1, K - 1)], p[min(k + 2, K - 1)], p[min(k + 3, K - 1)]};
       }
-      v[i] = x;
     }
   } else {
-    const int rq = (t % (R / 4)) * 4, kb = t / (R / 4);
-    f32x4 w[4];
+    const int rq = row0 + (t % (R / 4)) * 4, kb = min(t / (R / 4), 7);       // (threads past the tile repeat its last block: no branch)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int k = k0 + kb * 4 + j, gr = row0 + rq;
-      f32x4 x = {0.f, 0.f, 0.f, 0.f};
-      if (kb < 8 && k < K && gr < nrows) {
-        const float* p = base + (int64_t)k * ld + gr;
-        if (vec) {
-          x = *(const f32x4*)p;
-          if (gr + 3 >= nrows) {
-            if (gr + 1 >= nrows) x[1] = 0.f;
-            if (gr + 2 >= nrows) x[2] = 0.f;
-            x[3] = 0.f;
-          }
-        } else {
-          x[0] = p[0];
-          if (gr + 1 < nrows) x[1] = p[1];
-          if (gr + 2 < nrows) x[2] = p[2];
-          if (gr + 3 < nrows) x[3] = p[3];
-        }
+      const float* p = base + (int64_t)min(k0 + kb * 4 + j, K - 1) * ld;
+      if constexpr (VEC) {
+        v[j] = *(const f32x4*)(p + min(rq, (nrows - 1) & ~3));
+      } else {
+        v[j] = f32x4{p[min(rq, nrows - 1)], p[min(rq + 1, nrows - 1)], p[min(rq + 2, nrows - 1)], p[min(rq + 3, nrows - 1)]};
       }
-      w[j] = x;
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = f32x4{w[0][r], w[1][r], w[2][r], w[3][r]};
   }
 }
 
@@ -94,27 +70,49 @@ __device__ __forceinline__ void item_store(uint16_t* __restrict__ tile, int row,
   }
 }
 
+// registers of tile_load -> LDS planes; zeroes what lies outside [row0, nrows) x [k0, K)
 template <bool T, int R, int NS>
-__device__ __forceinline__ void tile_store(const f32x4 (&v)[4], uint16_t* __restrict__ tile, int t) {
+__device__ __forceinline__ void tile_store(const f32x4 (&v)[4], uint16_t* __restrict__ tile, int row0, int nrows, int k0, int K, int t) {
   if constexpr (!T) {
+    const int k4 = (t & 7) * 4, k = k0 + k4;
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) item_store<NS, R>(tile, (t >> 3) + 32 * i, (t & 7) * 4, v[i]);
+    for (int i = 0; i < R / 32; ++i) {
+      const int row = (t >> 3) + 32 * i;
+      const bool rv = row0 + row < nrows;
+      f32x4 x = v[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = (rv && k + j < K) ? x[j] : 0.f;
+      item_store<NS, R>(tile, row, k4, x);
+    }
   } else {
     const int rq = (t % (R / 4)) * 4, kb = t / (R / 4);
     if (kb < 8) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) item_store<NS, R>(tile, rq + r, kb * 4, v[r]);
+      for (int r = 0; r < 4; ++r) {
+        const bool rv = row0 + rq + r < nrows;
+        f32x4 x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = (rv && k0 + kb * 4 + j < K) ? v[j][r] : 0.f;
+        item_store<NS, R>(tile, rq + r, kb * 4, x);
+      }
     }
   }
 }
 
 // NS = 2: split-bf16x3 (hi*hi + hi*mid + mid*hi, 16 mantissa bits per operand); NS = 3: split-bf16x6 (+ mid*mid + hi*lo + lo*hi,
 // 24 bits: the f32 class)
-template <bool TA, bool TB, int BN, int NS>
+// VEC: both operands 16-byte aligned with pitches that are multiples of 4 (straight-line loads; the compiler then counts the
+// loads in flight and waits only for the register set it is about to use)
+template <bool TA, bool TB, int BM, int BN, int NS, bool VEC>
 __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
-  constexpr int BM = 128, MT = BN == 128 ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) uint16_t As[2][NS * BM * 32];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NS * BN * 32];
+  // wave grid 2 x 2 (4 x 1 for 64-column tiles); a wave owns MT x 2 MFMA tiles of 32 x 32
+  static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64) && !(BM == 64 && BN == 64), "tile geometry");
+  constexpr int MT = (BM == 128 && BN == 128) ? 2 : 1;
+  // ONE LDS stage (48 KB at 128 x 128, three planes: two or three workgroups per CU hide each other's barriers and the
+  // epilogue) fed from TWO register sets in flight: tile kt + 2 is requested right after tile kt went to LDS, so a global load
+  // has two compute phases to land
+  __shared__ __attribute__((aligned(16))) uint16_t As[NS * BM * 32];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[NS * BN * 32];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int nsplit = g.splits > 1 ? g.splits : 1;
@@ -123,10 +121,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
   // and the epilogue follow in splitk_reduce_kernel)
   const int kchunk = ((g.k + nsplit - 1) / nsplit + 31) & ~31;
   const int kbeg = split * kchunk, kend = min(g.k, kbeg + kchunk);
-  const int wm = BN == 128 ? (wave >> 1) * 64 : wave * 32, wn = BN == 128 ? (wave & 1) * 64 : 0;
+  const int wm = BN == 64 ? wave * 32 : (wave >> 1) * (32 * MT), wn = BN == 64 ? 0 : (wave & 1) * 64;
   const float* __restrict__ A = g.a + (int64_t)z * g.sa;
   const float* __restrict__ B = g.b + (int64_t)z * g.sb;
-  const bool va = (g.flags & 1) != 0, vb = (g.flags & 2) != 0;
 
   f32x16 acc[MT][2];
 #pragma unroll
@@ -136,28 +133,37 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[2][4], rb[2][4];
   const int nk = kend > kbeg ? (kend - kbeg + 31) / 32 : 0;
-  tile_load<TA, BM>(ra, A, g.lda, m0, g.m, kbeg, kend, va, t);
-  tile_load<TB, BN>(rb, B, g.ldb, n0, g.n, kbeg, kend, vb, t);
-  tile_store<TA, BM, NS>(ra, As[0], t);
-  tile_store<TB, BN, NS>(rb, Bs[0], t);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      tile_load<TA, BM>(ra, A, g.lda, m0, g.m, kbeg + (kt + 1) * 32, kend, va, t);
-      tile_load<TB, BN>(rb, B, g.ldb, n0, g.n, kbeg + (kt + 1) * 32, kend, vb, t);
+  if (nk > 0) {
+    tile_load<TA, BM, VEC>(ra[0], A, g.lda, m0, g.m, kbeg, kend, t);
+    tile_load<TB, BN, VEC>(rb[0], B, g.ldb, n0, g.n, kbeg, kend, t);
+    tile_load<TA, BM, VEC>(ra[1], A, g.lda, m0, g.m, kbeg + (nk > 1 ? 32 : 0), kend, t);
+    tile_load<TB, BN, VEC>(rb[1], B, g.ldb, n0, g.n, kbeg + (nk > 1 ? 32 : 0), kend, t);
+    tile_store<TA, BM, NS>(ra[0], As, m0, g.m, kbeg, kend, t);
+    tile_store<TB, BN, NS>(rb[0], Bs, n0, g.n, kbeg, kend, t);
+  }
+  // step kt (tile kt is in LDS, tile kt + 1 in flight in the other register set): request tile kt + 2 into the set that was just
+  // stored, multiply, then move tile kt + 1 to LDS.  The loop header sits right before an ISSUE point on purpose: the compiler's
+  // load counter is imprecise across the back edge, and the first wait behind it must not be the one that decides how far
+  // ahead the loads run (with the store first, it waited for the newest loads as well: prefetch distance one instead of two).
+  auto step = [&](auto set_c, int kt) {
+    constexpr int SET = decltype(set_c)::value;
+    {   // past the end: the last tile again -- unconditional, so the loop body stays straight-line code
+      const int kn = kbeg + min(kt + 2, nk - 1) * 32;
+      tile_load<TA, BM, VEC>(ra[SET], A, g.lda, m0, g.m, kn, kend, t);
+      tile_load<TB, BN, VEC>(rb[SET], B, g.ldb, n0, g.n, kn, kend, t);
     }
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[NS][MT], bfr[NS][2];
 #pragma unroll
       for (int pl = 0; pl < NS; ++pl) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[pl][i] = *(const bf16x8*)(As[buf] + pl * (BM * 32) + tile_off(wm + i * 32 + li, ks * 2 + lh));
+        for (int i = 0; i < MT; ++i) af[pl][i] = *(const bf16x8*)(As + pl * (BM * 32) + tile_off(wm + i * 32 + li, ks * 2 + lh));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bfr[pl][j] = *(const bf16x8*)(Bs[buf] + pl * (BN * 32) + tile_off(wn + j * 32 + li, ks * 2 + lh));
+        for (int j = 0; j < 2; ++j) bfr[pl][j] = *(const bf16x8*)(Bs + pl * (BN * 32) + tile_off(wn + j * 32 + li, ks * 2 + lh));
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -174,11 +180,15 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) {
-      tile_store<TA, BM, NS>(ra, As[buf ^ 1], t);
-      tile_store<TB, BN, NS>(rb, Bs[buf ^ 1], t);
-    }
     __syncthreads();
+    tile_store<TA, BM, NS>(ra[SET ^ 1], As, m0, g.m, kbeg + (kt + 1) * 32, kend, t);
+    tile_store<TB, BN, NS>(rb[SET ^ 1], Bs, n0, g.n, kbeg + (kt + 1) * 32, kend, t);
+  };
+  // (eight steps per trip -- no back edge for k <= 256 -- were tried: exact waits everywhere, but the hoisted addressing of eight
+  // steps spills; two steps per trip it is)
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
   }
 
   if (nsplit > 1) {
@@ -236,18 +246,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(gims_gemm g) {
   *cp = v;
 }
 
-template <bool TA, bool TB>
-static void gemm_launch(const gims_gemm& g, hipStream_t s) {
+template <bool TA, bool TB, int NS, bool VEC>
+static void gemm_launch_ns(const gims_gemm& g, hipStream_t s) {
   const int sp = g.splits > 1 ? g.splits : 1;
-  const dim3 g64(cdiv(g.n, 64), cdiv(g.m, 128), g.batch * sp), g128(cdiv(g.n, 128), cdiv(g.m, 128), g.batch * sp);
-  if (g.precision == GIMS_PREC_BF16X6) {
-    if (g.n <= 64) hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 64, 3>), g64, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 128, 3>), g128, dim3(256), 0, s, g);
+  if (g.n <= 64) {
+    hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 128, 64, NS, VEC>), dim3(cdiv(g.n, 64), cdiv(g.m, 128), g.batch * sp), dim3(256), 0, s, g);
+  } else if ((int64_t)cdiv(g.n, 128) * cdiv(g.m, 128) * g.batch * sp < 256 && g.m > 64) {
+    // too few 128 x 128 tiles for 256 CUs (the 4096-row linear layers): 64-row tiles
+    hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 64, 128, NS, VEC>), dim3(cdiv(g.n, 128), cdiv(g.m, 64), g.batch * sp), dim3(256), 0, s, g);
   } else {
-    if (g.n <= 64) hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 64, 2>), g64, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 128, 2>), g128, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_split_kernel<TA, TB, 128, 128, NS, VEC>), dim3(cdiv(g.n, 128), cdiv(g.m, 128), g.batch * sp), dim3(256), 0, s, g);
   }
   if (sp > 1) hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv((int64_t)g.m * g.n * g.batch, 256)), dim3(256), 0, s, g);
+}
+
+template <bool TA, bool TB>
+static void gemm_launch(const gims_gemm& g, hipStream_t s) {
+  const bool vec = (g.flags & 3) == 3;
+  if (g.precision == GIMS_PREC_BF16X6) {
+    if (vec) gemm_launch_ns<TA, TB, 3, true>(g, s);
+    else gemm_launch_ns<TA, TB, 3, false>(g, s);
+  } else {
+    if (vec) gemm_launch_ns<TA, TB, 2, true>(g, s);
+    else gemm_launch_ns<TA, TB, 2, false>(g, s);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm1d, train mode
