@@ -826,11 +826,9 @@ def train_loss(items, kept0, kept1, gt: torch.Tensor, alpha: float, pos_weight: 
     return out3, loss_vec[:K]
 
 
-def sinkhorn_score_gradients(items, alpha: float, iters: int, pos_weight: float, neg_weight: float, loss_state):
-    """d loss / d scores (list of [n, m] views with pitch m + 1) and d loss / d bin_score (0-dim tensor) for the loss of
-    ``train_loss`` (whose ``last`` state is passed in): a recorded streamed forward solve (gims_sinkhorn_history), the loss
-    gradient scattered into zeroed (n+1) x (m+1) buffers (gims_train_loss_grad), the reverse sweep through the unrolled
-    iterations (gims_sinkhorn_backward)."""
+def sinkhorn_history(items, alpha: float, iters: int):
+    """The streamed Sinkhorn solve with the potentials after every iteration recorded (gims_sinkhorn_history): returns the list
+    of history buffers; every item's ``uv`` holds the final potentials afterwards (what gims_train_loss reads)."""
     lib = load()
     dev = items[0]["scores"].device
     probs = make_ot_problems(items)
@@ -838,6 +836,20 @@ def sinkhorn_score_gradients(items, alpha: float, iters: int, pos_weight: float,
     hists = [torch.zeros(int(lib.gims_sinkhorn_history_floats(it["n"], it["m"], iters)), dtype=torch.float32, device=dev) for it in items]
     hp = (C.c_void_p * len(items))(*[h.data_ptr() for h in hists])
     _check(lib.gims_sinkhorn_history(probs, len(items), float(alpha), int(iters), hp, _p(work), work.numel(), _stream()), "gims_sinkhorn_history")
+    return hists
+
+
+def sinkhorn_score_gradients(items, alpha: float, iters: int, pos_weight: float, neg_weight: float, loss_state, hists=None):
+    """d loss / d scores (list of [n, m] views with pitch m + 1) and d loss / d bin_score (0-dim tensor) for the loss of
+    ``train_loss`` (whose ``last`` state is passed in): a recorded streamed forward solve (``hists`` from sinkhorn_history, made
+    here when absent), the loss gradient scattered into zeroed (n+1) x (m+1) buffers (gims_train_loss_grad), the reverse sweep
+    through the unrolled iterations (gims_sinkhorn_backward)."""
+    lib = load()
+    dev = items[0]["scores"].device
+    probs = make_ot_problems(items)
+    if hists is None:
+        hists = sinkhorn_history(items, alpha, iters)
+    hp = (C.c_void_p * len(items))(*[h.data_ptr() for h in hists])
     dzs = [torch.zeros((it["n"] + 1, it["m"] + 1), dtype=torch.float32, device=dev) for it in items]
     import numpy as np
     dz_tab = upload(np.asarray([d.data_ptr() for d in dzs], dtype=np.int64), dev)
@@ -882,6 +894,7 @@ def patch_extract(pyr: torch.Tensor, dev_levels: torch.Tensor, n_levels: int, kp
     bad = torch.empty(1, dtype=torch.int32, device=pyr.device)
     _check(load().gims_patch_extract(_p(pyr), _p(dev_levels), n_levels, _p(kp4), _p(kp_octave), n, _p(out), _p(bad), _stream()), "gims_patch_extract")
     return out, bad
+
 
 
 # ------------------------------------------------------------------------------------------------ training step

@@ -212,9 +212,9 @@ def forward(model, data):
                           mscores1=torch.empty(n1, dtype=torch.float32, device=dev), uv=torch.empty(n0 + n1 + 3, dtype=torch.float32, device=dev)))
     S.items = items
     S.alpha = float(P["bin_score"])
-    probs_ot = hip.make_ot_problems(items)
-    work = torch.empty(hip.sinkhorn_workspace_bytes(probs_ot), dtype=torch.uint8, device=dev)
-    hip.sinkhorn_match(probs_ot, S.alpha, cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
+    # ONE Sinkhorn solve serves both passes: the streamed kernels with the potentials after every iteration recorded (what the
+    # reverse sweep needs); the loss reads the final potentials it leaves in `uv`
+    S.hists = hip.sinkhorn_history(items, S.alpha, cfg['sinkhorn_iterations'])
     gt = data['matches'].to(device=dev, dtype=torch.int64).contiguous()
     out3, _ = hip.train_loss(items, [images[b]["kept"] for b in range(B)], [images[B + b]["kept"] for b in range(B)], gt, S.alpha,
                              cfg['pos_loss_weight'], cfg['neg_loss_weight'])
@@ -237,7 +237,7 @@ def backward(model, S, w_pos: float, w_neg: float):
         grads[name] = g.view(P[name].shape)
 
     # ---- loss -> scores (reverse sweep through the unrolled Sinkhorn iterations) -> matching descriptors
-    dscores, dalpha = hip.sinkhorn_score_gradients(S.items, S.alpha, cfg['sinkhorn_iterations'], w_pos, w_neg, S.loss_state)
+    dscores, dalpha = hip.sinkhorn_score_gradients(S.items, S.alpha, cfg['sinkhorn_iterations'], w_pos, w_neg, S.loss_state, S.hists)
     put("bin_score", dalpha)
     dm = torch.empty_like(S.mdesc)
     inv = 1.0 / math.sqrt(D)
