@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
   const int nsplit = g.splits > 1 ? g.splits : 1;
   const int z = blockIdx.z / nsplit, split = blockIdx.z - z * nsplit;
   // split-K: this workgroup covers k in [kbeg, kend) and leaves its raw partial sums in the workspace (fixed-order reduction
-  // and the epilogue follow in splitk_reduce_kernel)
+  // and the epilogue follow in splitk_reduce_kernel -- folding inside this kernel by the last split to arrive was tried: the
+  // partial sums then need device-scope stores to cross the XCDs' L2s, which made the weight-gradient GEMMs 3x slower)
   const int kchunk = ((g.k + nsplit - 1) / nsplit + 31) & ~31;
   const int kbeg = split * kchunk, kend = min(g.k, kbeg + kchunk);
   const int wm = BN == 64 ? wave * 32 : (wave >> 1) * (32 * MT), wn = BN == 64 ? 0 : (wave & 1) * 64;
