@@ -310,14 +310,21 @@ __global__ __launch_bounds__(256) void ch_input_block_kernel(const float* __rest
 // gates are computed from the LDS copy, and  y = max((x s + b) a_w a_h, tau)  leaves as f32 and / or split-bf16 pixel rows:
 // 8 bytes of HBM traffic per element instead of 12 (plain FRN layers) or 20 (FRN + CoordAtt layers: statistics pass, two
 // pooling sweeps, apply pass).  models.py:57-85 (FRN), 139-153 (CoordAtt), 107-108 (TLU).
+// position of channel c of pixel p inside the LDS image [NPIX][C] of frn_block_body
+__device__ __forceinline__ int frn_slot(int p, int c, int C) { return p * C + ((((c >> 2) ^ (p & 7)) << 2) | (c & 3)); }
+
 struct ChGateW { const float* w1; const float* b1; const float* wh; const float* bh; const float* ww; const float* bw; };   // null w1: no CoordAtt
 
 // body shared by ch_frn_block_kernel and ch_conv_block_kernel: the raw convolution output of ONE patch is in LDS (xb [NPIX][C],
 // followed by the scratch arrays); pbase = index of the patch's first pixel row in the outputs
 template <int C, int HW, int NT>
 __device__ __forceinline__ void frn_block_body(float* lds, const float* __restrict__ fw, const float* __restrict__ fb, float eps, const ChGateW& g,
-                                               const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp, int64_t ldsp, int64_t pbase) {
+                                               const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp, int64_t ldsp, int64_t pbase,
+                                               unsigned long long* prof = nullptr) {
   constexpr int NPIX = HW * HW, QPP = C / 4, NQ = NPIX * QPP / NT, GRP = NT / C;
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (prof && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) prof[k] = __builtin_readcyclecounter(); };
+  // xb is SWIZZLED: channel quad q of pixel p sits at quad position q ^ (p & 7) (frn_slot) -- the accumulator dump of the
+  // convolution writes one pixel per lane, 128 / 256 / 512 bytes apart: unswizzled, all lanes of a store hit the same four banks
   float* xb = lds;                          // [NPIX][C]
   float* red = xb + NPIX * C;               // [GRP][C]
   float* sc = red + GRP * C;                // [C]   FRN scale of this patch
@@ -327,9 +334,14 @@ __device__ __forceinline__ void frn_block_body(float* lds, const float* __restri
   const int t = threadIdx.x;
   {   // FRN statistic: mean of x^2 over the pixels, per channel
     const int c = t % C, gq = t / C;
-    float s = 0.f;
-    for (int pix = gq; pix < NPIX; pix += GRP) { const float v = xb[pix * C + c]; s = fmaf(v, v, s); }
-    red[gq * C + c] = s;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    static_assert((NPIX / GRP) % 4 == 0, "four partial sums per thread");
+#pragma unroll 2
+    for (int pix = gq; pix < NPIX; pix += 4 * GRP) {          // four independent LDS reads in flight (one chain of 64 reads ran at LDS latency)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const float v = xb[frn_slot(pix + u * GRP, c, C)]; s4[u] = fmaf(v, v, s4[u]); }
+    }
+    red[gq * C + c] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   }
   __syncthreads();
   if (t < C) {
@@ -339,21 +351,37 @@ __device__ __forceinline__ void frn_block_body(float* lds, const float* __restri
     sc[t] = fw[t] * rsqrtf(s / (float)NPIX + eps);
   }
   __syncthreads();
+  stamp(4);
   const bool coord = g.w1 != nullptr;
   if (coord) {
-    for (int i = t; i < 2 * HW * C; i += NT) {        // pools of the FRN output = FRN affine map of the raw pools
-      const bool over_x = i < HW * C;
-      const int j = over_x ? i : i - HW * C, line = j / C, ch = j % C;
-      float s = 0.f;
-      for (int k = 0; k < HW; ++k) s += xb[(over_x ? line * HW + k : k * HW + line) * C + ch];
-      (over_x ? ph : pw)[j] = fmaf(s / (float)HW, sc[ch], fb[ch]);
+    // pools of the FRN output = FRN affine map of the raw pools; one (line, channel quad) per thread: HW float4 reads
+    for (int i = t; i < 2 * HW * QPP; i += NT) {
+      const bool over_x = i < HW * QPP;
+      const int j = over_x ? i : i - HW * QPP, line = j / QPP, q = j % QPP;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+      for (int k = 0; k < HW; k += 2) {
+        const int p0 = over_x ? line * HW + k : k * HW + line, p1 = over_x ? p0 + 1 : p0 + HW;
+        const float4 v0 = *(const float4*)(xb + p0 * C + ((q ^ (p0 & 7)) << 2)), v1 = *(const float4*)(xb + p1 * C + ((q ^ (p1 & 7)) << 2));
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      }
+      const float4 s4 = *(const float4*)(sc + 4 * q), b4 = *(const float4*)(fb + 4 * q);
+      *(float4*)((over_x ? ph : pw) + line * C + 4 * q) =
+          make_float4(fmaf((a0.x + a1.x) / (float)HW, s4.x, b4.x), fmaf((a0.y + a1.y) / (float)HW, s4.y, b4.y),
+                      fmaf((a0.z + a1.z) / (float)HW, s4.z, b4.z), fmaf((a0.w + a1.w) / (float)HW, s4.w, b4.w));
     }
     __syncthreads();
     for (int i = t; i < 2 * HW * 8; i += NT) {
       const int r = i >> 3, m = i & 7;
       const float* src = r < HW ? ph + r * C : pw + (r - HW) * C;
-      float acc = g.b1[m];
-      for (int k = 0; k < C; ++k) acc = fmaf(src[k], g.w1[m * C + k], acc);
+      float a4[4] = {g.b1[m], 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int k = 0; k < C; k += 4) {
+        const float4 wv = *(const float4*)(g.w1 + m * C + k), xv = *(const float4*)(src + k);
+        a4[0] = fmaf(xv.x, wv.x, a4[0]); a4[1] = fmaf(xv.y, wv.y, a4[1]); a4[2] = fmaf(xv.z, wv.z, a4[2]); a4[3] = fmaf(xv.w, wv.w, a4[3]);
+      }
+      const float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
       mid[i] = acc * (fminf(fmaxf(acc + 3.f, 0.f), 6.f) / 6.f);
     }
     __syncthreads();
@@ -362,17 +390,19 @@ __device__ __forceinline__ void frn_block_body(float* lds, const float* __restri
       const int j = is_h ? i : i - HW * C, r = j / C, ch = j % C;
       const float* wt = (is_h ? g.wh : g.ww) + ch * 8;
       const float* mr = mid + (is_h ? r : HW + r) * 8;
+      const float4 w0 = *(const float4*)wt, w1v = *(const float4*)(wt + 4), m0 = *(const float4*)mr, m1 = *(const float4*)(mr + 4);
       float acc = (is_h ? g.bh : g.bw)[ch];
-#pragma unroll
-      for (int m = 0; m < 8; ++m) acc = fmaf(mr[m], wt[m], acc);
+      acc = fmaf(m0.x, w0.x, acc); acc = fmaf(m0.y, w0.y, acc); acc = fmaf(m0.z, w0.z, acc); acc = fmaf(m0.w, w0.w, acc);      // same order as the scalar loop
+      acc = fmaf(m1.x, w1v.x, acc); acc = fmaf(m1.y, w1v.y, acc); acc = fmaf(m1.z, w1v.z, acc); acc = fmaf(m1.w, w1v.w, acc);
       (is_h ? ph : pw)[j] = 1.f / (1.f + __expf(-acc));
     }
     __syncthreads();
   }
+  stamp(5);
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
     const int i = t + NT * j, pix = i / QPP, ch = 4 * (i % QPP), yy = pix / HW, xx = pix % HW;
-    const float4 v = *(const float4*)(xb + i * 4);
+    const float4 v = *(const float4*)(xb + frn_slot(pix, ch, C));
     const float4 s4 = *(const float4*)(sc + ch), b4 = *(const float4*)(fb + ch);
     float r[4] = {fmaf(v.x, s4.x, b4.x), fmaf(v.y, s4.y, b4.y), fmaf(v.z, s4.z, b4.z), fmaf(v.w, s4.w, b4.w)};
     if (coord) {
@@ -384,6 +414,7 @@ __device__ __forceinline__ void frn_block_body(float* lds, const float* __restri
     if (y) *(float4*)(y + (pbase * C) + (int64_t)i * 4) = make_float4(r[0], r[1], r[2], r[3]);
     if (ysp) store_split4(ysp + (pbase + pix) * ldsp + spl_col(ch), r);
   }
+  stamp(6);
 }
 
 template <int C, int HW, int NT>
@@ -400,7 +431,7 @@ __global__ __launch_bounds__(NT) void ch_frn_block_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < NQ; ++j) v[j] = *(const float4*)(xp + (int64_t)(t + NT * j) * 4);
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) *(float4*)(lds + (t + NT * j) * 4) = v[j];
+    for (int j = 0; j < NQ; ++j) { const int i = t + NT * j; *(float4*)(lds + frn_slot(i / QPP, 4 * (i % QPP), C)) = v[j]; }
   }
   __syncthreads();
   frn_block_body<C, HW, NT>(lds, fw, fb, eps, g, tau, y, ysp, ldsp, pbase);
@@ -436,7 +467,7 @@ struct ConvGeom {
   // hi chunk of channels [16 ks + 8 lh, +8) inside the pixel record; the lo chunk is HB further
   __device__ static __forceinline__ int chunk(int ks, int lh) { return (ks / (HB / 2)) * (2 * HB) + 2 * (ks % (HB / 2)) + lh; }
 };
-struct ChFirst { const float* fw0; const float* fb0; const float* tau0; float eps0; };   // FRN(3) + TLU(3) in front of the first convolution
+struct ChFirst { const float* fw0; const float* fb0; const float* tau0; float eps0; unsigned long long* prof; };   // prof: GIMS_CH_PROF=1 phase stamps, else null   // FRN(3) + TLU(3) in front of the first convolution
 
 // FIRST (layer 1, models.py:316-323): xin is the raw f32 patch [32*32][3]; FRN(3) + TLU(3) run here and the result is written
 // into the LDS image as 16-channel split-bf16 pixel records (channels 3-15 zero) -- no operand rows through HBM at all.
@@ -454,6 +485,8 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int64_t patch = blockIdx.x;
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (first.prof && blockIdx.x == gridDim.x / 2 && t == 0) first.prof[k] = __builtin_readcyclecounter(); };
+  stamp(0);
 
   // ---- input patch -> LDS (swizzled chunks) + ONE all-zero pixel record that every out-of-image tap reads (no border in LDS:
   // the 16x16x64 and 8x8x128 layers then fit two / three workgroups per CU)
@@ -501,16 +534,18 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
     if (t < CPP) *(uint4*)(img + ZQ * PXB + t * 16) = make_uint4(0u, 0u, 0u, 0u);
     const uint16_t* src = xin + patch * (HIN * HIN) * ldx;
     constexpr int TOT = HIN * HIN * CPP;
-    static_assert(TOT % (4 * NT) == 0, "whole trips of four loads per thread");
-    for (int i0 = t; i0 < TOT; i0 += 4 * NT) {                   // four independent 16-byte loads in flight per thread
-      uint4 v[4];
+    constexpr int LPT = TOT / NT >= 8 ? 8 : 4;                     // independent 16-byte loads in flight per thread
+    static_assert(TOT % (LPT * NT) == 0, "whole trips of LPT loads per thread");
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+    for (int i0 = t; i0 < TOT; i0 += LPT * NT) {                  // (four in flight left 4 dependent HBM round trips on the 128 KB layers)
+      uint4 v[LPT];
+#pragma unroll
+      for (int u = 0; u < LPT; ++u) {
         const int i = i0 + u * NT;
         v[u] = *(const uint4*)(src + (int64_t)(i / CPP) * ldx + (i % CPP) * 8);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LPT; ++u) {
         const int i = i0 + u * NT;
         const int q = i / CPP, ch = i % CPP;
         *(uint4*)(img + q * PXB + ((ch ^ G::swz(q)) * 16)) = v[u];
@@ -518,6 +553,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
     }
   }
   __syncthreads();
+  stamp(1);
 
   // ---- implicit GEMM: this wave's (m-block, n-block) tiles
   const int nb0 = wave % NB, mb0 = (wave / NB) * MBW;            // waves with the same n-block walk consecutive pixel blocks
@@ -589,6 +625,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
     }
   }
   __syncthreads();                                                // every wave is done with the input image
+  stamp(2);
 
   // ---- raw convolution output (+ bias) -> LDS [pixel][COUT], then the FRN block
 #pragma unroll
@@ -599,12 +636,13 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const float4 b4 = *(const float4*)(bias + c0 + 8 * gq);
-        *(float4*)(lds + pix * COUT + c0 + 8 * gq) =
+        *(float4*)(lds + frn_slot(pix, c0 + 8 * gq, COUT)) =
             make_float4(acc[m][n][4 * gq] + b4.x, acc[m][n][4 * gq + 1] + b4.y, acc[m][n][4 * gq + 2] + b4.z, acc[m][n][4 * gq + 3] + b4.w);
       }
     }
   __syncthreads();
-  frn_block_body<COUT, HOUT, NT>(lds, fw, fb, eps, g, tau, y, ysp, ldsp, patch * G::NPIX);
+  stamp(3);
+  frn_block_body<COUT, HOUT, NT>(lds, fw, fb, eps, g, tau, y, ysp, ldsp, patch * G::NPIX, first.prof);
 }
 
 // ---------------------------------------------------------------------------------------------- fused SandGlass block
@@ -633,6 +671,7 @@ struct ChSandglassW {          // all f32, BatchNorm folded
   const float* p1b;   // [C]
   const float* dw1;   // [9][C]
   const float* dw1b;  // [C]
+  unsigned long long* prof;   // GIMS_CH_PROF=1: cycle stamps of one workgroup, else null
 };
 
 template <int C, int HW, int NT>      // HW = H = W, NT threads
@@ -649,11 +688,14 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   const int t = threadIdx.x;
   const int64_t pbase = (int64_t)blockIdx.x * NPIX;
   const float* xp = x + pbase * C;
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (wts.prof && blockIdx.x == gridDim.x / 2 && t == 0) wts.prof[k] = __builtin_readcyclecounter(); };
+  stamp(0);
   for (int i = t; i < 9 * C; i += NT) { l_dw0[i] = wts.dw0[i]; l_dw1[i] = wts.dw1[i]; }
   for (int i = t; i < 16 * C; i += NT) { l_p0[i] = wts.p0[i]; l_p1[i] = wts.p1[i]; }
   if (t < C) { l_dw0b[t] = wts.dw0b[t]; l_dw1b[t] = wts.dw1b[t]; l_p1b[t] = wts.p1b[t]; }
   if (t < 16) l_p0b[t] = wts.p0b[t];
   __syncthreads();
+  stamp(1);
   auto slot = [&](int pix, int cq) { return pix * C + 4 * (cq ^ (pix & MASK)); };
 
   // ---- 0: the patch into LDS and, for the final residual, this thread's own quads into registers: NQ independent, fully
@@ -665,6 +707,7 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < NQ; ++j) { const int i = t + NT * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = xq[j]; }
   __syncthreads();
+  stamp(2);
   // ---- A: depthwise 3x3 + BN + ReLU6 from the LDS copy into registers, then over the copy.  The loop is unrolled (register
   // arrays), but the thread index is re-derived from an opaque copy every iteration: as loop invariants the compiler hoisted
   // all NQ x 9 addresses and weights and spilled 900 registers.
@@ -697,21 +740,35 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < NQ; ++j) { const int i = t + NT * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = yq[j]; }
   __syncthreads();
-  // ---- A2: pools (mean over x for every row, mean over y for every column)
-  for (int i = t; i < 2 * HW * C; i += NT) {
-    const bool over_x = i < HW * C;
-    const int j = over_x ? i : i - HW * C, line = j / C, ch = j % C, cq = ch >> 2, e = ch & 3;
-    float s = 0.f;
-    for (int k = 0; k < HW; ++k) { const int pix = over_x ? line * HW + k : k * HW + line; s += ybuf[slot(pix, cq) + e]; }
-    (over_x ? ph : pw)[j] = s / (float)HW;
+  stamp(3);
+  // ---- A2: pools (mean over x for every row, mean over y for every column): one (line, channel quad) per thread, HW float4 reads
+  for (int i = t; i < 2 * HW * QPP; i += NT) {
+    const bool over_x = i < HW * QPP;
+    const int j = over_x ? i : i - HW * QPP, line = j / QPP, q = j % QPP;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+    for (int k = 0; k < HW; k += 2) {
+      const int p0 = over_x ? line * HW + k : k * HW + line, p1 = over_x ? p0 + 1 : p0 + HW;
+      const float4 v0 = *(const float4*)(ybuf + slot(p0, q)), v1 = *(const float4*)(ybuf + slot(p1, q));
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    }
+    *(float4*)((over_x ? ph : pw) + line * C + 4 * q) =
+        make_float4((a0.x + a1.x) / (float)HW, (a0.y + a1.y) / (float)HW, (a0.z + a1.z) / (float)HW, (a0.w + a1.w) / (float)HW);
   }
   __syncthreads();
+  stamp(4);
   // ---- B: gate MLP
   for (int i = t; i < 2 * HW * 8; i += NT) {
     const int r = i >> 3, m = i & 7;
     const float* src = r < HW ? ph + r * C : pw + (r - HW) * C;
-    float acc = wts.b1[m];
-    for (int k = 0; k < C; ++k) acc = fmaf(src[k], wts.w1[m * C + k], acc);
+    float a4[4] = {wts.b1[m], 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < C; k += 4) {
+      const float4 wv = *(const float4*)(wts.w1 + m * C + k), xv = *(const float4*)(src + k);
+      a4[0] = fmaf(xv.x, wv.x, a4[0]); a4[1] = fmaf(xv.y, wv.y, a4[1]); a4[2] = fmaf(xv.z, wv.z, a4[2]); a4[3] = fmaf(xv.w, wv.w, a4[3]);
+    }
+    const float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     mid[i] = acc * (fminf(fmaxf(acc + 3.f, 0.f), 6.f) / 6.f);
   }
   __syncthreads();
@@ -726,6 +783,7 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
     (is_h ? ph : pw)[j] = 1.f / (1.f + __expf(-acc));
   }
   __syncthreads();
+  stamp(5);
   // ---- C: per pixel  z = ReLU6(W1 (W0 (y a_w a_h) + b0) + b1), in place
   for (int pix = t; pix < NPIX; pix += NT) {
     const int yy = pix / HW, xx = pix % HW;
@@ -765,6 +823,7 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
     }
   }
   __syncthreads();
+  stamp(6);
   // ---- D: out = 2 x + dw3x3(z) + BN, as split-bf16 pixel rows (x from the registers of step 0)
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) kw[tap] = *(const float4*)(l_dw1 + tap * C + 4 * (t % QPP));
@@ -786,6 +845,7 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
     const float r[4] = {fmaf(xq[j].x, 2.f, acc.x), fmaf(xq[j].y, 2.f, acc.y), fmaf(xq[j].z, 2.f, acc.z), fmaf(xq[j].w, 2.f, acc.w)};
     store_split4(out + (pbase + pix) * ldo + spl_col(ch), r);
   }
+  stamp(7);
 }
 
 // one wave per row of `c` (<= 256) values: y = x / sqrt(sum x^2 + eps)
@@ -937,7 +997,7 @@ extern "C" int gims_ch_frn_block(const float* x, int64_t patches, int32_t hw, in
 
 template <int CIN, int COUT, int HIN, int STRIDE, bool FIRST = false>
 static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, const uint16_t* w, const float* bias, const float* fw, const float* fb, float eps,
-                             gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st, gims::ChFirst first = {nullptr, nullptr, nullptr, 0.f}) {
+                             gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st, gims::ChFirst first = {nullptr, nullptr, nullptr, 0.f, nullptr}) {
   using namespace gims;
   using Geo = ConvGeom<CIN, COUT, HIN, STRIDE>;
   static bool attr = false;
@@ -945,9 +1005,22 @@ static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, co
     GIMS_HIP(hipFuncSetAttribute((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES));
     attr = true;
   }
+  static const bool prof_on = getenv("GIMS_CH_PROF") != nullptr;      // diagnostics: cycle stamps of one workgroup per launch (synchronous)
+  static unsigned long long* dprof = nullptr;
+  if (prof_on) {
+    if (!dprof) GIMS_HIP(hipMalloc(&dprof, 8 * sizeof(unsigned long long)));
+    first.prof = dprof;
+  }
   hipLaunchKernelGGL((ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>), dim3((unsigned)patches), dim3(512), Geo::LDS_BYTES, st, x, ldx, w, bias, fw, fb, eps, G,
                      tau, y, ysp, ldsp, first);
   GIMS_LAUNCH_CHECK();
+  if (prof_on) {
+    unsigned long long h[8];
+    GIMS_HIP(hipStreamSynchronize(st));
+    GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "ch_conv_block<%d,%d,%d,%d,%d> x %lld: load %llu  mfma %llu  acc->lds %llu  frn-stat %llu  pools+gates %llu  apply+store %llu  (cycles of one workgroup)\n",
+            CIN, COUT, HIN, STRIDE, (int)FIRST, (long long)patches, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5]);
+  }
   return GIMS_OK;
 }
 
@@ -964,7 +1037,7 @@ extern "C" int gims_ch_conv_block_first(const float* patches, int64_t n, const f
     G = ChGateW{gate_w[0], gate_w[1], gate_w[2], gate_w[3], gate_w[4], gate_w[5]};
   }
   return conv_block_launch<16, 32, 32, 1, true>((const uint16_t*)patches, 0, n, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split,
-                                                 (hipStream_t)stream, ChFirst{frn0_weight, frn0_bias, tau0, eps0});
+                                                 (hipStream_t)stream, ChFirst{frn0_weight, frn0_bias, tau0, eps0, nullptr});
 }
 
 extern "C" int gims_ch_conv_block(const uint16_t* x_split, int64_t ldx, int64_t patches, int32_t hin, int32_t cin, int32_t cout, int32_t stride,
@@ -1008,9 +1081,23 @@ extern "C" int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, in
     GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<64, 16, SG_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
+  static const bool prof_on = getenv("GIMS_CH_PROF") != nullptr;
+  static unsigned long long* dprof = nullptr;
+  W.prof = nullptr;
+  if (prof_on) {
+    if (!dprof) GIMS_HIP(hipMalloc(&dprof, 8 * sizeof(unsigned long long)));
+    W.prof = dprof;
+  }
   if (c == 32) hipLaunchKernelGGL((ch_sandglass_kernel<32, 32, SG_NT>), dim3((unsigned)patches), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split);
   else hipLaunchKernelGGL((ch_sandglass_kernel<64, 16, SG_NT>), dim3((unsigned)patches), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split);
   GIMS_LAUNCH_CHECK();
+  if (prof_on) {
+    unsigned long long h[8];
+    GIMS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "ch_sandglass<%d,%d> x %lld: weights->lds %llu  patch load %llu  A dw3x3 %llu  A2 pools %llu  B gates %llu  C pointwise %llu  D dw3x3+store %llu  (cycles of one workgroup)\n",
+            c, hw, (long long)patches, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6]);
+  }
   return GIMS_OK;
 }
 

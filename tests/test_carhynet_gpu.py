@@ -59,7 +59,7 @@ def test_fused_blocks_equal_layer_by_layer():
         m.fused_conv = False                        # same convolution GEMMs on both sides: this test isolates the two f32 blocks
         d, raw = m(torch.from_numpy(patches).permute(0, 3, 1, 2).cuda(), mode="train")
         outs.append((d.cpu().numpy(), raw.cpu().numpy()))
-    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=5e-5, rtol=1e-5)       # same f32 arithmetic, different summation orders
+    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=1e-4, rtol=1e-5)       # same f32 arithmetic, different summation orders (raw values up to ~3)
     np.testing.assert_allclose(outs[0][0], outs[1][0], atol=5e-6, rtol=0)
 
 
