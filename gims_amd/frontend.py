@@ -64,6 +64,30 @@ def filter_max_num(kps, max_num):
     return kps
 
 
+class PaddedKeyPoint:
+    """What ``cv2.KeyPoint(x, y, 1)`` carries (utils/common.py:683): size 1, angle -1, response 0, octave 0, class_id -1."""
+    __slots__ = ("pt", "size", "angle", "response", "octave", "class_id")
+
+    def __init__(self, x, y):
+        self.pt, self.size, self.angle, self.response, self.octave, self.class_id = (float(x), float(y)), 1.0, -1.0, 0.0, 0, -1
+
+
+def pad_training_keypoints(kps, max_keypoints, img_shape):
+    """The ``is_train`` branch of sift_forward (utils/common.py:866-880, ``copy=False``): an image with fewer than max_keypoints
+    detections gets random extra locations -- x and y drawn with the reference's own sequence of ``np.random`` calls (a
+    (n, 2) block scaled by the width, then the y column redrawn and scaled by the height), so a seeded run places them where
+    the reference does -- as size-1 keypoints, so that every image of a training batch carries exactly max_keypoints
+    (train.py:107-110 stacks them).  The reference passes the locations through ``cv2.SIFT.compute`` (682-685), which may
+    drop points OpenCV considers too close to the border: NOT restated (OpenCV is not available here; parity unpinned)."""
+    kps = list(kps)
+    if max_keypoints <= 0 or len(kps) >= max_keypoints:
+        return kps
+    to_add = max_keypoints - len(kps)
+    coordinates = np.random.random((to_add, 2)) * img_shape[1]
+    coordinates[:, 1] = np.random.random(to_add) * img_shape[0]
+    return kps + [PaddedKeyPoint(x, y) for x, y in coordinates]
+
+
 def _default_detector():
     try:
         import cv2
@@ -75,7 +99,7 @@ def _default_detector():
 
 
 def sift_forward_device(data, device, detector=None):
-    """``utils.common.sift_forward`` (common.py:837-893, inference branch) with patches and descriptors on the device.
+    """``utils.common.sift_forward`` (common.py:837-893; ``data['is_train']``: pad_training_keypoints) with patches and descriptors on the device.
     data: {'image': uint8 [B, H, W, 3], 'max_keypoints': int, 'carhynet': gims_amd.carhynet.CARHyNet (or any object with
     ``_forward_nhwc`` / ``compute_des_batches``)}.  Returns {'keypoints', 'scores', 'descriptors'}: lists with one tensor per
     image -- (n, 2), (n,), (256, n) with the 128-d descriptor duplicated (common.py:890-892)."""
@@ -85,6 +109,8 @@ def sift_forward_device(data, device, detector=None):
     for img in data["image"]:
         img = np.asarray(img.cpu() if torch.is_tensor(img) else img)
         k = filter_max_num(list(det(img)), data.get("max_keypoints", -1))
+        if data.get("is_train", False):
+            k = pad_training_keypoints(k, data.get("max_keypoints", -1), img.shape)
         kp4, _, resp = keypoint_arrays(k)
         patches = extract_patches(img, k, device)
         if hasattr(net, "_forward_nhwc"):                     # gims_amd.carhynet.CARHyNet: stays on the device

@@ -123,3 +123,21 @@ def test_pose_auc_and_summarize_equal_reference():
     s = evalh.summarize(rec)
     assert s["n_pairs"] == 2 and s["precision"] == 75.0 and s["recall"] == 50.0
     np.testing.assert_allclose(s["auc_ransac"], [100 * a for a in evalh.pose_auc([1.0, 3.0])], atol=1e-12)
+
+
+def test_training_front_end_pads_to_max_keypoints():
+    """sift_forward's is_train branch (utils/common.py:866-880): random extra size-1 keypoints up to max_keypoints, drawn with the
+    reference's sequence of np.random calls."""
+    from gims_amd import frontend
+    kps = [frontend.PaddedKeyPoint(3.0, 4.0)]
+    np.random.seed(5)
+    out = frontend.pad_training_keypoints(kps, 6, (480, 640, 3))
+    np.random.seed(5)
+    c = np.random.random((5, 2)) * 640
+    c[:, 1] = np.random.random(5) * 480
+    assert len(out) == 6 and out[0] is kps[0]
+    assert [k.pt for k in out[1:]] == [(float(x), float(y)) for x, y in c]
+    assert all(k.size == 1.0 and k.octave == 0 and k.response == 0.0 for k in out[1:])
+    assert frontend.pad_training_keypoints(kps * 7, 6, (480, 640, 3)) == kps * 7          # nothing to add
+    kp4, octv, resp = frontend.keypoint_arrays(out)
+    assert kp4.shape == (6, 4) and octv.tolist() == [0] * 6
