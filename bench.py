@@ -181,7 +181,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline):
     # homographies and the corner-error AUC run on the device (gims_eval_pairs) and the per-pair records are all-gathered
     # exactly like the reference's eval loop would (eval_homography.py:186-259)
     eval_rec = shard.gather_stats(shard.eval_stats(my_pairs, host_t["datas"], outs, [np.eye(3, dtype=np.float32)] * len(my_pairs), dev,
-                                                   ransac_iters=2000, seed=1), counts=rank_counts)
+                                                   ransac_iters=3000, seed=1), counts=rank_counts)
     eval_summary = shard.eval_summary(eval_rec)
     if rank != 0:
         return None

@@ -21,7 +21,7 @@ RECORD_FIELDS = hip.EVAL_FIELDS          # columns of the per-pair record (float
 
 
 def evaluate_pairs(datas: Sequence[dict], outs: Sequence[dict], h_gts: Sequence[np.ndarray], dist_thresh: float = 3, n_iters: int = 3,
-                   ransac_thresh: float = 3.0, ransac_iters: int = 2000, seed: int = 0) -> dict:
+                   ransac_thresh: float = 3.0, ransac_iters: int = 3000, seed: int = 0) -> dict:
     """datas: the dicts ``match_pairs`` / ``forward`` mutated (kept keypoints, image shapes); outs: the per-pair results;
     h_gts: 3x3 ground-truth homographies mapping image 0 to image 1.  Returns device tensors:
     records [P, 16] float32 (RECORD_FIELDS in the first columns), gt0 / inlier (lists of per-pair tensors),

@@ -658,7 +658,7 @@ EVAL_FIELDS = ("n_valid", "n_gt", "n_correct", "n_fn", "precision", "recall", "n
                "ransac_ok")
 
 
-def eval_pairs(items, dist_thresh=3.0, n_iters=3, ransac_thresh=3.0, ransac_iters=2000, seed=0, work=None):
+def eval_pairs(items, dist_thresh=3.0, n_iters=3, ransac_thresh=3.0, ransac_iters=3000, seed=0, work=None):
     """items: list of dicts with device tensors kpts0 [n0,2] f32, kpts1 [n1,2] f32, matches0 [n0] int64, mscores0 [n0] f32,
     h_gt (3x3 array-like), height, width, and outputs gt0 [n0] int32, inlier [n0] uint8, record [16] f32,
     homographies [18] f32.  One batched asynchronous call; see include/gims_hip.h."""

@@ -15,7 +15,7 @@ Only ``tests/`` may import it.  Pinning:
     installed here (opencv-python, requirements): ``cv2.getPerspectiveTransform`` (restated as the exact solution of the
     4-point system, which is what it documents) and ``cv2.findHomography(..., cv2.RANSAC)`` (OpenCV's sampler and
     refinement are not reproducible from outside; ``ransac_homography`` below is this build's own, fully specified
-    RANSAC: same model, same default 3 px reprojection threshold and 2000 iterations, deterministic sampler).
+    RANSAC: same model, same default 3 px reprojection threshold and 3000 hypotheses = the maxIters the reference passes, eval_homography.py:222; deterministic sampler).
 """
 from __future__ import annotations
 
@@ -132,7 +132,7 @@ def lsq_homography(p0: np.ndarray, p1: np.ndarray) -> np.ndarray:
     return np.append(h, 1.0).reshape(3, 3)
 
 
-def ransac_homography(p0: np.ndarray, p1: np.ndarray, seed: int, iters: int = 2000, thresh: float = 3.0):
+def ransac_homography(p0: np.ndarray, p1: np.ndarray, seed: int, iters: int = 3000, thresh: float = 3.0):
     """This build's RANSAC (see the header): `iters` 4-point hypotheses from `ransac_sample`, score = number of points
     with forward reprojection error <= thresh, best = most inliers (first such hypothesis), then ONE least-squares refit
     on the inliers of the best hypothesis and a final inlier mask under the refit model.  Returns (H, mask) or
