@@ -55,7 +55,12 @@ def test_train_step_vs_reference_golden(name, precision):
         for b in range(int(g["meta"][5])):
             assert data[f"kept_kpts{s}_indices"][b] == g[f"kept{s}_{b}"].tolist()
     grads = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
-    worst, where, p95 = check_step_gradients(g, grads, rtol=BARS[precision][0], rtol_p95=BARS[precision][1])
+    # one ReLU of a near-zero pre-activation falling the other way moves a bias-like gradient by ~1 / (positions per call of the
+    # module): with few kept keypoints (the sparse fixture keeps ~260 per image, the batch-of-two 2 x 64) the worst-tensor bar
+    # scales with that; the p95 bar does not move
+    positions = min(int(g["meta"][5]) * len(g[f"kept{s}_0"]) for s in "01")
+    worst_bar = max(BARS[precision][0], 10.0 / positions)
+    worst, where, p95 = check_step_gradients(g, grads, rtol=worst_bar, rtol_p95=BARS[precision][1])
     print(name, precision, "loss", got, "gradients: worst", worst, where, "p95", p95)
     bufs = dict(m.named_buffers())
     for k in g:
