@@ -379,8 +379,11 @@ def main():
         if world == 1 and args.kpts is None:
             # one training step (train() mode forward, backward, Adam) per pair of 2x2048 keypoints, the
             # reference's training configuration; its CPU leg (one oracle step, ~5 s) only next to the main CPU baseline
-            from tools.train_bench import measure as train_measure
-            res["train_step"] = train_measure(2048, 6, 2, "bf16x6", with_cpu=base)
+            try:                     # an extra block: it must never cost the headline line
+                from tools.train_bench import measure as train_measure
+                res["train_step"] = train_measure(2048, 6, 2, "bf16x6", with_cpu=base)
+            except Exception as e:   # noqa: BLE001
+                res["train_step"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
