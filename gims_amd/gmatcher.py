@@ -48,6 +48,12 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool):
         mod.register_parameter(parts[-1], nn.Parameter(tensor))
 
 
+def _stack(ts):
+    """torch.stack for the reference-shaped outputs; a single pair (what eval_homography.py passes) gets a leading-axis VIEW instead
+    of a copy kernel per output (the buffers behind it belong to this call alone)."""
+    return ts[0][None] if len(ts) == 1 else torch.stack(ts)
+
+
 class PairResults(list):
     """List of per-pair result dicts; ``.flat`` additionally exposes the batch-concatenated match tensors (what the
     per-pair entries are views of) so statistics can be reduced without touching each pair separately."""
@@ -722,27 +728,45 @@ class GMatcher(nn.Module):
         images = self._ingest([(data['keypoints' + side][b], data['descriptors' + side][b], data['scores' + side][b],
                                 data['image' + side].shape) for b in range(B) for side in ("0", "1")])
         items, pairs, mdesc = self._run(images, radius, percentile, min_size)
+        # what the host needs back -- the kept-index lists the reference returns as Python lists, and the Sinkhorn status words --
+        # travels in asynchronous copies into one pinned buffer behind ONE stream synchronisation (three blocking read-backs cost
+        # ~0.1 ms of a 5 ms single-pair call)
+        n_int = sum(g["n_kept"] for g in images)
+        pin = self.__dict__.get("_out_pin")
+        if pin is None or pin.numel() < n_int + len(items):
+            pin = self.__dict__["_out_pin"] = torch.empty(max(1 << 16, 2 * (n_int + len(items))), dtype=torch.int32, pin_memory=True)
+        o, views = 0, []
+        for g in images:
+            v = pin[o:o + g["n_kept"]]
+            v.copy_(g["kept"], non_blocking=True)
+            views.append(v)
+            o += g["n_kept"]
+        uv = self._last["outputs"][4]
+        st = pin[o:o + len(items)].view(torch.float32)
+        for i, so in enumerate(self._status_offs.tolist()):        # (an index tensor would be a pageable upload in the middle of the stream)
+            st[i:i + 1].copy_(uv[so:so + 1], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        if (st.numpy() == 2.0).any():        # cannot happen (rescued inside gims_sinkhorn_match); never return silently wrong
+            raise hip.GimsHipError("the Sinkhorn solve of this batch gave up and was not rescued")
         # the reference's in-place dict mutation (gmatcher.py:244-252); torch.stack raises for ragged B>1, as there
         for s, side in enumerate(("0", "1")):
             gs = [images[2 * b + s]["graph"] for b in range(B)]
-            data['keypoints' + side] = torch.stack([h.ndata['point'] for h in gs])
-            data['descriptors' + side] = torch.stack([h.ndata['feat'] for h in gs]).permute(0, 2, 1)
-            data['scores' + side] = torch.stack([h.ndata['score'] for h in gs])
-            data['kept_kpts%s_indices' % side] = [images[2 * b + s]["kept"].tolist() for b in range(B)]
+            data['keypoints' + side] = _stack([h.ndata['point'] for h in gs])
+            data['descriptors' + side] = _stack([h.ndata['feat'] for h in gs]).permute(0, 2, 1)
+            data['scores' + side] = _stack([h.ndata['score'] for h in gs])
+            data['kept_kpts%s_indices' % side] = [views[2 * b + s].tolist() for b in range(B)]
             data['graph' + side] = gs
-        if (self.sinkhorn_status() == 2.0).any():        # cannot happen (rescued inside gims_sinkhorn_match); never return silently wrong
-            raise hip.GimsHipError("the Sinkhorn solve of this batch gave up and was not rescued")
         if kwargs.get('mode', 'test') == "train":        # gmatcher.py:254
             return self._forward_train(data, images, items)
-        md0 = torch.stack([mdesc[o0:o0 + n0] for (o0, n0), _ in pairs])
-        md1 = torch.stack([mdesc[o1:o1 + n1] for _, (o1, n1) in pairs])
+        md0 = _stack([mdesc[o0:o0 + n0] for (o0, n0), _ in pairs])
+        md1 = _stack([mdesc[o1:o1 + n1] for _, (o1, n1) in pairs])
         return {
             'keypoints0': data['keypoints0'], 'keypoints1': data['keypoints1'],
             'descriptors0': data['descriptors0'], 'descriptors1': data['descriptors1'],
-            'matches0': torch.stack([it["matches0"] for it in items]),
-            'matches1': torch.stack([it["matches1"] for it in items]),
-            'matching_scores0': torch.stack([it["mscores0"] for it in items]),
-            'matching_scores1': torch.stack([it["mscores1"] for it in items]),
+            'matches0': _stack([it["matches0"] for it in items]),
+            'matches1': _stack([it["matches1"] for it in items]),
+            'matching_scores0': _stack([it["mscores0"] for it in items]),
+            'matching_scores1': _stack([it["mscores1"] for it in items]),
             'mdesc0': md0.squeeze(), 'mdesc1': md1.squeeze(),
         }
 
