@@ -479,6 +479,61 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// The reference's LayerNorm (gmatcher.py:74-85: over the channels of a point, UNBIASED std, eps added to the std) followed by ReLU
+// (gmatcher.py:19-23), reverse pass.  With d = x - mean, sd = sqrt(sum d^2 / (c - 1)), s = sd + eps, xhat = d / s,
+// y = a2 xhat + b2 and g = dy masked by y > 0:   dx_i = a2_i g_i / s - mean_j(a2_j g_j) / s - d_i / ((c - 1) sd s^2) sum_j a2_j g_j d_j.
+// One wave per row (c <= 512).  Also writes g and g * xhat ([rows][c] each): their column sums are d b2 and d a2.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t ldd,
+                                                            int64_t rows, int c, const float* __restrict__ a2, const float* __restrict__ b2, float eps,
+                                                            int relu, float* __restrict__ dx, int64_t ldo, float* __restrict__ gb, float* __restrict__ ga) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float v[8], g[8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ch = lane + 64 * k;
+    v[k] = ch < c ? xr[ch] : 0.f;
+    s += v[k];
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = lane + 64 * k < c ? v[k] - mean : 0.f;          // v <- d
+    q += v[k] * v[k];
+  }
+  const float sd = sqrtf(wave_sum(q) / (float)(c - 1));
+  const float sv = sd + eps, inv = 1.f / sv;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ch = lane + 64 * k;
+    g[k] = 0.f;
+    if (ch < c) {
+      const float xh = v[k] * inv, a = a2[ch];
+      float d = dy[row * ldd + ch];
+      if (relu && !(fmaf(a, xh, b2[ch]) > 0.f)) d = 0.f;
+      gb[row * c + ch] = d;
+      ga[row * c + ch] = d * xh;
+      g[k] = a * d;
+      s1 += g[k];
+      s2 = fmaf(g[k], v[k], s2);
+    }
+  }
+  s1 = wave_sum(s1) / (float)c;
+  s2 = wave_sum(s2);
+  const float k2 = sd > 0.f ? s2 / ((float)(c - 1) * sd * sv * sv) : 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < c) dx[row * ldo + ch] = (g[k] - s1) * inv - v[k] * k2;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ softmax rows
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
   v = is_max ? wave_max(v) : wave_sum(v);
@@ -774,6 +829,17 @@ extern "C" int gims_normalize_keypoints(const float* kpts, const float* norm3, c
   GIMS_CHECK_ARG(kpts && norm3 && seg_of_row && out && n >= 0, "gims_normalize_keypoints: bad arguments");
   if (n == 0) return GIMS_OK;
   hipLaunchKernelGGL(normalize_kpts_kernel, dim3((unsigned)cdiv(2 * n, 256)), dim3(256), 0, (hipStream_t)stream, kpts, norm3, seg_of_row, n, out);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_layernorm_backward(const float* x, int64_t ldx, const float* dy, int64_t ldd, int64_t rows, int32_t c, const float* a2, const float* b2,
+                                       float eps, int32_t relu, float* dx, int64_t ldo, float* g_bias, float* g_scale, void* stream) {
+  GIMS_CHECK_ARG(x && dy && a2 && b2 && dx && g_bias && g_scale && rows >= 0 && c >= 2 && c <= 512 && ldx >= c && ldd >= c && ldo >= c,
+                 "gims_layernorm_backward: bad arguments (2 <= c <= 512)");
+  if (rows == 0) return GIMS_OK;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, ldd, rows, c, a2, b2, eps, relu, dx,
+                     ldo, g_bias, g_scale);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

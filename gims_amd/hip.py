@@ -192,6 +192,8 @@ _SIGNATURES = {
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gims_batchnorm_train_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(Segments), C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gims_layernorm_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
+                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gims_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "gims_softmax_rows_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "gims_colsum_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
@@ -1039,3 +1041,14 @@ def normalize_keypoints(kpts, norm3, seg):
     out = torch.empty_like(kpts)
     _check(load().gims_normalize_keypoints(_p(kpts), _p(norm3), _p(seg), kpts.shape[0], _p(out), _stream()), "gims_normalize_keypoints")
     return out
+
+
+def layernorm_backward(x, dy, a2, b2, relu: bool, eps=1e-6):
+    """Reverse pass of layernorm_act on x [rows, c]: returns (dx, d a_2, d b_2)."""
+    rows, c = x.shape
+    dx = torch.empty_like(x)
+    gb = torch.empty((rows, c), dtype=torch.float32, device=x.device)
+    ga = torch.empty((rows, c), dtype=torch.float32, device=x.device)
+    _check(load().gims_layernorm_backward(_p(x), x.stride(0), _p(dy), dy.stride(0), rows, c, _p(a2), _p(b2), float(eps), int(relu), _p(dx), dx.stride(0),
+                                          _p(gb), _p(ga), _stream()), "gims_layernorm_backward")
+    return dx, colsum(ga), colsum(gb)

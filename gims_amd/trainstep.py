@@ -1,7 +1,7 @@
 """One training step of GMatcher on the HIP path (SURVEY row f3 = a25): the forward pass of ``forward_train``
 (models/gmatcher.py:309-386) with the module in train() mode -- BatchNorm on batch statistics, running statistics updated --
 and the reverse pass through every stage of it, so that ``loss.backward()`` of train.py:136-137 fills ``.grad`` of all 282
-parameters.  Host orchestration only: every product runs in gims_gemm_f32 (split-bf16 MFMA, f32 class by default), the norms, softmaxes, sums
+parameters (``use_layernorm=True``: the reference's LayerNorm instead of BatchNorm in every MLP, same path).  Host orchestration only: every product runs in gims_gemm_f32 (split-bf16 MFMA, f32 class by default), the norms, softmaxes, sums
 and graph aggregations in the kernels of csrc/train.hip, the Sinkhorn solve and its reverse sweep in csrc/sinkhorn.hip.
 
 Layout: rows of all images SIDE-major ([image 0 of every batch element | image 1 of every batch element]), activations
@@ -83,8 +83,7 @@ def forward(model, data):
     (gmatcher.py:244-252) and updates the BatchNorm buffers of ``model``."""
     cfg = model.config
     hip.GEMM_PRECISION = _precision(cfg)
-    if cfg['use_layernorm']:
-        raise NotImplementedError("training with use_layernorm=True is not on the HIP path (the reference default is BatchNorm)")
+    ln = bool(cfg['use_layernorm'])          # MLP(): Conv1d -> LayerNorm -> ReLU instead of Conv1d -> BatchNorm1d -> ReLU (gmatcher.py:17-23)
     radius, percentile, min_size = data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)
     B = data['keypoints0'].shape[0]
     D = cfg['descriptor_dim']
@@ -116,9 +115,13 @@ def forward(model, data):
     side_rows = [(images[s * B]["rows"][0], sum(images[s * B + b]["n_kept"] for b in range(B))) for s in range(2)]
     sg = hip.segments(side_rows)
     S = _Step()
-    S.images, S.G, S.rows, S.sg, S.B, S.n_tot, S.D = images, G, rows, sg, B, n_tot, D
+    S.images, S.G, S.rows, S.sg, S.B, S.n_tot, S.D, S.ln = images, G, rows, sg, B, n_tot, D, ln
 
     def bn(prefix, x, relu=True):
+        if ln:                                # the reference's LayerNorm has no state: the reverse pass recomputes everything from x
+            y = torch.empty_like(x)
+            hip.layernorm_act(x, P[prefix + ".a_2"], P[prefix + ".b_2"], out=y, act=hip.ACT_RELU if relu else hip.ACT_NONE)
+            return y, None
         y, save = hip.batchnorm_train_forward(x, sg, P[prefix + ".weight"], P[prefix + ".bias"], BN_EPS, BN_MOMENTUM,
                                               Bf.get(prefix + ".running_mean"), Bf.get(prefix + ".running_var"), relu)
         nbt = Bf.get(prefix + ".num_batches_tracked")
@@ -236,6 +239,19 @@ def backward(model, S, w_pos: float, w_neg: float):
     def put(name, g):
         grads[name] = g.view(P[name].shape)
 
+    def norm_backward(prefix, x_pre, g, save):
+        """Reverse pass of the norm + ReLU behind a convolution: returns the gradient of the convolution's output and stores
+        the gradients of the norm's two parameter vectors."""
+        if S.ln:
+            dxn, dscale, dshift = hip.layernorm_backward(x_pre, g, P[prefix + ".a_2"], P[prefix + ".b_2"], True)
+            put(prefix + ".a_2", dscale)
+            put(prefix + ".b_2", dshift)
+            return dxn
+        dxn, dgam, dbet = hip.batchnorm_train_backward(x_pre, g, sg, save, P[prefix + ".weight"], P[prefix + ".bias"], True)
+        put(prefix + ".weight", dgam)
+        put(prefix + ".bias", dbet)
+        return dxn
+
     # ---- loss -> scores (reverse sweep through the unrolled Sinkhorn iterations) -> matching descriptors
     dscores, dalpha = hip.sinkhorn_score_gradients(S.items, S.alpha, cfg['sinkhorn_iterations'], w_pos, w_neg, S.loss_state, S.hists)
     put("bin_score", dalpha)
@@ -263,9 +279,7 @@ def backward(model, S, w_pos: float, w_neg: float):
         put(pre + "mlp.3.weight", hip.gemm(dx.t(), L["hid"].t()))
         put(pre + "mlp.3.bias", hip.colsum(dx))
         dhid = hip.gemm(dx, w3.t())
-        dhpre, dgam, dbet = hip.batchnorm_train_backward(L["hpre"], dhid, sg, L["save"], P[pre + "mlp.1.weight"], P[pre + "mlp.1.bias"], True)
-        put(pre + "mlp.1.weight", dgam)
-        put(pre + "mlp.1.bias", dbet)
+        dhpre = norm_backward(pre + "mlp.1", L["hpre"], dhid, L["save"])
         dw0 = torch.empty_like(w0)
         hip.gemm(dhpre.t(), L["x"].t(), dw0[:, :D])
         hip.gemm(dhpre.t(), L["msg"].t(), dw0[:, D:])
@@ -314,9 +328,7 @@ def backward(model, S, w_pos: float, w_neg: float):
         K = S.kenc[i]
         idx = K["conv"]
         if "pre" in K:           # conv idx -> BN idx+1 -> ReLU: g is the gradient of the ReLU output
-            g, dgam, dbet = hip.batchnorm_train_backward(K["pre"], g, sg, K["save"], P[f"kenc.encoder.{idx + 1}.weight"], P[f"kenc.encoder.{idx + 1}.bias"], True)
-            put(f"kenc.encoder.{idx + 1}.weight", dgam)
-            put(f"kenc.encoder.{idx + 1}.bias", dbet)
+            g = norm_backward(f"kenc.encoder.{idx + 1}", K["pre"], g, K["save"])
         put(f"kenc.encoder.{idx}.weight", hip.gemm(g.t(), K["x"].t()))
         put(f"kenc.encoder.{idx}.bias", hip.colsum(g))
         if i > 0:

@@ -528,6 +528,11 @@ int gims_batchnorm_train_forward(const float* x, int64_t ld, int32_t c, const gi
 int gims_batchnorm_train_backward(const float* x, int64_t ld, const float* dy, int64_t ldd, int32_t c, const gims_segments* sg, const float* save,
                                   const float* gamma, const float* beta, int32_t relu, float* dx, int64_t ldx, float* dgamma, float* dbeta,
                                   float* work, void* stream);
+/* Reverse pass of gims_layernorm_act (the reference's LayerNorm, gmatcher.py:74-85, + ReLU): dy = gradient of the (post-ReLU) output, the
+ * mask is recomputed from x.  dx [rows][ldo]; g_bias / g_scale [rows][c] receive the masked dy and dy * xhat, whose column sums
+ * (gims_colsum) are the gradients of b_2 and a_2. */
+int gims_layernorm_backward(const float* x, int64_t ldx, const float* dy, int64_t ldd, int64_t rows, int32_t c, const float* a2, const float* b2,
+                            float eps, int32_t relu, float* dx, int64_t ldo, float* g_bias, float* g_scale, void* stream);
 /* softmax over the last dimension of `batch` matrices [rows][cols] (pitch ld, matrix stride `stride`), in place
  * (gmatcher.py:37), and its backward: dp <- prob * (dp - rowsum(dp * prob)), in place on dp. */
 int gims_softmax_rows(float* s, int64_t ld, int64_t rows, int32_t cols, int32_t batch, int64_t stride, void* stream);

@@ -54,6 +54,7 @@ def train_pairs(name, g):
             "trainstep_n512_s1003_i20": lambda: [synth.make_pair(512, 1003)],
             "trainstep_b2_n64_s1000_i100": lambda: [synth.make_pair(64, 1000), synth.make_pair(64, 1000, desc_noise=0.2)],
             "trainstep_n1024sparse_s2001_i20": lambda: [synth.make_pair(1024, 2001, canvas=(800, 600))],
+            "trainstep_ln_n256_s1002_i100": lambda: [synth.make_pair(256, 1002)],
             "trainstep_n2048_s1004_i100": lambda: [synth.make_pair(2048, 1004)]}[name]()
 
 

@@ -130,3 +130,24 @@ def test_sage_mean_transposed_is_the_adjoint():
     gt = hip.sage_mean_transposed(g, ip, ix)
     lhs, rhs = float((mean.double() * g.double()).sum()), float((h.double() * gt.double()).sum())
     assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("rows,c", [(300, 32), (1031, 512), (5, 256)])
+def test_layernorm_backward(rows, c):
+    """Reverse pass of the reference's LayerNorm (gmatcher.py:74-85: unbiased std over the channels, eps added to the std) + ReLU
+    against torch autograd of that formula in float64."""
+    x = _rand(rows, c, seed=1, scale=1.5) + 0.2
+    a2, b2 = _rand(c, seed=2).abs() + 0.5, _rand(c, seed=3) * 0.1
+    dy = _rand(rows, c, seed=4)
+    y = torch.empty_like(x)
+    hip.layernorm_act(x, a2, b2, out=y, act=hip.ACT_RELU)
+    dx, da, db = hip.layernorm_backward(x, dy, a2, b2, True)
+    with torch.enable_grad():
+        xr = x.double().cpu().requires_grad_(True)
+        ar, br = a2.double().cpu().requires_grad_(True), b2.double().cpu().requires_grad_(True)
+        mean, std = xr.mean(-1, keepdim=True), xr.std(-1, keepdim=True)
+        yr = (ar * (xr - mean) / (std + 1e-6) + br).relu()
+        yr.backward(dy.double().cpu())
+    assert float((y.double().cpu() - yr.detach()).abs().max()) < 1e-5
+    for mine, ref in ((dx, xr.grad), (da, ar.grad), (db, br.grad)):
+        assert float((mine.double().cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max())

@@ -15,7 +15,7 @@ def test_oracle_train_step_vs_reference(name):
     pairs = train_pairs(name, g)
     data = train_data(pairs, g)
     cfg = dict(sinkhorn_iterations=int(g["meta"][4]), pos_loss_weight=float(g["pos_loss_weight"]), neg_loss_weight=float(g["neg_loss_weight"]))
-    (loss, pos, neg), grads, bufs = O.train_step(synth.make_state_dict(123), data, cfg)
+    (loss, pos, neg), grads, bufs = O.train_step(synth.make_state_dict(123, use_layernorm=name.startswith("trainstep_ln_")), data, cfg)
     assert abs(loss - float(g["loss"])) <= 2e-6 * max(1.0, abs(float(g["loss"])))
     assert abs(pos - float(g["pos"])) <= 2e-6 and abs(neg - float(g["neg"])) <= 2e-6
     worst = check_step_gradients(g, grads, rtol=1e-2, rtol_p95=1e-3)

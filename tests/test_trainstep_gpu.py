@@ -31,9 +31,9 @@ RTOL_WORST, RTOL_P95 = BARS["bf16x6"]
 LOSS_ATOL = 1e-4
 
 
-def _model(sd, g, precision="bf16x6"):
+def _model(sd, g, precision="bf16x6", use_layernorm=False):
     m = GMatcher({"sinkhorn_iterations": int(g["meta"][4]), "pos_loss_weight": float(g["pos_loss_weight"]),
-                  "neg_loss_weight": float(g["neg_loss_weight"]), "train_precision": precision})
+                  "neg_loss_weight": float(g["neg_loss_weight"]), "train_precision": precision, "use_layernorm": use_layernorm})
     m.load_state_dict(sd)
     return m.cuda().train()
 
@@ -42,8 +42,9 @@ def _model(sd, g, precision="bf16x6"):
 @pytest.mark.parametrize("name", golden_names("trainstep_"))
 def test_train_step_vs_reference_golden(name, precision):
     g = load_golden(name)
-    sd = synth.make_state_dict(123)
-    m = _model(sd, g, precision)
+    ln = name.startswith("trainstep_ln_")          # use_layernorm=True: the reference's LayerNorm in every MLP
+    sd = synth.make_state_dict(123, use_layernorm=ln)
+    m = _model(sd, g, precision, ln)
     data = train_data(train_pairs(name, g), g, device="cuda")
     m.zero_grad()
     loss, pos, neg = m(data, mode="train")

@@ -80,6 +80,8 @@ def main():
     one("trainstep_b2_n64_s1000_i100", sd, {**w}, [synth.make_pair(64, 1000), synth.make_pair(64, 1000, desc_noise=0.2)], 15, 2, 7)
     # sparse canvas: the adaptive graph drops most keypoints (different counts per image) -> most ground-truth rows are remapped
     one("trainstep_n1024sparse_s2001_i20", sd, {**w, "sinkhorn_iterations": 20}, [synth.make_pair(1024, 2001, canvas=(800, 600))], 15, 2, 7)
+    # use_layernorm=True (gmatcher.py:19-20, 74-85): the reference's LayerNorm instead of BatchNorm in every MLP
+    one("trainstep_ln_n256_s1002_i100", synth.make_state_dict(123, use_layernorm=True), {**w, "use_layernorm": True}, [synth.make_pair(256, 1002)], 15, 2, 7)
     if "--large" in sys.argv:
         # the training configuration of the reference (configs/coco_config.yaml: batch_size 1, train.py:107 max_keypoints 2048)
         one("trainstep_n2048_s1004_i100", sd, {**w}, [synth.make_pair(2048, 1004)], 15, 2, 7)
