@@ -119,3 +119,31 @@ def test_train_mode_under_no_grad_and_eval_mode_are_graph_free():
     assert not loss.requires_grad
     loss2, _, _ = m.eval()(train_data(pairs, g, device="cuda"), mode="train")     # running statistics, forward value only
     assert not loss2.requires_grad
+
+
+def test_train_step_edge_cases_vs_oracle():
+    """Ground-truth tables the reference's loop can produce at the margins: only unmatched keypoints (every row reads the corner
+    cell, gmatcher.py:368-372), and a single positive row -- loss and all gradients against the oracle's autograd."""
+    g = load_golden("trainstep_n256_s1002_i100")
+    sd = synth.make_state_dict(123)
+    pairs = [synth.make_pair(96, 31)]
+    cfg = dict(sinkhorn_iterations=int(g["meta"][4]), pos_loss_weight=float(g["pos_loss_weight"]), neg_loss_weight=float(g["neg_loss_weight"]))
+    full = train_data(pairs, g)["matches"]
+    neg_only = full[(full[:, 1] < 0) | (full[:, 2] < 0)]
+    one_pos = full[(full[:, 1] >= 0) & (full[:, 2] >= 0)][:1]
+    for table in (neg_only, one_pos):
+        d_cpu, d_gpu = train_data(pairs, g), train_data(pairs, g, device="cuda")
+        d_cpu["matches"], d_gpu["matches"] = table.clone(), table.clone().cuda()
+        (l_ref, p_ref, n_ref), g_ref, _ = O.train_step(sd, d_cpu, cfg)
+        m = _model(sd, g)
+        loss, pos, neg = m(d_gpu, mode="train")
+        loss.backward()
+        assert abs(float(loss.detach()) - l_ref) < LOSS_ATOL and abs(float(neg.detach()) - n_ref) < LOSS_ATOL
+        big = max(float(np.abs(v).max()) for v in g_ref.values())
+        for k, p in m.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            if big > 0:
+                den = max(float(np.abs(g_ref[k]).max()), 1e-3 * big)
+                assert float(np.abs(p.grad.cpu().numpy() - g_ref[k]).max()) / den < 1.5e-1, k
+            else:
+                assert float(p.grad.abs().max()) == 0.0, k
