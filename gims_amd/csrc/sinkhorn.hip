@@ -37,6 +37,7 @@ struct OtDev {
   float* status;                 // 1 word: 0 ok / 1 numeric guard
   int G;
   float norm, log_mu_bin, log_nu_bin;  // norm = -log(n+m); log(m)+norm; log(n)+norm
+  float* hist;                   // gims_sinkhorn_history: potentials after iteration k go to hist + k * (n + m + 2); else null
 };
 
 struct OtBwd {                    // one problem of the backward sweep
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__
 
 // v_j += log nu_j - log(sum of partials)    block = 64 columns x 16 partial groups; every thread issues its
 // (<= 32) loads back to back so the fold is one memory round trip, not a dependent chain
-__global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restrict__ probs) {
+__global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restrict__ probs, int slot) {
   __shared__ float red[16][64];
   const OtDev p = probs[blockIdx.y];
   const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -300,7 +301,13 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restr
     for (int q = 0; q < 16; ++q) c += red[q][cl];
     if (!(c > 0.f) || !(c < 3.0e38f)) p.status[0] = 1.f;
     const float lognu = col < p.m ? p.norm : p.log_nu_bin;
-    p.v[col] += lognu - logf(c);
+    const float nv = p.v[col] + (lognu - logf(c));
+    p.v[col] = nv;
+    if (p.hist && slot >= 0) p.hist[(int64_t)slot * (p.n + p.m + 2) + p.n + 1 + col] = nv;       // recorded solve: v after this iteration
+  }
+  if (p.hist && slot >= 0 && g == 1) {                      // ... and u (final since the row kernel of this iteration)
+    float* hu = p.hist + (int64_t)slot * (p.n + p.m + 2);
+    for (int i = blockIdx.x * 64 + cl; i <= p.n; i += gridDim.x * 64) hu[i] = p.u[i];
   }
 }
 
@@ -1639,7 +1646,7 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     GIMS_CHECK_ARG(q.n > 0 && q.m > 0 && q.scores && q.uv && q.matches0 && q.matches1 && q.mscores0 && q.mscores1,
                    "gims_sinkhorn_match: problem %d has empty shape or null pointer", i);
     GIMS_CHECK_ARG((q.ld % 4) == 0 && (((uintptr_t)q.scores) & 15) == 0, "gims_sinkhorn_match: scores must be 16-byte aligned with ld %% 4 == 0");
-    OtDev d;
+    OtDev d{};
     d.z = q.scores; d.ld = q.ld; d.n = q.n; d.m = q.m;
     d.u = q.uv; d.v = q.uv + q.n + 1; d.status = q.uv + q.n + 1 + q.m + 1;
     d.G = ot_G(q.n, np, threads, cpt);
@@ -1679,7 +1686,7 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha);
     else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha);
     else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha);
-    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp);
+    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp, -1);
   }
   if (cpt == 1) hipLaunchKernelGGL(ot_select_kernel<1>, gi, dim3(threads), 0, s, dp);
   else if (cpt == 2) hipLaunchKernelGGL(ot_select_kernel<2>, gi, dim3(threads), 0, s, dp);
@@ -1754,6 +1761,7 @@ extern "C" int gims_sinkhorn_history(const gims_ot_problem* pr, int32_t np, floa
     d.cbest_val = nullptr; d.cbest_idx = nullptr; d.max0 = nullptr; d.idx0 = nullptr; d.max1 = nullptr; d.idx1 = nullptr;
     d.matches0 = nullptr; d.matches1 = nullptr; d.mscores0 = nullptr; d.mscores1 = nullptr;
     ot_fill_common(q, d.norm, d.log_mu_bin, d.log_nu_bin);
+    d.hist = h_hist[i];
     hprob[i] = d;
   }
   const int rc = upload_table(hprob.data(), sizeof(OtDev) * (size_t)np, work, s);
@@ -1761,15 +1769,11 @@ extern "C" int gims_sinkhorn_history(const gims_ot_problem* pr, int32_t np, floa
   const OtDev* dp = (const OtDev*)work;
   hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, 0);
   dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
-  for (int it = 0; it < iters; ++it) {        // the streamed kernels, one iteration at a time, potentials copied out after each
+  for (int it = 0; it < iters; ++it) {        // the streamed kernels, one iteration at a time
     if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha);
     else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha);
     else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha);
-    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp);
-    for (int i = 0; i < np; ++i) {
-      const size_t hs = (size_t)(pr[i].n + pr[i].m + 2);
-      GIMS_HIP(hipMemcpyAsync(h_hist[i] + (size_t)(it + 1) * hs, pr[i].uv, hs * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
+    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp, it + 1);      // writes u, v of this iteration into the history itself
   }
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
