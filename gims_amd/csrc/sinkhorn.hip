@@ -46,6 +46,10 @@ struct OtBwd {                    // one problem of the backward sweep
   float* dz;                               // [(n+1)][(m+1)], holds G on entry, dL/dZc on exit
   float* gu; float* gv; float* gv2;        // [n+1], [m+1], [m+1]
   float* colpart;                          // [ceil((n+1)/8)][m+1] per-slab column partials of the fused sweep
+  float* gu_rec; float* gv_rec;            // low-rank sweep: gu_k [iters + 1][n+1], gv_k [iters + 1][m+1] (slot k; gv_rec[iters] = column sums of G)
+  float* fp; float* fq;                    // factor matrices P [n+1][2 iters], Q [m+1][2 iters]
+  float* tmat;                             // P Q^T, [(n+1)][ldt]
+  int64_t ldt; int iters;
   float* dalpha;
   float norm, log_mu_bin, log_nu_bin;
 };
@@ -765,6 +769,151 @@ __global__ __launch_bounds__(512) void ot_bwd_fused_reg_kernel(const OtBwd* __re
       }
     p.colpart[(int64_t)blockIdx.x * ldz + j] = cs;
   }
+}
+
+// LOW-RANK form of the sweep (default): every term subtracted from dZc factorises,
+//     gv_k[j] C^k_ij = e^{Zc_ij} * e^{u_k[i]} * (gv_k[j] e^{v_k[j] - log nu_j}),    gu_k[i] R^k_ij = e^{Zc_ij} * (gu_k[i] e^{u_k[i] - log mu_i}) * e^{v_{k-1}[j]},
+// so  dZc = G - e^{Zc} o (P Q^T)  with P = [e^{u_k} | gu_k e^{u_k - log mu}] ((n+1) x 2I) and Q = [gv_k e^{v_k - log nu} | e^{v_{k-1}}] ((m+1) x 2I):
+// the per-iteration kernels only run the two reductions (gu_k, gv_{k-1}) and RECORD them -- Z is read once per iteration (17 MB at
+// 2048^2, L2 / MALL resident) and dZc is never touched (its read-modify-write was 34 of the 50 MB per iteration) --, and one K = 2I
+// product at the end (gims_gemm_f32, bf16x6) rebuilds all I updates at once.  Potentials stay within e^{+-20}: no range problem in f32.
+template <int CPT>
+__global__ __launch_bounds__(512) void ot_bwd_reduce_kernel(const OtBwd* __restrict__ probs, float alpha, int k, int first) {
+  const OtBwd p = probs[blockIdx.y];
+  const int r0 = blockIdx.x * BW_ROWS;
+  if (r0 > p.n) return;
+  const int nr = min(BW_ROWS, p.n + 1 - r0);
+  const int ldz = p.m + 1, tid = threadIdx.x;
+  __shared__ float red[8][BW_ROWS];
+  __shared__ float gnew[BW_ROWS];
+  const float* uk = p.hist + (int64_t)k * p.hstride;
+  const float* vk = uk + p.n + 1;
+  const float* vprev = p.hist + (int64_t)(k - 1) * p.hstride + p.n + 1;
+  const float* gvk = p.gv_rec + (int64_t)k * ldz;               // gv entering iteration k
+  float ui[BW_ROWS], acc[BW_ROWS], zc[CPT][BW_ROWS];
+#pragma unroll
+  for (int r = 0; r < BW_ROWS; ++r) {
+    ui[r] = r < nr ? uk[r0 + r] : 0.f;
+    acc[r] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int j = tid + 512 * c;
+    const bool on = j <= p.m;
+    const float w = on ? vk[j] - (j < p.m ? p.norm : p.log_nu_bin) : 0.f;
+    const float gvj = on ? gvk[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < BW_ROWS; ++r) {
+      const int i = r0 + r;
+      float z = alpha;
+      if (on && r < nr && i < p.n && j < p.m) z = p.z[(int64_t)i * p.ld + j];
+      zc[c][r] = z;
+      if (on && r < nr) acc[r] += gvj * __expf(z + ui[r] + w);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < BW_ROWS; ++r) acc[r] = wave_sum(acc[r]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int r = 0; r < BW_ROWS; ++r) red[tid >> 6][r] = acc[r];
+  __syncthreads();
+  if (tid < BW_ROWS) {
+    const float gn = ((first && tid < nr) ? p.gu[r0 + tid] : 0.f) -
+                     (((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid])));
+    gnew[tid] = gn;
+    if (tid < nr) p.gu_rec[(int64_t)k * (p.n + 1) + r0 + tid] = gn;
+  }
+  __syncthreads();
+  float gn[BW_ROWS];
+#pragma unroll
+  for (int r = 0; r < BW_ROWS; ++r) gn[r] = gnew[r];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int j = tid + 512 * c;
+    if (j > p.m) continue;
+    const float vp = k > 1 ? vprev[j] : 0.f;
+    float cs = 0.f;
+#pragma unroll
+    for (int r = 0; r < BW_ROWS; ++r)
+      if (r < nr) cs += gn[r] * __expf(zc[c][r] + ui[r] + vp - (r0 + r < p.n ? p.norm : p.log_mu_bin));
+    p.colpart[(int64_t)blockIdx.x * ldz + j] = cs;
+  }
+}
+
+// gv_rec[slot][j] = sign * sum over slabs of colpart[slab][j]
+__global__ __launch_bounds__(256) void ot_bwd_colsum_rec_kernel(const OtBwd* __restrict__ probs, float sign, int slot) {
+  const OtBwd p = probs[blockIdx.y];
+  __shared__ float red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, j = blockIdx.x * 32 + tx;
+  const int ns = (p.n + BW_ROWS) / BW_ROWS, ldz = p.m + 1;
+  float s = 0.f;
+  if (j <= p.m)
+    for (int b = ty; b < ns; b += 32) {                    // four independent loads per trip (a chain of 33 dependent ones ran at L2 latency)
+      float x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[q] = b + 8 * q < ns ? p.colpart[(int64_t)(b + 8 * q) * ldz + j] : 0.f;
+      s += (x[0] + x[1]) + (x[2] + x[3]);
+    }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j <= p.m) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][tx];
+    p.gv_rec[(int64_t)slot * ldz + j] = sign * t;
+  }
+}
+
+// per-row / per-column shifts of the factorisation: a_i = max_k u_k[i] (-> p.gu), b_j = max over the v_k[j] that occur (k = 0 .. I, v_0 = 0;
+// -> p.gv2).  With them every factor is <= 1 in magnitude times the recorded gradient: the potentials of a peaked problem span more
+// than the 88 nats e^x covers in f32, their differences from the running maximum do not matter below e^-88.
+__global__ __launch_bounds__(256) void ot_bwd_shift_kernel(const OtBwd* __restrict__ probs) {
+  const OtBwd p = probs[blockIdx.y];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t <= p.n) {
+    float a = -INFINITY;
+    for (int k = 1; k <= p.iters; ++k) a = fmaxf(a, p.hist[(int64_t)k * p.hstride + t]);
+    p.gu[t] = a;
+  }
+  if (t <= p.m) {
+    float b = 0.f;                                          // v_0 = 0
+    for (int k = 1; k <= p.iters; ++k) b = fmaxf(b, p.hist[(int64_t)k * p.hstride + p.n + 1 + t]);
+    p.gv2[t] = b;
+  }
+}
+
+// factor matrices: P[i][k-1] = e^{u_k[i] - a_i}, P[i][I + k-1] = gu_k[i] e^{u_k[i] - log mu_i - a_i};
+//                  Q[j][k-1] = gv_k[j] e^{v_k[j] - log nu_j - b_j}, Q[j][I + k-1] = e^{v_{k-1}[j] - b_j}
+__global__ __launch_bounds__(256) void ot_bwd_factor_kernel(const OtBwd* __restrict__ probs) {
+  const OtBwd p = probs[blockIdx.y];
+  const int I = p.iters, ld = 2 * I;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t np_ = (int64_t)(p.n + 1) * I, nq = (int64_t)(p.m + 1) * I;
+  if (idx < np_) {
+    const int i = (int)(idx / I), k = (int)(idx - (int64_t)i * I) + 1;
+    const float u = p.hist[(int64_t)k * p.hstride + i] - p.gu[i];
+    p.fp[(int64_t)i * ld + k - 1] = __expf(u);
+    p.fp[(int64_t)i * ld + I + k - 1] = p.gu_rec[(int64_t)k * (p.n + 1) + i] * __expf(u - (i < p.n ? p.norm : p.log_mu_bin));
+  } else if (idx < np_ + nq) {
+    const int64_t e = idx - np_;
+    const int j = (int)(e / I), k = (int)(e - (int64_t)j * I) + 1;
+    const float b = p.gv2[j];
+    const float v = p.hist[(int64_t)k * p.hstride + p.n + 1 + j] - b;
+    const float vp = (k > 1 ? p.hist[(int64_t)(k - 1) * p.hstride + p.n + 1 + j] : 0.f) - b;
+    p.fq[(int64_t)j * ld + k - 1] = p.gv_rec[(int64_t)k * (p.m + 1) + j] * __expf(v - (j < p.m ? p.norm : p.log_nu_bin));
+    p.fq[(int64_t)j * ld + I + k - 1] = __expf(vp);
+  }
+}
+
+// dZc = G - e^{Zc + a_i + b_j} o T
+__global__ __launch_bounds__(256) void ot_bwd_combine_kernel(const OtBwd* __restrict__ probs, float alpha) {
+  const OtBwd p = probs[blockIdx.z];
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (i > p.n || j > p.m) return;
+  const float t = p.tmat[(int64_t)i * p.ldt + j];
+  if (t == 0.f) return;
+  const float z = (i < p.n && j < p.m) ? p.z[(int64_t)i * p.ld + j] : alpha;
+  p.dz[(int64_t)i * (p.m + 1) + j] -= __expf(z + p.gu[i] + p.gv2[j]) * t;
 }
 
 // after a row step: gv <- gv', gu <- 0   (and after a column step gv is dead: it is overwritten here)
@@ -1779,12 +1928,22 @@ extern "C" int gims_sinkhorn_history(const gims_ot_problem* pr, int32_t np, floa
   return GIMS_OK;
 }
 
+// low-rank sweep buffers of one problem: gu_rec, gv_rec, P, Q, T (sized for OT_BWD_MAX_ITERS iterations: the workspace query does
+// not know the iteration count; more iterations fall back to the in-place sweep)
+constexpr int OT_BWD_MAX_ITERS = 128;
+static size_t ot_bwd_lowrank_bytes(int n, int m, int iters) {
+  const size_t ldt = ((size_t)m + 1 + 3) & ~(size_t)3;
+  return gims::al256((size_t)(iters + 1) * (n + 1) * 4) + gims::al256((size_t)(iters + 1) * (m + 1) * 4) + gims::al256((size_t)(n + 1) * 2 * iters * 4) +
+         gims::al256((size_t)(m + 1) * 2 * iters * 4) + gims::al256((size_t)(n + 1) * ldt * 4);
+}
+
 extern "C" size_t gims_sinkhorn_backward_workspace_bytes(const gims_ot_problem* pr, int32_t np) {
   using namespace gims;
   if (!pr || np <= 0) return 0;
   size_t b = al256(sizeof(OtBwd) * (size_t)np);
   for (int i = 0; i < np; ++i)
-    b += al256((size_t)(pr[i].n + 1) * 4) + 2 * al256((size_t)(pr[i].m + 1) * 4) + al256((size_t)((pr[i].n + 8) / 8) * (size_t)(pr[i].m + 1) * 4);
+    b += al256((size_t)(pr[i].n + 1) * 4) + 2 * al256((size_t)(pr[i].m + 1) * 4) + al256((size_t)((pr[i].n + 8) / 8) * (size_t)(pr[i].m + 1) * 4) +
+         ot_bwd_lowrank_bytes(pr[i].n, pr[i].m, OT_BWD_MAX_ITERS);
   return b;
 }
 
@@ -1809,6 +1968,16 @@ extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, flo
     b.gv = (float*)(base + off); off += al256((size_t)(q.m + 1) * 4);
     b.gv2 = (float*)(base + off); off += al256((size_t)(q.m + 1) * 4);
     b.colpart = (float*)(base + off); off += al256((size_t)((q.n + 8) / 8) * (size_t)(q.m + 1) * 4);
+    {
+      const int it = iters <= OT_BWD_MAX_ITERS ? iters : 0;          // 0: the low-rank buffers are not used
+      b.iters = iters;
+      b.ldt = ((int64_t)q.m + 1 + 3) & ~(int64_t)3;
+      b.gu_rec = (float*)(base + off); off += al256((size_t)(it + 1) * (q.n + 1) * 4);
+      b.gv_rec = (float*)(base + off); off += al256((size_t)(it + 1) * (q.m + 1) * 4);
+      b.fp = (float*)(base + off); off += al256((size_t)(q.n + 1) * 2 * it * 4);
+      b.fq = (float*)(base + off); off += al256((size_t)(q.m + 1) * 2 * it * 4);
+      b.tmat = (float*)(base + off); off += al256((size_t)(q.n + 1) * b.ldt * 4);
+    }
     b.dalpha = dalpha + i;
     ot_fill_common(q, b.norm, b.log_mu_bin, b.log_nu_bin);
     hp[i] = b;
@@ -1825,6 +1994,34 @@ extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, flo
       hipLaunchKernelGGL(ot_bwd_row_kernel, dim3(cdiv(maxm + 1, 256), np), dim3(256), 0, s, dp, alpha, k);
       hipLaunchKernelGGL(ot_bwd_swap_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
     }
+  } else if (iters <= OT_BWD_MAX_ITERS && cdiv(maxm + 1, 512) <= 9 && !ot_env("GIMS_OT_BWD_INPLACE", 0)) {
+    // low-rank form: reductions only per iteration, one K = 2 iters product at the end
+    const dim3 gs(cdiv(maxn + 1, BW_ROWS), np), gc(cdiv(maxm + 1, 32), np);
+    const int cpt = cdiv(maxm + 1, 512);
+    hipLaunchKernelGGL(ot_bwd_fused_kernel<true>, gs, dim3(256), 0, s, dp, alpha, 0, 0);
+    hipLaunchKernelGGL(ot_bwd_colsum_rec_kernel, gc, dim3(256), 0, s, dp, 1.f, iters);
+    for (int k = iters; k >= 1; --k) {
+      const int first = k == iters ? 1 : 0;
+      if (cpt <= 1) hipLaunchKernelGGL((ot_bwd_reduce_kernel<1>), gs, dim3(512), 0, s, dp, alpha, k, first);
+      else if (cpt <= 3) hipLaunchKernelGGL((ot_bwd_reduce_kernel<3>), gs, dim3(512), 0, s, dp, alpha, k, first);
+      else if (cpt <= 5) hipLaunchKernelGGL((ot_bwd_reduce_kernel<5>), gs, dim3(512), 0, s, dp, alpha, k, first);
+      else hipLaunchKernelGGL((ot_bwd_reduce_kernel<9>), gs, dim3(512), 0, s, dp, alpha, k, first);
+      hipLaunchKernelGGL(ot_bwd_colsum_rec_kernel, gc, dim3(256), 0, s, dp, -1.f, k - 1);
+    }
+    const int64_t fmax = (int64_t)(maxn + 1 + maxm + 1) * iters;
+    hipLaunchKernelGGL(ot_bwd_shift_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);          // (gu, gv2 are free after the loop)
+    hipLaunchKernelGGL(ot_bwd_factor_kernel, dim3((unsigned)cdiv(fmax, 256), np), dim3(256), 0, s, dp);
+    GIMS_LAUNCH_CHECK();
+    for (int i = 0; i < np; ++i) {
+      gims_gemm g{};
+      g.a = hp[i].fp; g.b = hp[i].fq; g.c = hp[i].tmat;
+      g.lda = 2 * iters; g.ldb = 2 * iters; g.ldc = hp[i].ldt;
+      g.m = hp[i].n + 1; g.n = hp[i].m + 1; g.k = 2 * iters; g.batch = 1;
+      g.alpha = 1.f; g.beta = 0.f; g.act = GIMS_ACT_NONE; g.precision = GIMS_PREC_BF16X6;
+      const int rcg = gims_gemm_f32(&g, stream);
+      if (rcg != GIMS_OK) return rcg;
+    }
+    hipLaunchKernelGGL(ot_bwd_combine_kernel, dim3(cdiv(maxm + 1, 256), maxn + 1, np), dim3(256), 0, s, dp, alpha);
   } else {
     const dim3 gs(cdiv(maxn + 1, BW_ROWS), np), gc(cdiv(maxm + 1, 32), np);
     const int cpt = cdiv(maxm + 1, 512);
