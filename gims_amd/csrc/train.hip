@@ -711,7 +711,10 @@ extern "C" int gims_gemm_f32(const gims_gemm* gp, void* stream) {
   if (g.work && g.k >= 512) {
     const int64_t tiles = (int64_t)cdiv(g.n, g.n <= 64 ? 64 : 128) * cdiv(g.m, 128) * g.batch;
     if (tiles < 128) {
-      int sp = (int)((384 + tiles - 1) / tiles);
+      // count 64-row tiles where the launch can use them (n > 64): half the splits fill the chip just as well, and the partial
+      // sums the fold has to read halve with them
+      const int64_t fine = g.n > 64 && g.m > 64 ? (int64_t)cdiv(g.n, 128) * cdiv(g.m, 64) * g.batch : tiles;
+      int sp = (int)((384 + fine - 1) / fine);
       sp = sp < g.k / 128 ? sp : g.k / 128;
       const int64_t cap = g.work_floats / ((int64_t)g.m * g.n * g.batch);
       sp = sp < cap ? sp : (int)cap;
