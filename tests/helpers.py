@@ -55,7 +55,8 @@ def train_pairs(name, g):
             "trainstep_b2_n64_s1000_i100": lambda: [synth.make_pair(64, 1000), synth.make_pair(64, 1000, desc_noise=0.2)],
             "trainstep_n1024sparse_s2001_i20": lambda: [synth.make_pair(1024, 2001, canvas=(800, 600))],
             "trainstep_ln_n256_s1002_i100": lambda: [synth.make_pair(256, 1002)],
-            "trainstep_n2048_s1004_i100": lambda: [synth.make_pair(2048, 1004)]}[name]()
+            "trainstep_n2048_s1004_i100": lambda: [synth.make_pair(2048, 1004)],
+            "trainstep_n4096_s1005_i20": lambda: [synth.make_pair(4096, 1005)]}[name]()
 
 
 def train_data(pairs, g, device="cpu"):

@@ -85,6 +85,8 @@ def main():
     if "--large" in sys.argv:
         # the training configuration of the reference (configs/coco_config.yaml: batch_size 1, train.py:107 max_keypoints 2048)
         one("trainstep_n2048_s1004_i100", sd, {**w}, [synth.make_pair(2048, 1004)], 15, 2, 7)
+        # twice the training size (the matcher's headline size); 20 iterations keep the reference's autograd tape within memory here
+        one("trainstep_n4096_s1005_i20", sd, {**w, "sinkhorn_iterations": 20}, [synth.make_pair(4096, 1005)], 15, 2, 7)
 
 
 if __name__ == "__main__":
