@@ -101,6 +101,8 @@ __device__ __forceinline__ void tile_store(const f32x4 (&v)[4], uint16_t* __rest
 
 // NS = 2: split-bf16x3 (hi*hi + hi*mid + mid*hi, 16 mantissa bits per operand); NS = 3: split-bf16x6 (+ mid*mid + hi*lo + lo*hi,
 // 24 bits: the f32 class)
+__device__ unsigned long long g_gemm_prof[8];     // GIMS_GEMM_PROF=1: cycle stamps of one workgroup (diagnostics)
+
 // VEC: both operands 16-byte aligned with pitches that are multiples of 4 (straight-line loads; the compiler then counts the
 // loads in flight and waits only for the register set it is about to use)
 template <bool TA, bool TB, int BM, int BN, int NS, bool VEC>
@@ -111,8 +113,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
   // ONE LDS stage (48 KB at 128 x 128, three planes: two or three workgroups per CU hide each other's barriers and the
   // epilogue) fed from TWO register sets in flight: tile kt + 2 is requested right after tile kt went to LDS, so a global load
   // has two compute phases to land
-  __shared__ __attribute__((aligned(16))) uint16_t As[NS * BM * 32];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[NS * BN * 32];
+  __shared__ __attribute__((aligned(16))) uint16_t smem[NS * (BM + BN) * 32];
+  uint16_t* const As = smem;
+  uint16_t* const Bs = smem + NS * BM * 32;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int nsplit = g.splits > 1 ? g.splits : 1;
@@ -125,6 +128,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
   const int wm = BN == 64 ? wave * 32 : (wave >> 1) * (32 * MT), wn = BN == 64 ? 0 : (wave & 1) * 64;
   const float* __restrict__ A = g.a + (int64_t)z * g.sa;
   const float* __restrict__ B = g.b + (int64_t)z * g.sb;
+  const bool prof = (g.flags & 4) && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && t == 0;
+  if (prof) g_gemm_prof[0] = __builtin_readcyclecounter();
 
   f32x16 acc[MT][2];
 #pragma unroll
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
     tile_store<TA, BM, NS>(ra[0], As, m0, g.m, kbeg, kend, t);
     tile_store<TB, BN, NS>(rb[0], Bs, n0, g.n, kbeg, kend, t);
   }
+  if (prof) g_gemm_prof[1] = __builtin_readcyclecounter();
   // step kt (tile kt is in LDS, tile kt + 1 in flight in the other register set): request tile kt + 2 into the set that was just
   // stored, multiply, then move tile kt + 1 to LDS.  The loop header sits right before an ISSUE point on purpose: the compiler's
   // load counter is imprecise across the back edge, and the first wait behind it must not be the one that decides how far
@@ -191,44 +197,73 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
     step(std::integral_constant<int, 0>{}, kt);
     if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
   }
+  if (prof) g_gemm_prof[2] = __builtin_readcyclecounter();
 
-  if (nsplit > 1) {
-    float* __restrict__ W = g.work + ((int64_t)split * g.batch + z) * (int64_t)g.m * g.n;
+  // ---- epilogue.  The accumulator layout (a lane holds ONE column of 16 rows) turns a direct store into 64 four-byte stores per
+  // thread, two 128-byte row pieces per instruction: measured, that was 12 k of the 37 k cycles of a 64 x 128 linear tile and 24 k of
+  // the 37 k of a 128 x 128, k = 64 attention product.  So the tile goes through LDS 32 rows at a time (the operand stages are
+  // dead) and leaves as 16-byte stores, a wave covering whole rows; bias / residual / beta C are read the same way.
+  constexpr int CP = BN + 4;                                 // LDS pitch of a staged row (floats)
+  static_assert(32 * CP * 4 <= NS * (BM + BN) * 64, "a 32-row slice of the tile fits the operand stages");
+  float* const Cs = (float*)smem;
+  const bool split_out = nsplit > 1;
+  float* __restrict__ Cz = split_out ? g.work + ((int64_t)split * g.batch + z) * (int64_t)g.m * g.n : g.c + (int64_t)z * g.sc;
+  const int64_t ldc = split_out ? g.n : g.ldc;
+  const float* __restrict__ Rz = (!split_out && g.residual) ? g.residual + (int64_t)z * g.sr : nullptr;
+  const float* __restrict__ bias = split_out ? nullptr : g.bias;
+  const float al = split_out ? 1.f : g.alpha, be = split_out ? 0.f : g.beta;
+  const int act = split_out ? GIMS_ACT_NONE : g.act;
+  const bool vecc = split_out ? (g.flags & 16) != 0 : (g.flags & 8) != 0;       // 16-byte aligned rows of C (and of the residual)
+  constexpr int TPR = BN / 4, RPI = 256 / TPR;               // threads per row, rows per iteration of the store loop
+  const int cq = (t % TPR) * 4, rr = t / TPR;
+  const int n = n0 + cq;
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (bias)
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int e = 0; e < 4; ++e) b4[e] = n + e < g.n ? bias[n + e] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn + j * 32 + li;
-        if (n >= g.n) continue;
+  for (int pass = 0; pass < BM / 32; ++pass) {
+    __syncthreads();                                          // the operand stages / the previous slice are no longer read
+    {
+      const int own_i = pass % MT;
+      const bool mine = BN == 64 ? wave == pass : (wave >> 1) == pass / MT;
+      if (mine) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < g.m) W[(int64_t)m * g.n + n] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-  float* __restrict__ Cz = g.c + (int64_t)z * g.sc;
-  const float* __restrict__ Rz = g.residual ? g.residual + (int64_t)z * g.sr : nullptr;
+        for (int i = 0; i < MT; ++i)
+          if (i == own_i)
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn + j * 32 + li;
-      if (n >= g.n) continue;
-      const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= g.m) continue;
-        float v = g.alpha * acc[i][j][r] + bv;
-        if (Rz) v += Rz[(int64_t)m * g.ldr + n];
-        float* cp = Cz + (int64_t)m * g.ldc + n;
-        if (g.beta != 0.f) v += g.beta * *cp;
-        if (g.act == GIMS_ACT_RELU) v = fmaxf(v, 0.f);
-        *cp = v;
+              for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * CP + wn + j * 32 + li] = acc[i][j][r];
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int row = rr + it * RPI, m = m0 + pass * 32 + row;
+      if (m >= g.m || n >= g.n) continue;
+      f32x4 v = *(const f32x4*)(Cs + row * CP + cq);
+      float* cp = Cz + (int64_t)m * ldc + n;
+      if (vecc && n + 3 < g.n) {
+        v = v * al + b4;
+        if (Rz) v += *(const f32x4*)(Rz + (int64_t)m * g.ldr + n);
+        if (be != 0.f) v += *(const f32x4*)cp * be;
+        if (act == GIMS_ACT_RELU) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        *(f32x4*)cp = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < g.n) {
+            float x = al * v[e] + b4[e];
+            if (Rz) x += Rz[(int64_t)m * g.ldr + n + e];
+            if (be != 0.f) x += be * cp[e];
+            if (act == GIMS_ACT_RELU) x = fmaxf(x, 0.f);
+            cp[e] = x;
+          }
+      }
+    }
+  }
+  if (prof) g_gemm_prof[3] = __builtin_readcyclecounter();
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(gims_gemm g) {
@@ -705,6 +740,12 @@ extern "C" int gims_gemm_f32(const gims_gemm* gp, void* stream) {
                  "gims_gemm_f32: leading dimension smaller than the row it strides");
   auto vec_ok = [&](const float* p, int64_t ld, int64_t st) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0 && (g.batch == 1 || (st & 3) == 0); };
   g.flags = (vec_ok(g.a, g.lda, g.sa) ? 1 : 0) | (vec_ok(g.b, g.ldb, g.sb) ? 2 : 0);
+  if (((uintptr_t)g.c & 15) == 0 && (g.ldc & 3) == 0 && (g.batch == 1 || (g.sc & 3) == 0) &&
+      (!g.residual || (((uintptr_t)g.residual & 15) == 0 && (g.ldr & 3) == 0 && (g.batch == 1 || (g.sr & 3) == 0))))
+    g.flags |= 8;
+  if (g.work && ((uintptr_t)g.work & 15) == 0 && (g.n & 3) == 0) g.flags |= 16;      // (m n is then a multiple of 4 as well: every partial tile starts aligned)
+  static const bool prof_on = getenv("GIMS_GEMM_PROF") != nullptr;
+  if (prof_on) g.flags |= 4;
   // split-K when the output has too few tiles to fill the chip and k is long (the weight gradients: k = keypoint rows):
   // every split covers >= 128 k, partial sums go through the caller's workspace and are added in split order
   g.splits = 1;
@@ -727,6 +768,13 @@ extern "C" int gims_gemm_f32(const gims_gemm* gp, void* stream) {
   else if (g.ta && !g.tb) gemm_launch<true, false>(g, s);
   else gemm_launch<true, true>(g, s);
   GIMS_LAUNCH_CHECK();
+  if (prof_on) {
+    unsigned long long h[8];
+    GIMS_HIP(hipStreamSynchronize(s));
+    GIMS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_prof), sizeof(h)));
+    fprintf(stderr, "gemm m %d n %d k %d b %d ta %d tb %d splits %d: prologue %llu  main loop %llu (%d k-tiles)  epilogue %llu  (cycles of one workgroup)\n", g.m, g.n, g.k,
+            g.batch, g.ta, g.tb, g.splits, h[1] - h[0], h[2] - h[1], (g.k / (g.splits > 1 ? g.splits : 1) + 31) / 32, h[3] - h[2]);
+  }
   return GIMS_OK;
 }
 
