@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
   const float* __restrict__ A = g.a + (int64_t)z * g.sa;
   const float* __restrict__ B = g.b + (int64_t)z * g.sb;
   const bool prof = (g.flags & 4) && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && t == 0;
-  if (prof) g_gemm_prof[0] = __builtin_readcyclecounter();
+  if (prof) { g_gemm_prof[0] = __builtin_readcyclecounter(); g_gemm_prof[4] = g_gemm_prof[5] = g_gemm_prof[6] = g_gemm_prof[7] = 0; }
 
   f32x16 acc[MT][2];
 #pragma unroll
@@ -156,12 +156,15 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
   // ahead the loads run (with the store first, it waited for the newest loads as well: prefetch distance one instead of two).
   auto step = [&](auto set_c, int kt) {
     constexpr int SET = decltype(set_c)::value;
+    unsigned long long c0 = 0;
+    if (prof) c0 = __builtin_readcyclecounter();
     {   // past the end: the last tile again -- unconditional, so the loop body stays straight-line code
       const int kn = kbeg + min(kt + 2, nk - 1) * 32;
       tile_load<TA, BM, VEC>(ra[SET], A, g.lda, m0, g.m, kn, kend, t);
       tile_load<TB, BN, VEC>(rb[SET], B, g.ldb, n0, g.n, kn, kend, t);
     }
     __syncthreads();
+    if (prof) { const unsigned long long c1 = __builtin_readcyclecounter(); g_gemm_prof[4] += c1 - c0; c0 = c1; }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[NS][MT], bfr[NS][2];
@@ -187,9 +190,12 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(gims_gemm g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
         }
     }
+    if (prof) { const unsigned long long c1 = __builtin_readcyclecounter(); g_gemm_prof[5] += c1 - c0; c0 = c1; }
     __syncthreads();
+    if (prof) { const unsigned long long c1 = __builtin_readcyclecounter(); g_gemm_prof[6] += c1 - c0; c0 = c1; }
     tile_store<TA, BM, NS>(ra[SET ^ 1], As, m0, g.m, kbeg + (kt + 1) * 32, kend, t);
     tile_store<TB, BN, NS>(rb[SET ^ 1], Bs, n0, g.n, kbeg + (kt + 1) * 32, kend, t);
+    if (prof) { const unsigned long long c1 = __builtin_readcyclecounter(); g_gemm_prof[7] += c1 - c0; }
   };
   // (eight steps per trip -- no back edge for k <= 256 -- were tried: exact waits everywhere, but the hoisted addressing of eight
   // steps spills; two steps per trip it is)
@@ -772,8 +778,8 @@ extern "C" int gims_gemm_f32(const gims_gemm* gp, void* stream) {
     unsigned long long h[8];
     GIMS_HIP(hipStreamSynchronize(s));
     GIMS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_prof), sizeof(h)));
-    fprintf(stderr, "gemm m %d n %d k %d b %d ta %d tb %d splits %d: prologue %llu  main loop %llu (%d k-tiles)  epilogue %llu  (cycles of one workgroup)\n", g.m, g.n, g.k,
-            g.batch, g.ta, g.tb, g.splits, h[1] - h[0], h[2] - h[1], (g.k / (g.splits > 1 ? g.splits : 1) + 31) / 32, h[3] - h[2]);
+    fprintf(stderr, "gemm m %d n %d k %d b %d ta %d tb %d splits %d: prologue %llu  main loop %llu (%d k-tiles: issue+barrier %llu, lds-read+mfma %llu, barrier %llu, convert+lds-write %llu)  epilogue %llu  (cycles of one workgroup)\n",
+            g.m, g.n, g.k, g.batch, g.ta, g.tb, g.splits, h[1] - h[0], h[2] - h[1], (g.k / (g.splits > 1 ? g.splits : 1) + 31) / 32, h[4], h[5], h[6], h[7], h[3] - h[2]);
   }
   return GIMS_OK;
 }
