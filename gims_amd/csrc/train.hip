@@ -702,6 +702,38 @@ __global__ __launch_bounds__(256) void permute3_kernel(float* __restrict__ dst, 
   *o = accumulate ? *o + v : v;
 }
 
+// All head-interleave permutations of ONE attention layer in one launch (they were 7 + 7 launches of ~5 us per layer):
+// forward = false: proj weights / biases (reference order: channel = d * H + h) -> wqkv [3D][D], bqkv [3D] (head-contiguous rows),
+//                  merge weight -> wm [D][D] (head-contiguous columns);
+// forward = true : the same maps applied to gradients, from the packed layout back to the parameters' layout.
+struct HeadPack {
+  float* pw[3]; float* pb[3]; float* mw;        // parameter-layout tensors: proj weights [D][D], proj biases [D], merge weight [D][D]
+  float* wqkv; float* bqkv; float* wm;           // packed tensors
+  int d, heads;
+};
+__global__ __launch_bounds__(256) void head_pack_kernel(HeadPack hp, int to_params) {
+  const int D = hp.d, H = hp.heads, dh = D / H;
+  const int64_t nw = (int64_t)3 * D * D, nb = 3 * D, nm = (int64_t)D * D;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < nw) {                                  // packed row r = j * D + h * dh + dd  <->  parameter row dd * H + h of projection j
+    const int col = (int)(idx % D), r = (int)(idx / D), j = r / D, rr = r - j * D, h = rr / dh, dd = rr - h * dh;
+    float* par = hp.pw[j] + (int64_t)(dd * H + h) * D + col;
+    float* pk = hp.wqkv + idx;
+    if (to_params) *par = *pk; else *pk = *par;
+  } else if (idx < nw + nb) {
+    const int r = (int)(idx - nw), j = r / D, rr = r - j * D, h = rr / dh, dd = rr - h * dh;
+    float* par = hp.pb[j] + dd * H + h;
+    float* pk = hp.bqkv + r;
+    if (to_params) *par = *pk; else *pk = *par;
+  } else if (idx < nw + nb + nm) {                 // packed column h * dh + dd  <->  parameter column dd * H + h
+    const int64_t e = idx - nw - nb;
+    const int n = (int)(e / D), c = (int)(e - (int64_t)n * D), h = c / dh, dd = c - h * dh;
+    float* par = hp.mw + (int64_t)n * D + dd * H + h;
+    float* pk = hp.wm + e;
+    if (to_params) *par = *pk; else *pk = *par;
+  }
+}
+
 // transposed mean aggregation: out_j = sum over in-neighbours i of j (symmetric CSR) of g_i / deg_i  -- the gradient of
 // mean_{j in N(i)} h_j with respect to h (SAGEConv 'mean', gmatcher.py:149-158)
 __global__ __launch_bounds__(256) void sage_mean_t_kernel(const float* __restrict__ g, int64_t ldg, const int32_t* __restrict__ indptr,
@@ -897,6 +929,22 @@ extern "C" int gims_layernorm_backward(const float* x, int64_t ldx, const float*
   if (rows == 0) return GIMS_OK;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, ldd, rows, c, a2, b2, eps, relu, dx,
                      ldo, g_bias, g_scale);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_head_pack(float* const* proj_w, float* const* proj_b, float* merge_w, float* wqkv, float* bqkv, float* wm, int32_t d, int32_t heads,
+                              int32_t to_params, void* stream) {
+  GIMS_CHECK_ARG(proj_w && proj_b && merge_w && wqkv && bqkv && wm && d > 0 && heads > 0 && (d % heads) == 0, "gims_head_pack: bad arguments");
+  HeadPack hp;
+  for (int j = 0; j < 3; ++j) {
+    GIMS_CHECK_ARG(proj_w[j] && proj_b[j], "gims_head_pack: projection %d has a null pointer", j);
+    hp.pw[j] = proj_w[j];
+    hp.pb[j] = proj_b[j];
+  }
+  hp.mw = merge_w; hp.wqkv = wqkv; hp.bqkv = bqkv; hp.wm = wm; hp.d = d; hp.heads = heads;
+  const int64_t total = (int64_t)3 * d * d + 3 * d + (int64_t)d * d;
+  hipLaunchKernelGGL(head_pack_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, hp, to_params);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

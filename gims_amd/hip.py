@@ -201,6 +201,7 @@ _SIGNATURES = {
     "gims_elementwise": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float,
                                    C.c_void_p]),
     "gims_permute3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_int64] * 6 + [C.c_int32, C.c_void_p]),
+    "gims_head_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_sage_mean_transposed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_normalize_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gims_ot_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
@@ -1052,3 +1053,11 @@ def layernorm_backward(x, dy, a2, b2, relu: bool, eps=1e-6):
     _check(load().gims_layernorm_backward(_p(x), x.stride(0), _p(dy), dy.stride(0), rows, c, _p(a2), _p(b2), float(eps), int(relu), _p(dx), dx.stride(0),
                                           _p(gb), _p(ga), _stream()), "gims_layernorm_backward")
     return dx, colsum(ga), colsum(gb)
+
+
+def head_pack(proj_w, proj_b, merge_w, wqkv, bqkv, wm, heads: int, to_params: bool):
+    """All head-interleave permutations of one attention layer in one launch (gims_head_pack): parameters -> packed tensors, or
+    packed gradients -> parameter-layout gradients."""
+    pw = (C.c_void_p * 3)(*[t.data_ptr() for t in proj_w])
+    pb = (C.c_void_p * 3)(*[t.data_ptr() for t in proj_b])
+    _check(load().gims_head_pack(pw, pb, _p(merge_w), _p(wqkv), _p(bqkv), _p(wm), merge_w.shape[0], int(heads), int(to_params), _stream()), "gims_head_pack")

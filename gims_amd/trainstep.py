@@ -9,7 +9,8 @@ row-major f32 [rows][channels].  The linear layers of a GNN layer run once over 
 gmatcher.py:139-141); BatchNorm statistics are per side (= per call of the module in the reference); attention runs per
 image with the probabilities P kept for the reverse pass (4 x n x m f32 per image and layer: 2.4 GB at 2 x 2048 keypoints
 -- HBM is 288 GB; nothing is recomputed).  Heads are made contiguous by permuting the projection weights on the way in
-(reference: channel = d * heads + h, gmatcher.py:108-113) and the weight gradients on the way out.
+(reference: channel = d * heads + h, gmatcher.py:108-113) and the weight gradients on the way out (gims_head_pack: one launch per
+layer and direction).
 """
 from __future__ import annotations
 
@@ -22,35 +23,6 @@ from . import hip
 
 HEADS = 4
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1        # nn.BatchNorm1d defaults (gmatcher.py:20)
-
-
-# ------------------------------------------------------------------------------------------------ head interleave <-> contiguous heads
-def _rows_in(w):
-    """Projection weight [D, k] / bias [D]: output channel d * H + h -> h * dh + d."""
-    D = w.shape[0]
-    k = w.numel() // D
-    out = torch.empty_like(w)
-    return hip.permute3(out, w, (D // HEADS, HEADS, k), (k, (D // HEADS) * k, 1), (HEADS * k, k, 1))
-
-
-def _rows_out(gp, like):
-    D = gp.shape[0]
-    k = gp.numel() // D
-    out = torch.empty_like(like)
-    return hip.permute3(out, gp, (D // HEADS, HEADS, k), (HEADS * k, k, 1), (k, (D // HEADS) * k, 1))
-
-
-def _cols_in(w):
-    """Merge weight [n, D]: input channel d * H + h -> h * dh + d."""
-    n, D = w.shape
-    out = torch.empty_like(w)
-    return hip.permute3(out, w, (n, D // HEADS, HEADS), (D, 1, D // HEADS), (D, HEADS, 1))
-
-
-def _cols_out(gp, like):
-    n, D = gp.shape
-    out = torch.empty_like(like)
-    return hip.permute3(out, gp, (n, D // HEADS, HEADS), (D, HEADS, 1), (D, 1, D // HEADS))
 
 
 def _w2(p):
@@ -173,9 +145,11 @@ def forward(model, data):
     S.layers = []
     for l, name in enumerate(cfg['transformer_layers']):
         pre = f"gnn.layers.{l}."
-        wqkv = torch.cat([_rows_in(_w2(P[pre + f"attn.proj.{j}.weight"])) for j in range(3)])
-        bqkv = torch.cat([_rows_in(P[pre + f"attn.proj.{j}.bias"]) for j in range(3)])
-        wm = _cols_in(_w2(P[pre + "attn.merge.weight"]))
+        wqkv = torch.empty((3 * D, D), dtype=torch.float32, device=dev)
+        bqkv = torch.empty(3 * D, dtype=torch.float32, device=dev)
+        wm = torch.empty((D, D), dtype=torch.float32, device=dev)
+        hip.head_pack([P[pre + f"attn.proj.{j}.weight"] for j in range(3)], [P[pre + f"attn.proj.{j}.bias"] for j in range(3)],
+                      P[pre + "attn.merge.weight"], wqkv, bqkv, wm, HEADS, to_params=False)
         qkv = hip.gemm(desc, wqkv, bias=bqkv)
         o = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
         probs = []
@@ -288,7 +262,7 @@ def backward(model, S, w_pos: float, w_neg: float):
         hip.gemm(dhpre, w0[:, :D].t(), dx, beta=1.0)              # dx += dhpre W0[:, :D]   (x enters the MLP directly)
         dmsg = hip.gemm(dhpre, w0[:, D:].t())
         # merge
-        put(pre + "attn.merge.weight", _cols_out(hip.gemm(dmsg.t(), L["o"].t()), _w2(P[pre + "attn.merge.weight"])))
+        dwm = hip.gemm(dmsg.t(), L["o"].t())                       # in the packed (head-contiguous) layout; unpacked with the projections below
         put(pre + "attn.merge.bias", hip.colsum(dmsg))
         do = hip.gemm(dmsg, L["wm"].t())
         # attention, image by image (every image's rows are queries once and sources once per layer: dqkv is written exactly once)
@@ -315,9 +289,14 @@ def backward(model, S, w_pos: float, w_neg: float):
                 hip.gemm(dp[:, :, :ns].transpose(1, 2), qh.transpose(1, 2), dkh, alpha=1.0 / math.sqrt(dh))   # dK = dS^T Q / sqrt(dh)
         dwqkv = hip.gemm(dqkv.t(), L["x"].t())
         dbqkv = hip.colsum(dqkv)
+        gw = [torch.empty_like(P[pre + f"attn.proj.{j}.weight"]) for j in range(3)]
+        gb = [torch.empty_like(P[pre + f"attn.proj.{j}.bias"]) for j in range(3)]
+        gm = torch.empty_like(P[pre + "attn.merge.weight"])
+        hip.head_pack(gw, gb, gm, dwqkv, dbqkv, dwm, HEADS, to_params=True)
         for j in range(3):
-            put(pre + f"attn.proj.{j}.weight", _rows_out(dwqkv[j * D:(j + 1) * D], _w2(P[pre + f"attn.proj.{j}.weight"])))
-            put(pre + f"attn.proj.{j}.bias", _rows_out(dbqkv[j * D:(j + 1) * D], P[pre + f"attn.proj.{j}.bias"]))
+            put(pre + f"attn.proj.{j}.weight", gw[j])
+            put(pre + f"attn.proj.{j}.bias", gb[j])
+        put(pre + "attn.merge.weight", gm)
         hip.gemm(dqkv, L["wqkv"].t(), dx, beta=1.0)               # dx += dQKV Wqkv
         S.layers[l] = None                                        # this layer's activations are no longer needed
 

@@ -552,6 +552,11 @@ int gims_elementwise(int32_t op, float* out, int64_t ldo, const float* a, int64_
  * (channel = d * heads + h, gmatcher.py:108-113) <-> contiguous heads, for weights on the way in and gradients on the way out. */
 int gims_permute3(float* dst, const float* src, int32_t n0, int32_t n1, int32_t n2, int64_t d0, int64_t d1, int64_t d2, int64_t s0, int64_t s1,
                   int64_t s2, int32_t accumulate, void* stream);
+/* Every head-interleave permutation of one attention layer in one launch.  proj_w / proj_b: HOST arrays of 3 device pointers (the q, k, v
+ * projections in the reference's layout, [d][d] and [d]); merge_w [d][d].  to_params = 0: pack them into wqkv [3d][d], bqkv [3d] (rows grouped by
+ * head) and wm [d][d] (columns grouped by head); to_params = 1: the reverse map (weight gradients back to the parameters' layout). */
+int gims_head_pack(float* const* proj_w, float* const* proj_b, float* merge_w, float* wqkv, float* bqkv, float* wm, int32_t d, int32_t heads,
+                   int32_t to_params, void* stream);
 /* gradient of gims_sage_mean with respect to its input: out_j = sum over neighbours i of j of g_i / deg_i (symmetric CSR). */
 int gims_sage_mean_transposed(const float* g, int64_t ldg, const int32_t* indptr, const int32_t* indices, int32_t n, int32_t c, float* out,
                               int64_t ldo, void* stream);
