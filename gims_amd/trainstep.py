@@ -131,7 +131,10 @@ def forward(model, data):
     for i in range(n_convs):
         w, bia = _w2(P[f"kenc.encoder.{idx}.weight"]), P[f"kenc.encoder.{idx}.bias"]
         if i == n_convs - 1:
-            y = hip.gemm(x, w, bias=bia, residual=sage)
+            # the residual stream of layer l lives in the LEFT half of that layer's [x | msg] buffer (the MLP of a layer reads
+            # cat([x, msg]), gmatcher.py:123: one product over k = 2D instead of two, and one weight-gradient product)
+            xm = torch.empty((n_tot, 2 * D), dtype=torch.float32, device=dev)
+            y = hip.gemm(x, w, xm[:, :D], bias=bia, residual=sage)
             S.kenc.append(dict(x=x, conv=idx))
         else:
             pre = hip.gemm(x, w, bias=bia)
@@ -139,7 +142,7 @@ def forward(model, data):
             S.kenc.append(dict(x=x, conv=idx, pre=pre, save=save))
             idx += 3
         x = y
-    desc = x
+    desc, xm_cur = x, xm
 
     # ---- attentional GNN (gmatcher.py:99-143)
     S.layers = []
@@ -150,6 +153,7 @@ def forward(model, data):
         wm = torch.empty((D, D), dtype=torch.float32, device=dev)
         hip.head_pack([P[pre + f"attn.proj.{j}.weight"] for j in range(3)], [P[pre + f"attn.proj.{j}.bias"] for j in range(3)],
                       P[pre + "attn.merge.weight"], wqkv, bqkv, wm, HEADS, to_params=False)
+        xm = xm_cur                                  # [x | msg] of this layer; desc is its left half
         qkv = hip.gemm(desc, wqkv, bias=bqkv)
         o = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
         probs = []
@@ -165,14 +169,14 @@ def forward(model, data):
                 hip.softmax_rows_(pm, ns)
                 hip.gemm(pm[:, :, :ns], vh.transpose(1, 2), o[oq:oq + nq].view(nq, HEADS, D // HEADS).permute(1, 0, 2))
                 probs.append(pm)
-        msg = hip.gemm(o, wm, bias=P[pre + "attn.merge.bias"])
+        msg = hip.gemm(o, wm, xm[:, D:], bias=P[pre + "attn.merge.bias"])
         w0, w3 = _w2(P[pre + "mlp.0.weight"]), _w2(P[pre + "mlp.3.weight"])
-        hpre = hip.gemm(desc, w0[:, :D], bias=P[pre + "mlp.0.bias"])
-        hip.gemm(msg, w0[:, D:], hpre, beta=1.0)
+        hpre = hip.gemm(xm, w0, bias=P[pre + "mlp.0.bias"])
         hid, save = bn(pre + "mlp.1", hpre)
-        nxt = hip.gemm(hid, w3, bias=P[pre + "mlp.3.bias"], residual=desc)       # desc + delta (gmatcher.py:142)
-        S.layers.append(dict(x=desc, wqkv=wqkv, wm=wm, qkv=qkv, o=o, probs=probs, msg=msg, hpre=hpre, save=save, hid=hid, cross=name == 'cross'))
-        desc = nxt
+        xm_next = torch.empty((n_tot, 2 * D), dtype=torch.float32, device=dev)
+        nxt = hip.gemm(hid, w3, xm_next[:, :D], bias=P[pre + "mlp.3.bias"], residual=desc)       # desc + delta (gmatcher.py:142)
+        S.layers.append(dict(x=desc, xm=xm, wqkv=wqkv, wm=wm, qkv=qkv, o=o, probs=probs, msg=msg, hpre=hpre, save=save, hid=hid, cross=name == 'cross'))
+        desc, xm_cur = nxt, xm_next
     S.desc = desc
 
     # ---- final projection, scores, Sinkhorn, loss (gmatcher.py:330-385)
@@ -254,10 +258,7 @@ def backward(model, S, w_pos: float, w_neg: float):
         put(pre + "mlp.3.bias", hip.colsum(dx))
         dhid = hip.gemm(dx, w3.t())
         dhpre = norm_backward(pre + "mlp.1", L["hpre"], dhid, L["save"])
-        dw0 = torch.empty_like(w0)
-        hip.gemm(dhpre.t(), L["x"].t(), dw0[:, :D])
-        hip.gemm(dhpre.t(), L["msg"].t(), dw0[:, D:])
-        put(pre + "mlp.0.weight", dw0)
+        put(pre + "mlp.0.weight", hip.gemm(dhpre.t(), L["xm"].t()))
         put(pre + "mlp.0.bias", hip.colsum(dhpre))
         hip.gemm(dhpre, w0[:, :D].t(), dx, beta=1.0)              # dx += dhpre W0[:, :D]   (x enters the MLP directly)
         dmsg = hip.gemm(dhpre, w0[:, D:].t())
