@@ -169,10 +169,12 @@ class GMatcher(nn.Module):
         self._pack = None
         self.__dict__.pop("_ops_cache", None)
         self.__dict__.pop("_plist", None)
+        self.__dict__.pop("_train_params", None)
         return super().load_state_dict(sd, strict=strict, **kw)
 
     def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .half() replace the parameter tensors
         self.__dict__.pop("_plist", None)
+        self.__dict__.pop("_train_params", None)
         self._pack = None
         return super()._apply(fn, *a, **kw)
 
@@ -719,7 +721,8 @@ class GMatcher(nn.Module):
         if kwargs.get('mode', 'test') == "train" and self.training:
             from . import trainstep
             return trainstep.train_forward(self, data)
-        return self._forward_eval(data, **kwargs)
+        with hip.pinned_stream():                 # one stream lookup for the ~150 launches of a call
+            return self._forward_eval(data, **kwargs)
 
     @torch.no_grad()
     def _forward_eval(self, data, **kwargs):
@@ -827,7 +830,7 @@ class GMatcher(nn.Module):
             lanes = [cur]
         ctxs = []
         for gi, grp in enumerate(groups):
-            with torch.cuda.stream(lanes[gi]):
+            with torch.cuda.stream(lanes[gi]), hip.pinned_stream():
                 self._lane = gi
                 raw = [(data['keypoints' + side][0], data['descriptors' + side][0], data['scores' + side][0], data['image' + side].shape)
                        for data in grp for side in ("0", "1")]
@@ -835,7 +838,7 @@ class GMatcher(nn.Module):
         tm1 = time.perf_counter()
         outs, flats = [], []
         for gi, grp in enumerate(groups):
-            with torch.cuda.stream(lanes[gi]):
+            with torch.cuda.stream(lanes[gi]), hip.pinned_stream():
                 self._lane = gi
                 items, pairs, mdesc = self._run_rest(ctxs[gi])
                 images = ctxs[gi]["images"]

@@ -44,6 +44,17 @@ class _Step:
     """Everything the reverse pass needs from the forward pass of one step."""
 
 
+def _params(model):
+    """(names, parameters) of the module, cached on it (walking the module tree three times per step cost ~2 ms of host time);
+    invalidated with the pack cache when parameters are replaced (GMatcher._apply / load_state_dict)."""
+    c = model.__dict__.get("_train_params")
+    if c is None or model.__dict__.get("_plist") is None:
+        named = list(model.named_parameters())
+        c = model.__dict__["_train_params"] = (tuple(n for n, _ in named), [p for _, p in named])
+        model.__dict__.setdefault("_plist", c[1])
+    return c
+
+
 def _sage_bias(P, i):
     k = f"gnn_encoder.layers.{i}.fc_self.bias"
     return k if k in P else f"gnn_encoder.layers.{i}.bias"
@@ -80,7 +91,7 @@ def forward(model, data):
         data['kept_kpts%s_indices' % side] = [images[s * B + b]["kept"].tolist() for b in range(B)]
         data['graph' + side] = gs
 
-    P = {k: v.detach() for k, v in model.named_parameters()}
+    P = {k: v.detach() for k, v in zip(*_params(model))}
     Bf = dict(model.named_buffers())
     n_tot = G["n_tot"]
     rows = [[images[s * B + b]["rows"] for s in range(2)] for b in range(B)]          # rows[b][s] = (offset, n)
@@ -209,7 +220,7 @@ def backward(model, S, w_pos: float, w_neg: float):
     effective weights of the two loss terms -- with respect to every parameter: dict name -> tensor shaped like the parameter."""
     cfg = model.config
     hip.GEMM_PRECISION = _precision(cfg)
-    P = {k: v.detach() for k, v in model.named_parameters()}
+    P = {k: v.detach() for k, v in zip(*_params(model))}
     D, B, n_tot, rows, sg, G = S.D, S.B, S.n_tot, S.rows, S.sg, S.G
     dev = S.mdesc.device
     grads = {}
@@ -348,7 +359,8 @@ class _TrainStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, data, names, *params):
-        out3, S = forward(model, data)
+        with hip.pinned_stream():
+            out3, S = forward(model, data)
         ctx.model, ctx.S, ctx.names = model, S, names
         return out3[0].clone(), out3[1].clone(), out3[2].clone()
 
@@ -361,7 +373,8 @@ class _TrainStepFn(torch.autograd.Function):
         gl, gp, gn = torch.stack([zero if g is None else g.float().reshape(()) for g in (g_loss, g_pos, g_neg)]).tolist()
         cfg = model.config
         # loss = pos_loss + neg_loss, pos_loss = pos_weight * mean-of-means, neg_loss likewise (gmatcher.py:383-385)
-        grads = backward(model, S, cfg['pos_loss_weight'] * (gl + gp), cfg['neg_loss_weight'] * (gl + gn))
+        with hip.pinned_stream():
+            grads = backward(model, S, cfg['pos_loss_weight'] * (gl + gp), cfg['neg_loss_weight'] * (gl + gn))
         ctx.S = None
         return (None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
@@ -369,6 +382,5 @@ class _TrainStepFn(torch.autograd.Function):
 def train_forward(model, data):
     """``GMatcher.forward(data, mode='train')`` for a module in train() mode: returns (loss, pos_loss, neg_loss), 0-dim tensors
     attached to the autograd graph of the module's parameters."""
-    named = [(n, p) for n, p in model.named_parameters()]
-    names = tuple(n for n, _ in named)
-    return _TrainStepFn.apply(model, data, names, *[p for _, p in named])
+    names, params = _params(model)
+    return _TrainStepFn.apply(model, data, names, *params)
