@@ -141,3 +141,24 @@ def test_training_front_end_pads_to_max_keypoints():
     assert frontend.pad_training_keypoints(kps * 7, 6, (480, 640, 3)) == kps * 7          # nothing to add
     kp4, octv, resp = frontend.keypoint_arrays(out)
     assert kp4.shape == (6, 4) and octv.tolist() == [0] * 6
+
+
+def test_training_entry_points_validate_arguments_without_a_gpu():
+    """Argument checks of the training-step ABI run before any HIP call: bad arguments come back as GIMS_EINVAL (-1) with a message,
+    also on a machine without a GPU."""
+    import ctypes as C
+    lib = hip.load()
+    g = hip.Gemm()                                        # all null
+    assert lib.gims_gemm_f32(C.byref(g), None) == -1 and b"gims_gemm_f32" in lib.gims_last_error()
+    assert lib.gims_gemm_f32(None, None) == -1
+    sg = hip.Segments()
+    sg.n = 0
+    assert lib.gims_batchnorm_workspace_floats(C.byref(sg), 32) == 0
+    assert lib.gims_batchnorm_train_forward(None, 0, 32, C.byref(sg), None, None, 1e-5, 0.1, None, None, None, None, 0, 1, None, None) == -1
+    assert lib.gims_softmax_rows(None, 0, 4, 4, 1, 0, None) == -1
+    assert lib.gims_colsum(None, 0, 4, 4, 0.0, None, None, None) == -1
+    assert lib.gims_colsum_workspace_floats(1000, 512) == 64 + 8 * 512
+    assert lib.gims_layernorm_backward(None, 0, None, 0, 4, 1, None, None, 1e-6, 1, None, 0, None, None, None) == -1
+    assert lib.gims_head_pack(None, None, None, None, None, None, 256, 4, 0, None) == -1
+    assert lib.gims_permute3(None, None, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, None) == -1
+    assert lib.gims_sinkhorn_history_floats(10, 12, 5) == 6 * 24
