@@ -81,6 +81,40 @@ int main() {
   EXPECT(gims_pack_graphs(nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr) == GIMS_EINVAL);
   EXPECT(gims_events_create(0, nullptr) == GIMS_EINVAL);
   EXPECT(gims_ops_graph_create(nullptr, 0, nullptr, nullptr) == GIMS_EINVAL);
+  // ---- training-step entry points: size queries over ragged shapes, argument checks, the split-K / alignment planning of gims_gemm_f32
+  {
+    gims_gemm g; memset(&g, 0, sizeof(g));
+    EXPECT(gims_gemm_f32(&g, nullptr) == GIMS_EINVAL);
+    EXPECT(gims_gemm_f32(nullptr, nullptr) == GIMS_EINVAL);
+    g.a = (const float*)0x1000; g.b = (const float*)0x2000; g.c = (float*)0x3000; g.m = 5; g.n = 7; g.k = 3; g.batch = 1; g.lda = 2; g.ldb = 3; g.ldc = 7;
+    g.precision = GIMS_PREC_BF16X6;
+    EXPECT(gims_gemm_f32(&g, nullptr) == GIMS_EINVAL);            // lda smaller than the row it strides
+    g.lda = 3; g.precision = GIMS_PREC_F32;
+    EXPECT(gims_gemm_f32(&g, nullptr) == GIMS_EINVAL);            // unsupported precision
+    gims_segments sg; memset(&sg, 0, sizeof(sg));
+    EXPECT(gims_batchnorm_workspace_floats(&sg, 32) == 0);
+    sg.n = 8;
+    for (int i = 0; i < 8; ++i) { sg.off[i] = 300 * i; sg.rows[i] = 1 + 37 * i; }
+    EXPECT(gims_batchnorm_workspace_floats(&sg, 512) > 0);
+    sg.n = 9;
+    EXPECT(gims_batchnorm_workspace_floats(&sg, 512) == 0);
+    EXPECT(gims_batchnorm_train_forward((const float*)0x1000, 512, 512, &sg, (const float*)0x1000, (const float*)0x1000, 1e-5f, 0.1f, nullptr, nullptr,
+                                        (float*)0x1000, (float*)0x1000, 512, 1, (float*)0x1000, nullptr) == GIMS_EINVAL);
+    EXPECT(gims_colsum_workspace_floats(4097, 768) == 64 + (size_t)33 * 768);
+    EXPECT(gims_colsum((const float*)0x1001, 512, 10, 512, 0.f, (float*)0x1000, (float*)0x1000, nullptr) == GIMS_EINVAL);   // unaligned
+    EXPECT(gims_softmax_rows(nullptr, 0, 1, 1, 1, 0, nullptr) == GIMS_EINVAL);
+    EXPECT(gims_layernorm_backward(nullptr, 0, nullptr, 0, 1, 600, nullptr, nullptr, 1e-6f, 1, nullptr, 0, nullptr, nullptr, nullptr) == GIMS_EINVAL);
+    EXPECT(gims_head_pack(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 256, 4, 0, nullptr) == GIMS_EINVAL);
+    EXPECT(gims_sage_mean_transposed(nullptr, 0, nullptr, nullptr, 1, 30, nullptr, 0, nullptr) == GIMS_EINVAL);
+    for (int n : {1, 63, 2048, 4097}) {
+      gims_ot_problem q; memset(&q, 0, sizeof(q)); q.n = n; q.m = n + 3; q.ld = (q.m + 3) / 4 * 4;
+      EXPECT(gims_sinkhorn_backward_workspace_bytes(&q, 1) > 0);
+      EXPECT(gims_sinkhorn_history_floats(q.n, q.m, 100) == (size_t)101 * (size_t)(q.n + q.m + 2));
+    }
+    EXPECT(gims_sinkhorn_backward_workspace_bytes(nullptr, 2) == 0);
+    EXPECT(gims_sinkhorn_backward(nullptr, 0, 1.f, 10, nullptr, nullptr, nullptr, nullptr, 0, nullptr) == GIMS_EINVAL);
+    EXPECT(gims_sinkhorn_history(nullptr, 0, 1.f, 10, nullptr, nullptr, 0, nullptr) == GIMS_EINVAL);
+  }
   // ---- a call that reaches the HIP runtime: no device in this container -> a clean GIMS_EHIP / error string, no crash
   char host_table[64] = {0};
   const int rc = gims_upload_table(host_table, sizeof(host_table), (void*)0x1000, nullptr);
