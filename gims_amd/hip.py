@@ -924,20 +924,24 @@ EW_SCALE, EW_ADD, EW_RELU_MASK, EW_RELU, EW_ACC = 0, 1, 2, 3, 4
 
 
 def _operand(x: torch.Tensor):
-    """A 2-D (or batched 3-D) f32 tensor VIEW as a GEMM operand [rows][k]: (transposed flag, pitch, batch stride).  The view
-    must be contiguous along one of its last two dimensions -- `w.t()`, column slices and head slices all qualify."""
-    if x.dtype != torch.float32 or not x.is_cuda or x.dim() not in (2, 3):
+    """A 2-D (or batched 3-D) f32 tensor VIEW as a GEMM operand [rows][k]: (transposed flag, pitch, batch stride, rows, k, dims).
+    The view must be contiguous along one of its last two dimensions -- `w.t()`, column slices and head slices all qualify.
+    (shape and strides are fetched once: this runs ~1 300 times per training step)"""
+    sh, sd = x.shape, x.stride()
+    nd = len(sh)
+    if x.dtype != torch.float32 or not x.is_cuda or nd not in (2, 3):
         raise GimsHipError("gemm operands are 2-D / 3-D f32 device tensors")
-    st = x.stride(0) if x.dim() == 3 else 0
-    r, k = x.shape[-2], x.shape[-1]
-    if x.stride(-1) == 1 or k == 1:
-        return 0, (x.stride(-2) if r > 1 else max(k, x.stride(-2))), st
-    if x.stride(-2) == 1 or r == 1:
-        return 1, (x.stride(-1) if k > 1 else max(r, x.stride(-1))), st
+    st = sd[0] if nd == 3 else 0
+    r, k, s2, s1 = sh[-2], sh[-1], sd[-2], sd[-1]
+    if s1 == 1 or k == 1:
+        return 0, (s2 if r > 1 else max(k, s2)), st, r, k, nd
+    if s2 == 1 or r == 1:
+        return 1, (s1 if k > 1 else max(r, s1)), st, r, k, nd
     raise GimsHipError("gemm operand is contiguous along neither of its last two dimensions")
 
 
 _gemm_work = {}
+_gemm_fn = None
 
 
 GEMM_PRECISION = PREC_BF16X6          # default of gemm(): gims_amd.trainstep sets it per step from config['train_precision']
@@ -945,30 +949,39 @@ GEMM_PRECISION = PREC_BF16X6          # default of gemm(): gims_amd.trainstep se
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, *, alpha=1.0, beta=0.0, bias=None, residual=None, act=ACT_NONE,
          precision=None):
-    """out = alpha * a @ b^T + beta * out (+ bias over the last dimension) (+ residual), then act (gims_gemm_f32, f32-class
-    split-bf16x3 MFMA).  a: [.., m, k], b: [.., n, k] views (either may be a transposed view), out: [.., m, n] with unit
+    """out = alpha * a @ b^T + beta * out (+ bias over the last dimension) (+ residual), then act (gims_gemm_f32, split-bf16 MFMA,
+    f32 class by default).  a: [.., m, k], b: [.., n, k] views (either may be a transposed view), out: [.., m, n] with unit
     stride along n.  Batched when the tensors are 3-D."""
-    ta, lda, sa = _operand(a)
-    tb, ldb, sb = _operand(b)
-    m, k, n = a.shape[-2], a.shape[-1], b.shape[-2]
-    if b.shape[-1] != k or a.dim() != b.dim():
+    global _gemm_fn
+    ta, lda, sa, m, k, nda = _operand(a)
+    tb, ldb, sb, n, kb, ndb = _operand(b)
+    if kb != k or nda != ndb:
         raise GimsHipError(f"gemm: shapes {tuple(a.shape)} x {tuple(b.shape)}^T do not agree")
-    batch = a.shape[0] if a.dim() == 3 else 1
+    batch = a.shape[0] if nda == 3 else 1
     if out is None:
-        out = torch.empty((batch, m, n) if a.dim() == 3 else (m, n), dtype=torch.float32, device=a.device)
-    if out.shape[-2:] != (m, n) or (out.stride(-1) != 1 and n > 1) or out.dtype != torch.float32:
+        out = torch.empty((batch, m, n) if nda == 3 else (m, n), dtype=torch.float32, device=a.device)
+    osh, osd = out.shape, out.stride()
+    if osh[-2] != m or osh[-1] != n or (osd[-1] != 1 and n > 1) or out.dtype != torch.float32:
         raise GimsHipError("gemm: bad output tensor")
-    g = Gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), lda, ldb, out.stride(-2) if m > 1 else max(n, out.stride(-2)),
-             (residual.stride(-2) if residual is not None else 0), sa, sb, out.stride(0) if out.dim() == 3 else 0,
-             (residual.stride(0) if (residual is not None and residual.dim() == 3) else 0), m, n, k, batch, ta, tb, int(act), 0, float(alpha), float(beta))
+    ldr = sr = 0
+    if residual is not None:
+        rsd = residual.stride()
+        ldr, sr = rsd[-2], (rsd[0] if len(rsd) == 3 else 0)
+    g = Gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _p(residual), lda, ldb, osd[-2] if m > 1 else max(n, osd[-2]), ldr, sa, sb,
+             osd[0] if len(osd) == 3 else 0, sr, m, n, k, batch, ta, tb, int(act), 0, float(alpha), float(beta))
     g.precision = GEMM_PRECISION if precision is None else int(precision)
+    stream = _stream()
     if k >= 512:                                  # split-K workspace (one arena per device and stream; stream order protects it)
-        key = (a.device, _stream())
+        key = (a.device, stream)
         w = _gemm_work.get(key)
         if w is None:
             w = _gemm_work[key] = torch.empty(32 << 20, dtype=torch.float32, device=a.device)
         g.work, g.work_floats = w.data_ptr(), w.numel()
-    _check(load().gims_gemm_f32(C.byref(g), _stream()), "gims_gemm_f32")
+    if _gemm_fn is None:
+        _gemm_fn = load().gims_gemm_f32
+    rc = _gemm_fn(C.byref(g), stream)
+    if rc != 0:
+        _check(rc, "gims_gemm_f32")
     return out
 
 
