@@ -22,7 +22,15 @@ namespace gims {
 // ------------------------------------------------------------------------------------------------ general GEMM, bf16x3
 // LDS tile: NS planes (bf16 hi, mid[, lo] of the f32 value) of [rows][32 k]; 16-byte chunk c (8 k) of row r lives at chunk
 // position c ^ ((r >> 1) & 3) (conflict-free ds_read_b128 of MFMA fragments: 8 consecutive rows cover all 32 banks).
-__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 3)) << 3); }
+// (the second term of the swizzle serves the TRANSPOSED loader, whose stores hit rows 4 l + r across the lanes l of a wave: with
+// (row >> 1) & 3 alone those take two chunk positions -- a 16-way bank conflict on every ds_write; the fragment reads see a constant
+// row >> 3 within their groups of 8 rows and stay conflict-free)
+// ... and rows 4 l + r all have the parity of r, i.e. sit in one half of the banks: the physical row swaps neighbours for odd l
+// (row ^ ((row >> 2) & 1): a permutation inside every group of 8 rows, so the reads are unaffected) and the 32 rows of a
+// transposed store spread over all 32 banks
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+  return (row ^ ((row >> 2) & 1)) * 32 + ((chunk ^ (((row >> 1) ^ (row >> 3)) & 3)) << 3);
+}
 
 // R rows x 32 k of an operand into registers.  T = false: stored [rows][k] (k contiguous); T = true: stored [k][rows].
 // The loads are UNCONDITIONAL (indices clamped into the operand) and nothing consumes them here: masking of the ragged edges
