@@ -151,3 +151,21 @@ def test_layernorm_backward(rows, c):
     assert float((y.double().cpu() - yr.detach()).abs().max()) < 1e-5
     for mine, ref in ((dx, xr.grad), (da, ar.grad), (db, br.grad)):
         assert float((mine.double().cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
+def test_head_pack_roundtrip():
+    """gims_head_pack: reference layout (channel = d * heads + h, gmatcher.py:108-113) -> head-contiguous rows / columns and back."""
+    D, H = 256, 4
+    pw = [_rand(D, D, 1, seed=10 + j) for j in range(3)]           # Conv1d weights [out, in, 1]
+    pb = [_rand(D, seed=20 + j) for j in range(3)]
+    mw = _rand(D, D, 1, seed=30)
+    wqkv, bqkv, wm = torch.empty(3 * D, D, device=DEV), torch.empty(3 * D, device=DEV), torch.empty(D, D, device=DEV)
+    hip.head_pack(pw, pb, mw, wqkv, bqkv, wm, H, to_params=False)
+    for j in range(3):
+        ref = pw[j].view(D // H, H, D).permute(1, 0, 2).reshape(D, D)
+        assert torch.equal(wqkv[j * D:(j + 1) * D], ref)
+        assert torch.equal(bqkv[j * D:(j + 1) * D], pb[j].view(D // H, H).t().reshape(D))
+    assert torch.equal(wm, mw.view(D, D // H, H).permute(0, 2, 1).reshape(D, D))
+    gw, gb, gm = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb], torch.empty_like(mw)
+    hip.head_pack(gw, gb, gm, wqkv, bqkv, wm, H, to_params=True)
+    assert all(torch.equal(a, b) for a, b in zip(gw, pw)) and all(torch.equal(a, b) for a, b in zip(gb, pb)) and torch.equal(gm, mw)
