@@ -37,11 +37,33 @@ __device__ __forceinline__ int k_off(int row, int chunk) {  // K tile: [64 keys]
   return row * DH + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
+// Peakedness statistic of the softmax rows a wave just finished (attention_precision='auto' of the Python shell decides per
+// layer between this file's bf16 kernels and attention_x3_kernel from it): per head, the sum over the reported queries of
+// the row maximum of P in 2^-24 fixed point, the number of reported queries, and the largest row maximum.  Integer
+// atomics: the totals do not depend on the arrival order.  stat: [n_heads][4] uint64 {sum, count, max, unused}.
+__device__ __forceinline__ void emit_peak_stat(unsigned long long* stat, int head, float pmax, bool valid) {
+  const unsigned int fx = valid ? (unsigned int)(fminf(fmaxf(pmax, 0.f), 1.f) * 16777216.f + 0.5f) : 0u;
+  unsigned int sum = fx, cnt = valid ? 1u : 0u, mx = fx;        // <= 64 x 2^24: no overflow in 32 bits
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o, 64);
+    cnt += __shfl_xor(cnt, o, 64);
+    const unsigned int other = __shfl_xor(mx, o, 64);
+    mx = mx > other ? mx : other;
+  }
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    atomicAdd(stat + 4 * head, (unsigned long long)sum);
+    atomicAdd(stat + 4 * head + 1, (unsigned long long)cnt);
+    atomicMax(stat + 4 * head + 2, (unsigned long long)mx);
+  }
+}
+
 template <int QP>   // 32-query blocks per wave: 1 (32 queries/wave, 128/workgroup) or 2 (64 / 256)
 __global__ __launch_bounds__(256) void attention_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
-    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c) {
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
+    unsigned long long* __restrict__ stat) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KB * DH];      // double-buffered: one barrier per key tile
   __shared__ __attribute__((aligned(16))) uint16_t Vt[2][DH * VT_LD];
   constexpr int QWV = QW * QP;            // queries per wave
@@ -83,9 +105,9 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
   // instead of 1, which bf16 (relative precision) and the f32 accumulators tolerate unchanged.
   constexpr float DEFER = 5.0f;
   const float defer_raw = DEFER / c;
-  float m_run[QP], l_run[QP];
+  float m_run[QP], l_run[QP], m_true[QP];         // m_true: the row maximum itself (m_run lags it by up to DEFER), for `stat`
 #pragma unroll
-  for (int qi = 0; qi < QP; ++qi) { m_run[qi] = -1e30f; l_run[qi] = 0.f; }
+  for (int qi = 0; qi < QP; ++qi) { m_run[qi] = -1e30f; l_run[qi] = 0.f; m_true[qi] = -1e30f; }
 
   // staging: K tile 64 rows x 8 chunks = 512 chunks (2 per thread); V tile: key pair kp = t&31, d-octet t>>5
   uint4 rk[2], rv[2];
@@ -169,6 +191,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      m_true[qi] = fmaxf(m_true[qi], tmax);
       if (__any(tmax > m_run[qi] + defer_raw)) {          // wave-uniform, rare after the first tiles
         const float m_new = fmaxf(m_run[qi], tmax);
         const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
@@ -228,6 +251,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
     const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
     const float inv = 1.f / l_tot;
     const int qr = q0 + wave * QWV + qi * QW + li;
+    if (stat) emit_peak_stat(stat, head, __builtin_amdgcn_exp2f((m_true[qi] - m_run[qi]) * c) * inv, lh == 0 && qr < pr.n_q);
     if (qr < pr.n_q) {
       const int64_t grow = pr.q_off + qr;
       const int col0 = head * DH + 4 * lh;
@@ -580,7 +604,8 @@ constexpr int X3_LDS_BYTES = 2 * 2 * (KB * DH + DH * VT_LD) * 2;
 __global__ __launch_bounds__(256) void attention_x3_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
-    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c) {
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
+    unsigned long long* __restrict__ stat) {
   extern __shared__ __attribute__((aligned(16))) uint16_t x3_lds[];
   // [plane p = hi/lo][buffer]: K tiles then V^T tiles
   auto Ks = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + (p * 2 + buf) * (KB * DH); };
@@ -617,7 +642,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   constexpr float DEFER = 5.0f;
   const float defer_raw = DEFER / c;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = -1e30f, l_run = 0.f, m_true = -1e30f;
 
   uint4 rk[2][2], rv[2][2];        // [plane][piece]
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
@@ -698,6 +723,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    m_true = fmaxf(m_true, tmax);
     if (__any(tmax > m_run + defer_raw)) {
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -754,6 +780,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   const int qr = q0 + wave * QW + li;
+  if (stat) emit_peak_stat(stat, head, __builtin_amdgcn_exp2f((m_true - m_run) * c) * inv, lh == 0 && qr < pr.n_q);
   if (qr < pr.n_q) {
     const int64_t grow = pr.q_off + qr;
     const int col0 = head * DH + 4 * lh;
@@ -786,7 +813,8 @@ template <int NS>      // key parts per query block: 2 (eight waves) or 4 (sixte
 __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
-    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c) {
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
+    unsigned long long* __restrict__ stat) {
   extern __shared__ __attribute__((aligned(16))) uint16_t sp_lds[];
   // [half][buffer]: K tiles, then V^T tiles
   auto Ks = [&](int hf, int buf) __attribute__((always_inline)) { return sp_lds + (hf * 2 + buf) * (KB * DH); };
@@ -818,7 +846,7 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   constexpr float DEFER = 5.0f;
   const float defer_raw = DEFER / c;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = -1e30f, l_run = 0.f, m_true = -1e30f;
 
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
   const int n_mine = (n_tiles - half + NS - 1) / NS;      // tiles half, half + NS, ...
@@ -891,6 +919,7 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][r]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      m_true = fmaxf(m_true, tmax);
       if (__any(tmax > m_run + defer_raw)) {
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -939,22 +968,24 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
   }
 
   // ---- merge the parts: parts 1 .. NS-1 hand (O, m, l) to part 0 through LDS (the staging buffers are idle now)
-  float* xo = (float*)sp_lds;                            // [NS - 1][4 waves][34][64 lanes]: 32 accumulator registers, m, l
+  float* xo = (float*)sp_lds;                            // [NS - 1][4 waves][35][64 lanes]: 32 accumulator registers, m, l, row maximum
   if (half > 0) {
-    float* dst = xo + (((half - 1) * 4 + wave) * 34) * 64 + lane;
+    float* dst = xo + (((half - 1) * 4 + wave) * 35) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[(i * 16 + r) * 64] = o[i][r];
     dst[32 * 64] = m_run;
     dst[33 * 64] = l_run;
+    dst[34 * 64] = m_true;
   }
   __syncthreads();
   if (half > 0) return;
 #pragma unroll
   for (int pt = 1; pt < NS; ++pt) {                      // fixed merge order
-    const float* src = xo + (((pt - 1) * 4 + wave) * 34) * 64 + lane;
+    const float* src = xo + (((pt - 1) * 4 + wave) * 35) * 64 + lane;
     const float m1 = src[32 * 64], l1 = src[33 * 64];
+    m_true = fmaxf(m_true, src[34 * 64]);
     const float m_new = fmaxf(m_run, m1);
     const float a0 = __builtin_amdgcn_exp2f((m_run - m_new) * c), a1 = __builtin_amdgcn_exp2f((m1 - m_new) * c);
     m_run = m_new;
@@ -967,6 +998,7 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   const int qr = q0 + wave * QW + li;
+  if (stat) emit_peak_stat(stat, head, __builtin_amdgcn_exp2f((m_true - m_run) * c) * inv, lh == 0 && qr < pr.n_q);
   if (qr < pr.n_q) {
     const int64_t grow = pr.q_off + qr;
     const int col0 = head * DH + 4 * lh;
@@ -987,7 +1019,90 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
       }
   }
 }
-template <int NS> constexpr int SPLIT_LDS_BYTES = NS * 2 * (KB * DH + DH * VT_LD) * 2;     // >= the (NS - 1) x 34 KB of the merge exchange
+// ---------------------------------------------------------------------------------------------- peakedness of a SAMPLE of rows
+// The 8-wave kernel's optimistic softmax never looks at a maximum, so it cannot report the row maxima of P; making some of
+// its workgroups take the exact pass instead cost 17 % of the launch (they become the tail of a two-round grid).  This
+// kernel measures a sample on the side: per (problem, head) group ONE workgroup of 16 waves takes 32 queries spread evenly
+// over the group's queries and walks ALL keys -- wave w the 32-key tiles w, w + 16, ... -- with S^T = K Q^T on the matrix
+// cores (K fragments straight from global memory: a lane's MFMA operand is one 16-byte piece of a key row), an exact online
+// (maximum, sum) per query, and a merge of the 32 partial pairs per query through LDS.  Row maximum of P = 1 / (sum of
+// exp2(s - max)).  A few microseconds per layer; the Python shell asks for it on every n-th batch only.
+constexpr int PS_WAVES = 16, PS_Q = 32;
+__global__ __launch_bounds__(64 * PS_WAVES) void attention_peak_sample_kernel(
+    const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads,
+    float c, unsigned long long* __restrict__ stat) {
+  __shared__ float xm[PS_WAVES][64], xl[PS_WAVES][64];
+  const int group = blockIdx.x;
+  if (group >= n_groups) return;
+  const gims_attn_problem pr = problems[group / n_heads];
+  const int head = group % n_heads;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int n_s = pr.n_q < PS_Q ? pr.n_q : PS_Q;                        // sampled queries: j -> row j * n_q / n_s
+  if (n_s <= 0 || pr.n_kv <= 0) return;
+  bf16x8 qf[4];
+  {
+    const int j = li < n_s ? li : n_s - 1;
+    const int qr = (int)(((long long)j * pr.n_q) / n_s);
+    const uint16_t* qp = qkv + (int64_t)(pr.q_off + qr) * ld + q_col + head * DH + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+  }
+  const int n_tiles = (pr.n_kv + 31) / 32;
+  float m_run = -1e30f, l_run = 0.f;
+  constexpr int TB = 4;                                                   // tiles in flight per wave (16 x 16-byte loads)
+  for (int t0 = wave; t0 < n_tiles; t0 += PS_WAVES * TB) {
+    bf16x8 kf[TB][4];
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int t = t0 + b * PS_WAVES;
+      int kr = t * 32 + li;
+      kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      const uint16_t* kp = qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * lh;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[b][s] = *(const bf16x8*)(kp + 16 * s);
+    }
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int t = t0 + b * PS_WAVES;
+      if (t >= n_tiles) break;                                            // wave-uniform
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][s], qf[s], sacc, 0, 0, 0);
+      float tmax = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= pr.n_kv) sacc[r] = -1e30f;
+        tmax = fmaxf(tmax, sacc[r]);
+      }
+      const float m_new = fmaxf(m_run, tmax);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f((sacc[r] - m_new) * c);
+      l_run = l_run * __builtin_amdgcn_exp2f((m_run - m_new) * c) + sum;
+      m_run = m_new;
+    }
+  }
+  xm[wave][lane] = m_run;
+  xl[wave][lane] = l_run;
+  __syncthreads();
+  if (wave == 0) {
+    float m = -1e30f;
+#pragma unroll
+    for (int w = 0; w < PS_WAVES; ++w) m = fmaxf(m, fmaxf(xm[w][li], xm[w][li + 32]));
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < PS_WAVES; ++w)                                     // fixed order
+      l += xl[w][li] * __builtin_amdgcn_exp2f((xm[w][li] - m) * c) + xl[w][li + 32] * __builtin_amdgcn_exp2f((xm[w][li + 32] - m) * c);
+    emit_peak_stat(stat, head, 1.f / l, lh == 0 && li < n_s);
+  }
+}
+
+template <int NS> constexpr int SPLIT_LDS_BYTES = NS * 2 * (KB * DH + DH * VT_LD) * 2;     // >= the (NS - 1) x 35 KB of the merge exchange
+static_assert(SPLIT_LDS_BYTES<2> >= 1 * 4 * 35 * 64 * 4 && SPLIT_LDS_BYTES<4> >= 3 * 4 * 35 * 64 * 4, "merge exchange must fit the staging buffers");
 
 }  // namespace gims
 
@@ -995,7 +1110,17 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
                               const gims_attn_problem* problems, int32_t n_problems, int32_t max_n_q,
                               int32_t n_heads, float* out, int64_t ld_out, uint16_t* out_hi, uint16_t* out_lo,
                               int64_t ld_split, int32_t flags, void* stream) {
+  return gims_attention_stat(qkv, ld, q_col, k_col, v_col, problems, n_problems, max_n_q, n_heads, out, ld_out, out_hi, out_lo, ld_split, flags,
+                             nullptr, stream);
+}
+
+extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
+                                   const gims_attn_problem* problems, int32_t n_problems, int32_t max_n_q,
+                                   int32_t n_heads, float* out, int64_t ld_out, uint16_t* out_hi, uint16_t* out_lo,
+                                   int64_t ld_split, int32_t flags, uint64_t* stat_u64, void* stream) {
   using namespace gims;
+  GIMS_CHECK_ARG((((uintptr_t)stat_u64) & 7) == 0, "gims_attention_stat: stat must be 8-byte aligned");
+  unsigned long long* stat = (unsigned long long*)stat_u64;
   GIMS_CHECK_ARG(qkv && problems && (out || out_hi), "gims_attention: null pointer");
   GIMS_CHECK_ARG((out_hi == nullptr) == (out_lo == nullptr) && (ld_split % 8) == 0 && (((uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
                  "gims_attention: out_hi/out_lo come together, 16-byte aligned, ld_split %% 8 == 0");
@@ -1018,7 +1143,7 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
     }
     const int n_qt = cdiv(max_n_q, QB);
     hipLaunchKernelGGL(attention_x3_kernel, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
     GIMS_LAUNCH_CHECK();
     return GIMS_OK;
   }
@@ -1045,10 +1170,10 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
     const bool four = ns_env == 4 || (ns_env != 2 && wgs <= 256 && max_n_q >= 2048);
     if (four)
       hipLaunchKernelGGL(attention_split_kernel<4>, dim3(wgs), dim3(1024), SPLIT_LDS_BYTES<4>, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col, problems,
-                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
+                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
     else
       hipLaunchKernelGGL(attention_split_kernel<2>, dim3(wgs), dim3(512), SPLIT_LDS_BYTES<2>, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col, problems,
-                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
+                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
   } else if (eight) {
     int exact_only = 0;                         // GIMS_ATTN_EXACT=1: running-maximum softmax only (no optimistic pass)
     { const char* e = getenv("GIMS_ATTN_EXACT"); exact_only = e ? atoi(e) : 0; }
@@ -1078,14 +1203,19 @@ extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, in
         hipLaunchKernelGGL((attention8_bf16_kernel<false, false>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
                            q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c);
     }
+    if (stat) {          // the optimistic 8-wave kernel tracks no maximum: a sample of the rows is measured on the side
+      GIMS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(attention_peak_sample_kernel, dim3(n_groups), dim3(64 * PS_WAVES), 0, (hipStream_t)stream, qkv, ld, q_col, k_col, problems,
+                         n_groups, n_heads, c, stat);
+    }
   } else if (two) {
     const int n_qt = cdiv(max_n_q, 2 * QB);
     hipLaunchKernelGGL(attention_bf16_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
   } else {
     const int n_qt = cdiv(max_n_q, QB);
     hipLaunchKernelGGL(attention_bf16_kernel<1>, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c);
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
   }
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;

@@ -95,6 +95,44 @@ __global__ void half_kernel(const uint8_t* __restrict__ src, int h, int w, int c
 
 // ---- warpAffine(INTER_CUBIC, BORDER_CONSTANT) + INTER_AREA halving + / 255, one workgroup per keypoint
 constexpr int PATCH_DIM = 64;           // int32(2 * ((64 - 1) / 2) + 1)   (library.py:91-93 with radius_size = 64)
+
+// Host arithmetic of ComputePatches for one keypoint (library.py:96-106): the 2x3 map A it hands to cv2.warpAffine, float64
+// except where the reference itself drops to float32, and the pyramid level index (octave - firstOctave) * 6 + layer
+// (may lie outside the pyramid).  Returns the layer.  Pinned bit for bit by tests/golden/patch_affine_*.npz through
+// gims_patch_affine.
+__device__ __forceinline__ int keypoint_affine(const float* __restrict__ kp4, const int32_t* __restrict__ kp_oct, int kp, double* A, int* level) {
+#pragma clang fp contract(off)
+  const double x = kp4[4 * kp], y = kp4[4 * kp + 1], size = kp4[4 * kp + 2], angle_in = kp4[4 * kp + 3];
+  const int packed = kp_oct[kp];
+  int octave = packed & 0xFF;
+  const int layer = (packed >> 8) & 0xFF;
+  if (octave >= 128) octave |= -128;
+  const double scale = octave >= 0 ? 1.0 / (double)(1 << octave) : (double)(1 << -octave);
+  const double step = size * scale * 0.5;
+  const double px = x * scale, py = y * scale;
+  double ang = 360.0 - angle_in;
+  if (fabs(ang - 360.0) < 1.19209e-07) ang = 0.0;
+  const double phi = ang * (3.14159265358979323846 / 180.0);
+  const double s = sin(phi), c = cos(phi);
+  const float stepf = (float)step;
+  A[0] = (double)((float)c / stepf); A[1] = (double)((float)(-s) / stepf); A[3] = (double)((float)s / stepf); A[4] = (double)((float)c / stepf);
+  const double r = (64 - 1) / 2.0;
+  A[2] = r - (A[0] * px + A[1] * py);
+  A[5] = r - (A[3] * px + A[4] * py);
+  *level = (octave + 1) * PYR_LAYERS + layer;
+  return layer;
+}
+
+__global__ void patch_affine_kernel(const float* __restrict__ kp4, const int32_t* __restrict__ kp_oct, int n_kp, double* __restrict__ A_out,
+                                    int32_t* __restrict__ level_out) {
+  const int kp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (kp >= n_kp) return;
+  double A[6];
+  int level;
+  keypoint_affine(kp4, kp_oct, kp, A, &level);
+  for (int i = 0; i < 6; ++i) A_out[6 * kp + i] = A[i];
+  level_out[kp] = level;
+}
 __global__ __launch_bounds__(256) void patch_kernel(const uint8_t* __restrict__ pyr, const gims_pyr_level* __restrict__ levels, int n_levels,
                                                     const float* __restrict__ kp4, const int32_t* __restrict__ kp_oct, int n_kp,
                                                     const int16_t* __restrict__ wtab, float* __restrict__ out, int32_t* __restrict__ bad) {
@@ -105,23 +143,10 @@ __global__ __launch_bounds__(256) void patch_kernel(const uint8_t* __restrict__ 
   const int kp = blockIdx.x;
   if (kp >= n_kp) return;
   if (threadIdx.x == 0) {
-    // host arithmetic of ComputePatches (library.py:96-106), float64 except where the reference itself drops to float32
-    const double x = kp4[4 * kp], y = kp4[4 * kp + 1], size = kp4[4 * kp + 2], angle_in = kp4[4 * kp + 3];
-    const int packed = kp_oct[kp];
-    int octave = packed & 0xFF;
-    const int layer = (packed >> 8) & 0xFF;
-    if (octave >= 128) octave |= -128;
-    const double scale = octave >= 0 ? 1.0 / (double)(1 << octave) : (double)(1 << -octave);
-    const double step = size * scale * 0.5;
-    const double px = x * scale, py = y * scale;
-    double ang = 360.0 - angle_in;
-    if (fabs(ang - 360.0) < 1.19209e-07) ang = 0.0;
-    const double phi = ang * (3.14159265358979323846 / 180.0);
-    const double s = sin(phi), c = cos(phi);
-    const float stepf = (float)step;
-    const double a00 = (double)((float)c / stepf), a01 = (double)((float)(-s) / stepf), a10 = (double)((float)s / stepf), a11 = (double)((float)c / stepf);
-    const double r = (64 - 1) / 2.0;
-    const double m2 = r - (a00 * px + a01 * py), m5 = r - (a10 * px + a11 * py);
+    double A[6];
+    int l;
+    const int layer = keypoint_affine(kp4, kp_oct, kp, A, &l);
+    const double a00 = A[0], a01 = A[1], m2 = A[2], a10 = A[3], a11 = A[4], m5 = A[5];
     // cv::warpAffine inverts the map in double (imgwarp.cpp)
     double D = a00 * a11 - a01 * a10;
     D = D != 0 ? 1.0 / D : 0.0;
@@ -129,7 +154,6 @@ __global__ __launch_bounds__(256) void patch_kernel(const uint8_t* __restrict__ 
     minv[0] = i0; minv[1] = i1; minv[3] = i3; minv[4] = i4;
     minv[2] = -i0 * m2 - i1 * m5;
     minv[5] = -i3 * m2 - i4 * m5;
-    const int l = (octave + 1) * PYR_LAYERS + layer;
     lvl = (l >= 0 && l < n_levels && layer < PYR_LAYERS) ? l : -1;
     if (lvl < 0) atomicAdd(bad, 1);
   }
@@ -323,6 +347,15 @@ extern "C" int gims_pyramid_build(const uint8_t* img, int32_t h, int32_t w, int3
       hipLaunchKernelGGL(blur_col_kernel, grid(total), dim3(256), 0, s, (const uint16_t*)scratch, L.h, L.w, c, bk[i], pyr + L.offset);
     }
   }
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+extern "C" int gims_patch_affine(const float* kp4, const int32_t* kp_octave, int32_t n_kp, double* A_out, int32_t* level_out, void* stream) {
+  using namespace gims;
+  GIMS_CHECK_ARG(n_kp >= 0 && (n_kp == 0 || (kp4 && kp_octave && A_out && level_out)), "gims_patch_affine: bad arguments");
+  if (n_kp > 0)
+    hipLaunchKernelGGL(patch_affine_kernel, dim3(cdiv(n_kp, 64)), dim3(64), 0, (hipStream_t)stream, kp4, kp_octave, n_kp, A_out, level_out);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

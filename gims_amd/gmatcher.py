@@ -94,8 +94,16 @@ class GMatcher(nn.Module):
         'linear_precision': 'bf16x3',   # 'bf16x3' (split-bf16 MFMA, ~2^-17) or 'f32' (exact-f32 MFMA)
         # 'bf16': plain bf16 MFMA attention (north_star's choice; meets the 1e-4 score bar for diffuse to moderately peaked
         # softmaxes -- mean row maximum up to ~0.2 measured).  'bf16x3': Q, K, V and P as split-bf16 pairs, three MFMAs
-        # per product (GIMS_ATTN_X3) -- for sharply peaked attention (mean row maximum ~0.8: the 'peaked' goldens need it)
-        'attention_precision': 'bf16',
+        # per product (GIMS_ATTN_X3) -- for sharply peaked attention (mean row maximum ~0.8: the 'peaked' goldens need it).
+        # 'auto' (default) picks between the two PER LAYER from the measured peakedness of that layer's softmax rows (mean
+        # over the queries of max_k P[q, k], per head; the kernels report it, gims_attention_stat): the first batch after the
+        # weights change runs every layer at 'bf16x3' and measures; from then on a layer runs in plain bf16 while the
+        # statistic of each of its heads stays below `attention_auto_threshold`, and a bf16 layer that later crosses it is
+        # switched to 'bf16x3' for good: every `attention_monitor_period`-th batch is measured again (the small-launch bf16
+        # kernels report as a by-product, the 8-wave kernel through a sampling kernel of a few microseconds per layer).
+        'attention_precision': 'auto',
+        'attention_auto_threshold': 0.08,
+        'attention_monitor_period': 8,
         'train_precision': 'bf16x6',      # products of the training step (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
         'verbose': False,               # the reference prints '>> ...' timing lines; off by default here
         # fold the attention 'merge' conv into the first MLP conv at load time:
@@ -299,6 +307,77 @@ class GMatcher(nn.Module):
         address is the same from call to call and the recorded launch sequence of the GNN layers can be replayed."""
         nbytes = rows * cols * torch.empty((), dtype=dtype).element_size()
         return self._buf("act_" + name, nbytes)[:nbytes].view(dtype).view(rows, cols)
+
+    # ------------------------------------------------------------------ attention_precision='auto'
+    def _attention_modes(self, P, dev):
+        """Per layer: True = attention_x3_kernel (split-bf16 operands), False = the bf16 kernels; and the device accumulator
+        [layers][heads][4] int64 the kernels report the softmax peakedness into (None when nothing is measured)."""
+        mode, L = self.config['attention_precision'], self.n_layers
+        if mode != 'auto' or not P["x3"]:          # (linear_precision='f32' has no split Q/K/V planes: 'auto' means bf16 there)
+            return [mode == 'bf16x3'] * L, None
+        self._attention_stats_consume(self._lane)
+        st = self.__dict__.get("_attn_auto")
+        if st is None or st["gen"] != P["gen"]:      # new weights: measure every layer at the accurate precision first
+            st = self.__dict__["_attn_auto"] = dict(gen=P["gen"], x3=[True] * L, calibrated=False, peak=np.zeros((L, self._heads)),
+                                                    peak_max=np.zeros((L, self._heads)), switched=[], batches={})
+        n_b = st["batches"][self._lane] = st["batches"].get(self._lane, -1) + 1
+        if st["calibrated"] and n_b % max(1, int(self.config['attention_monitor_period'])) != 0:
+            return list(st["x3"]), None              # not a measured batch
+        nbytes = L * self._heads * 4 * 8
+        stat = self._buf("attn_stat", nbytes)[:nbytes].view(torch.int64).view(L, self._heads, 4)
+        stat.zero_()
+        return list(st["x3"]), stat
+
+    def _attention_stats_enqueue(self, stat):
+        """Asynchronous read-back of this batch's statistics (consumed behind the next host synchronisation of this lane)."""
+        pend = self.__dict__.setdefault("_attn_pending", {})
+        slot = pend.get(self._lane)
+        if slot is None or slot[0].numel() != stat.numel():
+            slot = pend[self._lane] = [torch.empty(stat.shape, dtype=torch.int64, pin_memory=True), None, 0]
+        slot[0].copy_(stat, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        slot[2] = self._attn_auto["gen"]
+
+    def _attention_stats_consume(self, lane=None):
+        """Fold the read-back of `lane` (None: of every lane) into the per-layer decision.  Called by a lane right after the
+        host synchronisation of its next batch's graph build -- its previous batch, read-back included, has finished by then,
+        so WHEN a measurement takes effect does not depend on timing -- and after forward()'s final synchronisation.
+        Decisions only ever move towards 'bf16x3' once the first measurement is in."""
+        st = self.__dict__.get("_attn_auto")
+        for ln, slot in list(self.__dict__.get("_attn_pending", {}).items()):
+            if slot[1] is None or (lane is not None and ln != lane):
+                continue
+            slot[1].synchronize()
+            host, slot[1] = slot[0].numpy().astype(np.float64), None
+            if st is None or slot[2] != st["gen"]:
+                continue
+            cnt = host[:, :, 1]
+            seen = cnt > 0
+            mean = np.where(seen, host[:, :, 0] / np.maximum(cnt, 1.0) / hip.ATTN_STAT_SCALE, 0.0)
+            st["peak"] = np.where(seen, mean, st["peak"])
+            st["peak_max"] = np.maximum(st["peak_max"], np.where(seen, host[:, :, 2] / hip.ATTN_STAT_SCALE, 0.0))
+            thr = float(self.config['attention_auto_threshold'])
+            hot = (mean > thr).any(axis=1)
+            if not st["calibrated"]:
+                if seen.all():
+                    st["x3"] = [bool(h) for h in hot]
+                    st["calibrated"] = True
+            else:
+                for l in np.nonzero(hot)[0]:
+                    if not st["x3"][l]:
+                        st["x3"][l] = True
+                        st["switched"].append(int(l))
+
+    def attention_report(self):
+        """What 'auto' decided: per layer 'bf16' / 'bf16x3', the last measured peakedness per (layer, head), layers switched
+        after the first measurement.  None before the first batch or with a fixed attention_precision."""
+        self._attention_stats_consume()
+        st = self.__dict__.get("_attn_auto")
+        if st is None:
+            return None
+        return dict(modes=['bf16x3' if v else 'bf16' for v in st["x3"]], calibrated=st["calibrated"], peak=st["peak"].copy(),
+                    peak_max=st["peak_max"].copy(), switched=list(st["switched"]), threshold=float(self.config['attention_auto_threshold']))
 
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
     def enable_timing(self, on: bool = True, stepwise: bool = False):
@@ -542,14 +621,19 @@ class GMatcher(nn.Module):
         self_pr = hip.upload(spr, dev, out=self._buf("self_pr", spr.nbytes + 32))
         cross_pr = hip.upload(cpr, dev, out=self._buf("cross_pr", cpr.nbytes + 32))
         max_nq = max(g["n_kept"] for g in images)
-        if cfg['attention_precision'] not in ('bf16', 'bf16x3'):
-            raise ValueError("attention_precision must be 'bf16' or 'bf16x3'")
-        ax3 = cfg['attention_precision'] == 'bf16x3' and x3
+        if cfg['attention_precision'] not in ('auto', 'bf16', 'bf16x3'):
+            raise ValueError("attention_precision must be 'auto', 'bf16' or 'bf16x3'")
         if cfg['attention_precision'] == 'bf16x3' and not x3:
             raise ValueError("attention_precision='bf16x3' needs linear_precision='bf16x3' (the split Q/K/V projection)")
+        # per-layer choice of the attention kernel and, in 'auto' mode, the accumulator its peakedness statistic goes to
+        ax3, stat = self._attention_modes(P, dev)
         # bf16 attention: Q|K|V as one bf16 buffer [rows][768]; x3 attention: the same three matrices as SPL32 hi/lo planes
-        qkv = self._act("qkv", n_tot, (6 if ax3 else 3) * D, torch.bfloat16)
-        qkv_out = dict(out_split=qkv) if ax3 else dict(out_bf16=qkv, flags=self._qkv_flags)
+        qkv_b = self._act("qkv", n_tot, 3 * D, torch.bfloat16) if not all(ax3) else None
+        qkv_s = self._act("qkv6", n_tot, 6 * D, torch.bfloat16) if any(ax3) else None
+        qkv_of = lambda l: qkv_s if ax3[l] else qkv_b                                                       # noqa: E731
+        qkv_out_of = lambda l: dict(out_split=qkv_s) if ax3[l] else dict(out_bf16=qkv_b, flags=self._qkv_flags)   # noqa: E731
+        stat_of = lambda l: None if stat is None else stat[l]                                               # noqa: E731
+        sfx = lambda l: "_x3" if ax3[l] else ""          # stage-timer labels tell the two attention kernels apart       # noqa: E731
         if x3:
             # all GEMM operands travel as split-bf16 SPL32 buffers written by the producing kernel's epilogue; only the
             # residual stream `desc` also exists in f32
@@ -561,25 +645,28 @@ class GMatcher(nn.Module):
             if replay:
                 # the 72 launches of the 18 layers as ONE call into the library (gims_run_ops): their arguments depend only on
                 # the buffer addresses and the batch geometry, which repeat from call to call in steady state
-                key = (P["gen"], n_tot, max_nq, dpl.data_ptr(), mpl.data_ptr(), hpl.data_ptr(), desc.data_ptr(), qkv.data_ptr(),
-                       self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags, ax3)
+                key = (P["gen"], n_tot, max_nq, dpl.data_ptr(), mpl.data_ptr(), hpl.data_ptr(), desc.data_ptr(),
+                       0 if qkv_b is None else qkv_b.data_ptr(), 0 if qkv_s is None else qkv_s.data_ptr(),
+                       0 if stat is None else stat.data_ptr(),
+                       self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags, tuple(ax3))
                 cache = self.__dict__.setdefault("_ops_cache", {})
                 ops = cache.get(key)
                 if ops is None:
                     def la(e, a0, **kw):
                         return hip.op_linear(hip.linear_args(a0, e["w"], w_lo=e["w_lo"], bias=e["b"], precision=e["prec"], spl=e["spl"], **kw))
                     lst = []
-                    for L in P["layers"]:
-                        lst.append(la(L["qkv"], dpl, **qkv_out))
-                        lst.append(hip.op_attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D,
-                                                    out_split=mpl, q_prescaled=True, x3=ax3))
+                    for l, L in enumerate(P["layers"]):
+                        lst.append(la(L["qkv"], dpl, **qkv_out_of(l)))
+                        lst.append(hip.op_attention(qkv_of(l), cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D,
+                                                    out_split=mpl, q_prescaled=True, x3=ax3[l], stat=stat_of(l)))
                         lst.append(la(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl, flags=self._msg_flags))
                         lst.append(la(L["mlp1"], hpl, residual=desc, out=desc, out_split=dpl))
                     if len(cache) > 8:
                         cache.clear()
                     # table, HIP graph, uses, and references to every tensor whose address is baked into the table
-                    ops = cache[key] = [hip.make_ops(lst), None, 0, (P, dpl, mpl, hpl, desc, qkv, self_pr, cross_pr),
-                                        [lab for L in P["layers"] for lab in ("qkv", "attn_cross" if L["cross"] else "attn_self", "mlp", "mlp")]]
+                    ops = cache[key] = [hip.make_ops(lst), None, 0, (P, dpl, mpl, hpl, desc, qkv_b, qkv_s, stat, self_pr, cross_pr),
+                                        [lab for l, L in enumerate(P["layers"])
+                                         for lab in ("qkv" + sfx(l), ("attn_cross" if L["cross"] else "attn_self") + sfx(l), "mlp", "mlp")]]
                 # first use: plain replay (first-use initialisation inside the library); from the second use on a non-default
                 # stream, if GIMS_OPS_GRAPH=1: ONE graph launch
                 ops[2] += 1
@@ -593,11 +680,12 @@ class GMatcher(nn.Module):
                     ops[1].launch()
                 else:
                     hip.run_ops(ops[0])
-            for L in (() if replay else P["layers"]):
-                with St("qkv"):
-                    self._lin(L["qkv"], dpl, **qkv_out)
-                with St("attn_cross" if L["cross"] else "attn_self"):
-                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl, q_prescaled=True, x3=ax3)
+            for l, L in (() if replay else enumerate(P["layers"])):
+                with St("qkv" + sfx(l)):
+                    self._lin(L["qkv"], dpl, **qkv_out_of(l))
+                with St(("attn_cross" if L["cross"] else "attn_self") + sfx(l)):
+                    hip.attention(qkv_of(l), cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl,
+                                  q_prescaled=True, x3=ax3[l], stat=stat_of(l))
                 with St("mlp"):
                     if ln:        # LayerNorm between the two MLP convs: hidden activations in f32, normalised + split by the norm kernel
                         if hid_ln is None:
@@ -620,9 +708,9 @@ class GMatcher(nn.Module):
             hid = torch.empty((n_tot, 2 * D), dtype=torch.float32, device=dev)
             for L in P["layers"]:
                 with St("qkv"):
-                    self._lin(L["qkv"], desc, out_bf16=qkv)
+                    self._lin(L["qkv"], desc, out_bf16=qkv_b)
                 with St("attn_cross" if L["cross"] else "attn_self"):
-                    hip.attention(qkv, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D, q_prescaled=True)
+                    hip.attention(qkv_b, cross_pr if L["cross"] else self_pr, max_nq, self._heads, msg, 0, D, 2 * D, q_prescaled=True)
                 with St("mlp"):
                     act0 = hip.ACT_NONE if ln else hip.ACT_RELU
                     if L["mlp0_fused"] is not None:
@@ -633,6 +721,8 @@ class GMatcher(nn.Module):
                     if ln:
                         hip.layernorm_act(hid, *L["ln"], out=hid)
                     self._lin(L["mlp1"], hid, residual=desc, out=desc)          # desc += delta  (gmatcher.py:142)
+        if stat is not None:
+            self._attention_stats_enqueue(stat)
         # ---- final projection, score matrix, Sinkhorn, selection (gmatcher.py:273-294)
         with St("final_scores"):
             mdesc = self._lin(P["final"], dpl) if x3 else self._lin(P["final"], desc)
@@ -749,6 +839,7 @@ class GMatcher(nn.Module):
         for i, so in enumerate(self._status_offs.tolist()):        # (an index tensor would be a pageable upload in the middle of the stream)
             st[i:i + 1].copy_(uv[so:so + 1], non_blocking=True)
         torch.cuda.current_stream().synchronize()
+        self._attention_stats_consume(self._lane)   # ('auto' attention: the first call's measurement decides the next call's kernels)
         if (st.numpy() == 2.0).any():        # cannot happen (rescued inside gims_sinkhorn_match); never return silently wrong
             raise hip.GimsHipError("the Sinkhorn solve of this batch gave up and was not rescued")
         # the reference's in-place dict mutation (gmatcher.py:244-252); torch.stack raises for ragged B>1, as there

@@ -41,7 +41,7 @@ class AttnArgs(C.Structure):
     _fields_ = [("qkv", C.c_void_p), ("ld", C.c_int64), ("q_col", C.c_int32), ("k_col", C.c_int32), ("v_col", C.c_int32),
                 ("problems", C.c_void_p), ("n_problems", C.c_int32), ("max_n_q", C.c_int32), ("n_heads", C.c_int32),
                 ("out", C.c_void_p), ("ld_out", C.c_int64), ("out_hi", C.c_void_p), ("out_lo", C.c_void_p),
-                ("ld_split", C.c_int64), ("flags", C.c_int32)]
+                ("ld_split", C.c_int64), ("flags", C.c_int32), ("stat", C.c_void_p)]
 
 
 class _OpU(C.Union):
@@ -146,6 +146,9 @@ _SIGNATURES = {
     "gims_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_int32, C.c_void_p]),
+    "gims_attention_stat": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int32, C.c_void_p, C.c_void_p]),
     "gims_kenc_first": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_kenc_first_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
@@ -178,6 +181,7 @@ _SIGNATURES = {
                                       C.POINTER(C.c_size_t)]),
     "gims_pyramid_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gims_patch_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gims_patch_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gims_sinkhorn_history_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gims_sinkhorn_history": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gims_sinkhorn_backward_workspace_bytes": (C.c_size_t, [C.POINTER(OtProblem), C.c_int32]),
@@ -385,12 +389,13 @@ def op_linear(args: LinearArgs) -> Op:
     return o
 
 
-def op_attention(qkv, problems, max_n_q, n_heads, out=None, q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False) -> Op:
+def op_attention(qkv, problems, max_n_q, n_heads, out=None, q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False,
+                 stat=None) -> Op:
     o = Op()
     o.kind = 1
     o.u.att = AttnArgs(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0], max_n_q, n_heads, _p(out),
                        out.stride(0) if out is not None else 0, _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
-                       out_split.stride(0) if out_split is not None else 0, (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0))
+                       out_split.stride(0) if out_split is not None else 0, (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0), _p(stat))
     return o
 
 
@@ -483,18 +488,24 @@ ATTN_Q_SCALE = 0.125 * 1.4426950408889634      # log2(e) / sqrt(64): what q_pres
 ATTN_X3 = 2
 
 
+ATTN_STAT_SCALE = float(1 << 24)       # fixed point of the row maxima in gims_attention_stat's accumulator
+
+
 def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: int, out=None,
-              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False):
+              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False, stat=None):
     """qkv bf16 [rows, ld]; problems int32 [P,4] (q_off, n_q, kv_off, n_kv) on device; out f32 [rows, ld_out]
     and/or out_split = SPL32 bf16 buffer [rows, >= 512].  q_prescaled: Q already carries ATTN_Q_SCALE.
-    x3: qkv is the SPL32 split-bf16 buffer [rows, >= 1536] of the 3-pass projection (GIMS_ATTN_X3)."""
+    x3: qkv is the SPL32 split-bf16 buffer [rows, >= 1536] of the 3-pass projection (GIMS_ATTN_X3).
+    stat: int64 [n_heads, 4] accumulator of the softmax peakedness (gims_attention_stat; zero it before the first use)."""
     lib = load()
     assert qkv.dtype == torch.bfloat16 and problems.dtype == torch.int32 and problems.is_cuda
-    _check(lib.gims_attention(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0],
-                              max_n_q, n_heads, _p(out), out.stride(0) if out is not None else 0, _p(out_split),
-                              (out_split.data_ptr() + 64) if out_split is not None else None,
-                              out_split.stride(0) if out_split is not None else 0,
-                              (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0), _stream()),
+    if stat is not None:
+        assert stat.dtype == torch.int64 and stat.is_contiguous() and stat.numel() >= 4 * n_heads and stat.is_cuda
+    _check(lib.gims_attention_stat(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0],
+                                   max_n_q, n_heads, _p(out), out.stride(0) if out is not None else 0, _p(out_split),
+                                   (out_split.data_ptr() + 64) if out_split is not None else None,
+                                   out_split.stride(0) if out_split is not None else 0,
+                                   (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0), _p(stat), _stream()),
            "gims_attention")
     return out if out is not None else out_split
 
@@ -917,6 +928,14 @@ def patch_extract(pyr: torch.Tensor, dev_levels: torch.Tensor, n_levels: int, kp
     _check(load().gims_patch_extract(_p(pyr), _p(dev_levels), n_levels, _p(kp4), _p(kp_octave), n, _p(out), _p(bad), _stream()), "gims_patch_extract")
     return out, bad
 
+def patch_affine(kp4: torch.Tensor, kp_octave: torch.Tensor):
+    """The 2x3 warp matrix (f64 [N, 2, 3]) and pyramid level (int32 [N]) gims_patch_extract derives per keypoint (library.py:96-106)."""
+    assert kp4.dtype == torch.float32 and kp_octave.dtype == torch.int32 and kp4.is_contiguous() and kp4.is_cuda and kp_octave.is_cuda
+    n = int(kp4.shape[0])
+    A = torch.empty((n, 2, 3), dtype=torch.float64, device=kp4.device)
+    level = torch.empty(n, dtype=torch.int32, device=kp4.device)
+    _check(load().gims_patch_affine(_p(kp4), _p(kp_octave), n, _p(A), _p(level), _stream()), "gims_patch_affine")
+    return A, level
 
 
 # ------------------------------------------------------------------------------------------------ training step (SURVEY 8f, f3)

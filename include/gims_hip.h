@@ -146,6 +146,18 @@ int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col
                    const gims_attn_problem* problems /* device */, int32_t n_problems, int32_t max_n_q,
                    int32_t n_heads, float* out /* may be NULL */, int64_t ld_out,
                    uint16_t* out_hi /* may be NULL */, uint16_t* out_lo, int64_t ld_split, int32_t flags, void* stream);
+/* The same launch, additionally reporting how PEAKED the softmax rows were -- the quantity that decides whether plain bf16
+ * operands keep the reference's 1e-4 score bar (models/gmatcher.py:35-39 computes the softmax in f32): stat is a device array
+ * [n_heads][4] of uint64 {sum over the reported queries of max_k P[q,k] in 2^-24 fixed point, number of reported queries,
+ * largest row maximum (same fixed point), unused}, ACCUMULATED with integer atomics (zero it first; order-independent).
+ * The running-maximum kernels (GIMS_ATTN_X3, the 4-wave and split-key bf16 kernels) report every query as a by-product; the
+ * 8-wave bf16 kernel tracks no maximum, so for launches it serves a second, small kernel measures 32 evenly spaced queries of
+ * every (problem, head) against all keys (a few microseconds).  stat == NULL: exactly gims_attention. */
+int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
+                        const gims_attn_problem* problems /* device */, int32_t n_problems, int32_t max_n_q,
+                        int32_t n_heads, float* out /* may be NULL */, int64_t ld_out,
+                        uint16_t* out_hi /* may be NULL */, uint16_t* out_lo, int64_t ld_split, int32_t flags,
+                        uint64_t* stat /* device, may be NULL */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A recorded sequence of launches replayed by ONE call: the 18 layers of AttentionalGNN.forward (gmatcher.py:127-143) are
@@ -157,6 +169,7 @@ typedef struct gims_attn_args {
   const uint16_t* qkv; int64_t ld; int32_t q_col, k_col, v_col;
   const gims_attn_problem* problems; int32_t n_problems, max_n_q, n_heads;
   float* out; int64_t ld_out; uint16_t* out_hi; uint16_t* out_lo; int64_t ld_split; int32_t flags;
+  uint64_t* stat;                      /* gims_attention_stat's peakedness accumulator, or NULL */
 } gims_attn_args;
 #define GIMS_OP_LINEAR 0
 #define GIMS_OP_ATTENTION 1
@@ -480,6 +493,11 @@ int gims_pyramid_layout(int32_t h, int32_t w, int32_t c, gims_pyr_level* h_level
 int gims_pyramid_build(const uint8_t* img, int32_t h, int32_t w, int32_t c, uint8_t* pyr, void* scratch, void* stream);
 int gims_patch_extract(const uint8_t* pyr, const gims_pyr_level* dev_levels, int32_t n_levels, const float* kp4, const int32_t* kp_octave,
                        int32_t n_kp, float* out, int32_t* bad_count, void* stream);
+/* The per-keypoint arithmetic of gims_patch_extract on its own: A_out [n][6] f64 = the 2x3 map ComputePatches hands to
+ * cv2.warpAffine (utils/library.py:96-106, row-major a00 a01 a02 a10 a11 a12), level_out [n] = the pyramid level it warps,
+ * (octave - firstOctave) * 6 + layer (utils/library.py:100; unchecked).  The same device function as inside patch extraction;
+ * it exists so that this arithmetic can be pinned against the reference's own (tests/golden/patch_affine_*.npz). */
+int gims_patch_affine(const float* kp4, const int32_t* kp_octave, int32_t n_kp, double* A_out, int32_t* level_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training step (SURVEY 8f, row f3 = a25): GMatcher.forward(data, mode='train') on a module in train() mode followed by

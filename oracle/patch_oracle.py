@@ -7,7 +7,11 @@ Restates in NumPy what the reference does between keypoint detection and the CAR
     pts     = ComputePatches(k, pyramid, radius_size=64)              utils/library.py:84-110
     pts     = [cv2.resize(p, (32, 32), interpolation=cv2.INTER_AREA) for p in pts] / 255.0
 
-**PARITY UNPINNED.**  Every arithmetic step here lives in OpenCV (opencv-python==4.9.0.80, requirements:3), which is neither
+**PINNED UP TO OPENCV'S RESAMPLERS.**  What the reference computes ITSELF before it calls OpenCV -- the octave unpacking, the
+2x3 map / pyramid level / size / flags ComputePatches hands to cv2.warpAffine, the octave count, call order and sigma schedule
+of buildGaussianPyramid -- is pinned bit for bit by tests/golden/patch_affine_*.npz and patch_pyramid_calls.npz, recorded from
+the reference's own functions running against an argument-recording cv2 stand-in (tools/gen_golden_patches.py;
+tests/test_patch_oracle_cpu.py).  The pixel arithmetic itself stays **PARITY UNPINNED**: every step of it lives in OpenCV (opencv-python==4.9.0.80, requirements:3), which is neither
 under /root/reference nor installed in this image: `cv2.resize(INTER_LINEAR_EXACT / INTER_NEAREST / INTER_AREA)`,
 `cv2.GaussianBlur` on uint8 (fixed-point kernel with error diffusion, Q8.8 row pass, Q16.16 column pass) and
 `cv2.warpAffine(INTER_CUBIC, BORDER_CONSTANT)` (inverse map in double, 1/32-pixel fixed-point coordinates, 32x32 table of
@@ -108,18 +112,35 @@ def half_nearest(img: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(img[ys][:, xs])
 
 
-def layer_sigmas():
-    """library.py:252-257 with the scalar promotions of the reference's pinned numpy==1.26.4 (requirements:2) written out, so
-    the result does not depend on the NumPy running this file: 1.0 / np.float32(3) and pow(2.0, .) are float64 there, k is
-    rounded to float32, pow(k, np.float32(i-1)) is a float32 power, and its product with the python float sigma is float64
-    (under NumPy 2's NEP 50 that product would stay float32)."""
+def layer_sigmas(promotion: str = "numpy1"):
+    """library.py:252-257, with the scalar promotions written out so the result does not depend on the NumPy running this file.
+    ``"numpy1"`` (default; what the product uses): the reference's pinned numpy==1.26.4 (requirements:2) -- 1.0 / np.float32(3)
+    and pow(2.0, .) are float64 there, k is rounded to float32, pow(k, np.float32(i-1)) is a float32 power, and its product with
+    the python float sigma is float64.  ``"numpy2"``: NumPy >= 2 (NEP 50: python scalars are weak) -- 1.0 / np.float32(3), the
+    power, both products and the square root all stay float32.  The second is what the golden fixture records (the reference
+    runs under NumPy 2 in the build container); the two schedules differ by <= 3e-7 relative and give the same Q8.8 kernels."""
     sig = [SIGMA]
-    k = np.float32(pow(2.0, 1.0 / float(np.float32(N_OCTAVE_LAYERS))))
+    if promotion == "numpy1":
+        k = np.float32(pow(2.0, 1.0 / float(np.float32(N_OCTAVE_LAYERS))))
+        for i in range(1, N_OCTAVE_LAYERS + 3):
+            sig_prev = float(pow(k, np.float32(i - 1))) * SIGMA            # scalar float32 power (libm powf), like the reference's pow()
+            sig_total = sig_prev * float(k)
+            sig.append(float(np.sqrt(sig_total * sig_total - sig_prev * sig_prev)))
+        return sig
+    if promotion != "numpy2":
+        raise ValueError(promotion)
+    f32 = np.float32
+    k = f32(pow(f32(2.0), f32(1.0) / f32(N_OCTAVE_LAYERS)))
     for i in range(1, N_OCTAVE_LAYERS + 3):
-        sig_prev = float(np.power(k, np.float32(i - 1), dtype=np.float32)) * SIGMA
-        sig_total = sig_prev * float(k)
-        sig.append(float(np.sqrt(sig_total * sig_total - sig_prev * sig_prev)))
+        sig_prev = f32(pow(k, f32(i - 1)) * f32(SIGMA))
+        sig_total = f32(sig_prev * k)
+        sig.append(float(np.sqrt(f32(f32(sig_total * sig_total) - f32(sig_prev * sig_prev)))))
     return sig
+
+
+def n_octaves(rows: int, cols: int) -> int:
+    """library.py:248-250 on the DOUBLED image size (rows, cols): round(log(float32(min)) / log(2.0) - 2) - firstOctave."""
+    return int(np.int32(np.round(np.log(np.float32(min(cols, rows))) / np.log(2.0) - 2) - FIRST_OCTAVE))
 
 
 def build_pyramid(base: np.ndarray):
@@ -127,7 +148,7 @@ def build_pyramid(base: np.ndarray):
     nOctaves * 6 uint8 images.  Note: unlike OpenCV's SIFT the first image of octave 0 is the UNBLURRED doubled input."""
     base = up2x_linear_exact(base)
     rows, cols = base.shape[:2]
-    n_oct = int(np.int32(np.round(np.log(np.float32(min(cols, rows))) / np.log(2.0) - 2) - FIRST_OCTAVE))
+    n_oct = n_octaves(rows, cols)
     sig = layer_sigmas()
     L = N_OCTAVE_LAYERS + 3
     pyr = []

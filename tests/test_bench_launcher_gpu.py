@@ -1,0 +1,33 @@
+"""`python bench.py --gpus N` without a launcher (bench.py:spawn_ranks; the reference's launch shape is mp.spawn, train.py:189-197,
+231): the N ranks are child processes created BEFORE the launcher touches the GPU, every rank matches its shard of the pairs
+and the per-pair statistics are all-gathered.  Run here as a fresh child process with two ranks sharing the one GPU of the
+test box over gloo (GIMS_BENCH_BACKEND=gloo; the streamed Sinkhorn, because two processes cannot both own the whole chip);
+on an 8-GPU node the same code path runs over RCCL, one rank per GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_self_launch_two_ranks():
+    env = dict(os.environ, GIMS_BENCH_BACKEND="gloo", GIMS_OT_RESIDENT="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--kpts", "256", "--pairs", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]              # rank 0 prints ONE JSON line; the other rank's stdout is dropped
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["world_size_seen"] == 2
+    assert res["stats_rows_gathered"] == 4                 # 2 pairs per rank, all-gathered
+    assert sorted(x["rank"] for x in res["ranks"]) == [0, 1] and all(x["backend"] == "gloo" for x in res["ranks"])
+    assert len({x["pid"] for x in res["ranks"]}) == 2      # two processes, neither of them the launcher
+    assert res["scaling"] == "weak" and res["value"] > 0 and res["steps"] == 2 and res["warmup"] == 1
+    assert res["matches_pair0"]["matched"] > 128

@@ -23,8 +23,16 @@ def models(synth_sd):
             m = GMatcher({"sinkhorn_iterations": iters, "match_threshold": thr, "linear_precision": prec.split("-")[0],
                           "fuse_merge": not prec.endswith("unfused")}).eval()
             m.load_state_dict(synth_sd)
+            _settle(m)
             out[(prec, iters)] = m
     return out
+
+
+def _settle(m):
+    """attention_precision='auto' (the default): the first call after the weights change measures every layer at bf16x3 and
+    decides; tests that compare calls with each other start from the settled state."""
+    m(pair_to_data(synth.make_pair(256, 1002), 15, 2, 7, device="cuda"))
+    assert m.attention_report() is None or m.attention_report()["calibrated"]
 
 
 def _compare(out, data, g, thr):
@@ -82,20 +90,71 @@ def test_e2e_vs_reference_golden(models, monkeypatch, name, prec, sinkhorn):
 def test_e2e_sharp_attention_vs_reference_golden(monkeypatch, name, sinkhorn):
     """Trained-like, PEAKED attention (query / key projections of every layer scaled up: mean row maximum of the softmax
     0.21 for the 'sharp' fixtures and 0.76 for the 'peaked' ones, against 0.007 with the default synthetic weights).  The
-    reference produced the goldens with the same weights; bars as everywhere: indices exact, scores within 1e-4."""
+    reference produced the goldens with the same weights; bars as everywhere: indices exact, scores within 1e-4.
+    The model is built WITHOUT naming an attention precision: the default ('auto') measures the peakedness itself and routes
+    the layers that need it to the split-bf16 kernel (plain bf16 attention is at 3.1e-4 on the 'peaked' fixtures).  Both the
+    measuring first call and the settled second call are held to the bars."""
     monkeypatch.setenv("GIMS_OT_RESIDENT", "0" if sinkhorn == "streamed" else "2")
     g = load_golden(name)
     n, seed, rad, pct, ms, iters = [int(x) for x in g["meta"]]
     gq = float(g["gain_qk"])
-    # plain bf16 attention holds the bar up to the 'sharp' weights (measured); the 'peaked' ones need the split-bf16 mode
-    # (with bf16 attention their score error is 3.1e-4: indices still exact, scores over the 1e-4 bar)
-    m = GMatcher({"sinkhorn_iterations": iters, "match_threshold": float(g["match_threshold"]),
-                  "attention_precision": "bf16x3" if name.startswith("peaked") else "bf16"}).eval()
+    m = GMatcher({"sinkhorn_iterations": iters, "match_threshold": float(g["match_threshold"])}).eval()
+    assert m.config["attention_precision"] == "auto"
     m.load_state_dict(synth.make_state_dict(123, gains={"attn.proj.0": gq, "attn.proj.1": gq}))
-    data = pair_to_data(synth.make_pair(n, seed), rad, pct, ms, device="cuda")
-    out = m(data)
-    stats = _compare(out, data, g, float(g["match_threshold"]))
-    print(name, sinkhorn, stats)
+    for call in ("measuring", "settled"):
+        data = pair_to_data(synth.make_pair(n, seed), rad, pct, ms, device="cuda")
+        out = m(data)
+        stats = _compare(out, data, g, float(g["match_threshold"]))
+        rep = m.attention_report()
+        print(name, sinkhorn, call, stats, "x3 layers:", rep["modes"].count("bf16x3"), "peak per layer:", np.round(rep["peak"].max(1), 3))
+    assert rep["calibrated"]
+    if name.startswith("peaked"):
+        assert rep["modes"].count("bf16x3") >= 12, rep["modes"]          # mean row maximum 0.76: (nearly) every layer is over the threshold
+
+
+def test_auto_attention_settles_on_bf16_and_switches_when_a_layer_sharpens(synth_sd):
+    """attention_precision='auto' with the default synthetic weights (mean row maximum 0.007): the first call measures at
+    bf16x3, every later call runs the plain bf16 kernels and still agrees with the measuring call within the score bar; the bf16
+    layers keep being measured -- lowering the threshold under their statistic switches them to bf16x3 on the next call."""
+    m = GMatcher({"attention_monitor_period": 1}).eval()       # (measure every call, so that the test does not have to count them)
+    m.load_state_dict(synth_sd)
+    mk = lambda: pair_to_data(synth.make_pair(1024, 1003), 15, 2, 7, device="cuda")      # noqa: E731
+    o1 = m(mk())
+    rep = m.attention_report()
+    assert rep["calibrated"] and rep["modes"] == ["bf16"] * 18, rep
+    assert 0 < rep["peak"].max() < 0.05
+    o2 = m(mk())
+    np.testing.assert_array_equal(o1["matches0"].cpu().numpy(), o2["matches0"].cpu().numpy())
+    assert np.abs(o1["matching_scores0"].cpu().numpy() - o2["matching_scores0"].cpu().numpy()).max() < 5e-5
+    rep2 = m.attention_report()                    # the settled call reported too (split-key / sampled 8-wave kernels)
+    assert (rep2["peak"] > 0).all() and np.abs(rep2["peak"] - rep["peak"]).max() < 0.2 * rep["peak"].max()
+    m.config["attention_auto_threshold"] = 0.5 * float(rep2["peak"].max(1).min())
+    m(mk())                                        # measured over the (new) threshold on this call ...
+    rep3 = m.attention_report()
+    assert rep3["modes"] == ["bf16x3"] * 18 and sorted(rep3["switched"]) == list(range(18))
+    o4 = m(mk())                                   # ... so this one runs at bf16x3
+    np.testing.assert_array_equal(o1["matches0"].cpu().numpy(), o4["matches0"].cpu().numpy())
+    np.testing.assert_allclose(o1["matching_scores0"].cpu().numpy(), o4["matching_scores0"].cpu().numpy(), atol=1e-6)
+    # match_pairs (ragged batch, 8-wave kernels on sampled workgroups) settles the same way
+    m2 = GMatcher({"attention_monitor_period": 1}).eval()
+    m2.load_state_dict(synth_sd)
+    batch = lambda: [pair_to_data(synth.make_pair(1024, 1000 + i), 15, 2, 7, device="cuda") for i in range(8)]      # noqa: E731
+    m2.match_pairs(batch())
+    r1 = m2.match_pairs(batch())
+    torch.cuda.synchronize()
+    repb = m2.attention_report()
+    assert repb["calibrated"] and repb["modes"] == ["bf16"] * 18
+    m2.match_pairs(batch())
+    torch.cuda.synchronize()
+    repc = m2.attention_report()
+    # (the settled batch is measured by the sampling kernel: 32 queries per problem and head instead of all of them)
+    assert (repc["peak"] > 0).all() and np.abs(repc["peak"] - repb["peak"]).max() < 0.5 * repb["peak"].max()
+    m3 = GMatcher({"attention_precision": "bf16"}).eval()
+    m3.load_state_dict(synth_sd)
+    r3 = m3.match_pairs(batch())
+    for a, b in zip(r1, r3):
+        np.testing.assert_array_equal(a["matches0"].cpu().numpy(), b["matches0"].cpu().numpy())
+        assert np.abs(a["matching_scores0"].cpu().numpy() - b["matching_scores0"].cpu().numpy()).max() < 5e-5
 
 
 @pytest.mark.parametrize("name", golden_names("full_"))
@@ -201,6 +260,7 @@ def test_replayed_layers_equal_stepwise(synth_sd):
     pairs = [synth.make_pair(n, s) for n, s in ((256, 1002), (512, 1004), (256, 1003))]
     m = GMatcher({}).eval()
     m.load_state_dict(synth_sd)
+    _settle(m)
     res = []
     for timed in (False, True, False):           # replay (cold cache), stepwise, replay (warm cache)
         m.enable_timing(timed, stepwise=timed)
@@ -365,6 +425,7 @@ def test_matching_without_keypoints_through_a_front_end(synth_sd):
 
     m = Matching({"front_end": front_end}).eval()
     m.gmodel.load_state_dict(synth_sd)
+    _settle(m.gmodel)
     dev = torch.device("cuda")
     out = m({"image0": pair["image0"], "image1": pair["image1"], "carhynet": "the-net", "device": dev, "radius": 15, "percentile": 2, "min_size": 7})
     assert len(order) == 2

@@ -265,6 +265,62 @@ def test_attention(hip, monkeypatch, sizes, sharp, kernel, prescaled):
         assert (np.abs(rec[qo:qo + nq] - o[qo:qo + nq]) <= np.abs(o[qo:qo + nq]) * 2.0 ** -15 + 1e-30).all()
 
 
+@pytest.mark.parametrize("kernel", ["4wave", "4wave2", "8", "split", "split4", "x3"])
+@pytest.mark.parametrize("sharp", [1.0, 4.0])
+def test_attention_peak_statistic(hip, monkeypatch, kernel, sharp):
+    """gims_attention_stat: per head, sum / count / maximum of the softmax row maxima (2^-24 fixed point), what
+    attention_precision='auto' decides from -- against the float64 softmax of the same bf16 operands.  The running-maximum
+    kernels report every query; launches served by the 8-wave kernel are measured by the sampling kernel (32 evenly spaced
+    queries of every (problem, head) against all keys)."""
+    env = {"4wave": ("1", None), "4wave2": ("2", None), "8": ("8", None), "split": ("3", "2"), "split4": ("3", "4"), "x3": (None, None)}[kernel]
+    if env[0]:
+        monkeypatch.setenv("GIMS_ATTN_QP", env[0])
+    if env[1]:
+        monkeypatch.setenv("GIMS_ATTN_SPLIT", env[1])
+    r = _rng(17)
+    sizes = [(700, 900), (900, 700), (64, 64)]
+    rows = sum(a + b for a, b in sizes)
+    qkv = (r.normal(size=(rows, 768)) * np.r_[np.full(512, sharp), np.ones(256)]).astype(np.float32)
+    qkv[:, :256] *= np.float32(hip.ATTN_Q_SCALE)
+    probs, off = [], 0
+    for nq, nk in sizes:
+        probs.append((off, nq, off + nq, nk))
+        off += nq + nk
+    pr = torch.tensor(probs, dtype=torch.int32, device="cuda")
+    stat = torch.zeros((4, 4), dtype=torch.int64, device="cuda")
+    if kernel == "x3":
+        qd = hip.split_spl32(_dev(qkv))
+        f = qkv.astype(np.float64)
+        hip.attention(qd, pr, 900, 4, None, out_split=torch.zeros((rows, 512), dtype=torch.bfloat16, device="cuda"), q_prescaled=True, x3=True, stat=stat)
+    else:
+        qb = torch.from_numpy(qkv).to(torch.bfloat16)
+        f = qb.float().numpy().astype(np.float64)
+        hip.attention(qb.cuda(), pr, 900, 4, torch.empty((rows, 256), dtype=torch.float32, device="cuda"), q_prescaled=True, stat=stat)
+    got = stat.cpu().numpy().astype(np.float64)
+    ref_sum, ref_cnt, ref_max = np.zeros(4), np.zeros(4), np.zeros(4)
+    for p, (qo, nq, ko, nk) in enumerate(probs):
+        q = f[qo:qo + nq, 0:256].reshape(nq, 4, 64)
+        k = f[ko:ko + nk, 256:512].reshape(nk, 4, 64)
+        sc = np.einsum("qhd,khd->hqk", q, k) * np.log(2.0)              # Q carries log2(e) / sqrt(dh)
+        pm = np.exp(sc - sc.max(-1, keepdims=True))
+        pmax = 1.0 / pm.sum(-1)                                          # [head][query]
+        for h in range(4):
+            if kernel == "8":        # attention_peak_sample_kernel: query j * n_q / n_s, j < n_s = min(32, n_q)
+                n_s = min(32, nq)
+                sel = (np.arange(n_s) * nq) // n_s
+            else:
+                sel = np.arange(nq)
+            ref_sum[h] += pmax[h, sel].sum()
+            ref_cnt[h] += len(sel)
+            if len(sel):
+                ref_max[h] = max(ref_max[h], pmax[h, sel].max())
+    np.testing.assert_array_equal(got[:, 1], ref_cnt)
+    tol = 2e-3 if kernel == "x3" else 6e-2            # bf16 logits move the probabilities by a few per cent
+    np.testing.assert_allclose(got[:, 0] / 2 ** 24, ref_sum, rtol=tol)
+    np.testing.assert_allclose(got[:, 2] / 2 ** 24, ref_max, rtol=3 * tol)
+    assert (got[:, 3] == 0).all()
+
+
 @pytest.mark.parametrize("prescaled", [False, True])
 @pytest.mark.parametrize("sizes,sharp", [([(64, 64)], 1.0), ([(200, 333), (333, 200)], 1.0), ([(1, 5), (129, 64), (1000, 777)], 1.0),
                                          ([(256, 256)], 6.0), ([(500, 300)], 12.0)])

@@ -33,6 +33,19 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(hip.AgcImage) == 3 * 8 + 2 * 4 + 3 * 8 + 8 + 8      # max_edges_dir is padded to 8
     assert ctypes.sizeof(hip.PackImage) == 7 * 8 + 4 * 4
     assert ctypes.sizeof(hip.IngestImage) == 4 * 8 + 2 * 4
+    assert ctypes.sizeof(hip.AttnArgs) == 8 + 8 + 3 * 4 + 4 + 8 + 3 * 4 + 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8      # ... flags, pad, stat
+    assert ctypes.sizeof(hip.Op) == 8 + ctypes.sizeof(hip.LinearArgs)                         # the union is as large as its linear arm
+
+
+def test_pyramid_layout_equals_the_reference_schedule(golden_dir):
+    """gims_pyramid_layout (host arithmetic only): number of levels and every level's size, against what the reference's
+    buildGaussianPyramid produced for the same image sizes (tests/golden/patch_pyramid_calls.npz, tools/gen_golden_patches.py)."""
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "patch_pyramid_calls.npz"))
+    for (h, w) in g["shapes"]:
+        levels, _, _ = hip.pyramid_layout(int(h), int(w), 3)
+        assert len(levels) == int(g[f"{h}x{w}/n_levels"])
+        assert [[L.h, L.w] for L in levels] == g[f"{h}x{w}/level_shapes"].tolist()
 
 
 def test_missing_library_fails_loudly(tmp_path):

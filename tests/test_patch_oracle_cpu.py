@@ -1,9 +1,76 @@
-"""Known-answer tests of the patch-extraction oracle (oracle/patch_oracle.py): closed-form properties that hold for the
-algorithms it restates (OpenCV is not available, so there is no golden vector from the reference for this row: parity
-unpinned, see the oracle's header).  CPU only."""
+"""The patch-extraction oracle (oracle/patch_oracle.py), CPU only.
+  * PINNED against the reference: everything the reference computes itself before it calls OpenCV -- octave unpacking, the
+    2x3 map / level / size / flags handed to cv2.warpAffine, octave count, call order and sigma schedule of the pyramid --
+    against tests/golden/patch_affine_*.npz and patch_pyramid_calls.npz (tools/gen_golden_patches.py: the reference's own
+    functions run against an argument-recording cv2 stand-in);
+  * known-answer tests of the OpenCV resamplers it restates (closed-form properties; OpenCV is not available, so that part
+    has no golden vector: parity unpinned, see the oracle's header)."""
+import os
+
 import numpy as np
+import pytest
 
 from oracle import patch_oracle as P
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLD) if f.startswith("patch_affine_")))
+def test_keypoint_affine_equals_the_reference_bit_for_bit(name):
+    """unpackSIFTOctave (library.py:16-35) and the arguments ComputePatches gives cv2.warpAffine (library.py:96-108): 220
+    keypoints over octaves -1..3, layers 0..3, angles 0 / 360 - eps / arbitrary."""
+    g = np.load(os.path.join(GOLD, name))
+    assert len(g["kp4"]) >= 200 and set(g["octave_layer"][:, 0]) == {-1, 0, 1, 2, 3} and set(g["octave_layer"][:, 1]) == {0, 1, 2, 3}
+    assert list(g["A_dtype"]) == ["float64"] and g["dsize"].tolist() == [[64, 64]]
+    assert g["flags"].tolist() == [2] and g["border"].tolist() == [0]            # INTER_CUBIC, BORDER_CONSTANT
+    assert g["patch_shape"].tolist() == [64, 64, 3] and str(g["patch_dtype"]) == "float32"
+    for i, (kp, packed) in enumerate(zip(g["kp4"], g["packed_octave"])):
+        octave, layer, scale = P.unpack_octave(int(packed))
+        assert (octave, layer) == tuple(g["octave_layer"][i]) and scale == g["scale"][i]
+        A, level = P.keypoint_affine(kp[:2], kp[2], kp[3], int(packed), radius_size=64)
+        assert level == g["level"][i]
+        assert A.dtype == np.float64 and A.tobytes() == g["A"][i].tobytes(), (i, A, g["A"][i])
+    # the 360 - eps branch of library.py:99 is exercised both ways
+    near = np.abs((360.0 - g["kp4"][:, 3]) - 360.0) < 1.19209e-07
+    assert near.any() and (~near).any()
+
+
+def test_pyramid_schedule_equals_the_reference():
+    """buildGaussianPyramid (library.py:234-271): number of levels, the order of resize / blur calls, level sizes, resize
+    arguments and the sigma of every blur, as recorded from the reference (running under NumPy 2: `numpy2` promotion)."""
+    g = np.load(os.path.join(GOLD, "patch_pyramid_calls.npz"))
+    assert str(g["numpy_version"]).startswith("2.")
+    nep = P.layer_sigmas("numpy2")
+    leg = P.layer_sigmas("numpy1")
+    for (h, w) in g["shapes"]:
+        key = f"{h}x{w}/"
+        n_oct = P.n_octaves(2 * h, 2 * w)
+        assert g[key + "n_levels"] == 6 * n_oct
+        # call order: one 2x INTER_LINEAR_EXACT upsampling, then per octave [resize INTER_NEAREST unless first] + 5 blurs
+        kinds = [0] + [k for o in range(n_oct) for k in (([] if o == 0 else [0]) + [1] * 5)]
+        assert g[key + "kinds"].tolist() == kinds
+        rs = g[key + "resize"]                        # fx, fy, interpolation, src h, src w, dst h, dst w
+        assert rs[0].tolist() == [2.0, 2.0, 5.0, h, w, 2 * h, 2 * w]
+        assert (rs[1:, :3] == [0.5, 0.5, 0.0]).all()
+        # level sizes, incl. cvRound(n / 2) of odd sizes: the oracle's own pyramid for the small images, its size rule for the rest
+        if h * w <= 320 * 240:
+            shapes = [list(p.shape[:2]) for p in P.build_pyramid(np.zeros((h, w, 3), dtype=np.uint8))]
+        else:
+            shapes, hh, ww = [], 2 * h, 2 * w
+            for o in range(n_oct):
+                if o:
+                    hh, ww = P.half_nearest(np.zeros((hh, ww, 1), np.uint8)).shape[:2]
+                shapes += [[hh, ww]] * 6
+        assert shapes == g[key + "level_shapes"].tolist()
+        assert g[key + "blur_ksize"].tolist() == [[0, 0]] and list(g[key + "blur_sigma_type"]) == ["float32"]
+        sig = g[key + "blur_sigma"]
+        assert (sig == g[key + "blur_sigma_y"]).all()
+        want = np.array(nep[1:] * n_oct, dtype=np.float64)
+        assert sig.tobytes() == want.tobytes()                                           # bit for bit
+    # the product uses the reference's PINNED numpy (1.26: float64 products, library.py:252-257) -- same kernels either way
+    for a, b in zip(leg[1:], nep[1:]):
+        assert abs(a - b) <= 3e-7 * a
+        assert (P.gaussian_kernel_q8(a) == P.gaussian_kernel_q8(b)).all()
 
 
 def _img(h, w, seed=0):

@@ -43,6 +43,35 @@ def random_keypoints(n, h, w, seed, octaves=(-1, 0, 1), n_levels=None):
     return out
 
 
+def test_keypoint_affine_equals_the_reference_bit_for_bit(golden_dir):
+    """The per-keypoint arithmetic inside gims_patch_extract (one lane per keypoint: octave unpacking, the float32 / float64 mix
+    of the 2x3 map, the pyramid level) through gims_patch_affine, against what the REFERENCE's ComputePatches handed to
+    cv2.warpAffine for the same keypoints (tests/golden/patch_affine_*.npz, tools/gen_golden_patches.py): bit for bit."""
+    import os
+    names = sorted(f for f in os.listdir(golden_dir) if f.startswith("patch_affine_"))
+    assert names
+    for name in names:
+        g = np.load(os.path.join(golden_dir, name))
+        kp4 = g["kp4"].astype(np.float32)
+        assert (kp4.astype(np.float64) == g["kp4"]).all()                 # cv2.KeyPoint attributes are C floats
+        A, level = hip.patch_affine(torch.from_numpy(kp4).cuda(), torch.from_numpy(g["packed_octave"].astype(np.int32)).cuda())
+        np.testing.assert_array_equal(level.cpu().numpy(), g["level"])
+        A = A.cpu().numpy()
+        bad = np.nonzero((A.view(np.int64) != g["A"].view(np.int64)).any(axis=(1, 2)))[0]
+        assert len(bad) == 0, f"{len(bad)} of {len(A)} matrices differ from the reference's, e.g. #{bad[0]}: {A[bad[0]]} vs {g['A'][bad[0]]}"
+
+
+def test_pyramid_layout_equals_the_reference_schedule(golden_dir):
+    """gims_pyramid_layout: the number of levels and every level's size against what the reference's buildGaussianPyramid
+    produced for the same image sizes (recorded call sequence, tests/golden/patch_pyramid_calls.npz)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "patch_pyramid_calls.npz"))
+    for (h, w) in g["shapes"]:
+        levels, _, _ = hip.pyramid_layout(int(h), int(w), 3)
+        assert len(levels) == int(g[f"{h}x{w}/n_levels"])
+        assert [[L.h, L.w] for L in levels] == g[f"{h}x{w}/level_shapes"].tolist()
+
+
 @pytest.mark.parametrize("h,w,seed", [(96, 128, 0), (75, 101, 1), (33, 250, 2)])
 def test_pyramid_bit_exact(h, w, seed):
     img = texture(h, w, seed)

@@ -19,14 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--kpts", type=int, default=8192)
-    ap.add_argument("--pairs", type=int, default=2)
-    ap.add_argument("--reps", type=int, default=3)
-    a = ap.parse_args()
-    import __graft_entry__
-    __graft_entry__.build()
+PEAK_BF16_TFLOPS = 2500.0
+CARHYNET_MFLOP_PER_PATCH = 84.5          # flop counter on the reference's CAR_HyNet, one 32x32x3 patch
+
+
+def measure(kpts=8192, pairs=2, reps=3):
+    """The JSON block of one measurement (also embedded in bench.py's line as also["pipeline_2x8192"])."""
     from gims_amd import GMatcher, synth
     from gims_amd.carhynet import CARHyNet
     torch.set_grad_enabled(False)
@@ -36,9 +34,9 @@ def main():
     matcher.load_state_dict(synth.make_state_dict(123))
     dev = "cuda"
     work = []
-    for p in range(a.pairs):
-        pair = synth.make_pair(a.kpts, 1000 + p)
-        p0 = synth.make_patches(a.kpts, 50 + p)
+    for p in range(pairs):
+        pair = synth.make_pair(kpts, 1000 + p)
+        p0 = synth.make_patches(kpts, 50 + p)
         perm = pair["gt_perm"]                                   # keypoint i of image 0 is keypoint perm[i] of image 1
         p1 = np.empty_like(p0)
         p1[perm] = np.clip(p0 + 0.01 * np.random.default_rng(p).normal(size=p0.shape).astype(np.float32), 0, 1)
@@ -64,19 +62,40 @@ def main():
         torch.cuda.synchronize()
         return r, time.perf_counter() - t0
 
-    for _ in range(2):
+    for _ in range(3):                                           # (the first matcher call measures the attention peakedness at bf16x3)
         outs = match(descriptors())
     t_desc = t_match = t_all = 0.0
-    for _ in range(a.reps):
+    for _ in range(reps):
         descs, dt = timed(descriptors); t_desc += dt
         outs, dt = timed(match, descs); t_match += dt
         outs, dt = timed(lambda: match(descriptors())); t_all += dt
     m0 = outs[0]["matches0"][0].cpu().numpy()
     perm = work[0][3]
-    print(json.dumps({"metric": f"image-pairs/sec at 2x{a.kpts} keypoints INCLUDING CAR-HyNet descriptor extraction", "value": a.pairs * a.reps / t_all,
-                      "unit": "pairs/s", "pairs_per_step": a.pairs, "ms_per_pair": 1e3 * t_all / (a.pairs * a.reps),
-                      "ms_per_pair_descriptors_only": 1e3 * t_desc / (a.pairs * a.reps), "ms_per_pair_matcher_only": 1e3 * t_match / (a.pairs * a.reps),
-                      "matches_pair0": int((m0 >= 0).sum()), "correct_vs_planted_pair0": int(((m0 >= 0) & (m0 == perm[:len(m0)])).sum())}))
+    n_patches = 2 * kpts * pairs * reps
+    ch_tflops = n_patches * CARHYNET_MFLOP_PER_PATCH * 1e6 / t_desc / 1e12
+    return {"metric": f"image-pairs/sec at 2x{kpts} keypoints INCLUDING CAR-HyNet descriptor extraction", "value": pairs * reps / t_all,
+            "unit": "pairs/s", "pairs_per_step": pairs, "steps": reps, "ms_per_pair": 1e3 * t_all / (pairs * reps),
+            "ms_per_pair_descriptors_only": 1e3 * t_desc / (pairs * reps), "ms_per_pair_matcher_only": 1e3 * t_match / (pairs * reps),
+            "matches_pair0": int((m0 >= 0).sum()), "correct_vs_planted_pair0": int(((m0 >= 0) & (m0 == perm[:len(m0)])).sum()),
+            "data": "synthetic", "dtype": "split-bf16x3 MFMA convolutions (f32-class) + the matcher's dtypes",
+            "config": {"workload": f"{pairs} pairs/step: 32x32x3 patches of 2x{kpts} keypoints -> CAR-HyNet 128-d descriptors (duplicated to 256-d) -> "
+                                   "GMatcher.match_pairs (BASELINE config 5)"},
+            "carhynet": {"patches_per_s": n_patches / t_desc, "bound": "mfma", "achieved": ch_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ch_tflops / PEAK_BF16_TFLOPS, "mfma_passes": 3, "mfma_issue_frac": 3 * ch_tflops / PEAK_BF16_TFLOPS,
+                         "algorithmic_mflop_per_patch": CARHYNET_MFLOP_PER_PATCH,
+                         "note": "whole descriptor network (7 convolutions + SandGlass + FRN/CoordAtt blocks), wall time of the launches between "
+                                 "two device synchronisations"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kpts", type=int, default=8192)
+    ap.add_argument("--pairs", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    import __graft_entry__
+    __graft_entry__.build()
+    print(json.dumps(measure(a.kpts, a.pairs, a.reps)))
 
 
 if __name__ == "__main__":
