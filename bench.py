@@ -246,7 +246,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     # iteration); SURVEY's byte figure is reported as `hbm_equivalent` for orientation only.
     ot_plan = int(getattr(model, "sinkhorn_plan_last", 0))
     if ot_plan > 0:
-        ot_name = "ot_resident_kernel"
+        ot_name = "ot_res2_kernel" if os.environ.get("GIMS_OT_RES2", "1") != "0" else "ot_resident_kernel"
         cand[ot_name] = ("valu", ot_fma_flops / ot_plan, per_step("sinkhorn") / ot_plan, PEAK_F32_VALU_TFLOPS, "TFLOP/s", ot_plan)
     else:
         ot_name = "ot_iter_kernel"
@@ -272,6 +272,10 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
         "ot_resident_kernel": "on-chip Sinkhorn: exp(Z+u+v) stays in registers + LDS for all iterations (no HBM traffic in the loop; real HBM bytes per "
                               "launch in `traffic`), so it is priced on the fp32 vector roof: 2 fma per matrix entry per iteration / 157.3 TFLOP/s; the "
                               "iteration is dominated by the cross-workgroup exchange of column sums (DESIGN.md 4.1), not by the ALU",
+        "ot_res2_kernel": "on-chip Sinkhorn, 2-D decomposition (row groups per XCD x 128-column blocks per CU): exp(Z+u+v) stays in registers + LDS for all "
+                          "iterations, the wide exchanges stay inside one XCD's L2 and one 0.5-KB edge crosses XCDs (DESIGN.md 4.1); priced on the fp32 "
+                          "vector roof: 2 fma per matrix entry per iteration / 157.3 TFLOP/s; `avg_launch_ms` is the stage time (init + solve + selection) "
+                          "per on-chip launch",
         "attention_x3_kernel": "the same flash attention on split-bf16 operand pairs (Q, K, V from the 3-pass projection, P split in registers): THREE "
                                "bf16 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi); `achieved` counts ALGORITHMIC flops, `mfma_issue_frac` is 3x that",
         "attention8_bf16_kernel": "flash-style attention, head dim 64: per 64-key tile a wave issues 16 MFMAs against ~2 VALU/transcendental issues per "

@@ -94,4 +94,10 @@ int upload_table(const void* host, size_t bytes, void* dev, hipStream_t stream);
 int linear_x6_batch_launch(const gims_linear_args* dev_args, int count, int max_m, int max_n, hipStream_t s);
 int split_spl3_launch(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int k, hipStream_t s);
 
+// sinkhorn2d.hip: the 2-D on-chip Sinkhorn (all iterations in one launch; see that file's header)
+struct OtR2Host { const float* z; int64_t ld; int n, m; float* u; float* v; float* status; float norm, log_mu_bin, log_nu_bin; };
+struct OtR2Plan { bool ok; int nx, nc, ppg, ngroups; size_t bytes; };
+OtR2Plan ot_res2_plan(const OtR2Host* pr, int np, int iters);
+int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, char* base, hipStream_t s);
+
 }  // namespace gims

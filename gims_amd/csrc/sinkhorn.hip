@@ -311,7 +311,9 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restr
   }
   if (p.hist && slot >= 0 && g == 1) {                      // ... and u (final since the row kernel of this iteration)
     float* hu = p.hist + (int64_t)slot * (p.n + p.m + 2);
-    for (int i = blockIdx.x * 64 + cl; i <= p.n; i += gridDim.x * 64) hu[i] = p.u[i];
+    // striped over THIS problem's live blocks (blockIdx.x <= m / 64): the grid is sized for the largest m of the call, and the
+    // blocks beyond a smaller problem's columns have returned above
+    for (int i = blockIdx.x * 64 + cl; i <= p.n; i += (p.m / 64 + 1) * 64) hu[i] = p.u[i];
   }
 }
 
@@ -511,7 +513,7 @@ __global__ void train_loss_gather_kernel(const gims_loss_pair* __restrict__ pair
   tag[k] = (int32_t)b | (neg ? (int32_t)0x40000000 : 0);
 }
 
-__global__ __launch_bounds__(1024) void train_loss_reduce_kernel(const float* __restrict__ loss_vec, const int32_t* __restrict__ tag, int K,
+__global__ __launch_bounds__(1024) void train_loss_reduce_kernel(const float* __restrict__ loss_vec, int32_t* __restrict__ tag, int K,
                                                                  int n_pairs, float pos_w, float neg_w, float* __restrict__ out3) {
   __shared__ float pos_mean[1024], neg_mean[1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -523,7 +525,10 @@ __global__ __launch_bounds__(1024) void train_loss_reduce_kernel(const float* __
       if (t & 0x40000000) { ns += loss_vec[k]; nc += 1.f; } else { ps += loss_vec[k]; pc += 1.f; }
     }
     ps = wave_sum(ps); ns = wave_sum(ns); pc = wave_sum(pc); nc = wave_sum(nc);
-    if (lane == 0) { pos_mean[b] = ps / fmaxf(pc, 1.f); neg_mean[b] = ns / fmaxf(nc, 1.f); }   // scatter_mean: empty groups give 0
+    if (lane == 0) {
+      pos_mean[b] = ps / fmaxf(pc, 1.f); neg_mean[b] = ns / fmaxf(nc, 1.f);    // scatter_mean: empty groups give 0
+      tag[K + 2 * b] = (int32_t)pc; tag[K + 2 * b + 1] = (int32_t)nc;          // group sizes, for gims_train_loss_grad
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -942,15 +947,14 @@ __global__ __launch_bounds__(256) void ot_bwd_alpha_kernel(const OtBwd* __restri
 // with x = clamp(out, -100, 0): d/d out = -w / (B cnt) inside the clamp, 0 outside (gmatcher.py:372-385).
 __global__ void train_loss_grad_kernel(const gims_loss_pair* __restrict__ pairs, int n_pairs, const int64_t* __restrict__ gt, int K, float alpha,
                                        const int32_t* __restrict__ tag, float pos_w, float neg_w, float* const* __restrict__ dz_ptrs) {
-  // one thread per ground-truth row; counts per (batch element, sign) are recomputed by a loop over the tags (K <= a few thousand)
+  // one thread per ground-truth row; the group sizes per (batch element, sign) were left behind the tags by gims_train_loss
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
   const int32_t t = tag[k];
   if (t < 0) return;
   const int b = t & 0x3fffffff;
   const bool neg = (t & 0x40000000) != 0;
-  int cnt = 0;
-  for (int q = 0; q < K; ++q) cnt += (tag[q] == t) ? 1 : 0;
+  const int cnt = tag[K + 2 * b + (neg ? 1 : 0)];
   const gims_loss_pair p = pairs[b];
   int r0 = p.n, r1 = p.m;                                   // negatives: the corner cell
   if (!neg) { r0 = kept_find(p.kept0, p.n, gt[3 * k + 1]); r1 = kept_find(p.kept1, p.m, gt[3 * k + 2]); }
@@ -958,7 +962,7 @@ __global__ void train_loss_grad_kernel(const gims_loss_pair* __restrict__ pairs,
   const float* u = p.uv;
   const float* v = p.uv + p.n + 1;
   const float x = neg ? ((alpha + u[p.n]) + v[p.m]) - norm : ((p.scores[(int64_t)r0 * p.ld + r1] + u[r0]) + v[r1]) - norm;
-  if (!(x > -100.f && x < 0.f)) return;                      // clamped: zero gradient (torch.clamp passes the gradient only inside)
+  if (!(x >= -100.f && x <= 0.f)) return;                    // clamped: zero gradient (torch.clamp's backward passes it on [min, max], bounds included)
   const float g = -(neg ? neg_w : pos_w) / ((float)n_pairs * (float)cnt);
   atomicAdd(dz_ptrs[b] + (int64_t)r0 * (p.m + 1) + r1, g);   // equal addends per cell group: the sum does not depend on the order
 }
@@ -1728,6 +1732,19 @@ static int ot_res_run(const OtResPlan& P, const std::vector<OtDev>& hprob, float
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Which on-chip kernel a call uses: the 2-D decomposition of sinkhorn2d.hip (default) or ot_resident_kernel above
+// (GIMS_OT_RES2=0; kept as the cross-check).  Both share the gate of ot_res_plan (GIMS_OT_RESIDENT, the size threshold).
+static OtR2Plan ot_res2_choose(const gims_ot_problem* pr, int np, int iters) {
+  OtR2Plan none{};
+  if (!ot_env("GIMS_OT_RES2", 1) || !ot_env("GIMS_OT_RESIDENT", 1) || iters < 1 || ot_res_cus() < 256) return none;
+  double cells = 0.0;
+  for (int i = 0; i < np; ++i) cells += (double)pr[i].n * pr[i].m;
+  if (cells < 6.0e6 && ot_env("GIMS_OT_RESIDENT", 1) != 2) return none;
+  std::vector<OtR2Host> h(np);
+  for (int i = 0; i < np; ++i) { h[i] = OtR2Host{}; h[i].n = pr[i].n; h[i].m = pr[i].m; }
+  return ot_res2_plan(h.data(), np, iters);
+}
+
 static void ot_launch_shape(const gims_ot_problem* pr, int np, int& threads, int& cpt, int& maxn, int& maxm) {
   maxn = 0; maxm = 0;
   for (int i = 0; i < np; ++i) { maxn = pr[i].n > maxn ? pr[i].n : maxn; maxm = pr[i].m > maxm ? pr[i].m : maxm; }
@@ -1765,12 +1782,15 @@ extern "C" size_t gims_sinkhorn_workspace_bytes(const gims_ot_problem* pr, int32
   ot_launch_shape(pr, np, threads, cpt, maxn, maxm);
   size_t b = al256(sizeof(OtDev) * (size_t)np);
   for (int i = 0; i < np; ++i) b += ot_problem_bytes(pr[i], ot_G(pr[i].n, np, threads, cpt));
-  return b + al256(ot_res_plan(pr, np, 1).bytes);       // resident-path buffers (0 when that path is off or does not fit)
+  const size_t r1 = ot_res_plan(pr, np, 1).bytes, r2 = ot_res2_choose(pr, np, 1).bytes;
+  return b + al256(r1 > r2 ? r1 : r2);                  // on-chip-path buffers (0 when that path is off or does not fit)
 }
 
 extern "C" int gims_sinkhorn_plan(const gims_ot_problem* pr, int32_t np, int32_t iters) {
   using namespace gims;
   if (!pr || np <= 0) return 0;
+  const OtR2Plan p2 = ot_res2_choose(pr, np, iters);
+  if (p2.ok) return p2.ngroups;
   const OtResPlan plan = ot_res_plan(pr, np, iters);
   return plan.ok ? plan.ngroups : 0;
 }
@@ -1821,10 +1841,22 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   const OtDev* dp = (const OtDev*)work;
   hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, iters == 0 ? 1 : 0);
   dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
-  const OtResPlan plan = ot_res_plan(pr, np, iters);
-  if (plan.ok) {      // whole iteration loop on chip (one launch per group of problems)
+  const OtR2Plan plan2 = ot_res2_choose(pr, np, iters);
+  OtResPlan plan = plan2.ok ? OtResPlan{} : ot_res_plan(pr, np, iters);
+  if (plan2.ok) {     // whole iteration loop on chip, 2-D decomposition (sinkhorn2d.hip)
+    std::vector<OtR2Host> h2(np);
+    for (int i = 0; i < np; ++i) {
+      const OtDev& d = hprob[i];
+      h2[i] = OtR2Host{d.z, d.ld, d.n, d.m, d.u, d.v, d.status, d.norm, d.log_mu_bin, d.log_nu_bin};
+    }
+    const int rc = ot_res2_run(plan2, h2.data(), np, alpha, iters, base + off, s);
+    if (rc != GIMS_OK) return rc;
+    plan.ok = true;   // (the rescue and the skipped streamed loop below are shared)
+  } else if (plan.ok) {      // whole iteration loop on chip (one launch per group of problems)
     const int rc = ot_res_run(plan, hprob, alpha, iters, base + off, s);
     if (rc != GIMS_OK) return rc;
+  }
+  if (plan.ok) {
     const int force_fail = ot_env("GIMS_OT_FORCE_FAIL", 0);       // test hook: pretend every resident solve timed out
     if (force_fail) hipLaunchKernelGGL(ot_poison_kernel, dim3(np), dim3(256), 0, s, dp);
     // problems whose on-chip solve gave up (status 2) are re-solved here, before the selection kernels read u and v:

@@ -1,0 +1,689 @@
+// On-chip Sinkhorn, 2-D decomposition (round 3): all iterations of log_sinkhorn_iterations (gmatcher.py:41-47) in ONE launch with
+// the transport matrix resident in registers + LDS, like ot_resident_kernel (sinkhorn.hip) -- but decomposed so that the
+// per-iteration exchanges are small and mostly stay inside one XCD's L2.
+//
+// ot_resident_kernel gives a workgroup a slab of whole ROWS: row sums are local, but the column sums are an all-reduce of an
+// (m+1)-vector over all 128 slabs of a problem -- 16 KB published and 34 KB read per workgroup and iteration, all of it
+// through memory-side (cross-XCD) coherence: 62 % of its 13 us iteration.  Here a problem of (n+1) x (m+1) is cut into
+//     nx row groups (<= 1024 rows each; one group lives on the CUs of ONE XCD)  x  nc column blocks (<= 128 columns each),
+// one workgroup (512 threads, one per CU) per (row group, column block), holding a <= 1024 x 128 block of
+// K = exp(Z + u + v) as 16 x 16 tiles per thread (12 tile rows in registers, 4 in LDS).  Per iteration:
+//   row sums     partial over the 128 columns -> 4 KB published IN THE XCD'S L2 (plain stores, L1-bypassing loads) ->
+//                every workgroup folds 1/nc of the group's rows over the nc blocks, updates u and the cumulative row factor F
+//                -> publishes 4 F per fold lane -> every workgroup of the group reads the group's F (4 KB, same L2);
+//   column sums  partial over the group's rows for the workgroup's OWN 128 columns -> 512 B published cross-XCD
+//                (write-through stores) -> each of the nx workgroups that share the columns reads the other nx - 1 partials
+//                and updates v and the cumulative column factor G for its own columns, redundantly and identically.
+// So the two wide edges (32 participants) never leave the XCD, and the one edge that crosses XCDs has 4 participants and
+// 0.5 KB -- no all-gather of G at all, because a workgroup only ever needs G for its own columns.
+// Numerics: the lazy-scaling form of ot_resident_kernel (K of the last derivation is never rewritten, transport matrix =
+// diag(F) K diag(G), u and v accumulated in the log domain, K re-derived from Z, u, v every `refresh` iterations and on the
+// last one), fixed summation orders everywhere: bitwise deterministic.
+// Exchange protocol: no barrier; every exchanged value is >= +0 and carries the parity of its iteration in the sign bit,
+// readers re-read until it matches (bounded: a wait that runs out flags status 2 and the caller's rescue re-solves).
+// The column edge is double-buffered by iteration parity (its readers are not ordered against its next writer).
+// Placement: the host puts the nc workgroups of a row group on blockIdx values that share b % 8 (observed: block b runs on XCD
+// b % 8).  Each workgroup CHECKS its XCC id against that; on any mismatch the launch uses write-through stores for the local
+// edges too (slower, placement-independent) -- results never depend on where the dispatcher put a workgroup.
+#include "common.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+#include <vector>
+
+namespace gims {
+
+struct OtR2Block { int prob, xr, cc, pad; };
+struct OtR2Dev {
+  const float* z; int64_t ld; int n, m;
+  float* u; float* v; float* status;
+  float norm, log_mu_bin, log_nu_bin;
+  int nx, nc;          // row groups, column blocks (workgroups per row group)
+  int rb, cb;          // rows per row group (<= 1024), columns per block (<= 128, multiple of 4)
+  int rbf, rbs;        // row slots folded per workgroup (multiple of 4), row slots per group = nc * rbf >= rb + 1
+  float* rpart;        // [nx][nc][rbs]  partial row sums (slot nrl of the last group = the dustbin row)
+  float* fbuf;         // [nx][2][rbs]   F (tagged), then u on the iterations that precede a derivation
+  float* cpart;        // [2][nx][nc][R2_CSEG]  partial column sums (slot 128 = the dustbin column, last block only)
+  int* placement;      // [1] set to 1 by any workgroup whose XCC id is not blockIdx % 8
+};
+struct OtR2Args {
+  const OtR2Dev* probs; const OtR2Block* blocks;
+  float alpha; int iters, refresh, wt_local;
+  unsigned long long* prof;
+};
+
+constexpr int R2_CSEG = 132;                    // floats per (workgroup, buffer) of the column edge: 128 columns + dustbin + pad
+constexpr int R2_LDS_K = 16 * 512 * 4;          // 4 tile rows x 4 quads per thread, float4 each
+constexpr int R2_ROWST = 1028, R2_FACS = 1160, R2_GVEC = 132, R2_COLRED = 8 * 128, R2_PB = 1028, R2_PR = 132, R2_CSST = 132, R2_XRD = 4 * R2_CSEG;
+constexpr int R2_OWN = 2 * 132 + 2 * 132;      // v and G of the block's columns; u and F of the row slots this workgroup folds (rbf <= 132)
+constexpr int R2_LDS_FLOATS = R2_LDS_K + R2_ROWST + R2_FACS + R2_GVEC + R2_COLRED + R2_PB + R2_PR + R2_CSST + R2_XRD + 16 + R2_OWN;
+
+typedef float r2f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void r2_st4_wt(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void r2_st4_plain(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void r2_ld4_issue(f32x4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void r2_ld4_wait(f32x4& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void r2_swap16(float& x, float& y) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+__device__ __forceinline__ void r2_swap32(float& x, float& y) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+template <int CTRL>
+__device__ __forceinline__ float r2_dpp_add(float x) {
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// all-reduce over the 8 lanes that share lane >> 3 (the 8 column groups of a tile row)
+__device__ __forceinline__ float r2_sum8(float x) {
+  x = r2_dpp_add<0xB1>(x);      // quad_perm [1,0,3,2]
+  x = r2_dpp_add<0x4E>(x);      // quad_perm [2,3,0,1]
+  return r2_dpp_add<0x141>(x);  // row_half_mirror
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
+#pragma clang fp contract(off)
+  __shared__ int fail_flag;
+  __shared__ unsigned long long prof_acc[8];
+  unsigned long long prof_t = 0;
+  auto stamp = [&](int phase) {
+    if (PROF && threadIdx.x == 0) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      if (phase >= 0) prof_acc[phase] += now - prof_t;
+      prof_t = now;
+    }
+  };
+  if (PROF && threadIdx.x < 8) prof_acc[threadIdx.x] = 0;
+  if (threadIdx.x == 0) fail_flag = 0;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* klds = lds;                       // [16][512] float4: tile rows 12..15 of every thread
+  float* rowst = klds + R2_LDS_K;          // row sums of this block, by row slot (slot nrl of the last group: the dustbin row)
+  float* facs = rowst + R2_ROWST;          // F of the group's row slots
+  float* gvec = facs + R2_FACS;            // G of the block's columns (v ahead of a derivation); [128] = the dustbin column's
+  float* colred = gvec + R2_GVEC;          // [8 waves][128] column partials
+  float* pb = colred + R2_COLRED;          // dustbin-column entries of the group's rows (last column block only)
+  float* pr = pb + R2_PB;                  // dustbin-row entries of the block's columns (last row group only)
+  float* csst = pr + R2_PR;                // this block's column sums, staged for the 16-byte publish
+  float* xrd = csst + R2_CSST;             // [nx][R2_CSEG] column partials of all row groups
+  float* wred = xrd + R2_XRD;              // [16] per-wave partials of the small reductions
+  // state that lives across iterations in LDS rather than in registers (the 192 registers of P leave no room): v and the
+  // cumulative factor G of the block's columns (owner: thread t < 128, thread 128 the dustbin column), u and the cumulative
+  // factor F of the row slots this workgroup folds (owner: the fc == 0 lane of every fold group)
+  float* vown_l = wred + 16;               // [132]
+  float* gown_l = vown_l + 132;            // [132]
+  float* uo_l = gown_l + 132;              // [132]
+  float* fo_l = uo_l + 132;                // [132]
+
+  const OtR2Block bk = a.blocks[blockIdx.x];
+  if (bk.prob < 0) return;
+  const OtR2Dev p = a.probs[bk.prob];
+  const int xr = bk.xr, cc = bk.cc;
+  const float alpha = a.alpha;
+  const int row0 = xr * p.rb;
+  int nrl = p.n - row0;
+  nrl = nrl < p.rb ? nrl : p.rb;
+  nrl = nrl > 0 ? nrl : 0;                                 // real rows of the group
+  const bool lastg = xr == p.nx - 1;
+  const int nslots = nrl + (lastg ? 1 : 0);               // + the dustbin row
+  const int col0 = cc * p.cb;
+  int ncl = p.m - col0;
+  ncl = ncl < p.cb ? ncl : p.cb;
+  ncl = ncl > 0 ? ncl : 0;                                 // real columns of the block
+  const bool lastc = cc == p.nc - 1;
+  const bool wt = a.wt_local != 0;
+  {  // placement check (speed only: see the header)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0 && (xcc & 7u) != (blockIdx.x & 7u)) atomicOr(p.placement, 1);
+  }
+  float* rpart_mine = p.rpart + (int64_t)(xr * p.nc + cc) * p.rbs;
+  const float* rpart_grp = p.rpart + (int64_t)(xr * p.nc) * p.rbs;
+  float* fb = p.fbuf + (int64_t)xr * 2 * p.rbs;
+
+  // K tile of this thread: rows rg*16 + i (i < 16), columns 32 k + 4 cg + e (k < 4, e < 4); rows i < 12 in registers
+  r2f2 P[12][8];
+  // fold duty: thread t reads source block fc = t % nc for quad fq = t / nc of this workgroup's rbf slots (first slot fs0)
+  const int nc_sh = 31 - __builtin_clz((unsigned)p.nc);    // nc is a power of two
+  {
+    const int fc = threadIdx.x & (p.nc - 1), fq = threadIdx.x >> nc_sh, fs0 = cc * p.rbf + 4 * fq;
+    if (4 * fq < p.rbf && fc == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = fs0 + e;
+        uo_l[4 * fq + e] = s < nrl ? p.u[row0 + s] : (s == nrl && lastg ? p.u[p.n] : 0.f);
+        fo_l[4 * fq + e] = 1.f;
+      }
+    }
+  }
+  // column duty: thread t < 128 owns column col0 + t, thread 128 of the last block the dustbin column
+  if (threadIdx.x < 132) { vown_l[threadIdx.x] = 0.f; gown_l[threadIdx.x] = 1.f; }
+  for (int r = threadIdx.x; r < R2_ROWST; r += 512) { rowst[r] = 0.f; pb[r] = 0.f; }
+  for (int r = threadIdx.x; r < R2_FACS; r += 512) facs[r] = 1.f;
+  for (int r = threadIdx.x; r < R2_GVEC; r += 512) { gvec[r] = 0.f; pr[r] = 0.f; csst[r] = 0.f; }     // v0 = 0
+  __syncthreads();
+
+  for (int it = 0; it < a.iters; ++it) {
+    // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration (as loop invariants the
+    // compiler keeps their hoisted addresses alive next to the 192 registers of P)
+    int tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));
+    const int t = tq, lane = t & 63, wave = t >> 6, cg = t & 7, rg = t >> 3;
+    const bool fresh = it == 0 || it == a.iters - 1 || (a.refresh > 0 && it % a.refresh == 0);
+    const bool next_fresh = it + 1 < a.iters && (it + 2 == a.iters || (a.refresh > 0 && (it + 1) % a.refresh == 0));
+    const unsigned tagbit = (unsigned)(it & 1) << 31;
+    const unsigned xtagbit = (unsigned)((it >> 1) & 1) << 31;
+    auto tg = [&](float x) { return __uint_as_float(__float_as_uint(x) | tagbit); };
+    stamp(-1);
+    // ---------------- derivation: K = exp((Z + u) + v) from scratch
+    if (fresh) {
+      const float* usrc = it == 0 ? p.u + row0 : fb + p.rbs;          // u by row slot (iteration 0: by global row)
+      const float u_bin_row = lastg ? (it == 0 ? p.u[p.n] : __hip_atomic_load(usrc + nrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
+      const float* zb = p.z;
+      int row0_o = row0, col0_o = col0;
+      asm volatile("" : "+s"(row0_o), "+s"(col0_o), "+s"(zb));
+      // every load is unconditional with a clamped address (a select behind each load costs an exec-mask save per load: 64 of them
+      // spilled the scalar file); what lies outside the block is masked when the exponentials are formed
+      const int row_hi = p.n - 1, quad_hi = (p.m - 1) & ~3, u_hi = it == 0 ? p.n - row0 : p.rbs - 1;
+      // tile rows two at a time (8 x 16-byte loads in flight per thread), the four LDS rows FIRST: the registers of P fill up as
+      // the loop advances, so the staging registers of the last steps sit next to 160, not 192, live registers of P
+      constexpr int DB = 2;
+#pragma unroll
+      for (int ibs = 0; ibs < 16; ibs += DB) {
+        const int ib = (ibs + 12) % 16;
+        f32x4 zq[DB][4];
+        float ur[DB];
+#pragma unroll
+        for (int i4 = 0; i4 < DB; ++i4) {
+          const int rl = rg * 16 + ib + i4;
+          ur[i4] = __hip_atomic_load(usrc + (rl < u_hi ? rl : u_hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int gr = row0_o + rl;
+          gr = gr < row_hi ? gr : row_hi;
+          const float* zr = zb + (int64_t)gr * p.ld;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            int cq = col0_o + 32 * k + 4 * cg;
+            cq = cq < quad_hi ? cq : quad_hi;                        // rows are padded to 4 floats: the last quad of a row is readable
+            zq[i4][k] = __builtin_nontemporal_load((const f32x4*)(zr + cq));
+          }
+        }
+#pragma unroll
+        for (int i4 = 0; i4 < DB; ++i4) {
+          const int rl = rg * 16 + ib + i4;
+          const bool rin = rl < nrl;
+          f32x4 kq[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const f32x4 vq = *(const f32x4*)(gvec + 32 * k + 4 * cg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = __expf((zq[i4][k][e] + ur[i4]) + vq[e]);
+              kq[k][e] = (rin && 32 * k + 4 * cg + e < ncl) ? x : 0.f;
+            }
+          }
+          if (ib < 12) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              P[(ib + i4) % 12][2 * k] = r2f2{kq[k][0], kq[k][1]};
+              P[(ib + i4) % 12][2 * k + 1] = r2f2{kq[k][2], kq[k][3]};
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ((f32x4*)klds)[((ib + i4 - 12) * 4 + k) * 512 + t] = kq[k];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // borders: dustbin column (last block) by row, dustbin row (last group) by column, corner where both
+      const float vbin = gvec[128];
+      if (lastc) {
+        for (int r = t; r < nrl; r += 512) pb[r] = __expf((alpha + __hip_atomic_load(usrc + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + vbin);
+        if (lastg && t == 0) pb[nrl] = __expf((alpha + u_bin_row) + vbin);
+      }
+      if (lastg && t < 128) pr[t] = t < ncl ? __expf((alpha + u_bin_row) + gvec[t]) : 0.f;
+      __syncthreads();
+      for (int r = t; r < R2_FACS; r += 512) facs[r] = 1.f;
+      for (int r = t; r < R2_GVEC; r += 512) gvec[r] = 1.f;
+      if (t < 132) { gown_l[t] = 1.f; fo_l[t] = 1.f; }
+      __syncthreads();
+    }
+    stamp(0);
+    // ---------------- row pass: sum_j K_ij G_j over the block's columns
+    {
+      r2f2 g2[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 q = *(const f32x4*)(gvec + 32 * k + 4 * cg);
+        g2[2 * k] = r2f2{q[0], q[1]};
+        g2[2 * k + 1] = r2f2{q[2], q[3]};
+      }
+      // four tile rows at a time: four independent fma chains, their 8-lane reductions interleaved, one 16-byte LDS store
+      // (the dustbin column's share, pb_i G_bin, is added when the sums are published)
+#pragma unroll
+      for (int ib = 0; ib < 16; ib += 4) {
+        float s4[4];
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const int i = ib + i4;
+          r2f2 s2;
+          if (i < 12) {
+            s2 = P[i % 12][0] * g2[0];
+#pragma unroll
+            for (int h = 1; h < 8; ++h) s2 = __builtin_elementwise_fma(P[i % 12][h], g2[h], s2);
+          } else {
+            s2 = r2f2{0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const f32x4 q = ((const f32x4*)klds)[((i - 12) * 4 + k) * 512 + t];
+              s2 = __builtin_elementwise_fma(r2f2{q[0], q[1]}, g2[2 * k], s2);
+              s2 = __builtin_elementwise_fma(r2f2{q[2], q[3]}, g2[2 * k + 1], s2);
+            }
+          }
+          s4[i4] = s2[0] + s2[1];
+        }
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) s4[i4] = r2_dpp_add<0xB1>(s4[i4]);
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) s4[i4] = r2_dpp_add<0x4E>(s4[i4]);
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) s4[i4] = r2_dpp_add<0x141>(s4[i4]);
+        if (cg == 0) *(f32x4*)(rowst + rg * 16 + ib) = f32x4{s4[0], s4[1], s4[2], s4[3]};
+      }
+      if (lastg) {        // the dustbin row: sum_j pr_j G_j (the corner is its dustbin-column entry: added at the publish like every row's)
+        __syncthreads();  // (slot nrl is a real-row slot of some thread above when nrl < 1024: it wrote a zero there, overwritten here)
+        if (wave == 0) {
+          float s = pr[lane] * gvec[lane] + pr[lane + 64] * gvec[lane + 64];
+          s = wave_sum(s);
+          if (lane == 0) rowst[nrl] = s;
+        }
+      }
+    }
+    __syncthreads();
+    if (fail_flag) {
+      if (threadIdx.x == 0) p.status[0] = 2.f;
+      return;
+    }
+    stamp(1);
+    // ---------------- publish the row partials (16-byte stores; stay in this XCD's L2 unless wt)
+    if (4 * t < nslots) {
+      f32x4 q = *(const f32x4*)(rowst + 4 * t);
+      if (lastc) {
+        const f32x4 b4 = *(const f32x4*)(pb + 4 * t);
+        const float gbin = gvec[128];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] += b4[e] * gbin;
+      }
+      const f32x4 w = {tg(q[0]), tg(q[1]), tg(q[2]), tg(q[3])};
+      if (wt) r2_st4_wt(rpart_mine + 4 * t, w); else r2_st4_plain(rpart_mine + 4 * t, w);
+    }
+    // ---------------- fold this workgroup's share of the row slots over the nc blocks; u += log f, F *= f
+    // (the fold indices are re-derived from the opaque thread id here: kept across the passes above they are spilled to scratch
+    // and a scratch reload costs more than the fold itself)
+    const int fc = t & (p.nc - 1), fq = t >> nc_sh, fs0 = cc * p.rbf + 4 * fq;
+    const bool folder = 4 * fq < p.rbf;
+    if (folder) {
+      f32x4 q = {0.f, 0.f, 0.f, 0.f};
+      unsigned vmask = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vmask |= (fs0 + e < nslots ? 1u : 0u) << e;
+      if (vmask) {
+        const float* src = rpart_grp + (int64_t)fc * p.rbs + fs0;
+        int spins = 0;
+        for (;;) {
+          r2_ld4_issue(q, src);
+          r2_ld4_wait(q);
+          unsigned stale = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) stale |= ((__float_as_uint(q[e]) ^ tagbit) >> 31) << e;
+          if ((stale & vmask) == 0) break;
+          if (++spins > (1 << 16)) { fail_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      stamp(2);
+      // butterfly over the nc source lanes (the same total, in the same order, in every lane): DPP inside a 16-lane row, one
+      // cross-row exchange for nc = 32
+      f32x4 tot;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tot[e] = (vmask >> e) & 1u ? fabsf(q[e]) : 0.f;
+      if (p.nc >= 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tot[e] = r2_dpp_add<0xB1>(tot[e]);
+      }
+      if (p.nc >= 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tot[e] = r2_dpp_add<0x4E>(tot[e]);
+      }
+      if (p.nc >= 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tot[e] = r2_dpp_add<0x141>(tot[e]);
+      }
+      if (p.nc >= 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tot[e] = r2_dpp_add<0x140>(tot[e]);
+      }
+      if (p.nc >= 32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tot[e] += __shfl_xor(tot[e], 16, 64);
+      }
+      if (fc == 0 && vmask) {
+        f32x4 fw, uo = *(const f32x4*)(uo_l + 4 * fq), fo = *(const f32x4*)(fo_l + 4 * fq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int s = fs0 + e;
+          if (s < nslots) {
+            const float tr = fo[e] * tot[e];                                  // true row sum F_i sum_j K_ij G_j
+            if (!(tr > 0.f) || !(tr < 3.0e38f)) p.status[0] = 1.f;
+            const float du = (s < nrl ? p.norm : p.log_mu_bin) - logf(tr);
+            uo[e] += du;
+            fo[e] *= __expf(du);
+          }
+          fw[e] = tg(fo[e]);
+        }
+        *(f32x4*)(uo_l + 4 * fq) = uo;
+        *(f32x4*)(fo_l + 4 * fq) = fo;
+        if (next_fresh) {                                                    // u first, acknowledged, then the tagged F readers wait on
+          if (wt) r2_st4_wt(fb + p.rbs + fs0, uo); else r2_st4_plain(fb + p.rbs + fs0, uo);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (wt) r2_st4_wt(fb + fs0, fw); else r2_st4_plain(fb + fs0, fw);
+      }
+    }
+    stamp(3);
+    // ---------------- gather the group's F
+    if (4 * t < nslots) {
+      f32x4 q;
+      unsigned vmask = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vmask |= (4 * t + e < nslots ? 1u : 0u) << e;
+      int spins = 0;
+      for (;;) {
+        r2_ld4_issue(q, fb + 4 * t);
+        r2_ld4_wait(q);
+        unsigned stale = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stale |= ((__float_as_uint(q[e]) ^ tagbit) >> 31) << e;
+        if ((stale & vmask) == 0) break;
+        if (++spins > (1 << 16)) { fail_flag = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      *(f32x4*)(facs + 4 * t) = f32x4{fabsf(q[0]), fabsf(q[1]), fabsf(q[2]), fabsf(q[3])};
+    }
+    __syncthreads();
+    stamp(4);
+    // ---------------- column pass: sum_i F_i K_ij over the group's rows, for the block's columns
+    {
+      r2f2 cs2[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) cs2[h] = r2f2{0.f, 0.f};
+#pragma unroll
+      for (int ib = 0; ib < 16; ib += 4) {
+        const f32x4 f4 = *(const f32x4*)(facs + rg * 16 + ib);
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const int i = ib + i4;
+          const r2f2 f2 = {f4[i4], f4[i4]};
+          if (i < 12) {
+#pragma unroll
+            for (int h = 0; h < 8; ++h) cs2[h] = __builtin_elementwise_fma(P[i % 12][h], f2, cs2[h]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const f32x4 q = ((const f32x4*)klds)[((i - 12) * 4 + k) * 512 + t];
+              cs2[2 * k] = __builtin_elementwise_fma(r2f2{q[0], q[1]}, f2, cs2[2 * k]);
+              cs2[2 * k + 1] = __builtin_elementwise_fma(r2f2{q[2], q[3]}, f2, cs2[2 * k + 1]);
+            }
+          }
+        }
+      }
+      // reduce over the 8 tile rows of the wave (lane bits 3, 4, 5): value 4 k + e <-> column 32 k + 4 cg + e
+      float v[16];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) { v[2 * h] = cs2[h][0]; v[2 * h + 1] = cs2[h][1]; }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = r2_dpp_add<0x128>(v[i]);           // row_ror:8 -- lane ^ 8
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { r2_swap16(v[2 * j], v[2 * j + 1]); w[j] = v[2 * j] + v[2 * j + 1]; }     // 16-lane rows 0,2: value 2j; rows 1,3: value 2j+1
+      float z4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { r2_swap32(w[2 * j], w[2 * j + 1]); z4[j] = w[2 * j] + w[2 * j + 1]; }   // 16-lane row q: value 4j + q
+      if ((lane & 8) == 0) {
+        const int q = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) colred[wave * 128 + 32 * j + 4 * cg + q] = z4[j];
+      }
+      if (lastc) {              // dustbin column: sum_i F_i pb_i over the group's slots (the corner included: it sits in slot nrl)
+        float s = 0.f;
+        for (int r = t; r < nslots; r += 512) s += facs[r] * pb[r];
+        s = wave_sum(s);
+        if (lane == 0) wred[wave] = s;
+      }
+    }
+    __syncthreads();
+    float ctot = 0.f;                                                          // this row group's partial for the thread's column
+    if (t < 128) {
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) ctot += colred[w8 * 128 + t];
+      if (lastg) ctot += facs[nrl] * pr[t];
+      csst[t] = ctot;
+    } else if (t == 128 && lastc) {
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) ctot += wred[w8];
+      csst[128] = ctot;
+    }
+    stamp(5);
+    // ---------------- column edge: the nx workgroups that hold the same columns exchange their partials (write-through: cross-XCD)
+    if (p.nx > 1) {
+      __syncthreads();
+      float* cmine = p.cpart + ((int64_t)(((it & 1) * p.nx + xr) * p.nc + cc)) * R2_CSEG;
+      const auto xtg = [&](float x) { return __uint_as_float(__float_as_uint(x) | xtagbit); };
+      if (t < 33) {
+        const f32x4 q = *(const f32x4*)(csst + 4 * t);
+        r2_st4_wt(cmine + 4 * t, f32x4{xtg(q[0]), xtg(q[1]), xtg(q[2]), xtg(q[3])});
+        *(f32x4*)(xrd + xr * R2_CSEG + 4 * t) = q;
+      } else if (t >= 64 && t < 64 + 33 * (p.nx - 1)) {
+        const int o = (t - 64) / 33, qd = (t - 64) % 33;
+        const int xs = o < xr ? o : o + 1;                                    // the other row groups, in order
+        const float* src = p.cpart + ((int64_t)(((it & 1) * p.nx + xs) * p.nc + cc)) * R2_CSEG + 4 * qd;
+        unsigned vmask = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int c = 4 * qd + e; vmask |= ((c < ncl || (c == 128 && lastc)) ? 1u : 0u) << e; }
+        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+        int spins = 0;
+        if (vmask)
+          for (;;) {
+            r2_ld4_issue(q, src);
+            r2_ld4_wait(q);
+            unsigned stale = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stale |= ((__float_as_uint(q[e]) ^ xtagbit) >> 31) << e;
+            if ((stale & vmask) == 0) break;
+            if (++spins > (1 << 16)) { fail_flag = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        *(f32x4*)(xrd + xs * R2_CSEG + 4 * qd) = f32x4{fabsf(q[0]), fabsf(q[1]), fabsf(q[2]), fabsf(q[3])};
+      }
+      __syncthreads();
+      if (t <= 128) {
+        ctot = 0.f;
+        for (int xs = 0; xs < p.nx; ++xs) ctot += xrd[xs * R2_CSEG + t];       // fixed order: the same bits in all nx workgroups
+      }
+    }
+    stamp(6);
+    // ---------------- v += log g, G *= g for the block's own columns
+    if (t <= 128) {
+      const bool own = t < ncl || (t == 128 && lastc);
+      float vown = vown_l[t], gown = gown_l[t];
+      if (own) {
+        const float tr = gown * ctot;                                           // true column sum G_j sum_i F_i K_ij
+        if (!(tr > 0.f) || !(tr < 3.0e38f)) p.status[0] = 1.f;
+        const float dv = (t < 128 ? p.norm : p.log_nu_bin) - logf(tr);
+        vown += dv;
+        gown *= __expf(dv);
+        vown_l[t] = vown;
+        gown_l[t] = gown;
+      }
+      gvec[t] = own ? (next_fresh ? vown : gown) : (next_fresh ? 0.f : 1.f);
+    }
+    __syncthreads();
+    stamp(7);
+  }
+  if (PROF && blockIdx.x == 0 && threadIdx.x < 8) a.prof[threadIdx.x] = prof_acc[threadIdx.x];
+  __syncthreads();
+  if (fail_flag) {
+    if (threadIdx.x == 0) p.status[0] = 2.f;
+    return;
+  }
+  // ---------------- potentials out (the selection kernels read Z, u, v)
+  {
+    const int fc = threadIdx.x & (p.nc - 1), fq = threadIdx.x >> nc_sh, fs0 = cc * p.rbf + 4 * fq;
+    if (4 * fq < p.rbf && fc == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = fs0 + e;
+        if (s < nrl) p.u[row0 + s] = uo_l[4 * fq + e];
+        else if (s == nrl && lastg) p.u[p.n] = uo_l[4 * fq + e];
+      }
+    }
+  }
+  if (xr == 0) {
+    if ((int)threadIdx.x < ncl) p.v[col0 + threadIdx.x] = vown_l[threadIdx.x];
+    else if (threadIdx.x == 128 && lastc) p.v[p.m] = vown_l[128];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int r2_env(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+static inline size_t r2_al(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int r2_up4(int x) { return (x + 3) & ~3; }
+
+OtR2Plan ot_res2_plan(const OtR2Host* pr, int np, int iters) {
+  OtR2Plan P{};
+  if (iters < 1 || np < 1) return P;
+  int maxn = 0, maxm = 0;
+  for (int i = 0; i < np; ++i) { maxn = pr[i].n > maxn ? pr[i].n : maxn; maxm = pr[i].m > maxm ? pr[i].m : maxm; }
+  if (maxn > 4096 || maxm > 4096) return P;
+  int nc = 1;
+  while (nc * 128 < maxm) nc *= 2;                                  // column blocks per row group: a power of two <= 32
+  const int nx = cdiv(maxn, 1024);
+  const int units = 8 * (32 / nc);                                  // row groups one launch holds (each on the CUs of one XCD)
+  if (nx > units) return P;
+  P.nx = nx; P.nc = nc;
+  P.ppg = units / nx;
+  P.ppg = P.ppg < np ? P.ppg : np;
+  P.ngroups = cdiv(np, P.ppg);
+  if (P.ngroups > 64) return P;
+  size_t b = r2_al(sizeof(OtR2Dev) * (size_t)np) + (size_t)P.ngroups * r2_al(sizeof(OtR2Block) * 256) + 256;
+  for (int i = 0; i < np; ++i) {
+    const int rb = cdiv(pr[i].n, nx);
+    const int rbf = r2_up4(cdiv(rb + 1, nc)), rbs = nc * rbf;
+    b += r2_al((size_t)nx * nc * rbs * 4) + r2_al((size_t)nx * 2 * rbs * 4) + r2_al((size_t)2 * nx * nc * R2_CSEG * 4);
+  }
+  P.bytes = b;
+  P.ok = true;
+  return P;
+}
+
+int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, char* base, hipStream_t s) {
+  size_t off = 0;
+  OtR2Dev* dprob = (OtR2Dev*)(base + off); off += r2_al(sizeof(OtR2Dev) * (size_t)np);
+  int* dplace = (int*)(base + off); off += 256;
+  std::vector<OtR2Dev> hd(np);
+  const size_t ex0 = off;
+  for (int i = 0; i < np; ++i) {
+    const OtR2Host& d = hp[i];
+    OtR2Dev q{};
+    q.z = d.z; q.ld = d.ld; q.n = d.n; q.m = d.m; q.u = d.u; q.v = d.v; q.status = d.status;
+    q.norm = d.norm; q.log_mu_bin = d.log_mu_bin; q.log_nu_bin = d.log_nu_bin;
+    q.nx = P.nx; q.nc = P.nc;
+    q.rb = cdiv(d.n, P.nx);
+    q.cb = r2_up4(cdiv(d.m, P.nc));
+    q.rbf = r2_up4(cdiv(q.rb + 1, P.nc));
+    q.rbs = P.nc * q.rbf;
+    q.rpart = (float*)(base + off); off += r2_al((size_t)P.nx * P.nc * q.rbs * 4);
+    q.fbuf = (float*)(base + off); off += r2_al((size_t)P.nx * 2 * q.rbs * 4);
+    q.cpart = (float*)(base + off); off += r2_al((size_t)2 * P.nx * P.nc * R2_CSEG * 4);
+    q.placement = dplace;
+    hd[i] = q;
+  }
+  // exchange buffers start with every sign bit set: iteration 0 waits for sign 0
+  GIMS_HIP(hipMemsetAsync(base + ex0, 0xFF, off - ex0, s));
+  GIMS_HIP(hipMemsetAsync(dplace, 0, 256, s));
+  int rc = upload_table(hd.data(), sizeof(OtR2Dev) * (size_t)np, dprob, s);
+  if (rc != GIMS_OK) return rc;
+  static bool attr = false;
+  constexpr size_t lds = R2_LDS_FLOATS * sizeof(float);
+  if (!attr) {
+    GIMS_HIP(hipFuncSetAttribute((const void*)ot_res2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ot_res2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  // all 256 workgroups wait on each other: they must be co-resident (one per CU) -- checked once against the occupancy query
+  static int resident_ok = -1;
+  if (resident_ok < 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ot_res2_kernel<false>, 512, lds);
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    resident_ok = (e == hipSuccess && per_cu * cus >= 256) ? 1 : 0;
+  }
+  if (!resident_ok) {
+    set_error("the on-chip Sinkhorn kernel does not fit: 256 workgroups of 512 threads with %zu bytes of LDS are not co-resident on this device", lds);
+    return GIMS_EHIP;
+  }
+  // write-through stores on the local edges as well when the dispatcher was seen to place blocks elsewhere than XCD b % 8 (sticky per
+  // process; read back lazily: the flag of call k is looked at by call k + 1, without a synchronisation of its own)
+  static int wt_local = -1;
+  static int* h_place = nullptr;
+  static hipEvent_t place_ev = nullptr;
+  if (wt_local < 0) {
+    wt_local = r2_env("GIMS_OT_R2_WT", 0) ? 1 : 0;
+    if (hipHostMalloc((void**)&h_place, sizeof(int)) != hipSuccess) h_place = nullptr;
+    if (h_place) { *h_place = 0; if (hipEventCreateWithFlags(&place_ev, hipEventDisableTiming) != hipSuccess) place_ev = nullptr; }
+  }
+  if (h_place && *h_place) wt_local = 1;
+  const int refresh = r2_env("GIMS_OT_REFRESH", 50);
+  const int prof = r2_env("GIMS_OT_PROF", 0);
+  for (int gi = 0; gi < P.ngroups; ++gi) {
+    OtR2Block* dblk = (OtR2Block*)(base + off); off += r2_al(sizeof(OtR2Block) * 256);
+    OtR2Block hb[256];
+    for (int b = 0; b < 256; ++b) hb[b] = OtR2Block{-1, 0, 0, 0};
+    const int p0 = gi * P.ppg, p1 = (p0 + P.ppg < np) ? p0 + P.ppg : np;
+    for (int q = 0; q < p1 - p0; ++q)
+      for (int xr = 0; xr < P.nx; ++xr) {
+        const int unit = q * P.nx + xr, xcd = unit % 8, slot = unit / 8;
+        for (int c = 0; c < P.nc; ++c) hb[8 * (slot * P.nc + c) + xcd] = OtR2Block{p0 + q, xr, c, 0};
+      }
+    rc = upload_table(hb, sizeof(hb), dblk, s);
+    if (rc != GIMS_OK) return rc;
+    OtR2Args a{};
+    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local;
+    if (prof) {
+      static unsigned long long* dprof = nullptr;
+      if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 8 * sizeof(unsigned long long)));
+      a.prof = dprof;
+      hipLaunchKernelGGL(ot_res2_kernel<true>, dim3(256), dim3(512), lds, s, a);
+      GIMS_LAUNCH_CHECK();
+      unsigned long long h[8];
+      GIMS_HIP(hipStreamSynchronize(s));
+      GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
+      static const char* names[8] = {"derive", "row pass", "publish + wait for the row partials", "fold + publish F", "gather F (incl. wait)", "column pass",
+                                     "column edge (incl. wait)", "column update"};
+      fprintf(stderr, "[ot_res2 nx=%d nc=%d iters=%d wt=%d] cycles/iteration of workgroup 0:", P.nx, P.nc, iters, wt_local);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.0f;", names[i], (double)h[i] / iters);
+      fprintf(stderr, "\n");
+    } else {
+      hipLaunchKernelGGL(ot_res2_kernel<false>, dim3(256), dim3(512), lds, s, a);
+      GIMS_LAUNCH_CHECK();
+    }
+  }
+  if (h_place && place_ev && !wt_local) {
+    if (hipEventQuery(place_ev) != hipErrorNotReady) {      // the previous read-back (if any) has landed: start the next one
+      GIMS_HIP(hipMemcpyAsync(h_place, dplace, sizeof(int), hipMemcpyDeviceToHost, s));
+      GIMS_HIP(hipEventRecord(place_ev, s));
+    }
+  }
+  return GIMS_OK;
+}
+
+}  // namespace gims

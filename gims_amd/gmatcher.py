@@ -811,6 +811,12 @@ class GMatcher(nn.Module):
         if kwargs.get('mode', 'test') == "train" and self.training:
             from . import trainstep
             return trainstep.train_forward(self, data)
+        if (kwargs.get('mode', 'test') == "train" and torch.is_grad_enabled() and not self.__dict__.get("_warned_eval_train")
+                and any(p.requires_grad for p in self.parameters())):
+            import warnings
+            self.__dict__["_warned_eval_train"] = True
+            warnings.warn("GMatcher.forward(mode='train') on a module in eval() mode returns the loss VALUE only (running-statistics BatchNorm, no "
+                          "autograd graph): loss.backward() will raise.  Call model.train() first for a differentiable training step.", stacklevel=2)
         with hip.pinned_stream():                 # one stream lookup for the ~150 launches of a call
             return self._forward_eval(data, **kwargs)
 
@@ -868,8 +874,10 @@ class GMatcher(nn.Module):
         """Forward value of the reference's training loss (gmatcher.py:309-386) on the potentials the Sinkhorn kernels just
         produced: kept-index remap of data['matches'] (340-367), gather of the OT log-scores at the ground-truth cells --
         negatives read the corner cell OT[N, M], the reference's scores[b, -1, -1] (368-372) --, clamp, scatter_mean per
-        batch element, weights (373-385).  Returns (loss, pos_loss, neg_loss) as 0-dim tensors.  No autograd graph is
-        attached (no backward on the HIP path yet): calling .backward() on the result raises, it does not silently no-op."""
+        batch element, weights (373-385).  Returns (loss, pos_loss, neg_loss) as 0-dim tensors.  This is the eval()-mode
+        value (running-statistics BatchNorm) and carries no autograd graph -- .backward() on it raises, it does not silently
+        no-op; the differentiable training step (train() mode: batch statistics, full reverse pass on the HIP path) is
+        gims_amd/trainstep.py, which forward() routes to when the module is in train() mode."""
         gt = data['matches']
         dev = images[0]["kp"].device
         gt = gt.to(device=dev, dtype=torch.int64).contiguous()
@@ -883,8 +891,9 @@ class GMatcher(nn.Module):
         """``forward(data, mode='train')`` plus the first stage of its backward pass: the gradient of the loss
         with respect to the score matrix of every pair and to ``bin_score``, by reverse mode through the unrolled Sinkhorn
         iterations (what autograd does in the reference, gmatcher.py:41-69, 372-385).  Returns
-        ``{'loss', 'pos_loss', 'neg_loss', 'dscores': [per pair, (n_kept0, n_kept1)], 'dbin_score'}``.  The rest of the backward
-        pass (final projection, attention layers, encoders) is not built."""
+        ``{'loss', 'pos_loss', 'neg_loss', 'dscores': [per pair, (n_kept0, n_kept1)], 'dbin_score'}``.  A diagnostic of the
+        Sinkhorn reverse sweep for a module in eval() mode; the complete backward pass (final projection, attention layers,
+        encoders, GraphSAGE) is the training step of gims_amd/trainstep.py (``model.train(); model(data, mode='train')``)."""
         loss, pos, neg = self._forward_eval(data, mode="train")
         items = self._last["items"]
         dscores, dalpha = hip.sinkhorn_score_gradients(items, self._packed(items[0]["scores"].device)["alpha"], self.config['sinkhorn_iterations'],

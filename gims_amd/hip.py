@@ -242,26 +242,31 @@ def _check(rc: int, what: str):
         raise GimsHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
-_STREAM_PIN = None          # set by pinned_stream(): the raw hipStream_t of the current stream, looked up once
+import threading  # noqa: E402
+
+_TLS = threading.local()    # per thread: .pin = the raw hipStream_t pinned by pinned_stream(), .gemm_prec = gemm()'s default precision
 
 
 def _stream() -> int:
-    return _STREAM_PIN if _STREAM_PIN is not None else torch.cuda.current_stream().cuda_stream
+    pin = getattr(_TLS, "pin", None)
+    return pin if pin is not None else torch.cuda.current_stream().cuda_stream
 
 
 class pinned_stream:
     """``with pinned_stream():`` -- look the current torch stream up ONCE for a run of launches (torch.cuda.current_stream() costs a
-    few microseconds per call; a training step makes ~1 800 launches).  The stream must not be switched inside the block."""
+    few microseconds per call; a training step makes ~1 800 launches).  The pin belongs to the calling THREAD (other threads
+    keep resolving their own current stream), and the stream must not be switched inside the block: leaving it with a
+    different current stream raises instead of having launched on the wrong one silently."""
 
     def __enter__(self):
-        global _STREAM_PIN
-        self._prev = _STREAM_PIN
-        _STREAM_PIN = torch.cuda.current_stream().cuda_stream
+        self._prev = getattr(_TLS, "pin", None)
+        _TLS.pin = torch.cuda.current_stream().cuda_stream
         return self
 
-    def __exit__(self, *exc):
-        global _STREAM_PIN
-        _STREAM_PIN = self._prev
+    def __exit__(self, exc_type, *exc):
+        pin, _TLS.pin = _TLS.pin, self._prev
+        if exc_type is None and torch.cuda.current_stream().cuda_stream != pin:
+            raise GimsHipError("the current CUDA stream changed inside a pinned_stream() block: launches went to the stream that was current on entry")
         return False
 
 
@@ -851,7 +856,7 @@ def train_loss(items, kept0, kept1, gt: torch.Tensor, alpha: float, pos_weight: 
     tab = upload(np.frombuffer(bytes(arr), dtype=np.uint8), dev)
     K = int(gt.shape[0])
     loss_vec = torch.empty(max(K, 1), dtype=torch.float32, device=dev)
-    tag = torch.empty(max(K, 1), dtype=torch.int32, device=dev)
+    tag = torch.empty(max(K, 1) + 2 * B, dtype=torch.int32, device=dev)      # row classes, then 2 group sizes per batch element
     out3 = torch.empty(3, dtype=torch.float32, device=dev)
     _check(load().gims_train_loss(_p(tab), B, _p(gt), K, float(alpha), float(pos_weight), float(neg_weight), _p(loss_vec), _p(tag), _p(out3),
                                   _stream()), "gims_train_loss")
@@ -963,7 +968,25 @@ _gemm_work = {}
 _gemm_fn = None
 
 
-GEMM_PRECISION = PREC_BF16X6          # default of gemm(): gims_amd.trainstep sets it per step from config['train_precision']
+GEMM_PRECISION = PREC_BF16X6          # default precision of gemm() outside a gemm_precision() block
+
+
+class gemm_precision:
+    """``with gemm_precision(PREC_BF16X3):`` -- default precision of gemm() for the calling thread inside the block (the training
+    step sets it per pass from config['train_precision']); restored on exit, so two models with different settings, or a direct
+    gemm() user, never see each other's choice."""
+
+    def __init__(self, precision: int):
+        self.precision = int(precision)
+
+    def __enter__(self):
+        self._prev = getattr(_TLS, "gemm_prec", None)
+        _TLS.gemm_prec = self.precision
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.gemm_prec = self._prev
+        return False
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, *, alpha=1.0, beta=0.0, bias=None, residual=None, act=ACT_NONE,
@@ -988,6 +1011,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, *, a
         ldr, sr = rsd[-2], (rsd[0] if len(rsd) == 3 else 0)
     g = Gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _p(residual), lda, ldb, osd[-2] if m > 1 else max(n, osd[-2]), ldr, sa, sb,
              osd[0] if len(osd) == 3 else 0, sr, m, n, k, batch, ta, tb, int(act), 0, float(alpha), float(beta))
+    if precision is None:
+        precision = getattr(_TLS, "gemm_prec", None)
     g.precision = GEMM_PRECISION if precision is None else int(precision)
     stream = _stream()
     if k >= 512:                                  # split-K workspace (one arena per device and stream; stream order protects it)

@@ -64,8 +64,16 @@ def _sage_bias(P, i):
 def forward(model, data):
     """Returns (out3 = [loss, pos_loss, neg_loss] device tensor, _Step).  Mutates ``data`` like the reference's forward does
     (gmatcher.py:244-252) and updates the BatchNorm buffers of ``model``."""
+    with hip.gemm_precision(_precision(model.config)):
+        out = _forward(model, data)
+    # the running statistics just changed through raw pointers (no tensor version bump): an inference pack with the old
+    # statistics folded in must not survive a train() -> eval() switch
+    model._pack = None
+    return out
+
+
+def _forward(model, data):
     cfg = model.config
-    hip.GEMM_PRECISION = _precision(cfg)
     ln = bool(cfg['use_layernorm'])          # MLP(): Conv1d -> LayerNorm -> ReLU instead of Conv1d -> BatchNorm1d -> ReLU (gmatcher.py:17-23)
     radius, percentile, min_size = data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)
     B = data['keypoints0'].shape[0]
@@ -218,8 +226,12 @@ def forward(model, data):
 def backward(model, S, w_pos: float, w_neg: float):
     """Gradients of  w_pos * (pos_loss / pos_loss_weight) + w_neg * (neg_loss / neg_loss_weight)  -- i.e. with w_pos / w_neg the
     effective weights of the two loss terms -- with respect to every parameter: dict name -> tensor shaped like the parameter."""
+    with hip.gemm_precision(_precision(model.config)):
+        return _backward(model, S, w_pos, w_neg)
+
+
+def _backward(model, S, w_pos: float, w_neg: float):
     cfg = model.config
-    hip.GEMM_PRECISION = _precision(cfg)
     P = {k: v.detach() for k, v in zip(*_params(model))}
     D, B, n_tot, rows, sg, G = S.D, S.B, S.n_tot, S.rows, S.sg, S.G
     dev = S.mdesc.device

@@ -378,7 +378,8 @@ int gims_ot_matrix(const float* scores, int64_t ld, int32_t n, int32_t m, float 
  * reference's tensor indexing reads as the corner cell OT[N, M] (gmatcher.py:372), and count as negatives.  Each gathered
  * log-score is clamped to [-100, 0] and negated; positives and negatives are averaged per batch element (scatter_mean,
  * empty groups give 0), then over the batch, and weighted: out3 = {loss, pos_weight * pos, neg_weight * neg}.
- * loss_vec [n_gt] f32 and tag [n_gt] int32 are scratch (loss_vec holds the per-row losses afterwards).  Deterministic. */
+ * loss_vec [n_gt] f32 and tag [n_gt + 2 * n_pairs] int32 are scratch (loss_vec holds the per-row losses afterwards, tag the row
+ * classes followed by the per-(batch element, sign) group sizes: gims_train_loss_grad reads both).  Deterministic. */
 typedef struct gims_loss_pair {
   const float* scores; int64_t ld; int32_t n, m; const float* uv; const int32_t* kept0; const int32_t* kept1;
 } gims_loss_pair;

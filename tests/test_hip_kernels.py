@@ -522,6 +522,33 @@ def test_sinkhorn_batched_ragged(hip, monkeypatch, resident, shapes):
         assert float(it["uv"][-1]) == 0.0
 
 
+def test_sinkhorn_history_of_a_ragged_batch(hip):
+    """gims_sinkhorn_history with problems of DIFFERENT sizes in one call (the grid is sized for the largest m: the blocks
+    beyond a smaller problem's columns return early and must not own a stripe of its u copy -- ADVICE r02): every problem's
+    recorded potentials equal, bit for bit, those of the same problem solved alone, and no slot stays at its zero fill."""
+    r = _rng(77)
+    iters = 7
+    shapes = [(900, 130), (150, 1000), (64, 64), (333, 700)]
+
+    def item(z, n, m):
+        zs = torch.zeros((n, (m + 3) // 4 * 4), dtype=torch.float32, device="cuda")
+        zs[:, :m] = _dev(z)
+        return dict(scores=zs, n=n, m=m, matches0=torch.empty(n, dtype=torch.int64, device="cuda"), matches1=torch.empty(m, dtype=torch.int64, device="cuda"),
+                    mscores0=torch.empty(n, device="cuda"), mscores1=torch.empty(m, device="cuda"), uv=torch.empty(n + m + 3, device="cuda"))
+
+    zs = [(r.normal(size=(n, m)) * 3).astype(np.float32) for n, m in shapes]
+    together = hip.sinkhorn_history([item(z, n, m) for z, (n, m) in zip(zs, shapes)], 0.8, iters)
+    for z, (n, m), h in zip(zs, shapes, together):
+        alone = hip.sinkhorn_history([item(z, n, m)], 0.8, iters)[0]
+        assert torch.equal(h, alone), (n, m)
+        hh = h.cpu().numpy().reshape(iters + 1, n + m + 2)                          # slot 0 unused, slot k = (u_k, v_k)
+        assert (hh[1:] != 0).all(), (n, m)                                          # every u_k[i], v_k[j] was written
+        ref = O.log_optimal_transport(torch.from_numpy(z)[None], torch.tensor(0.8), iters)[0].numpy()
+        u, v = hh[iters, :n + 1], hh[iters, n + 1:]
+        full = np.pad(z, ((0, 1), (0, 1)), constant_values=0.8) + u[:, None] + v[None, :] + np.log(n + m)
+        np.testing.assert_allclose(full, ref, atol=1e-3)
+
+
 def test_sinkhorn_resident_matches_streamed(hip, monkeypatch):
     """The two Sinkhorn implementations (streamed log-domain sweeps / on-chip multiplicative scaling with periodic
     re-derivation) must agree on the potentials to f32 noise and on every match, at the bench's problem shape."""
@@ -699,16 +726,10 @@ def test_agc_vs_reference_golden(hip, name):
         assert abs(float(thr) - float(g[f"agc{s}/thr"])) < 1e-6, (thr, g[f"agc{s}/thr"])
         if float(g[f"agc{s}/margin"]) < 2e-6:
             # ill-conditioned fixture: a radius candidate's similarity sits within 2e-6 of the percentile threshold, so the
-            # reference's own edge decision hangs on its BLAS summation order.  Not skipped: the comparison is made in
-            # ORIGINAL node ids and reported; at most the near-threshold edges (and what hangs on them) may differ.
-            mine = kept[_csr_edges(indptr, indices)]
-            a = {tuple(e) for e in mine.tolist()}
-            b = {tuple(e) for e in g[f"agc{s}/final"].tolist()}
-            kd = len(set(kept.tolist()) ^ set(g[f"agc{s}/kept"].tolist()))
-            print(f"{name} image {s}: margin {float(g[f'agc{s}/margin']):.2e} (ill-conditioned): coarse edges {int(inf[2])} vs "
-                  f"{len(g[f'agc{s}/coarse'])}, final edge symmetric difference {len(a ^ b)}, kept-id symmetric difference {kd}")
-            assert abs(int(inf[2]) - len(g[f"agc{s}/coarse"])) <= 2 and len(a ^ b) <= 4 and kd <= 2 * ms
-            continue
+            # reference's own edge decision hangs on its BLAS summation order.  Measured on MI355X (round 3, all four such images:
+            # agc_n300_s2003 0 / 1, e2e_n256_s1003 0 / 1): coarse edge counts equal, final edge set and kept ids identical to the
+            # reference's -- so they are held to exact equality like every other fixture; the print stays for the record.
+            print(f"{name} image {s}: margin {float(g[f'agc{s}/margin']):.2e} (ill-conditioned)")
         assert int(inf[2]) == len(g[f"agc{s}/coarse"])
         np.testing.assert_array_equal(kept, g[f"agc{s}/kept"])
         relabel = -np.ones(n, dtype=np.int64)
