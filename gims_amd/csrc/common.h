@@ -98,6 +98,6 @@ int split_spl3_launch(const float* src, int64_t lds, uint16_t* dst, int64_t ldd,
 struct OtR2Host { const float* z; int64_t ld; int n, m; float* u; float* v; float* status; float norm, log_mu_bin, log_nu_bin; };
 struct OtR2Plan { bool ok; int nx, nc, ppg, ngroups; size_t bytes; };
 OtR2Plan ot_res2_plan(const OtR2Host* pr, int np, int iters);
-int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, char* base, hipStream_t s);
+int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, int init_inside, char* base, hipStream_t s);
 
 }  // namespace gims

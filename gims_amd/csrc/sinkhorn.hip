@@ -100,6 +100,12 @@ __global__ void ot_init_kernel(const OtDev* __restrict__ probs, float alpha, int
   if (lane == 0) p.u[row] = zero_init ? 0.f : -mx;   // iters == 0: the reference returns Z + 0 + 0 - norm
 }
 
+// status words only (the 2-D on-chip kernel forms the start potentials itself)
+__global__ void ot_status0_kernel(const OtDev* __restrict__ probs, int np) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np) probs[i].status[0] = 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------- fused iteration
 template <int CPT, int R>
 __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__ probs, float alpha) {
@@ -1580,9 +1586,10 @@ static inline size_t al256r(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // One launch = 256 workgroups (one per CU, all resident).  Every problem of a call gets the same number of workgroups
 // `nbu`; when nbu <= 32 the problems are placed XCD by XCD (workgroup b runs on XCD b % 8) and synchronise per XCD.
+static thread_local bool tl_streamed_only = false;   // set for the duration of a *_ex call with GIMS_OT_STREAMED
 static OtResPlan ot_res_plan(const gims_ot_problem* pr, int np, int iters) {
   OtResPlan P{};
-  if (!ot_env("GIMS_OT_RESIDENT", 1) || iters < 1 || ot_res_cus() < 256) return P;
+  if (tl_streamed_only || !ot_env("GIMS_OT_RESIDENT", 1) || iters < 1 || ot_res_cus() < 256) return P;
   int maxm = 0;
   double cells = 0.0;
   for (int i = 0; i < np; ++i) {
@@ -1736,7 +1743,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // (GIMS_OT_RES2=0; kept as the cross-check).  Both share the gate of ot_res_plan (GIMS_OT_RESIDENT, the size threshold).
 static OtR2Plan ot_res2_choose(const gims_ot_problem* pr, int np, int iters) {
   OtR2Plan none{};
-  if (!ot_env("GIMS_OT_RES2", 1) || !ot_env("GIMS_OT_RESIDENT", 1) || iters < 1 || ot_res_cus() < 256) return none;
+  if (tl_streamed_only || !ot_env("GIMS_OT_RES2", 1) || !ot_env("GIMS_OT_RESIDENT", 1) || iters < 1 || ot_res_cus() < 256) return none;
   double cells = 0.0;
   for (int i = 0; i < np; ++i) cells += (double)pr[i].n * pr[i].m;
   if (cells < 6.0e6 && ot_env("GIMS_OT_RESIDENT", 1) != 2) return none;
@@ -1839,9 +1846,12 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     if (rc != GIMS_OK) return rc;
   }
   const OtDev* dp = (const OtDev*)work;
-  hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, iters == 0 ? 1 : 0);
-  dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
   const OtR2Plan plan2 = ot_res2_choose(pr, np, iters);
+  // the 2-D on-chip kernel forms the start potentials itself (GIMS_OT_R2_INIT=0: the separate sweep, for cross-checks)
+  const int init_inside = plan2.ok && ot_env("GIMS_OT_R2_INIT", 1) ? 1 : 0;
+  if (init_inside) hipLaunchKernelGGL(ot_status0_kernel, dim3(cdiv(np, 256)), dim3(256), 0, s, dp, np);
+  else hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, iters == 0 ? 1 : 0);
+  dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
   OtResPlan plan = plan2.ok ? OtResPlan{} : ot_res_plan(pr, np, iters);
   if (plan2.ok) {     // whole iteration loop on chip, 2-D decomposition (sinkhorn2d.hip)
     std::vector<OtR2Host> h2(np);
@@ -1849,7 +1859,7 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
       const OtDev& d = hprob[i];
       h2[i] = OtR2Host{d.z, d.ld, d.n, d.m, d.u, d.v, d.status, d.norm, d.log_mu_bin, d.log_nu_bin};
     }
-    const int rc = ot_res2_run(plan2, h2.data(), np, alpha, iters, base + off, s);
+    const int rc = ot_res2_run(plan2, h2.data(), np, alpha, iters, init_inside, base + off, s);
     if (rc != GIMS_OK) return rc;
     plan.ok = true;   // (the rescue and the skipped streamed loop below are shared)
   } else if (plan.ok) {      // whole iteration loop on chip (one launch per group of problems)
@@ -1877,6 +1887,21 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   hipLaunchKernelGGL(ot_mutual_kernel, dim3(cdiv(mx, 256), np), dim3(256), 0, s, dp, match_threshold);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
+}
+
+extern "C" int gims_sinkhorn_plan_ex(const gims_ot_problem* pr, int32_t np, int32_t iters, int32_t flags) {
+  gims::tl_streamed_only = (flags & GIMS_OT_STREAMED) != 0;
+  const int k = gims_sinkhorn_plan(pr, np, iters);
+  gims::tl_streamed_only = false;
+  return k;
+}
+
+extern "C" int gims_sinkhorn_match_ex(const gims_ot_problem* pr, int32_t np, float alpha, int32_t iters, float match_threshold, void* work,
+                                      size_t work_bytes, int32_t flags, void* stream) {
+  gims::tl_streamed_only = (flags & GIMS_OT_STREAMED) != 0;
+  const int rc = gims_sinkhorn_match(pr, np, alpha, iters, match_threshold, work, work_bytes, stream);
+  gims::tl_streamed_only = false;
+  return rc;
 }
 
 extern "C" int gims_ot_matrix(const float* scores, int64_t ld, int32_t n, int32_t m, float alpha, const float* uv,

@@ -45,11 +45,13 @@ struct OtR2Dev {
   float* rpart;        // [nx][nc][rbs]  partial row sums (slot nrl of the last group = the dustbin row)
   float* fbuf;         // [nx][2][rbs]   F (tagged), then u on the iterations that precede a derivation
   float* cpart;        // [2][nx][nc][R2_CSEG]  partial column sums (slot 128 = the dustbin column, last block only)
+  float* mpart;        // [nx][nc][rbs]  partial row maxima of Z (start potentials, exchanged once)
   int* placement;      // [1] set to 1 by any workgroup whose XCC id is not blockIdx % 8
 };
 struct OtR2Args {
   const OtR2Dev* probs; const OtR2Block* blocks;
   float alpha; int iters, refresh, wt_local;
+  int init_inside;     // 1: the start potentials u0 = -max(alpha, row max of Z), v0 = 0 are formed in here (no ot_init_kernel sweep of Z)
   unsigned long long* prof;
 };
 
@@ -67,6 +69,10 @@ __device__ __forceinline__ void r2_ld4_issue(f32x4& v, const float* p) { asm vol
 __device__ __forceinline__ void r2_ld4_wait(f32x4& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a)::"memory"); }
 __device__ __forceinline__ void r2_swap16(float& x, float& y) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
 __device__ __forceinline__ void r2_swap32(float& x, float& y) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+template <int CTRL>
+__device__ __forceinline__ float r2_dpp_max(float x) {
+  return fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true)));
+}
 template <int CTRL>
 __device__ __forceinline__ float r2_dpp_add(float x) {
   return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int s = fs0 + e;
-        uo_l[4 * fq + e] = s < nrl ? p.u[row0 + s] : (s == nrl && lastg ? p.u[p.n] : 0.f);
+        uo_l[4 * fq + e] = a.init_inside ? 0.f : (s < nrl ? p.u[row0 + s] : (s == nrl && lastg ? p.u[p.n] : 0.f));
         fo_l[4 * fq + e] = 1.f;
       }
     }
@@ -160,13 +166,179 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
   for (int r = threadIdx.x; r < R2_GVEC; r += 512) { gvec[r] = 0.f; pr[r] = 0.f; csst[r] = 0.f; }     // v0 = 0
   __syncthreads();
 
+  // ---------------- start potentials formed on chip (replaces ot_init_kernel's sweep of Z): u0_i = -max(alpha, max_j Z_ij), v0 = 0.
+  // Z is read ONCE into the registers / LDS that will hold K, the row maxima take the same two local hops as the row sums
+  // (readiness: the buffers start as 0xFFFFFFFF, which no maximum and no potential can be), then K = exp((Z + u0) + 0) in place.
+  if (a.init_inside) {
+    int tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));
+    const int t = tq, cg = t & 7, rg = t >> 3;
+    const float* zb = p.z;
+    const int row_hi = p.n - 1, quad_hi = (p.m - 1) & ~3;
+    constexpr float NEG = -3.0e38f;
+#pragma unroll
+    for (int ibs = 0; ibs < 16; ibs += 4) {
+      const int ib = (ibs + 12) % 16;
+      f32x4 zq[4][4];
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        int gr = row0 + rg * 16 + ib + i4;
+        gr = gr < row_hi ? gr : row_hi;
+        const float* zr = zb + (int64_t)gr * p.ld;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int cq = col0 + 32 * k + 4 * cg;
+          cq = cq < quad_hi ? cq : quad_hi;
+          zq[i4][k] = __builtin_nontemporal_load((const f32x4*)(zr + cq));
+        }
+      }
+      float m4[4];
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const bool rin = rg * 16 + ib + i4 < nrl;
+        float mx = NEG;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = (rin && 32 * k + 4 * cg + e < ncl) ? zq[i4][k][e] : NEG;       // outside the block: exp(NEG + u) = 0 later
+            zq[i4][k][e] = z;
+            mx = fmaxf(mx, z);
+          }
+        m4[i4] = mx;
+        if (ib < 12) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            P[(ib + i4) % 12][2 * k] = r2f2{zq[i4][k][0], zq[i4][k][1]};
+            P[(ib + i4) % 12][2 * k + 1] = r2f2{zq[i4][k][2], zq[i4][k][3]};
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ((f32x4*)klds)[((ib + i4 - 12) * 4 + k) * 512 + t] = zq[i4][k];
+        }
+      }
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) m4[i4] = r2_dpp_max<0xB1>(m4[i4]);
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) m4[i4] = r2_dpp_max<0x4E>(m4[i4]);
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) m4[i4] = r2_dpp_max<0x141>(m4[i4]);
+      if (cg == 0) *(f32x4*)(rowst + rg * 16 + ib) = f32x4{m4[0], m4[1], m4[2], m4[3]};
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    float* mpart_mine = p.mpart + (int64_t)(xr * p.nc + cc) * p.rbs;
+    if (4 * t < nrl) {
+      const f32x4 q = *(const f32x4*)(rowst + 4 * t);
+      if (wt) r2_st4_wt(mpart_mine + 4 * t, q); else r2_st4_plain(mpart_mine + 4 * t, q);
+    }
+    const int fc = t & (p.nc - 1), fq = t >> nc_sh, fs0 = cc * p.rbf + 4 * fq;
+    if (4 * fq < p.rbf) {
+      unsigned vmask = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vmask |= (fs0 + e < nrl ? 1u : 0u) << e;
+      f32x4 q = {NEG, NEG, NEG, NEG};
+      if (vmask) {
+        const float* src = p.mpart + (int64_t)(xr * p.nc + fc) * p.rbs + fs0;
+        int spins = 0;
+        for (;;) {
+          r2_ld4_issue(q, src);
+          r2_ld4_wait(q);
+          unsigned stale = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) stale |= (__float_as_uint(q[e]) == 0xFFFFFFFFu ? 1u : 0u) << e;
+          if ((stale & vmask) == 0) break;
+          if (++spins > (1 << 16)) { fail_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      f32x4 mx;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx[e] = (vmask >> e) & 1u ? q[e] : NEG;
+      if (p.nc >= 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = r2_dpp_max<0xB1>(mx[e]);
+      }
+      if (p.nc >= 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = r2_dpp_max<0x4E>(mx[e]);
+      }
+      if (p.nc >= 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = r2_dpp_max<0x141>(mx[e]);
+      }
+      if (p.nc >= 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = r2_dpp_max<0x140>(mx[e]);
+      }
+      if (p.nc >= 32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], 16, 64));
+      }
+      if (fc == 0 && fs0 < nslots) {
+        f32x4 u0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u0[e] = fs0 + e < nrl ? -fmaxf(alpha, mx[e]) : -alpha;      // (slot nrl of the last group: the dustbin row)
+        *(f32x4*)(uo_l + 4 * fq) = u0;
+        if (wt) r2_st4_wt(fb + p.rbs + fs0, u0); else r2_st4_plain(fb + p.rbs + fs0, u0);
+      }
+    }
+    if (4 * t < nslots) {                      // gather the group's u0 (into facs, which is idle until the first row fold)
+      f32x4 q;
+      unsigned vmask = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vmask |= (4 * t + e < nslots ? 1u : 0u) << e;
+      int spins = 0;
+      for (;;) {
+        r2_ld4_issue(q, fb + p.rbs + 4 * t);
+        r2_ld4_wait(q);
+        unsigned stale = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stale |= (__float_as_uint(q[e]) == 0xFFFFFFFFu ? 1u : 0u) << e;
+        if ((stale & vmask) == 0) break;
+        if (++spins > (1 << 16)) { fail_flag = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      *(f32x4*)(facs + 4 * t) = q;
+    }
+    __syncthreads();
+    // K = exp((Z + u0) + v0), v0 = 0, in place
+#pragma unroll
+    for (int ib = 0; ib < 16; ib += 4) {
+      const f32x4 u4 = *(const f32x4*)(facs + rg * 16 + ib);
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int i = ib + i4;
+        if (i < 12) {
+#pragma unroll
+          for (int h = 0; h < 8; ++h) P[i % 12][h] = r2f2{__expf((P[i % 12][h][0] + u4[i4]) + 0.f), __expf((P[i % 12][h][1] + u4[i4]) + 0.f)};
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            f32x4 q = ((const f32x4*)klds)[((i - 12) * 4 + k) * 512 + t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = __expf((q[e] + u4[i4]) + 0.f);
+            ((f32x4*)klds)[((i - 12) * 4 + k) * 512 + t] = q;
+          }
+        }
+      }
+    }
+    if (lastc)
+      for (int r = t; r < nslots; r += 512) pb[r] = __expf((alpha + facs[r]) + 0.f);       // (slot nrl: the corner)
+    if (lastg && t < 128) pr[t] = t < ncl ? __expf((alpha + facs[nrl]) + 0.f) : 0.f;
+    __syncthreads();
+    for (int r = t; r < R2_FACS; r += 512) facs[r] = 1.f;
+    for (int r = t; r < R2_GVEC; r += 512) gvec[r] = 1.f;
+    __syncthreads();
+  }
+
   for (int it = 0; it < a.iters; ++it) {
     // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration (as loop invariants the
     // compiler keeps their hoisted addresses alive next to the 192 registers of P)
     int tq = threadIdx.x;
     asm volatile("" : "+v"(tq));
     const int t = tq, lane = t & 63, wave = t >> 6, cg = t & 7, rg = t >> 3;
-    const bool fresh = it == 0 || it == a.iters - 1 || (a.refresh > 0 && it % a.refresh == 0);
+    const bool fresh = (it == 0 && !a.init_inside) || (it > 0 && (it == a.iters - 1 || (a.refresh > 0 && it % a.refresh == 0)));
     const bool next_fresh = it + 1 < a.iters && (it + 2 == a.iters || (a.refresh > 0 && (it + 1) % a.refresh == 0));
     const unsigned tagbit = (unsigned)(it & 1) << 31;
     const unsigned xtagbit = (unsigned)((it >> 1) & 1) << 31;
@@ -578,14 +750,14 @@ OtR2Plan ot_res2_plan(const OtR2Host* pr, int np, int iters) {
   for (int i = 0; i < np; ++i) {
     const int rb = cdiv(pr[i].n, nx);
     const int rbf = r2_up4(cdiv(rb + 1, nc)), rbs = nc * rbf;
-    b += r2_al((size_t)nx * nc * rbs * 4) + r2_al((size_t)nx * 2 * rbs * 4) + r2_al((size_t)2 * nx * nc * R2_CSEG * 4);
+    b += 2 * r2_al((size_t)nx * nc * rbs * 4) + r2_al((size_t)nx * 2 * rbs * 4) + r2_al((size_t)2 * nx * nc * R2_CSEG * 4);
   }
   P.bytes = b;
   P.ok = true;
   return P;
 }
 
-int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, char* base, hipStream_t s) {
+int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, int init_inside, char* base, hipStream_t s) {
   size_t off = 0;
   OtR2Dev* dprob = (OtR2Dev*)(base + off); off += r2_al(sizeof(OtR2Dev) * (size_t)np);
   int* dplace = (int*)(base + off); off += 256;
@@ -604,6 +776,7 @@ int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int 
     q.rpart = (float*)(base + off); off += r2_al((size_t)P.nx * P.nc * q.rbs * 4);
     q.fbuf = (float*)(base + off); off += r2_al((size_t)P.nx * 2 * q.rbs * 4);
     q.cpart = (float*)(base + off); off += r2_al((size_t)2 * P.nx * P.nc * R2_CSEG * 4);
+    q.mpart = (float*)(base + off); off += r2_al((size_t)P.nx * P.nc * q.rbs * 4);
     q.placement = dplace;
     hd[i] = q;
   }
@@ -657,7 +830,7 @@ int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int 
     rc = upload_table(hb, sizeof(hb), dblk, s);
     if (rc != GIMS_OK) return rc;
     OtR2Args a{};
-    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local;
+    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local; a.init_inside = init_inside;
     if (prof) {
       static unsigned long long* dprof = nullptr;
       if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 8 * sizeof(unsigned long long)));

@@ -750,12 +750,16 @@ class GMatcher(nn.Module):
         with St("sinkhorn"):
             probs = hip.make_ot_problems(items)
             work = self._buf("ot", hip.sinkhorn_workspace_bytes(probs))
-            self.sinkhorn_plan_last = hip.sinkhorn_plan(probs, cfg['sinkhorn_iterations'])   # 0 streamed / k resident launches
+            # stream lanes run concurrently, and the on-chip Sinkhorn kernels need every CU of the device to themselves: next to
+            # another lane's kernels they cannot get their workgroups co-resident, give up and fall to the slow rescue -- so a
+            # model with streams > 1 plans the streamed kernels up front
+            otf = hip.OT_STREAMED if self.__dict__.get("_lanes_active", 1) > 1 else 0
+            self.sinkhorn_plan_last = hip.sinkhorn_plan(probs, cfg['sinkhorn_iterations'], otf)   # 0 streamed / k resident launches
             # (a resident solve that gives up -- status 2: its 256 workgroups were not co-resident, e.g. next to another
             # process's kernels -- is re-solved inside this call by a dependency-free kernel before the selection runs, so the
             # matches of THIS batch are valid when the call returns; see ot_rescue_kernel.  The status words stay readable:
             # `sinkhorn_status()` after a synchronise.)
-            hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work)
+            hip.sinkhorn_match(probs, P["alpha"], cfg['sinkhorn_iterations'], cfg['match_threshold'], work, otf)
             self._status_offs = np.cumsum([it["n"] + it["m"] + 3 for it in items]) - 1
         self._finish_graphs(images, G)
         self._last = dict(items=items, pairs=pairs, mdesc=mdesc, desc=desc, sage=sage, images=images,
@@ -911,6 +915,7 @@ class GMatcher(nn.Module):
         n_lanes = int(self.config.get('streams', 1))
         if n_lanes < 2 or len(datas) < 2 * n_lanes:
             n_lanes = 1
+        self._lanes_active = n_lanes
         cuts = [round(i * len(datas) / n_lanes) for i in range(n_lanes + 1)]
         groups = [datas[cuts[i]:cuts[i + 1]] for i in range(n_lanes)]
         for data in datas:
@@ -963,6 +968,7 @@ class GMatcher(nn.Module):
                         'mdesc0': mdesc[o0:o0 + n0], 'mdesc1': mdesc[o1:o1 + n1],
                     })
         self._lane = 0
+        self._lanes_active = 1
         if n_lanes > 1:
             for L in lanes:
                 cur.wait_stream(L)

@@ -174,6 +174,9 @@ _SIGNATURES = {
     "gims_sinkhorn_plan": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_int32]),
     "gims_sinkhorn_match": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_float,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gims_sinkhorn_plan_ex": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_int32, C.c_int32]),
+    "gims_sinkhorn_match_ex": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_float,
+                                         C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "gims_eval_workspace_bytes": (C.c_size_t, [C.POINTER(EvalPair), C.c_int32, C.c_int32]),
     "gims_eval_pairs": (C.c_int, [C.POINTER(EvalPair), C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_uint64,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -672,15 +675,18 @@ def sinkhorn_workspace_bytes(problems) -> int:
     return int(load().gims_sinkhorn_workspace_bytes(problems, len(problems)))
 
 
-def sinkhorn_plan(problems, iters: int) -> int:
+OT_STREAMED = 1      # flag of sinkhorn_plan / sinkhorn_match: never an on-chip kernel (concurrent streams on one GPU)
+
+
+def sinkhorn_plan(problems, iters: int, flags: int = 0) -> int:
     """0: streamed kernels (one launch per iteration); k > 0: on-chip resident kernel in k launches."""
-    return int(load().gims_sinkhorn_plan(problems, len(problems), int(iters)))
+    return int(load().gims_sinkhorn_plan_ex(problems, len(problems), int(iters), int(flags)))
 
 
-def sinkhorn_match(problems, alpha: float, iters: int, match_threshold: float, work: torch.Tensor):
+def sinkhorn_match(problems, alpha: float, iters: int, match_threshold: float, work: torch.Tensor, flags: int = 0):
     lib = load()
-    _check(lib.gims_sinkhorn_match(problems, len(problems), float(alpha), int(iters), float(match_threshold), _p(work),
-                                   work.numel() * work.element_size(), _stream()), "gims_sinkhorn_match")
+    _check(lib.gims_sinkhorn_match_ex(problems, len(problems), float(alpha), int(iters), float(match_threshold), _p(work),
+                                      work.numel() * work.element_size(), int(flags), _stream()), "gims_sinkhorn_match")
 
 
 def ot_matrix(scores, n, m, alpha, uv):

@@ -308,9 +308,13 @@ int gims_pack_graphs(const gims_pack_image* dev_images /* DEVICE array */, int32
  *   streamed  -- one launch per iteration, Z read from HBM once per iteration (any size);
  *   resident  -- ONE launch for all iterations of a group of problems: exp(Z + u + v) is held in the registers and LDS
  *                of the 256 CUs and scaled lazily by cumulative row / column factors (re-derived from Z every 50 iterations and on the last),
- *                no HBM traffic inside the loop.  Used when the matrices fit on chip (m <= 4096, about 134 MB of
+ *                no HBM traffic inside the loop.  Used when the matrices fit on chip (n, m <= 4096, about 134 MB of
  *                matrix per launch) and are large enough to pay (>= 6 M entries); GIMS_OT_RESIDENT=0 / 2 in the
  *                environment forces streamed / resident.  gims_sinkhorn_plan() tells which one a call will take.
+ *                Two on-chip kernels exist: the 2-D decomposition of csrc/sinkhorn2d.hip (default: a problem is cut into row
+ *                groups, one per XCD, times 128-column blocks, one per CU; the row-sum exchange stays inside the XCD's L2, only
+ *                a 0.5-KB column edge crosses XCDs; start potentials formed in the kernel) and the 1-D row-slab kernel of
+ *                csrc/sinkhorn.hip (GIMS_OT_RES2=0; the cross-check).
  */
 typedef struct gims_ot_problem {
   const float* scores; int64_t ld; int32_t n, m;
@@ -323,6 +327,14 @@ size_t gims_sinkhorn_workspace_bytes(const gims_ot_problem* h_problems, int32_t 
 int gims_sinkhorn_plan(const gims_ot_problem* h_problems, int32_t n_problems, int32_t iters);
 int gims_sinkhorn_match(const gims_ot_problem* h_problems /* HOST array */, int32_t n_problems, float alpha,
                         int32_t iters, float match_threshold, void* work, size_t work_bytes, void* stream);
+/* The same two calls with flags.  GIMS_OT_STREAMED: never take an on-chip kernel -- they occupy every CU of the device for the
+ * whole solve and wait on each other across workgroups, so a caller that runs several streams (or processes) on one GPU
+ * concurrently must use the streamed kernels: next to another stream's kernels an on-chip solve cannot get its 256 workgroups
+ * resident, gives up and is re-solved by the slow rescue path. */
+#define GIMS_OT_STREAMED 1
+int gims_sinkhorn_plan_ex(const gims_ot_problem* h_problems, int32_t n_problems, int32_t iters, int32_t flags);
+int gims_sinkhorn_match_ex(const gims_ot_problem* h_problems /* HOST array */, int32_t n_problems, float alpha,
+                           int32_t iters, float match_threshold, void* work, size_t work_bytes, int32_t flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-pair evaluation after the matcher -- batched over pairs, everything stays on the device.
