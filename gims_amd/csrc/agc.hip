@@ -26,7 +26,7 @@ struct AgcWs {
   uint16_t* dn3;        // non-null: the similarity GEMM runs as GIMS_PREC_BF16X6
   float* S;             // [n][lds]
   uint64_t* bits;       // [n][nw]
-  uint32_t* hist;       // [256]
+  uint32_t* hist;       // [4096] histogram of the current radix digit
   uint32_t* sel;        // [4]: prefix, k_lo, k_hi, pad
   int32_t* deg;         // [n]
   int32_t* nn;          // [n]
@@ -59,7 +59,7 @@ __global__ void agc_init_kernel(const AgcWs* __restrict__ ws) {
     for (int i = 0; i < 8; ++i) w.info[i] = 0;
     for (int i = 0; i < 16; ++i) w.counters[i] = 0;
   }
-  w.hist[threadIdx.x] = 0u;
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) w.hist[i] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------- K1 prologue
@@ -91,40 +91,92 @@ __global__ __launch_bounds__(256) void agc_normalize_kernel(const AgcWs* __restr
 }
 
 // ---------------------------------------------------------------------------------------------- K2 radix select
-__global__ __launch_bounds__(256) void agc_hist_kernel(const AgcWs* __restrict__ ws, int pass) {
+// Exact k-th smallest of the strict upper triangle (agc.py:367-380) by radix select on order-preserving keys in THREE digits
+// (12 + 12 + 8 bits) and TWO sweeps of the N x N matrix instead of four: the second sweep, which only looks at the entries whose
+// top 12 bits equal the selected prefix (about 1 % of them for cosine similarities), also appends those keys to a candidate
+// list (the adjacency-bit buffer, not in use yet), and the last digit is counted from that list.  mode 0: count from S;
+// mode 1: count from S and append the matching keys; mode 2: count from the list (from S if the list overflowed).
+// The order of the list depends on the run; the selected VALUE does not.
+constexpr int AGC_CAND_LDS = 1024;      // (with the 16-KB histogram: 20 KB of LDS per workgroup, eight workgroups per CU -- 32 KB halved the occupancy and cost 60 %)
+__global__ __launch_bounds__(256) void agc_hist_kernel(const AgcWs* __restrict__ ws, int shift, int bits, int mode) {
   const AgcWs& w = ws[blockIdx.y];
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
+  __shared__ uint32_t h[4096];
+  __shared__ uint32_t cand[AGC_CAND_LDS];
+  __shared__ uint32_t ncand, gbase;
+  const int nb = 1 << bits;
+  for (int i = threadIdx.x; i < nb; i += 256) h[i] = 0;
+  if (threadIdx.x == 0) ncand = 0;
   __syncthreads();
   const uint32_t prefix = w.sel[0];
-  const int shift = 24 - 8 * pass;
-  const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-  for (int i = blockIdx.x; i < w.n; i += gridDim.x) {
-    const float* row = w.S + (int64_t)i * w.lds;
-    // 16-byte loads over the strict upper triangle of row i (rows are 16-byte aligned: lds % 4 == 0)
-    for (int j4 = ((i + 1) & ~3) + 4 * threadIdx.x; j4 < w.n; j4 += 4 * 256) {
-      const float4 v = *(const float4*)(row + j4);
-      const float x[4] = {v.x, v.y, v.z, v.w};
+  const uint32_t himask = shift + bits >= 32 ? 0u : (0xffffffffu << (shift + bits));
+  const uint32_t dmask = (uint32_t)nb - 1u;
+  uint32_t* list = (uint32_t*)w.bits;
+  const uint32_t cap = (uint32_t)((int64_t)w.n * w.nw * 2);
+  const uint32_t nlist = w.sel[3];
+  if (mode == 2 && nlist <= cap) {                 // the candidates of the previous sweep (they share the prefix of THAT sweep)
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) {
+      const uint32_t k = list[i];
+      if ((k & himask) == (prefix & himask)) atomicAdd(&h[(k >> shift) & dmask], 1u);
+    }
+  } else {
+    for (int i = blockIdx.x; i < w.n; i += gridDim.x) {
+      const float* row = w.S + (int64_t)i * w.lds;
+      // 16-byte loads over the strict upper triangle of row i (rows are 16-byte aligned: lds % 4 == 0), four in flight per thread
+      for (int j0 = ((i + 1) & ~3) + 4 * threadIdx.x; j0 < w.n; j0 += 4 * 4 * 256) {
+        float4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int j = j4 + q;
-        if (j > i && j < w.n) {
-          const uint32_t k = f32_key(x[q]);
-          if ((k & himask) == (prefix & himask)) atomicAdd(&h[(k >> shift) & 255u], 1u);
+        for (int u = 0; u < 4; ++u) {
+          const int j4 = j0 + u * 4 * 256;
+          const f32x4 q4 = j4 < w.n ? __builtin_nontemporal_load((const f32x4*)(row + j4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          v[u] = make_float4(q4[0], q4[1], q4[2], q4[3]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j4 = j0 + u * 4 * 256;
+          const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = j4 + q;
+            if (j > i && j < w.n) {
+              const uint32_t k = f32_key(x[q]);
+              if ((k & himask) == (prefix & himask)) {
+                atomicAdd(&h[(k >> shift) & dmask], 1u);
+                if (mode == 1) {
+                  const uint32_t slot = atomicAdd(&ncand, 1u);
+                  if (slot < AGC_CAND_LDS) cand[slot] = k;
+                }
+              }
+            }
+          }
         }
       }
     }
   }
   __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&w.hist[threadIdx.x], h[threadIdx.x]);
+  for (int i = threadIdx.x; i < nb; i += 256)
+    if (h[i]) atomicAdd(&w.hist[i], h[i]);
+  if (mode == 1) {
+    const uint32_t nc = ncand;
+    if (threadIdx.x == 0) {
+      // one reservation per workgroup; a workgroup whose LDS buffer ran over, or a list that would, marks the list unusable
+      gbase = nc <= AGC_CAND_LDS ? atomicAdd(&w.sel[3], nc) : 0xffffffffu;
+      if (nc > AGC_CAND_LDS) atomicOr(&w.sel[3], 0x80000000u);
+    }
+    __syncthreads();
+    const uint32_t base = gbase;
+    if (base != 0xffffffffu && base + nc <= cap)
+      for (uint32_t i = threadIdx.x; i < nc; i += 256) list[base + i] = cand[i];
+  }
 }
 
-// the bin holding rank k: parallel inclusive scan of the 256 counts (a single lane walking them through LDS took 16-19 us)
-__global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__ ws, int pass) {
+// the bin holding rank k: parallel inclusive scan of the counts (thread t owns nb / 256 consecutive bins)
+__global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__ ws, int shift, int bits) {
   const AgcWs& w = ws[blockIdx.y];
   __shared__ uint64_t wsum[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const uint64_t v = w.hist[t];
+  const int nb = 1 << bits, per = nb >> 8;             // bits >= 8
+  uint64_t v = 0;
+  for (int q = 0; q < per; ++q) v += w.hist[t * per + q];
   uint64_t incl = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -135,17 +187,25 @@ __global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__
   __syncthreads();
   for (int q = 0; q < wave; ++q) incl += wsum[q];
   const uint64_t k = (uint64_t)w.sel[1] | ((uint64_t)w.sel[2] << 32);
-  const uint64_t excl = incl - v;
-  // first bin b < 255 with cum(b) + h[b] > k, else 255 (the reference walk)
-  const bool hit = t < 255 ? (excl <= k && k < incl) : excl <= k;
+  uint64_t excl = incl - v;
+  // first bin b < nb - 1 with cum(b) + h[b] > k, else nb - 1 (the reference walk): the owning thread walks its own bins
+  const bool mine = t < 255 ? (excl <= k && k < incl) : excl <= k;
   __syncthreads();                      // every thread has read sel[1..2]
-  if (hit) {
+  if (mine) {
+    int b = t * per;
+    for (int q = 0; q < per; ++q, ++b) {
+      const uint64_t c = w.hist[b];
+      if (k < excl + c || b == nb - 1) break;
+      excl += c;
+    }
     const uint64_t r = k - excl;
-    w.sel[0] |= ((uint32_t)t) << (24 - 8 * pass);
+    w.sel[0] |= ((uint32_t)b) << shift;
     w.sel[1] = (uint32_t)r;
     w.sel[2] = (uint32_t)(r >> 32);
   }
-  w.hist[t] = 0;
+  __syncthreads();
+  for (int q = 0; q < per; ++q) w.hist[t * per + q] = 0;
+  for (int i = nb + t; i < 4096; i += 256) w.hist[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------- K3 adjacency bits
@@ -641,7 +701,7 @@ static size_t agc_layout(int n, int d, int max_edges_dir, char* base, AgcWs* w) 
   p = take((size_t)n * d * 6); if (w) { w->dn = (float*)p; w->dn3 = (d % 32 == 0 && agc_sim_x6()) ? (uint16_t*)p : nullptr; }
   p = take((size_t)n * lds * 4); if (w) w->S = (float*)p;
   p = take((size_t)n * nw * 8); if (w) w->bits = (uint64_t*)p;
-  p = take(256 * 4); if (w) w->hist = (uint32_t*)p;
+  p = take(4096 * 4); if (w) w->hist = (uint32_t*)p;
   p = take(16); if (w) w->sel = (uint32_t*)p;
   p = take((size_t)n * 4); if (w) w->deg = (int32_t*)p;
   p = take((size_t)n * 4); if (w) w->nn = (int32_t*)p;
@@ -743,10 +803,12 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   int hgrid = 4096 / (B > 0 ? B : 1);
   hgrid = hgrid < 16 ? 16 : (hgrid > 1024 ? 1024 : hgrid);
   hgrid = hgrid < maxn ? hgrid : maxn;
-  for (int pass = 0; pass < 4; ++pass) {
-    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, pass);
-    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, pass);
-  }
+  hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 20, 12, 0);
+  hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 20, 12);
+  hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 8, 12, 1);
+  hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 8, 12);
+  hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 0, 8, 2);
+  hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 0, 8);
   // K3
   hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv(maxn, 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
   hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 1);
