@@ -354,8 +354,8 @@ extern "C" int gims_pyramid_build(const uint8_t* img, int32_t h, int32_t w, int3
 extern "C" int gims_patch_affine(const float* kp4, const int32_t* kp_octave, int32_t n_kp, double* A_out, int32_t* level_out, void* stream) {
   using namespace gims;
   GIMS_CHECK_ARG(n_kp >= 0 && (n_kp == 0 || (kp4 && kp_octave && A_out && level_out)), "gims_patch_affine: bad arguments");
-  if (n_kp > 0)
-    hipLaunchKernelGGL(patch_affine_kernel, dim3(cdiv(n_kp, 64)), dim3(64), 0, (hipStream_t)stream, kp4, kp_octave, n_kp, A_out, level_out);
+  if (n_kp == 0) return GIMS_OK;
+  hipLaunchKernelGGL(patch_affine_kernel, dim3(cdiv(n_kp, 64)), dim3(64), 0, (hipStream_t)stream, kp4, kp_octave, n_kp, A_out, level_out);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

@@ -76,6 +76,13 @@ int main() {
   EXPECT(gims_linear(nullptr, nullptr) != GIMS_OK);
   EXPECT(gims_linear_batch(nullptr, 0, 0, 0, GIMS_PREC_F32, nullptr) != GIMS_OK);
   EXPECT(gims_attention(nullptr, 0, 0, 0, 0, nullptr, 0, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_attention_stat(nullptr, 0, 0, 0, 0, nullptr, 0, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_attention_stat((const uint16_t*)0x1000, 768, 0, 256, 512, (const gims_attn_problem*)0x2000, 1, 64, 4, (float*)0x3000, 256, nullptr, nullptr, 0, 0,
+                             (uint64_t*)0x4004, nullptr) == GIMS_EINVAL);      // misaligned statistics accumulator
+  EXPECT(gims_patch_affine(nullptr, nullptr, 3, nullptr, nullptr, nullptr) == GIMS_EINVAL);
+  EXPECT(gims_patch_affine(nullptr, nullptr, 0, nullptr, nullptr, nullptr) == GIMS_OK);          // nothing to do
+  EXPECT(gims_sinkhorn_plan_ex(pr.data(), (int)pr.size(), 100, GIMS_OT_STREAMED) == 0);           // streamed on request, whatever the sizes
+  EXPECT(gims_sinkhorn_match_ex(nullptr, 0, 1.f, 10, 0.2f, nullptr, 0, GIMS_OT_STREAMED, nullptr) == GIMS_EINVAL);
   EXPECT(gims_train_loss(nullptr, 0, nullptr, 0, 1.f, 0.45f, 1.f, nullptr, nullptr, nullptr, nullptr) == GIMS_EINVAL);
   EXPECT(gims_ingest_images(nullptr, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr) == GIMS_EINVAL);
   EXPECT(gims_pack_graphs(nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr) == GIMS_EINVAL);
