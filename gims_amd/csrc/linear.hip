@@ -322,6 +322,10 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int m0 = ((slot / nt_n) * 8 + xcd) * TM, n0 = (slot % nt_n) * TN;
   if (m0 >= p.m) return;
+  // probe (tools/gemm_probe.py): flag 0x1000 starts the workgroups of the odd slots conv_reserved x 3.4 us late, so that the
+  // HBM-bound epilogues of one half of the CUs fall into the L2-bound K loops of the other half
+  if ((p.flags & 0x1000) && (slot & 1))
+    for (int d = 0; d < p.conv_reserved; ++d) __builtin_amdgcn_s_sleep(127);
   const int li = lane & 31, lh = lane >> 5;
   // diagnostic bits (tools/gemm_probe.py only): 0x100 = no main loop, 0x200 = no epilogue memory traffic
   const int nk = (p.flags & 0x100) ? 0 : p.k / BK;

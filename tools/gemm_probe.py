@@ -50,10 +50,11 @@ def main():
     print(f"rows={rows} reps={reps} GIMS_X3P_TILE={os.environ.get('GIMS_X3P_TILE', '(default)')}")
     for name, (mk, flops, byts) in cases.items():
         res = []
-        variants = [0, 0]          # repeats of the full kernel: the first timing of a case runs on a cold clock
+        variants = [0, 0] + ([0x1000 + d for d in (1, 2, 3, 4, 6, 8)] if os.environ.get("GIMS_PROBE_DELAY") else [])   # repeats of the full kernel (the first timing of a case runs on a cold clock); 0x1000 + d: odd slots start d x 3.4 us late
         for fl in [0, 0x200, 0x100, 0x200 | 0x400, 0x200 | 0x800] + variants:
             a = mk()
-            a.flags |= fl
+            a.flags |= fl & ~0xff
+            a.conv_reserved = fl & 0xff
             for _ in range(10):
                 lib.gims_linear(C.byref(a), st)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

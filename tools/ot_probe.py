@@ -19,7 +19,7 @@ def make(n, np_, seed=0):
 
 
 def run(items, iters, resident, reps=3):
-    os.environ["GIMS_OT_RESIDENT"] = "1" if resident else "0"
+    os.environ["GIMS_OT_RESIDENT"] = str(int(resident))        # 0 streamed, 1 on-chip where the plan says so, 2 on-chip forced
     probs = hip.make_ot_problems(items)
     work = torch.empty(hip.sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device="cuda")
     ms = []

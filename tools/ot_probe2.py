@@ -13,14 +13,12 @@ for n, np_ in cases:
     os.environ["GIMS_OT_RES2"] = "1"
     t0, uv0, m0 = run(items, 100, False)
     os.environ["GIMS_OT_RES2"] = "0"
-    t1, uv1, m1 = run(items, 100, True)
-    os.environ["GIMS_OT_RESIDENT"] = "2"
+    t1, uv1, m1 = run(items, 100, 2)
     os.environ["GIMS_OT_RES2"] = "1"
     os.environ["GIMS_OT_R2_INIT"] = "0"
-    t3, uv3, m3 = run(items, 100, True)
-    os.environ["GIMS_OT_RESIDENT"] = "2"
+    t3, uv3, m3 = run(items, 100, 2)
     os.environ["GIMS_OT_R2_INIT"] = "1"
-    t2, uv2, m2 = run(items, 100, True)
+    t2, uv2, m2 = run(items, 100, 2)
     for name, (uv, m) in (("1-D", (uv1, m1)), ("2-D", (uv2, m2)), ("2-D, separate init", (uv3, m3))):
         du = max(float((a[:-1] - b[:-1]).abs().max()) for a, b in zip(uv0, uv))
         st = max(float(b[-1]) for b in uv)
