@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) stale |= (__float_as_uint(q[e]) == 0xFFFFFFFFu ? 1u : 0u) << e;
           if ((stale & vmask) == 0) break;
-          if (++spins > (1 << 16)) { fail_flag = 1; break; }
+          if (++spins > (1 << 16)) { fail_flag = 1; atomicMax(p.placement + 1, 1); break; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) stale |= (__float_as_uint(q[e]) == 0xFFFFFFFFu ? 1u : 0u) << e;
         if ((stale & vmask) == 0) break;
-        if (++spins > (1 << 16)) { fail_flag = 1; break; }
+        if (++spins > (1 << 16)) { fail_flag = 1; atomicMax(p.placement + 1, 2); break; }
         __builtin_amdgcn_s_sleep(1);
       }
       *(f32x4*)(facs + 4 * t) = q;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) stale |= ((__float_as_uint(q[e]) ^ tagbit) >> 31) << e;
           if ((stale & vmask) == 0) break;
-          if (++spins > (1 << 16)) { fail_flag = 1; break; }
+          if (++spins > (1 << 16)) { fail_flag = 1; atomicMax(p.placement + 1, 3); break; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) stale |= ((__float_as_uint(q[e]) ^ tagbit) >> 31) << e;
         if ((stale & vmask) == 0) break;
-        if (++spins > (1 << 16)) { fail_flag = 1; break; }
+        if (++spins > (1 << 16)) { fail_flag = 1; atomicMax(p.placement + 1, 4); break; }
         __builtin_amdgcn_s_sleep(1);
       }
       *(f32x4*)(facs + 4 * t) = f32x4{fabsf(q[0]), fabsf(q[1]), fabsf(q[2]), fabsf(q[3])};
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) stale |= ((__float_as_uint(q[e]) ^ xtagbit) >> 31) << e;
             if ((stale & vmask) == 0) break;
-            if (++spins > (1 << 16)) { fail_flag = 1; break; }
+            if (++spins > (1 << 16)) { fail_flag = 1; atomicMax(p.placement + 1, 5); break; }
             __builtin_amdgcn_s_sleep(1);
           }
         *(f32x4*)(xrd + xs * R2_CSEG + 4 * qd) = f32x4{fabsf(q[0]), fabsf(q[1]), fabsf(q[2]), fabsf(q[3])};
@@ -849,6 +849,12 @@ int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int 
       hipLaunchKernelGGL(ot_res2_kernel<false>, dim3(256), dim3(512), lds, s, a);
       GIMS_LAUNCH_CHECK();
     }
+  }
+  if (r2_env("GIMS_OT_R2_DEBUG", 0)) {          // diagnostics (synchronous): which bounded wait ran out, by site number in source order
+    int h[4] = {0, 0, 0, 0};
+    GIMS_HIP(hipStreamSynchronize(s));
+    GIMS_HIP(hipMemcpy(h, dplace, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[ot_res2 debug] nx=%d nc=%d placement flag %d, last bounded wait that ran out: site %d\n", P.nx, P.nc, h[0], h[1]);
   }
   if (h_place && place_ev && !wt_local) {
     if (hipEventQuery(place_ev) != hipErrorNotReady) {      // the previous read-back (if any) has landed: start the next one
