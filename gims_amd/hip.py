@@ -97,6 +97,16 @@ class Segments(C.Structure):
     _fields_ = [("n", C.c_int32), ("off", C.c_int32 * 8), ("rows", C.c_int32 * 8)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
+                ("group", C.c_int32), ("reserved", C.c_int32)]
+
+
+class AdamGroup(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("step", C.c_int64)]
+
+
 class EvalPair(C.Structure):
     _fields_ = [("kpts0", C.c_void_p), ("kpts1", C.c_void_p), ("matches0", C.c_void_p), ("mscores0", C.c_void_p),
                 ("n0", C.c_int32), ("n1", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("h_gt", C.c_float * 9),
@@ -211,6 +221,7 @@ _SIGNATURES = {
     "gims_head_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gims_sage_mean_transposed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gims_normalize_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gims_adam_step": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.POINTER(AdamGroup), C.c_int32, C.c_void_p]),
     "gims_ot_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
 }
@@ -1143,3 +1154,19 @@ def head_pack(proj_w, proj_b, merge_w, wqkv, bqkv, wm, heads: int, to_params: bo
     pw = (C.c_void_p * 3)(*[t.data_ptr() for t in proj_w])
     pb = (C.c_void_p * 3)(*[t.data_ptr() for t in proj_b])
     _check(load().gims_head_pack(pw, pb, _p(merge_w), _p(wqkv), _p(bqkv), _p(wm), merge_w.shape[0], int(heads), int(to_params), _stream()), "gims_head_pack")
+
+
+ADAM_TENSOR_DTYPE = [("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("n", "<i8"), ("group", "<i4"), ("reserved", "<i4")]
+
+
+def adam_step(table, groups):
+    """One fused Adam step (gims_adam_step).  table: C-contiguous NumPy structured array of dtype ADAM_TENSOR_DTYPE (= gims_adam_tensor:
+    device pointers of contiguous float32 tensors, element count, group index); groups: at most 8 dicts with lr, beta1, beta2, eps,
+    weight_decay, step (1-based, after the increment)."""
+    import numpy as np
+    assert table.dtype == np.dtype(ADAM_TENSOR_DTYPE) and table.flags["C_CONTIGUOUS"] and table.dtype.itemsize == C.sizeof(AdamTensor)
+    gt = (AdamGroup * max(len(groups), 1))()
+    for i, g in enumerate(groups):
+        gt[i].lr, gt[i].beta1, gt[i].beta2, gt[i].eps, gt[i].weight_decay, gt[i].step = (float(g["lr"]), float(g["beta1"]), float(g["beta2"]), float(g["eps"]),
+                                                                                      float(g["weight_decay"]), int(g["step"]))
+    _check(load().gims_adam_step(table.ctypes.data_as(C.POINTER(AdamTensor)), len(table), gt, len(groups), _stream()), "gims_adam_step")

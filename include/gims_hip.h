@@ -594,6 +594,17 @@ int gims_sage_mean_transposed(const float* g, int64_t ldg, const int32_t* indptr
 /* normalize_keypoints (gmatcher.py:26-33) as a tensor: out [n][2] = (kpts - norm3[seg][0..1]) / norm3[seg][2]. */
 int gims_normalize_keypoints(const float* kpts, const float* norm3, const int32_t* seg_of_row, int64_t n, float* out, void* stream);
 
+/* ---- optimizer step of the training loop (train.py:52-57 builds torch.optim.Adam over three parameter groups -- BatchNorm weights +
+ * bin_score / other weights with weight decay / biases --, train.py:138 calls optimizer.step()) ----
+ * One fused multi-tensor Adam step over HOST tables of device pointers (contiguous float32 tensors): ~count/80 launches for the
+ * whole model instead of one list-kernel per operation and 64-tensor bucket.  Arithmetic = torch's _single_tensor_adam (amsgrad =
+ * False, maximize = False), operation by operation in float32; the step-dependent scalars (lr / (1 - beta1^step), sqrt(1 - beta2^step))
+ * are formed in double and rounded once.  `step` is the 1-based count AFTER this step's increment, per group (torch keeps it per
+ * parameter; all parameters of a group that are stepped together share it).  Tensors with n = 0 are skipped. */
+typedef struct gims_adam_tensor { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t n; int32_t group; int32_t reserved; } gims_adam_tensor;
+typedef struct gims_adam_group { double lr, beta1, beta2, eps, weight_decay; int64_t step; } gims_adam_group;
+int gims_adam_step(const gims_adam_tensor* tensors, int32_t count, const gims_adam_group* groups, int32_t n_groups /* <= 8 */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

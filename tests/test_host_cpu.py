@@ -175,3 +175,29 @@ def test_training_entry_points_validate_arguments_without_a_gpu():
     assert lib.gims_head_pack(None, None, None, None, None, None, 256, 4, 0, None) == -1
     assert lib.gims_permute3(None, None, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, None) == -1
     assert lib.gims_sinkhorn_history_floats(10, 12, 5) == 6 * 24
+
+
+def test_adam_table_layout_and_cpu_refusal():
+    """gims_adam_tensor / gims_adam_group as the binding lays them out (include/gims_hip.h), and the optimizer's refusal to step CPU
+    parameters (there is no CPU path)."""
+    import ctypes as C
+    import numpy as np
+    import pytest
+    import torch
+    from gims_amd import hip
+    from gims_amd.optim import Adam
+    assert C.sizeof(hip.AdamTensor) == 48 == np.dtype(hip.ADAM_TENSOR_DTYPE).itemsize
+    assert [f[0] for f in hip.AdamTensor._fields_] == [f[0] for f in hip.ADAM_TENSOR_DTYPE]
+    assert C.sizeof(hip.AdamGroup) == 48
+    p = [torch.nn.Parameter(torch.zeros(4))]
+    with pytest.raises(NotImplementedError):
+        Adam(p, amsgrad=True)
+    with pytest.raises(ValueError):
+        Adam(p, lr=-1.0)
+    o = Adam(p, lr=1e-3, weight_decay=1e-4)
+    assert o.param_groups[0]['betas'] == (0.9, 0.999) and o.param_groups[0]['weight_decay'] == 1e-4
+    o.add_param_group({'params': [torch.nn.Parameter(torch.zeros(2))], 'weight_decay': 0.5})       # train.py:56
+    assert len(o.param_groups) == 2 and o.param_groups[1]['lr'] == 1e-3
+    p[0].grad = torch.ones(4)
+    with pytest.raises(RuntimeError):
+        o.step()

@@ -16,6 +16,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gims_amd import GMatcher, synth  # noqa: E402
+from gims_amd.optim import Adam as FusedAdam  # noqa: E402
 from tools.gen_pairs import matches_of  # noqa: E402
 
 
@@ -28,14 +29,14 @@ def batch(n, seed, device):
     return d
 
 
-def measure(keypoints=2048, steps=10, warmup=2, precision="bf16x6", with_cpu=True):
+def measure(keypoints=2048, steps=10, warmup=2, precision="bf16x6", with_cpu=True, optimizer="fused"):
     """The JSON block of one measurement (also embedded in bench.py's line as `train_step`)."""
     cfg = {"sinkhorn_iterations": 100, "pos_loss_weight": 0.45, "neg_loss_weight": 1.0, "train_precision": precision}
     sd = synth.make_state_dict(123)
     m = GMatcher(cfg)
     m.load_state_dict(sd)
     m = m.cuda().train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    opt = (torch.optim.Adam if optimizer == "torch" else FusedAdam)(m.parameters(), lr=1e-4)      # train.py:53
     fw, bw, st, losses = [], [], [], []
     with torch.enable_grad():
         for i in range(warmup + steps):
@@ -58,7 +59,7 @@ def measure(keypoints=2048, steps=10, warmup=2, precision="bf16x6", with_cpu=Tru
            "ms_per_step": 1e3 * float(np.median(st)), "forward_ms": 1e3 * float(np.median(fw)), "backward_ms": 1e3 * float(np.median(bw)),
            "optimizer_ms": 1e3 * float(np.median(st) - np.median(fw) - np.median(bw)), "steps": steps, "loss_first_last": [losses[0], losses[-1]],
            "dtype": "split-%s MFMA products, f32 everything else" % precision, "data": "synthetic",
-           "config": {"workload": "1 pair/step of 2x%d synthetic keypoints, 18 layers, 100 Sinkhorn iterations, train() mode forward + backward + Adam" % keypoints}}
+           "config": {"workload": "1 pair/step of 2x%d synthetic keypoints, 18 layers, 100 Sinkhorn iterations, train() mode forward + backward + Adam (%s)" % (keypoints, "gims_amd.optim.Adam, fused" if optimizer != "torch" else "torch.optim.Adam"), "optimizer": optimizer}}
     if with_cpu:
         from oracle import gims_oracle as O
         cores = min(os.cpu_count() or 1, 16)            # more threads than that make torch's CPU autograd crawl on many-core hosts
@@ -78,8 +79,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "bf16x3"])
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"], help="gims_amd.optim.Adam (one fused multi-tensor launch sequence) or torch.optim.Adam")
     a = ap.parse_args()
-    print(json.dumps(measure(a.keypoints, a.steps, a.warmup, a.precision, not a.no_cpu)))
+    print(json.dumps(measure(a.keypoints, a.steps, a.warmup, a.precision, not a.no_cpu, a.optimizer)))
 
 
 if __name__ == "__main__":
