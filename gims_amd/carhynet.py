@@ -26,7 +26,7 @@ EPS_L2_NORM = 1e-10
 
 
 class CARHyNet(nn.Module):
-    chunk = 2048                      # patches per pass
+    chunk = 8192                      # patches per pass (32 per CU and launch: the start-time stagger of the per-patch kernels and the launch tails amortise)
     fused_sandglass = True            # False: the layer-by-layer kernels (kept as the cross-check of the fused one)
     fused_frn = True                  # likewise for the FRN (+ CoordAtt) + TLU block
     fused_conv = True                 # 3x3 convolution + FRN block of layers 2-6 as ONE per-patch kernel (gims_ch_conv_block); False: GEMM + FRN block

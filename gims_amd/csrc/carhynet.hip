@@ -467,7 +467,18 @@ struct ConvGeom {
   // hi chunk of channels [16 ks + 8 lh, +8) inside the pixel record; the lo chunk is HB further
   __device__ static __forceinline__ int chunk(int ks, int lh) { return (ks / (HB / 2)) * (2 * HB) + 2 * (ks % (HB / 2)) + lh; }
 };
-struct ChFirst { const float* fw0; const float* fb0; const float* tau0; float eps0; unsigned long long* prof; };   // prof: GIMS_CH_PROF=1 phase stamps, else null   // FRN(3) + TLU(3) in front of the first convolution
+// Start-time stagger of the per-patch kernels (GIMS_CH_STAGGER = cycles per slot; 0 = off).  Every workgroup of these kernels takes the
+// same time and all 256 CUs start together, so their HBM phases (patch load, result store) coincide: 256 x 128 KB arrive as one burst at
+// the HBM rate while the memory idles during the compute phases.  Delaying workgroup b of the FIRST resident wave by ((b / 8) % 8) slots
+// spreads the bursts; later workgroups inherit the offsets from the ones they replace.
+__device__ __forceinline__ void ch_stagger(int cycles, int first_wave) {
+  if (cycles > 0 && (int)blockIdx.x < first_wave) {
+    const long long wait = (long long)(((int)blockIdx.x >> 3) & 7) * cycles;
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
+}
+struct ChFirst { const float* fw0; const float* fb0; const float* tau0; float eps0; unsigned long long* prof; int stagger, first_wave; };   // prof: GIMS_CH_PROF=1 phase stamps, else null   // FRN(3) + TLU(3) in front of the first convolution
 
 // FIRST (layer 1, models.py:316-323): xin is the raw f32 patch [32*32][3]; FRN(3) + TLU(3) run here and the result is written
 // into the LDS image as 16-channel split-bf16 pixel records (channels 3-15 zero) -- no operand rows through HBM at all.
@@ -486,6 +497,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   const int li = lane & 31, lh = lane >> 5;
   const int64_t patch = blockIdx.x;
   auto stamp = [&](int k) __attribute__((always_inline)) { if (first.prof && blockIdx.x == gridDim.x / 2 && t == 0) first.prof[k] = __builtin_readcyclecounter(); };
+  ch_stagger(first.stagger, first.first_wave);
   stamp(0);
 
   // ---- input patch -> LDS (swizzled chunks) + ONE all-zero pixel record that every out-of-image tap reads (no border in LDS:
@@ -672,6 +684,7 @@ struct ChSandglassW {          // all f32, BatchNorm folded
   const float* dw1;   // [9][C]
   const float* dw1b;  // [C]
   unsigned long long* prof;   // GIMS_CH_PROF=1: cycle stamps of one workgroup, else null
+  int stagger, first_wave;    // GIMS_CH_STAGGER (ch_stagger)
 };
 
 template <int C, int HW, int NT>      // HW = H = W, NT threads
@@ -683,15 +696,17 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   float* pw = ph + HW * C;                  // [HW][C]  -> a_w
   float* mid = pw + HW * C;                 // [2 HW][8]
   float* wl = mid + 2 * HW * 8;             // dw0 [9][C], dw0b [C], dw1 [9][C], dw1b [C], p0 [16][C], p0b [16], p1 [C][16], p1b [C]
-  float* l_dw0 = wl, *l_dw0b = l_dw0 + 9 * C, *l_dw1 = l_dw0b + C, *l_dw1b = l_dw1 + 9 * C, *l_p0 = l_dw1b + C, *l_p0b = l_p0 + 16 * C,
-        *l_p1 = l_p0b + 16, *l_p1b = l_p1 + 16 * C;
+  constexpr int P0P = C + 4, P1P = 20;      // padded pitches of the pointwise weights: their MFMA fragment reads (one row per lane) are conflict-free
+  float* l_dw0 = wl, *l_dw0b = l_dw0 + 9 * C, *l_dw1 = l_dw0b + C, *l_dw1b = l_dw1 + 9 * C, *l_p0 = l_dw1b + C, *l_p0b = l_p0 + 16 * P0P,
+        *l_p1 = l_p0b + 16, *l_p1b = l_p1 + C * P1P;
   const int t = threadIdx.x;
   const int64_t pbase = (int64_t)blockIdx.x * NPIX;
   const float* xp = x + pbase * C;
   auto stamp = [&](int k) __attribute__((always_inline)) { if (wts.prof && blockIdx.x == gridDim.x / 2 && t == 0) wts.prof[k] = __builtin_readcyclecounter(); };
+  ch_stagger(wts.stagger, wts.first_wave);
   stamp(0);
   for (int i = t; i < 9 * C; i += NT) { l_dw0[i] = wts.dw0[i]; l_dw1[i] = wts.dw1[i]; }
-  for (int i = t; i < 16 * C; i += NT) { l_p0[i] = wts.p0[i]; l_p1[i] = wts.p1[i]; }
+  for (int i = t; i < 16 * C; i += NT) { l_p0[(i / C) * P0P + i % C] = wts.p0[i]; l_p1[(i / 16) * P1P + i % 16] = wts.p1[i]; }
   if (t < C) { l_dw0b[t] = wts.dw0b[t]; l_dw1b[t] = wts.dw1b[t]; l_p1b[t] = wts.p1b[t]; }
   if (t < 16) l_p0b[t] = wts.p0b[t];
   __syncthreads();
@@ -780,46 +795,88 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
     float acc = (is_h ? wts.bh : wts.bw)[ch];
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc = fmaf(mr[m], wt[m], acc);
-    (is_h ? ph : pw)[j] = 1.f / (1.f + __expf(-acc));
+    // a_w is stored with its channel quads XOR-swizzled by the column index: phase C reads one column per lane (stride C floats)
+    (is_h ? ph : pw)[is_h ? j : r * C + 4 * ((ch >> 2) ^ (r & MASK)) + (ch & 3)] = 1.f / (1.f + __expf(-acc));
   }
   __syncthreads();
   stamp(5);
-  // ---- C: per pixel  z = ReLU6(W1 (W0 (y a_w a_h) + b0) + b1), in place
-  for (int pix = t; pix < NPIX; pix += NT) {
-    const int yy = pix / HW, xx = pix % HW;
-    // the pointwise weights are read with UNIFORM (compile-time) indices straight from global memory: the compiler turns
-    // them into scalar loads (SGPR operands of the fmas) -- as LDS broadcast reads they were 256 of the ~300 LDS reads per
-    // pixel of this phase, which is LDS-bandwidth bound
-    typedef const __attribute__((address_space(4))) float* cfp;      // constant address space: uniform loads become s_load
-    const cfp gp0 = (cfp)wts.p0, gp1 = (cfp)wts.p1, gb0 = (cfp)wts.p0b, gb1 = (cfp)wts.p1b;
-    float hid[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) hid[m] = gb0[m];
-#pragma unroll
-    for (int cq = 0; cq < QPP; ++cq) {
-      const float4 v = *(const float4*)(ybuf + slot(pix, cq));
-      const float4 g1 = *(const float4*)(ph + yy * C + 4 * cq), g2 = *(const float4*)(pw + xx * C + 4 * cq);
-      const float tv[4] = {v.x * g2.x * g1.x, v.y * g2.y * g1.y, v.z * g2.z * g1.z, v.w * g2.w * g1.w};
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const cfp k4 = gp0 + m * C + 4 * cq;
-        hid[m] = fmaf(tv[0], k4[0], fmaf(tv[1], k4[1], fmaf(tv[2], k4[2], fmaf(tv[3], k4[3], hid[m]))));
-      }
-    }
-#pragma unroll
-    for (int cq = 0; cq < QPP; ++cq) {
-      float r[4];
+  // ---- C: per pixel  z = ReLU6(W1 (W0 (y a_w a_h) + b0) + b1), in place -- on the matrix cores, three bf16 passes per product like the
+  // convolutions.  A wave owns 32-pixel blocks, one pixel per lane COLUMN:  hid^T [16 (+16 zero rows)][32 px] = W0 T^T  over C / 16
+  // k-steps, then  z^T [32 ch][32 px] = W1 hid  per 32-channel block.  The C layout of hid^T (lane = pixel, registers 0-7 = hidden units
+  // (j & 3) + 8 (j >> 2) + 4 lh) IS a B-operand layout of the second product once W1's k-slots are loaded in that order, so the
+  // hidden vector never leaves registers; the z^T registers 4g..4g+3 are channel quad 2g + lh of the lane's pixel and go back over the
+  // pixel's LDS record as float4.  (As per-pixel VALU work this phase was 1 M fma per patch: 23 k of the kernel's 79 k cycles at
+  // 32x32x32, and at 16x16x64 only a quarter of the threads had a pixel.)
+  {
+    const int lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+    constexpr int KS = C / 16, NBK = C / 32, NWAVES = NT / 64, NBLK = NPIX / 32;
+    auto split8 = [&](const float (&v)[8], bf16x8& hi, bf16x8& lo) __attribute__((always_inline)) {
+      uint32_t h[4], l[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float acc = gb1[4 * cq + j];
-#pragma unroll
-        for (int m = 0; m < 16; m += 4) {
-          const cfp k4 = gp1 + (4 * cq + j) * 16 + m;
-          acc = fmaf(hid[m], k4[0], fmaf(hid[m + 1], k4[1], fmaf(hid[m + 2], k4[2], fmaf(hid[m + 3], k4[3], acc))));
-        }
-        r[j] = fminf(fmaxf(acc, 0.f), 6.f);
+        h[j] = pack_bf2(v[2 * j], v[2 * j + 1]);
+        l[j] = pack_bf2(v[2 * j] - __uint_as_float(h[j] << 16), v[2 * j + 1] - __uint_as_float(h[j] & 0xffff0000u));
       }
-      *(float4*)(ybuf + slot(pix, cq)) = make_float4(r[0], r[1], r[2], r[3]);
+      hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+      lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+    };
+    bf16x8 a0h[KS], a0l[KS], a1h[NBK], a1l[NBK];
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {                       // W0 rows = hidden units (rows 16-31 are padding), k = channels 16 s + 8 lh ..
+      float w[8];
+      const float4 w0 = *(const float4*)(l_p0 + (li & 15) * P0P + 16 * s2 + 8 * lh), w1 = *(const float4*)(l_p0 + (li & 15) * P0P + 16 * s2 + 8 * lh + 4);
+      const float keep = li < 16 ? 1.f : 0.f;
+      w[0] = w0.x * keep; w[1] = w0.y * keep; w[2] = w0.z * keep; w[3] = w0.w * keep;
+      w[4] = w1.x * keep; w[5] = w1.y * keep; w[6] = w1.z * keep; w[7] = w1.w * keep;
+      split8(w, a0h[s2], a0l[s2]);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {                      // W1 rows = output channels 32 nb + li, k-slot j = hidden (j & 3) + 8 (j >> 2) + 4 lh
+      const float4 w0 = *(const float4*)(l_p1 + (32 * nb + li) * P1P + 4 * lh), w1 = *(const float4*)(l_p1 + (32 * nb + li) * P1P + 8 + 4 * lh);
+      const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      split8(w, a1h[nb], a1l[nb]);
+    }
+    const float4 hb0 = *(const float4*)(l_p0b + 4 * lh), hb1 = *(const float4*)(l_p0b + 8 + 4 * lh);
+    for (int blk = wave; blk < NBLK; blk += NWAVES) {
+      int l2 = li;
+      asm volatile("" : "+v"(l2));                          // (keeps the per-block addresses out of the loop-invariant set: registers)
+      const int pix = 32 * blk + l2, yy = pix / HW, xx = pix % HW;
+      f32x16 hacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        const int q0 = 4 * s2 + 2 * lh;
+        const float4 v0 = *(const float4*)(ybuf + slot(pix, q0)), v1 = *(const float4*)(ybuf + slot(pix, q0 + 1));
+        const float4 g0 = *(const float4*)(ph + yy * C + 4 * q0), g1 = *(const float4*)(ph + yy * C + 4 * q0 + 4);
+        const float4 e0 = *(const float4*)(pw + xx * C + 4 * (q0 ^ (xx & MASK))), e1 = *(const float4*)(pw + xx * C + 4 * ((q0 + 1) ^ (xx & MASK)));
+        const float tv[8] = {v0.x * e0.x * g0.x, v0.y * e0.y * g0.y, v0.z * e0.z * g0.z, v0.w * e0.w * g0.w,
+                             v1.x * e1.x * g1.x, v1.y * e1.y * g1.y, v1.z * e1.z * g1.z, v1.w * e1.w * g1.w};
+        bf16x8 bh, bl;
+        split8(tv, bh, bl);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l[s2], bh, hacc, 0, 0, 0);      // small terms first
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[s2], bl, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[s2], bh, hacc, 0, 0, 0);
+      }
+      const float hid[8] = {hacc[0] + hb0.x, hacc[1] + hb0.y, hacc[2] + hb0.z, hacc[3] + hb0.w, hacc[4] + hb1.x, hacc[5] + hb1.y, hacc[6] + hb1.z, hacc[7] + hb1.w};
+      bf16x8 hh, hl;
+      split8(hid, hh, hl);
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l[nb], hh, z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[nb], hl, z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[nb], hh, z, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cq = 8 * nb + 2 * g + lh;
+          const float4 b1 = *(const float4*)(l_p1b + 4 * cq);
+          *(float4*)(ybuf + slot(pix, cq)) = make_float4(fminf(fmaxf(z[4 * g] + b1.x, 0.f), 6.f), fminf(fmaxf(z[4 * g + 1] + b1.y, 0.f), 6.f),
+                                                         fminf(fmaxf(z[4 * g + 2] + b1.z, 0.f), 6.f), fminf(fmaxf(z[4 * g + 3] + b1.w, 0.f), 6.f));
+        }
+      }
     }
   }
   __syncthreads();
@@ -997,7 +1054,7 @@ extern "C" int gims_ch_frn_block(const float* x, int64_t patches, int32_t hw, in
 
 template <int CIN, int COUT, int HIN, int STRIDE, bool FIRST = false>
 static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, const uint16_t* w, const float* bias, const float* fw, const float* fb, float eps,
-                             gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st, gims::ChFirst first = {nullptr, nullptr, nullptr, 0.f, nullptr}) {
+                             gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st, gims::ChFirst first = {nullptr, nullptr, nullptr, 0.f, nullptr, 0, 0}) {
   using namespace gims;
   using Geo = ConvGeom<CIN, COUT, HIN, STRIDE>;
   static bool attr = false;
@@ -1011,6 +1068,9 @@ static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, co
     if (!dprof) GIMS_HIP(hipMalloc(&dprof, 8 * sizeof(unsigned long long)));
     first.prof = dprof;
   }
+  static const int stagger = getenv("GIMS_CH_STAGGER") ? atoi(getenv("GIMS_CH_STAGGER")) : 8000;
+  first.stagger = stagger;
+  first.first_wave = 256 * (int)((160 * 1024) / Geo::LDS_BYTES);
   hipLaunchKernelGGL((ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>), dim3((unsigned)patches), dim3(512), Geo::LDS_BYTES, st, x, ldx, w, bias, fw, fb, eps, G,
                      tau, y, ysp, ldsp, first);
   GIMS_LAUNCH_CHECK();
@@ -1074,7 +1134,7 @@ extern "C" int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, in
   const float** dst = (const float**)&W;
   for (int i = 0; i < 14; ++i) { GIMS_CHECK_ARG(w[i] != nullptr, "gims_ch_sandglass: weight pointer %d is null", i); dst[i] = w[i]; }
   constexpr int SG_NT = 1024;
-  const size_t lds = ((size_t)hw * hw * c + 2 * (size_t)hw * c + 16 * (size_t)hw + (size_t)c * (9 + 1 + 9 + 1 + 16 + 16 + 1) + 16) * sizeof(float);
+  const size_t lds = ((size_t)hw * hw * c + 2 * (size_t)hw * c + 16 * (size_t)hw + (size_t)c * (9 + 1 + 9 + 1 + 16 + 20 + 1) + 16 * 4 + 16) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<32, 32, SG_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1088,6 +1148,9 @@ extern "C" int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, in
     if (!dprof) GIMS_HIP(hipMalloc(&dprof, 8 * sizeof(unsigned long long)));
     W.prof = dprof;
   }
+  static const int stagger = getenv("GIMS_CH_STAGGER") ? atoi(getenv("GIMS_CH_STAGGER")) : 8000;
+  W.stagger = stagger;
+  W.first_wave = 256 * (int)((160 * 1024) / lds);
   if (c == 32) hipLaunchKernelGGL((ch_sandglass_kernel<32, 32, SG_NT>), dim3((unsigned)patches), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split);
   else hipLaunchKernelGGL((ch_sandglass_kernel<64, 16, SG_NT>), dim3((unsigned)patches), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split);
   GIMS_LAUNCH_CHECK();

@@ -266,6 +266,24 @@ def _stream() -> int:
     return pin if pin is not None else torch.cuda.current_stream().cuda_stream
 
 
+class on_stream:
+    """``with on_stream(handle):`` -- launches of the calling thread go to the raw HIP stream `handle` inside the block (the side stream of
+    the training step's parameter-gradient work).  Ordering against the surrounding stream and the lifetime of the tensors involved are
+    the caller's business (events; references held until the streams have joined)."""
+
+    def __init__(self, handle: int):
+        self._h = int(handle)
+
+    def __enter__(self):
+        self._prev = getattr(_TLS, "pin", None)
+        _TLS.pin = self._h
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.pin = self._prev
+        return False
+
+
 class pinned_stream:
     """``with pinned_stream():`` -- look the current torch stream up ONCE for a run of launches (torch.cuda.current_stream() costs a
     few microseconds per call; a training step makes ~1 800 launches).  The pin belongs to the calling THREAD (other threads
@@ -1105,6 +1123,8 @@ def colsum(x: torch.Tensor, out: torch.Tensor | None = None, beta=0.0):
     w = _colsum_work.get(key)
     if w is None or w.numel() < need:
         w = _colsum_work[key] = torch.zeros(max(need, 1 << 16), dtype=torch.float32, device=x.device)
+        if getattr(_TLS, "pin", None) is not None:
+            torch.cuda.current_stream(x.device).synchronize()      # the zero fill ran on torch's stream, the kernel may run on another (on_stream)
     # (the kernel leaves its counters -- the first 64 words -- zeroed; partials are overwritten before they are read)
     _check(load().gims_colsum(_p(x), x.stride(0), rows, c, float(beta), _p(out), _p(w), _stream()), "gims_colsum")
     return out

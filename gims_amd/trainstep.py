@@ -15,6 +15,7 @@ layer and direction).
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -223,6 +224,18 @@ def _forward(model, data):
 
 
 # ------------------------------------------------------------------------------------------------ backward
+_SIDE_STREAM = os.environ.get("GIMS_TRAIN_SIDE_STREAM", "1") != "0"      # A/B switch: 0 = parameter gradients on the main stream
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def backward(model, S, w_pos: float, w_neg: float):
     """Gradients of  w_pos * (pos_loss / pos_loss_weight) + w_neg * (neg_loss / neg_loss_weight)  -- i.e. with w_pos / w_neg the
     effective weights of the two loss terms -- with respect to every parameter: dict name -> tensor shaped like the parameter."""
@@ -239,6 +252,25 @@ def _backward(model, S, w_pos: float, w_neg: float):
 
     def put(name, g):
         grads[name] = g.view(P[name].shape)
+
+    # Parameter gradients (weight-gradient products with their split-K folds, bias column sums, the head un-permutation) are off the
+    # critical path: nothing in the reverse pass reads them.  They go to a SIDE STREAM and fill the CUs that the narrow products of the
+    # activation-gradient chain (64-192 tiles per launch) leave idle.  Every job waits for an event recorded on the main stream at its
+    # submission (its inputs are complete then); its input tensors are held until the streams have joined at the end, and the main
+    # stream never writes a buffer in place that a job may still be reading (dx and dqkv are fresh tensors per layer).
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev) if _SIDE_STREAM else None
+    hold = []
+
+    def aside(fn, *inputs):
+        if side is None:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        hold.extend(inputs)
+        with hip.on_stream(side.cuda_stream):
+            return fn()
 
     def norm_backward(prefix, x_pre, g, save):
         """Reverse pass of the norm + ReLU behind a convolution: returns the gradient of the convolution's output and stores
@@ -263,12 +295,10 @@ def _backward(model, S, w_pos: float, w_neg: float):
         hip.gemm(dscores[b], S.mdesc[o1:o1 + n1].t(), dm[o0:o0 + n0], alpha=inv)
         hip.gemm(dscores[b].t(), S.mdesc[o0:o0 + n0].t(), dm[o1:o1 + n1], alpha=inv)
     wf = _w2(P["final_proj.weight"])
-    put("final_proj.weight", hip.gemm(dm.t(), S.desc.t()))
-    put("final_proj.bias", hip.colsum(dm))
+    aside(lambda: (put("final_proj.weight", hip.gemm(dm.t(), S.desc.t())), put("final_proj.bias", hip.colsum(dm))), dm, S.desc)
     dx = hip.gemm(dm, wf.t())                                     # gradient w.r.t. the residual stream after the last layer
 
     # ---- GNN layers in reverse
-    dqkv = torch.empty((n_tot, 3 * D), dtype=torch.float32, device=dev)
     max_p = max(p.numel() for L in S.layers for p in L["probs"])
     dp_buf = torch.empty(max_p, dtype=torch.float32, device=dev)
     dh = D // HEADS
@@ -277,18 +307,17 @@ def _backward(model, S, w_pos: float, w_neg: float):
         pre = f"gnn.layers.{l}."
         w0, w3 = _w2(P[pre + "mlp.0.weight"]), _w2(P[pre + "mlp.3.weight"])
         # delta = mlp(cat[x, msg]); x_next = x + delta: dx is d/dx_next = d/ddelta
-        put(pre + "mlp.3.weight", hip.gemm(dx.t(), L["hid"].t()))
-        put(pre + "mlp.3.bias", hip.colsum(dx))
+        aside(lambda dx=dx, L=L: (put(pre + "mlp.3.weight", hip.gemm(dx.t(), L["hid"].t())), put(pre + "mlp.3.bias", hip.colsum(dx))), dx, L["hid"])
         dhid = hip.gemm(dx, w3.t())
         dhpre = norm_backward(pre + "mlp.1", L["hpre"], dhid, L["save"])
-        put(pre + "mlp.0.weight", hip.gemm(dhpre.t(), L["xm"].t()))
-        put(pre + "mlp.0.bias", hip.colsum(dhpre))
-        hip.gemm(dhpre, w0[:, :D].t(), dx, beta=1.0)              # dx += dhpre W0[:, :D]   (x enters the MLP directly)
+        aside(lambda: (put(pre + "mlp.0.weight", hip.gemm(dhpre.t(), L["xm"].t())), put(pre + "mlp.0.bias", hip.colsum(dhpre))), dhpre, L["xm"])
+        dx = hip.gemm(dhpre, w0[:, :D].t(), residual=dx)          # dx + dhpre W0[:, :D]   (x enters the MLP directly); a fresh tensor: see aside
         dmsg = hip.gemm(dhpre, w0[:, D:].t())
         # merge
-        dwm = hip.gemm(dmsg.t(), L["o"].t())                       # in the packed (head-contiguous) layout; unpacked with the projections below
-        put(pre + "attn.merge.bias", hip.colsum(dmsg))
+        dwm = aside(lambda: hip.gemm(dmsg.t(), L["o"].t()), dmsg, L["o"])   # in the packed (head-contiguous) layout; unpacked with the projections below
+        aside(lambda: put(pre + "attn.merge.bias", hip.colsum(dmsg)))
         do = hip.gemm(dmsg, L["wm"].t())
+        dqkv = torch.empty((n_tot, 3 * D), dtype=torch.float32, device=dev)
         # attention, image by image (every image's rows are queries once and sources once per layer: dqkv is written exactly once)
         qkv = L["qkv"]
         pi = 0
@@ -311,17 +340,21 @@ def _backward(model, S, w_pos: float, w_neg: float):
                 hip.softmax_rows_backward_(pm, dp, ns)                                               # dS
                 hip.gemm(dp[:, :, :ns], kh.transpose(1, 2), dqh, alpha=1.0 / math.sqrt(dh))          # dQ = dS K / sqrt(dh)
                 hip.gemm(dp[:, :, :ns].transpose(1, 2), qh.transpose(1, 2), dkh, alpha=1.0 / math.sqrt(dh))   # dK = dS^T Q / sqrt(dh)
-        dwqkv = hip.gemm(dqkv.t(), L["x"].t())
-        dbqkv = hip.colsum(dqkv)
         gw = [torch.empty_like(P[pre + f"attn.proj.{j}.weight"]) for j in range(3)]
         gb = [torch.empty_like(P[pre + f"attn.proj.{j}.bias"]) for j in range(3)]
         gm = torch.empty_like(P[pre + "attn.merge.weight"])
-        hip.head_pack(gw, gb, gm, dwqkv, dbqkv, dwm, HEADS, to_params=True)
+
+        def qkv_grads(dqkv=dqkv, L=L, dwm=dwm, gw=gw, gb=gb, gm=gm):
+            dwqkv = hip.gemm(dqkv.t(), L["x"].t())
+            dbqkv = hip.colsum(dqkv)
+            hip.head_pack(gw, gb, gm, dwqkv, dbqkv, dwm, HEADS, to_params=True)
+            hold.extend((dwqkv, dbqkv))
+        aside(qkv_grads, dqkv, L["x"], dwm)
         for j in range(3):
             put(pre + f"attn.proj.{j}.weight", gw[j])
             put(pre + f"attn.proj.{j}.bias", gb[j])
         put(pre + "attn.merge.weight", gm)
-        hip.gemm(dqkv, L["wqkv"].t(), dx, beta=1.0)               # dx += dQKV Wqkv
+        dx = hip.gemm(dqkv, L["wqkv"].t(), residual=dx)           # dx + dQKV Wqkv
         S.layers[l] = None                                        # this layer's activations are no longer needed
 
     # ---- keypoint encoder (dx is now d/d(sage + kenc))
@@ -332,8 +365,7 @@ def _backward(model, S, w_pos: float, w_neg: float):
         idx = K["conv"]
         if "pre" in K:           # conv idx -> BN idx+1 -> ReLU: g is the gradient of the ReLU output
             g = norm_backward(f"kenc.encoder.{idx + 1}", K["pre"], g, K["save"])
-        put(f"kenc.encoder.{idx}.weight", hip.gemm(g.t(), K["x"].t()))
-        put(f"kenc.encoder.{idx}.bias", hip.colsum(g))
+        aside(lambda g=g, K=K, idx=idx: (put(f"kenc.encoder.{idx}.weight", hip.gemm(g.t(), K["x"].t())), put(f"kenc.encoder.{idx}.bias", hip.colsum(g))), g, K["x"])
         if i > 0:
             g = hip.gemm(g, _w2(P[f"kenc.encoder.{idx}.weight"]).t())
 
@@ -345,22 +377,25 @@ def _backward(model, S, w_pos: float, w_neg: float):
         ws, wn = P[pre + "fc_self.weight"], P[pre + "fc_neigh.weight"]
         if i < 2:                 # ReLU after layers 0 and 1
             g = hip.elementwise(hip.EW_RELU_MASK, torch.empty_like(g), g, L["out"])
-        put(pre + "fc_self.weight", hip.gemm(g.t(), L["h"].t()))
-        put(_sage_bias(P, i), hip.colsum(g))
+        aside(lambda g=g, L=L, pre=pre, i=i: (put(pre + "fc_self.weight", hip.gemm(g.t(), L["h"].t())), put(_sage_bias(P, i), hip.colsum(g))), g, L["h"])
         if L["before"]:           # out = h Ws^T + b + mean(h Wn^T)
             dxn = hip.sage_mean_transposed(g, G["indptr_all"], G["indices_all"])
-            put(pre + "fc_neigh.weight", hip.gemm(dxn.t(), L["h"].t()))
+            aside(lambda dxn=dxn, L=L, pre=pre: put(pre + "fc_neigh.weight", hip.gemm(dxn.t(), L["h"].t())), dxn, L["h"])
             if i > 0:
                 gh = hip.gemm(g, ws.t())
                 hip.gemm(dxn, wn.t(), gh, beta=1.0)
                 g = gh
         else:                     # out = h Ws^T + b + mean(h) Wn^T
-            put(pre + "fc_neigh.weight", hip.gemm(g.t(), L["agg"].t()))
+            aside(lambda g=g, L=L, pre=pre: put(pre + "fc_neigh.weight", hip.gemm(g.t(), L["agg"].t())), g, L["agg"])
             if i > 0:
                 dagg = hip.gemm(g, wn.t())
                 gh = hip.gemm(g, ws.t())
                 hip.elementwise(hip.EW_ACC, gh, hip.sage_mean_transposed(dagg, G["indptr_all"], G["indices_all"]), alpha=1.0)
                 g = gh
+    if side is not None:                                          # join: the caller (and the allocator's reuse of everything held) comes after the side jobs
+        ev = torch.cuda.Event()
+        ev.record(side)
+        main.wait_event(ev)
     return grads
 
 
