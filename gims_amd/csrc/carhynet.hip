@@ -320,7 +320,9 @@ struct ChGateW { const float* w1; const float* b1; const float* wh; const float*
 template <int C, int HW, int NT>
 __device__ __forceinline__ void frn_block_body(float* lds, const float* __restrict__ fw, const float* __restrict__ fb, float eps, const ChGateW& g,
                                                const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp, int64_t ldsp, int64_t pbase,
-                                               unsigned long long* prof = nullptr) {
+                                               unsigned long long* prof = nullptr, const float* gl = nullptr) {
+  // gl: the CoordAtt gate weights staged in LDS by the caller ([w1 8C][b1 8][wh 8C][ww 8C][bh C][bw C], ch_conv_block_kernel), or null:
+  // read from global memory (two L2 round trips in the middle of the block)
   constexpr int NPIX = HW * HW, QPP = C / 4, NQ = NPIX * QPP / NT, GRP = NT / C;
   auto stamp = [&](int k) __attribute__((always_inline)) { if (prof && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) prof[k] = __builtin_readcyclecounter(); };
   // xb is SWIZZLED: channel quad q of pixel p sits at quad position q ^ (p & 7) (frn_slot) -- the accumulator dump of the
@@ -353,6 +355,8 @@ __device__ __forceinline__ void frn_block_body(float* lds, const float* __restri
   __syncthreads();
   stamp(4);
   const bool coord = g.w1 != nullptr;
+  const float* g_w1 = gl ? gl : g.w1, *g_b1 = gl ? gl + 8 * C : g.b1, *g_wh = gl ? gl + 8 * C + 8 : g.wh, *g_ww = gl ? gl + 16 * C + 8 : g.ww,
+              *g_bh = gl ? gl + 24 * C + 8 : g.bh, *g_bw = gl ? gl + 25 * C + 8 : g.bw;
   if (coord) {
     // pools of the FRN output = FRN affine map of the raw pools; one (line, channel quad) per thread: HW float4 reads
     for (int i = t; i < 2 * HW * QPP; i += NT) {
@@ -375,10 +379,10 @@ __device__ __forceinline__ void frn_block_body(float* lds, const float* __restri
     for (int i = t; i < 2 * HW * 8; i += NT) {
       const int r = i >> 3, m = i & 7;
       const float* src = r < HW ? ph + r * C : pw + (r - HW) * C;
-      float a4[4] = {g.b1[m], 0.f, 0.f, 0.f};
-#pragma unroll 4
+      float a4[4] = {g_b1[m], 0.f, 0.f, 0.f};
+#pragma unroll 8
       for (int k = 0; k < C; k += 4) {
-        const float4 wv = *(const float4*)(g.w1 + m * C + k), xv = *(const float4*)(src + k);
+        const float4 wv = *(const float4*)(g_w1 + m * C + k), xv = *(const float4*)(src + k);
         a4[0] = fmaf(xv.x, wv.x, a4[0]); a4[1] = fmaf(xv.y, wv.y, a4[1]); a4[2] = fmaf(xv.z, wv.z, a4[2]); a4[3] = fmaf(xv.w, wv.w, a4[3]);
       }
       const float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
@@ -388,10 +392,10 @@ __device__ __forceinline__ void frn_block_body(float* lds, const float* __restri
     for (int i = t; i < 2 * HW * C; i += NT) {
       const bool is_h = i < HW * C;
       const int j = is_h ? i : i - HW * C, r = j / C, ch = j % C;
-      const float* wt = (is_h ? g.wh : g.ww) + ch * 8;
+      const float* wt = (is_h ? g_wh : g_ww) + ch * 8;
       const float* mr = mid + (is_h ? r : HW + r) * 8;
       const float4 w0 = *(const float4*)wt, w1v = *(const float4*)(wt + 4), m0 = *(const float4*)mr, m1 = *(const float4*)(mr + 4);
-      float acc = (is_h ? g.bh : g.bw)[ch];
+      float acc = (is_h ? g_bh : g_bw)[ch];
       acc = fmaf(m0.x, w0.x, acc); acc = fmaf(m0.y, w0.y, acc); acc = fmaf(m0.z, w0.z, acc); acc = fmaf(m0.w, w0.w, acc);      // same order as the scalar loop
       acc = fmaf(m1.x, w1v.x, acc); acc = fmaf(m1.y, w1v.y, acc); acc = fmaf(m1.z, w1v.z, acc); acc = fmaf(m1.w, w1v.w, acc);
       (is_h ? ph : pw)[j] = 1.f / (1.f + __expf(-acc));
@@ -461,6 +465,7 @@ struct ConvGeom {
   static constexpr int IN_BYTES = (HIN * HIN + 1) * PXB;
   static constexpr int FRN_FLOATS = NPIX * COUT + (NT / COUT) * COUT + COUT + 2 * HOUT * COUT + 16 * HOUT;
   static constexpr int LDS_BYTES = IN_BYTES > FRN_FLOATS * 4 ? IN_BYTES : FRN_FLOATS * 4;
+  static constexpr int GATE_BYTES = (26 * COUT + 8) * 4;               // staged CoordAtt gate weights (layers with CoordAtt only), behind FRN_FLOATS
   static_assert(MB * NB == WAVES * MBW * NBW, "blocks divide over the waves");
   static constexpr int HB = (CIN < 32 ? CIN : 32) / 8;                 // 16-byte chunks per plane of a channel block (32-channel blocks; 16 for the first layer)
   __device__ static __forceinline__ int swz(int q) { return CIN == 16 ? ((q >> 2) & 3) : (CIN == 32 ? ((q >> 1) & 7) : (q & 15)); }
@@ -499,6 +504,15 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   auto stamp = [&](int k) __attribute__((always_inline)) { if (first.prof && blockIdx.x == gridDim.x / 2 && t == 0) first.prof[k] = __builtin_readcyclecounter(); };
   ch_stagger(first.stagger, first.first_wave);
   stamp(0);
+  // CoordAtt gate weights: requested before the patch, written to LDS (behind the FRN block's arrays) after it -- their latency hides
+  // under the patch load instead of costing two L2 round trips inside the FRN block
+  const bool stage_gates = g.w1 != nullptr && 8 * COUT <= NT;
+  float gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (stage_gates) {
+    if (t < 8 * COUT) { gv[0] = g.w1[t]; gv[1] = g.wh[t]; gv[2] = g.ww[t]; }
+    if (t < COUT) { gv[3] = g.bh[t]; gv[4] = g.bw[t]; }
+    if (t < 8) gv[5] = g.b1[t];
+  }
 
   // ---- input patch -> LDS (swizzled chunks) + ONE all-zero pixel record that every out-of-image tap reads (no border in LDS:
   // the 16x16x64 and 8x8x128 layers then fit two / three workgroups per CU)
@@ -563,6 +577,12 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
         *(uint4*)(img + q * PXB + ((ch ^ G::swz(q)) * 16)) = v[u];
       }
     }
+  }
+  float* gl = lds + G::FRN_FLOATS;
+  if (stage_gates) {
+    if (t < 8 * COUT) { gl[t] = gv[0]; gl[8 * COUT + 8 + t] = gv[1]; gl[16 * COUT + 8 + t] = gv[2]; }
+    if (t < COUT) { gl[24 * COUT + 8 + t] = gv[3]; gl[25 * COUT + 8 + t] = gv[4]; }
+    if (t < 8) gl[8 * COUT + t] = gv[5];
   }
   __syncthreads();
   stamp(1);
@@ -654,7 +674,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
     }
   __syncthreads();
   stamp(3);
-  frn_block_body<COUT, HOUT, NT>(lds, fw, fb, eps, g, tau, y, ysp, ldsp, patch * G::NPIX, first.prof);
+  frn_block_body<COUT, HOUT, NT>(lds, fw, fb, eps, g, tau, y, ysp, ldsp, patch * G::NPIX, first.prof, stage_gates ? gl : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------- fused SandGlass block
@@ -699,61 +719,97 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   constexpr int P0P = C + 4, P1P = 20;      // padded pitches of the pointwise weights: their MFMA fragment reads (one row per lane) are conflict-free
   float* l_dw0 = wl, *l_dw0b = l_dw0 + 9 * C, *l_dw1 = l_dw0b + C, *l_dw1b = l_dw1 + 9 * C, *l_p0 = l_dw1b + C, *l_p0b = l_p0 + 16 * P0P,
         *l_p1 = l_p0b + 16, *l_p1b = l_p1 + C * P1P;
+  // gate weights of CoordAtt (w1 [8][C], b1 [8], wh / ww [C][8], bh / bw [C]): read from global memory inside phase B they cost two L2 round
+  // trips per patch in the middle of the kernel; staged here, their latency hides under the patch load
+  float* l_w1 = l_p1b + C, *l_b1 = l_w1 + 8 * C, *l_wh = l_b1 + 8, *l_ww = l_wh + 8 * C, *l_bh = l_ww + 8 * C, *l_bw = l_bh + C;
   const int t = threadIdx.x;
   const int64_t pbase = (int64_t)blockIdx.x * NPIX;
   const float* xp = x + pbase * C;
   auto stamp = [&](int k) __attribute__((always_inline)) { if (wts.prof && blockIdx.x == gridDim.x / 2 && t == 0) wts.prof[k] = __builtin_readcyclecounter(); };
   ch_stagger(wts.stagger, wts.first_wave);
   stamp(0);
+  // ---- 0: the patch is REQUESTED first (NQ independent, fully coalesced 16-byte loads per thread), the weights are staged into LDS while
+  // it is in flight: one memory latency for both.  x is NOT kept in registers for the final residual: next to the accumulators and taps of
+  // the depthwise passes its 4 NQ registers spilled to scratch; phase D requests it again (an L2 / Infinity-Cache hit a few microseconds later)
+  // before its own arithmetic
+  // Thread <-> data: channel quad cq of the pixels (xx, y0 .. y0 + NQ - 1) -- a VERTICAL strip.  A wave covers XW adjacent columns x all
+  // channel quads = one contiguous KiB per image row (coalesced loads and stores), and the depthwise passes read every input row of
+  // the strip ONCE for the three output rows it feeds: (NQ + 2) x 3 LDS reads per pass instead of NQ x 9 (these passes are
+  // LDS-bandwidth bound).
+  constexpr int NQ = NPIX * QPP / NT, XW = 64 / QPP, XG = HW / XW;
+  static_assert((NT / 64 / XG) * NQ == HW && XG * XW == HW, "the strips tile the patch");
+  const int cq = (t & 63) % QPP, xx = ((t >> 6) % XG) * XW + (t & 63) / QPP, y0 = __builtin_amdgcn_readfirstlane(((t >> 6) / XG) * NQ);
+  f32x4 xq[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) xq[j] = *(const f32x4*)(xp + (int64_t)((y0 + j) * HW + xx) * C + 4 * cq);
   for (int i = t; i < 9 * C; i += NT) { l_dw0[i] = wts.dw0[i]; l_dw1[i] = wts.dw1[i]; }
   for (int i = t; i < 16 * C; i += NT) { l_p0[(i / C) * P0P + i % C] = wts.p0[i]; l_p1[(i / 16) * P1P + i % 16] = wts.p1[i]; }
   if (t < C) { l_dw0b[t] = wts.dw0b[t]; l_dw1b[t] = wts.dw1b[t]; l_p1b[t] = wts.p1b[t]; }
   if (t < 16) l_p0b[t] = wts.p0b[t];
-  __syncthreads();
+  for (int i = t; i < 8 * C; i += NT) { l_w1[i] = wts.w1[i]; l_wh[i] = wts.wh[i]; l_ww[i] = wts.ww[i]; }
+  if (t < C) { l_bh[t] = wts.bh[t]; l_bw[t] = wts.bw[t]; }
+  if (t < 8) l_b1[t] = wts.b1[t];
   stamp(1);
   auto slot = [&](int pix, int cq) { return pix * C + 4 * (cq ^ (pix & MASK)); };
 
-  // ---- 0: the patch into LDS and, for the final residual, this thread's own quads into registers: NQ independent, fully
-  // coalesced 16-byte loads in flight at once (with two waves per SIMD nothing else would hide a dependent load)
-  constexpr int NQ = NPIX * QPP / NT;
-  float4 xq[NQ];
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) xq[j] = *(const float4*)(xp + (int64_t)(t + NT * j) * 4);
-#pragma unroll
-  for (int j = 0; j < NQ; ++j) { const int i = t + NT * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = xq[j]; }
+  for (int j = 0; j < NQ; ++j) *(f32x4*)(ybuf + slot((y0 + j) * HW + xx, cq)) = xq[j];
+  asm volatile("" ::: "memory");
   __syncthreads();
   stamp(2);
+  // depthwise 3x3 of the LDS image for this thread's strip: acc[j] (preset to the bias) += taps in the reference's order (row-major
+  // over the 3x3 window; out-of-image taps add nothing).  The quad swizzle depends on the column only (HW is a multiple of QPP).
+  static_assert(HW % QPP == 0 || QPP % HW == 0, "swizzle independent of the row");
+  auto dw3x3 = [&](const f32x4 (&kw)[9], f32x4 (&acc)[NQ], auto o_first, auto o_count) __attribute__((always_inline)) {   // output rows [O0, O0 + ON) of the strip
+    constexpr int O0 = decltype(o_first)::value, ON = decltype(o_count)::value;
+    int xo[3];
+    float keep[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int x2 = xx + d - 1, xc = x2 < 0 ? 0 : (x2 >= HW ? HW - 1 : x2);
+      xo[d] = xc * C + 4 * (cq ^ (xc & MASK));
+      keep[d] = (x2 >= 0 && x2 < HW) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int rr = O0 - 1; rr <= O0 + ON; ++rr) {
+      const int yin = y0 + rr;
+      if (yin < 0 || yin >= HW) continue;                  // wave-uniform
+      f32x4 v[3];                                         // ext-vector arithmetic: the compiler pairs it into v_pk_mul / v_pk_fma_f32 (these passes are VALU-issue bound)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v[d] = *(const f32x4*)(ybuf + yin * HW * C + xo[d]) * keep[d];
+#pragma unroll
+      for (int dy = 1; dy >= -1; --dy) {                    // output row rr - dy takes this input row as window row dy + 1
+        const int o = rr - dy;
+        if (o < O0 || o >= O0 + ON) continue;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          acc[o] = __builtin_elementwise_fma(v[d], kw[(dy + 1) * 3 + d], acc[o]);
+        }
+      }
+      if (rr & 1) asm volatile("" ::: "memory");            // at most two rows of reads in flight: hoisting all of them spilled registers
+    }
+  };
   // ---- A: depthwise 3x3 + BN + ReLU6 from the LDS copy into registers, then over the copy.  The loop is unrolled (register
   // arrays), but the thread index is re-derived from an opaque copy every iteration: as loop invariants the compiler hoisted
   // all NQ x 9 addresses and weights and spilled 900 registers.
   // a thread's quads all belong to ONE channel quad (NT % QPP == 0): its nine tap weights stay in registers (they were half of
   // the LDS reads of this LDS-bandwidth-bound pass)
-  static_assert(NT % QPP == 0, "a thread keeps its channel quad");
-  float4 kw[9];
+  f32x4 kw[9];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) kw[tap] = *(const float4*)(l_dw0 + tap * C + 4 * (t % QPP));
-  const float4 kb0 = *(const float4*)(l_dw0b + 4 * (t % QPP));
-  float4 yq[NQ];
+  for (int tap = 0; tap < 9; ++tap) kw[tap] = *(const f32x4*)(l_dw0 + tap * C + 4 * cq);
+  const f32x4 kb0 = *(const f32x4*)(l_dw0b + 4 * cq);
+  f32x4 yq[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) yq[j] = kb0;
+  dw3x3(kw, yq, std::integral_constant<int, 0>{}, std::integral_constant<int, NQ>{});
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
-    int tt = t;
-    asm volatile("" : "+v"(tt));
-    const int i = tt + NT * j, pix = i / QPP, cq = i % QPP, yy = pix / HW, xx = pix % HW;
-    float4 acc = kb0;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
-      if (y2 < 0 || y2 >= HW || x2 < 0 || x2 >= HW) continue;
-      const float4 v = *(const float4*)(ybuf + slot(y2 * HW + x2, cq));
-      const float4 k4 = kw[tap];
-      acc.x = fmaf(v.x, k4.x, acc.x); acc.y = fmaf(v.y, k4.y, acc.y); acc.z = fmaf(v.z, k4.z, acc.z); acc.w = fmaf(v.w, k4.w, acc.w);
-    }
-    acc.x = fminf(fmaxf(acc.x, 0.f), 6.f); acc.y = fminf(fmaxf(acc.y, 0.f), 6.f); acc.z = fminf(fmaxf(acc.z, 0.f), 6.f); acc.w = fminf(fmaxf(acc.w, 0.f), 6.f);
-    yq[j] = acc;
+    for (int e = 0; e < 4; ++e) yq[j][e] = fminf(fmaxf(yq[j][e], 0.f), 6.f);
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) { const int i = t + NT * j; *(float4*)(ybuf + slot(i / QPP, i % QPP)) = yq[j]; }
+  for (int j = 0; j < NQ; ++j) *(f32x4*)(ybuf + slot((y0 + j) * HW + xx, cq)) = yq[j];
   __syncthreads();
   stamp(3);
   // ---- A2: pools (mean over x for every row, mean over y for every column): one (line, channel quad) per thread, HW float4 reads
@@ -777,10 +833,10 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   for (int i = t; i < 2 * HW * 8; i += NT) {
     const int r = i >> 3, m = i & 7;
     const float* src = r < HW ? ph + r * C : pw + (r - HW) * C;
-    float a4[4] = {wts.b1[m], 0.f, 0.f, 0.f};
-#pragma unroll 4
+    float a4[4] = {l_b1[m], 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (int k = 0; k < C; k += 4) {
-      const float4 wv = *(const float4*)(wts.w1 + m * C + k), xv = *(const float4*)(src + k);
+      const float4 wv = *(const float4*)(l_w1 + m * C + k), xv = *(const float4*)(src + k);
       a4[0] = fmaf(xv.x, wv.x, a4[0]); a4[1] = fmaf(xv.y, wv.y, a4[1]); a4[2] = fmaf(xv.z, wv.z, a4[2]); a4[3] = fmaf(xv.w, wv.w, a4[3]);
     }
     const float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
@@ -790,9 +846,9 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   for (int i = t; i < 2 * HW * C; i += NT) {
     const bool is_h = i < HW * C;
     const int j = is_h ? i : i - HW * C, r = j / C, ch = j % C;
-    const float* wt = (is_h ? wts.wh : wts.ww) + ch * 8;
+    const float* wt = (is_h ? l_wh : l_ww) + ch * 8;
     const float* mr = mid + (is_h ? r : HW + r) * 8;
-    float acc = (is_h ? wts.bh : wts.bw)[ch];
+    float acc = (is_h ? l_bh : l_bw)[ch];
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc = fmaf(mr[m], wt[m], acc);
     // a_w is stored with its channel quads XOR-swizzled by the column index: phase C reads one column per lane (stride C floats)
@@ -883,25 +939,26 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   stamp(6);
   // ---- D: out = 2 x + dw3x3(z) + BN, as split-bf16 pixel rows (x from the registers of step 0)
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) kw[tap] = *(const float4*)(l_dw1 + tap * C + 4 * (t % QPP));
-  const float4 kb0d = *(const float4*)(l_dw1b + 4 * (t % QPP));
+  for (int j = 0; j < NQ; ++j) xq[j] = __builtin_nontemporal_load((const f32x4*)(xp + (int64_t)((y0 + j) * HW + xx) * C + 4 * cq));
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) {
-    int tt = t;
-    asm volatile("" : "+v"(tt));
-    const int i = tt + NT * j, pix = i / QPP, cq = i % QPP, ch = 4 * cq, yy = pix / HW, xx = pix % HW;
-    float4 acc = kb0d;
+  for (int tap = 0; tap < 9; ++tap) kw[tap] = *(const f32x4*)(l_dw1 + tap * C + 4 * cq);
+  const f32x4 kb0d = *(const f32x4*)(l_dw1b + 4 * cq);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
-      if (y2 < 0 || y2 >= HW || x2 < 0 || x2 >= HW) continue;
-      const float4 v = *(const float4*)(ybuf + slot(y2 * HW + x2, cq));
-      const float4 k4 = kw[tap];
-      acc.x = fmaf(v.x, k4.x, acc.x); acc.y = fmaf(v.y, k4.y, acc.y); acc.z = fmaf(v.z, k4.z, acc.z); acc.w = fmaf(v.w, k4.w, acc.w);
+  for (int j = 0; j < NQ; ++j) yq[j] = kb0d;
+  // in two halves when the strip is 8 rows: 16 accumulator registers instead of 32 next to x (32) and the taps (36) -- the whole
+  // strip at once spilled 28 registers; the price is two input rows read twice
+  constexpr int HALF = NQ > 4 ? NQ / 2 : NQ;
+  auto finish = [&](auto o_first) __attribute__((always_inline)) {
+    constexpr int O0 = decltype(o_first)::value;
+    dw3x3(kw, yq, o_first, std::integral_constant<int, HALF>{});
+#pragma unroll
+    for (int j = O0; j < O0 + HALF; ++j) {
+      const float r[4] = {fmaf(xq[j][0], 2.f, yq[j][0]), fmaf(xq[j][1], 2.f, yq[j][1]), fmaf(xq[j][2], 2.f, yq[j][2]), fmaf(xq[j][3], 2.f, yq[j][3])};
+      store_split4(out + (pbase + (y0 + j) * HW + xx) * ldo + spl_col(4 * cq), r);
     }
-    const float r[4] = {fmaf(xq[j].x, 2.f, acc.x), fmaf(xq[j].y, 2.f, acc.y), fmaf(xq[j].z, 2.f, acc.z), fmaf(xq[j].w, 2.f, acc.w)};
-    store_split4(out + (pbase + pix) * ldo + spl_col(ch), r);
-  }
+  };
+  finish(std::integral_constant<int, 0>{});
+  if constexpr (HALF < NQ) finish(std::integral_constant<int, HALF>{});
   stamp(7);
 }
 
@@ -1059,7 +1116,8 @@ static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, co
   using Geo = ConvGeom<CIN, COUT, HIN, STRIDE>;
   static bool attr = false;
   if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (Geo::FRN_FLOATS * 4 > Geo::LDS_BYTES ? Geo::FRN_FLOATS * 4 : Geo::LDS_BYTES) + Geo::GATE_BYTES));
     attr = true;
   }
   static const bool prof_on = getenv("GIMS_CH_PROF") != nullptr;      // diagnostics: cycle stamps of one workgroup per launch (synchronous)
@@ -1070,8 +1128,11 @@ static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, co
   }
   static const int stagger = getenv("GIMS_CH_STAGGER") ? atoi(getenv("GIMS_CH_STAGGER")) : 8000;
   first.stagger = stagger;
-  first.first_wave = 256 * (int)((160 * 1024) / Geo::LDS_BYTES);
-  hipLaunchKernelGGL((ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>), dim3((unsigned)patches), dim3(512), Geo::LDS_BYTES, st, x, ldx, w, bias, fw, fb, eps, G,
+  // (FRN_FLOATS * 4 <= LDS_BYTES by construction; the staged gate weights sit behind the FRN arrays)
+  const int lds_bytes = G.w1 ? Geo::FRN_FLOATS * 4 + Geo::GATE_BYTES : Geo::LDS_BYTES;
+  const int lds_launch = lds_bytes > Geo::LDS_BYTES ? lds_bytes : Geo::LDS_BYTES;
+  first.first_wave = 256 * (int)((160 * 1024) / lds_launch);
+  hipLaunchKernelGGL((ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>), dim3((unsigned)patches), dim3(512), lds_launch, st, x, ldx, w, bias, fw, fb, eps, G,
                      tau, y, ysp, ldsp, first);
   GIMS_LAUNCH_CHECK();
   if (prof_on) {
@@ -1134,7 +1195,7 @@ extern "C" int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, in
   const float** dst = (const float**)&W;
   for (int i = 0; i < 14; ++i) { GIMS_CHECK_ARG(w[i] != nullptr, "gims_ch_sandglass: weight pointer %d is null", i); dst[i] = w[i]; }
   constexpr int SG_NT = 1024;
-  const size_t lds = ((size_t)hw * hw * c + 2 * (size_t)hw * c + 16 * (size_t)hw + (size_t)c * (9 + 1 + 9 + 1 + 16 + 20 + 1) + 16 * 4 + 16) * sizeof(float);
+  const size_t lds = ((size_t)hw * hw * c + 2 * (size_t)hw * c + 16 * (size_t)hw + (size_t)c * (9 + 1 + 9 + 1 + 16 + 20 + 1 + 8 + 8 + 8 + 1 + 1) + 16 * 4 + 16 + 8) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<32, 32, SG_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
