@@ -504,11 +504,14 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   auto stamp = [&](int k) __attribute__((always_inline)) { if (first.prof && blockIdx.x == gridDim.x / 2 && t == 0) first.prof[k] = __builtin_readcyclecounter(); };
   ch_stagger(first.stagger, first.first_wave);
   stamp(0);
+  // (a persistent patch loop, as in ch_sandglass_kernel, was measured here and dropped: the loop's live ranges took the 32x32 layers to 256
+  // registers with spills and the smaller layers out of their two / three workgroups per CU -- 841 -> 878 us per 8192 patches of layer 2)
   // CoordAtt gate weights: requested before the patch, written to LDS (behind the FRN block's arrays) after it -- their latency hides
   // under the patch load instead of costing two L2 round trips inside the FRN block
   const bool stage_gates = g.w1 != nullptr && 8 * COUT <= NT;
+  const bool stage_now = stage_gates;
   float gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (stage_gates) {
+  if (stage_now) {
     if (t < 8 * COUT) { gv[0] = g.w1[t]; gv[1] = g.wh[t]; gv[2] = g.ww[t]; }
     if (t < COUT) { gv[3] = g.bh[t]; gv[4] = g.bw[t]; }
     if (t < 8) gv[5] = g.b1[t];
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
     }
   }
   float* gl = lds + G::FRN_FLOATS;
-  if (stage_gates) {
+  if (stage_now) {
     if (t < 8 * COUT) { gl[t] = gv[0]; gl[8 * COUT + 8 + t] = gv[1]; gl[16 * COUT + 8 + t] = gv[2]; }
     if (t < COUT) { gl[24 * COUT + 8 + t] = gv[3]; gl[25 * COUT + 8 + t] = gv[4]; }
     if (t < 8) gl[8 * COUT + t] = gv[5];
@@ -708,7 +711,8 @@ struct ChSandglassW {          // all f32, BatchNorm folded
 };
 
 template <int C, int HW, int NT>      // HW = H = W, NT threads
-__global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restrict__ x, ChSandglassW wts, uint16_t* __restrict__ out, int64_t ldo) {
+__global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restrict__ x, ChSandglassW wts, uint16_t* __restrict__ out, int64_t ldo,
+                                                          int n_patches) {
   constexpr int NPIX = HW * HW, QPP = C / 4, MASK = QPP - 1;          // quads per pixel
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ybuf = lds;                        // [NPIX][C] swizzled
@@ -723,8 +727,6 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   // trips per patch in the middle of the kernel; staged here, their latency hides under the patch load
   float* l_w1 = l_p1b + C, *l_b1 = l_w1 + 8 * C, *l_wh = l_b1 + 8, *l_ww = l_wh + 8 * C, *l_bh = l_ww + 8 * C, *l_bw = l_bh + C;
   const int t = threadIdx.x;
-  const int64_t pbase = (int64_t)blockIdx.x * NPIX;
-  const float* xp = x + pbase * C;
   auto stamp = [&](int k) __attribute__((always_inline)) { if (wts.prof && blockIdx.x == gridDim.x / 2 && t == 0) wts.prof[k] = __builtin_readcyclecounter(); };
   ch_stagger(wts.stagger, wts.first_wave);
   stamp(0);
@@ -739,9 +741,14 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   constexpr int NQ = NPIX * QPP / NT, XW = 64 / QPP, XG = HW / XW;
   static_assert((NT / 64 / XG) * NQ == HW && XG * XW == HW, "the strips tile the patch");
   const int cq = (t & 63) % QPP, xx = ((t >> 6) % XG) * XW + (t & 63) / QPP, y0 = __builtin_amdgcn_readfirstlane(((t >> 6) / XG) * NQ);
+  // PERSISTENT: a workgroup walks patches blockIdx.x, + gridDim.x, ... -- the weights are staged once per workgroup instead of once per
+  // patch, and a CU does not pay a workgroup dispatch (16 waves, 150 KB of LDS) between two patches.
   f32x4 xq[NQ];
+  {
+    const float* xp = x + (int64_t)blockIdx.x * NPIX * C;
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) xq[j] = *(const f32x4*)(xp + (int64_t)((y0 + j) * HW + xx) * C + 4 * cq);
+    for (int j = 0; j < NQ; ++j) xq[j] = *(const f32x4*)(xp + (int64_t)((y0 + j) * HW + xx) * C + 4 * cq);
+  }
   for (int i = t; i < 9 * C; i += NT) { l_dw0[i] = wts.dw0[i]; l_dw1[i] = wts.dw1[i]; }
   for (int i = t; i < 16 * C; i += NT) { l_p0[(i / C) * P0P + i % C] = wts.p0[i]; l_p1[(i / 16) * P1P + i % 16] = wts.p1[i]; }
   if (t < C) { l_dw0b[t] = wts.dw0b[t]; l_dw1b[t] = wts.dw1b[t]; l_p1b[t] = wts.p1b[t]; }
@@ -752,6 +759,24 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   stamp(1);
   auto slot = [&](int pix, int cq) { return pix * C + 4 * (cq ^ (pix & MASK)); };
 
+  // (32x32x32 only: at 16x16x64 the looped form measured slower, 495 -> 556 us per 8192 patches -- it is launched one workgroup per patch and
+  // compiled without the loop)
+  constexpr bool PERSIST = C == 32;
+  int patch = blockIdx.x;
+  do {
+  // every thread-derived index is re-derived from an OPAQUE copy of the thread id inside the loop: as loop invariants the compiler hoisted the
+  // weight fragments, taps and addresses of all phases out of the patch loop and spilled 100 registers
+  int t_opaque = threadIdx.x;
+  if (PERSIST) asm volatile("" : "+v"(t_opaque));
+  const int t = t_opaque;
+  const int cq = (t & 63) % QPP, xx = ((t >> 6) % XG) * XW + (t & 63) / QPP, y0 = __builtin_amdgcn_readfirstlane(((t >> 6) / XG) * NQ);
+  const int64_t pbase = (int64_t)patch * NPIX;
+  const float* xp = x + pbase * C;
+  if (patch != (int)blockIdx.x) {
+    __syncthreads();                                        // the previous patch's last LDS reads (phase D) are done
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) xq[j] = *(const f32x4*)(xp + (int64_t)((y0 + j) * HW + xx) * C + 4 * cq);
+  }
 #pragma unroll
   for (int j = 0; j < NQ; ++j) *(f32x4*)(ybuf + slot((y0 + j) * HW + xx, cq)) = xq[j];
   asm volatile("" ::: "memory");
@@ -960,6 +985,8 @@ __global__ __launch_bounds__(NT) void ch_sandglass_kernel(const float* __restric
   finish(std::integral_constant<int, 0>{});
   if constexpr (HALF < NQ) finish(std::integral_constant<int, HALF>{});
   stamp(7);
+  patch += gridDim.x;
+  } while (PERSIST && patch < n_patches);
 }
 
 // one wave per row of `c` (<= 256) values: y = x / sqrt(sum x^2 + eps)
@@ -1212,8 +1239,11 @@ extern "C" int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, in
   static const int stagger = getenv("GIMS_CH_STAGGER") ? atoi(getenv("GIMS_CH_STAGGER")) : 8000;
   W.stagger = stagger;
   W.first_wave = 256 * (int)((160 * 1024) / lds);
-  if (c == 32) hipLaunchKernelGGL((ch_sandglass_kernel<32, 32, SG_NT>), dim3((unsigned)patches), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split);
-  else hipLaunchKernelGGL((ch_sandglass_kernel<64, 16, SG_NT>), dim3((unsigned)patches), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split);
+  // 32x32x32: one 1024-thread workgroup per CU, persistent over the patches (806 -> 691 us per 8192 patches); 16x16x64: one workgroup per patch
+  static const int persist = getenv("GIMS_CH_PERSIST") ? atoi(getenv("GIMS_CH_PERSIST")) : 1;
+  const unsigned grid = (unsigned)(c == 32 && persist && patches > 256 ? 256 : patches);
+  if (c == 32) hipLaunchKernelGGL((ch_sandglass_kernel<32, 32, SG_NT>), dim3(grid), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split, (int)patches);
+  else hipLaunchKernelGGL((ch_sandglass_kernel<64, 16, SG_NT>), dim3(grid), dim3(SG_NT), lds, (hipStream_t)stream, x, W, out_split, ld_split, (int)patches);
   GIMS_LAUNCH_CHECK();
   if (prof_on) {
     unsigned long long h[8];
