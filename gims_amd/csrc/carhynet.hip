@@ -451,20 +451,24 @@ __global__ __launch_bounds__(NT) void ch_frn_block_kernel(const float* __restric
 // and the FRN (+ CoordAtt) + TLU block runs on them as in ch_frn_block_kernel: the raw convolution output never reaches HBM.
 // 16-byte chunks of a pixel record are XOR-swizzled by the pixel index so that the fragment reads of 16 consecutive pixels
 // hit distinct banks.
-template <int CIN, int COUT, int HIN, int STRIDE>
+template <int CIN, int COUT, int HIN, int STRIDE, int PP = 1>
 struct ConvGeom {
+  // PP patches per workgroup: the deep layers stream their whole weight set (295 / 590 KB) from L2 per patch -- 8192 patches of the 8x8x128
+  // layer in 537 us are 9 TB/s of L2 -> L1 traffic, the bound of that launch; with PP patches side by side in LDS a wave owns PP times as
+  // many pixel blocks of its channel block and every weight fragment serves PP times as many MFMAs.
   static constexpr int NT = 512, WAVES = 8;
-  static constexpr int HOUT = (HIN - 1) / STRIDE + 1, NPIX = HOUT * HOUT, ZQ = HIN * HIN;   // ZQ: index of the all-zero pixel record
+  static constexpr int HOUT = (HIN - 1) / STRIDE + 1, NPIX = HOUT * HOUT, ZQ = PP * HIN * HIN;   // ZQ: index of the all-zero pixel record
   static constexpr int PXB = CIN * 4, CPP = PXB / 16;                 // bytes / 16-byte chunks per pixel record (hi + lo planes)
-  static constexpr int MB = NPIX / 32, NB = COUT / 32, KS = CIN / 16;
+  static constexpr int MB = PP * NPIX / 32, NB = COUT / 32, KS = CIN / 16;
   // wave tiling: MBW m-blocks x ONE n-block per wave (the weight fragments come from global memory through L1: a wave that
   // owns several pixel blocks of one channel block loads each weight fragment once for all of them; the pixel fragments
   // come from LDS, where re-reads are cheap)
   static constexpr int NBW = 1;
   static constexpr int MBW = MB * NB / WAVES;                          // L2: 4, L3/L4: 2, L5/L6: 1
-  static constexpr int IN_BYTES = (HIN * HIN + 1) * PXB;
-  static constexpr int FRN_FLOATS = NPIX * COUT + (NT / COUT) * COUT + COUT + 2 * HOUT * COUT + 16 * HOUT;
-  static constexpr int LDS_BYTES = IN_BYTES > FRN_FLOATS * 4 ? IN_BYTES : FRN_FLOATS * 4;
+  static constexpr int IN_BYTES = (PP * HIN * HIN + 1) * PXB;
+  static constexpr int FRN_FLOATS = NPIX * COUT + (NT / COUT) * COUT + COUT + 2 * HOUT * COUT + 16 * HOUT;     // per patch
+  static constexpr int LDS_BYTES = IN_BYTES > PP * FRN_FLOATS * 4 ? IN_BYTES : PP * FRN_FLOATS * 4;
+  static_assert(NPIX % 32 == 0, "a 32-pixel block belongs to one patch");
   static constexpr int GATE_BYTES = (26 * COUT + 8) * 4;               // staged CoordAtt gate weights (layers with CoordAtt only), behind FRN_FLOATS
   static_assert(MB * NB == WAVES * MBW * NBW, "blocks divide over the waves");
   static constexpr int HB = (CIN < 32 ? CIN : 32) / 8;                 // 16-byte chunks per plane of a channel block (32-channel blocks; 16 for the first layer)
@@ -487,12 +491,13 @@ struct ChFirst { const float* fw0; const float* fb0; const float* tau0; float ep
 
 // FIRST (layer 1, models.py:316-323): xin is the raw f32 patch [32*32][3]; FRN(3) + TLU(3) run here and the result is written
 // into the LDS image as 16-channel split-bf16 pixel records (channels 3-15 zero) -- no operand rows through HBM at all.
-template <int CIN, int COUT, int HIN, int STRIDE, bool FIRST = false>
+template <int CIN, int COUT, int HIN, int STRIDE, bool FIRST = false, int PP = 1>
 __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __restrict__ xin, int64_t ldx, const uint16_t* __restrict__ wpk,
                                                             const float* __restrict__ bias, const float* __restrict__ fw, const float* __restrict__ fb, float eps,
                                                             ChGateW g, const float* __restrict__ tau, float* __restrict__ y, uint16_t* __restrict__ ysp,
-                                                            int64_t ldsp, ChFirst first) {
-  using G = ConvGeom<CIN, COUT, HIN, STRIDE>;
+                                                            int64_t ldsp, ChFirst first, int n_patches) {
+  using G = ConvGeom<CIN, COUT, HIN, STRIDE, PP>;
+  static_assert(!FIRST || PP == 1, "the first layer takes one patch per workgroup");
   static_assert(!FIRST || (CIN == 16 && HIN == 32 && STRIDE == 1), "the first layer is 32x32x3 -> 16-channel records");
   constexpr int NT = G::NT, ZQ = G::ZQ, PXB = G::PXB, CPP = G::CPP, HOUT = G::HOUT, MBW = G::MBW, NBW = G::NBW, KS = G::KS, NB = G::NB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -500,7 +505,8 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int64_t patch = blockIdx.x;
+  const int64_t patch = (int64_t)blockIdx.x * PP;                 // first patch of this workgroup
+  const int valid = n_patches - (int)patch < PP ? n_patches - (int)patch : PP;      // patches that exist (the last workgroup of a launch)
   auto stamp = [&](int k) __attribute__((always_inline)) { if (first.prof && blockIdx.x == gridDim.x / 2 && t == 0) first.prof[k] = __builtin_readcyclecounter(); };
   ch_stagger(first.stagger, first.first_wave);
   stamp(0);
@@ -562,7 +568,8 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   } else {
     if (t < CPP) *(uint4*)(img + ZQ * PXB + t * 16) = make_uint4(0u, 0u, 0u, 0u);
     const uint16_t* src = xin + patch * (HIN * HIN) * ldx;
-    constexpr int TOT = HIN * HIN * CPP;
+    constexpr int TOT = PP * HIN * HIN * CPP;
+    const int last_row = valid * HIN * HIN - 1;                    // rows of missing patches re-read the last existing row (results discarded)
     constexpr int LPT = TOT / NT >= 8 ? 8 : 4;                     // independent 16-byte loads in flight per thread
     static_assert(TOT % (LPT * NT) == 0, "whole trips of LPT loads per thread");
 #pragma unroll
@@ -571,7 +578,8 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
 #pragma unroll
       for (int u = 0; u < LPT; ++u) {
         const int i = i0 + u * NT;
-        v[u] = *(const uint4*)(src + (int64_t)(i / CPP) * ldx + (i % CPP) * 8);
+        const int row = PP == 1 ? i / CPP : (i / CPP < last_row ? i / CPP : last_row);
+        v[u] = *(const uint4*)(src + (int64_t)row * ldx + (i % CPP) * 8);
       }
 #pragma unroll
       for (int u = 0; u < LPT; ++u) {
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
       }
     }
   }
-  float* gl = lds + G::FRN_FLOATS;
+  float* gl = lds + PP * G::FRN_FLOATS;
   if (stage_now) {
     if (t < 8 * COUT) { gl[t] = gv[0]; gl[8 * COUT + 8 + t] = gv[1]; gl[16 * COUT + 8 + t] = gv[2]; }
     if (t < COUT) { gl[24 * COUT + 8 + t] = gv[3]; gl[25 * COUT + 8 + t] = gv[4]; }
@@ -592,12 +600,13 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
 
   // ---- implicit GEMM: this wave's (m-block, n-block) tiles
   const int nb0 = wave % NB, mb0 = (wave / NB) * MBW;            // waves with the same n-block walk consecutive pixel blocks
-  int y0[MBW], x0[MBW];                                          // input coordinates of tap (0, 0) of this lane's output pixels (may be -1)
+  int y0[MBW], x0[MBW], qb[MBW];                                 // input coordinates of tap (0, 0) of this lane's output pixels (may be -1), first record of their patch
 #pragma unroll
   for (int m = 0; m < MBW; ++m) {
-    const int p = (mb0 + m) * 32 + li;
+    const int pg = (mb0 + m) * 32 + li, p = pg % G::NPIX;
     y0[m] = (p / HOUT) * STRIDE - 1;
     x0[m] = (p % HOUT) * STRIDE - 1;
+    qb[m] = (pg / G::NPIX) * (HIN * HIN);
   }
   f32x16 acc[MBW][NBW];
 #pragma unroll
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
 #pragma unroll
     for (int m = 0; m < MBW; ++m) {
       const int iy = y0[m] + ky, ix = x0[m] + kx;
-      const int q = ((unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN) ? iy * HIN + ix : ZQ;
+      const int q = ((unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN) ? qb[m] + iy * HIN + ix : ZQ;
       const int sw = G::swz(q);
       ah[m] = *(const bf16x8*)(img + q * PXB + ((chunk ^ sw) * 16));
       al[m] = *(const bf16x8*)(img + q * PXB + (((chunk + G::HB) ^ sw) * 16));
@@ -645,7 +654,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   // register ring of weight fragments, WD K steps deep: the loads of step + WD - 1 are issued before the MFMAs of step.  The
   // loop body covers UNR steps (a multiple of WD, so the ring indices are compile-time constants: registers, not scratch)
   // and is NOT unrolled further: 72 unrolled steps of the 128-channel layer overflow the instruction cache.
-  constexpr int WD = KS <= 2 ? 3 : 4, UNR = KS == 1 ? 9 : (KS == 2 ? 6 : KS);
+  constexpr int WD = KS <= 2 ? 3 : 4, UNR = KS == 1 ? 9 : (KS == 2 ? 6 : KS);      // (a ring 6-8 steps deep was measured: 10-40 % slower on every layer)
   static_assert(STEPS % UNR == 0 && UNR % WD == 0, "ring geometry");
   bf16x8 rh[WD][NBW], rl[WD][NBW];
 #pragma unroll
@@ -667,17 +676,21 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
   for (int m = 0; m < MBW; ++m)
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
-      const int pix = (mb0 + m) * 32 + li, c0 = (nb0 + n) * 32 + 4 * lh;
+      const int pg = (mb0 + m) * 32 + li, pix = pg % G::NPIX, c0 = (nb0 + n) * 32 + 4 * lh;
+      float* xb = lds + (pg / G::NPIX) * G::FRN_FLOATS;            // this patch's FRN arrays
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const float4 b4 = *(const float4*)(bias + c0 + 8 * gq);
-        *(float4*)(lds + frn_slot(pix, c0 + 8 * gq, COUT)) =
+        *(float4*)(xb + frn_slot(pix, c0 + 8 * gq, COUT)) =
             make_float4(acc[m][n][4 * gq] + b4.x, acc[m][n][4 * gq + 1] + b4.y, acc[m][n][4 * gq + 2] + b4.z, acc[m][n][4 * gq + 3] + b4.w);
       }
     }
   __syncthreads();
   stamp(3);
-  frn_block_body<COUT, HOUT, NT>(lds, fw, fb, eps, g, tau, y, ysp, ldsp, patch * G::NPIX, first.prof, stage_gates ? gl : nullptr);
+#pragma unroll
+  for (int pp = 0; pp < PP; ++pp)
+    if (pp < valid)                                              // workgroup-uniform
+      frn_block_body<COUT, HOUT, NT>(lds + pp * G::FRN_FLOATS, fw, fb, eps, g, tau, y, ysp, ldsp, (patch + pp) * G::NPIX, first.prof, stage_gates ? gl : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------- fused SandGlass block
@@ -1136,15 +1149,16 @@ extern "C" int gims_ch_frn_block(const float* x, int64_t patches, int32_t hw, in
   return GIMS_OK;
 }
 
-template <int CIN, int COUT, int HIN, int STRIDE, bool FIRST = false>
+constexpr int CH_PP5 = 1, CH_PP6 = 2;      // patches per workgroup of the 16x16x64 -> 8x8x128 layer (two measured slower: 357 -> 374 us) and of the 8x8x128 layer (537 -> 505 us per 8192 patches)
+template <int CIN, int COUT, int HIN, int STRIDE, bool FIRST = false, int PP = 1>
 static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, const uint16_t* w, const float* bias, const float* fw, const float* fb, float eps,
                              gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st, gims::ChFirst first = {nullptr, nullptr, nullptr, 0.f, nullptr, 0, 0}) {
   using namespace gims;
-  using Geo = ConvGeom<CIN, COUT, HIN, STRIDE>;
+  using Geo = ConvGeom<CIN, COUT, HIN, STRIDE, PP>;
   static bool attr = false;
   if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (Geo::FRN_FLOATS * 4 > Geo::LDS_BYTES ? Geo::FRN_FLOATS * 4 : Geo::LDS_BYTES) + Geo::GATE_BYTES));
+    GIMS_HIP(hipFuncSetAttribute((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 Geo::LDS_BYTES + Geo::GATE_BYTES));
     attr = true;
   }
   static const bool prof_on = getenv("GIMS_CH_PROF") != nullptr;      // diagnostics: cycle stamps of one workgroup per launch (synchronous)
@@ -1156,11 +1170,11 @@ static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, co
   static const int stagger = getenv("GIMS_CH_STAGGER") ? atoi(getenv("GIMS_CH_STAGGER")) : 8000;
   first.stagger = stagger;
   // (FRN_FLOATS * 4 <= LDS_BYTES by construction; the staged gate weights sit behind the FRN arrays)
-  const int lds_bytes = G.w1 ? Geo::FRN_FLOATS * 4 + Geo::GATE_BYTES : Geo::LDS_BYTES;
+  const int lds_bytes = G.w1 ? PP * Geo::FRN_FLOATS * 4 + Geo::GATE_BYTES : Geo::LDS_BYTES;
   const int lds_launch = lds_bytes > Geo::LDS_BYTES ? lds_bytes : Geo::LDS_BYTES;
   first.first_wave = 256 * (int)((160 * 1024) / lds_launch);
-  hipLaunchKernelGGL((ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST>), dim3((unsigned)patches), dim3(512), lds_launch, st, x, ldx, w, bias, fw, fb, eps, G,
-                     tau, y, ysp, ldsp, first);
+  hipLaunchKernelGGL((ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST, PP>), dim3((unsigned)cdiv(patches, PP)), dim3(512), lds_launch, st, x, ldx, w, bias, fw, fb,
+                     eps, G, tau, y, ysp, ldsp, first, (int)patches);
   GIMS_LAUNCH_CHECK();
   if (prof_on) {
     unsigned long long h[8];
@@ -1207,8 +1221,8 @@ extern "C" int gims_ch_conv_block(const uint16_t* x_split, int64_t ldx, int64_t 
     case 32 * 1000000 + 32 * 10000 + 32 * 10 + 1: return conv_block_launch<32, 32, 32, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
     case 32 * 1000000 + 32 * 10000 + 64 * 10 + 2: return conv_block_launch<32, 64, 32, 2>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
     case 16 * 1000000 + 64 * 10000 + 64 * 10 + 1: return conv_block_launch<64, 64, 16, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
-    case 16 * 1000000 + 64 * 10000 + 128 * 10 + 2: return conv_block_launch<64, 128, 16, 2>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
-    case 8 * 1000000 + 128 * 10000 + 128 * 10 + 1: return conv_block_launch<128, 128, 8, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+    case 16 * 1000000 + 64 * 10000 + 128 * 10 + 2: return conv_block_launch<64, 128, 16, 2, false, CH_PP5>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+    case 8 * 1000000 + 128 * 10000 + 128 * 10 + 1: return conv_block_launch<128, 128, 8, 1, false, CH_PP6>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
     default: break;
   }
   GIMS_CHECK_ARG(false, "gims_ch_conv_block: unsupported geometry hin=%d cin=%d cout=%d stride=%d (the five 3x3 layers of CAR-HyNet after the first)", hin, cin, cout, stride);
