@@ -730,7 +730,17 @@ static int r2_env(const char* name, int dflt) {
 static inline size_t r2_al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int r2_up4(int x) { return (x + 3) & ~3; }
 
-OtR2Plan ot_res2_plan(const OtR2Host* pr, int np, int iters) {
+// Geometry classes.  The decomposition of a problem -- nx row groups x nc column blocks, hence every summation order inside the solve -- is a
+// function of ITS OWN size only: a ragged list is split into classes of equal (nx, nc) and every class gets its own launches.  (One geometry
+// per call, taken from the largest problem, made a 256-keypoint pair's potentials depend on what else was in the batch: 5.6e-6 on the scores
+// between match_pairs and forward() on the same pair.)
+static inline int r2_class_key(const OtR2Host& h) {
+  int nc = 1;
+  while (nc * 128 < h.m) nc *= 2;
+  return cdiv(h.n > 1 ? h.n : 1, 1024) * 64 + nc;
+}
+
+static OtR2Plan plan_class(const OtR2Host* pr, int np, int iters) {
   OtR2Plan P{};
   if (iters < 1 || np < 1) return P;
   int maxn = 0, maxm = 0;
@@ -757,7 +767,54 @@ OtR2Plan ot_res2_plan(const OtR2Host* pr, int np, int iters) {
   return P;
 }
 
-int ot_res2_run(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, int init_inside, char* base, hipStream_t s) {
+static std::vector<std::vector<int>> r2_classes(const OtR2Host* pr, int np) {
+  std::vector<std::vector<int>> out;
+  std::vector<int> keys;
+  for (int i = 0; i < np; ++i) {
+    const int k = r2_class_key(pr[i]);
+    size_t c = 0;
+    while (c < keys.size() && keys[c] != k) ++c;
+    if (c == keys.size()) { keys.push_back(k); out.emplace_back(); }
+    out[c].push_back(i);
+  }
+  return out;
+}
+
+OtR2Plan ot_res2_plan(const OtR2Host* pr, int np, int iters) {
+  OtR2Plan P{};
+  if (iters < 1 || np < 1) return P;
+  P.ok = true;
+  for (const std::vector<int>& cls : r2_classes(pr, np)) {
+    std::vector<OtR2Host> sub;
+    for (int i : cls) sub.push_back(pr[i]);
+    const OtR2Plan c = plan_class(sub.data(), (int)sub.size(), iters);
+    if (!c.ok) return OtR2Plan{};
+    P.nx = c.nx > P.nx ? c.nx : P.nx;
+    P.nc = c.nc > P.nc ? c.nc : P.nc;
+    P.ppg = c.ppg > P.ppg ? c.ppg : P.ppg;
+    P.ngroups += c.ngroups;
+    P.bytes += r2_al(c.bytes);
+  }
+  return P;
+}
+
+static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, int init_inside, char* base, hipStream_t s);
+
+int ot_res2_run(const OtR2Plan&, const OtR2Host* hp, int np, float alpha, int iters, int init_inside, char* base, hipStream_t s) {
+  size_t off = 0;
+  for (const std::vector<int>& cls : r2_classes(hp, np)) {
+    std::vector<OtR2Host> sub;
+    for (int i : cls) sub.push_back(hp[i]);
+    const OtR2Plan c = plan_class(sub.data(), (int)sub.size(), iters);
+    if (!c.ok) { set_error("ot_res2_run: a geometry class has no plan"); return GIMS_EINVAL; }
+    const int rc = run_class(c, sub.data(), (int)sub.size(), alpha, iters, init_inside, base + off, s);
+    if (rc != GIMS_OK) return rc;
+    off += r2_al(c.bytes);
+  }
+  return GIMS_OK;
+}
+
+static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, int init_inside, char* base, hipStream_t s) {
   size_t off = 0;
   OtR2Dev* dprob = (OtR2Dev*)(base + off); off += r2_al(sizeof(OtR2Dev) * (size_t)np);
   int* dplace = (int*)(base + off); off += 256;
