@@ -301,6 +301,8 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   // diagnostics (GIMS_ATTN_PROF=1): cycles of wave 0 (group A) and wave 4 (group B) of workgroup 0 per phase, split into
   // work (phase start -> barrier reached) and wait (inside the barrier)
   unsigned long long pt = 0, pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_entry = PROF ? __builtin_readcyclecounter() : 0, r_entry = PROF ? __builtin_amdgcn_s_memrealtime() : 0;   // whole-kernel span of this wave
+  unsigned long long t_loop0 = 0, t_loop1 = 0;
   auto stamp_work = [&](int ph) __attribute__((always_inline)) { if (PROF) { const unsigned long long n = __builtin_readcyclecounter(); pacc[2 * ph] += n - pt; pt = n; } };
   // sub-stamps of the staging phase: [8] = its matrix segment, [9] = store_tile (the rest of the phase's work is load_tile)
   auto stamp_sub = [&](int i) __attribute__((always_inline)) {
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   // read of tile t-1 -- the previous barrier -- and read after the next one).  The two waves of a SIMD drift freely inside a
   // tile; the earlier design kept them half a tile apart with four barriers ("A multiplies while B exponentiates"), which
   // the overlap probes showed to buy nothing (section 4.2 of DESIGN.md) and this order beats by 9 %.
-  if (PROF) pt = __builtin_readcyclecounter();
+  if (PROF) { pt = __builtin_readcyclecounter(); t_loop0 = pt; }
   for (int kt = 0; kt < n_tiles; ++kt) {
     seg_qk(kt);
     stamp_work(0);
@@ -520,6 +522,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     if (kt + 2 < n_tiles) load_tile(kt + 2);
     ATT8_BAR(3);
   }
+  if (PROF) t_loop1 = __builtin_readcyclecounter();
   bool bad = false;
 #pragma unroll
   for (int qi = 0; qi < QP; ++qi) bad = bad || !(l_run[qi] < 1e30f) || (NOFMA && !(l_run[qi] > 1e-30f));      // inf / NaN / implausible
@@ -585,6 +588,10 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
           }
         }
     }
+  }
+  if (PROF && blockIdx.x == 0 && wave == 0 && lane == 0) {      // spans of wave 0: prologue, tile loop, epilogue (shader cycles) and the whole kernel on the 100-MHz counter
+    const unsigned long long t_exit = __builtin_readcyclecounter(), r_exit = __builtin_amdgcn_s_memrealtime();
+    prof[20] = t_loop0 - t_entry; prof[21] = t_loop1 - t_loop0; prof[22] = t_exit - t_loop1; prof[23] = r_exit - r_entry;
   }
 }
 
@@ -1181,7 +1188,7 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
     if (prof < 0) { const char* e = getenv("GIMS_ATTN_PROF"); prof = e ? atoi(e) : 0; }
     if (prof) {                                 // diagnostics only: synchronous, prints the phase anatomy of workgroup 0
       static unsigned long long* dprof = nullptr;
-      if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 20 * sizeof(unsigned long long)));
+      if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 24 * sizeof(unsigned long long)));
       if (prescaled)
         hipLaunchKernelGGL((attention8_bf16_kernel<true, true>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
                            q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
@@ -1189,8 +1196,10 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
         hipLaunchKernelGGL((attention8_bf16_kernel<true, false>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
                            q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
       GIMS_HIP(hipStreamSynchronize((hipStream_t)stream));
-      unsigned long long h[20];
+      unsigned long long h[24];
       GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[attention8 wave 0 of workgroup 0] prologue %llu, tile loop %llu, epilogue %llu shader cycles; %.1f us on the 100-MHz counter -> %.2f GHz\n",
+              h[20], h[21], h[22], h[23] / 100.0, (double)(h[20] + h[21] + h[22]) / (h[23] / 100.0) * 1e-3);
       for (int g = 0; g < 2; ++g)
         fprintf(stderr, "[attention8 wave %d] cycles over the whole tile loop: QK %llu, softmax0 %llu, softmax1 %llu, PV %llu, store_tile %llu, "
                 "load_tile %llu, barrier wait %llu\n", 4 * g, h[g * 10 + 0], h[g * 10 + 2], h[g * 10 + 4], h[g * 10 + 8], h[g * 10 + 9], h[g * 10 + 6],
