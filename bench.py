@@ -235,7 +235,12 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
         lin_name: ("mfma", lin_flops_layer / (lpl * nl), (per_step("qkv") + per_step("qkv_x3") + per_step("mlp")) / (lpl * L * nl), PEAK_BF16_TFLOPS,
                    "TFLOP/s", lpl * L * nl),
     }
-    for kname, mode, sfx in (("attention8_bf16_kernel", "bf16", ""), ("attention_x3_kernel", "bf16x3", "_x3")):
+    # which split-bf16 attention kernel a launch of this workload takes (the rule of gims_attention: the wide kernel when two 256-query
+    # workgroups per CU still fill the chip)
+    heads = 4
+    groups = 2 * pairs * heads // max(1, nl)
+    x3_name = "attention_x3w_kernel" if 8 * -(-groups // 8) * -(-kpts // 256) >= 512 else "attention_x3_kernel"
+    for kname, mode, sfx in (("attention8_bf16_kernel", "bf16", ""), (x3_name, "bf16x3", "_x3")):
         nl_k = cnt("self", mode) + cnt("cross", mode)
         if nl_k:
             cand[kname] = ("mfma", (cnt("self", mode) * attn_flops_layer + cnt("cross", mode) * cross_flops_layer) / (nl_k * nl),
@@ -276,7 +281,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
                           "iterations, the wide exchanges stay inside one XCD's L2 and one 0.5-KB edge crosses XCDs (DESIGN.md 4.1); priced on the fp32 "
                           "vector roof: 2 fma per matrix entry per iteration / 157.3 TFLOP/s; `avg_launch_ms` is the stage time (init + solve + selection) "
                           "per on-chip launch",
-        "attention_x3_kernel": "the same flash attention on split-bf16 operand pairs (Q, K, V from the 3-pass projection, P split in registers): THREE "
+        x3_name: "the same flash attention on split-bf16 operand pairs (Q, K, V from the 3-pass projection, P split in registers): THREE "
                                "bf16 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi); `achieved` counts ALGORITHMIC flops, `mfma_issue_frac` is 3x that",
         "attention8_bf16_kernel": "flash-style attention, head dim 64: per 64-key tile a wave issues 16 MFMAs against ~2 VALU/transcendental issues per "
                                   "score for the softmax, and MFMA and VALU of one SIMD do not overlap (DESIGN.md 4.2); `achieved` counts 4*N*M*64 flops per head",
@@ -286,9 +291,9 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     }
     allk = {k: {"bound": v[0], "avg_launch_ms": float(v[2]), "launches_per_step": v[5], "achieved": rate(v), "unit": v[4],
                 "peak": v[3], "frac": rate(v) / v[3], "traffic": traffic_of(k)} for k, v in cand.items()}
-    if "attention_x3_kernel" in allk:
-        allk["attention_x3_kernel"]["mfma_passes"] = 3
-        allk["attention_x3_kernel"]["mfma_issue_frac"] = 3.0 * allk["attention_x3_kernel"]["frac"]
+    if x3_name in allk:
+        allk[x3_name]["mfma_passes"] = 3
+        allk[x3_name]["mfma_issue_frac"] = 3.0 * allk[x3_name]["frac"]
     if ot_plan > 0:
         hb = ot_bytes / ot_plan / (cand[ot_name][2] * 1e-3) / 1e9
         allk[ot_name]["hbm_equivalent"] = {"achieved": hb, "unit": "GB/s", "note": "SURVEY 8(d) bytes / time: what a streamed implementation would "
@@ -307,7 +312,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     x3_cross = cnt("cross", "bf16x3") > cnt("cross", "bf16")
     n_x = cnt("cross", "bf16x3") if x3_cross else cnt("cross", "bf16")
     xms = per_step("attn_cross_x3" if x3_cross else "attn_cross") / max(1, n_x * nl)
-    cross = {"kernel": "attention_x3_kernel" if x3_cross else "attention8_bf16_kernel", "bound": "mfma", "avg_launch_ms": xms,
+    cross = {"kernel": x3_name if x3_cross else "attention8_bf16_kernel", "bound": "mfma", "avg_launch_ms": xms,
              "launches_per_step": n_x * nl, "achieved": cross_flops_layer / nl / (xms * 1e-3) / 1e12 if xms > 0 else 0.0,
              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "mfma_passes": 3 if x3_cross else 1}
     cross["frac"] = cross["achieved"] / PEAK_BF16_TFLOPS

@@ -809,6 +809,250 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------- split-bf16 (x3), wide form
+// attention_x3_kernel above gives a wave 32 queries and runs two workgroups per CU: per 64-key tile a wave reads 16 KB of K fragments and 16 KB of
+// V^T fragments from LDS for 48 MFMAs -- LDS bandwidth, not the matrix pipes, bounds it (27 % MFMA occupancy, 1.2 ms per launch of 16 x 4096 keys).
+// Here a wave owns 128 queries (four 32-query blocks), ONE wave per SIMD with the whole register file (<= 512 VGPRs), and walks its blocks in
+// PAIRS: every K and V^T fragment serves two blocks (half the LDS bytes per MFMA), the 96 MFMAs of a pair are one stream in which the fragment
+// reads of the next k-step sit between MFMAs that do not depend on them, and four waves stage a tile for 512 queries instead of 128 (a quarter of
+// the staging stores and barriers per query).  Same arithmetic, same tile order and the same running-maximum rule per query block as
+// attention_x3_kernel: the outputs are bit-identical to it.
+template <int X3W_QP>      // 32-query blocks per wave: 4 (one workgroup per CU, the whole register file) or 2 (two workgroups per CU, <= 256 registers)
+__global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel(
+    const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
+    const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
+    unsigned long long* __restrict__ stat) {
+  constexpr int X3W_QW = QW * X3W_QP, X3W_QB = X3W_QW * ATT_WAVES;
+  extern __shared__ __attribute__((aligned(16))) uint16_t x3_lds[];
+  auto Ks = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + (p * 2 + buf) * (KB * DH); };
+  auto Vt = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + 4 * (KB * DH) + (p * 2 + buf) * (DH * VT_LD); };
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int group = (slot / n_qt) * 8 + xcd;
+  if (group >= n_groups) return;
+  const gims_attn_problem pr = problems[group / n_heads];
+  const int q0 = (slot % n_qt) * X3W_QB;
+  if (q0 >= pr.n_q) return;
+  const int head = group % n_heads;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int qs = spl_col(q_col + head * DH), ks = spl_col(k_col + head * DH), vs = spl_col(v_col + head * DH);
+  auto doff = [&](int d8) __attribute__((always_inline)) { return ((d8 >> 2) << 6) + ((d8 & 3) << 3); };
+
+  bf16x8 qh[X3W_QP][4], ql[X3W_QP][4];
+#pragma unroll
+  for (int qi = 0; qi < X3W_QP; ++qi) {
+    int qr = q0 + wave * X3W_QW + qi * QW + li;
+    qr = qr < pr.n_q ? qr : pr.n_q - 1;
+    const uint16_t* qp = qkv + (int64_t)(pr.q_off + qr) * ld + qs;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qh[qi][s] = *(const bf16x8*)(qp + doff(2 * s + lh));
+      ql[qi][s] = *(const bf16x8*)(qp + doff(2 * s + lh) + 32);
+    }
+  }
+  f32x16 o[X3W_QP][2];
+  float m_run[X3W_QP], l_run[X3W_QP], m_true[X3W_QP];
+#pragma unroll
+  for (int qi = 0; qi < X3W_QP; ++qi) {
+    m_run[qi] = -1e30f; l_run[qi] = 0.f; m_true[qi] = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qi][i][r] = 0.f;
+  }
+  constexpr float DEFER = 5.0f;
+  const float defer_raw = DEFER / c;
+
+  // staging registers of the NEXT tile, requested at the top of a tile and stored at its end (storing K behind the first pair's products and
+  // requesting V only then -- one set of 8 registers live at a time -- measured slower: 937 -> 983 us)
+  uint4 rk[2][2], rv[2][2];        // [plane][piece]
+  const int n_tiles = (pr.n_kv + KB - 1) / KB;
+  const int vkp = t & 31, voct = t >> 5;
+  auto load_k = [&](int kt) __attribute__((always_inline)) {
+    const int kbase = kt * KB;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int f = t + 256 * it, row = f >> 3, ch = f & 7;
+      int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + ks + doff(ch);
+      rk[0][it] = *(const uint4*)(src);
+      rk[1][it] = *(const uint4*)(src + 32);
+    }
+  };
+  auto load_v = [&](int kt) __attribute__((always_inline)) {
+    const int kbase = kt * KB;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + vs + doff(voct);
+      rv[0][e] = *(const uint4*)(src);
+      rv[1][e] = *(const uint4*)(src + 32);
+    }
+  };
+  auto store_k = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int f = t + 256 * it, row = f >> 3, ch = f & 7;
+        *(uint4*)(Ks(p, buf) + k_off(row, ch)) = rk[p][it];
+      }
+  };
+  auto store_v = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const uint32_t a[4] = {rv[p][0].x, rv[p][0].y, rv[p][0].z, rv[p][0].w};
+      const uint32_t b[4] = {rv[p][1].x, rv[p][1].y, rv[p][1].z, rv[p][1].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
+        const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
+        *(uint32_t*)(Vt(p, buf) + (8 * voct + 2 * j) * VT_LD + 2 * vkp) = lo;
+        *(uint32_t*)(Vt(p, buf) + (8 * voct + 2 * j + 1) * VT_LD + 2 * vkp) = hi;
+      }
+    }
+  };
+
+  load_k(0);
+  load_v(0);
+  store_k(0);
+  store_v(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < n_tiles) { load_k(kt + 1); load_v(kt + 1); }
+    const int kbase = kt * KB;
+#pragma unroll
+    for (int pq = 0; pq < X3W_QP; pq += 2) {              // a pair of query blocks shares every K / V^T fragment
+      f32x16 sacc[2][2];                                  // [block of the pair][key block]
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[u][b][r] = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 kh = *(const bf16x8*)(Ks(0, buf) + k_off(b * 32 + li, 2 * s + lh));
+          const bf16x8 kl = *(const bf16x8*)(Ks(1, buf) + k_off(b * 32 + li, 2 * s + lh));
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {                   // per accumulator: small terms first, as in attention_x3_kernel
+            sacc[u][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[pq + u][s], sacc[u][b], 0, 0, 0);
+            sacc[u][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[pq + u][s], sacc[u][b], 0, 0, 0);
+            sacc[u][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[pq + u][s], sacc[u][b], 0, 0, 0);
+          }
+        }
+      bf16x8 ph[2][4], pl[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qi = pq + u;
+        if (kbase + KB > pr.n_kv) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kbase + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (key >= pr.n_kv) sacc[u][b][r] = -1e30f;
+            }
+        }
+        float tmax = -1e30f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[u][b][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        m_true[qi] = fmaxf(m_true[qi], tmax);
+        if (__any(tmax > m_run[qi] + defer_raw)) {
+          const float m_new = fmaxf(m_run[qi], tmax);
+          const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
+          m_run[qi] = m_new;
+          l_run[qi] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qi][i][r] *= alpha;
+        }
+        const float mc = m_run[qi] * c;
+        float lsum = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float pv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][b][r], c, -mc));
+            lsum += pv[r];
+          }
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            uint32_t hw[4], lw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float x = pv[8 * h2 + 2 * j], y = pv[8 * h2 + 2 * j + 1];
+              hw[j] = pack_bf2(x, y);
+              lw[j] = pack_bf2(x - __uint_as_float(hw[j] << 16), y - __uint_as_float(hw[j] & 0xffff0000u));
+            }
+            ph[u][2 * b + h2] = __builtin_bit_cast(bf16x8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+            pl[u][2 * b + h2] = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+          }
+        }
+        l_run[qi] += lsum;
+      }
+      // (forming P one 16-key slice at a time, straight into that k-step's products -- 48 registers less on paper -- measured slower: 937 -> 1058 us)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint16_t* vph = Vt(0, buf) + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
+          const uint16_t* vpl = Vt(1, buf) + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
+          const uint2 a0 = *(const uint2*)(vph), a1 = *(const uint2*)(vph + 8);
+          const uint2 b0 = *(const uint2*)(vpl), b1 = *(const uint2*)(vpl + 8);
+          const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+          const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            o[pq + u][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[u][s], o[pq + u][i], 0, 0, 0);
+            o[pq + u][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[u][s], o[pq + u][i], 0, 0, 0);
+            o[pq + u][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[u][s], o[pq + u][i], 0, 0, 0);
+          }
+        }
+    }
+    if (kt + 1 < n_tiles) { store_k(buf ^ 1); store_v(buf ^ 1); }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qi = 0; qi < X3W_QP; ++qi) {
+    const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+    const float inv = 1.f / l_tot;
+    const int qr = q0 + wave * X3W_QW + qi * QW + li;
+    if (stat) emit_peak_stat(stat, head, __builtin_amdgcn_exp2f((m_true[qi] - m_run[qi]) * c) * inv, lh == 0 && qr < pr.n_q);
+    if (qr < pr.n_q) {
+      const int64_t grow = pr.q_off + qr;
+      const int col0 = head * DH + 4 * lh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = make_float4(o[qi][i][4 * g] * inv, o[qi][i][4 * g + 1] * inv, o[qi][i][4 * g + 2] * inv, o[qi][i][4 * g + 3] * inv);
+          const int col = col0 + 32 * i + 8 * g;
+          if (out) *(float4*)(out + grow * ld_out + col) = v;
+          if (out_hi) {
+            const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
+            const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+            const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+            *(uint2*)(out_hi + grow * ld_split + spl_col(col)) = make_uint2(h01, h23);
+            *(uint2*)(out_lo + grow * ld_split + spl_col(col)) = make_uint2(l01, l23);
+          }
+        }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- split-key variant (small launches)
 // One image pair through the reference-shaped forward() (B = 1) gives a launch of 2 problems x 4 heads: with 32 queries per
 // wave that is ONE wave per SIMD at 4096 keypoints (and a quarter of the chip at 1024) -- every wave then sits out its own
@@ -1147,6 +1391,27 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
     if (!attr_set) {
       GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
       attr_set = true;
+    }
+    // wide form (128 queries per wave, one workgroup per CU) when its 512-query workgroups still fill the chip; GIMS_ATTN_X3W=0/1 forces
+    int wide = -1;
+    { const char* e = getenv("GIMS_ATTN_X3W"); if (e) wide = atoi(e); }
+    if (wide < 0) wide = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB) >= 512 ? 2 : 0;      // two 256-query workgroups per CU (measured: 937 vs 999 us for the 512-query form)
+    if (wide) {
+      static bool attr_w = false;
+      if (!attr_w) {
+        GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        attr_w = true;
+      }
+      const int qp = wide == 2 ? 2 : 4, n_qtw = cdiv(max_n_q, qp * QB);
+      if (qp == 4)
+        hipLaunchKernelGGL(attention_x3w_kernel<4>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat);
+      else
+        hipLaunchKernelGGL(attention_x3w_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat);
+      GIMS_LAUNCH_CHECK();
+      return GIMS_OK;
     }
     const int n_qt = cdiv(max_n_q, QB);
     hipLaunchKernelGGL(attention_x3_kernel, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, qkv, ld,

@@ -265,14 +265,17 @@ def test_attention(hip, monkeypatch, sizes, sharp, kernel, prescaled):
         assert (np.abs(rec[qo:qo + nq] - o[qo:qo + nq]) <= np.abs(o[qo:qo + nq]) * 2.0 ** -15 + 1e-30).all()
 
 
-@pytest.mark.parametrize("kernel", ["4wave", "4wave2", "8", "split", "split4", "x3"])
+@pytest.mark.parametrize("kernel", ["4wave", "4wave2", "8", "split", "split4", "x3", "x3w2", "x3w4"])
 @pytest.mark.parametrize("sharp", [1.0, 4.0])
 def test_attention_peak_statistic(hip, monkeypatch, kernel, sharp):
     """gims_attention_stat: per head, sum / count / maximum of the softmax row maxima (2^-24 fixed point), what
     attention_precision='auto' decides from -- against the float64 softmax of the same bf16 operands.  The running-maximum
     kernels report every query; launches served by the 8-wave kernel are measured by the sampling kernel (32 evenly spaced
     queries of every (problem, head) against all keys)."""
-    env = {"4wave": ("1", None), "4wave2": ("2", None), "8": ("8", None), "split": ("3", "2"), "split4": ("3", "4"), "x3": (None, None)}[kernel]
+    env = {"4wave": ("1", None), "4wave2": ("2", None), "8": ("8", None), "split": ("3", "2"), "split4": ("3", "4"), "x3": (None, None), "x3w2": (None, None),
+           "x3w4": (None, None)}[kernel]
+    if kernel.startswith("x3"):
+        monkeypatch.setenv("GIMS_ATTN_X3W", {"x3": "0", "x3w2": "2", "x3w4": "4"}[kernel])
     if env[0]:
         monkeypatch.setenv("GIMS_ATTN_QP", env[0])
     if env[1]:
@@ -288,7 +291,7 @@ def test_attention_peak_statistic(hip, monkeypatch, kernel, sharp):
         off += nq + nk
     pr = torch.tensor(probs, dtype=torch.int32, device="cuda")
     stat = torch.zeros((4, 4), dtype=torch.int64, device="cuda")
-    if kernel == "x3":
+    if kernel.startswith("x3"):
         qd = hip.split_spl32(_dev(qkv))
         f = qkv.astype(np.float64)
         hip.attention(qd, pr, 900, 4, None, out_split=torch.zeros((rows, 512), dtype=torch.bfloat16, device="cuda"), q_prescaled=True, x3=True, stat=stat)
@@ -315,19 +318,23 @@ def test_attention_peak_statistic(hip, monkeypatch, kernel, sharp):
             if len(sel):
                 ref_max[h] = max(ref_max[h], pmax[h, sel].max())
     np.testing.assert_array_equal(got[:, 1], ref_cnt)
-    tol = 2e-3 if kernel == "x3" else 6e-2            # bf16 logits move the probabilities by a few per cent
+    tol = 2e-3 if kernel.startswith("x3") else 6e-2            # bf16 logits move the probabilities by a few per cent
     np.testing.assert_allclose(got[:, 0] / 2 ** 24, ref_sum, rtol=tol)
     np.testing.assert_allclose(got[:, 2] / 2 ** 24, ref_max, rtol=3 * tol)
     assert (got[:, 3] == 0).all()
 
 
+@pytest.mark.parametrize("wide", ["0", "2", "4"])
 @pytest.mark.parametrize("prescaled", [False, True])
 @pytest.mark.parametrize("sizes,sharp", [([(64, 64)], 1.0), ([(200, 333), (333, 200)], 1.0), ([(1, 5), (129, 64), (1000, 777)], 1.0),
                                          ([(256, 256)], 6.0), ([(500, 300)], 12.0)])
-def test_attention_x3(hip, sizes, sharp, prescaled):
+def test_attention_x3(hip, monkeypatch, sizes, sharp, prescaled, wide):
     """Split-bf16 attention (GIMS_ATTN_X3): f32 Q/K/V given as SPL32 hi/lo planes, three MFMAs per product, against the
     float64 softmax attention of the SAME f32 values -- f32-class agreement (1e-4 of the value scale; the plain bf16 kernel
-    is held to 1.5e-2), also for sharply peaked softmaxes (sharp = 6, 12: logits of magnitude 50-150)."""
+    is held to 1.5e-2), also for sharply peaked softmaxes (sharp = 6, 12: logits of magnitude 50-150).  wide: the 32-query-per-wave
+    kernel (0) and the wide kernels with 64 / 128 queries per wave (GIMS_ATTN_X3W = 2 / 4: large launches take 2 by themselves), which
+    must return the SAME BITS -- a pair's scores may not depend on whether it was matched alone or inside a big batch."""
+    monkeypatch.setenv("GIMS_ATTN_X3W", wide)
     r = _rng(len(sizes) * 100 + sizes[0][0] + 1)
     rows = sum(a + b for a, b in sizes)
     qkv = (r.normal(size=(rows, 768)) * np.r_[np.full(512, sharp), np.ones(256)]).astype(np.float32)
@@ -367,6 +374,11 @@ def test_attention_x3(hip, sizes, sharp, prescaled):
     rec = h2.float().cpu().numpy().astype(np.float64) + l2.float().cpu().numpy()
     for qo, nq, ko, nk in probs:
         assert (np.abs(rec[qo:qo + nq] - o[qo:qo + nq]) <= np.abs(o[qo:qo + nq]) * 2.0 ** -15 + 1e-30).all()
+    if wide != "0":
+        monkeypatch.setenv("GIMS_ATTN_X3W", "0")
+        ref_out = torch.full((rows, 256), float("nan"), dtype=torch.float32, device="cuda")
+        hip.attention(spl, pr, max(s[0] for s in sizes), 4, ref_out, q_prescaled=prescaled, x3=True)
+        assert torch.equal(ref_out.view(torch.int32), out.view(torch.int32)), "wide and 32-query-per-wave split-bf16 attention kernels differ in bits"
 
 
 @pytest.mark.parametrize("kernel", ["auto", "8", "8exact", "split", "split4"])
