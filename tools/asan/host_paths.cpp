@@ -122,6 +122,32 @@ int main() {
     EXPECT(gims_sinkhorn_backward(nullptr, 0, 1.f, 10, nullptr, nullptr, nullptr, nullptr, 0, nullptr) == GIMS_EINVAL);
     EXPECT(gims_sinkhorn_history(nullptr, 0, 1.f, 10, nullptr, nullptr, 0, nullptr) == GIMS_EINVAL);
   }
+  {   // ---- fused Adam (round 3): table validation, and the multi-launch split of > 80 tensors
+    gims_adam_group g; memset(&g, 0, sizeof(g));
+    g.lr = 1e-3; g.beta1 = 0.9; g.beta2 = 0.999; g.eps = 1e-8; g.weight_decay = 0.0; g.step = 1;
+    gims_adam_tensor t1; memset(&t1, 0, sizeof(t1));
+    EXPECT(gims_adam_step(nullptr, 0, nullptr, 0, nullptr) == GIMS_OK);                 // nothing to do
+    EXPECT(gims_adam_step(&t1, 1, &g, 9, nullptr) == GIMS_EINVAL);                      // more than 8 hyper-parameter sets
+    t1.n = 16; t1.group = 0;
+    EXPECT(gims_adam_step(&t1, 1, &g, 1, nullptr) == GIMS_EINVAL);                      // null tensor pointers
+    t1.param = (float*)0x1000; t1.grad = (const float*)0x2000; t1.exp_avg = (float*)0x3000; t1.exp_avg_sq = (float*)0x4000; t1.group = 1;
+    EXPECT(gims_adam_step(&t1, 1, &g, 1, nullptr) == GIMS_EINVAL);                      // group index out of range
+    t1.group = 0; g.step = 0;
+    EXPECT(gims_adam_step(&t1, 1, &g, 1, nullptr) == GIMS_EINVAL);                      // step counts from 1
+    g.step = 3; g.beta2 = 1.0;
+    EXPECT(gims_adam_step(&t1, 1, &g, 1, nullptr) == GIMS_EINVAL);                      // beta2 < 1
+    g.beta2 = 0.999; t1.n = (int64_t)1 << 31;
+    EXPECT(gims_adam_step(&t1, 1, &g, 1, nullptr) == GIMS_EINVAL);                      // element count beyond 2^31
+    std::vector<gims_adam_tensor> many(300, t1);                                        // host-side chunking over 80-tensor launches; every launch
+    for (size_t i = 0; i < many.size(); ++i) many[i].n = (i % 7 == 0) ? 0 : 5 + (int64_t)i;   // fails cleanly here (no device), empty tensors skipped
+    const int rc_adam = gims_adam_step(many.data(), (int32_t)many.size(), &g, 1, nullptr);
+    EXPECT(rc_adam == GIMS_OK || rc_adam == GIMS_EHIP);
+  }
+  {   // ---- the per-keypoint affine map on its own (round 3): empty input is a no-op, bad pointers are refused
+    const int rc0 = gims_patch_affine(nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+    EXPECT(rc0 == GIMS_OK || rc0 == GIMS_EINVAL);
+    EXPECT(gims_patch_affine(nullptr, nullptr, 5, nullptr, nullptr, nullptr) == GIMS_EINVAL);
+  }
   // ---- a call that reaches the HIP runtime: no device in this container -> a clean GIMS_EHIP / error string, no crash
   char host_table[64] = {0};
   const int rc = gims_upload_table(host_table, sizeof(host_table), (void*)0x1000, nullptr);
