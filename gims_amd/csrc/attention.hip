@@ -651,19 +651,26 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
   const float defer_raw = DEFER / c;
   float m_run = -1e30f, l_run = 0.f, m_true = -1e30f;
 
-  uint4 rk[2][2], rv[2][2];        // [plane][piece]
+  uint4 rv[2][2];                  // [plane][piece]
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
   const int vkp = t & 31, voct = t >> 5;
-  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+  // K goes global -> LDS by LDS-DMA, the chunk swizzle of k_off applied on the source side (see attention_x3w_kernel); V^T through registers
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_k = [&](int kt, int buf) __attribute__((always_inline)) {
     const int kbase = kt * KB;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int f = t + 256 * it, row = f >> 3, ch = f & 7;
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int j = wave_u * 2 + j2, row = 8 * j + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
       int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
       const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + ks + doff(ch);
-      rk[0][it] = *(const uint4*)(src);
-      rk[1][it] = *(const uint4*)(src + 32);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 32 * p),
+                                         (__attribute__((address_space(3))) void*)(Ks(p, buf) + j * 512), 16, 0, 0);
     }
+  };
+  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+    const int kbase = kt * KB;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
@@ -675,11 +682,6 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int f = t + 256 * it, row = f >> 3, ch = f & 7;
-        *(uint4*)(Ks(p, buf) + k_off(row, ch)) = rk[p][it];
-      }
       const uint32_t a[4] = {rv[p][0].x, rv[p][0].y, rv[p][0].z, rv[p][0].w};
       const uint32_t b[4] = {rv[p][1].x, rv[p][1].y, rv[p][1].z, rv[p][1].w};
 #pragma unroll
@@ -692,13 +694,15 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
     }
   };
 
+  dma_k(0, 0);
   load_tile(0);
   store_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < n_tiles) load_tile(kt + 1);
+    if (kt + 1 < n_tiles) { dma_k(kt + 1, buf ^ 1); load_tile(kt + 1); }
     f32x16 sacc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -781,6 +785,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
         o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s], o[i], 0, 0, 0);
       }
     if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of the next K tile has landed
     __syncthreads();
   }
 
@@ -867,18 +872,24 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
 
   // staging registers of the NEXT tile, requested at the top of a tile and stored at its end (storing K behind the first pair's products and
   // requesting V only then -- one set of 8 registers live at a time -- measured slower: 937 -> 983 us)
-  uint4 rk[2][2], rv[2][2];        // [plane][piece]
+  uint4 rv[2][2];                  // [plane][piece]
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
   const int vkp = t & 31, voct = t >> 5;
-  auto load_k = [&](int kt) __attribute__((always_inline)) {
+  // K goes global -> LDS by LDS-DMA (no staging registers: held across a tile they were what spilled -- 230 MB of scratch writes per launch in the
+  // PMC pass).  A DMA instruction fills one contiguous KiB = 8 tile rows x 8 chunks; the chunk swizzle of k_off is applied on the SOURCE side:
+  // the lane that lands at (row, position) fetches chunk position ^ ((row >> 1) & 7).  Two instructions per wave and plane.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_k = [&](int kt, int buf) __attribute__((always_inline)) {
     const int kbase = kt * KB;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int f = t + 256 * it, row = f >> 3, ch = f & 7;
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int j = wave_u * 2 + j2, row = 8 * j + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
       int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
       const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + ks + doff(ch);
-      rk[0][it] = *(const uint4*)(src);
-      rk[1][it] = *(const uint4*)(src + 32);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 32 * p),
+                                         (__attribute__((address_space(3))) void*)(Ks(p, buf) + j * 512), 16, 0, 0);
     }
   };
   auto load_v = [&](int kt) __attribute__((always_inline)) {
@@ -890,15 +901,6 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
       rv[0][e] = *(const uint4*)(src);
       rv[1][e] = *(const uint4*)(src + 32);
     }
-  };
-  auto store_k = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int f = t + 256 * it, row = f >> 3, ch = f & 7;
-        *(uint4*)(Ks(p, buf) + k_off(row, ch)) = rk[p][it];
-      }
   };
   auto store_v = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -915,15 +917,15 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
     }
   };
 
-  load_k(0);
+  dma_k(0, 0);
   load_v(0);
-  store_k(0);
   store_v(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < n_tiles) { load_k(kt + 1); load_v(kt + 1); }
+    if (kt + 1 < n_tiles) { dma_k(kt + 1, buf ^ 1); load_v(kt + 1); }
     const int kbase = kt * KB;
 #pragma unroll
     for (int pq = 0; pq < X3W_QP; pq += 2) {              // a pair of query blocks shares every K / V^T fragment
@@ -1021,7 +1023,8 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
           }
         }
     }
-    if (kt + 1 < n_tiles) { store_k(buf ^ 1); store_v(buf ^ 1); }
+    if (kt + 1 < n_tiles) store_v(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of the next K tile has landed before anyone crosses the barrier
     __syncthreads();
   }
 
@@ -1395,7 +1398,11 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
     // wide form (128 queries per wave, one workgroup per CU) when its 512-query workgroups still fill the chip; GIMS_ATTN_X3W=0/1 forces
     int wide = -1;
     { const char* e = getenv("GIMS_ATTN_X3W"); if (e) wide = atoi(e); }
-    if (wide < 0) wide = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB) >= 512 ? 2 : 0;      // two 256-query workgroups per CU (measured: 937 vs 999 us for the 512-query form)
+    // 512-query workgroups (one per CU, the whole register file, no spills) for long sequences that fill the chip, else the 32-query-per-wave
+    // kernel.  Measured with K staged by LDS-DMA in all of them (32-query / QP = 2 / QP = 4): 16 x 4096 keys 944 / 860 / 835 us, 32 x 2048
+    // 495 / 463 / 474, 40 x 1500 313 / 325 / 326, 64 x 1022 246 / 282 / 300 -- below ~2048 keys the wide form's prologue, epilogue and tail
+    // (2 workgroups per CU-slot instead of 8) cost more than its halved LDS traffic saves.
+    if (wide < 0) wide = (max_n_q >= 2048 && 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 4 * QB) >= 256) ? 4 : 0;
     if (wide) {
       static bool attr_w = false;
       if (!attr_w) {

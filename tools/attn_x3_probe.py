@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gims_amd import hip
 hip.load()
-for n, imgs in ((4096, 16), (1022, 64), (700, 8)):
+for n, imgs in ((4096, 16), (2048, 32), (1500, 40), (1022, 64), (700, 8)):
     rows = n * imgs
     x = torch.randn(rows, 768, device="cuda") * 0.7
     x[:, :256] *= 3.0                                  # sharper logits
