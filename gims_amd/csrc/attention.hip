@@ -110,17 +110,24 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
   for (int qi = 0; qi < QP; ++qi) { m_run[qi] = -1e30f; l_run[qi] = 0.f; m_true[qi] = -1e30f; }
 
   // staging: K tile 64 rows x 8 chunks = 512 chunks (2 per thread); V tile: key pair kp = t&31, d-octet t>>5
-  uint4 rk[2], rv[2];
+  // K goes global -> LDS by LDS-DMA: its staging registers, held across a whole tile, were being spilled to scratch (48 B per lane).  One DMA
+  // instruction fills a contiguous KiB = 8 tile rows; the chunk swizzle of k_off is applied on the source side.  V^T still goes through registers.
+  uint4 rv[2];
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
   const int vkp = t & 31, voct = t >> 5;
-  auto load_tile = [&](int kt) {
+  const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+  auto dma_k = [&](int kt, int buf) __attribute__((always_inline)) {
     const int kbase = kt * KB;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int f = t + 256 * it, row = f >> 3, ch = f & 7;
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int j = wave_u * 2 + j2, row = 8 * j + ((t & 63) >> 3), ch = (t & 7) ^ ((row >> 1) & 7);
       int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-      rk[it] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * ch);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * ch),
+                                       (__attribute__((address_space(3))) void*)(Ks[buf] + j * 512), 16, 0, 0);
     }
+  };
+  auto load_tile = [&](int kt) {
+    const int kbase = kt * KB;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
@@ -128,11 +135,6 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
     }
   };
   auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int f = t + 256 * it, row = f >> 3, ch = f & 7;
-      *(uint4*)(Ks[buf] + k_off(row, ch)) = rk[it];
-    }
     const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
     const uint32_t b[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
 #pragma unroll
@@ -144,13 +146,15 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
     }
   };
 
+  dma_k(0, 0);
   load_tile(0);
   store_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < n_tiles) load_tile(kt + 1);
+    if (kt + 1 < n_tiles) { dma_k(kt + 1, (kt + 1) & 1); load_tile(kt + 1); }
 
     // ---- S^T = K Q^T : two 32-key blocks x QP query blocks, K = 64 (4 steps of 16); K fragments shared by the query blocks
     f32x16 sacc[QP][2];
@@ -242,6 +246,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
     }
     __builtin_amdgcn_s_setprio(0);
     if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of the next K tile has landed
     __syncthreads();
   }
 
@@ -1105,16 +1110,22 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
   const int n_mine = (n_tiles - half + NS - 1) / NS;      // tiles half, half + NS, ...
   const int n_iter = (n_tiles + NS - 1) / NS;             // every part passes the same number of barriers
-  uint4 rk[2], rv[2];
+  // K by LDS-DMA (see attention_bf16_kernel: its staging registers were spilled to scratch -- 48 / 128 B per lane here); V^T through registers
+  uint4 rv[2];
   const int vkp = t & 31, voct = t >> 5;
-  auto load_tile = [&](int it) __attribute__((always_inline)) {
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_k = [&](int it, int buf) __attribute__((always_inline)) {
     const int kbase = (NS * it + half) * KB;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int f = t + 256 * e, row = f >> 3, ch = f & 7;
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int j = wave_u * 2 + j2, row = 8 * j + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
       int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-      rk[e] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * ch);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * ch),
+                                       (__attribute__((address_space(3))) void*)(Ks(half, buf) + j * 512), 16, 0, 0);
     }
+  };
+  auto load_tile = [&](int it) __attribute__((always_inline)) {
+    const int kbase = (NS * it + half) * KB;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
@@ -1122,11 +1133,6 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
     }
   };
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int f = t + 256 * e, row = f >> 3, ch = f & 7;
-      *(uint4*)(Ks(half, buf) + k_off(row, ch)) = rk[e];
-    }
     const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
     const uint32_t b[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
 #pragma unroll
@@ -1138,12 +1144,13 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
     }
   };
 
-  if (n_mine > 0) { load_tile(0); store_tile(0); }
+  if (n_mine > 0) { dma_k(0, 0); load_tile(0); store_tile(0); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int it = 0; it < n_iter; ++it) {
     const int buf = it & 1;
     const bool live = it < n_mine;
-    if (it + 1 < n_mine) load_tile(it + 1);
+    if (it + 1 < n_mine) { dma_k(it + 1, buf ^ 1); load_tile(it + 1); }
     if (live) {
       f32x16 sacc[2];
 #pragma unroll
@@ -1218,6 +1225,7 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
         }
     }
     if (it + 1 < n_mine) store_tile(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of the next K tile has landed
     __syncthreads();
   }
 
