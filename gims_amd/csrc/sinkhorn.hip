@@ -326,6 +326,13 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restr
 // ---------------------------------------------------------------------------------------------- selection
 // t_ij = ((Z_ij + u_i) + v_j) - norm on the inner block (gmatcher.py:47,68,284): row max/argmax directly,
 // column max/argmax through per-workgroup partials (rows visited in ascending order; ties -> lower index).
+template <int CTRL>
+__device__ __forceinline__ void ot_argmax_step(float& bv, int& bi) {
+  const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bv), CTRL, 0xf, 0xf, true));
+  const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, true);
+  if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+
 template <int CPT>
 __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict__ probs) {
   __shared__ float rv[16][OT_R];
@@ -346,20 +353,45 @@ __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict
     cbi[s] = make_int4(0, 0, 0, 0);
   }
   const int n_slabs = (p.n + OT_R - 1) / OT_R;
+  // all OT_R x CPT row pieces of a slab are requested before the first one is used (clamped rows: unconditional loads), and the NEXT slab's
+  // pieces are requested before this slab's reductions: row by row the kernel paid one HBM latency per row (12.8 us per 8-row slab, 2.7 TB/s)
+  float4 zs[OT_R][CPT], zn[OT_R][CPT];
+  float us[OT_R], un[OT_R];
+  auto request = [&](int slab, float4 (&zd)[OT_R][CPT], float (&ud)[OT_R]) __attribute__((always_inline)) {
+    const int r0 = slab * OT_R;
+#pragma unroll
+    for (int r = 0; r < OT_R; ++r) {
+      int rowc = r0 + r < p.n ? r0 + r : p.n - 1;
+      rowc = rowc < 0 ? 0 : rowc;
+      ud[r] = p.u[rowc];
+#pragma unroll
+      for (int s = 0; s < CPT; ++s) {
+        const int c0 = 4 * (t + blockDim.x * s);
+        zd[r][s] = *(const float4*)(p.z + (int64_t)rowc * p.ld + (c0 < p.m ? c0 : 0));     // rows are padded to 4 floats: in bounds
+      }
+    }
+  };
+  if ((int)blockIdx.x < n_slabs) request(blockIdx.x, zn, un);
   for (int slab = blockIdx.x; slab < n_slabs; slab += p.G) {
     const int r0 = slab * OT_R;
+#pragma unroll
+    for (int r = 0; r < OT_R; ++r) {
+      us[r] = un[r];
+#pragma unroll
+      for (int s = 0; s < CPT; ++s) zs[r][s] = zn[r][s];
+    }
+    if (slab + p.G < n_slabs) request(slab + p.G, zn, un);
 #pragma unroll
     for (int r = 0; r < OT_R; ++r) {
       const int row = r0 + r;
       float bv = -INFINITY;
       int bi = 0x7fffffff;
       if (row < p.n) {
-        const float ui = p.u[row];
-        const float* zr = p.z + (int64_t)row * p.ld;
+        const float ui = us[r];
 #pragma unroll
         for (int s = 0; s < CPT; ++s) {
           const int c0 = 4 * (t + blockDim.x * s);
-          const float4 z = *(const float4*)(zr + (c0 < p.m ? c0 : 0));     // rows are padded to 4 floats: in bounds
+          const float4 z = zs[r][s];
           const float zz[4] = {z.x, z.y, z.z, z.w};
           const float vv[4] = {vq[s].x, vq[s].y, vq[s].z, vq[s].w};
           float* cbp = (float*)&cb[s];
@@ -374,14 +406,25 @@ __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict
           }
         }
       }
-      // wave argmax (ties -> lower column)
+      // wave argmax (ties -> lower column).  The comparison is a strict total order, so the result does not depend on the combination order:
+      // four DPP steps inside every 16-lane row, then lanes 0 / 16 / 32 / 48 are read back and folded.  (The butterfly of twelve __shfl_xor
+      // = ds_bpermute per row made this kernel LDS-permute bound: 1 536 of them per 8-row slab and CU, 205 us per 8 x 4096^2 against ~110 us of
+      // HBM time.)
+      ot_argmax_step<0xB1>(bv, bi);      // quad_perm [1,0,3,2]
+      ot_argmax_step<0x4E>(bv, bi);      // quad_perm [2,3,0,1]
+      ot_argmax_step<0x141>(bv, bi);     // row_half_mirror
+      ot_argmax_step<0x140>(bv, bi);     // row_mirror
+      {
+        float fv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 0));
+        int fi = __builtin_amdgcn_readlane(bi, 0);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        for (int q = 1; q < 4; ++q) {
+          const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 16 * q));
+          const int oi = __builtin_amdgcn_readlane(bi, 16 * q);
+          if (ov > fv || (ov == fv && oi < fi)) { fv = ov; fi = oi; }
+        }
+        if (lane == 0) { rv[wave][r] = fv; ri[wave][r] = fi; }
       }
-      if (lane == 0) { rv[wave][r] = bv; ri[wave][r] = bi; }
     }
     __syncthreads();
     if (t < OT_R && r0 + t < p.n) {
