@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
     const uint16_t* src = xin + patch * (HIN * HIN) * ldx;
     constexpr int TOT = PP * HIN * HIN * CPP;
     const int last_row = valid * HIN * HIN - 1;                    // rows of missing patches re-read the last existing row (results discarded)
-    constexpr int LPT = TOT / NT >= 8 ? 8 : 4;                     // independent 16-byte loads in flight per thread
+    constexpr int LPT = TOT / NT >= 16 ? 16 : (TOT / NT >= 8 ? 8 : 4);   // independent 16-byte loads in flight per thread: the whole patch in ONE round trip
     static_assert(TOT % (LPT * NT) == 0, "whole trips of LPT loads per thread");
 #pragma unroll
     for (int i0 = t; i0 < TOT; i0 += LPT * NT) {                  // (four in flight left 4 dependent HBM round trips on the 128 KB layers)
