@@ -239,7 +239,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     # workgroups per CU still fill the chip)
     heads = 4
     groups = 2 * pairs * heads // max(1, nl)
-    x3_name = "attention_x3w_kernel" if (kpts >= 2048 and 8 * -(-groups // 8) * -(-kpts // 512) >= 256) else "attention_x3_kernel"
+    x3_name = "attention_x3w_kernel" if 8 * -(-groups // 8) * -(-kpts // 256) >= 512 else "attention_x3_kernel"
     for kname, mode, sfx in (("attention8_bf16_kernel", "bf16", ""), (x3_name, "bf16x3", "_x3")):
         nl_k = cnt("self", mode) + cnt("cross", mode)
         if nl_k:

@@ -611,7 +611,8 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
 // 32-channel block 32 hi then 32 lo values); P is split in registers.  Geometry of attention_bf16_kernel<1> (4 waves x
 // 32 queries, 64-key tiles, running maximum with deferred rescale); LDS is dynamic (67 KB: hi and lo planes of the
 // double-buffered K and V^T tiles).
-constexpr int X3_LDS_BYTES = 2 * 2 * (KB * DH + DH * VT_LD) * 2;
+constexpr int X3W_VR = 80;                 // V row pitch in bf16 elements (160 bytes): row-major V tiles of the split-bf16 kernels
+constexpr int X3_LDS_BYTES = 2 * 2 * (KB * DH + KB * X3W_VR) * 2;      // 72 KB: hi and lo planes of the double-buffered K and V tiles
 
 __global__ __launch_bounds__(256) void attention_x3_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
@@ -621,7 +622,8 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
   extern __shared__ __attribute__((aligned(16))) uint16_t x3_lds[];
   // [plane p = hi/lo][buffer]: K tiles then V^T tiles
   auto Ks = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + (p * 2 + buf) * (KB * DH); };
-  auto Vt = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + 4 * (KB * DH) + (p * 2 + buf) * (DH * VT_LD); };
+  // V tiles row-major [key][d], 160-byte pitch, filled by LDS-DMA and read transposed (see attention_x3w_kernel)
+  auto Vr = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + 4 * (KB * DH) + (p * 2 + buf) * (KB * X3W_VR); };
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int group = (slot / n_qt) * 8 + xcd;
@@ -656,9 +658,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
   const float defer_raw = DEFER / c;
   float m_run = -1e30f, l_run = 0.f, m_true = -1e30f;
 
-  uint4 rv[2][2];                  // [plane][piece]
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
-  const int vkp = t & 31, voct = t >> 5;
   // K goes global -> LDS by LDS-DMA, the chunk swizzle of k_off applied on the source side (see attention_x3w_kernel); V^T through registers
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto dma_k = [&](int kt, int buf) __attribute__((always_inline)) {
@@ -674,40 +674,30 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
                                          (__attribute__((address_space(3))) void*)(Ks(p, buf) + j * 512), 16, 0, 0);
     }
   };
-  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+  auto dma_v = [&](int kt, int buf) __attribute__((always_inline)) {
     const int kbase = kt * KB;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-      const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + vs + doff(voct);
-      rv[0][e] = *(const uint4*)(src);
-      rv[1][e] = *(const uint4*)(src + 32);
-    }
-  };
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    for (int j3 = 0; j3 < 3; ++j3) {
+      const int j = wave_u + 4 * j3;
+      if (j < 10) {
+        const int B = 1024 * j + 16 * lane, row = B / (2 * X3W_VR), pos = (B % (2 * X3W_VR)) >> 4, ch = pos < 8 ? pos : 0;
+        int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+        const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + vs + doff(ch);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const uint32_t a[4] = {rv[p][0].x, rv[p][0].y, rv[p][0].z, rv[p][0].w};
-      const uint32_t b[4] = {rv[p][1].x, rv[p][1].y, rv[p][1].z, rv[p][1].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
-        const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
-        *(uint32_t*)(Vt(p, buf) + (8 * voct + 2 * j) * VT_LD + 2 * vkp) = lo;
-        *(uint32_t*)(Vt(p, buf) + (8 * voct + 2 * j + 1) * VT_LD + 2 * vkp) = hi;
+        for (int p = 0; p < 2; ++p)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 32 * p),
+                                           (__attribute__((address_space(3))) void*)(Vr(p, buf) + j * 512), 16, 0, 0);
       }
     }
   };
-
   dma_k(0, 0);
-  load_tile(0);
-  store_tile(0);
+  dma_v(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < n_tiles) { dma_k(kt + 1, buf ^ 1); load_tile(kt + 1); }
+    if (kt + 1 < n_tiles) { dma_k(kt + 1, buf ^ 1); dma_v(kt + 1, buf ^ 1); }
     f32x16 sacc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -779,17 +769,17 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const uint16_t* vph = Vt(0, buf) + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
-        const uint16_t* vpl = Vt(1, buf) + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
-        const uint2 a0 = *(const uint2*)(vph), a1 = *(const uint2*)(vph + 8);
-        const uint2 b0 = *(const uint2*)(vpl), b1 = *(const uint2*)(vpl + 8);
-        const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-        const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+        const int voff = (4 * lh + ((lane & 15) >> 2)) * X3W_VR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + 16 * s * X3W_VR + 32 * i;
+        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(0, buf) + voff));
+        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(0, buf) + voff + 8 * X3W_VR));
+        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(1, buf) + voff));
+        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(1, buf) + voff + 8 * X3W_VR));
+        const bf16x8 vh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+        const bf16x8 vl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
         o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s], o[i], 0, 0, 0);
         o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s], o[i], 0, 0, 0);
         o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s], o[i], 0, 0, 0);
       }
-    if (kt + 1 < n_tiles) store_tile(buf ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of the next K tile has landed
     __syncthreads();
   }
@@ -827,6 +817,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
 // reads of the next k-step sit between MFMAs that do not depend on them, and four waves stage a tile for 512 queries instead of 128 (a quarter of
 // the staging stores and barriers per query).  Same arithmetic, same tile order and the same running-maximum rule per query block as
 // attention_x3_kernel: the outputs are bit-identical to it.
+constexpr int X3W_LDS_BYTES = X3_LDS_BYTES;
 template <int X3W_QP>      // 32-query blocks per wave: 4 (one workgroup per CU, the whole register file) or 2 (two workgroups per CU, <= 256 registers)
 __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
@@ -836,7 +827,9 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
   constexpr int X3W_QW = QW * X3W_QP, X3W_QB = X3W_QW * ATT_WAVES;
   extern __shared__ __attribute__((aligned(16))) uint16_t x3_lds[];
   auto Ks = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + (p * 2 + buf) * (KB * DH); };
-  auto Vt = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + 4 * (KB * DH) + (p * 2 + buf) * (DH * VT_LD); };
+  // V tiles ROW-MAJOR [key][d] with a 160-byte pitch (X3W_VR elements): filled by LDS-DMA like K, read transposed by ds_read_b64_tr_b16 (the
+  // four key rows of a transposing read land on disjoint quarters of the 64 banks at this pitch, like the 192-byte pitch of attention8_bf16_kernel)
+  auto Vr = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + 4 * (KB * DH) + (p * 2 + buf) * (KB * X3W_VR); };
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int group = (slot / n_qt) * 8 + xcd;
@@ -877,9 +870,7 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
 
   // staging registers of the NEXT tile, requested at the top of a tile and stored at its end (storing K behind the first pair's products and
   // requesting V only then -- one set of 8 registers live at a time -- measured slower: 937 -> 983 us)
-  uint4 rv[2][2];                  // [plane][piece]
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
-  const int vkp = t & 31, voct = t >> 5;
   // K goes global -> LDS by LDS-DMA (no staging registers: held across a tile they were what spilled -- 230 MB of scratch writes per launch in the
   // PMC pass).  A DMA instruction fills one contiguous KiB = 8 tile rows x 8 chunks; the chunk swizzle of k_off is applied on the SOURCE side:
   // the lane that lands at (row, position) fetches chunk position ^ ((row >> 1) & 7).  Two instructions per wave and plane.
@@ -897,40 +888,32 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
                                          (__attribute__((address_space(3))) void*)(Ks(p, buf) + j * 512), 16, 0, 0);
     }
   };
-  auto load_v = [&](int kt) __attribute__((always_inline)) {
+  // a DMA instruction fills one contiguous KiB of the padded tile image: byte B = 1024 j + 16 lane is (row B / 160, chunk (B % 160) / 16); the
+  // two pad chunks of a row re-fetch chunk 0.  Ten instructions per plane and tile: waves 0 and 1 issue three, waves 2 and 3 two.
+  auto dma_v = [&](int kt, int buf) __attribute__((always_inline)) {
     const int kbase = kt * KB;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-      const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + vs + doff(voct);
-      rv[0][e] = *(const uint4*)(src);
-      rv[1][e] = *(const uint4*)(src + 32);
-    }
-  };
-  auto store_v = [&](int buf) __attribute__((always_inline)) {
+    for (int j3 = 0; j3 < 3; ++j3) {
+      const int j = wave_u + 4 * j3;
+      if (j < 10) {
+        const int B = 1024 * j + 16 * lane, row = B / (2 * X3W_VR), pos = (B % (2 * X3W_VR)) >> 4, ch = pos < 8 ? pos : 0;
+        int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+        const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + vs + doff(ch);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const uint32_t a[4] = {rv[p][0].x, rv[p][0].y, rv[p][0].z, rv[p][0].w};
-      const uint32_t b[4] = {rv[p][1].x, rv[p][1].y, rv[p][1].z, rv[p][1].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
-        const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
-        *(uint32_t*)(Vt(p, buf) + (8 * voct + 2 * j) * VT_LD + 2 * vkp) = lo;
-        *(uint32_t*)(Vt(p, buf) + (8 * voct + 2 * j + 1) * VT_LD + 2 * vkp) = hi;
+        for (int p = 0; p < 2; ++p)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 32 * p),
+                                           (__attribute__((address_space(3))) void*)(Vr(p, buf) + j * 512), 16, 0, 0);
       }
     }
   };
-
   dma_k(0, 0);
-  load_v(0);
-  store_v(0);
+  dma_v(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < n_tiles) { dma_k(kt + 1, buf ^ 1); load_v(kt + 1); }
+    if (kt + 1 < n_tiles) { dma_k(kt + 1, buf ^ 1); dma_v(kt + 1, buf ^ 1); }
     const int kbase = kt * KB;
 #pragma unroll
     for (int pq = 0; pq < X3W_QP; pq += 2) {              // a pair of query blocks shares every K / V^T fragment
@@ -1014,12 +997,15 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const uint16_t* vph = Vt(0, buf) + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
-          const uint16_t* vpl = Vt(1, buf) + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
-          const uint2 a0 = *(const uint2*)(vph), a1 = *(const uint2*)(vph + 8);
-          const uint2 b0 = *(const uint2*)(vpl), b1 = *(const uint2*)(vpl + 8);
-          const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-          const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+          // V^T fragments by transposing reads of the row-major tiles (addressing of attention8_bf16_kernel's seg_pv: MFMA k-slot j of lane
+          // (d = li, lh) is key 16 s + 8 (j >> 2) + 4 lh + (j & 3) -- the order P already has)
+          const int voff = (4 * lh + ((lane & 15) >> 2)) * X3W_VR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + 16 * s * X3W_VR + 32 * i;
+          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(0, buf) + voff));
+          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(0, buf) + voff + 8 * X3W_VR));
+          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(1, buf) + voff));
+          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(1, buf) + voff + 8 * X3W_VR));
+          const bf16x8 vh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+          const bf16x8 vl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             o[pq + u][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[u][s], o[pq + u][i], 0, 0, 0);
@@ -1028,7 +1014,6 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
           }
         }
     }
-    if (kt + 1 < n_tiles) store_v(buf ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of the next K tile has landed before anyone crosses the barrier
     __syncthreads();
   }
@@ -1406,24 +1391,23 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
     // wide form (128 queries per wave, one workgroup per CU) when its 512-query workgroups still fill the chip; GIMS_ATTN_X3W=0/1 forces
     int wide = -1;
     { const char* e = getenv("GIMS_ATTN_X3W"); if (e) wide = atoi(e); }
-    // 512-query workgroups (one per CU, the whole register file, no spills) for long sequences that fill the chip, else the 32-query-per-wave
-    // kernel.  Measured with K staged by LDS-DMA in all of them (32-query / QP = 2 / QP = 4): 16 x 4096 keys 944 / 860 / 835 us, 32 x 2048
-    // 495 / 463 / 474, 40 x 1500 313 / 325 / 326, 64 x 1022 246 / 282 / 300 -- below ~2048 keys the wide form's prologue, epilogue and tail
-    // (2 workgroups per CU-slot instead of 8) cost more than its halved LDS traffic saves.
-    if (wide < 0) wide = (max_n_q >= 2048 && 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 4 * QB) >= 256) ? 4 : 0;
+    // 256-query workgroups (64 queries per wave in a pair that shares every K / V fragment; two workgroups per CU) when they fill the chip,
+    // else the 32-query-per-wave kernel.  Measured with K and V staged by LDS-DMA in all of them (32-query / QP = 2 / QP = 4):
+    // 16 x 4096 keys 912 / 730 / 867 us, 32 x 2048 460 / 398 / 504, 40 x 1500 298 / 274 / 337, 64 x 1022 206 / 197 / 236, 8 x 700 26 / 41 / 76.
+    if (wide < 0) wide = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB) >= 512 ? 2 : 0;
     if (wide) {
       static bool attr_w = false;
       if (!attr_w) {
-        GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3W_LDS_BYTES));
+        GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3W_LDS_BYTES));
         attr_w = true;
       }
       const int qp = wide == 2 ? 2 : 4, n_qtw = cdiv(max_n_q, qp * QB);
       if (qp == 4)
-        hipLaunchKernelGGL(attention_x3w_kernel<4>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, qkv, ld,
+        hipLaunchKernelGGL(attention_x3w_kernel<4>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
                            q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat);
       else
-        hipLaunchKernelGGL(attention_x3w_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, qkv, ld,
+        hipLaunchKernelGGL(attention_x3w_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
                            q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat);
       GIMS_LAUNCH_CHECK();
       return GIMS_OK;
