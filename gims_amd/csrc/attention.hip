@@ -32,6 +32,8 @@ constexpr int QW = 32;          // queries per wave
 constexpr int ATT_WAVES = 4;    // waves per workgroup
 constexpr int QB = QW * ATT_WAVES;
 constexpr int VT_LD = KB + 4;   // V^T pitch in bf16 elements (136 bytes)
+constexpr int VR_LD = 80;       // pitch of a ROW-MAJOR V tile [key][d] in bf16 elements (160 bytes): filled by LDS-DMA, read by ds_read_b64_tr_b16
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int k_off(int row, int chunk) {  // K tile: [64 keys][64 d], 16-byte chunks swizzled
   return row * DH + ((chunk ^ ((row >> 1) & 7)) << 3);
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
     int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
     unsigned long long* __restrict__ stat) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KB * DH];      // double-buffered: one barrier per key tile
-  __shared__ __attribute__((aligned(16))) uint16_t Vt[2][DH * VT_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Vr[2][KB * VR_LD];      // row-major V tiles (LDS-DMA in, transposing reads out)
   constexpr int QWV = QW * QP;            // queries per wave
   constexpr int QBK = QWV * ATT_WAVES;    // queries per workgroup
 
@@ -112,9 +114,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
   // staging: K tile 64 rows x 8 chunks = 512 chunks (2 per thread); V tile: key pair kp = t&31, d-octet t>>5
   // K goes global -> LDS by LDS-DMA: its staging registers, held across a whole tile, were being spilled to scratch (48 B per lane).  One DMA
   // instruction fills a contiguous KiB = 8 tile rows; the chunk swizzle of k_off is applied on the source side.  V^T still goes through registers.
-  uint4 rv[2];
   const int n_tiles = (pr.n_kv + KB - 1) / KB;
-  const int vkp = t & 31, voct = t >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
   auto dma_k = [&](int kt, int buf) __attribute__((always_inline)) {
     const int kbase = kt * KB;
@@ -126,35 +126,29 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
                                        (__attribute__((address_space(3))) void*)(Ks[buf] + j * 512), 16, 0, 0);
     }
   };
-  auto load_tile = [&](int kt) {
+  // V the same way: row-major tiles with a 160-byte pitch; byte B = 1024 j + 16 lane of the padded image is (row B / 160, chunk (B % 160) / 16),
+  // the two pad chunks of a row re-fetch chunk 0; ten instructions per tile (waves 0 and 1 issue three, waves 2 and 3 two)
+  auto dma_v = [&](int kt, int buf) __attribute__((always_inline)) {
     const int kbase = kt * KB;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-      rv[e] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * voct);
+    for (int j3 = 0; j3 < 3; ++j3) {
+      const int j = wave_u + 4 * j3;
+      if (j < 10) {
+        const int B = 1024 * j + 16 * (t & 63), row = B / (2 * VR_LD), pos = (B % (2 * VR_LD)) >> 4, ch = pos < 8 ? pos : 0;
+        int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * ch),
+                                         (__attribute__((address_space(3))) void*)(Vr[buf] + j * 512), 16, 0, 0);
+      }
     }
   };
-  auto store_tile = [&](int buf) {
-    const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
-    const uint32_t b[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {  // d = 8*voct + 2j, 2j+1 ; pack (key 2kp, key 2kp+1) per d: lanes -> consecutive dwords
-      const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
-      const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
-      *(uint32_t*)(Vt[buf] + (8 * voct + 2 * j) * VT_LD + 2 * vkp) = lo;
-      *(uint32_t*)(Vt[buf] + (8 * voct + 2 * j + 1) * VT_LD + 2 * vkp) = hi;
-    }
-  };
-
   dma_k(0, 0);
-  load_tile(0);
-  store_tile(0);
+  dma_v(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < n_tiles) { dma_k(kt + 1, (kt + 1) & 1); load_tile(kt + 1); }
+    if (kt + 1 < n_tiles) { dma_k(kt + 1, (kt + 1) & 1); dma_v(kt + 1, (kt + 1) & 1); }
 
     // ---- S^T = K Q^T : two 32-key blocks x QP query blocks, K = 64 (4 steps of 16); K fragments shared by the query blocks
     f32x16 sacc[QP][2];
@@ -236,16 +230,15 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         // lane's k-slots of step s: keys 16s + {0-3, 8-11} + 4*lh
-        const uint16_t* vp = Vt[buf] + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
-        const uint2 v0 = *(const uint2*)(vp);
-        const uint2 v1 = *(const uint2*)(vp + 8);
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+        const int voff = (4 * lh + ((lane & 15) >> 2)) * VR_LD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + 16 * s * VR_LD + 32 * i;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr[buf] + voff));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr[buf] + voff + 8 * VR_LD));
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
         for (int qi = 0; qi < QP; ++qi) o[qi][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][s], o[qi][i], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
-    if (kt + 1 < n_tiles) store_tile(buf ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of the next K tile has landed
     __syncthreads();
   }
@@ -294,7 +287,6 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 //   * row sums by v_pk_add_f32; V row-major in LDS, read transposed by ds_read_b64_tr_b16 (tr16_probe.hip);
 //   * the split-bf16 output leaves as whole 256-byte rows through a wave-private LDS transpose.
 constexpr int ATT8_WAVES = 8;
-typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <bool PROF, bool NOFMA>     // NOFMA: Q carries the softmax scale (c == 1): the optimistic pass is P = exp2(S), reference 0
@@ -611,7 +603,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
 // 32-channel block 32 hi then 32 lo values); P is split in registers.  Geometry of attention_bf16_kernel<1> (4 waves x
 // 32 queries, 64-key tiles, running maximum with deferred rescale); LDS is dynamic (67 KB: hi and lo planes of the
 // double-buffered K and V^T tiles).
-constexpr int X3W_VR = 80;                 // V row pitch in bf16 elements (160 bytes): row-major V tiles of the split-bf16 kernels
+constexpr int X3W_VR = VR_LD;              // row-major V tiles of the split-bf16 kernels
 constexpr int X3_LDS_BYTES = 2 * 2 * (KB * DH + KB * X3W_VR) * 2;      // 72 KB: hi and lo planes of the double-buffered K and V tiles
 
 __global__ __launch_bounds__(256) void attention_x3_kernel(
@@ -1062,7 +1054,7 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
   extern __shared__ __attribute__((aligned(16))) uint16_t sp_lds[];
   // [half][buffer]: K tiles, then V^T tiles
   auto Ks = [&](int hf, int buf) __attribute__((always_inline)) { return sp_lds + (hf * 2 + buf) * (KB * DH); };
-  auto Vt = [&](int hf, int buf) __attribute__((always_inline)) { return sp_lds + 2 * NS * (KB * DH) + (hf * 2 + buf) * (DH * VT_LD); };
+  auto Vr = [&](int hf, int buf) __attribute__((always_inline)) { return sp_lds + 2 * NS * (KB * DH) + (hf * 2 + buf) * (KB * VR_LD); };      // row-major V tiles
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int group = (slot / n_qt) * 8 + xcd;
@@ -1096,8 +1088,6 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
   const int n_mine = (n_tiles - half + NS - 1) / NS;      // tiles half, half + NS, ...
   const int n_iter = (n_tiles + NS - 1) / NS;             // every part passes the same number of barriers
   // K by LDS-DMA (see attention_bf16_kernel: its staging registers were spilled to scratch -- 48 / 128 B per lane here); V^T through registers
-  uint4 rv[2];
-  const int vkp = t & 31, voct = t >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto dma_k = [&](int it, int buf) __attribute__((always_inline)) {
     const int kbase = (NS * it + half) * KB;
@@ -1109,33 +1099,26 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
                                        (__attribute__((address_space(3))) void*)(Ks(half, buf) + j * 512), 16, 0, 0);
     }
   };
-  auto load_tile = [&](int it) __attribute__((always_inline)) {
+  auto dma_v = [&](int it, int buf) __attribute__((always_inline)) {      // row-major V tile of this part, 160-byte pitch (see attention_bf16_kernel)
     const int kbase = (NS * it + half) * KB;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      int kr = kbase + 2 * vkp + e; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-      rv[e] = *(const uint4*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * voct);
+    for (int j3 = 0; j3 < 3; ++j3) {
+      const int j = wave_u + 4 * j3;
+      if (j < 10) {
+        const int B = 1024 * j + 16 * lane, row = B / (2 * VR_LD), pos = (B % (2 * VR_LD)) >> 4, ch = pos < 8 ? pos : 0;
+        int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qkv + (int64_t)(pr.kv_off + kr) * ld + v_col + head * DH + 8 * ch),
+                                         (__attribute__((address_space(3))) void*)(Vr(half, buf) + j * 512), 16, 0, 0);
+      }
     }
   };
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
-    const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
-    const uint32_t b[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
-      const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
-      *(uint32_t*)(Vt(half, buf) + (8 * voct + 2 * j) * VT_LD + 2 * vkp) = lo;
-      *(uint32_t*)(Vt(half, buf) + (8 * voct + 2 * j + 1) * VT_LD + 2 * vkp) = hi;
-    }
-  };
-
-  if (n_mine > 0) { dma_k(0, 0); load_tile(0); store_tile(0); }
+  if (n_mine > 0) { dma_k(0, 0); dma_v(0, 0); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int it = 0; it < n_iter; ++it) {
     const int buf = it & 1;
     const bool live = it < n_mine;
-    if (it + 1 < n_mine) { dma_k(it + 1, buf ^ 1); load_tile(it + 1); }
+    if (it + 1 < n_mine) { dma_k(it + 1, buf ^ 1); dma_v(it + 1, buf ^ 1); }
     if (live) {
       f32x16 sacc[2];
 #pragma unroll
@@ -1202,14 +1185,13 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const uint16_t* vp = Vt(half, buf) + (i * 32 + li) * VT_LD + 16 * s + 4 * lh;
-          const uint2 v0 = *(const uint2*)(vp);
-          const uint2 v1 = *(const uint2*)(vp + 8);
-          const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+          const int voff = (4 * lh + ((lane & 15) >> 2)) * VR_LD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + 16 * s * VR_LD + 32 * i;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(half, buf) + voff));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(half, buf) + voff + 8 * VR_LD));
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
           o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o[i], 0, 0, 0);
         }
     }
-    if (it + 1 < n_mine) store_tile(buf ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of the next K tile has landed
     __syncthreads();
   }
@@ -1348,7 +1330,7 @@ __global__ __launch_bounds__(64 * PS_WAVES) void attention_peak_sample_kernel(
   }
 }
 
-template <int NS> constexpr int SPLIT_LDS_BYTES = NS * 2 * (KB * DH + DH * VT_LD) * 2;     // >= the (NS - 1) x 35 KB of the merge exchange
+template <int NS> constexpr int SPLIT_LDS_BYTES = NS * 2 * (KB * DH + KB * VR_LD) * 2;     // >= the (NS - 1) x 35 KB of the merge exchange
 static_assert(SPLIT_LDS_BYTES<2> >= 1 * 4 * 35 * 64 * 4 && SPLIT_LDS_BYTES<4> >= 3 * 4 * 35 * 64 * 4, "merge exchange must fit the staging buffers");
 
 }  // namespace gims
