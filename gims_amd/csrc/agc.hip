@@ -462,7 +462,6 @@ __global__ __launch_bounds__(1024) void agc_cc_kernel(const AgcWs* __restrict__ 
   extern __shared__ int32_t sm[];
   int32_t* parent = sm;
   int32_t* count = sm + w.n;
-  __shared__ int changed;
   __shared__ int wsum[16];
   __shared__ int carry[2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -479,27 +478,24 @@ __global__ __launch_bounds__(1024) void agc_cc_kernel(const AgcWs* __restrict__ 
       x = p;
     }
   };
-  for (int iter = 0; iter < 100000; ++iter) {
-    if (t == 0) changed = 0;
-    __syncthreads();
-    for (int u = t; u < n; u += 1024) {
-      const int beg = w.ptr0[u], end = w.ptr0[u + 1] < w.cap ? w.ptr0[u + 1] : w.cap;
-      for (int e = beg; e < end; ++e) {
-        const int v = w.idx0[e];
-        if (v < u) continue;   // each undirected edge once
-        int ru = find(u), rv = find(v);
-        if (ru != rv) {
-          const int hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
-          atomicMin(&parent[hi], lo);
-          changed = 1;
-        }
+  // ONE pass over the edges: a lock-free union (hook the larger root under the smaller one by compare-and-swap, retry when the root was taken
+  // meanwhile).  Roots only ever move to smaller indices, so a component's final root is its smallest node whatever the interleaving -- the
+  // labels are the same as the min-label propagation this replaces, which rescanned all edges until a pass changed nothing (three scans of
+  // ~50 us each at 4096 nodes: 160 -> 65 us).
+  for (int u = t; u < n; u += 1024) {
+    const int beg = w.ptr0[u], end = w.ptr0[u + 1] < w.cap ? w.ptr0[u + 1] : w.cap;
+    for (int e = beg; e < end; ++e) {
+      const int v = w.idx0[e];
+      if (v < u) continue;   // each undirected edge once
+      for (;;) {
+        const int ru = find(u), rv = find(v);
+        if (ru == rv) break;
+        const int hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
+        if (atomicCAS(&parent[hi], hi, lo) == hi) break;     // hi was still a root: hooked
       }
     }
-    __syncthreads();
-    const int c = changed;
-    __syncthreads();
-    if (!c) break;
   }
+  __syncthreads();
   for (int u = t; u < n; u += 1024) {
     const int x = find(u);
     w.label[u] = x;

@@ -31,7 +31,6 @@ constexpr int KB = 64;          // keys per tile
 constexpr int QW = 32;          // queries per wave
 constexpr int ATT_WAVES = 4;    // waves per workgroup
 constexpr int QB = QW * ATT_WAVES;
-constexpr int VT_LD = KB + 4;   // V^T pitch in bf16 elements (136 bytes)
 constexpr int VR_LD = 80;       // pitch of a ROW-MAJOR V tile [key][d] in bf16 elements (160 bytes): filled by LDS-DMA, read by ds_read_b64_tr_b16
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -1064,7 +1063,7 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
   if (q0 >= pr.n_q) return;
   const int head = group % n_heads;
   const int tt = threadIdx.x, lane = tt & 63;
-  const int half = __builtin_amdgcn_readfirstlane(tt >> 8), wave = (tt >> 6) & 3, t = tt & 255;
+  const int half = __builtin_amdgcn_readfirstlane(tt >> 8), wave = (tt >> 6) & 3;
   const int li = lane & 31, lh = lane >> 5;
 
   bf16x8 qf[4];

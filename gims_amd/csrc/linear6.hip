@@ -17,7 +17,7 @@
 
 namespace gims {
 
-constexpr int X6_TM = 256, X6_TN = 128, X6_WM = 4, X6_WN = 2, X6_BK = 32;
+constexpr int X6_TM = 256, X6_TN = 128, X6_WN = 2, X6_BK = 32;          // 8 waves as 4 x X6_WN, 64 x 64 each
 constexpr int X6_ROW = 96;                                   // bf16 elements per stage row (3 planes x 32 channels)
 constexpr int X6_STAGE = (X6_TM + X6_TN) * X6_ROW;           // elements per stage (73 728 bytes)
 constexpr int X6_PIECES = (X6_TM + X6_TN) * 12 / 64 / 8;     // 16-byte x 64-lane DMA instructions per wave per stage (9)
