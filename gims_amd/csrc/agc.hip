@@ -553,29 +553,42 @@ __global__ __launch_bounds__(256) void agc_members_kernel(const AgcWs* __restric
   const float* __restrict__ kpts = w.kpts;
   const int32_t* __restrict__ coff = w.coff2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + wave;
   const int C = w.counters[1];
-  if (c >= C) return;
-  int off = coff[c];
-  double sx = 0.0, sy = 0.0;
-  int cnt = 0;
-  for (int base = 0; base < w.n; base += 64) {
-    const int u = base + lane;
-    bool mem = false;
-    if (u < w.n && w.alive[u]) mem = w.crank[w.label[u]] == c;
-    const uint64_t m = __ballot(mem);
-    if (mem) {
-      w.members[off + __popcll(m & ((1ull << lane) - 1))] = u;
-      sx += (double)kpts[2 * u];
-      sy += (double)kpts[2 * u + 1];
+  // a small grid walks the components (there are usually one to a handful: a wave per POSSIBLE component was 16 k workgroups that only exited),
+  // and the membership test of four 64-node chunks is in flight at once (alive -> label -> rank is three dependent loads: 64 chunks of them one
+  // after the other were the kernel's 76 us).  Members stay in ascending order and every lane adds its own members in the same order as before.
+  for (int c = blockIdx.x * 4 + wave; c < C; c += gridDim.x * 4) {
+    int off = coff[c];
+    double sx = 0.0, sy = 0.0;
+    int cnt = 0;
+    for (int base = 0; base < w.n; base += 256) {
+      bool mem[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int u = base + 64 * q + lane;
+        int lab = 0;
+        const bool al = u < w.n && w.alive[u] != 0;
+        if (al) lab = w.label[u];
+        mem[q] = al && w.crank[lab] == c;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int u = base + 64 * q + lane;
+        const uint64_t m = __ballot(mem[q]);
+        if (mem[q]) {
+          w.members[off + __popcll(m & ((1ull << lane) - 1))] = u;
+          sx += (double)kpts[2 * u];
+          sy += (double)kpts[2 * u + 1];
+        }
+        const int pc = __popcll(m);
+        off += pc;
+        cnt += pc;
+      }
     }
-    const int pc = __popcll(m);
-    off += pc;
-    cnt += pc;
+    sx = wave_sum_f64(sx);
+    sy = wave_sum_f64(sy);
+    if (lane == 0) { w.cent[2 * c] = sx / (double)cnt; w.cent[2 * c + 1] = sy / (double)cnt; }
   }
-  sx = wave_sum_f64(sx);
-  sy = wave_sum_f64(sy);
-  if (lane == 0) { w.cent[2 * c] = sx / (double)cnt; w.cent[2 * c + 1] = sy / (double)cnt; }
 }
 
 __global__ __launch_bounds__(256) void agc_nnc_kernel(const AgcWs* __restrict__ ws) {
@@ -609,14 +622,15 @@ __global__ __launch_bounds__(256) void agc_link_kernel(const AgcWs* __restrict__
   const int32_t* __restrict__ coff = w.coff2;
   __shared__ double sd[256];
   __shared__ int sv[256], su[256];
-  const int i = blockIdx.x, t = threadIdx.x;
+  const int t = threadIdx.x;
   const int C = w.counters[1];
-  if (i >= C || C <= 1) return;
+  if (C <= 1) return;
+  for (int i = blockIdx.x; i < C; i += gridDim.x) {      // (a workgroup per POSSIBLE component was 65 k workgroups that only exited: 70 us)
   const int j = w.nnc[i];
   // agc.py:550-552: skip when the reverse pair was linked earlier (j < i and nn(j) == i)
   if (j < i && w.nnc[j] == i) {
     if (t == 0) { w.link[2 * i] = -1; w.link[2 * i + 1] = -1; }
-    return;
+    continue;
   }
   const int ai = coff[i], na = coff[i + 1] - ai;
   const int aj = coff[j], nb = coff[j + 1] - aj;
@@ -640,6 +654,8 @@ __global__ __launch_bounds__(256) void agc_link_kernel(const AgcWs* __restrict__
     __syncthreads();
   }
   if (t == 0) { w.link[2 * i] = su[0]; w.link[2 * i + 1] = sv[0]; }
+  __syncthreads();
+  }
 }
 
 __global__ __launch_bounds__(256) void agc_link_apply_kernel(const AgcWs* __restrict__ ws) {
@@ -820,9 +836,9 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   hipLaunchKernelGGL(agc_cc_kernel, g1, dim3(1024), (size_t)maxn * 8, s, dws, min_size);
   // K6: component sizes -> offsets; members, centroids, nearest component, links
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 1);
-  hipLaunchKernelGGL(agc_members_kernel, gw, dim3(256), 0, s, dws);
+  hipLaunchKernelGGL(agc_members_kernel, dim3(cdiv(maxn, 4) < 64 ? cdiv(maxn, 4) : 64, B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_nnc_kernel, gw, dim3(256), 0, s, dws);
-  hipLaunchKernelGGL(agc_link_kernel, dim3(maxn, B), dim3(256), 0, s, dws);
+  hipLaunchKernelGGL(agc_link_kernel, dim3(maxn < 256 ? maxn : 256, B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_link_apply_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
   // K7: final CSR over the kept nodes, relabelled in sorted order
   hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 0);
