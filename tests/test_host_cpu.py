@@ -218,7 +218,8 @@ def test_hot_kernels_use_no_scratch():
         import pytest
         pytest.skip("no hipcc")
     must_be_clean = {"attention.hip": ["attention8_bf16_kernel", "attention_bf16_kernel", "attention_x3_kernel", "attention_x3w_kernelILi4", "attention_split_kernelILi2"],
-                     "linear6.hip": ["linear_x6_kernel"]}
+                     "linear6.hip": ["linear_x6_kernel"], "linear.hip": ["linear_x3p_kernel"],
+                     "carhynet.hip": ["ch_conv_block_kernel", "ch_sandglass_kernelILi32"]}
     with tempfile.TemporaryDirectory() as tmp:
         for src, names in must_be_clean.items():
             cmd = [hipcc, *B.FLAGS, *B.EXTRA.get(src, []), "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(B.CSRC, src), "-o", os.path.join(tmp, "x.o")]
