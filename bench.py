@@ -251,7 +251,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     # iteration); SURVEY's byte figure is reported as `hbm_equivalent` for orientation only.
     ot_plan = int(getattr(model, "sinkhorn_plan_last", 0))
     if ot_plan > 0:
-        ot_name = "ot_res2_kernel" if os.environ.get("GIMS_OT_RES2", "1") != "0" else "ot_resident_kernel"
+        ot_name = "ot_res2_kernel"
         cand[ot_name] = ("valu", ot_fma_flops / ot_plan, per_step("sinkhorn") / ot_plan, PEAK_F32_VALU_TFLOPS, "TFLOP/s", ot_plan)
     else:
         ot_name = "ot_iter_kernel"

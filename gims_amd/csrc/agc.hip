@@ -760,12 +760,8 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   char* base = (char*)work + agc_batch_header(n_images);
   int maxn = 0, maxnw = 0;
   bool all_x6 = true;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)agc_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AGC_MAX_N * 8));
-    GIMS_HIP(hipFuncSetAttribute((const void*)agc_iso_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AGC_MAX_N * 4 + (AGC_MAX_N / 32 + 2) * 4));
-    attr_set = true;
-  }
+  GIMS_LDS_ATTR((const void*)agc_cc_kernel, AGC_MAX_N * 8);
+  GIMS_LDS_ATTR((const void*)agc_iso_seq_kernel, AGC_MAX_N * 4 + (AGC_MAX_N / 32 + 2) * 4);
   std::vector<AgcWs> hws(n_images);
   std::vector<gims_linear_args> hla(n_images);
   for (int i = 0; i < n_images; ++i) {

@@ -1364,11 +1364,7 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
   if (flags & GIMS_ATTN_X3) {                  // split-bf16 operands from the SPL32 Q/K/V buffer, three MFMAs per product
     GIMS_CHECK_ARG((q_col % 32) == 0 && (k_col % 32) == 0 && (v_col % 32) == 0 && (ld % 64) == 0,
                    "gims_attention: GIMS_ATTN_X3 takes logical column offsets that are multiples of 32 and an SPL32 pitch (multiple of 64)");
-    static bool attr_set = false;
-    if (!attr_set) {
-      GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-      attr_set = true;
-    }
+    GIMS_LDS_ATTR((const void*)attention_x3_kernel, X3_LDS_BYTES);
     // wide form (128 queries per wave, one workgroup per CU) when its 512-query workgroups still fill the chip; GIMS_ATTN_X3W=0/1 forces
     int wide = -1;
     { const char* e = getenv("GIMS_ATTN_X3W"); if (e) wide = atoi(e); }
@@ -1377,12 +1373,8 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
     // 16 x 4096 keys 912 / 730 / 867 us, 32 x 2048 460 / 398 / 504, 40 x 1500 298 / 274 / 337, 64 x 1022 206 / 197 / 236, 8 x 700 26 / 41 / 76.
     if (wide < 0) wide = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB) >= 512 ? 2 : 0;
     if (wide) {
-      static bool attr_w = false;
-      if (!attr_w) {
-        GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3W_LDS_BYTES));
-        GIMS_HIP(hipFuncSetAttribute((const void*)attention_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3W_LDS_BYTES));
-        attr_w = true;
-      }
+      GIMS_LDS_ATTR((const void*)attention_x3w_kernel<4>, X3W_LDS_BYTES);
+      GIMS_LDS_ATTR((const void*)attention_x3w_kernel<2>, X3W_LDS_BYTES);
       const int qp = wide == 2 ? 2 : 4, n_qtw = cdiv(max_n_q, qp * QB);
       if (qp == 4)
         hipLaunchKernelGGL(attention_x3w_kernel<4>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
@@ -1408,12 +1400,8 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
   // a small launch (one pair through forward()): split the keys of every query block over two wave groups (GIMS_ATTN_QP=3: always)
   const bool split = force == 3 || (force == 0 && !eight && !two && 8 * cdiv(n_groups, 8) * cdiv(max_n_q, QB) <= 512 && max_n_q >= 512);
   if (split) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      GIMS_HIP(hipFuncSetAttribute((const void*)attention_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES<2>));
-      GIMS_HIP(hipFuncSetAttribute((const void*)attention_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES<4>));
-      attr_set = true;
-    }
+    GIMS_LDS_ATTR((const void*)attention_split_kernel<2>, SPLIT_LDS_BYTES<2>);
+    GIMS_LDS_ATTR((const void*)attention_split_kernel<4>, SPLIT_LDS_BYTES<4>);
     const int n_qt = cdiv(max_n_q, QB);
     const int wgs = 8 * cdiv(n_groups, 8) * n_qt;
     int ns_env = 0;                                  // read per call: the tests switch between the two variants
@@ -1432,8 +1420,8 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
     static int prof = -1;
     if (prof < 0) { const char* e = getenv("GIMS_ATTN_PROF"); prof = e ? atoi(e) : 0; }
     if (prof) {                                 // diagnostics only: synchronous, prints the phase anatomy of workgroup 0
-      static unsigned long long* dprof = nullptr;
-      if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 24 * sizeof(unsigned long long)));
+      unsigned long long* dprof = (unsigned long long*)device_once("attention8_prof", 24 * sizeof(unsigned long long), nullptr);
+      GIMS_CHECK_ARG(dprof, "gims_attention: no profile buffer");
       if (prescaled)
         hipLaunchKernelGGL((attention8_bf16_kernel<true, true>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
                            q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);

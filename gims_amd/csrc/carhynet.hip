@@ -1133,13 +1133,9 @@ extern "C" int gims_ch_frn_block(const float* x, int64_t patches, int32_t hw, in
   }
   constexpr int FRN_NT = 1024;
   const size_t lds = ((size_t)hw * hw * c + (FRN_NT / c) * (size_t)c + c + 2 * (size_t)hw * c + 16 * (size_t)hw) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_frn_block_kernel<32, 32, FRN_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_frn_block_kernel<64, 16, FRN_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_frn_block_kernel<128, 8, FRN_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  GIMS_LDS_ATTR((const void*)ch_frn_block_kernel<32, 32, FRN_NT>, 160 * 1024);
+  GIMS_LDS_ATTR((const void*)ch_frn_block_kernel<64, 16, FRN_NT>, 160 * 1024);
+  GIMS_LDS_ATTR((const void*)ch_frn_block_kernel<128, 8, FRN_NT>, 160 * 1024);
   const dim3 grid((unsigned)patches);
   hipStream_t st = (hipStream_t)stream;
   if (c == 32) hipLaunchKernelGGL((ch_frn_block_kernel<32, 32, FRN_NT>), grid, dim3(FRN_NT), lds, st, x, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split);
@@ -1155,16 +1151,12 @@ static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, co
                              gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st, gims::ChFirst first = {nullptr, nullptr, nullptr, 0.f, nullptr, 0, 0}) {
   using namespace gims;
   using Geo = ConvGeom<CIN, COUT, HIN, STRIDE, PP>;
-  static bool attr = false;
-  if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 Geo::LDS_BYTES + Geo::GATE_BYTES));
-    attr = true;
-  }
+  GIMS_LDS_ATTR((const void*)ch_conv_block_kernel<CIN, COUT, HIN, STRIDE, FIRST, PP>, Geo::LDS_BYTES + Geo::GATE_BYTES);
   static const bool prof_on = getenv("GIMS_CH_PROF") != nullptr;      // diagnostics: cycle stamps of one workgroup per launch (synchronous)
-  static unsigned long long* dprof = nullptr;
+  unsigned long long* dprof = nullptr;
   if (prof_on) {
-    if (!dprof) GIMS_HIP(hipMalloc(&dprof, 8 * sizeof(unsigned long long)));
+    dprof = (unsigned long long*)device_once("ch_conv_prof", 8 * sizeof(unsigned long long), nullptr);
+    GIMS_CHECK_ARG(dprof, "gims_ch_conv_block: no profile buffer");
     first.prof = dprof;
   }
   static const int stagger = getenv("GIMS_CH_STAGGER") ? atoi(getenv("GIMS_CH_STAGGER")) : 8000;
@@ -1237,17 +1229,14 @@ extern "C" int gims_ch_sandglass(const float* x, int64_t patches, int32_t hw, in
   for (int i = 0; i < 14; ++i) { GIMS_CHECK_ARG(w[i] != nullptr, "gims_ch_sandglass: weight pointer %d is null", i); dst[i] = w[i]; }
   constexpr int SG_NT = 1024;
   const size_t lds = ((size_t)hw * hw * c + 2 * (size_t)hw * c + 16 * (size_t)hw + (size_t)c * (9 + 1 + 9 + 1 + 16 + 20 + 1 + 8 + 8 + 8 + 1 + 1) + 16 * 4 + 16 + 8) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<32, 32, SG_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    GIMS_HIP(hipFuncSetAttribute((const void*)ch_sandglass_kernel<64, 16, SG_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  GIMS_LDS_ATTR((const void*)ch_sandglass_kernel<32, 32, SG_NT>, 160 * 1024);
+  GIMS_LDS_ATTR((const void*)ch_sandglass_kernel<64, 16, SG_NT>, 160 * 1024);
   static const bool prof_on = getenv("GIMS_CH_PROF") != nullptr;
-  static unsigned long long* dprof = nullptr;
+  unsigned long long* dprof = nullptr;
   W.prof = nullptr;
   if (prof_on) {
-    if (!dprof) GIMS_HIP(hipMalloc(&dprof, 8 * sizeof(unsigned long long)));
+    dprof = (unsigned long long*)device_once("ch_sandglass_prof", 8 * sizeof(unsigned long long), nullptr);
+    GIMS_CHECK_ARG(dprof, "gims_ch_sandglass: no profile buffer");
     W.prof = dprof;
   }
   static const int stagger = getenv("GIMS_CH_STAGGER") ? atoi(getenv("GIMS_CH_STAGGER")) : 8000;

@@ -36,6 +36,12 @@ void set_error(const char* fmt, ...);
     }                                                                                      \
   } while (0)
 
+#define GIMS_LDS_ATTR(...) /* (function, bytes); variadic because template argument lists carry commas */ \
+  do {                                                                                                     \
+    const int rc_ = ::gims::lds_attr(__VA_ARGS__);                                                         \
+    if (rc_ != GIMS_OK) return rc_;                                                                        \
+  } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -85,11 +91,26 @@ __device__ __forceinline__ float key_f32(uint32_t k) {
   return __uint_as_float(u);
 }
 
+// Sinkhorn status word (0 ok, 1 numeric guard, 2 a bounded wait ran out): raised monotonically, device scope -- workgroups on
+// different XCDs may report different codes for one problem and the larger one must survive whatever the write-back order
+// (positive floats order like their bit patterns)
+__device__ __forceinline__ void ot_raise_status(float* status, float code) {
+  __hip_atomic_fetch_max((int*)status, __float_as_int(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Host descriptor table -> device memory through KERNEL ARGUMENTS (chunks of <= 3968 bytes per launch): asynchronous on
 // the stream, no staging buffer whose lifetime would need a synchronisation, no pageable-memory pinning by the runtime.
 int upload_table(const void* host, size_t bytes, void* dev, hipStream_t stream);
+// Process-wide state is keyed by DEVICE and created under a lock (no per-process function statics that would bind to whichever
+// device was current at the first call).  lds_attr: hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, device).
+// device_once: one device buffer per (key, device), optionally filled from `init` (synchronous copy, first call only); nullptr on failure.
+// pinned_once: one pinned host buffer (zero-filled) per (key, device).
+int lds_attr(const void* fn, int bytes);
+void* device_once(const char* key, size_t bytes, const void* init);
+void* pinned_once(const char* key, size_t bytes);
+int current_device();
 // linear6.hip: exact-class bf16x6 GEMM on SPL3 operands (batched), and its operand split
 int linear_x6_batch_launch(const gims_linear_args* dev_args, int count, int max_m, int max_n, hipStream_t s);
 int split_spl3_launch(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int k, hipStream_t s);

@@ -644,13 +644,9 @@ static int linear_validate(const gims_linear_args* a) {
 
 static int x3_attr() {
   using namespace gims;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const int lds = 4 * X3_PLANE * (int)sizeof(uint16_t);
-    GIMS_HIP(hipFuncSetAttribute((const void*)linear_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    GIMS_HIP(hipFuncSetAttribute((const void*)linear_bf16x3_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
+  const int lds = 4 * X3_PLANE * (int)sizeof(uint16_t);
+  GIMS_LDS_ATTR((const void*)linear_bf16x3_kernel, lds);
+  GIMS_LDS_ATTR((const void*)linear_bf16x3_batch_kernel, lds);
   return GIMS_OK;
 }
 
@@ -694,28 +690,20 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
     const bool big = force == 256 || (force != 128 && big_blocks >= 192 && (a->n % 256 == 0 || a->n > 512));
     if (force == 1288) {      // experiment: 128 x 128 tiles on EIGHT waves (two per SIMD) for small, latency-bound launches
       using T8 = X3P<128, 128, 4, 2, 2>;
-      static bool attr8 = false;
-      if (!attr8) {
-        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 128, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T8::LDS_BYTES));
-        attr8 = true;
-      }
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 128, 4, 2, 2>, (int)T8::LDS_BYTES);
       constexpr size_t lds = T8::LDS_BYTES;
       hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 4, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(512), lds, s, *a);
     } else if (force == 1283 || force == 1284 || force == 2563) {      // experimental ring geometries
-      static bool attr2 = false;
       using T3 = X3P<256, 128, 4, 2, 3>;
       using T4 = X3P<128, 128, 2, 2, 4>;
       using T5 = X3P<128, 128, 2, 2, 3>;
-      if (!attr2) {
-        const void* f3 = (const void*)linear_x3p_kernel<256, 128, 4, 2, 3>;
-        const void* f4 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 4>;
-        const void* f5 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 3>;
-        constexpr int l3 = T3::LDS_BYTES, l4 = T4::LDS_BYTES, l5 = T5::LDS_BYTES;
-        GIMS_HIP(hipFuncSetAttribute(f3, hipFuncAttributeMaxDynamicSharedMemorySize, l3));
-        GIMS_HIP(hipFuncSetAttribute(f4, hipFuncAttributeMaxDynamicSharedMemorySize, l4));
-        GIMS_HIP(hipFuncSetAttribute(f5, hipFuncAttributeMaxDynamicSharedMemorySize, l5));
-        attr2 = true;
-      }
+      const void* f3 = (const void*)linear_x3p_kernel<256, 128, 4, 2, 3>;
+      const void* f4 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 4>;
+      const void* f5 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 3>;
+      constexpr int l3 = T3::LDS_BYTES, l4 = T4::LDS_BYTES, l5 = T5::LDS_BYTES;
+      GIMS_LDS_ATTR(f3, l3);
+      GIMS_LDS_ATTR(f4, l4);
+      GIMS_LDS_ATTR(f5, l5);
       if (force == 2563) {
         constexpr size_t lds = T3::LDS_BYTES;
         hipLaunchKernelGGL((linear_x3p_kernel<256, 128, 4, 2, 3>), dim3(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 128)), dim3(512), lds, s, *a);
@@ -731,12 +719,8 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       // tiles with 64 accumulator registers per wave let TWO workgroups share a CU, one's epilogue under the other's loads
       using TQ2 = X3P<256, 128, 4, 2, 2, true>;
       using TQ3 = X3P<256, 128, 4, 2, 3, true>;
-      static bool attr5 = false;
-      if (!attr5) {
-        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<256, 128, 4, 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TQ2::LDS_BYTES));
-        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<256, 128, 4, 2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TQ3::LDS_BYTES));
-        attr5 = true;
-      }
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<256, 128, 4, 2, 2, 1>, (int)TQ2::LDS_BYTES);
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<256, 128, 4, 2, 3, 1>, (int)TQ3::LDS_BYTES);
       const dim3 g(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 128));
       if (qkv_tile == 2) { constexpr size_t lds = TQ2::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<256, 128, 4, 2, 2, 1>), g, dim3(512), lds, s, *a); }
       else { constexpr size_t lds = TQ3::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<256, 128, 4, 2, 3, 1>), g, dim3(512), lds, s, *a); }
@@ -750,13 +734,9 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
     } else if (a->flags & GIMS_LINEAR_CONV3) {
       using T32 = X3P<128, 32, 4, 1, 2>;
       using T64 = X3P<128, 64, 2, 2, 2>;
-      static bool attr4 = false;
-      if (!attr4) {
-        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 32, 4, 1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T32::LDS_BYTES));
-        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 64, 2, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T64::LDS_BYTES));
-        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 128, 2, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TS::LDS_BYTES));
-        attr4 = true;
-      }
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 32, 4, 1, 2, 4>, (int)T32::LDS_BYTES);
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 64, 2, 2, 2, 4>, (int)T64::LDS_BYTES);
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 128, 2, 2, 2, 4>, (int)TS::LDS_BYTES);
       const int mt = 8 * cdiv(cdiv(a->m, 128), 8);
       if (a->n <= 32) { constexpr size_t lds = T32::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<128, 32, 4, 1, 2, 4>), dim3(mt * cdiv(a->n, 32)), dim3(256), lds, s, *a); }
       else if (a->n <= 64) { constexpr size_t lds = T64::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<128, 64, 2, 2, 2, 4>), dim3(mt * cdiv(a->n, 64)), dim3(256), lds, s, *a); }
@@ -766,12 +746,8 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       // tiles instead of wasting three quarters / half of a 128-wide one
       using T32 = X3P<128, 32, 4, 1, 2>;
       using T64 = X3P<128, 64, 2, 2, 2>;
-      static bool attr3 = false;
-      if (!attr3) {
-        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 32, 4, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T32::LDS_BYTES));
-        GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 64, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T64::LDS_BYTES));
-        attr3 = true;
-      }
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 32, 4, 1, 2>, (int)T32::LDS_BYTES);
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 64, 2, 2, 2>, (int)T64::LDS_BYTES);
       if (a->n <= 32) {
         constexpr size_t lds = T32::LDS_BYTES;
         hipLaunchKernelGGL((linear_x3p_kernel<128, 32, 4, 1, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 32)), dim3(256), lds, s, *a);
@@ -791,11 +767,7 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
         // small launches are latency-bound (one tile per CU, ~1 us per K step at one wave per SIMD): the same 128 x 128 tile on
         // EIGHT waves (two per SIMD, 64 x 32 ... per wave) hides the LDS and MFMA-chain latencies: 23 -> 18 us at 8192 rows,
         // 21 -> 15 us at 2048 rows (tools/gemm_probe.py); same K order per output element: bit-identical results
-        static bool attr8 = false;
-        if (!attr8) {
-          GIMS_HIP(hipFuncSetAttribute((const void*)linear_x3p_kernel<128, 128, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3P<128, 128, 4, 2, 2>::LDS_BYTES));
-          attr8 = true;
-        }
+        GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 128, 4, 2, 2>, (int)X3P<128, 128, 4, 2, 2>::LDS_BYTES);
         constexpr size_t lds8 = X3P<128, 128, 4, 2, 2>::LDS_BYTES;
         hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 4, 2, 2>), g, dim3(512), lds8, s, *a);
       }

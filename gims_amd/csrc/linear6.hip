@@ -218,11 +218,7 @@ __global__ void split_spl3_kernel(const float* __restrict__ src, int64_t lds, ui
 }
 
 int linear_x6_batch_launch(const gims_linear_args* dev_args, int count, int max_m, int max_n, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)linear_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES + X6_TABLE_BYTES));
-    attr = true;
-  }
+  GIMS_LDS_ATTR((const void*)linear_x6_kernel, X6_LDS_BYTES + X6_TABLE_BYTES);
   GIMS_CHECK_ARG(count >= 1 && count <= X6_MAX_PROBLEMS, "gims_linear_batch(bf16x6): at most %d problems per launch", X6_MAX_PROBLEMS);
   const int64_t bound = (int64_t)cdiv(max_n, X6_TN) * cdiv(max_m, X6_TM) * count;      // workgroups beyond the tile list exit at once
   hipLaunchKernelGGL(linear_x6_kernel, dim3((int)(bound < 256 ? bound : 256)), dim3(512), X6_LDS_BYTES + X6_TABLE_BYTES, s, dev_args, count);

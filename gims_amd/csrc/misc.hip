@@ -5,6 +5,11 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+
 namespace gims {
 
 static thread_local char g_err[512] = "";
@@ -13,6 +18,51 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return dev;
+}
+
+static std::mutex g_once_mu;
+
+int lds_attr(const void* fn, int bytes) {
+  static std::map<std::pair<const void*, int>, int> done;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_once_mu);
+  int& have = done[std::make_pair(fn, dev)];
+  if (have >= bytes) return GIMS_OK;
+  GIMS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  have = bytes;
+  return GIMS_OK;
+}
+
+void* device_once(const char* key, size_t bytes, const void* init) {
+  static std::map<std::pair<std::string, int>, void*> bufs;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_once_mu);
+  void*& p = bufs[std::make_pair(std::string(key), dev)];
+  if (p) return p;
+  void* d = nullptr;
+  if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+  if ((init ? hipMemcpy(d, init, bytes, hipMemcpyHostToDevice) : hipMemset(d, 0, bytes)) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  p = d;
+  return p;
+}
+
+void* pinned_once(const char* key, size_t bytes) {
+  static std::map<std::pair<std::string, int>, void*> bufs;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_once_mu);
+  void*& p = bufs[std::make_pair(std::string(key), dev)];
+  if (p) return p;
+  void* h = nullptr;
+  if (hipHostMalloc(&h, bytes) != hipSuccess) return nullptr;
+  memset(h, 0, bytes);
+  p = h;
+  return p;
 }
 
 struct Blob4K { uint4 v[248]; };   // 3968 bytes: below the 4 KiB kernel-argument limit

@@ -240,10 +240,8 @@ static int n_octaves(int h2, int w2) {             // library.py:248-250 on the 
   return (int)nearbyint(v) + 1;
 }
 
-static const int16_t* cubic_table(hipStream_t s) {
+static std::vector<int16_t> cubic_table_host() {
 #pragma clang fp contract(off)
-  static int16_t* dtab = nullptr;
-  if (dtab) return dtab;
   std::vector<float> t1(32 * 4);
   for (int i = 0; i < 32; ++i) {
     const float x = (float)i * (1.0f / 32), A = -0.75f;
@@ -277,10 +275,12 @@ static const int16_t* cubic_table(hipStream_t s) {
         if (diff < 0) w[Mk] = (int16_t)(w[Mk] - diff); else w[mk] = (int16_t)(w[mk] - diff);
       }
     }
-  if (hipMalloc((void**)&dtab, tab.size() * sizeof(int16_t)) != hipSuccess) return nullptr;
-  if (hipMemcpy(dtab, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dtab); dtab = nullptr; }
-  (void)s;
-  return dtab;
+  return tab;
+}
+// one device copy per device, created under a lock (the table is a constant of the algorithm, 32 KB; the host copy is built once per process)
+static const int16_t* cubic_table() {
+  static const std::vector<int16_t> tab = cubic_table_host();
+  return (const int16_t*)device_once("patch_cubic_table", tab.size() * sizeof(int16_t), tab.data());
 }
 
 static int pyramid_levels(int h, int w, int c, std::vector<gims_pyr_level>& lv, size_t& bytes) {
@@ -364,7 +364,7 @@ extern "C" int gims_patch_extract(const uint8_t* pyr, const gims_pyr_level* dev_
                                   int32_t n_kp, float* out, int32_t* bad_count, void* stream) {
   using namespace gims;
   GIMS_CHECK_ARG(pyr && dev_levels && n_levels > 0 && n_kp >= 0 && bad_count && (n_kp == 0 || (kp4 && kp_octave && out)), "gims_patch_extract: bad arguments");
-  const int16_t* wt = cubic_table((hipStream_t)stream);
+  const int16_t* wt = cubic_table();
   GIMS_CHECK_ARG(wt, "gims_patch_extract: could not create the bicubic weight table");
   GIMS_HIP(hipMemsetAsync(bad_count, 0, sizeof(int32_t), (hipStream_t)stream));
   if (n_kp > 0)

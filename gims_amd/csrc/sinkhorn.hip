@@ -19,6 +19,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -84,13 +86,16 @@ __device__ __forceinline__ float wave_reduce_rows(float (&v)[R], int lane, int& 
 }
 
 // ---------------------------------------------------------------------------------------------- init
-__global__ void ot_init_kernel(const OtDev* __restrict__ probs, float alpha, int zero_init) {
+// rescue = 1 (the streamed re-solve of a given-up on-chip solve, see ot_rescue_begin_kernel): only problems whose status word is 3
+// are touched, and the status word is left alone
+__global__ void ot_init_kernel(const OtDev* __restrict__ probs, float alpha, int zero_init, int rescue) {
   const OtDev p = probs[blockIdx.y];
+  if (rescue && p.status[0] != 3.f) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   if (blockIdx.x == 0) {
     for (int j = threadIdx.x; j <= p.m; j += blockDim.x) p.v[j] = 0.f;
-    if (threadIdx.x == 0) { p.u[p.n] = zero_init ? 0.f : -alpha; p.status[0] = 0.f; }
+    if (threadIdx.x == 0) { p.u[p.n] = zero_init ? 0.f : -alpha; if (!rescue) p.status[0] = 0.f; }
   }
   if (row >= p.n) return;
   const float* zr = p.z + (int64_t)row * p.ld;
@@ -108,11 +113,13 @@ __global__ void ot_status0_kernel(const OtDev* __restrict__ probs, int np) {
 
 // ---------------------------------------------------------------------------------------------- fused iteration
 template <int CPT, int R>
-__global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__ probs, float alpha) {
+__global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__ probs, float alpha, int rescue) {
   __shared__ float red[16][R];
   __shared__ float fac[R];
   const OtDev p = probs[blockIdx.y];
   if ((int)blockIdx.x >= p.G) return;
+  if (rescue && p.status[0] != 3.f && p.status[0] != 4.f) return;
+  const float guard_code = rescue ? 4.f : 1.f;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
 
   // owned columns: quads q = t + blockDim*s
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__
       for (int w = 0; w < nw; ++w) tot += red[w][0];
       const float corner = __expf(alpha + ub + vbin);
       tot += corner;
-      if (!(tot > 0.f) || !(tot < 3.0e38f)) p.status[0] = 1.f;
+      if (!(tot > 0.f) || !(tot < 3.0e38f)) ot_raise_status(p.status, guard_code);
       const float du = p.log_mu_bin - logf(tot);
       p.u[p.n] = ub + du;
       const float f = __expf(du);
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__
         const float ui = p.u[row];
         const float ebin = __expf(alpha + ui + vbin);
         tot += ebin;
-        if (!(tot > 0.f) || !(tot < 3.0e38f)) p.status[0] = 1.f;
+        if (!(tot > 0.f) || !(tot < 3.0e38f)) ot_raise_status(p.status, guard_code);
         const float du = p.norm - logf(tot);
         p.u[row] = ui + du;
         f = __expf(du);
@@ -283,9 +290,11 @@ __global__ __launch_bounds__(1024) void ot_iter_kernel(const OtDev* __restrict__
 
 // v_j += log nu_j - log(sum of partials)    block = 64 columns x 16 partial groups; every thread issues its
 // (<= 32) loads back to back so the fold is one memory round trip, not a dependent chain
-__global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restrict__ probs, int slot) {
+__global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restrict__ probs, int slot, int rescue) {
   __shared__ float red[16][64];
   const OtDev p = probs[blockIdx.y];
+  if (rescue && p.status[0] != 3.f && p.status[0] != 4.f) return;
+  const float guard_code = rescue ? 4.f : 1.f;
   const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
   if (blockIdx.x * 64 > p.m) return;
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restr
     float c = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) c += red[q][cl];
-    if (!(c > 0.f) || !(c < 3.0e38f)) p.status[0] = 1.f;
+    if (!(c > 0.f) || !(c < 3.0e38f)) ot_raise_status(p.status, guard_code);
     const float lognu = col < p.m ? p.norm : p.log_nu_bin;
     const float nv = p.v[col] + (lognu - logf(c));
     p.v[col] = nv;
@@ -597,67 +606,9 @@ __global__ __launch_bounds__(1024) void train_loss_reduce_kernel(const float* __
 // C^k_ij = exp(Zc_ij + u_k[i] + v_k[j] - log nu_j).  Reverse sweep, k = I .. 1, with gu = dL/du_k, gv = dL/dv_k:
 //     dZc -= gv[j] C^k_ij ;  gu[i] -= sum_j gv[j] C^k_ij ;   then   dZc -= gu[i] R^k_ij ;  gv'[j] = - sum_i gu[i] R^k_ij
 // starting from dZc = G = dL/dout, gu = row sums of G, gv = column sums of G.  The potentials of every iteration come from
-// a recorded forward solve (gims_sinkhorn_history).  Correct-first kernels: one sweep of the matrix per half step, rows
-// by waves (column step) or columns by threads (row step); fixed summation order.
-__global__ __launch_bounds__(256) void ot_bwd_init_kernel(const OtBwd* __restrict__ probs) {
-  const OtBwd p = probs[blockIdx.y];
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int ldz = p.m + 1;
-  if (t <= p.n) {                 // row sums -> gu
-    float s = 0.f;
-    for (int j = 0; j <= p.m; ++j) s += p.dz[(int64_t)t * ldz + j];
-    p.gu[t] = s;
-  }
-  if (t <= p.m) {                 // column sums -> gv
-    float s = 0.f;
-    for (int i = 0; i <= p.n; ++i) s += p.dz[(int64_t)i * ldz + t];
-    p.gv[t] = s;
-  }
-}
-
-// column step of iteration k: uses u_k, v_k.  One wave per row.
-__global__ __launch_bounds__(256) void ot_bwd_col_kernel(const OtBwd* __restrict__ probs, float alpha, int k) {
-  const OtBwd p = probs[blockIdx.y];
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row > p.n) return;
-  const float* uk = p.hist + (int64_t)k * p.hstride;
-  const float* vk = uk + p.n + 1;
-  const float ui = uk[row];
-  const int ldz = p.m + 1;
-  float acc = 0.f;
-  for (int j = lane; j <= p.m; j += 64) {
-    const float z = (row < p.n && j < p.m) ? p.z[(int64_t)row * p.ld + j] : alpha;
-    const float lognu = j < p.m ? p.norm : p.log_nu_bin;
-    const float t = p.gv[j] * __expf(z + ui + vk[j] - lognu);
-    p.dz[(int64_t)row * ldz + j] -= t;
-    acc += t;
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) p.gu[row] -= acc;
-}
-
-// row step of iteration k: uses u_k, v_{k-1} (v_0 = 0).  One thread per column; writes gv' (the gradient w.r.t. v_{k-1}).
-__global__ __launch_bounds__(256) void ot_bwd_row_kernel(const OtBwd* __restrict__ probs, float alpha, int k) {
-  const OtBwd p = probs[blockIdx.y];
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j > p.m) return;
-  const float* uk = p.hist + (int64_t)k * p.hstride;
-  const float* vprev = p.hist + (int64_t)(k - 1) * p.hstride + p.n + 1;
-  const float vj = k > 1 ? vprev[j] : 0.f;
-  const int ldz = p.m + 1;
-  float acc = 0.f;
-  for (int i = 0; i <= p.n; ++i) {
-    const float z = (i < p.n && j < p.m) ? p.z[(int64_t)i * p.ld + j] : alpha;
-    const float logmu = i < p.n ? p.norm : p.log_mu_bin;
-    const float t = p.gu[i] * __expf(z + uk[i] + vj - logmu);
-    p.dz[(int64_t)i * ldz + j] -= t;
-    acc += t;
-  }
-  p.gv2[j] = -acc;
-}
-
-// The sweep as it runs (the three kernels above are the unfused statement of the same arithmetic, kept for the small-problem
-// cross-check in tests): ONE pass over Z and one read-modify-write of dZc per iteration.  A workgroup owns a slab of 8 rows, a
+// a recorded forward solve (gims_sinkhorn_history).  Fixed summation order throughout.
+//
+// The fused sweep: ONE pass over Z and one read-modify-write of dZc per iteration.  A workgroup owns a slab of 8 rows, a
 // thread the columns j = t, t + 256, ...: phase 1 reduces sum_j gv[j] C_ij per row over the workgroup (gu_k[i] is final right
 // after its own row's reduction); phase 2 recomputes C, adds the row-step term gu_k[i] R_ij, updates dZc once and keeps the
 // column sums of the row-step terms of its 8 rows -> colpart[slab][j]; ot_bwd_colsum_kernel folds the slabs in order -> gv_{k-1}.
@@ -970,14 +921,6 @@ __global__ __launch_bounds__(256) void ot_bwd_combine_kernel(const OtBwd* __rest
   p.dz[(int64_t)i * (p.m + 1) + j] -= __expf(z + p.gu[i] + p.gv2[j]) * t;
 }
 
-// after a row step: gv <- gv', gu <- 0   (and after a column step gv is dead: it is overwritten here)
-__global__ __launch_bounds__(256) void ot_bwd_swap_kernel(const OtBwd* __restrict__ probs) {
-  const OtBwd p = probs[blockIdx.y];
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t <= p.m) p.gv[t] = p.gv2[t];
-  if (t <= p.n) p.gu[t] = 0.f;
-}
-
 // d alpha = sum of dZc over the border cells (dustbin row, dustbin column, corner once)
 __global__ __launch_bounds__(256) void ot_bwd_alpha_kernel(const OtBwd* __restrict__ probs) {
   const OtBwd p = probs[blockIdx.x];
@@ -1016,512 +959,6 @@ __global__ void train_loss_grad_kernel(const gims_loss_pair* __restrict__ pairs,
   atomicAdd(dz_ptrs[b] + (int64_t)r0 * (p.m + 1) + r1, g);   // equal addends per cell group: the sum does not depend on the order
 }
 
-// ---------------------------------------------------------------------------------------------- resident Sinkhorn
-// All iterations in ONE launch with the transport matrix held ON CHIP.  The streamed kernels above are pinned to the HBM
-// rate (one 4-byte read per matrix entry per iteration); here every workgroup (one per CU) keeps a slab of rows of
-//     P_ij = exp(Z_ij + u_i + v_j)
-// in its registers (192 values per thread) and in LDS (up to 144 KiB), and the iteration becomes the classical scaling
-//     row:  f_i = mu_i / sum_j P_ij ;  P_ij *= f_i ;  u_i += log f_i
-//     col:  g_j = nu_j / sum_i P_ij ;  P_ij *= g_j ;  v_j += log g_j
-// -- two multiplies and two adds per entry per iteration, no transcendental, no HBM traffic.  Only the column sums cross
-// workgroups: per iteration each workgroup publishes its partial column sums, every workgroup folds an equal share of the
-// columns over all slabs (fixed order: deterministic) and publishes g.  There is no barrier: the exchanged values carry
-// the parity of their iteration in the sign bit and readers re-read until it matches (see "publish" in the kernel).
-// Problems that fit the 32 CUs of one XCD are placed XCD by XCD (workgroup b runs on XCD b % 8).
-// The multiplicative form accumulates one rounding per multiply, so P is re-derived from Z, u and v (one HBM sweep)
-// every `refresh` iterations; u and v themselves are updated in the log domain exactly like the streamed path.
-// The dustbin row is an ordinary row (index n, all alpha); the dustbin column is kept per row in LDS (pb_i).
-struct OtResProb {
-  const float* z; int64_t ld; int n, m;
-  float* u; float* v; float* status;
-  float norm, log_mu_bin, log_nu_bin;
-  float* partial;     // [nblk][mpad]   partial column sums (column m = dustbin column)
-  float* gbuf;        // [2][mpad]      g_j, and v_j on the iterations that precede a refresh
-  int nblk, rpb, mpad, cpb;   // workgroups, rows per workgroup, padded columns (= nblk * cpb), columns folded per workgroup
-};
-struct OtResBlock { int prob, slab; };
-struct OtResArgs {
-  const OtResProb* probs; const OtResBlock* blocks;
-  float alpha; int iters, refresh;
-  unsigned long long* prof;   // diagnostics (GIMS_OT_PROF=1): cycles per phase of workgroup 0, else null
-};
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st4_agent(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-// Several agent-scope 16-byte loads in flight: the loads are issued back to back and ONE wait covers them.  The wait asm
-// takes the destination registers as read-write operands, so every later use depends on it (no stale read).
-__device__ __forceinline__ void ld4_agent_issue(f32x4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
-__device__ __forceinline__ void ld4_agent_wait(f32x4& a, f32x4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
-__device__ __forceinline__ void ld4_agent_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
-}
-__device__ __forceinline__ f32x4 ld4_agent(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-
-// ---- cross-lane sums without LDS traffic (gfx950): v_permlane16_swap / v_permlane32_swap fold two registers at a time
-// across the 16-lane rows of a wave, DPP finishes inside a row.  (Inline asm: the ROCm 7.2 builtins for the two swaps
-// return the same register for both halves of the result.)
-__device__ __forceinline__ void swap16(float& x, float& y) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
-__device__ __forceinline__ void swap32(float& x, float& y) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
-template <int CTRL>
-__device__ __forceinline__ float dpp_sum(float x) {
-  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_sum(float x) {   // all-reduce over the 16 lanes of a DPP row
-  x = dpp_sum<0xB1>(x);     // quad_perm [1,0,3,2]
-  x = dpp_sum<0x4E>(x);     // quad_perm [2,3,0,1]
-  x = dpp_sum<0x141>(x);    // row_half_mirror
-  return dpp_sum<0x140>(x); // row_mirror
-}
-// 8 per-lane values -> their totals over the 64 lanes.  Every lane of 16-lane row q (= lane >> 4) returns the total of
-// v[q] in t0 and of v[4 + q] in t1.  Fixed association order: deterministic.
-__device__ __forceinline__ void wave_rows8(float (&v)[8], float& t0, float& t1) {
-  swap16(v[0], v[1]); float s0 = v[0] + v[1];     // rows 0,2: v0 partials; rows 1,3: v1 partials
-  swap16(v[2], v[3]); float s1 = v[2] + v[3];
-  swap16(v[4], v[5]); float s2 = v[4] + v[5];
-  swap16(v[6], v[7]); float s3 = v[6] + v[7];
-  swap32(s0, s1); t0 = row16_sum(s0 + s1);        // row q: v[q]
-  swap32(s2, s3); t1 = row16_sum(s2 + s3);        // row q: v[4 + q]
-}
-
-template <int C> struct OtResGeom {
-  static constexpr int RR = 192 / C;                                  // register rows per workgroup
-  static constexpr int RL = C == 1 ? 64 : (C == 2 ? 36 : (C == 4 ? 18 : 9));   // LDS rows per workgroup
-  static constexpr int RMAX = RR + RL;                                // rows per workgroup
-  static constexpr int COLS = 512 * C;
-  static constexpr int COLRED_OFF = (RL * COLS + 11 * RMAX + 3) & ~3;
-  static constexpr int LDS_FLOATS = COLRED_OFF + 2048;
-};
-
-template <int C, bool PROF>
-__global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
-  // No fma contraction in here: with it the compiler turns `P *= f; cs += P` into an fma on the OLD P plus a separate
-  // multiply, sinks all the multiplies behind the pass and keeps every row factor alive meanwhile -- 100+ spills.
-#pragma clang fp contract(off)
-  __shared__ int fail_flag;
-  __shared__ unsigned long long prof_acc[8];
-  unsigned long long prof_t = 0;
-  auto stamp = [&](int phase) {
-    if (PROF && threadIdx.x == 0) {
-      const unsigned long long now = __builtin_readcyclecounter();
-      if (phase >= 0) prof_acc[phase] += now - prof_t;
-      prof_t = now;
-    }
-  };
-  if (PROF && threadIdx.x < 8) prof_acc[threadIdx.x] = 0;
-  if (threadIdx.x == 0) fail_flag = 0;
-  using G = OtResGeom<C>;
-  constexpr int RR = G::RR, RMAX = G::RMAX, COLS = G::COLS;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* plds = lds;                       // [RL][COLS]
-  float* red = plds + G::RL * COLS;        // [8][RMAX]
-  float* us = red + 8 * RMAX;              // [RMAX] u of the slab rows
-  float* fac = us + RMAX;                  // [RMAX] row factors of the current iteration
-  float* pb = fac + RMAX;                  // [RMAX] dustbin-column entry of the slab rows
-  float* colred = lds + G::COLRED_OFF;     // [2048], 16-byte aligned
-
-  const OtResBlock bk = a.blocks[blockIdx.x];
-  if (bk.prob < 0) return;
-  const OtResProb p = a.probs[bk.prob];
-  const int t = threadIdx.x;
-  const int row0 = bk.slab * p.rpb;
-  int nrows = p.n + 1 - row0;
-  nrows = nrows < p.rpb ? nrows : p.rpb;
-  nrows = nrows > 0 ? nrows : 0;                          // a workgroup past the last row only folds columns
-  const int nl = nrows > RR ? nrows - RR : 0;            // rows kept in LDS
-  const float alpha = a.alpha;
-
-  // P lives in registers as aligned pairs (two adjacent columns): the sweeps then run on v_pk_mul_f32 / v_pk_add_f32,
-  // half the VALU instructions of scalar code
-  constexpr int H = C >= 2 ? C / 2 : 1;
-  using E = typename std::conditional<(C >= 2), f32x2, float>::type;
-  auto mk = [](float x, float y) -> E { if constexpr (C >= 2) return E{x, y}; else return x; };
-  auto lo = [](E v) -> float { if constexpr (C >= 2) return v[0]; else return v; };
-  auto hi = [](E v) -> float { if constexpr (C >= 2) return v[1]; else return 0.f; };
-  auto fmaE = [](E x, E y, E z) -> E { return __builtin_elementwise_fma(x, y, z); };   // explicit: contraction is off in here
-  E P[RR][H];
-  // LDS rows: a thread's C values as 16-byte quads (C >= 4), one pair (C == 2) or one float, element q of thread t at
-  // [(row * NQ + q) * 512 + t]: consecutive lanes are adjacent, so ds_read/write_b128 (b64, b32) are conflict-free
-  constexpr int NQ = C >= 4 ? C / 4 : 1;
-  auto lds_load = [&](int r, E (&x)[H]) {
-    if constexpr (C >= 4) {
-      const f32x4* b = (const f32x4*)plds + r * NQ * 512 + t;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const f32x4 v = b[q * 512];
-        x[2 * q] = E{v[0], v[1]};
-        x[2 * q + 1] = E{v[2], v[3]};
-      }
-    } else {
-      x[0] = ((const E*)plds)[r * 512 + t];
-    }
-  };
-  auto lds_store = [&](int r, const E (&x)[H]) {
-    if constexpr (C >= 4) {
-      f32x4* b = (f32x4*)plds + r * NQ * 512 + t;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) b[q * 512] = f32x4{x[2 * q][0], x[2 * q][1], x[2 * q + 1][0], x[2 * q + 1][1]};
-    } else {
-      ((E*)plds)[r * 512 + t] = x[0];
-    }
-  };
-  // LAZY SCALING: the stored matrix is K = exp(Z + u + v) of the last fresh iteration and is never rewritten; the row
-  // and column factors since then live as cumulative vectors F (fac[], per slab row) and G (g[], per column), the
-  // transport matrix being diag(F) K diag(G).  A sweep is then one fma per entry and no write-back -- row sums
-  // F_i sum_j K_ij G_j, column sums G_j sum_i F_i K_ij -- instead of a multiply, an add and a store.
-  // g: cumulative column factors.  Ahead of a fresh iteration the same registers carry v instead (K is re-derived from
-  // Z, u, v there); v0 = 0.
-  float g[C];
-#pragma unroll
-  for (int k = 0; k < C; ++k) g[k] = 0.f;
-  float gbin = 0.f;
-  for (int r = t; r < RMAX; r += 512) {
-    fac[r] = 0.f;
-    pb[r] = 0.f;
-    us[r] = r < nrows ? p.u[row0 + r] : 0.f;
-  }
-  // column fold duty: columns [slab * cpb, slab * cpb + cpb) in groups of 4, slabs split over S thread subsets
-  const int G4 = p.cpb >> 2;
-  const int S = 512 / G4 < p.nblk ? 512 / G4 : p.nblk;
-  float vfold = 0.f;                                      // v of that column, carried across iterations
-  float gcf = 1.f;                                        // its cumulative factor G since the last fresh iteration
-  __syncthreads();
-
-  // P = exp(Z + u + v) for one row held in registers / LDS
-  // row0_o / c0_o / z_o are re-materialised through an empty asm at every fresh iteration: without that the compiler
-  // treats all RR rows' addresses and predicates as loop invariants, hoists them out of the iteration loop and spills
-  auto fresh_row = [&](int r, float (&out)[C], int row0_o, int c0_o, const float* z_o) {
-    const int grow = r < nrows ? row0_o + r : p.n + 1;     // rows past the slab stay zero
-    const float ui = us[r];
-    if (grow < p.n) {
-      const float* zr = z_o + (int64_t)grow * p.ld + c0_o;
-      float z[C];
-      if (C >= 4) {
-#pragma unroll
-        for (int k = 0; k < C; k += 4) {
-          const bool in = c0_o + k < p.m;                    // rows are padded to 4 floats: a quad that starts inside ends inside
-          const f32x4 q = in ? __builtin_nontemporal_load((const f32x4*)(zr + k)) : f32x4{0.f, 0.f, 0.f, 0.f};
-          z[k] = q[0]; z[k + 1] = q[1]; z[k + 2] = q[2]; z[k + 3] = q[3];
-        }
-      } else if (C == 2) {
-        const bool in = c0_o < p.m;                          // ld % 4 == 0, c0 even: the pair is inside the padded row
-        const f32x2 q = in ? __builtin_nontemporal_load((const f32x2*)zr) : f32x2{0.f, 0.f};
-        z[0] = q[0]; z[C - 1] = q[1];
-      } else {
-        z[0] = c0_o < p.m ? __builtin_nontemporal_load(zr) : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < C; ++k) out[k] = c0_o + k < p.m ? __expf((z[k] + ui) + g[k]) : 0.f;
-    } else if (grow == p.n) {                              // the dustbin row: every entry alpha
-#pragma unroll
-      for (int k = 0; k < C; ++k) out[k] = c0_o + k < p.m ? __expf((alpha + ui) + g[k]) : 0.f;
-    } else {
-#pragma unroll
-      for (int k = 0; k < C; ++k) out[k] = 0.f;
-    }
-  };
-
-  for (int it = 0; it < a.iters; ++it) {
-    // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration: as loop invariants
-    // the compiler would keep ~20 registers of hoisted addresses alive next to the 192 registers of P
-    int tq = threadIdx.x;
-    asm volatile("" : "+v"(tq));
-    const int t = tq, lane = t & 63, wave = t >> 6, c0 = t * C;
-    const int fg4 = t % G4, fss = t / G4, fcol = bk.slab * p.cpb + t;
-    const bool fresh = it == 0 || it == a.iters - 1 || (a.refresh > 0 && it % a.refresh == 0);   // the last one: exact P behind the final u, v
-    const bool publish_v = it + 1 < a.iters && (it + 2 == a.iters || (a.refresh > 0 && (it + 1) % a.refresh == 0));
-    // ---------------- row pass: row sums sum_j K_ij G_j (K re-derived from Z, u, v first on a fresh iteration)
-    stamp(-1);
-    if (fresh) {
-      int row0_o = row0, c0_o = c0;
-      const float* z_o = p.z;
-      asm volatile("" : "+s"(row0_o), "+s"(z_o));
-      constexpr int FB = C == 8 ? 4 : 8;                 // rows of loads in flight, then their exps; the fences keep the
-#pragma unroll                                           // compiler from hoisting all RR rows' addresses and loads at once
-      for (int rb = 0; rb < RR; rb += FB) {
-#pragma unroll
-        for (int r8 = 0; r8 < FB; ++r8) {
-          float x[C];
-          fresh_row(rb + r8, x, row0_o, c0_o, z_o);
-#pragma unroll
-          for (int h = 0; h < H; ++h) P[rb + r8][h] = mk(x[2 * h], x[(2 * h + 1) % C]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      for (int r = 0; r < nl; ++r) {
-        float x[C];
-        fresh_row(RR + r, x, row0_o, c0_o, z_o);
-        E y[H];
-#pragma unroll
-        for (int h = 0; h < H; ++h) y[h] = mk(x[2 * h], x[(2 * h + 1) % C]);
-        lds_store(r, y);
-      }
-      for (int r = t; r < nrows; r += 512) { pb[r] = __expf((alpha + us[r]) + gbin); fac[r] = 1.f; }
-#pragma unroll
-      for (int k = 0; k < C; ++k) g[k] = 1.f;
-      gbin = 1.f;
-      gcf = 1.f;
-    }
-    E g2[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) g2[h] = mk(g[2 * h], g[(2 * h + 1) % C]);
-#pragma unroll
-    for (int rb = 0; rb < RR; rb += 8) {
-      float rs[8];
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const int r = rb + r8;
-        E s2 = P[r][0] * g2[0];
-#pragma unroll
-        for (int h = 1; h < H; ++h) s2 = fmaE(P[r][h], g2[h], s2);
-        rs[r8] = lo(s2) + hi(s2);
-      }
-      float t0, t1;
-      wave_rows8(rs, t0, t1);
-      if ((lane & 15) == 0) { red[wave * RMAX + rb + (lane >> 4)] = t0; red[wave * RMAX + rb + 4 + (lane >> 4)] = t1; }
-      if (rb % 16 == 8) __builtin_amdgcn_sched_barrier(0);   // two batches may interleave (reduction chains are latency-bound)
-    }
-    stamp(5);
-    for (int rb = 0; rb < nl; rb += 8) {
-      float rs[8];
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const int r = rb + r8;
-        float s = 0.f;
-        if (r < nl) {
-          E x[H];
-          lds_load(r, x);
-          E s2 = x[0] * g2[0];
-#pragma unroll
-          for (int h = 1; h < H; ++h) s2 = fmaE(x[h], g2[h], s2);
-          s = lo(s2) + hi(s2);
-        }
-        rs[r8] = s;
-      }
-      float t0, t1;
-      wave_rows8(rs, t0, t1);
-      if ((lane & 15) == 0) {
-        const int ra = rb + (lane >> 4), rc = ra + 4;
-        if (ra < nl) red[wave * RMAX + RR + ra] = t0;
-        if (rc < nl) red[wave * RMAX + RR + rc] = t1;
-      }
-    }
-    __syncthreads();
-    if (fail_flag) {                                     // a bounded wait ran out somewhere in this workgroup (uniform exit)
-      if (threadIdx.x == 0) p.status[0] = 2.f;
-      return;
-    }
-    stamp(0);
-    for (int r = t; r < nrows; r += 512) {
-      float tot = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) tot += red[w * RMAX + r];
-      const float fc = fac[r];
-      tot = fc * (tot + pb[r] * gbin);                      // true row sum: F_i (sum_j K_ij G_j + K_i,bin G_bin)
-      if (!(tot > 0.f) || !(tot < 3.0e38f)) p.status[0] = 1.f;
-      const float du = (row0 + r < p.n ? p.norm : p.log_mu_bin) - logf(tot);
-      us[r] += du;
-      fac[r] = fc * __expf(du);
-    }
-    __syncthreads();
-    stamp(1);
-    // ---------------- column pass: partial column sums sum_i F_i K_ij of this slab (G_j is applied by the folding workgroup)
-    E cs2[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) cs2[h] = mk(0.f, 0.f);
-#pragma unroll
-    for (int rb = 0; rb < RR; rb += 8) {
-      const f32x4 fa = *(const f32x4*)(fac + rb), fb = *(const f32x4*)(fac + rb + 4);   // LDS broadcast reads
-      const float f8[8] = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const E f2 = mk(f8[r8], f8[r8]);
-#pragma unroll
-        for (int h = 0; h < H; ++h) cs2[h] = fmaE(P[rb + r8][h], f2, cs2[h]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    stamp(7);
-    for (int r = 0; r < nl; ++r) {
-      const float f = fac[RR + r];
-      const E f2 = mk(f, f);
-      E x[H];
-      lds_load(r, x);
-#pragma unroll
-      for (int h = 0; h < H; ++h) cs2[h] = fmaE(x[h], f2, cs2[h]);
-    }
-    float cs[C];
-#pragma unroll
-    for (int h = 0; h < H; ++h) { cs[2 * h] = lo(cs2[h]); if (C >= 2) cs[(2 * h + 1) % C] = hi(cs2[h]); }
-    stamp(2);
-    // ---------------- publish.  No barrier anywhere: every exchanged value is >= +0, so its sign bit carries the parity of
-    // the iteration that wrote it and a reader simply re-reads until the parity is the one it is waiting for.  Safe with
-    // ONE bit: a slab overwrites its partials of iteration i only after it has read g of iteration i from every fold
-    // workgroup, and a fold workgroup publishes that g only after it has read the partials of iteration i of every slab
-    // (likewise for g); so a location holds the value of iteration i or i-1, never anything older.  The buffers start as
-    // 0xFF.. (sign 1) and iteration 0 waits for sign 0.
-    const unsigned tagbit = (unsigned)(it & 1) << 31;
-    auto tg = [&](float x) { return __uint_as_float(__float_as_uint(x) | tagbit); };
-    float* mine = p.partial + (int64_t)bk.slab * p.mpad;
-    if (C >= 4) {
-#pragma unroll
-      for (int k = 0; k < C; k += 4)
-        if (c0 + k + 3 < p.m) {
-          st4_agent(mine + c0 + k, f32x4{tg(cs[k]), tg(cs[k + 1]), tg(cs[k + 2]), tg(cs[k + 3])});
-        } else {                                         // the quad that straddles m must not touch the dustbin slot
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (c0 + k + j < p.m) st_agent(mine + c0 + k + j, tg(cs[k + j]));
-        }
-    } else {
-#pragma unroll
-      for (int k = 0; k < C; ++k)
-        if (c0 + k < p.m) st_agent(mine + c0 + k, tg(cs[k]));
-    }
-    if (wave == 0) {                                    // dustbin column: sum of pb over the slab rows
-      float s = 0.f;
-      for (int r = lane; r < nrows; r += 64) s += pb[r] * fac[r];
-      s = wave_sum(s);
-      if (lane == 0) st_agent(mine + p.m, tg(s));
-    }
-    stamp(3);
-    // ---------------- fold this workgroup's share of the columns over all slabs; v += log g
-    if (fss < S) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const int colbase = bk.slab * p.cpb + 4 * fg4;
-      const float* src = p.partial + colbase;
-      unsigned vmask = 0;                                 // lanes of the quad that are real columns (<= m: dustbin included)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) vmask |= (colbase + j <= p.m ? 1u : 0u) << j;
-      for (int k = fss; k < p.nblk; k += 4 * S) {         // 4 loads in flight per trip (slabs past the end re-read slab k)
-        f32x4 q0, q1, q2, q3;
-        const int k1 = k + S, k2 = k + 2 * S, k3 = k + 3 * S;
-        int spins = 0;
-        for (;;) {
-          ld4_agent_issue(q0, src + (int64_t)k * p.mpad);
-          ld4_agent_issue(q1, src + (int64_t)(k1 < p.nblk ? k1 : k) * p.mpad);
-          ld4_agent_issue(q2, src + (int64_t)(k2 < p.nblk ? k2 : k) * p.mpad);
-          ld4_agent_issue(q3, src + (int64_t)(k3 < p.nblk ? k3 : k) * p.mpad);
-          ld4_agent_wait(q0, q1, q2, q3);
-          unsigned stale = 0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const unsigned w = (__float_as_uint(q0[j]) ^ tagbit) | (__float_as_uint(q1[j]) ^ tagbit) | (__float_as_uint(q2[j]) ^ tagbit) |
-                               (__float_as_uint(q3[j]) ^ tagbit);
-            stale |= (w >> 31) << j;
-          }
-          if ((stale & vmask) == 0) break;
-          if (++spins > (1 << 16)) { fail_flag = 1; break; }    // a workgroup of the launch is not resident: give up, never hang
-          __builtin_amdgcn_s_sleep(1);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                     // same order as a one-by-one loop: deterministic
-          acc[j] += fabsf(q0[j]);
-          if (k1 < p.nblk) acc[j] += fabsf(q1[j]);
-          if (k2 < p.nblk) acc[j] += fabsf(q2[j]);
-          if (k3 < p.nblk) acc[j] += fabsf(q3[j]);
-        }
-      }
-      *(f32x4*)(colred + (fss * G4 + fg4) * 4) = acc;
-    }
-    __syncthreads();
-    if (t < p.cpb && fcol <= p.m) {
-      float tot = 0.f;
-      const int j4 = t >> 2, jc = t & 3;
-      for (int s = 0; s < S; ++s) tot += colred[(s * G4 + j4) * 4 + jc];
-      tot *= gcf;                                          // true column sum
-      if (!(tot > 0.f) || !(tot < 3.0e38f)) p.status[0] = 1.f;
-      const float dv = (fcol < p.m ? p.norm : p.log_nu_bin) - logf(tot);
-      vfold += dv;
-      gcf *= __expf(dv);
-      if (publish_v) {                                    // v first, acknowledged, then the tagged g that readers wait on
-        st_agent(p.gbuf + p.mpad + fcol, vfold);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      st_agent(p.gbuf + fcol, tg(gcf));
-    }
-    stamp(4);
-    if (it + 1 < a.iters) {
-      // next column factors -- or, ahead of a fresh iteration, v itself (see the declaration of g); either way the wait
-      // is on the tagged g
-      const float idle = publish_v ? 0.f : 1.f;          // columns >= m hold zeros in P: keep their factor finite
-      int spins = 0;
-      if (C >= 4) {
-        f32x4 q0, q1;
-        const int ka = c0 < p.m ? c0 : 0, kb = (C > 4 && c0 + 4 < p.m) ? c0 + 4 : 0;
-        unsigned vmask = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) vmask |= ((j < C && c0 + j < p.m) ? 1u : 0u) << j;
-        for (;;) {
-          ld4_agent_issue(q0, p.gbuf + ka);
-          ld4_agent_issue(q1, p.gbuf + kb);
-          ld4_agent_wait(q0, q1);
-          unsigned stale = 0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            stale |= ((__float_as_uint(q0[j]) ^ tagbit) >> 31) << j;
-            stale |= ((__float_as_uint(q1[j]) ^ tagbit) >> 31) << (4 + j);
-          }
-          if ((stale & vmask) == 0) break;
-          if (++spins > (1 << 16)) { fail_flag = 1; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (publish_v) {
-          ld4_agent_issue(q0, p.gbuf + p.mpad + ka);
-          ld4_agent_issue(q1, p.gbuf + p.mpad + kb);
-          ld4_agent_wait(q0, q1);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          g[j] = c0 + j < p.m ? (publish_v ? q0[j] : fabsf(q0[j])) : idle;
-          if (C > 4) g[(4 + j) % C] = c0 + 4 + j < p.m ? (publish_v ? q1[j] : fabsf(q1[j])) : idle;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-          float x = idle;
-          if (c0 + k < p.m) {
-            for (;;) {
-              x = ld_agent(p.gbuf + c0 + k);
-              if (((__float_as_uint(x) ^ tagbit) >> 31) == 0) break;
-              if (++spins > (1 << 16)) { fail_flag = 1; break; }
-              __builtin_amdgcn_s_sleep(1);
-            }
-            x = publish_v ? ld_agent(p.gbuf + p.mpad + c0 + k) : fabsf(x);
-          }
-          g[k] = x;
-        }
-      }
-      float xb;
-      for (;;) {
-        xb = ld_agent(p.gbuf + p.m);
-        if (((__float_as_uint(xb) ^ tagbit) >> 31) == 0) break;
-        if (++spins > (1 << 16)) { fail_flag = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      gbin = publish_v ? ld_agent(p.gbuf + p.mpad + p.m) : fabsf(xb);
-    }
-    stamp(6);
-  }
-  if (PROF && blockIdx.x == 0 && threadIdx.x < 8) a.prof[threadIdx.x] = prof_acc[threadIdx.x];
-  // a bounded wait that ran out in the LAST iteration (or with iters == 1) falls out of the loop without passing the test
-  // at its top: test again before any potential is written, so that a timed-out solve can never leave with status 0
-  __syncthreads();
-  if (fail_flag) {
-    if (threadIdx.x == 0) p.status[0] = 2.f;
-    return;
-  }
-  // ---------------- potentials out (the selection kernels read Z, u, v)
-  for (int r = t; r < nrows; r += 512) p.u[row0 + r] = us[r];
-  if (t < p.cpb && bk.slab * p.cpb + t <= p.m) p.v[bk.slab * p.cpb + t] = vfold;
-}
-
 // ---------------------------------------------------------------------------------------------- rescue
 // The on-chip kernel needs its 256 workgroups co-resident; when a bounded wait runs out (another process's kernels on the
 // GPU, a straggling workgroup) it leaves status 2 and no potentials.  This kernel is enqueued right after the resident
@@ -1530,9 +967,10 @@ __global__ __launch_bounds__(512) void ot_resident_kernel(OtResArgs a) {
 // (one workgroup per problem walks the matrix twice per iteration: slow -- ~0.25 s for a 4096^2 problem -- but it cannot
 // stall, and the batch leaves with valid matches instead of -1s).  Same recurrence as the streamed kernels
 // (u = log mu - LSE_j(Z + v); v = log nu - LSE_i(Z + u), gmatcher.py:41-47), fixed summation order.
-__global__ __launch_bounds__(1024) void ot_rescue_kernel(const OtDev* __restrict__ probs, float alpha, int iters, int force) {
+__global__ __launch_bounds__(1024) void ot_rescue_kernel(const OtDev* __restrict__ probs, float alpha, int iters, int force, int* __restrict__ counter) {
   const OtDev p = probs[blockIdx.x];
   if (!force && p.status[0] != 2.f) return;
+  if (threadIdx.x == 0 && counter) atomicAdd(counter, 1);
   __shared__ float wsum[16];
   __shared__ int bad;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1603,196 +1041,76 @@ __global__ void ot_poison_kernel(const OtDev* __restrict__ probs) {
   const OtDev p = probs[blockIdx.x];
   for (int i = threadIdx.x; i <= p.n; i += blockDim.x) p.u[i] = __uint_as_float(0x7fc00000u);
   for (int j = threadIdx.x; j <= p.m; j += blockDim.x) p.v[j] = __uint_as_float(0x7fc00000u);
-  if (threadIdx.x == 0) p.status[0] = 2.f;
+  if (threadIdx.x == 0) ot_raise_status(p.status, 2.f);
 }
 
-// ---- host side of the resident path: geometry, workspace, launches
-struct OtResPlan {
-  bool ok; int C, local, nbu, ppg, ngroups;
-  size_t bytes;       // workspace bytes on top of the streamed path's
-};
-static int ot_res_cap(int C) { return C == 1 ? OtResGeom<1>::RMAX : (C == 2 ? OtResGeom<2>::RMAX : (C == 4 ? OtResGeom<4>::RMAX : OtResGeom<8>::RMAX)); }
+// ---- rescue by the streamed kernels (no cross-workgroup waits, full-chip parallelism: ~ the cost of a streamed solve).  All of its
+// launches look at the problem's status word first and return at once unless the solve gave up: begin (2 -> 3 "being re-solved",
+// counted), start potentials, `iters` x (ot_iter_kernel + ot_colreduce_kernel) with rescue = 1 (numeric guard raises 4), end (3 -> 0,
+// 4 -> 1).  2 * iters + 3 near-empty launches when nothing happened, so the host enqueues the sequence only while the device is
+// MARGINAL -- a give-up was seen during the last OT_MARGINAL_CALLS calls (the counter is read back lazily, without a synchronisation
+// of its own) -- and the one-workgroup ot_rescue_kernel stays behind it as the last resort for the first give-up ever seen.
+__global__ void ot_rescue_begin_kernel(const OtDev* __restrict__ probs, int np, int* __restrict__ counter) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np || probs[i].status[0] != 2.f) return;
+  probs[i].status[0] = 3.f;
+  atomicAdd(counter, 1);
+}
+__global__ void ot_rescue_end_kernel(const OtDev* __restrict__ probs, int np) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  const float st = probs[i].status[0];
+  if (st == 3.f) probs[i].status[0] = 0.f;
+  else if (st == 4.f) probs[i].status[0] = 1.f;
+}
+
+// ---- host side of the on-chip path
 static int ot_env(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
 }
-static int ot_res_cus() {
-  static int n = -1;
-  if (n < 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-  }
+static int ot_cus() {
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess) n = 0;
   return n;
 }
-static inline int roundup4(int x) { return (x + 3) & ~3; }
-static inline size_t al256r(size_t x) { return (x + 255) & ~(size_t)255; }
-
-// One launch = 256 workgroups (one per CU, all resident).  Every problem of a call gets the same number of workgroups
-// `nbu`; when nbu <= 32 the problems are placed XCD by XCD (workgroup b runs on XCD b % 8) and synchronise per XCD.
 static thread_local bool tl_streamed_only = false;   // set for the duration of a *_ex call with GIMS_OT_STREAMED
-static OtResPlan ot_res_plan(const gims_ot_problem* pr, int np, int iters) {
-  OtResPlan P{};
-  if (tl_streamed_only || !ot_env("GIMS_OT_RESIDENT", 1) || iters < 1 || ot_res_cus() < 256) return P;
-  int maxm = 0;
-  double cells = 0.0;
-  for (int i = 0; i < np; ++i) {
-    maxm = pr[i].m > maxm ? pr[i].m : maxm;
-    cells += (double)pr[i].n * pr[i].m;
-  }
-  // an iteration of the resident kernel costs ~12 us whatever the size (two barriers + the register sweep); below
-  // ~6 M matrix entries the streamed kernels finish an iteration sooner (GIMS_OT_RESIDENT=2 forces the resident path)
-  if (cells < 6.0e6 && ot_env("GIMS_OT_RESIDENT", 1) != 2) return P;
-  const int C = maxm <= 512 ? 1 : (maxm <= 1024 ? 2 : (maxm <= 2048 ? 4 : (maxm <= 4096 ? 8 : 0)));
-  if (!C) return P;
-  const int cap = ot_res_cap(C);
-  int need = 1;
-  for (int i = 0; i < np; ++i) {
-    const int a = cdiv(pr[i].n + 1, cap), b = cdiv(pr[i].m + 1, 508);   // rows fit on chip; fold duty: cpb <= 512 columns
-    need = a > need ? a : need;
-    need = b > need ? b : need;
-  }
-  if (need > 256) return P;
-  P.C = C;
-  if (need <= 32) {
-    P.local = 1;
-    int nbu = 1;
-    while (nbu < need) nbu *= 2;
-    while (nbu < 32 && np <= 8 * (32 / (2 * nbu))) nbu *= 2;       // spare CUs: spread every problem over more of them
-    P.nbu = nbu;
-    P.ppg = 8 * (32 / nbu);
-  } else {
-    P.local = 0;
-    int ppg = 256 / need;
-    ppg = np < ppg ? np : ppg;
-    P.ppg = ppg;
-    // as FEW workgroups per problem as its rows need (rounded up to whole groups of 8): every fold spans all slabs of the
-    // problem, so spreading one 4096^2 problem over all 256 CUs (16 rows each) made its iteration slower than two such
-    // problems side by side -- measured 1.60 -> 1.29 ms per solve with 128 instead of 256 slabs (tools/ot_probe.py 4096x1)
-    int nbu = (need + 7) & ~7;
-    nbu = nbu < 256 / ppg ? nbu : 256 / ppg;
-    const int cap_nbu = ot_env("GIMS_OT_MAXNBU", 0);            // experiments: force a (larger) number of slabs per problem
-    if (cap_nbu >= need && cap_nbu <= 256 / ppg) nbu = cap_nbu;
-    P.nbu = nbu;
-  }
-  P.ngroups = cdiv(np, P.ppg);
-  if (P.ngroups > 16) return P;
-  size_t b = al256r(sizeof(OtResProb) * (size_t)np) + (size_t)P.ngroups * al256r(sizeof(OtResBlock) * 256);
-  for (int i = 0; i < np; ++i) {
-    const size_t mpad = (size_t)P.nbu * roundup4(cdiv(pr[i].m + 1, P.nbu));
-    b += al256r((size_t)P.nbu * mpad * 4) + al256r(2 * mpad * 4);
-  }
-  P.bytes = b;
-  P.ok = true;
-  return P;
+
+// Give-up bookkeeping, per device: a device counter of re-solved problems (bumped by the rescue kernels), mirrored into pinned host
+// memory by an asynchronous copy at the end of every on-chip call; the copy of call k is looked at by call k + 1.
+constexpr int OT_MARGINAL_CALLS = 256;
+struct OtRescueState {
+  int* d_count; volatile int* h_count; hipEvent_t ev;
+  long calls, last_giveup_call; int seen;
+};
+static std::mutex g_rescue_mu;
+static OtRescueState* ot_rescue_state() {
+  static std::map<int, OtRescueState> states;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_rescue_mu);
+  auto it = states.find(dev);
+  if (it != states.end()) return &it->second;
+  OtRescueState st{};
+  st.d_count = (int*)device_once("ot_rescue_count", 256, nullptr);
+  st.h_count = (volatile int*)pinned_once("ot_rescue_count", 256);
+  if (!st.d_count || !st.h_count || hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  st.last_giveup_call = -(long)OT_MARGINAL_CALLS - 1;
+  return &states.emplace(dev, st).first->second;
 }
 
-template <int C>
-static int ot_res_launch(OtResArgs a, hipStream_t s) {
-  static bool attr = false;
-  constexpr size_t lds = OtResGeom<C>::LDS_FLOATS * sizeof(float);
-  if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ot_resident_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    GIMS_HIP(hipFuncSetAttribute((const void*)ot_resident_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
-  if (ot_env("GIMS_OT_PROF", 0)) {     // diagnostics: per-phase cycles of workgroup 0 (synchronous; tools/ot_probe.py)
-    static unsigned long long* dprof = nullptr;
-    if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 8 * sizeof(unsigned long long)));
-    a.prof = dprof;
-    hipLaunchKernelGGL((ot_resident_kernel<C, true>), dim3(256), dim3(512), lds, s, a);
-    GIMS_LAUNCH_CHECK();
-    unsigned long long h[8];
-    GIMS_HIP(hipStreamSynchronize(s));
-    GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
-    static const char* names[8] = {"row pass LDS rows + sync", "row totals", "column pass LDS rows", "publish", "fold (incl. wait)", "row pass register rows", "read g (incl. wait)", "column pass register rows"};
-    fprintf(stderr, "[ot_resident C=%d iters=%d] cycles/iteration of workgroup 0:", C, a.iters);
-    for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.0f;", names[i], (double)h[i] / a.iters);
-    fprintf(stderr, "\n");
-    return GIMS_OK;
-  }
-  // The kernel's workgroups wait on each other, so the whole grid (256 workgroups) must be resident at once.  Checked here
-  // against the occupancy query (once per instantiation): workgroups per CU x CUs >= 256, else the call fails loudly.
-  // What a cooperative launch adds is only that same check at launch time (same residency as a plain launch, +15-19 us of
-  // host time per launch); it is available as GIMS_OT_COOP=1 but not the default: under rocprofv3 a process that issued
-  // cooperative launches segfaults at exit, after the tool has written its output (measured on this image, ROCm 7.2).
-  // A solve that still gives up (another process's kernels on the GPU) is re-solved by ot_rescue_kernel in the same call.
-  static int resident_ok = -1;
-  if (resident_ok < 0) {
-    int per_cu = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ot_resident_kernel<C, false>, 512, lds);
-    resident_ok = (e == hipSuccess && per_cu * ot_res_cus() >= 256) ? 1 : 0;
-  }
-  if (!resident_ok) {
-    set_error("the on-chip Sinkhorn kernel does not fit: 256 workgroups of 512 threads with %zu bytes of LDS are not co-resident on this device", lds);
-    return GIMS_EHIP;
-  }
-  if (ot_env("GIMS_OT_COOP", 0)) {
-    void* kargs[] = {(void*)&a};
-    const hipError_t e = hipLaunchCooperativeKernel((const void*)ot_resident_kernel<C, false>, dim3(256), dim3(512), kargs, (unsigned)lds, s);
-    if (e == hipSuccess) return GIMS_OK;
-    (void)hipGetLastError();
-    set_error("cooperative launch of the on-chip Sinkhorn kernel failed: %s", hipGetErrorString(e));
-    return GIMS_EHIP;
-  }
-  hipLaunchKernelGGL((ot_resident_kernel<C, false>), dim3(256), dim3(512), lds, s, a);
-  GIMS_LAUNCH_CHECK();
-  return GIMS_OK;
-}
-
-// Runs all `iters` iterations of every problem; `base` is the resident part of the workspace (P.bytes).
-static int ot_res_run(const OtResPlan& P, const std::vector<OtDev>& hprob, float alpha, int iters, char* base, hipStream_t s) {
-  const int np = (int)hprob.size();
-  size_t off = 0;
-  OtResProb* dprob = (OtResProb*)(base + off); off += al256r(sizeof(OtResProb) * (size_t)np);
-  std::vector<OtResProb> hp(np);
-  for (int i = 0; i < np; ++i) {
-    const OtDev& d = hprob[i];
-    OtResProb q;
-    q.z = d.z; q.ld = d.ld; q.n = d.n; q.m = d.m; q.u = d.u; q.v = d.v; q.status = d.status;
-    q.norm = d.norm; q.log_mu_bin = d.log_mu_bin; q.log_nu_bin = d.log_nu_bin;
-    q.nblk = P.nbu; q.rpb = cdiv(d.n + 1, P.nbu); q.cpb = roundup4(cdiv(d.m + 1, P.nbu)); q.mpad = q.nblk * q.cpb;
-    q.partial = (float*)(base + off); off += al256r((size_t)q.nblk * q.mpad * 4);
-    q.gbuf = (float*)(base + off); off += al256r((size_t)2 * q.mpad * 4);
-    hp[i] = q;
-  }
-  // exchange buffers start with every sign bit set: iteration 0 waits for sign 0 (see the kernel)
-  GIMS_HIP(hipMemsetAsync(base + al256r(sizeof(OtResProb) * (size_t)np), 0xFF, off - al256r(sizeof(OtResProb) * (size_t)np), s));
-  int rc = upload_table(hp.data(), sizeof(OtResProb) * (size_t)np, dprob, s);
-  if (rc != GIMS_OK) return rc;
-  const int refresh = ot_env("GIMS_OT_REFRESH", 50);
-  for (int gi = 0; gi < P.ngroups; ++gi) {
-    OtResBlock* dblk = (OtResBlock*)(base + off); off += al256r(sizeof(OtResBlock) * 256);
-    OtResBlock hb[256];
-    for (int b = 0; b < 256; ++b) hb[b] = OtResBlock{-1, 0};
-    OtResArgs a{};
-    const int p0 = gi * P.ppg, p1 = (p0 + P.ppg < np) ? p0 + P.ppg : np;
-    for (int q = 0; q < p1 - p0; ++q)
-      for (int sl = 0; sl < P.nbu; ++sl) {
-        const int b = P.local ? ((q / 8) * P.nbu + sl) * 8 + (q % 8) : q * P.nbu + sl;
-        hb[b] = OtResBlock{p0 + q, sl};
-      }
-    rc = upload_table(hb, sizeof(hb), dblk, s);
-    if (rc != GIMS_OK) return rc;
-    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh;
-    rc = P.C == 1 ? ot_res_launch<1>(a, s) : (P.C == 2 ? ot_res_launch<2>(a, s) : (P.C == 4 ? ot_res_launch<4>(a, s) : ot_res_launch<8>(a, s)));
-    if (rc != GIMS_OK) return rc;
-  }
-  return GIMS_OK;
-}
-
-static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-// Which on-chip kernel a call uses: the 2-D decomposition of sinkhorn2d.hip (default) or ot_resident_kernel above
-// (GIMS_OT_RES2=0; kept as the cross-check).  Both share the gate of ot_res_plan (GIMS_OT_RESIDENT, the size threshold).
+// The on-chip kernel (2-D decomposition, sinkhorn2d.hip) is used whenever every problem has a geometry (n, m <= 4096) and the device has
+// the 256 CUs its workgroups need; GIMS_OT_RESIDENT=0 / GIMS_OT_STREAMED select the streamed kernels.
 static OtR2Plan ot_res2_choose(const gims_ot_problem* pr, int np, int iters) {
   OtR2Plan none{};
-  if (tl_streamed_only || !ot_env("GIMS_OT_RES2", 1) || !ot_env("GIMS_OT_RESIDENT", 1) || iters < 1 || ot_res_cus() < 256) return none;
+  if (tl_streamed_only || !ot_env("GIMS_OT_RESIDENT", 1) || iters < 1 || ot_cus() < 256) return none;
   // (no size gate: measured down to one problem of 128^2 the 2-D kernel's ~5.5 us per iteration beats the two launches per
-  // iteration of the streamed kernels -- 0.60 vs 0.75 ms per 100 iterations; the 1-D kernel below keeps its 6 M-entry gate)
+  // iteration of the streamed kernels -- 0.60 vs 0.75 ms per 100 iterations)
   std::vector<OtR2Host> h(np);
   for (int i = 0; i < np; ++i) { h[i] = OtR2Host{}; h[i].n = pr[i].n; h[i].m = pr[i].m; }
   return ot_res2_plan(h.data(), np, iters);
 }
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static void ot_launch_shape(const gims_ot_problem* pr, int np, int& threads, int& cpt, int& maxn, int& maxm) {
   maxn = 0; maxm = 0;
@@ -1831,17 +1149,14 @@ extern "C" size_t gims_sinkhorn_workspace_bytes(const gims_ot_problem* pr, int32
   ot_launch_shape(pr, np, threads, cpt, maxn, maxm);
   size_t b = al256(sizeof(OtDev) * (size_t)np);
   for (int i = 0; i < np; ++i) b += ot_problem_bytes(pr[i], ot_G(pr[i].n, np, threads, cpt));
-  const size_t r1 = ot_res_plan(pr, np, 1).bytes, r2 = ot_res2_choose(pr, np, 1).bytes;
-  return b + al256(r1 > r2 ? r1 : r2);                  // on-chip-path buffers (0 when that path is off or does not fit)
+  return b + al256(ot_res2_choose(pr, np, 1).bytes);    // on-chip-path buffers (0 when that path is off or does not fit)
 }
 
 extern "C" int gims_sinkhorn_plan(const gims_ot_problem* pr, int32_t np, int32_t iters) {
   using namespace gims;
   if (!pr || np <= 0) return 0;
   const OtR2Plan p2 = ot_res2_choose(pr, np, iters);
-  if (p2.ok) return p2.ngroups;
-  const OtResPlan plan = ot_res_plan(pr, np, iters);
-  return plan.ok ? plan.ngroups : 0;
+  return p2.ok ? p2.ngroups : 0;
 }
 
 extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float alpha, int32_t iters,
@@ -1892,9 +1207,16 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   // the 2-D on-chip kernel forms the start potentials itself (GIMS_OT_R2_INIT=0: the separate sweep, for cross-checks)
   const int init_inside = plan2.ok && ot_env("GIMS_OT_R2_INIT", 1) ? 1 : 0;
   if (init_inside) hipLaunchKernelGGL(ot_status0_kernel, dim3(cdiv(np, 256)), dim3(256), 0, s, dp, np);
-  else hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, iters == 0 ? 1 : 0);
+  else hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, iters == 0 ? 1 : 0, 0);
   dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
-  OtResPlan plan = plan2.ok ? OtResPlan{} : ot_res_plan(pr, np, iters);
+  auto streamed_iterations = [&](int rescue) {
+    for (int it = 0; it < iters; ++it) {
+      if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha, rescue);
+      else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha, rescue);
+      else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha, rescue);
+      hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp, -1, rescue);
+    }
+  };
   if (plan2.ok) {     // whole iteration loop on chip, 2-D decomposition (sinkhorn2d.hip)
     std::vector<OtR2Host> h2(np);
     for (int i = 0; i < np; ++i) {
@@ -1903,23 +1225,33 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     }
     const int rc = ot_res2_run(plan2, h2.data(), np, alpha, iters, init_inside, base + off, s);
     if (rc != GIMS_OK) return rc;
-    plan.ok = true;   // (the rescue and the skipped streamed loop below are shared)
-  } else if (plan.ok) {      // whole iteration loop on chip (one launch per group of problems)
-    const int rc = ot_res_run(plan, hprob, alpha, iters, base + off, s);
-    if (rc != GIMS_OK) return rc;
-  }
-  if (plan.ok) {
-    const int force_fail = ot_env("GIMS_OT_FORCE_FAIL", 0);       // test hook: pretend every resident solve timed out
+    const int force_fail = ot_env("GIMS_OT_FORCE_FAIL", 0);       // test hook: pretend every on-chip solve timed out
     if (force_fail) hipLaunchKernelGGL(ot_poison_kernel, dim3(np), dim3(256), 0, s, dp);
-    // problems whose on-chip solve gave up (status 2) are re-solved here, before the selection kernels read u and v:
-    // an empty launch otherwise (see ot_rescue_kernel)
-    hipLaunchKernelGGL(ot_rescue_kernel, dim3(np), dim3(1024), 0, s, dp, alpha, iters, 0);
-  }
-  for (int it = 0; it < (plan.ok ? 0 : iters); ++it) {
-    if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha);
-    else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha);
-    else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha);
-    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp, -1);
+    // Problems whose on-chip solve gave up (status 2) are re-solved here, before the selection kernels read u and v.
+    OtRescueState* rs = ot_rescue_state();
+    if (!rs) { set_error("gims_sinkhorn_match: no rescue state on this device"); return GIMS_EHIP; }
+    const int mode = ot_env("GIMS_OT_RESCUE", -1);                // 0: one-workgroup kernel only, 1: streamed always, default: streamed while marginal
+    bool marginal;
+    {
+      std::lock_guard<std::mutex> lock(g_rescue_mu);
+      rs->calls += 1;
+      if (*rs->h_count != rs->seen) { rs->seen = *rs->h_count; rs->last_giveup_call = rs->calls; }
+      marginal = mode == 1 || (mode != 0 && rs->calls - rs->last_giveup_call <= OT_MARGINAL_CALLS);
+    }
+    if (marginal) {
+      hipLaunchKernelGGL(ot_rescue_begin_kernel, dim3(cdiv(np, 256)), dim3(256), 0, s, dp, np, rs->d_count);
+      hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, 0, 1);
+      streamed_iterations(1);
+      hipLaunchKernelGGL(ot_rescue_end_kernel, dim3(cdiv(np, 256)), dim3(256), 0, s, dp, np);
+    }
+    // last resort (and the only rescue while the device is not marginal): an empty launch unless a status word still reads 2
+    hipLaunchKernelGGL(ot_rescue_kernel, dim3(np), dim3(1024), 0, s, dp, alpha, iters, 0, rs->d_count);
+    if (hipEventQuery(rs->ev) != hipErrorNotReady) {              // the previous read-back has landed: start the next one
+      GIMS_HIP(hipMemcpyAsync((void*)rs->h_count, rs->d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+      GIMS_HIP(hipEventRecord(rs->ev, s));
+    }
+  } else {
+    streamed_iterations(0);
   }
   if (cpt == 1) hipLaunchKernelGGL(ot_select_kernel<1>, gi, dim3(threads), 0, s, dp);
   else if (cpt == 2) hipLaunchKernelGGL(ot_select_kernel<2>, gi, dim3(threads), 0, s, dp);
@@ -1929,6 +1261,17 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   hipLaunchKernelGGL(ot_mutual_kernel, dim3(cdiv(mx, 256), np), dim3(256), 0, s, dp, match_threshold);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
+}
+
+extern "C" int64_t gims_sinkhorn_rescues(void) {
+  using namespace gims;
+  OtRescueState* rs = ot_rescue_state();
+  int n = 0;
+  if (!rs || hipDeviceSynchronize() != hipSuccess || hipMemcpy(&n, rs->d_count, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+    set_error("gims_sinkhorn_rescues: the counter of the current device could not be read");
+    return -1;
+  }
+  return n;
 }
 
 extern "C" int gims_sinkhorn_plan_ex(const gims_ot_problem* pr, int32_t np, int32_t iters, int32_t flags) {
@@ -2015,13 +1358,13 @@ extern "C" int gims_sinkhorn_history(const gims_ot_problem* pr, int32_t np, floa
   const int rc = upload_table(hprob.data(), sizeof(OtDev) * (size_t)np, work, s);
   if (rc != GIMS_OK) return rc;
   const OtDev* dp = (const OtDev*)work;
-  hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, 0);
+  hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, 0, 0);
   dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
   for (int it = 0; it < iters; ++it) {        // the streamed kernels, one iteration at a time
-    if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha);
-    else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha);
-    else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha);
-    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp, it + 1);      // writes u, v of this iteration into the history itself
+    if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha, 0);
+    else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha, 0);
+    else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha, 0);
+    hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp, it + 1, 0);      // writes u, v of this iteration into the history itself
   }
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
@@ -2086,14 +1429,7 @@ extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, flo
   if (rc != GIMS_OK) return rc;
   const OtBwd* dp = (const OtBwd*)work;
   const int mx = maxn > maxm ? maxn : maxm;
-  if (ot_env("GIMS_OT_BWD_UNFUSED", 0)) {          // the unfused statement of the sweep (cross-check)
-    hipLaunchKernelGGL(ot_bwd_init_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
-    for (int k = iters; k >= 1; --k) {
-      hipLaunchKernelGGL(ot_bwd_col_kernel, dim3(cdiv(maxn + 1, 4), np), dim3(256), 0, s, dp, alpha, k);
-      hipLaunchKernelGGL(ot_bwd_row_kernel, dim3(cdiv(maxm + 1, 256), np), dim3(256), 0, s, dp, alpha, k);
-      hipLaunchKernelGGL(ot_bwd_swap_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);
-    }
-  } else if (iters <= OT_BWD_MAX_ITERS && cdiv(maxm + 1, 512) <= 9 && !ot_env("GIMS_OT_BWD_INPLACE", 0)) {
+  if (iters <= OT_BWD_MAX_ITERS && cdiv(maxm + 1, 512) <= 9 && !ot_env("GIMS_OT_BWD_INPLACE", 0)) {
     // low-rank form: reductions only per iteration, one K = 2 iters product at the end
     const dim3 gs(cdiv(maxn + 1, BW_ROWS), np), gc(cdiv(maxm + 1, 32), np);
     const int cpt = cdiv(maxm + 1, 512);

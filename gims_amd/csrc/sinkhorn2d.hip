@@ -29,6 +29,8 @@
 
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -58,7 +60,7 @@ struct OtR2Args {
 constexpr int R2_CSEG = 132;                    // floats per (workgroup, buffer) of the column edge: 128 columns + dustbin + pad
 constexpr int R2_LDS_K = 16 * 512 * 4;          // 4 tile rows x 4 quads per thread, float4 each
 constexpr int R2_ROWST = 1028, R2_FACS = 1160, R2_GVEC = 132, R2_COLRED = 8 * 128, R2_PB = 1028, R2_PR = 132, R2_CSST = 132, R2_XRD = 4 * R2_CSEG;
-constexpr int R2_OWN = 2 * 132 + 2 * 132;      // v and G of the block's columns; u and F of the row slots this workgroup folds (rbf <= 132)
+constexpr int R2_OWN = 2 * 132 + 2 * 132;      // v and G of the block's columns; u and F of the row slots this workgroup folds (rbf <= R2_FOLD = 132: r2_geom)
 constexpr int R2_LDS_FLOATS = R2_LDS_K + R2_ROWST + R2_FACS + R2_GVEC + R2_COLRED + R2_PB + R2_PR + R2_CSST + R2_XRD + 16 + R2_OWN;
 
 typedef float r2f2 __attribute__((ext_vector_type(2)));
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
     }
     __syncthreads();
     if (fail_flag) {
-      if (threadIdx.x == 0) p.status[0] = 2.f;
+      if (threadIdx.x == 0) ot_raise_status(p.status, 2.f);
       return;
     }
     stamp(1);
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
           const int s = fs0 + e;
           if (s < nslots) {
             const float tr = fo[e] * tot[e];                                  // true row sum F_i sum_j K_ij G_j
-            if (!(tr > 0.f) || !(tr < 3.0e38f)) p.status[0] = 1.f;
+            if (!(tr > 0.f) || !(tr < 3.0e38f)) ot_raise_status(p.status, 1.f);
             const float du = (s < nrl ? p.norm : p.log_mu_bin) - logf(tr);
             uo[e] += du;
             fo[e] *= __expf(du);
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
       float vown = vown_l[t], gown = gown_l[t];
       if (own) {
         const float tr = gown * ctot;                                           // true column sum G_j sum_i F_i K_ij
-        if (!(tr > 0.f) || !(tr < 3.0e38f)) p.status[0] = 1.f;
+        if (!(tr > 0.f) || !(tr < 3.0e38f)) ot_raise_status(p.status, 1.f);
         const float dv = (t < 128 ? p.norm : p.log_nu_bin) - logf(tr);
         vown += dv;
         gown *= __expf(dv);
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
   if (PROF && blockIdx.x == 0 && threadIdx.x < 8) a.prof[threadIdx.x] = prof_acc[threadIdx.x];
   __syncthreads();
   if (fail_flag) {
-    if (threadIdx.x == 0) p.status[0] = 2.f;
+    if (threadIdx.x == 0) ot_raise_status(p.status, 2.f);
     return;
   }
   // ---------------- potentials out (the selection kernels read Z, u, v)
@@ -734,21 +736,34 @@ static inline int r2_up4(int x) { return (x + 3) & ~3; }
 // function of ITS OWN size only: a ragged list is split into classes of equal (nx, nc) and every class gets its own launches.  (One geometry
 // per call, taken from the largest problem, made a 256-keypoint pair's potentials depend on what else was in the batch: 5.6e-6 on the scores
 // between match_pairs and forward() on the same pair.)
+// (nx, nc) of one problem: nx row groups of <= 1024 rows; nc = the smallest power of two of <= 128-column blocks that covers m, RAISED
+// until the row slots a workgroup folds (rbf = up4(ceil((rb + 1) / nc)): u and F of them live in uo_l / fo_l) fit R2_FOLD = 132 --
+// a tall, narrow problem (m <= 512 with more than ~132 nc rows per group) otherwise indexes past those arrays.  nc = 32 always fits
+// (rbf <= 36).  false: no on-chip geometry (empty or oversized problem).
+constexpr int R2_FOLD = 132;
+static inline bool r2_geom(int n, int m, int& nx, int& nc) {
+  if (n < 1 || m < 1 || n > 4096 || m > 4096) return false;
+  nc = 1;
+  while (nc * 128 < m) nc *= 2;
+  nx = cdiv(n, 1024);
+  const int rb = cdiv(n, nx);
+  while (nc < 32 && r2_up4(cdiv(rb + 1, nc)) > R2_FOLD) nc *= 2;
+  return r2_up4(cdiv(rb + 1, nc)) <= R2_FOLD;
+}
 static inline int r2_class_key(const OtR2Host& h) {
-  int nc = 1;
-  while (nc * 128 < h.m) nc *= 2;
-  return cdiv(h.n > 1 ? h.n : 1, 1024) * 64 + nc;
+  int nx = 0, nc = 0;
+  return r2_geom(h.n, h.m, nx, nc) ? nx * 64 + nc : -1;
 }
 
 static OtR2Plan plan_class(const OtR2Host* pr, int np, int iters) {
   OtR2Plan P{};
   if (iters < 1 || np < 1) return P;
-  int maxn = 0, maxm = 0;
-  for (int i = 0; i < np; ++i) { maxn = pr[i].n > maxn ? pr[i].n : maxn; maxm = pr[i].m > maxm ? pr[i].m : maxm; }
-  if (maxn > 4096 || maxm > 4096) return P;
-  int nc = 1;
-  while (nc * 128 < maxm) nc *= 2;                                  // column blocks per row group: a power of two <= 32
-  const int nx = cdiv(maxn, 1024);
+  int nx = 0, nc = 0;
+  if (!r2_geom(pr[0].n, pr[0].m, nx, nc)) return P;                 // (every problem of a class has the same geometry: r2_classes)
+  for (int i = 1; i < np; ++i) {
+    int nxi = 0, nci = 0;
+    if (!r2_geom(pr[i].n, pr[i].m, nxi, nci) || nxi != nx || nci != nc) return P;
+  }
   const int units = 8 * (32 / nc);                                  // row groups one launch holds (each on the CUs of one XCD)
   if (nx > units) return P;
   P.nx = nx; P.nc = nc;
@@ -760,6 +775,7 @@ static OtR2Plan plan_class(const OtR2Host* pr, int np, int iters) {
   for (int i = 0; i < np; ++i) {
     const int rb = cdiv(pr[i].n, nx);
     const int rbf = r2_up4(cdiv(rb + 1, nc)), rbs = nc * rbf;
+    if (rbf > R2_FOLD || rb > 1024 || r2_up4(cdiv(pr[i].m, nc)) > 128) return P;
     b += 2 * r2_al((size_t)nx * nc * rbs * 4) + r2_al((size_t)nx * 2 * rbs * 4) + r2_al((size_t)2 * nx * nc * R2_CSEG * 4);
   }
   P.bytes = b;
@@ -799,6 +815,26 @@ OtR2Plan ot_res2_plan(const OtR2Host* pr, int np, int iters) {
 }
 
 static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha, int iters, int init_inside, char* base, hipStream_t s);
+
+// per-device state of the launcher (created once per device under a lock)
+struct R2State { int resident_ok, wt_local; volatile int* h_place; hipEvent_t place_ev; };
+static R2State* r2_state(const void* kernel, size_t lds) {
+  static std::mutex mu;
+  static std::map<int, R2State> states;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = states.find(dev);
+  if (it != states.end()) return &it->second;
+  R2State st{};
+  int per_cu = 0, cus = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, lds);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  st.resident_ok = (e == hipSuccess && per_cu * cus >= 256) ? 1 : 0;
+  st.wt_local = r2_env("GIMS_OT_R2_WT", 0) ? 1 : 0;
+  st.h_place = (volatile int*)pinned_once("ot_res2_place", 256);
+  if (!st.h_place || hipEventCreateWithFlags(&st.place_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return &states.emplace(dev, st).first->second;
+}
 
 int ot_res2_run(const OtR2Plan&, const OtR2Host* hp, int np, float alpha, int iters, int init_inside, char* base, hipStream_t s) {
   size_t off = 0;
@@ -842,36 +878,20 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
   GIMS_HIP(hipMemsetAsync(dplace, 0, 256, s));
   int rc = upload_table(hd.data(), sizeof(OtR2Dev) * (size_t)np, dprob, s);
   if (rc != GIMS_OK) return rc;
-  static bool attr = false;
   constexpr size_t lds = R2_LDS_FLOATS * sizeof(float);
-  if (!attr) {
-    GIMS_HIP(hipFuncSetAttribute((const void*)ot_res2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    GIMS_HIP(hipFuncSetAttribute((const void*)ot_res2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
-  // all 256 workgroups wait on each other: they must be co-resident (one per CU) -- checked once against the occupancy query
-  static int resident_ok = -1;
-  if (resident_ok < 0) {
-    int per_cu = 0, dev = 0, cus = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ot_res2_kernel<false>, 512, lds);
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    resident_ok = (e == hipSuccess && per_cu * cus >= 256) ? 1 : 0;
-  }
-  if (!resident_ok) {
+  GIMS_LDS_ATTR((const void*)ot_res2_kernel<false>, (int)lds);
+  GIMS_LDS_ATTR((const void*)ot_res2_kernel<true>, (int)lds);
+  R2State* st = r2_state((const void*)ot_res2_kernel<false>, lds);
+  if (!st) { set_error("ot_res2_run: no per-device state"); return GIMS_EHIP; }
+  // all 256 workgroups wait on each other: they must be co-resident (one per CU) -- checked once per device against the occupancy query
+  if (!st->resident_ok) {
     set_error("the on-chip Sinkhorn kernel does not fit: 256 workgroups of 512 threads with %zu bytes of LDS are not co-resident on this device", lds);
     return GIMS_EHIP;
   }
   // write-through stores on the local edges as well when the dispatcher was seen to place blocks elsewhere than XCD b % 8 (sticky per
-  // process; read back lazily: the flag of call k is looked at by call k + 1, without a synchronisation of its own)
-  static int wt_local = -1;
-  static int* h_place = nullptr;
-  static hipEvent_t place_ev = nullptr;
-  if (wt_local < 0) {
-    wt_local = r2_env("GIMS_OT_R2_WT", 0) ? 1 : 0;
-    if (hipHostMalloc((void**)&h_place, sizeof(int)) != hipSuccess) h_place = nullptr;
-    if (h_place) { *h_place = 0; if (hipEventCreateWithFlags(&place_ev, hipEventDisableTiming) != hipSuccess) place_ev = nullptr; }
-  }
-  if (h_place && *h_place) wt_local = 1;
+  // device; read back lazily: the flag of call k is looked at by call k + 1, without a synchronisation of its own)
+  if (*st->h_place) st->wt_local = 1;
+  const int wt_local = st->wt_local;
   const int refresh = r2_env("GIMS_OT_REFRESH", 50);
   const int prof = r2_env("GIMS_OT_PROF", 0);
   for (int gi = 0; gi < P.ngroups; ++gi) {
@@ -889,8 +909,8 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
     OtR2Args a{};
     a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local; a.init_inside = init_inside;
     if (prof) {
-      static unsigned long long* dprof = nullptr;
-      if (!dprof) GIMS_HIP(hipMalloc((void**)&dprof, 8 * sizeof(unsigned long long)));
+      unsigned long long* dprof = (unsigned long long*)device_once("ot_res2_prof", 8 * sizeof(unsigned long long), nullptr);
+      GIMS_CHECK_ARG(dprof, "ot_res2_run: no profile buffer");
       a.prof = dprof;
       hipLaunchKernelGGL(ot_res2_kernel<true>, dim3(256), dim3(512), lds, s, a);
       GIMS_LAUNCH_CHECK();
@@ -913,10 +933,10 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
     GIMS_HIP(hipMemcpy(h, dplace, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[ot_res2 debug] nx=%d nc=%d placement flag %d, last bounded wait that ran out: site %d\n", P.nx, P.nc, h[0], h[1]);
   }
-  if (h_place && place_ev && !wt_local) {
-    if (hipEventQuery(place_ev) != hipErrorNotReady) {      // the previous read-back (if any) has landed: start the next one
-      GIMS_HIP(hipMemcpyAsync(h_place, dplace, sizeof(int), hipMemcpyDeviceToHost, s));
-      GIMS_HIP(hipEventRecord(place_ev, s));
+  if (!wt_local) {
+    if (hipEventQuery(st->place_ev) != hipErrorNotReady) {      // the previous read-back (if any) has landed: start the next one
+      GIMS_HIP(hipMemcpyAsync((void*)st->h_place, dplace, sizeof(int), hipMemcpyDeviceToHost, s));
+      GIMS_HIP(hipEventRecord(st->place_ev, s));
     }
   }
   return GIMS_OK;

@@ -185,6 +185,7 @@ _SIGNATURES = {
     "gims_sinkhorn_match": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_float,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "gims_sinkhorn_plan_ex": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_int32, C.c_int32]),
+    "gims_sinkhorn_rescues": (C.c_int64, []),
     "gims_sinkhorn_match_ex": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_float,
                                          C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "gims_eval_workspace_bytes": (C.c_size_t, [C.POINTER(EvalPair), C.c_int32, C.c_int32]),
@@ -710,6 +711,14 @@ OT_STREAMED = 1      # flag of sinkhorn_plan / sinkhorn_match: never an on-chip 
 def sinkhorn_plan(problems, iters: int, flags: int = 0) -> int:
     """0: streamed kernels (one launch per iteration); k > 0: on-chip resident kernel in k launches."""
     return int(load().gims_sinkhorn_plan_ex(problems, len(problems), int(iters), int(flags)))
+
+
+def sinkhorn_rescues() -> int:
+    """On-chip solves of this process that gave up and were re-solved by a rescue path on the current device (synchronises)."""
+    n = int(load().gims_sinkhorn_rescues())
+    if n < 0:
+        _check(GIMS_EHIP if "GIMS_EHIP" in globals() else 2, "gims_sinkhorn_rescues")
+    return n
 
 
 def sinkhorn_match(problems, alpha: float, iters: int, match_threshold: float, work: torch.Tensor, flags: int = 0):

@@ -336,6 +336,12 @@ int gims_sinkhorn_plan_ex(const gims_ot_problem* h_problems, int32_t n_problems,
 int gims_sinkhorn_match_ex(const gims_ot_problem* h_problems /* HOST array */, int32_t n_problems, float alpha,
                            int32_t iters, float match_threshold, void* work, size_t work_bytes, int32_t flags, void* stream);
 
+/* Diagnostics: how many on-chip solves gave up and were re-solved by a rescue path on the CURRENT device since the process started
+ * (synchronises the device; -1 on error).  A given-up solve is re-solved inside the same call -- by the streamed kernels when a
+ * give-up was seen during the last 256 calls (GIMS_OT_RESCUE=1: always), else by a one-workgroup kernel -- so results never
+ * depend on it; the counter lets a caller (and the tests) see that it happened.  No reference counterpart. */
+int64_t gims_sinkhorn_rescues(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Per-pair evaluation after the matcher -- batched over pairs, everything stays on the device.
  * replaces: the per-pair block of eval_homography.py:186-226 --

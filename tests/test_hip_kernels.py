@@ -507,9 +507,15 @@ def test_sinkhorn_match(hip, monkeypatch, n, m, iters, scale, resident):
                                              # chip-wide barrier mode (a problem needs more than the 32 CUs of one XCD), two launches
                                              ("2", [(2300, 2200), (2100, 2250), (1500, 2300), (2290, 2100)]),
                                              # XCD-local mode with more problems than one launch holds
-                                             ("2", [(600 + 7 * i, 640 - 5 * i) for i in range(40)])])
+                                             ("2", [(600 + 7 * i, 640 - 5 * i) for i in range(40)]),
+                                             # tall and narrow: with the fewest column blocks that cover m, a workgroup would fold more
+                                             # row slots than its LDS arrays hold -- the planner raises the number of column blocks instead
+                                             ("2", [(600, 300), (1024, 500), (300, 100), (900, 130), (1024, 5), (4096, 2), (2049, 129)]),
+                                             # empty trailing column blocks (m just over a multiple of the block width) and single rows / columns
+                                             ("2", [(2100, 2049), (1, 1), (1, 700), (700, 1), (513, 2108)])])
 def test_sinkhorn_batched_ragged(hip, monkeypatch, resident, shapes):
     monkeypatch.setenv("GIMS_OT_RESIDENT", resident)
+    rescues0 = hip.sinkhorn_rescues()
     r = _rng(9)
     items, refs = [], []
     for n, m in shapes:
@@ -532,6 +538,9 @@ def test_sinkhorn_batched_ragged(hip, monkeypatch, resident, shapes):
         assert safe.mean() > 0.9
         np.testing.assert_array_equal(it["matches0"].cpu().numpy()[safe], i0[0].numpy()[safe])     # every well-conditioned row: exact
         assert float(it["uv"][-1]) == 0.0
+    if resident == "2":
+        assert hip.sinkhorn_plan(probs, 30) > 0
+    assert hip.sinkhorn_rescues() == rescues0, "an on-chip solve gave up and was re-solved by the rescue path"
 
 
 def test_sinkhorn_history_of_a_ragged_batch(hip):
@@ -590,11 +599,13 @@ def test_sinkhorn_resident_matches_streamed(hip, monkeypatch):
         assert float((a["mscores0"] - b["mscores0"]).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("coop", ["1", "0"])
-def test_sinkhorn_resident_giveup_is_rescued(hip, monkeypatch, coop):
+@pytest.mark.parametrize("rescue", ["0", "1"])
+def test_sinkhorn_resident_giveup_is_rescued(hip, monkeypatch, rescue):
     """A resident solve that gives up (status 2, garbage potentials -- forced here by GIMS_OT_FORCE_FAIL=1, which poisons
-    u, v and the status word after the on-chip launches) is re-solved INSIDE the same call by the dependency-free rescue
-    kernel: the caller gets status 0, the streamed path's potentials (f32 rounding) and exactly its matches -- never -1s."""
+    u, v and the status word after the on-chip launches) is re-solved INSIDE the same call -- by the one-workgroup kernel
+    (GIMS_OT_RESCUE=0: what the first give-up of a process gets) or by the streamed kernels (GIMS_OT_RESCUE=1: what every give-up
+    gets while one was seen during the last 256 calls): the caller gets status 0, the streamed path's potentials (f32 rounding)
+    and exactly its matches -- never -1s -- and the counter of re-solved problems moves."""
     gg = torch.Generator(device="cpu").manual_seed(11)
     zs = []
     for n, m in ((700, 650), (300, 333), (1022, 1024), (64, 31)):
@@ -607,7 +618,8 @@ def test_sinkhorn_resident_giveup_is_rescued(hip, monkeypatch, coop):
     for mode, fail in (("0", "0"), ("2", "1")):
         monkeypatch.setenv("GIMS_OT_RESIDENT", mode)
         monkeypatch.setenv("GIMS_OT_FORCE_FAIL", fail)
-        monkeypatch.setenv("GIMS_OT_COOP", coop)
+        monkeypatch.setenv("GIMS_OT_RESCUE", rescue)
+        before = hip.sinkhorn_rescues()
         items = [dict(scores=z.cuda(), n=n, m=m, matches0=torch.empty(n, dtype=torch.int64, device="cuda"),
                       matches1=torch.empty(m, dtype=torch.int64, device="cuda"), mscores0=torch.empty(n, device="cuda"),
                       mscores1=torch.empty(m, device="cuda"), uv=torch.empty(n + m + 3, device="cuda")) for n, m, z in zs]
@@ -617,6 +629,7 @@ def test_sinkhorn_resident_giveup_is_rescued(hip, monkeypatch, coop):
         work = torch.empty(hip.sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device="cuda")
         hip.sinkhorn_match(probs, 1.0, 30, 0.2, work)
         outs[mode] = items
+        assert hip.sinkhorn_rescues() - before == (len(zs) if fail == "1" else 0)
     for a, b in zip(outs["0"], outs["2"]):
         assert float(b["uv"][-1]) == 0.0
         assert torch.isfinite(b["uv"]).all()
@@ -624,6 +637,43 @@ def test_sinkhorn_resident_giveup_is_rescued(hip, monkeypatch, coop):
         assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches1"], b["matches1"])
         assert int((b["matches0"] >= 0).sum()) > 0
         assert float((a["mscores0"] - b["mscores0"]).abs().max()) < 1e-5
+
+
+def test_sinkhorn_streamed_rescue_has_no_cliff(hip, monkeypatch):
+    """a given-up 4096 x 4096 solve re-solved by the STREAMED kernels (device-side early exit keyed on the status
+    word) costs at most twice a plain streamed solve -- the one-workgroup kernel takes ~0.25 s for it.  Timed with events around
+    whole calls (on-chip launch + poison + rescue included on the rescue side)."""
+    gg = torch.Generator(device="cpu").manual_seed(5)
+    n = m = 4096
+    z = (torch.randn(n, m, generator=gg) * 3).cuda()
+
+    def run(resident, fail, rescue):
+        monkeypatch.setenv("GIMS_OT_RESIDENT", resident)
+        monkeypatch.setenv("GIMS_OT_FORCE_FAIL", fail)
+        monkeypatch.setenv("GIMS_OT_RESCUE", rescue)
+        it = dict(scores=z, n=n, m=m, matches0=torch.empty(n, dtype=torch.int64, device="cuda"), matches1=torch.empty(m, dtype=torch.int64, device="cuda"),
+                  mscores0=torch.empty(n, device="cuda"), mscores1=torch.empty(m, device="cuda"), uv=torch.empty(n + m + 3, device="cuda"))
+        probs = hip.make_ot_problems([it])
+        work = torch.empty(hip.sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device="cuda")
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hip.sinkhorn_match(probs, 1.0, 100, 0.2, work)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best, it
+
+    t_streamed, a = run("0", "0", "0")
+    t_rescued, b = run("2", "1", "1")
+    assert float(b["uv"][-1]) == 0.0 and torch.equal(a["matches0"], b["matches0"])
+    assert float((a["uv"][:-1] - b["uv"][:-1]).abs().max()) < 1e-4
+    assert t_rescued <= 2.0 * t_streamed + 4.0, f"streamed rescue {t_rescued:.2f} ms vs streamed solve {t_streamed:.2f} ms"
+    # and when nothing gave up, the armed rescue costs near-empty launches only
+    t_armed, _ = run("2", "0", "1")
+    t_plain, _ = run("2", "0", "0")
+    assert t_armed <= t_plain + 1.5, f"armed {t_armed:.2f} ms vs {t_plain:.2f} ms"
 
 
 # --------------------------------------------------------------------------------------------- small kernels
