@@ -34,21 +34,42 @@ constexpr int QB = QW * ATT_WAVES;
 constexpr int VR_LD = 80;       // pitch of a ROW-MAJOR V tile [key][d] in bf16 elements (160 bytes): filled by LDS-DMA, read by ds_read_b64_tr_b16
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// The 16-bit operand format of a kernel instance: bf16 (v_mfma_f32_32x32x16_bf16) or, F16, IEEE half (v_mfma_f32_32x32x16_f16: the
+// same rate, three more mantissa bits, range 65504).  Fragments travel as 8 x 16-bit lanes either way (LDS images, DMA and the
+// transposing reads are type-agnostic); only the MFMA opcode and the f32 -> 16-bit packing of P differ (both round to nearest even).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_16b(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ uint32_t pack_16b(float lo, float hi) {
+  if constexpr (F16) {
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));     // v_cvt_pk_f16_f32
+  } else return pack_bf2(lo, hi);
+}
+
 __device__ __forceinline__ int k_off(int row, int chunk) {  // K tile: [64 keys][64 d], 16-byte chunks swizzled
   return row * DH + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
 // Peakedness statistic of the softmax rows a wave just finished (attention_precision='auto' of the Python shell decides per
 // layer between this file's bf16 kernels and attention_x3_kernel from it): per head, the sum over the reported queries of
-// the row maximum of P in 2^-24 fixed point, the number of reported queries, and the largest row maximum.  Integer
-// atomics: the totals do not depend on the arrival order.  stat: [n_heads][4] uint64 {sum, count, max, unused}.
+// the row maximum of P in 2^-24 fixed point, the number of reported queries, the largest row maximum, and the number of reported
+// queries whose row maximum exceeds 1/2 (the TAIL of the distribution: a head with a few one-hot rows among many diffuse ones has a
+// small mean).  Integer atomics: the totals do not depend on the arrival order.  stat: [n_heads + 1][4] uint64 {sum, count, max, tail};
+// row n_heads belongs to attention_range_kernel.
 __device__ __forceinline__ void emit_peak_stat(unsigned long long* stat, int head, float pmax, bool valid) {
   const unsigned int fx = valid ? (unsigned int)(fminf(fmaxf(pmax, 0.f), 1.f) * 16777216.f + 0.5f) : 0u;
-  unsigned int sum = fx, cnt = valid ? 1u : 0u, mx = fx;        // <= 64 x 2^24: no overflow in 32 bits
+  unsigned int sum = fx, cnt = valid ? 1u : 0u, mx = fx, tail = (valid && pmax > 0.5f) ? 1u : 0u;        // <= 64 x 2^24: no overflow in 32 bits
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     sum += __shfl_xor(sum, o, 64);
     cnt += __shfl_xor(cnt, o, 64);
+    tail += __shfl_xor(tail, o, 64);
     const unsigned int other = __shfl_xor(mx, o, 64);
     mx = mx > other ? mx : other;
   }
@@ -56,10 +77,11 @@ __device__ __forceinline__ void emit_peak_stat(unsigned long long* stat, int hea
     atomicAdd(stat + 4 * head, (unsigned long long)sum);
     atomicAdd(stat + 4 * head + 1, (unsigned long long)cnt);
     atomicMax(stat + 4 * head + 2, (unsigned long long)mx);
+    if (tail) atomicAdd(stat + 4 * head + 3, (unsigned long long)tail);
   }
 }
 
-template <int QP>   // 32-query blocks per wave: 1 (32 queries/wave, 128/workgroup) or 2 (64 / 256)
+template <int QP, bool F16 = false>   // 32-query blocks per wave: 1 (32 queries/wave, 128/workgroup) or 2 (64 / 256); F16: operands and P in IEEE half
 __global__ __launch_bounds__(256) void attention_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
@@ -164,7 +186,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
       for (int s = 0; s < 4; ++s) {
         const bf16x8 kf = *(const bf16x8*)(Ks[buf] + k_off(b * 32 + li, 2 * s + lh));
 #pragma unroll
-        for (int qi = 0; qi < QP; ++qi) sacc[qi][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][s], sacc[qi][b], 0, 0, 0);
+        for (int qi = 0; qi < QP; ++qi) sacc[qi][b] = mfma_16b<F16>(kf, qf[qi][s], sacc[qi][b]);
       }
     __builtin_amdgcn_s_setprio(0);
     const int kbase = kt * KB;
@@ -213,10 +235,10 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {  // 16-key step h2 of block b: regs 8*h2 .. 8*h2+7
           uint4 pk;
-          pk.x = pack_bf2(pv[8 * h2 + 0], pv[8 * h2 + 1]);
-          pk.y = pack_bf2(pv[8 * h2 + 2], pv[8 * h2 + 3]);
-          pk.z = pack_bf2(pv[8 * h2 + 4], pv[8 * h2 + 5]);
-          pk.w = pack_bf2(pv[8 * h2 + 6], pv[8 * h2 + 7]);
+          pk.x = pack_16b<F16>(pv[8 * h2 + 0], pv[8 * h2 + 1]);
+          pk.y = pack_16b<F16>(pv[8 * h2 + 2], pv[8 * h2 + 3]);
+          pk.z = pack_16b<F16>(pv[8 * h2 + 4], pv[8 * h2 + 5]);
+          pk.w = pack_16b<F16>(pv[8 * h2 + 6], pv[8 * h2 + 7]);
           pf[qi][2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
         }
       }
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
         const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr[buf] + voff + 8 * VR_LD));
         const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-        for (int qi = 0; qi < QP; ++qi) o[qi][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][s], o[qi][i], 0, 0, 0);
+        for (int qi = 0; qi < QP; ++qi) o[qi][i] = mfma_16b<F16>(vf, pf[qi][s], o[qi][i]);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 constexpr int ATT8_WAVES = 8;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool PROF, bool NOFMA>     // NOFMA: Q carries the softmax scale (c == 1): the optimistic pass is P = exp2(S), reference 0
+template <bool PROF, bool NOFMA, bool F16 = false>     // NOFMA: Q carries the softmax scale (c == 1): the optimistic pass is P = exp2(S), reference 0
 __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int qi = 0; qi < QP; ++qi) sacc[qi][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][s], qf[qi][s], sacc[qi][b], 0, 0, 0);
+        for (int qi = 0; qi < QP; ++qi) sacc[qi][b] = mfma_16b<F16>(kf[b][s], qf[qi][s], sacc[qi][b]);
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // 8 LDS reads ...
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);    // ... then the 16 MFMAs (the scheduler otherwise serialises read -> wait -> MFMA)
   };
@@ -411,6 +433,63 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     // workgroup then repeats its tiles in the exact mode (running maximum, deferred rescale).
     // With the scale folded into Q (NOFMA) the optimistic pass needs no reference at all: P = exp2(S) as the MFMA left it
     // (row sums outside [1e-30, 1e30] send the workgroup to the exact pass) -- 64 fewer VALU per wave and tile again.
+    if constexpr (F16) {
+      if (!exact) {
+        // IEEE half has range 65504, so P = exp2(S) cannot go unreferenced like the bf16 pass above.  LAZY reference: the row maximum of
+        // the first key tile, raised only when a tile turns out to hold a score more than ~10 octaves above it -- seen from the lane's
+        // partial row sum (32 scores: a sum below 2^15 bounds every P below 2^15, no comparison per score), in which case the tile's
+        // own maximum becomes the reference, O and l are rescaled and the tile's exponentials are taken again (wave-uniform, at most
+        // once per tile, rare after the first tiles).  The reference never exceeds the true row maximum, so the dominant keys always
+        // sit in half's normal range (11-bit significand); keys 2^-14 below the reference go subnormal at an absolute 2^-25.
+        if (kt == 0) {
+          float tmax = -1e30f;
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
+          m_run[qi] = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        }
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+          const float mc = m_run[qi] * c;
+          f32x2 lsum2 = {0.f, 0.f};
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[r] = NOFMA ? __builtin_amdgcn_exp2f(sacc[qi][b][r] - mc) : __builtin_amdgcn_exp2f(fmaf(sacc[qi][b][r], c, -mc));
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) lsum2 += f32x2{pv[r], pv[r + 1]};
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              uint4 pk;
+              pk.x = pack_16b<F16>(pv[8 * h2 + 0], pv[8 * h2 + 1]);
+              pk.y = pack_16b<F16>(pv[8 * h2 + 2], pv[8 * h2 + 3]);
+              pk.z = pack_16b<F16>(pv[8 * h2 + 4], pv[8 * h2 + 5]);
+              pk.w = pack_16b<F16>(pv[8 * h2 + 6], pv[8 * h2 + 7]);
+              pf[qi][2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
+            }
+          }
+          const float lsum = lsum2.x + lsum2.y;
+          if (round == 1 || !__any(!(lsum < 32768.f))) { l_run[qi] += lsum; break; }
+          float tmax = -1e30f;
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+          const float m_new = fmaxf(m_run[qi], tmax);
+          const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
+          m_run[qi] = m_new;
+          l_run[qi] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qi][i][r] *= alpha;
+        }
+        return;
+      }
+    }
     const bool track = exact || (!NOFMA && kt == 0);
     if (track) {
       float tmax = -1e30f;
@@ -443,10 +522,10 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
         uint4 pk;
-        pk.x = pack_bf2(pv[8 * h2 + 0], pv[8 * h2 + 1]);
-        pk.y = pack_bf2(pv[8 * h2 + 2], pv[8 * h2 + 3]);
-        pk.z = pack_bf2(pv[8 * h2 + 4], pv[8 * h2 + 5]);
-        pk.w = pack_bf2(pv[8 * h2 + 6], pv[8 * h2 + 7]);
+        pk.x = pack_16b<F16>(pv[8 * h2 + 0], pv[8 * h2 + 1]);
+        pk.y = pack_16b<F16>(pv[8 * h2 + 2], pv[8 * h2 + 3]);
+        pk.z = pack_16b<F16>(pv[8 * h2 + 4], pv[8 * h2 + 5]);
+        pk.w = pack_16b<F16>(pv[8 * h2 + 6], pv[8 * h2 + 7]);
         pf[qi][2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
       }
     }
@@ -477,7 +556,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int qi = 0; qi < QP; ++qi) o[qi][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s][i], pf[qi][s], o[qi][i], 0, 0, 0);
+        for (int qi = 0; qi < QP; ++qi) o[qi][i] = mfma_16b<F16>(vf[s][i], pf[qi][s], o[qi][i]);
     __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);    // the V fragments are two 8-byte transposing reads each
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
   };
@@ -1044,7 +1123,7 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
 // key tiles, waves 4-7 the other half (own K / V^T staging buffers), and the two partial results (unnormalised O, running
 // maximum, row sum) are merged through LDS at the end -- the flash-decoding split, inside one workgroup: no workspace, no
 // second launch.  Same math and layouts as attention_bf16_kernel<1>.
-template <int NS>      // key parts per query block: 2 (eight waves) or 4 (sixteen waves)
+template <int NS, bool F16 = false>      // key parts per query block: 2 (eight waves) or 4 (sixteen waves); F16: operands and P in IEEE half
 __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
@@ -1129,7 +1208,7 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const bf16x8 kf = *(const bf16x8*)(Ks(half, buf) + k_off(b * 32 + li, 2 * s + lh));
-          sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[b], 0, 0, 0);
+          sacc[b] = mfma_16b<F16>(kf, qf[s], sacc[b]);
         }
       const int kbase = (NS * it + half) * KB;
       if (kbase + KB > pr.n_kv) {
@@ -1172,10 +1251,10 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           uint4 pk;
-          pk.x = pack_bf2(pv[8 * h2 + 0], pv[8 * h2 + 1]);
-          pk.y = pack_bf2(pv[8 * h2 + 2], pv[8 * h2 + 3]);
-          pk.z = pack_bf2(pv[8 * h2 + 4], pv[8 * h2 + 5]);
-          pk.w = pack_bf2(pv[8 * h2 + 6], pv[8 * h2 + 7]);
+          pk.x = pack_16b<F16>(pv[8 * h2 + 0], pv[8 * h2 + 1]);
+          pk.y = pack_16b<F16>(pv[8 * h2 + 2], pv[8 * h2 + 3]);
+          pk.z = pack_16b<F16>(pv[8 * h2 + 4], pv[8 * h2 + 5]);
+          pk.w = pack_16b<F16>(pv[8 * h2 + 6], pv[8 * h2 + 7]);
           pf[2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
         }
       }
@@ -1188,7 +1267,7 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
           const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(half, buf) + voff));
           const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Vr(half, buf) + voff + 8 * VR_LD));
           const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
-          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o[i], 0, 0, 0);
+          o[i] = mfma_16b<F16>(vf, pf[s], o[i]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA of the next K tile has landed
@@ -1256,6 +1335,7 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
 // (maximum, sum) per query, and a merge of the 32 partial pairs per query through LDS.  Row maximum of P = 1 / (sum of
 // exp2(s - max)).  A few microseconds per layer; the Python shell asks for it on every n-th batch only.
 constexpr int PS_WAVES = 16, PS_Q = 32;
+template <bool F16>
 __global__ __launch_bounds__(64 * PS_WAVES) void attention_peak_sample_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads,
     float c, unsigned long long* __restrict__ stat) {
@@ -1298,7 +1378,7 @@ __global__ __launch_bounds__(64 * PS_WAVES) void attention_peak_sample_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][s], qf[s], sacc, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) sacc = mfma_16b<F16>(kf[b][s], qf[s], sacc);
       float tmax = -1e30f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1334,6 +1414,131 @@ static_assert(SPLIT_LDS_BYTES<2> >= 1 * 4 * 35 * 64 * 4 && SPLIT_LDS_BYTES<4> >=
 
 }  // namespace gims
 
+namespace gims {
+// |Q| (as stored: with the softmax scale when the caller folded it in), |K|, |V| abs-max of the rows a launch touches, for the range
+// guard of the IEEE-half tier (finite range 65504): stat[n_heads][0..2] = the float bit patterns of the three maxima (positive floats
+// order like their bit patterns: atomicMax on the integer view).  kind: 0 bf16 / 1 half buffers [rows][ld] of 16-bit values; 2 SPL32
+// (the hi planes are read: |hi| is |x| to 2^-9).  One wave per row piece of 8 x 16 bytes; launched on measured batches only.
+__global__ __launch_bounds__(256) void attention_range_kernel(const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
+                                                              const gims_attn_problem* __restrict__ problems, int n_heads, int kind,
+                                                              unsigned long long* __restrict__ stat) {
+  const gims_attn_problem pr = problems[blockIdx.y];
+  const int width = n_heads * DH;                      // logical channels per matrix
+  const int cpr = width / 8;                           // 16-byte pieces per row and matrix
+  float mx[3] = {0.f, 0.f, 0.f};
+  for (int which = 0; which < 3; ++which) {
+    const int rows = which == 0 ? pr.n_q : pr.n_kv, off = which == 0 ? pr.q_off : pr.kv_off, col = which == 0 ? q_col : (which == 1 ? k_col : v_col);
+    const int64_t total = (int64_t)rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int r = (int)(i / cpr), pc = (int)(i - (int64_t)r * cpr);
+      const int ch = col + 8 * pc;
+      const uint16_t* src = qkv + (int64_t)(off + r) * ld + (kind == 2 ? spl_col(ch) : ch);
+      const uint4 w = *(const uint4*)src;
+      const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a, b;
+        if (kind == 1) {
+          const f16x2 h = __builtin_bit_cast(f16x2, u[e]);
+          a = fabsf((float)h[0]); b = fabsf((float)h[1]);
+        } else {
+          a = fabsf(__uint_as_float(u[e] << 16)); b = fabsf(__uint_as_float(u[e] & 0xffff0000u));
+        }
+        mx[which] = fmaxf(mx[which], fmaxf(a, b));        // (NaN operands are dropped by fmaxf; inf is kept)
+      }
+    }
+  }
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    const float m = wave_max(mx[which]);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(stat + 4 * n_heads + which, (unsigned long long)__float_as_uint(m));
+  }
+}
+static int attention_range_launch(const uint16_t* qkv, int64_t ld, int q_col, int k_col, int v_col, const gims_attn_problem* problems, int n_problems,
+                                  int n_heads, int kind, unsigned long long* stat, hipStream_t stream) {
+  hipLaunchKernelGGL(attention_range_kernel, dim3(64, n_problems), dim3(256), 0, stream, qkv, ld, q_col, k_col, v_col, problems, n_heads, kind, stat);
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+
+// launch of the one-pass 16-bit kernels (F16 = false: bf16 operands, true: IEEE half), by launch shape
+template <bool F16>
+static int attention_16b_launch(const uint16_t* qkv, int64_t ld, int q_col, int k_col, int v_col, const gims_attn_problem* problems, int n_groups, int max_n_q,
+                                int n_heads, float* out, int64_t ld_out, uint16_t* out_hi, uint16_t* out_lo, int64_t ld_split, bool prescaled, float c,
+                                unsigned long long* stat, hipStream_t stream) {
+  int force = 0;
+  { const char* e = getenv("GIMS_ATTN_QP"); force = e ? atoi(e) : 0; }
+  const int blocks2 = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB);
+  const bool two = force == 2 || (force != 1 && blocks2 >= 512);
+  const int n_qt8 = cdiv(max_n_q, 512);
+  const bool eight = force == 8 || (force == 0 && 8 * cdiv(n_groups, 8) * n_qt8 >= 256);   // 8-wave workgroups of 512 queries
+  // a small launch (one pair through forward()): split the keys of every query block over two wave groups (GIMS_ATTN_QP=3: always)
+  const bool split = force == 3 || (force == 0 && !eight && !two && 8 * cdiv(n_groups, 8) * cdiv(max_n_q, QB) <= 512 && max_n_q >= 512);
+  if (split) {
+    GIMS_LDS_ATTR((const void*)attention_split_kernel<2, F16>, SPLIT_LDS_BYTES<2>);
+    GIMS_LDS_ATTR((const void*)attention_split_kernel<4, F16>, SPLIT_LDS_BYTES<4>);
+    const int n_qt = cdiv(max_n_q, QB);
+    const int wgs = 8 * cdiv(n_groups, 8) * n_qt;
+    int ns_env = 0;                                  // read per call: the tests switch between the two variants
+    { const char* e = getenv("GIMS_ATTN_SPLIT"); ns_env = e ? atoi(e) : 0; }
+    // four key parts (sixteen waves) when the launch is at most one workgroup per CU and the keys are many
+    const bool four = ns_env == 4 || (ns_env != 2 && wgs <= 256 && max_n_q >= 2048);
+    if (four)
+      hipLaunchKernelGGL((attention_split_kernel<4, F16>), dim3(wgs), dim3(1024), SPLIT_LDS_BYTES<4>, stream, qkv, ld, q_col, k_col, v_col, problems,
+                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
+    else
+      hipLaunchKernelGGL((attention_split_kernel<2, F16>), dim3(wgs), dim3(512), SPLIT_LDS_BYTES<2>, stream, qkv, ld, q_col, k_col, v_col, problems,
+                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
+  } else if (eight) {
+    int exact_only = 0;                         // GIMS_ATTN_EXACT=1: running-maximum softmax only (no optimistic pass)
+    { const char* e = getenv("GIMS_ATTN_EXACT"); exact_only = e ? atoi(e) : 0; }
+    static int prof = -1;
+    if (prof < 0) { const char* e = getenv("GIMS_ATTN_PROF"); prof = e ? atoi(e) : 0; }
+    if (prof) {                                 // diagnostics only: synchronous, prints the phase anatomy of workgroup 0
+      unsigned long long* dprof = (unsigned long long*)device_once("attention8_prof", 24 * sizeof(unsigned long long), nullptr);
+      GIMS_CHECK_ARG(dprof, "gims_attention: no profile buffer");
+      if (prescaled)
+        hipLaunchKernelGGL((attention8_bf16_kernel<true, true, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
+      else
+        hipLaunchKernelGGL((attention8_bf16_kernel<true, false, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
+      GIMS_HIP(hipStreamSynchronize(stream));
+      unsigned long long h[24];
+      GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[attention8 wave 0 of workgroup 0] prologue %llu, tile loop %llu, epilogue %llu shader cycles; %.1f us on the 100-MHz counter -> %.2f GHz\n",
+              h[20], h[21], h[22], h[23] / 100.0, (double)(h[20] + h[21] + h[22]) / (h[23] / 100.0) * 1e-3);
+      for (int g = 0; g < 2; ++g)
+        fprintf(stderr, "[attention8 wave %d] cycles over the whole tile loop: QK %llu, softmax0 %llu, softmax1 %llu, PV %llu, store_tile %llu, "
+                "load_tile %llu, barrier wait %llu\n", 4 * g, h[g * 10 + 0], h[g * 10 + 2], h[g * 10 + 4], h[g * 10 + 8], h[g * 10 + 9], h[g * 10 + 6],
+                h[g * 10 + 7]);
+    } else {
+      if (prescaled)
+        hipLaunchKernelGGL((attention8_bf16_kernel<false, true, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c);
+      else
+        hipLaunchKernelGGL((attention8_bf16_kernel<false, false, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c);
+    }
+    if (stat) {          // the optimistic 8-wave kernel tracks no maximum: a sample of the rows is measured on the side
+      GIMS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(attention_peak_sample_kernel<F16>, dim3(n_groups), dim3(64 * PS_WAVES), 0, stream, qkv, ld, q_col, k_col, problems,
+                         n_groups, n_heads, c, stat);
+    }
+  } else if (two) {
+    const int n_qt = cdiv(max_n_q, 2 * QB);
+    hipLaunchKernelGGL((attention_bf16_kernel<2, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, stream, qkv, ld,
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
+  } else {
+    const int n_qt = cdiv(max_n_q, QB);
+    hipLaunchKernelGGL((attention_bf16_kernel<1, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, stream, qkv, ld,
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
+  }
+  GIMS_LAUNCH_CHECK();
+  return GIMS_OK;
+}
+}  // namespace gims
+
 extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
                               const gims_attn_problem* problems, int32_t n_problems, int32_t max_n_q,
                               int32_t n_heads, float* out, int64_t ld_out, uint16_t* out_hi, uint16_t* out_lo,
@@ -1361,6 +1566,13 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
   const float c = prescaled ? 1.f : 0.125f * 1.4426950408889634f;      // 1/sqrt(64) * log2(e)
   // 64 queries per wave (K/V fragments and barriers shared by two query blocks) when that still fills the chip
   // (environment read per call, not cached: the tests switch kernels with it)
+  const bool f16 = (flags & GIMS_ATTN_F16) != 0;
+  GIMS_CHECK_ARG(!(f16 && (flags & GIMS_ATTN_X3)), "gims_attention: GIMS_ATTN_F16 and GIMS_ATTN_X3 exclude each other");
+  if (stat) {          // range of the operands as stored (measured launches only): see attention_range_kernel
+    const int rc = attention_range_launch(qkv, ld, q_col, k_col, v_col, problems, n_problems, n_heads, (flags & GIMS_ATTN_X3) ? 2 : (f16 ? 1 : 0), stat,
+                                          (hipStream_t)stream);
+    if (rc != GIMS_OK) return rc;
+  }
   if (flags & GIMS_ATTN_X3) {                  // split-bf16 operands from the SPL32 Q/K/V buffer, three MFMAs per product
     GIMS_CHECK_ARG((q_col % 32) == 0 && (k_col % 32) == 0 && (v_col % 32) == 0 && (ld % 64) == 0,
                    "gims_attention: GIMS_ATTN_X3 takes logical column offsets that are multiples of 32 and an SPL32 pitch (multiple of 64)");
@@ -1391,74 +1603,9 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
     GIMS_LAUNCH_CHECK();
     return GIMS_OK;
   }
-  int force = 0;
-  { const char* e = getenv("GIMS_ATTN_QP"); force = e ? atoi(e) : 0; }
-  const int blocks2 = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB);
-  const bool two = force == 2 || (force != 1 && blocks2 >= 512);
-  const int n_qt8 = cdiv(max_n_q, 512);
-  const bool eight = force == 8 || (force == 0 && 8 * cdiv(n_groups, 8) * n_qt8 >= 256);   // 8-wave workgroups of 512 queries
-  // a small launch (one pair through forward()): split the keys of every query block over two wave groups (GIMS_ATTN_QP=3: always)
-  const bool split = force == 3 || (force == 0 && !eight && !two && 8 * cdiv(n_groups, 8) * cdiv(max_n_q, QB) <= 512 && max_n_q >= 512);
-  if (split) {
-    GIMS_LDS_ATTR((const void*)attention_split_kernel<2>, SPLIT_LDS_BYTES<2>);
-    GIMS_LDS_ATTR((const void*)attention_split_kernel<4>, SPLIT_LDS_BYTES<4>);
-    const int n_qt = cdiv(max_n_q, QB);
-    const int wgs = 8 * cdiv(n_groups, 8) * n_qt;
-    int ns_env = 0;                                  // read per call: the tests switch between the two variants
-    { const char* e = getenv("GIMS_ATTN_SPLIT"); ns_env = e ? atoi(e) : 0; }
-    // four key parts (sixteen waves) when the launch is at most one workgroup per CU and the keys are many
-    const bool four = ns_env == 4 || (ns_env != 2 && wgs <= 256 && max_n_q >= 2048);
-    if (four)
-      hipLaunchKernelGGL(attention_split_kernel<4>, dim3(wgs), dim3(1024), SPLIT_LDS_BYTES<4>, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col, problems,
-                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
-    else
-      hipLaunchKernelGGL(attention_split_kernel<2>, dim3(wgs), dim3(512), SPLIT_LDS_BYTES<2>, (hipStream_t)stream, qkv, ld, q_col, k_col, v_col, problems,
-                         n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
-  } else if (eight) {
-    int exact_only = 0;                         // GIMS_ATTN_EXACT=1: running-maximum softmax only (no optimistic pass)
-    { const char* e = getenv("GIMS_ATTN_EXACT"); exact_only = e ? atoi(e) : 0; }
-    static int prof = -1;
-    if (prof < 0) { const char* e = getenv("GIMS_ATTN_PROF"); prof = e ? atoi(e) : 0; }
-    if (prof) {                                 // diagnostics only: synchronous, prints the phase anatomy of workgroup 0
-      unsigned long long* dprof = (unsigned long long*)device_once("attention8_prof", 24 * sizeof(unsigned long long), nullptr);
-      GIMS_CHECK_ARG(dprof, "gims_attention: no profile buffer");
-      if (prescaled)
-        hipLaunchKernelGGL((attention8_bf16_kernel<true, true>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
-      else
-        hipLaunchKernelGGL((attention8_bf16_kernel<true, false>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
-      GIMS_HIP(hipStreamSynchronize((hipStream_t)stream));
-      unsigned long long h[24];
-      GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[attention8 wave 0 of workgroup 0] prologue %llu, tile loop %llu, epilogue %llu shader cycles; %.1f us on the 100-MHz counter -> %.2f GHz\n",
-              h[20], h[21], h[22], h[23] / 100.0, (double)(h[20] + h[21] + h[22]) / (h[23] / 100.0) * 1e-3);
-      for (int g = 0; g < 2; ++g)
-        fprintf(stderr, "[attention8 wave %d] cycles over the whole tile loop: QK %llu, softmax0 %llu, softmax1 %llu, PV %llu, store_tile %llu, "
-                "load_tile %llu, barrier wait %llu\n", 4 * g, h[g * 10 + 0], h[g * 10 + 2], h[g * 10 + 4], h[g * 10 + 8], h[g * 10 + 9], h[g * 10 + 6],
-                h[g * 10 + 7]);
-    } else {
-      if (prescaled)
-        hipLaunchKernelGGL((attention8_bf16_kernel<false, true>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c);
-      else
-        hipLaunchKernelGGL((attention8_bf16_kernel<false, false>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, (hipStream_t)stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c);
-    }
-    if (stat) {          // the optimistic 8-wave kernel tracks no maximum: a sample of the rows is measured on the side
-      GIMS_LAUNCH_CHECK();
-      hipLaunchKernelGGL(attention_peak_sample_kernel, dim3(n_groups), dim3(64 * PS_WAVES), 0, (hipStream_t)stream, qkv, ld, q_col, k_col, problems,
-                         n_groups, n_heads, c, stat);
-    }
-  } else if (two) {
-    const int n_qt = cdiv(max_n_q, 2 * QB);
-    hipLaunchKernelGGL(attention_bf16_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
-  } else {
-    const int n_qt = cdiv(max_n_q, QB);
-    hipLaunchKernelGGL(attention_bf16_kernel<1>, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
-  }
-  GIMS_LAUNCH_CHECK();
-  return GIMS_OK;
+  return f16 ? attention_16b_launch<true>(qkv, ld, q_col, k_col, v_col, problems, n_groups, max_n_q, n_heads, out, ld_out, out_hi, out_lo, ld_split, prescaled, c,
+                                          stat, (hipStream_t)stream)
+             : attention_16b_launch<false>(qkv, ld, q_col, k_col, v_col, problems, n_groups, max_n_q, n_heads, out, ld_out, out_hi, out_lo, ld_split, prescaled, c,
+                                           stat, (hipStream_t)stream);
 }
+

@@ -56,6 +56,12 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   hwbf16x2 h = __builtin_convertvector(f, hwbf16x2);
   return __builtin_bit_cast(uint32_t, h);
 }
+// round-to-nearest-even f32 -> IEEE half, saturated to the finite range (v_med3_f32 + v_cvt_pk_f16_f32)
+typedef _Float16 hwf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_h2_sat(float lo, float hi) {
+  f32x2 f = {__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, hwf16x2));
+}
 __device__ __forceinline__ uint16_t f2bf(float x) { return (uint16_t)(pack_bf2(x, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 

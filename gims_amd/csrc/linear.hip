@@ -27,7 +27,7 @@ __device__ __forceinline__ void epilogue_store(const gims_linear_args& p, int ro
   if (p.act == GIMS_ACT_RELU) v = fmaxf(v, 0.f);
   if (p.residual) v += p.residual[(int64_t)row * p.ldc + col];
   if (p.out_f32) p.out_f32[(int64_t)row * p.ldc + col] = v;
-  if (p.out_bf16) p.out_bf16[(int64_t)row * p.ldc_bf16 + col] = f2bf(v);
+  if (p.out_bf16) p.out_bf16[(int64_t)row * p.ldc_bf16 + col] = (p.flags & GIMS_LINEAR_OUT_F16) ? (uint16_t)(pack_h2_sat(v, 0.f) & 0xffffu) : f2bf(v);
   if (p.out_hi) {
     const uint16_t h = f2bf(v);
     p.out_hi[(int64_t)row * p.ld_split + spl_col(col)] = h;
@@ -533,10 +533,15 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
         for (int e = 0; e < 4; ++e) h[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
         if (p.out_bf16) {
           uint16_t* o = p.out_bf16 + (int64_t)row * p.ldc_bf16 + col;
-          if (full && (p.ldc_bf16 & 7) == 0) *(uint4*)o = make_uint4(h[0], h[1], h[2], h[3]);
+          uint32_t q[4] = {h[0], h[1], h[2], h[3]};
+          if (p.flags & GIMS_LINEAR_OUT_F16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = pack_h2_sat(v[2 * e], v[2 * e + 1]);
+          }
+          if (full && (p.ldc_bf16 & 7) == 0) *(uint4*)o = make_uint4(q[0], q[1], q[2], q[3]);
           else {
-            *(uint2*)o = make_uint2(h[0], h[1]);
-            if (full) *(uint2*)(o + 4) = make_uint2(h[2], h[3]);
+            *(uint2*)o = make_uint2(q[0], q[1]);
+            if (full) *(uint2*)(o + 4) = make_uint2(q[2], q[3]);
           }
         }
         if (p.out_hi) {

@@ -93,16 +93,21 @@ class GMatcher(nn.Module):
         # --- additions (defaults keep the reference behaviour) ---
         'linear_precision': 'bf16x3',   # 'bf16x3' (split-bf16 MFMA, ~2^-17) or 'f32' (exact-f32 MFMA)
         # 'bf16': plain bf16 MFMA attention (north_star's choice; meets the 1e-4 score bar for diffuse to moderately peaked
-        # softmaxes -- mean row maximum up to ~0.2 measured).  'bf16x3': Q, K, V and P as split-bf16 pairs, three MFMAs
-        # per product (GIMS_ATTN_X3) -- for sharply peaked attention (mean row maximum ~0.8: the 'peaked' goldens need it).
-        # 'auto' (default) picks between the two PER LAYER from the measured peakedness of that layer's softmax rows (mean
-        # over the queries of max_k P[q, k], per head; the kernels report it, gims_attention_stat): the first batch after the
-        # weights change runs every layer at 'bf16x3' and measures; from then on a layer runs in plain bf16 while the
-        # statistic of each of its heads stays below `attention_auto_threshold`, and a bf16 layer that later crosses it is
-        # switched to 'bf16x3' for good: every `attention_monitor_period`-th batch is measured again (the small-launch bf16
-        # kernels report as a by-product, the 8-wave kernel through a sampling kernel of a few microseconds per layer).
+        # softmaxes -- mean row maximum up to ~0.2 measured).  'f16': the same kernels on IEEE-half operands
+        # (v_mfma_f32_32x32x16_f16: same rate, 2^-12 instead of 2^-9 per operand; Q/K/V from the 3-pass projection, rounded to half in
+        # its epilogue) -- holds the bar on the sharply peaked 'peaked' goldens (mean row maximum ~0.8) where bf16 does not.
+        # 'bf16x3': Q, K, V and P as split-bf16 pairs, three MFMAs per product (GIMS_ATTN_X3): f32 class, no range limit.
+        # 'auto' (default) picks PER LAYER from what the kernels measure about that layer (gims_attention_stat): per head the mean
+        # over the queries of max_k P[q, k] and the fraction of queries whose maximum exceeds 1/2 (the tail: a head with a few
+        # one-hot rows among diffuse ones), and max |Q|, |K|, |V| as stored.  The first batch after the weights change runs every
+        # layer at 'bf16x3' and measures; from then on a layer runs in plain bf16 while every head stays below
+        # `attention_auto_threshold` (mean) and `attention_auto_tail` (fraction), in half above that while its operands stay
+        # below `attention_f16_range` (half's finite range is 65504), else at 'bf16x3'.  Every `attention_monitor_period`-th batch
+        # is measured again and a layer only ever moves UP (bf16 -> f16 -> bf16x3), for good.
         'attention_precision': 'auto',
         'attention_auto_threshold': 0.08,
+        'attention_auto_tail': 0.02,
+        'attention_f16_range': 3.0e4,
         'attention_monitor_period': 8,
         'train_precision': 'bf16x6',      # products of the training step (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
         'verbose': False,               # the reference prints '>> ...' timing lines; off by default here
@@ -309,24 +314,28 @@ class GMatcher(nn.Module):
         return self._buf("act_" + name, nbytes)[:nbytes].view(dtype).view(rows, cols)
 
     # ------------------------------------------------------------------ attention_precision='auto'
+    _MODE_NAMES = ('bf16', 'f16', 'bf16x3')
+
     def _attention_modes(self, P, dev):
-        """Per layer: True = attention_x3_kernel (split-bf16 operands), False = the bf16 kernels; and the device accumulator
-        [layers][heads][4] int64 the kernels report the softmax peakedness into (None when nothing is measured)."""
+        """Per layer the attention kernel family -- 0: bf16 operands, 1: IEEE half (GIMS_ATTN_F16), 2: split-bf16 pairs
+        (GIMS_ATTN_X3) -- and the device accumulator [layers][heads + 1][4] int64 the kernels report the softmax peakedness and the
+        operand range into (None when nothing is measured)."""
         mode, L = self.config['attention_precision'], self.n_layers
         if mode != 'auto' or not P["x3"]:          # (linear_precision='f32' has no split Q/K/V planes: 'auto' means bf16 there)
-            return [mode == 'bf16x3'] * L, None
+            return [self._MODE_NAMES.index(mode) if mode in self._MODE_NAMES and P["x3"] else 0] * L, None
         self._attention_stats_consume(self._lane)
         st = self.__dict__.get("_attn_auto")
         if st is None or st["gen"] != P["gen"]:      # new weights: measure every layer at the accurate precision first
-            st = self.__dict__["_attn_auto"] = dict(gen=P["gen"], x3=[True] * L, calibrated=False, peak=np.zeros((L, self._heads)),
-                                                    peak_max=np.zeros((L, self._heads)), switched=[], batches={})
+            st = self.__dict__["_attn_auto"] = dict(gen=P["gen"], mode=[2] * L, calibrated=False, peak=np.zeros((L, self._heads)),
+                                                    peak_max=np.zeros((L, self._heads)), tail=np.zeros((L, self._heads)),
+                                                    range=np.zeros((L, 3)), switched=[], batches={})
         n_b = st["batches"][self._lane] = st["batches"].get(self._lane, -1) + 1
         if st["calibrated"] and n_b % max(1, int(self.config['attention_monitor_period'])) != 0:
-            return list(st["x3"]), None              # not a measured batch
-        nbytes = L * self._heads * 4 * 8
-        stat = self._buf("attn_stat", nbytes)[:nbytes].view(torch.int64).view(L, self._heads, 4)
+            return list(st["mode"]), None              # not a measured batch
+        nbytes = L * (self._heads + 1) * 4 * 8
+        stat = self._buf("attn_stat", nbytes)[:nbytes].view(torch.int64).view(L, self._heads + 1, 4)
         stat.zero_()
-        return list(st["x3"]), stat
+        return list(st["mode"]), stat
 
     def _attention_stats_enqueue(self, stat):
         """Asynchronous read-back of this batch's statistics (consumed behind the next host synchronisation of this lane)."""
@@ -343,41 +352,49 @@ class GMatcher(nn.Module):
         """Fold the read-back of `lane` (None: of every lane) into the per-layer decision.  Called by a lane right after the
         host synchronisation of its next batch's graph build -- its previous batch, read-back included, has finished by then,
         so WHEN a measurement takes effect does not depend on timing -- and after forward()'s final synchronisation.
-        Decisions only ever move towards 'bf16x3' once the first measurement is in."""
+        Decisions only ever move UP (bf16 -> f16 -> bf16x3) once the first measurement is in."""
         st = self.__dict__.get("_attn_auto")
+        H = self._heads
         for ln, slot in list(self.__dict__.get("_attn_pending", {}).items()):
             if slot[1] is None or (lane is not None and ln != lane):
                 continue
             slot[1].synchronize()
-            host, slot[1] = slot[0].numpy().astype(np.float64), None
+            raw, slot[1] = slot[0].numpy().copy(), None
             if st is None or slot[2] != st["gen"]:
                 continue
+            host = raw[:, :H, :].astype(np.float64)
             cnt = host[:, :, 1]
             seen = cnt > 0
             mean = np.where(seen, host[:, :, 0] / np.maximum(cnt, 1.0) / hip.ATTN_STAT_SCALE, 0.0)
+            tail = np.where(seen, host[:, :, 3] / np.maximum(cnt, 1.0), 0.0)
+            rng = raw[:, H, :3].astype(np.uint32).view(np.float32).astype(np.float64)       # max |Q|, |K|, |V| as stored
             st["peak"] = np.where(seen, mean, st["peak"])
+            st["tail"] = np.where(seen, tail, st["tail"])
             st["peak_max"] = np.maximum(st["peak_max"], np.where(seen, host[:, :, 2] / hip.ATTN_STAT_SCALE, 0.0))
-            thr = float(self.config['attention_auto_threshold'])
-            hot = (mean > thr).any(axis=1)
+            st["range"] = np.maximum(st["range"], np.where(np.isfinite(rng), rng, np.inf))
+            hot = (mean > float(self.config['attention_auto_threshold'])).any(axis=1) | (tail > float(self.config['attention_auto_tail'])).any(axis=1)
+            wide = (st["range"] > float(self.config['attention_f16_range'])).any(axis=1)
+            want = np.where(hot, np.where(wide, 2, 1), 0)
             if not st["calibrated"]:
                 if seen.all():
-                    st["x3"] = [bool(h) for h in hot]
+                    st["mode"] = [int(w) for w in want]
                     st["calibrated"] = True
             else:
-                for l in np.nonzero(hot)[0]:
-                    if not st["x3"][l]:
-                        st["x3"][l] = True
-                        st["switched"].append(int(l))
+                for l in np.nonzero(want > np.asarray(st["mode"]))[0]:
+                    st["mode"][l] = int(want[l])
+                    st["switched"].append(int(l))
 
     def attention_report(self):
-        """What 'auto' decided: per layer 'bf16' / 'bf16x3', the last measured peakedness per (layer, head), layers switched
-        after the first measurement.  None before the first batch or with a fixed attention_precision."""
+        """What 'auto' decided: per layer 'bf16' / 'f16' / 'bf16x3', the last measured peakedness (mean row maximum) and tail
+        fraction (row maximum above 1/2) per (layer, head), max |Q|, |K|, |V| per layer, layers moved up after the first measurement.
+        None before the first batch or with a fixed attention_precision."""
         self._attention_stats_consume()
         st = self.__dict__.get("_attn_auto")
         if st is None:
             return None
-        return dict(modes=['bf16x3' if v else 'bf16' for v in st["x3"]], calibrated=st["calibrated"], peak=st["peak"].copy(),
-                    peak_max=st["peak_max"].copy(), switched=list(st["switched"]), threshold=float(self.config['attention_auto_threshold']))
+        return dict(modes=[self._MODE_NAMES[v] for v in st["mode"]], calibrated=st["calibrated"], peak=st["peak"].copy(),
+                    peak_max=st["peak_max"].copy(), tail=st["tail"].copy(), range=st["range"].copy(), switched=list(st["switched"]),
+                    threshold=float(self.config['attention_auto_threshold']), tail_threshold=float(self.config['attention_auto_tail']))
 
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
     def enable_timing(self, on: bool = True, stepwise: bool = False):
@@ -621,19 +638,24 @@ class GMatcher(nn.Module):
         self_pr = hip.upload(spr, dev, out=self._buf("self_pr", spr.nbytes + 32))
         cross_pr = hip.upload(cpr, dev, out=self._buf("cross_pr", cpr.nbytes + 32))
         max_nq = max(g["n_kept"] for g in images)
-        if cfg['attention_precision'] not in ('auto', 'bf16', 'bf16x3'):
-            raise ValueError("attention_precision must be 'auto', 'bf16' or 'bf16x3'")
-        if cfg['attention_precision'] == 'bf16x3' and not x3:
-            raise ValueError("attention_precision='bf16x3' needs linear_precision='bf16x3' (the split Q/K/V projection)")
-        # per-layer choice of the attention kernel and, in 'auto' mode, the accumulator its peakedness statistic goes to
-        ax3, stat = self._attention_modes(P, dev)
-        # bf16 attention: Q|K|V as one bf16 buffer [rows][768]; x3 attention: the same three matrices as SPL32 hi/lo planes
+        if cfg['attention_precision'] not in ('auto', 'bf16', 'f16', 'bf16x3'):
+            raise ValueError("attention_precision must be 'auto', 'bf16', 'f16' or 'bf16x3'")
+        if cfg['attention_precision'] in ('f16', 'bf16x3') and not x3:
+            raise ValueError(f"attention_precision='{cfg['attention_precision']}' needs linear_precision='bf16x3' (the 3-pass Q/K/V projection)")
+        # per-layer choice of the attention kernel family (0 bf16, 1 half, 2 split-bf16) and, in 'auto' mode, the accumulator its
+        # statistic goes to
+        amode, stat = self._attention_modes(P, dev)
+        ax3 = [a == 2 for a in amode]
+        # bf16 / half attention: Q|K|V as one 16-bit buffer [rows][768] (a layer writes and reads it in its own format); x3 attention:
+        # the same three matrices as SPL32 hi/lo planes
         qkv_b = self._act("qkv", n_tot, 3 * D, torch.bfloat16) if not all(ax3) else None
         qkv_s = self._act("qkv6", n_tot, 6 * D, torch.bfloat16) if any(ax3) else None
         qkv_of = lambda l: qkv_s if ax3[l] else qkv_b                                                       # noqa: E731
-        qkv_out_of = lambda l: dict(out_split=qkv_s) if ax3[l] else dict(out_bf16=qkv_b, flags=self._qkv_flags)   # noqa: E731
+        # the half tier rounds the THREE-pass projection (f32 class) to half in the epilogue; the bf16 tier multiplies hi planes only
+        qkv_out_of = lambda l: (dict(out_split=qkv_s) if amode[l] == 2 else                                 # noqa: E731
+                                dict(out_bf16=qkv_b, flags=hip.LINEAR_OUT_F16) if amode[l] == 1 else dict(out_bf16=qkv_b, flags=self._qkv_flags))
         stat_of = lambda l: None if stat is None else stat[l]                                               # noqa: E731
-        sfx = lambda l: "_x3" if ax3[l] else ""          # stage-timer labels tell the two attention kernels apart       # noqa: E731
+        sfx = lambda l: ("", "_f16", "_x3")[amode[l]]      # stage-timer labels tell the attention kernels apart       # noqa: E731
         if x3:
             # all GEMM operands travel as split-bf16 SPL32 buffers written by the producing kernel's epilogue; only the
             # residual stream `desc` also exists in f32
@@ -648,7 +670,7 @@ class GMatcher(nn.Module):
                 key = (P["gen"], n_tot, max_nq, dpl.data_ptr(), mpl.data_ptr(), hpl.data_ptr(), desc.data_ptr(),
                        0 if qkv_b is None else qkv_b.data_ptr(), 0 if qkv_s is None else qkv_s.data_ptr(),
                        0 if stat is None else stat.data_ptr(),
-                       self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags, tuple(ax3))
+                       self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags, tuple(amode))
                 cache = self.__dict__.setdefault("_ops_cache", {})
                 ops = cache.get(key)
                 if ops is None:
@@ -658,7 +680,7 @@ class GMatcher(nn.Module):
                     for l, L in enumerate(P["layers"]):
                         lst.append(la(L["qkv"], dpl, **qkv_out_of(l)))
                         lst.append(hip.op_attention(qkv_of(l), cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D,
-                                                    out_split=mpl, q_prescaled=True, x3=ax3[l], stat=stat_of(l)))
+                                                    out_split=mpl, q_prescaled=True, x3=ax3[l], f16=amode[l] == 1, stat=stat_of(l)))
                         lst.append(la(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl, flags=self._msg_flags))
                         lst.append(la(L["mlp1"], hpl, residual=desc, out=desc, out_split=dpl))
                     if len(cache) > 8:
@@ -685,7 +707,7 @@ class GMatcher(nn.Module):
                     self._lin(L["qkv"], dpl, **qkv_out_of(l))
                 with St(("attn_cross" if L["cross"] else "attn_self") + sfx(l)):
                     hip.attention(qkv_of(l), cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl,
-                                  q_prescaled=True, x3=ax3[l], stat=stat_of(l))
+                                  q_prescaled=True, x3=ax3[l], f16=amode[l] == 1, stat=stat_of(l))
                 with St("mlp"):
                     if ln:        # LayerNorm between the two MLP convs: hidden activations in f32, normalised + split by the norm kernel
                         if hid_ln is None:

@@ -19,6 +19,7 @@ LINEAR_UPPER = 1
 LINEAR_HI_ONLY = 2
 LINEAR_A1_HI_ONLY = 4
 LINEAR_CONV3 = 8
+LINEAR_OUT_F16 = 16      # out_bf16 receives IEEE half (saturated) instead of bf16
 ACT_NONE, ACT_RELU = 0, 1
 
 
@@ -427,13 +428,18 @@ def op_linear(args: LinearArgs) -> Op:
     return o
 
 
+def _attn_flags(q_prescaled, x3, f16):
+    assert not (x3 and f16)
+    return (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0) | (ATTN_F16 if f16 else 0)
+
+
 def op_attention(qkv, problems, max_n_q, n_heads, out=None, q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False,
-                 stat=None) -> Op:
+                 stat=None, f16=False) -> Op:
     o = Op()
     o.kind = 1
     o.u.att = AttnArgs(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0], max_n_q, n_heads, _p(out),
                        out.stride(0) if out is not None else 0, _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
-                       out_split.stride(0) if out_split is not None else 0, (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0), _p(stat))
+                       out_split.stride(0) if out_split is not None else 0, _attn_flags(q_prescaled, x3, f16), _p(stat))
     return o
 
 
@@ -524,26 +530,29 @@ ATTN_Q_SCALE = 0.125 * 1.4426950408889634      # log2(e) / sqrt(64): what q_pres
 
 
 ATTN_X3 = 2
+ATTN_F16 = 4        # qkv holds IEEE half (gims_linear with LINEAR_OUT_F16); v_mfma_f32_32x32x16_f16 kernels
 
 
 ATTN_STAT_SCALE = float(1 << 24)       # fixed point of the row maxima in gims_attention_stat's accumulator
 
 
 def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: int, out=None,
-              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False, stat=None):
+              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False, stat=None, f16=False):
     """qkv bf16 [rows, ld]; problems int32 [P,4] (q_off, n_q, kv_off, n_kv) on device; out f32 [rows, ld_out]
     and/or out_split = SPL32 bf16 buffer [rows, >= 512].  q_prescaled: Q already carries ATTN_Q_SCALE.
     x3: qkv is the SPL32 split-bf16 buffer [rows, >= 1536] of the 3-pass projection (GIMS_ATTN_X3).
-    stat: int64 [n_heads, 4] accumulator of the softmax peakedness (gims_attention_stat; zero it before the first use)."""
+    f16: the 16-bit values of qkv are IEEE half, not bf16 (GIMS_ATTN_F16; the tensor's dtype stays torch.bfloat16: raw storage).
+    stat: int64 [n_heads + 1, 4] accumulator of the softmax peakedness and the operand range (gims_attention_stat; zero it before the
+    first use)."""
     lib = load()
     assert qkv.dtype == torch.bfloat16 and problems.dtype == torch.int32 and problems.is_cuda
     if stat is not None:
-        assert stat.dtype == torch.int64 and stat.is_contiguous() and stat.numel() >= 4 * n_heads and stat.is_cuda
+        assert stat.dtype == torch.int64 and stat.is_contiguous() and stat.numel() >= 4 * (n_heads + 1) and stat.is_cuda
     _check(lib.gims_attention_stat(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0],
                                    max_n_q, n_heads, _p(out), out.stride(0) if out is not None else 0, _p(out_split),
                                    (out_split.data_ptr() + 64) if out_split is not None else None,
                                    out_split.stride(0) if out_split is not None else 0,
-                                   (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0), _p(stat), _stream()),
+                                   _attn_flags(q_prescaled, x3, f16), _p(stat), _stream()),
            "gims_attention")
     return out if out is not None else out_split
 

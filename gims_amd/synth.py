@@ -195,13 +195,16 @@ def state_dict_spec(descriptor_dim=256, keypoint_encoder=(32, 64, 128, 256), n_l
     return spec
 
 
-def make_state_dict(seed: int = 123, bias_std: float = 0.02, bn_jitter: float = 0.2, gains=None, **kw):
+def make_state_dict(seed: int = 123, bias_std: float = 0.02, bn_jitter: float = 0.2, gains=None, head_gains=None, num_heads: int = 4, **kw):
     """Synthetic GMatcher weights as {name: np.ndarray}.
 
     Conv/linear weights ~ N(0, g^2/fan_in); biases ~ N(0, bias_std^2) (non-zero so the bias
     paths are exercised); BatchNorm gamma/var ~ 1 +- bn_jitter, beta/mean small -- so the
     BN-folding path is exercised as well.  ``bin_score`` = 1 (gmatcher.py:206).  ``gains`` overrides / extends GAINS (see
     ``_gain_for``): e.g. ``{"attn.proj.0": 1.2, "attn.proj.1": 1.2}`` sharpens the attention of every layer.
+    ``head_gains``: ``{(layer, head): g}`` multiplies the query and key projection rows of ONE head of one attentional layer (the
+    reference interleaves heads: output channel c belongs to head c % num_heads, gmatcher.py:111) by g, bias included -- that
+    head's logits grow by g^2 while the other heads of the layer keep theirs.
     """
     out = {}
     for i, (name, shape) in enumerate(state_dict_spec(**kw)):
@@ -233,6 +236,11 @@ def make_state_dict(seed: int = 123, bias_std: float = 0.02, bn_jitter: float = 
             g = _gain_for(name, gains)
             a = (normal(seed, stream, n) * (g / np.sqrt(float(fan_in)))).astype(np.float32).reshape(shape)
         out[name] = a
+    for (layer, head), g in (head_gains or {}).items():
+        for j in (0, 1):
+            for part in ("weight", "bias"):
+                t = out[f"gnn.layers.{layer}.attn.proj.{j}.{part}"]
+                t[head::num_heads] = (t[head::num_heads] * np.float32(g)).astype(np.float32)
     return out
 
 

@@ -102,6 +102,9 @@ typedef struct gims_linear_args {
    * from bf16 data and carries no information below bf16 precision (the attention message in MLP0) */
 #define GIMS_LINEAR_A1_HI_ONLY 4
 #define GIMS_LINEAR_CONV3 8
+  /* GIMS_LINEAR_OUT_F16: out_bf16 receives IEEE half instead of bf16 (round to nearest even, saturated to +-65504 so that no
+   * infinity is ever stored) -- the Q/K/V projection in front of the GIMS_ATTN_F16 attention kernels */
+#define GIMS_LINEAR_OUT_F16 16
 
 int gims_linear(const gims_linear_args* args, void* stream);
 /* Many independent problems in ONE launch (ragged batch: per-pair score matrices, per-image similarity
@@ -140,6 +143,12 @@ int gims_split_spl32(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, 
  * channel offsets (multiples of 32), and every product of the kernel (Q K^T and P V) is three bf16 MFMAs on hi/lo pairs
  * (hi*hi + hi*lo + lo*hi); P is split in registers.  About three times the matrix work of the plain bf16 kernel. */
 #define GIMS_ATTN_X3 2
+/* GIMS_ATTN_F16: qkv holds IEEE half instead of bf16 (same layout; written by gims_linear with GIMS_LINEAR_OUT_F16 from the 3-pass
+ * projection) and the kernels multiply on v_mfma_f32_32x32x16_f16 -- the bf16 kernels' structure and rate with three more mantissa
+ * bits (2^-12 instead of 2^-9 relative per operand), P rounded to half with a row reference that keeps it below 2^15.  For
+ * peaked softmaxes, where bf16 operands miss the reference's 1e-4 score bar; |Q|, |K|, |V| must stay below 65504 (the statistic of
+ * gims_attention_stat reports them).  Not together with GIMS_ATTN_X3. */
+#define GIMS_ATTN_F16 4
 typedef struct gims_attn_problem { int32_t q_off, n_q, kv_off, n_kv; } gims_attn_problem;
 
 int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
@@ -148,8 +157,10 @@ int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col
                    uint16_t* out_hi /* may be NULL */, uint16_t* out_lo, int64_t ld_split, int32_t flags, void* stream);
 /* The same launch, additionally reporting how PEAKED the softmax rows were -- the quantity that decides whether plain bf16
  * operands keep the reference's 1e-4 score bar (models/gmatcher.py:35-39 computes the softmax in f32): stat is a device array
- * [n_heads][4] of uint64 {sum over the reported queries of max_k P[q,k] in 2^-24 fixed point, number of reported queries,
- * largest row maximum (same fixed point), unused}, ACCUMULATED with integer atomics (zero it first; order-independent).
+ * [n_heads + 1][4] of uint64.  Rows 0 .. n_heads-1: {sum over the reported queries of max_k P[q,k] in 2^-24 fixed point, number of
+ * reported queries, largest row maximum (same fixed point), number of reported queries with a row maximum above 1/2}; row n_heads:
+ * {bit patterns of max|Q|, max|K|, max|V| as stored (f32), unused} over the rows the launch touches -- the range guard of
+ * GIMS_ATTN_F16.  ACCUMULATED with integer atomics (zero it first; order-independent).
  * The running-maximum kernels (GIMS_ATTN_X3, the 4-wave and split-key bf16 kernels) report every query as a by-product; the
  * 8-wave bf16 kernel tracks no maximum, so for launches it serves a second, small kernel measures 32 evenly spaced queries of
  * every (problem, head) against all keys (a few microseconds).  stat == NULL: exactly gims_attention. */

@@ -236,3 +236,41 @@ def test_hot_kernels_use_no_scratch():
                 hits = {k: v for k, v in scratch.items() if n in k}
                 assert hits, f"{src}: no kernel named like {n} in the compiler remarks"
                 assert all(v == 0 for v in hits.values()), f"{src}: scratch in a hot kernel: {hits}"
+
+
+def test_auto_attention_routes_on_the_tail_and_the_range():
+    """The decision rule of 'auto' on hand-made statistics (no GPU work: the folding of a read-back into per-layer modes):
+    a head with 5 % one-hot rows among diffuse ones has a small MEAN row maximum (0.05) but a tail fraction of 0.05 -> half;
+    operands beyond `attention_f16_range` -> split-bf16; layers only move up."""
+    m = GMatcher({}).eval()
+    L, H = m.n_layers, 4
+    st = m.__dict__["_attn_auto"] = dict(gen=7, mode=[2] * L, calibrated=False, peak=np.zeros((L, H)), peak_max=np.zeros((L, H)),
+                                         tail=np.zeros((L, H)), range=np.zeros((L, 3)), switched=[], batches={})
+
+    class Ev:
+        def synchronize(self):
+            pass
+
+    def feed(mean, tail, rng):
+        raw = np.zeros((L, H + 1, 4), dtype=np.int64)
+        raw[:, :H, 1] = 1000
+        raw[:, :H, 0] = np.round(np.asarray(mean) * 1000 * 2 ** 24).astype(np.int64)
+        raw[:, :H, 3] = np.round(np.asarray(tail) * 1000).astype(np.int64)
+        raw[:, H, :3] = np.asarray(rng, dtype=np.float32).view(np.uint32).astype(np.int64)
+        m.__dict__["_attn_pending"] = {0: [torch.from_numpy(raw), Ev(), 7]}
+        m._attention_stats_consume()
+        return m.attention_report()["modes"]
+
+    mean, tail, rng = np.full((L, H), 0.01), np.zeros((L, H)), np.full((L, 3), 20.0)
+    mean[1, 2] = 0.3                     # plainly peaked head
+    mean[2, 0], tail[2, 0] = 0.05, 0.05  # small mean, fat tail
+    mean[3, 1], rng[3, 1] = 0.5, 5.0e4   # peaked AND out of half's range
+    rng[4, 0] = 5.0e4                    # wide operands but diffuse: bf16 has the range
+    modes = feed(mean, tail, rng)
+    assert modes[:5] == ["bf16", "f16", "f16", "bf16x3", "bf16"] and set(modes[5:]) == {"bf16"}
+    mean2 = np.full((L, H), 0.01)        # a later, calmer measurement never moves a layer down ...
+    assert feed(mean2, np.zeros((L, H)), np.full((L, 3), 20.0)) == modes
+    rng3 = np.full((L, 3), 20.0); rng3[1, 2] = 4.0e4      # ... and a half layer whose operands grow goes up
+    mean3 = mean2.copy(); mean3[1, 2] = 0.3
+    modes3 = feed(mean3, np.zeros((L, H)), rng3)
+    assert modes3[1] == "bf16x3" and m.attention_report()["switched"] == [1]

@@ -13,7 +13,11 @@ stubbed by tools/_ref_stubs), for the cases VERDICT r01 asked to pin:
 Only outputs are stored (inputs are regenerated from the seed by gims_amd.synth on any box): kept ids, DGL edge lists,
 matches, scores, the top-1/top-2 gaps of the OT matrix, per-image AGC stages.
 
-    python tools/gen_golden_large.py [--only sharp|4096|8192]
+  * MIXED regimes (round 4): per-layer query / key gains -- layers 0-5 at 0.3 (diffuse), 6-11 at 1.0, 12-17 at 2.0 -- so that
+    attention_precision='auto' really holds a launch table with different kernel families in one pass; and ONE sharpened head
+    (head 2 of layers 4-6 at 3 x, of layers 7-9 at 6 x the default gain 0.3) next to diffuse ones in the same layers.
+
+    python tools/gen_golden_large.py [--only sharp|mixed|4096|8192]
 """
 import os
 import sys
@@ -32,6 +36,24 @@ SHARP_GAINS = {"sharp": 1.0, "peaked": 2.0}
 def sharp_state_dict(kind):
     g = SHARP_GAINS[kind]
     return synth.make_state_dict(123, gains={"attn.proj.0": g, "attn.proj.1": g})
+
+
+MIXED_LAYER_GAINS = [0.3] * 6 + [1.0] * 6 + [2.0] * 6
+
+
+def mixed_state_dict():
+    gains = {}
+    for l, g in enumerate(MIXED_LAYER_GAINS):
+        gains[f"layers.{l}.attn.proj.0"] = g
+        gains[f"layers.{l}.attn.proj.1"] = g
+    return synth.make_state_dict(123, gains=gains)
+
+
+HEAD_GAIN = {**{(l, 2): 3.0 for l in range(4, 7)}, **{(l, 2): 6.0 for l in range(7, 10)}}
+
+
+def head_state_dict():
+    return synth.make_state_dict(123, head_gains=HEAD_GAIN)
 
 
 def one(name, model, n, seed, rad, pct, ms, iters, thr, with_agc=True, extra=None):
@@ -62,6 +84,13 @@ def main():
             one(f"{kind}e2e_n256_s1012_r15p2m7_i100", m100, 256, 1012, 15, 2, 7, 100, 0.2, with_agc=False, extra=ex)
             one(f"{kind}e2e_n1024_s1010_r15p2m7_i100", m100, 1024, 1010, 15, 2, 7, 100, 0.2, with_agc=False, extra=ex)
             one(f"{kind}e2e_n1024_s1011_r15p2m7_i20", m20, 1024, 1011, 15, 2, 7, 20, 0.02, with_agc=False, extra=ex)
+    if only in (None, "mixed"):
+        for kind, sds in (("mixed", mixed_state_dict()), ("headsharp", head_state_dict())):
+            m100 = G.ref_model(sds, {})
+            m20 = G.ref_model(sds, {"sinkhorn_iterations": 20, "match_threshold": 0.02})
+            one(f"{kind}e2e_n256_s1022_r15p2m7_i100", m100, 256, 1022, 15, 2, 7, 100, 0.2, with_agc=False)
+            one(f"{kind}e2e_n1024_s1020_r15p2m7_i100", m100, 1024, 1020, 15, 2, 7, 100, 0.2, with_agc=False)
+            one(f"{kind}e2e_n1024_s1021_r15p2m7_i20", m20, 1024, 1021, 15, 2, 7, 20, 0.02, with_agc=False)
     m100 = G.ref_model(sd, {})
     m20 = G.ref_model(sd, {"sinkhorn_iterations": 20, "match_threshold": 0.02})
     if only in (None, "4096"):
