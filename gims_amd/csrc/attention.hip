@@ -360,9 +360,12 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     const int kbase = kt * KB;
     const int row = t >> 3, ch = t & 7;
     int kr = kbase + row; kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-    const uint16_t* src = qkv + (int64_t)(pr.kv_off + kr) * ld + head * DH + 8 * ch;
-    rk = *(const uint4*)(src + k_col);
-    rv = *(const uint4*)(src + v_col);
+    // wave-uniform 64-bit base (the problem's first key row) + a 32-bit element offset per lane: the loads take the scalar-base addressing
+    // form and no 64-bit per-lane address stays alive across the tile (n_kv * ld < 2^32: ld <= 16384 is checked by the launcher)
+    const uint16_t* base = qkv + (int64_t)pr.kv_off * ld + head * DH;
+    const uint32_t off = (uint32_t)kr * (uint32_t)ld + 8u * (uint32_t)ch;
+    rk = *(const uint4*)(base + k_col + off);
+    rv = *(const uint4*)(base + v_col + off);
   };
   load_tile(0);                                // in flight together with the Q fragments below
   bool tile0_requested = true;
@@ -441,6 +444,9 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
         // own maximum becomes the reference, O and l are rescaled and the tile's exponentials are taken again (wave-uniform, at most
         // once per tile, rare after the first tiles).  The reference never exceeds the true row maximum, so the dominant keys always
         // sit in half's normal range (11-bit significand); keys 2^-14 below the reference go subnormal at an absolute 2^-25.
+        // (Tried and measured out, round 4: straight-line softmax with the test behind it and the raise as an inlined cold path, the
+        // second block's softmax in one basic block with the first block's P V MFMAs -- 96-220 bytes of scratch per lane whose reloads
+        // put a vmcnt(0) behind the next tile's global loads: 400 us per launch against 315 for this loop form.)
         if (kt == 0) {
           float tmax = -1e30f;
 #pragma unroll
@@ -451,13 +457,19 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
         }
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) {
-          const float mc = m_run[qi] * c;
+          const float mc = NOFMA ? m_run[qi] : m_run[qi] * c;
+          const f32x2 mc2 = {mc, mc};
           f32x2 lsum2 = {0.f, 0.f};
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             float pv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pv[r] = NOFMA ? __builtin_amdgcn_exp2f(sacc[qi][b][r] - mc) : __builtin_amdgcn_exp2f(fmaf(sacc[qi][b][r], c, -mc));
+            for (int r = 0; r < 16; r += 2) {
+              // the reference is subtracted two scores per issue (v_pk_add_f32): one VALU issue per score pair more than the bf16 pass
+              const f32x2 d = NOFMA ? f32x2{sacc[qi][b][r], sacc[qi][b][r + 1]} - mc2 : f32x2{sacc[qi][b][r], sacc[qi][b][r + 1]} * f32x2{c, c} - mc2;
+              pv[r] = __builtin_amdgcn_exp2f(d.x);
+              pv[r + 1] = __builtin_amdgcn_exp2f(d.y);
+            }
 #pragma unroll
             for (int r = 0; r < 16; r += 2) lsum2 += f32x2{pv[r], pv[r + 1]};
 #pragma unroll
@@ -1418,7 +1430,7 @@ namespace gims {
 // |Q| (as stored: with the softmax scale when the caller folded it in), |K|, |V| abs-max of the rows a launch touches, for the range
 // guard of the IEEE-half tier (finite range 65504): stat[n_heads][0..2] = the float bit patterns of the three maxima (positive floats
 // order like their bit patterns: atomicMax on the integer view).  kind: 0 bf16 / 1 half buffers [rows][ld] of 16-bit values; 2 SPL32
-// (the hi planes are read: |hi| is |x| to 2^-9).  One wave per row piece of 8 x 16 bytes; launched on measured batches only.
+// (the hi planes are read: |hi| is |x| to 2^-9).  16-byte pieces, grid-stride; launched on measured batches only.
 __global__ __launch_bounds__(256) void attention_range_kernel(const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
                                                               const gims_attn_problem* __restrict__ problems, int n_heads, int kind,
                                                               unsigned long long* __restrict__ stat) {
@@ -1426,37 +1438,53 @@ __global__ __launch_bounds__(256) void attention_range_kernel(const uint16_t* __
   const int width = n_heads * DH;                      // logical channels per matrix
   const int cpr = width / 8;                           // 16-byte pieces per row and matrix
   float mx[3] = {0.f, 0.f, 0.f};
+  auto fold = [&](int which, uint4 w) __attribute__((always_inline)) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a, b;
+      if (kind == 1) {
+        const f16x2 h = __builtin_bit_cast(f16x2, u[e]);
+        a = fabsf((float)h[0]); b = fabsf((float)h[1]);
+      } else {
+        a = fabsf(__uint_as_float(u[e] << 16)); b = fabsf(__uint_as_float(u[e] & 0xffff0000u));
+      }
+      mx[which] = fmaxf(mx[which], fmaxf(a, b));        // (NaN operands are dropped by fmaxf; inf is kept)
+    }
+  };
+#pragma unroll
   for (int which = 0; which < 3; ++which) {
     const int rows = which == 0 ? pr.n_q : pr.n_kv, off = which == 0 ? pr.q_off : pr.kv_off, col = which == 0 ? q_col : (which == 1 ? k_col : v_col);
-    const int64_t total = (int64_t)rows * cpr;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-      const int r = (int)(i / cpr), pc = (int)(i - (int64_t)r * cpr);
-      const int ch = col + 8 * pc;
-      const uint16_t* src = qkv + (int64_t)(off + r) * ld + (kind == 2 ? spl_col(ch) : ch);
-      const uint4 w = *(const uint4*)src;
-      const uint32_t u[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a, b;
-        if (kind == 1) {
-          const f16x2 h = __builtin_bit_cast(f16x2, u[e]);
-          a = fabsf((float)h[0]); b = fabsf((float)h[1]);
-        } else {
-          a = fabsf(__uint_as_float(u[e] << 16)); b = fabsf(__uint_as_float(u[e] & 0xffff0000u));
-        }
-        mx[which] = fmaxf(mx[which], fmaxf(a, b));        // (NaN operands are dropped by fmaxf; inf is kept)
-      }
+    const int total = rows * cpr, stride = gridDim.x * blockDim.x;
+    auto src = [&](int i) __attribute__((always_inline)) {
+      const int r = i / cpr, ch = col + 8 * (i - r * cpr);
+      return (const uint4*)(qkv + (int64_t)(off + r) * ld + (kind == 2 ? spl_col(ch) : ch));
+    };
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < total; i += 4 * stride) {         // four 16-byte loads in flight per thread
+      const uint4 w0 = *src(i), w1 = *src(i + stride), w2 = *src(i + 2 * stride), w3 = *src(i + 3 * stride);
+      fold(which, w0); fold(which, w1); fold(which, w2); fold(which, w3);
     }
+    for (; i < total; i += stride) fold(which, *src(i));
   }
+  // one atomic per workgroup and quantity (thousands of waves on three addresses serialise: 150 us per launch with one atomic per wave)
+  __shared__ float red[3][4];
 #pragma unroll
   for (int which = 0; which < 3; ++which) {
     const float m = wave_max(mx[which]);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(stat + 4 * n_heads + which, (unsigned long long)__float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) red[which][threadIdx.x >> 6] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float m = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+    // (a stale read can only be too small: the atomic then happens needlessly, never the other way round)
+    unsigned long long* dst = stat + 4 * n_heads + threadIdx.x;
+    if (m > 0.f && (unsigned long long)__float_as_uint(m) > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, (unsigned long long)__float_as_uint(m));
   }
 }
 static int attention_range_launch(const uint16_t* qkv, int64_t ld, int q_col, int k_col, int v_col, const gims_attn_problem* problems, int n_problems,
                                   int n_heads, int kind, unsigned long long* stat, hipStream_t stream) {
-  hipLaunchKernelGGL(attention_range_kernel, dim3(64, n_problems), dim3(256), 0, stream, qkv, ld, q_col, k_col, v_col, problems, n_heads, kind, stat);
+  hipLaunchKernelGGL(attention_range_kernel, dim3(32, n_problems), dim3(256), 0, stream, qkv, ld, q_col, k_col, v_col, problems, n_heads, kind, stat);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }
@@ -1561,6 +1589,7 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
   GIMS_CHECK_ARG((ld % 8) == 0 && (q_col % 8) == 0 && (k_col % 8) == 0 && (v_col % 8) == 0,
                  "gims_attention: qkv ld / column offsets must be multiples of 8 (16-byte loads)");
   GIMS_CHECK_ARG((ld_out % 4) == 0, "gims_attention: ld_out must be a multiple of 4");
+  GIMS_CHECK_ARG(ld <= 16384, "gims_attention: qkv pitch %lld too large (32-bit tile offsets)", (long long)ld);
   const int n_groups = n_heads * n_problems;
   const bool prescaled = (flags & GIMS_ATTN_Q_PRESCALED) != 0;
   const float c = prescaled ? 1.f : 0.125f * 1.4426950408889634f;      // 1/sqrt(64) * log2(e)
@@ -1568,7 +1597,7 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
   // (environment read per call, not cached: the tests switch kernels with it)
   const bool f16 = (flags & GIMS_ATTN_F16) != 0;
   GIMS_CHECK_ARG(!(f16 && (flags & GIMS_ATTN_X3)), "gims_attention: GIMS_ATTN_F16 and GIMS_ATTN_X3 exclude each other");
-  if (stat) {          // range of the operands as stored (measured launches only): see attention_range_kernel
+  if (stat && (flags & (GIMS_ATTN_X3 | GIMS_ATTN_F16))) {   // range of the operands as stored (measured launches of the half / calibration tiers: bf16 has f32's range)
     const int rc = attention_range_launch(qkv, ld, q_col, k_col, v_col, problems, n_problems, n_heads, (flags & GIMS_ATTN_X3) ? 2 : (f16 ? 1 : 0), stat,
                                           (hipStream_t)stream);
     if (rc != GIMS_OK) return rc;

@@ -160,7 +160,7 @@ int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col
  * [n_heads + 1][4] of uint64.  Rows 0 .. n_heads-1: {sum over the reported queries of max_k P[q,k] in 2^-24 fixed point, number of
  * reported queries, largest row maximum (same fixed point), number of reported queries with a row maximum above 1/2}; row n_heads:
  * {bit patterns of max|Q|, max|K|, max|V| as stored (f32), unused} over the rows the launch touches -- the range guard of
- * GIMS_ATTN_F16.  ACCUMULATED with integer atomics (zero it first; order-independent).
+ * GIMS_ATTN_F16, filled by GIMS_ATTN_F16 and GIMS_ATTN_X3 launches only (bf16 operands have f32's range).  ACCUMULATED with integer atomics (zero it first; order-independent).
  * The running-maximum kernels (GIMS_ATTN_X3, the 4-wave and split-key bf16 kernels) report every query as a by-product; the
  * 8-wave bf16 kernel tracks no maximum, so for launches it serves a second, small kernel measures 32 evenly spaced queries of
  * every (problem, head) against all keys (a few microseconds).  stat == NULL: exactly gims_attention. */

@@ -379,6 +379,9 @@ def test_attention_peak_statistic(hip, monkeypatch, kernel, sharp):
         assert ref_tail.sum() > 0
     # row 4: |Q|, |K|, |V| maxima of the touched rows as stored (f32 bit patterns); the SPL32 form reads the hi planes (2^-8 of the value)
     rng_got = raw[4, :3].astype(np.uint32).view(np.float32)
+    if not (f16 or kernel.startswith("x3")):          # bf16 operands have f32's range: their launches are not scanned
+        assert (raw[4] == 0).all()
+        return
     rows_used = np.concatenate([np.arange(qo, qo + nq) for qo, nq, _, _ in probs]), np.concatenate([np.arange(ko, ko + nk) for _, _, ko, nk in probs])
     rng_ref = [np.abs(f[rows_used[0], 0:256]).max(), np.abs(f[rows_used[1], 256:512]).max(), np.abs(f[rows_used[1], 512:768]).max()]
     np.testing.assert_allclose(rng_got, rng_ref, rtol=2.0 ** -7 if kernel.startswith("x3") else 1e-6)
