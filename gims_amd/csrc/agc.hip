@@ -1,8 +1,13 @@
 // Adaptive graph construction on the GPU -- models/agc.py:682-709 (live subset) for one image.
 //
-//   K1 cosine similarity  S = Dn Dn^T                      (agc.py:382-391)  exact-f32 MFMA GEMM (linear.hip)
+//   K1 cosine similarity  S = Dn Dn^T                      (agc.py:382-391)
 //   K2 exact percentile threshold over the strict upper triangle (agc.py:367-380, 439-440)
-//        4-pass 8-bit radix select on order-preserving uint keys -- exact, no sort, no host round trip
+//        round 4: APPROXIMATE everywhere, EXACT only where it decides.  The N x N matrix is formed once in IEEE half on the matrix cores
+//        (one MFMA pass, |error| <= AGC_EPS by Cauchy-Schwarz on unit rows); a 12-bit histogram of it brackets the k-th value; only the
+//        entries inside a rigorous error band around that bracket (~0.3 %) and the radius candidates (~19 k per image) are re-evaluated
+//        exactly (f32 operands, float64 accumulation in a fixed order), and the exact k-th value is selected among the band entries
+//        with the exact count below the band.  GIMS_AGC_EXACT_S=1: the earlier flow (all N^2 similarities at f32-GEMM accuracy,
+//        radix select over the whole matrix) as the cross-check.
 //   K3 radius candidates (float64, inclusive) AND sim >= thr  (agc.py:435-447) -> adjacency BIT MATRIX
 //   K4 connect_isolated_nodes, sequential semantics           (agc.py:476-495)
 //   K5 connected components (min-label union-find in LDS) + small-component removal (agc.py:497-516)
@@ -20,11 +25,20 @@
 namespace gims {
 
 constexpr int AGC_MAX_N = 16384;
+constexpr int ADJ_R = 4;      // rows per wave of the radius search: one load of point j serves four row tests (the loop is issue bound)
 
 struct AgcWs {
   float* dn;            // [n][d] normalised descriptors (f32 GEMM) -- or, as dn3, their SPL3 three-way bf16 split [n][3d]
   uint16_t* dn3;        // non-null: the similarity GEMM runs as GIMS_PREC_BF16X6
-  float* S;             // [n][lds]
+  float* S;             // [n][lds]  (GIMS_AGC_EXACT_S=1 flow only)
+  float* dnf;           // [n][d] normalised descriptors in f32: operands of the exact evaluations
+  uint16_t* dn16;       // [n][d] the same rounded to IEEE half: operands of the approximate similarity GEMM (null: exact-S flow)
+  uint16_t* S16;        // [n][lds16] approximate similarities in half; tiles that touch the upper triangle are valid
+  uint32_t* list;       // band entries: packed (i << 14 | j), overwritten in place by the order-preserving keys of their exact values
+  uint32_t* band;       // [4]: first and last 12-bit bin of the band, pad
+  uint32_t* clist;      // radius candidates, packed (i << 14 | j) with i < j; ckey: the order-preserving keys of their exact similarities
+  uint32_t* ckey;
+  uint32_t list_cap, clist_cap; int lds16;
   uint64_t* bits;       // [n][nw]
   uint32_t* hist;       // [4096] histogram of the current radix digit
   uint32_t* sel;        // [4]: prefix, k_lo, k_hi, pad
@@ -75,6 +89,14 @@ __global__ __launch_bounds__(256) void agc_normalize_kernel(const AgcWs* __restr
   for (int j = lane; j < d; j += 64) s = fmaf(x[j], x[j], s);
   s = wave_sum(s);
   const float nrm = fmaxf(sqrtf(s), 1e-12f);   // F.normalize: x / max(||x||, eps)
+  if (w.dn16) {    // band-limited flow: the f32 quotient (exact evaluations) and its rounding to half (approximate GEMM)
+    for (int j = lane; j < d; j += 64) {
+      const float v = x[j] / nrm;
+      w.dnf[(int64_t)row * d + j] = v;
+      w.dn16[(int64_t)row * d + j] = (uint16_t)(pack_h2_sat(v, 0.f) & 0xffffu);
+    }
+    return;
+  }
   if (w.dn3) {     // exact three-way split of the f32 quotient (linear6.hip: SPL3 layout)
     uint16_t* o = w.dn3 + (int64_t)row * 3 * d;
     for (int j = lane; j < d; j += 64) {
@@ -110,8 +132,8 @@ __global__ __launch_bounds__(256) void agc_hist_kernel(const AgcWs* __restrict__
   const uint32_t prefix = w.sel[0];
   const uint32_t himask = shift + bits >= 32 ? 0u : (0xffffffffu << (shift + bits));
   const uint32_t dmask = (uint32_t)nb - 1u;
-  uint32_t* list = (uint32_t*)w.bits;
-  const uint32_t cap = (uint32_t)((int64_t)w.n * w.nw * 2);
+  uint32_t* list = w.list ? w.list : (uint32_t*)w.bits;
+  const uint32_t cap = w.list ? w.list_cap : (uint32_t)((int64_t)w.n * w.nw * 2);
   const uint32_t nlist = w.sel[3];
   if (mode == 2 && nlist <= cap) {                 // the candidates of the previous sweep (they share the prefix of THAT sweep)
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) {
@@ -208,12 +230,397 @@ __global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__
   for (int i = nb + t; i < 4096; i += 256) w.hist[i] = 0;
 }
 
+// ---------------------------------------------------------------------------------------------- K1/K2, band-limited flow (round 4)
+// |S - S16| <= AGC_EPS for unit rows: operands rounded to half (unit roundoff 2^-11 each: <= 2 * 2^-11 + 2^-22 by Cauchy-Schwarz;
+// elements below 2^-14 go subnormal at an absolute 2^-25, < 2^-21 over 256 of them), products exact in f32, 256 f32 additions
+// (< 2e-5), result rounded to half (<= 2^-11 for |S| <= 2).  0.000977 + 0.00002 + 0.00049 < 0.0016.
+constexpr float AGC_EPS = 0.0016f;
+typedef _Float16 agc_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 agc_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t h16_key(uint16_t h) { return (h & 0x8000u) ? (uint32_t)(uint16_t)~h : (uint32_t)(h | 0x8000u); }
+__device__ __forceinline__ float h16_val(uint32_t key) {      // inverse of h16_key, as f32
+  const uint16_t h = (key & 0x8000u) ? (uint16_t)(key & 0x7fffu) : (uint16_t)~key;
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+
+// The exact evaluation of one similarity (both the threshold and the edge tests go through it: decisions are self-consistent).
+// dot(a, b) of two f32 rows in FLOAT64, fixed order: partial q (0..7) takes the 4-element pieces q, q + 8, q + 16 ... in ascending
+// order; the partials are combined as ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) and the sum is rounded to f32 once.  Eight lanes per pair
+// (lane q = partial q, xor-butterfly: every lane of the group ends with the same bits); d % 32 == 0.
+__device__ __forceinline__ float agc_exact_sim8(const float* __restrict__ a, const float* __restrict__ b, int d, int q) {
+  double acc = 0.0;
+  if (d == 256) {                 // the descriptor size of the path: all sixteen 16-byte loads of the lane in flight before the first fma
+    float4 x[8], y[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { x[t] = *(const float4*)(a + 4 * q + 32 * t); y[t] = *(const float4*)(b + 4 * q + 32 * t); }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      acc = fma((double)x[t].x, (double)y[t].x, acc);
+      acc = fma((double)x[t].y, (double)y[t].y, acc);
+      acc = fma((double)x[t].z, (double)y[t].z, acc);
+      acc = fma((double)x[t].w, (double)y[t].w, acc);
+    }
+  } else {
+    for (int k = 4 * q; k < d; k += 32) {
+      const float4 x = *(const float4*)(a + k), y = *(const float4*)(b + k);
+      acc = fma((double)x.x, (double)y.x, acc);
+      acc = fma((double)x.y, (double)y.y, acc);
+      acc = fma((double)x.z, (double)y.z, acc);
+      acc = fma((double)x.w, (double)y.w, acc);
+    }
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  return (float)acc;
+}
+
+// S16 = Dn16 Dn16^T, 128 x 128 tiles that touch the upper triangle, one MFMA pass on v_mfma_f32_32x32x16_f16.  4 waves (2 x 2), 64 x 64 per wave;
+// K in chunks of 128 (operands by LDS-DMA: 2 x 32 KB, 16-byte chunks XOR-swizzled with row & 15 on the source side); two workgroups per CU take
+// turns loading and multiplying.  The tile leaves as whole 256-byte row pieces through an LDS transpose.
+constexpr int S16_T = 128, S16_KC = 128, S16_EP = 136;        // tile, K chunk, epilogue pitch (halves)
+__global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  const int n = w.n, d = w.d, T = (n + S16_T - 1) / S16_T;
+  // linear index -> (ti <= tj): rows of the upper triangle hold T, T - 1, ... tiles
+  int rem = blockIdx.x, ti = 0;
+  if (rem >= T * (T + 1) / 2) return;
+  while (rem >= T - ti) { rem -= T - ti; ++ti; }
+  const int tj = ti + rem;
+  const int i0 = ti * S16_T, j0 = tj * S16_T;
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * S16_T * S16_KC];        // 64 KB: A chunk | B chunk; epilogue: [128][136]
+  uint16_t* As = lds;
+  uint16_t* Bs = lds + S16_T * S16_KC;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wi = wave >> 1, wj = wave & 1, li = lane & 31, lh = lane >> 5;
+  f32x16 acc[2][2];        // [jb][ib]: lane holds S[i = wi*64 + ib*32 + li][j = wj*64 + jb*32 + (r&3) + 8*(r>>2) + 4*lh]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  for (int k0 = 0; k0 < d; k0 += S16_KC) {
+    const int kc = d - k0 < S16_KC ? d - k0 : S16_KC;       // multiple of 32
+    const int cpr = kc / 8;                                  // 16-byte chunks per row of this K chunk (<= 16)
+    // 64 pieces of 1 KiB (A rows then B rows, 4 rows of 256 bytes per piece), 16 per wave; short chunks leave the row tails untouched
+#pragma unroll 4
+    for (int pc = 0; pc < 16; ++pc) {
+      const int piece = wave * 16 + pc;                      // wave-uniform
+      const bool is_b = piece >= 32;
+      const int row = 4 * (piece & 31) + (lane >> 4), pos = lane & 15, ch = pos ^ (row & 15);
+      int gr = (is_b ? j0 : i0) + row;
+      gr = gr < n ? gr : n - 1;
+      const uint16_t* src = w.dn16 + (int64_t)gr * d + k0 + 8 * (ch < cpr ? ch : 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)((is_b ? Bs : As) + (piece & 31) * 512), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < kc / 16; ++s) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        const int row = wi * 64 + ib * 32 + li;
+        af[ib] = *(const bf16x8*)(As + row * S16_KC + (((2 * s + lh) ^ (row & 15)) << 3));
+      }
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int row = wj * 64 + jb * 32 + li;
+        bf[jb] = *(const bf16x8*)(Bs + row * S16_KC + (((2 * s + lh) ^ (row & 15)) << 3));
+      }
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+          acc[jb][ib] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(agc_h8, bf[jb]), __builtin_bit_cast(agc_h8, af[ib]), acc[jb][ib], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: half values -> LDS [row i][col j] (pitch 136 halves), then whole row pieces out
+  uint16_t* es = lds;
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = wi * 64 + ib * 32 + li, j = wj * 64 + jb * 32 + 8 * g + 4 * lh;
+        *(uint2*)(es + i * S16_EP + j) = make_uint2(pack_h2_sat(acc[jb][ib][4 * g], acc[jb][ib][4 * g + 1]), pack_h2_sat(acc[jb][ib][4 * g + 2], acc[jb][ib][4 * g + 3]));
+      }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = 16 * it + (t >> 4), c = t & 15;            // 16 lanes per row: 16 x 16 bytes = the row's 128 columns
+    const int gi = i0 + i, gj = j0 + 8 * c;
+    if (gi < n && gj < w.lds16) *(uint4*)(w.S16 + (int64_t)gi * w.lds16 + gj) = *(const uint4*)(es + i * S16_EP + 8 * c);
+  }
+}
+
+// 12-bit histogram (top bits of the 16-bit order-preserving key) of the strict upper triangle of S16 (collect == 0), or, collect == 1, the packed
+// indices (i << 14 | j) of the entries whose bin lies in the band [band[0], band[1]] appended to the list (LDS-staged: one global reservation per
+// flush).  Rows are walked with 16-byte loads (8 entries), four in flight per thread.
+constexpr int AGC_STAGE = 4096;
+__global__ __launch_bounds__(256) void agc_sweep16_kernel(const AgcWs* __restrict__ ws, int collect) {
+  const AgcWs& w = ws[blockIdx.y];
+  __shared__ uint32_t h[4096];               // histogram, or the staging buffer of the collect pass
+  __shared__ uint32_t nst, gbase;
+  for (int i = threadIdx.x; i < 4096; i += 256) h[i] = 0;
+  if (threadIdx.x == 0) nst = 0;
+  __syncthreads();
+  const uint32_t blo = collect ? w.band[0] : 0u, bhi = collect ? w.band[1] : 0u;
+  auto flush = [&]() __attribute__((always_inline)) {        // (called by the whole workgroup)
+    __syncthreads();
+    const uint32_t cnt = nst < (uint32_t)AGC_STAGE ? nst : (uint32_t)AGC_STAGE;
+    if (threadIdx.x == 0) gbase = atomicAdd(&w.sel[3], cnt);
+    __syncthreads();
+    const uint32_t base = gbase;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256)
+      if (base + i < w.list_cap) w.list[base + i] = h[i];
+    __syncthreads();
+    if (threadIdx.x == 0) nst = 0;
+    __syncthreads();
+  };
+  // Work unit = the row pair (a, n - 1 - a): its two strict-upper-triangle pieces together hold n - 1 entries whatever a is, so every unit
+  // is the same amount of work (single rows run from n - 1 entries down to none).  The unit's 16-byte chunks (row a's, then row b's) are
+  // dealt round-robin to the threads, four loads in flight per thread.
+  const int n = w.n, half = (n + 1) / 2;
+  for (int a = blockIdx.x; a < half; a += gridDim.x) {
+    const int b = n - 1 - a;
+    const int ca0 = (a + 1) >> 3, cb0 = (b + 1) >> 3, cend = (n + 7) >> 3;          // first chunk of each row piece; chunks per full row
+    const int na = cend - ca0, nb = b > a ? cend - cb0 : 0;
+    for (int c0 = threadIdx.x; c0 < na + nb; c0 += 4 * 256) {
+      uint4 v[4];
+      int ri[4], cj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 256;
+        const bool first = c < na;
+        ri[u] = first ? a : b;
+        cj[u] = first ? ca0 + c : cb0 + (c - na);
+        v[u] = c < na + nb ? *(const uint4*)(w.S16 + (int64_t)ri[u] * w.lds16 + 8 * cj[u]) : make_uint4(0, 0, 0, 0);
+        if (c >= na + nb) cj[u] = -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (cj[u] < 0) continue;
+        const int i = ri[u], j8 = 8 * cj[u];
+        const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int j = j8 + q;
+          if (j > i && j < n) {
+            const uint32_t bin = h16_key((uint16_t)(x[q >> 1] >> (16 * (q & 1)))) >> 4;
+            if (!collect) atomicAdd(&h[bin], 1u);
+            else if (bin >= blo && bin <= bhi) {
+              const uint32_t slot = atomicAdd(&nst, 1u);
+              const uint32_t packed = ((uint32_t)i << 14) | (uint32_t)j;
+              if (slot < (uint32_t)AGC_STAGE) h[slot] = packed;
+              else {                                          // staging buffer full inside one unit: straight to the list (rare)
+                const uint32_t g = atomicAdd(&w.sel[3], 1u);
+                if (g < w.list_cap) w.list[g] = packed;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (collect) {                                            // between units (uniform for the workgroup): keep room for a dense one
+      __syncthreads();
+      if (nst > (uint32_t)AGC_STAGE / 2) flush();
+    }
+  }
+  if (collect) { flush(); return; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4096; i += 256)
+    if (h[i]) atomicAdd(&w.hist[i], h[i]);
+}
+
+// The bin b* that holds rank k of the approximate matrix, the band of bins whose values can be within 2 AGC_EPS of b*'s, the exact count below the
+// band -> band[0..1], sel = {prefix 0, k - count below (64 bit), list length 0}; histogram cleared for the digit passes over the list.
+__global__ __launch_bounds__(256) void agc_band_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  __shared__ uint64_t wsum[4];
+  __shared__ int bstar;
+  __shared__ unsigned int s_lo, s_hi;
+  __shared__ unsigned long long below;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int per = 16;
+  uint64_t v = 0;
+  for (int q = 0; q < per; ++q) v += w.hist[t * per + q];
+  uint64_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  if (t == 0) { s_lo = 4095u; s_hi = 0u; below = 0ull; bstar = 4095; }
+  __syncthreads();
+  for (int q = 0; q < wave; ++q) incl += wsum[q];
+  const uint64_t k = (uint64_t)w.sel[1] | ((uint64_t)w.sel[2] << 32);
+  uint64_t excl = incl - v;
+  if (t < 255 ? (excl <= k && k < incl) : excl <= k) {
+    int b = t * per;
+    for (int q = 0; q < per; ++q, ++b) {
+      const uint64_t c = w.hist[b];
+      if (k < excl + c || b == 4095) break;
+      excl += c;
+    }
+    bstar = b;
+  }
+  __syncthreads();
+  const int bs = bstar;
+  const float lo_val = h16_val((uint32_t)bs << 4) - 2.f * AGC_EPS, hi_val = h16_val(((uint32_t)bs << 4) | 15u) + 2.f * AGC_EPS;
+  // a bin belongs to the band iff its value range [v(b << 4), v(b << 4 | 15)] meets [lo_val, hi_val]; NaN bins (keys past the infinities) never do
+  unsigned long long mybelow = 0;
+  unsigned int mlo = 4095u, mhi = 0u;
+  bool any = false;
+  for (int q = 0; q < per; ++q) {
+    const uint32_t b = (uint32_t)(t * per + q);
+    const float vlo = h16_val(b << 4), vhi = h16_val((b << 4) | 15u);
+    const bool in = (vhi >= lo_val && vlo <= hi_val) || (int)b == bs;
+    if (in) { mlo = b < mlo ? b : mlo; mhi = b > mhi ? b : mhi; any = true; }
+  }
+  if (any) { atomicMin(&s_lo, mlo); atomicMax(&s_hi, mhi); }
+  __syncthreads();
+  const unsigned int blo = s_lo, bhi = s_hi;
+  for (int q = 0; q < per; ++q) {
+    const uint32_t b = (uint32_t)(t * per + q);
+    if (b < blo) mybelow += w.hist[b];
+  }
+  if (mybelow) atomicAdd(&below, mybelow);
+  __syncthreads();
+  if (t == 0) {
+    const uint64_t r = k - below;
+    w.band[0] = blo; w.band[1] = bhi;
+    w.sel[0] = 0u; w.sel[1] = (uint32_t)r; w.sel[2] = (uint32_t)(r >> 32); w.sel[3] = 0u;
+  }
+  __syncthreads();
+  for (int q = 0; q < per; ++q) w.hist[t * per + q] = 0;
+}
+
+// list[e] = (i << 14 | j)  ->  the order-preserving key of the exact similarity of rows i and j (in place); the same for the radius candidates
+// (clist -> ckey).  Eight lanes per entry.
+__global__ __launch_bounds__(256) void agc_exact_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  const uint32_t nl = w.sel[3] < w.list_cap ? w.sel[3] : w.list_cap;
+  const uint32_t nc = (uint32_t)w.counters[4] < w.clist_cap ? (uint32_t)w.counters[4] : w.clist_cap;
+  const uint32_t nlp = (nl + 31u) & ~31u, total = nlp + ((nc + 31u) & ~31u);       // (whole waves stay in the loop: shuffles)
+  const int q = threadIdx.x & 7;
+  for (uint32_t e = (blockIdx.x * 256 + threadIdx.x) >> 3; e < total; e += (gridDim.x * 256) >> 3) {
+    const bool band = e < nlp;
+    const uint32_t idx = band ? e : e - nlp;
+    const bool live = band ? idx < nl : idx < nc;
+    const uint32_t pk = live ? (band ? w.list[idx] : w.clist[idx]) : 0u;
+    const int i = (int)(pk >> 14), j = (int)(pk & 0x3fffu);
+    const float sim = agc_exact_sim8(w.dnf + (int64_t)i * w.d, w.dnf + (int64_t)j * w.d, w.d, q);
+    if (live && q == 0) (band ? w.list : w.ckey)[idx] = f32_key(sim);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- K3, band-limited flow
+// Radius candidates (agc.py:435-447: ||xi - xj||^2 <= r^2 in float64, inclusive), every unordered pair tested ONCE (j > i) and appended to the
+// candidate list as i << 14 | j; their similarities are evaluated by agc_exact_kernel, agc_apply_kernel sets the adjacency bits of those at or
+// above the threshold.  A wave takes four rows from the top of the matrix and the four mirrored rows from the bottom (together n - 1 tests per
+// mirrored row pair whatever the position: equal work per wave), 64 columns per step, one load of point j serving four row tests; it also clears
+// the adjacency rows it owns.  Candidates are staged in LDS (one global reservation per workgroup).
+constexpr int RAD_STAGE = 2048;
+__global__ __launch_bounds__(256) void agc_radius_kernel(const AgcWs* __restrict__ ws, double r2) {
+  const AgcWs& w = ws[blockIdx.y];
+  const float* __restrict__ kpts = w.kpts;
+  __shared__ uint32_t st[RAD_STAGE];
+  __shared__ uint32_t nst, gbase;
+  if (threadIdx.x == 0) nst = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = w.n, v = blockIdx.x * 4 + wave;              // wave v: rows 4v .. 4v+3 and n-4-4v .. n-1-4v (those not already in the first set)
+  const float r2f = (float)(r2 * 1.00002);
+  const bool al8 = ((uintptr_t)kpts & 7) == 0;
+  if (8 * v < n + 7) {
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+      int rows[ADJ_R];
+      float xif[ADJ_R], yif[ADJ_R];
+      int rmin = n;
+#pragma unroll
+      for (int r = 0; r < ADJ_R; ++r) {
+        // row i belongs to the top set of wave i / 4 and to the bottom set of wave (n - 1 - i) / 4: the smaller wave index owns it (top on a tie)
+        int i = side == 0 ? 4 * v + r : n - 1 - 4 * v - r;
+        if (i < 0 || i >= n) i = -1;
+        else if (side == 0 ? (i / 4 > (n - 1 - i) / 4) : ((n - 1 - i) / 4 >= i / 4)) i = -1;
+        rows[r] = i;
+        const int ic = i >= 0 ? i : 0;
+        xif[r] = kpts[2 * ic];
+        yif[r] = kpts[2 * ic + 1];
+        if (i >= 0) {
+          rmin = i < rmin ? i : rmin;
+          for (int k = lane; k < w.nw; k += 64) w.bits[(int64_t)i * w.nw + k] = 0ull;        // the adjacency row starts empty
+        }
+      }
+      if (rmin >= n) continue;
+      for (int j0 = ((rmin + 1) >> 6) << 6; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const int jc = j < n ? j : n - 1;
+        float xj, yj;
+        if (al8) { const float2 pj = *(const float2*)(kpts + 2 * jc); xj = pj.x; yj = pj.y; }
+        else { xj = kpts[2 * jc]; yj = kpts[2 * jc + 1]; }
+#pragma unroll
+        for (int r = 0; r < ADJ_R; ++r) {
+          // f32 screen first (relative error of dxf^2 + dyf^2 <= 3e-7, margin 2e-5): only the pairs it cannot rule out take the float64 test that decides
+          const float dxf = xif[r] - xj, dyf = yif[r] - yj;
+          bool pred = false;
+          if (rows[r] >= 0 && j < n && j > rows[r] && !(dxf * dxf + dyf * dyf > r2f)) {
+            const double dx = (double)xif[r] - (double)xj, dy = (double)yif[r] - (double)yj;
+            pred = dx * dx + dy * dy <= r2;
+          }
+          const uint64_t mask = __ballot(pred);
+          if (mask) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&nst, (uint32_t)__popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (pred) {
+              const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+              const uint32_t packed = ((uint32_t)rows[r] << 14) | (uint32_t)j;
+              if (slot < (uint32_t)RAD_STAGE) st[slot] = packed;
+              else {
+                const uint32_t g = atomicAdd((uint32_t*)&w.counters[4], 1u);
+                if (g < w.clist_cap) w.clist[g] = packed;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = nst < (uint32_t)RAD_STAGE ? nst : (uint32_t)RAD_STAGE;
+  if (threadIdx.x == 0) gbase = cnt ? atomicAdd((uint32_t*)&w.counters[4], cnt) : 0u;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < cnt; i += 256)
+    if (gbase + i < w.clist_cap) w.clist[gbase + i] = st[i];
+}
+
+// adjacency bits of the candidates whose exact similarity reaches the threshold (the reference tests sim_matrix[i, j] >= thr, agc.py:445-446)
+__global__ __launch_bounds__(256) void agc_apply_kernel(const AgcWs* __restrict__ ws) {
+  const AgcWs& w = ws[blockIdx.y];
+  const float thr = key_f32(w.sel[0]);
+  const uint32_t nc = (uint32_t)w.counters[4] < w.clist_cap ? (uint32_t)w.counters[4] : w.clist_cap;
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < nc; e += gridDim.x * 256) {
+    if (!(key_f32(w.ckey[e]) >= thr)) continue;
+    const uint32_t pk = w.clist[e];
+    const int i = (int)(pk >> 14), j = (int)(pk & 0x3fffu);
+    atomicOr((unsigned long long*)&w.bits[(int64_t)i * w.nw + (j >> 6)], 1ull << (j & 63));
+    atomicOr((unsigned long long*)&w.bits[(int64_t)j * w.nw + (i >> 6)], 1ull << (i & 63));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- K3 adjacency bits
 // one wave per row i, walking its 64-column words: bit j set iff j != i, ||xi-xj||^2 <= r^2 in float64 (inclusive),
 // and S[min(i,j)][max(i,j)] >= thr  (the reference tests sim_matrix[i,j] with i<j, agc.py:445-446).  (One wave per WORD
 // was 4 M one-shot waves per batch at 4096 keypoints; with the S read inside the column loop every in-radius pair cost the
 // wave a full memory round trip, ~9 per row.)
-constexpr int ADJ_R = 4;      // rows per wave: one load of point j serves four row tests (the loop is issue bound)
 __global__ __launch_bounds__(256) void agc_adj_kernel(const AgcWs* __restrict__ ws, double r2) {
   const AgcWs& w = ws[blockIdx.y];
   const float* __restrict__ kpts = w.kpts;
@@ -255,13 +662,13 @@ __global__ __launch_bounds__(256) void agc_adj_kernel(const AgcWs* __restrict__ 
         if (lane == q) mine[r] = mask;
       }
     }
-    // similarity test of the (few) pairs inside the radius: lane q walks the candidates of ITS word, so the dependent,
-    // scattered reads of S of a row are in flight together instead of one after the other inside the loop above
+    // similarity test of the (few) pairs inside the radius
 #pragma unroll
     for (int r = 0; r < ADJ_R; ++r) {
       const int i = i0 + r;
       if (i >= w.n) break;
       uint64_t cand = mine[r];
+      // lane q walks the candidates of ITS word, so the dependent, scattered reads of S of a row are in flight together
       while (cand) {
         const int bit = __ffsll((unsigned long long)cand) - 1;
         cand &= cand - 1;
@@ -554,40 +961,59 @@ __global__ __launch_bounds__(256) void agc_members_kernel(const AgcWs* __restric
   const int32_t* __restrict__ coff = w.coff2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int C = w.counters[1];
-  // a small grid walks the components (there are usually one to a handful: a wave per POSSIBLE component was 16 k workgroups that only exited),
-  // and the membership test of four 64-node chunks is in flight at once (alive -> label -> rank is three dependent loads: 64 chunks of them one
-  // after the other were the kernel's 76 us).  Members stay in ascending order and every lane adds its own members in the same order as before.
-  for (int c = blockIdx.x * 4 + wave; c < C; c += gridDim.x * 4) {
-    int off = coff[c];
-    double sx = 0.0, sy = 0.0;
+  // One WORKGROUP per component (there are usually one to a handful; a small grid walks them): the four waves take one quarter of the node range
+  // each -- a single wave walking all nodes with three dependent loads per chunk (alive -> label -> rank) was 67 us of pure latency per image.
+  // Pass 1 finds the members of the quarter (kept as one bit per chunk and lane) and counts them, the counts give every wave its offset, pass 2
+  // writes the members in ascending order and sums their coordinates in float64.
+  __shared__ int wcnt[4];
+  __shared__ double part[4][2];
+  const int per = ((w.n + 3) / 4 + 63) & ~63;                 // nodes per wave, a multiple of 64 (<= 4096: at most 64 chunks)
+  const int u0 = wave * per, u1 = (u0 + per < w.n) ? u0 + per : w.n;
+  for (int c = blockIdx.x; c < C; c += gridDim.x) {
+    uint64_t mine = 0;                                         // bit k: node u0 + 64 k + lane belongs to component c
     int cnt = 0;
-    for (int base = 0; base < w.n; base += 256) {
+    for (int base = u0, k = 0; base < u1; base += 256, k += 4) {
       bool mem[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q) {                            // four chunks in flight
         const int u = base + 64 * q + lane;
         int lab = 0;
-        const bool al = u < w.n && w.alive[u] != 0;
+        const bool al = u < u1 && w.alive[u] != 0;
         if (al) lab = w.label[u];
         mem[q] = al && w.crank[lab] == c;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int u = base + 64 * q + lane;
-        const uint64_t m = __ballot(mem[q]);
-        if (mem[q]) {
-          w.members[off + __popcll(m & ((1ull << lane) - 1))] = u;
-          sx += (double)kpts[2 * u];
-          sy += (double)kpts[2 * u + 1];
-        }
-        const int pc = __popcll(m);
-        off += pc;
-        cnt += pc;
+        if (mem[q]) mine |= 1ull << (k + q);
+        cnt += __popcll(__ballot(mem[q]));
       }
+    }
+    if (lane == 0) wcnt[wave] = cnt;
+    __syncthreads();
+    int off = coff[c];
+    for (int q = 0; q < wave; ++q) off += wcnt[q];
+    const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    double sx = 0.0, sy = 0.0;
+    for (int base = u0, k = 0; base < u1; base += 64, ++k) {
+      const bool mem = (mine >> k) & 1ull;
+      const uint64_t m = __ballot(mem);
+      if (mem) {
+        const int u = base + lane;
+        w.members[off + __popcll(m & ((1ull << lane) - 1))] = u;
+        sx += (double)kpts[2 * u];
+        sy += (double)kpts[2 * u + 1];
+      }
+      off += __popcll(m);
     }
     sx = wave_sum_f64(sx);
     sy = wave_sum_f64(sy);
-    if (lane == 0) { w.cent[2 * c] = sx / (double)cnt; w.cent[2 * c + 1] = sy / (double)cnt; }
+    if (lane == 0) { part[wave][0] = sx; part[wave][1] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      w.cent[2 * c] = (((part[0][0] + part[1][0]) + part[2][0]) + part[3][0]) / (double)total;
+      w.cent[2 * c + 1] = (((part[0][1] + part[1][1]) + part[2][1]) + part[3][1]) / (double)total;
+    }
+    __syncthreads();
   }
 }
 
@@ -636,12 +1062,21 @@ __global__ __launch_bounds__(256) void agc_link_kernel(const AgcWs* __restrict__
   const int aj = coff[j], nb = coff[j + 1] - aj;
   double bd = 1e300;
   int bv = 0x7fffffff, bu = 0x7fffffff;
-  const int64_t total = (int64_t)na * nb;
-  for (int64_t p = t; p < total; p += 256) {
-    const int v = w.members[aj + (int)(p / na)], u = w.members[ai + (int)(p % na)];
-    const double dx = (double)kpts[2 * u] - (double)kpts[2 * v], dy = (double)kpts[2 * u + 1] - (double)kpts[2 * v + 1];
-    const double dd = dx * dx + dy * dy;
-    if (dd < bd || (dd == bd && (v < bv || (v == bv && u < bu)))) { bd = dd; bv = v; bu = u; }
+  // every (v, u) pair once; the lexicographic minimum of (d2, v, u) does not depend on the visiting order.  The LARGER member list runs across the
+  // threads (its points loaded once per thread and kept), the smaller one is walked by every thread -- no index arithmetic per pair (a flat
+  // pair index cost a 64-bit division and four dependent loads per pair: 63 us for one 4000 x 10 product)
+  const bool swap = nb > na;
+  const int big0 = swap ? aj : ai, nbig = swap ? nb : na, small0 = swap ? ai : aj, nsmall = swap ? na : nb;
+  for (int p = t; p < nbig; p += 256) {
+    const int pb = w.members[big0 + p];
+    const double bx = (double)kpts[2 * pb], by = (double)kpts[2 * pb + 1];
+    for (int q = 0; q < nsmall; ++q) {
+      const int ps = w.members[small0 + q];
+      const double dx = bx - (double)kpts[2 * ps], dy = by - (double)kpts[2 * ps + 1];
+      const double dd = dx * dx + dy * dy;                   // (u - v)^2 == (v - u)^2 bit for bit: the roles of the two lists do not matter
+      const int v = swap ? pb : ps, u = swap ? ps : pb;
+      if (dd < bd || (dd == bd && (v < bv || (v == bv && u < bu)))) { bd = dd; bv = v; bu = u; }
+    }
   }
   sd[t] = bd; sv[t] = bv; su[t] = bu;
   __syncthreads();
@@ -681,6 +1116,10 @@ __global__ void agc_finish_kernel(const AgcWs* __restrict__ ws) {
   info[2] = w.counters[0] / 2;
   info[6] = (int32_t)__float_as_uint(key_f32(w.sel[0]));
   info[7] = (info[1] > max_edges_dir || w.counters[0] > w.cap || w.counters[2] > w.cap) ? 1 : 0;
+  if (w.clist && (uint32_t)w.counters[4] > w.clist_cap) {       // more radius candidates than the list holds: like an edge overflow (the caller
+    info[7] = 1;                                                // repeats the build with larger buffers), sized from the candidate count
+    info[2] = w.counters[4];
+  }
 }
 
 // degree by kept id (rows past n_kept get 0 so that the scan over n entries ends at the edge total)
@@ -703,18 +1142,43 @@ static bool agc_sim_x6() {
   static const int v = [] { const char* e = getenv("GIMS_SIM_PREC"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
   return v != 0;
 }
+// GIMS_AGC_EXACT_S=1: every similarity at f32-GEMM accuracy and the select over the whole matrix (the flow of rounds 1-3), else band-limited
+static bool agc_exact_s() {
+  const char* e = getenv("GIMS_AGC_EXACT_S");           // read per call: the tests switch flows
+  return e && atoi(e) != 0;
+}
 
-static size_t agc_layout(int n, int d, int max_edges_dir, char* base, AgcWs* w) {
-  const int lds = (n + 3) & ~3, nw = (n + 63) / 64;
+static size_t agc_layout(int n, int d, int max_edges_dir, bool exact_s, char* base, AgcWs* w) {
+  const int lds = (n + 3) & ~3, nw = (n + 63) / 64, lds16 = (n + 7) & ~7;
   const int cap = max_edges_dir > n * AGC_MIN_CAP_PER_NODE ? max_edges_dir : n * AGC_MIN_CAP_PER_NODE;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return base ? base + o : (char*)nullptr; };
   char* p;
-  p = take((size_t)n * d * 6); if (w) { w->dn = (float*)p; w->dn3 = (d % 32 == 0 && agc_sim_x6()) ? (uint16_t*)p : nullptr; }
-  p = take((size_t)n * lds * 4); if (w) w->S = (float*)p;
+  // descriptors: [n][d] f32 followed by [n][d] half (band-limited flow), or the SPL3 / f32 operand of the exact-S GEMM -- 6 n d bytes either way
+  p = take((size_t)n * d * 6);
+  if (w) {
+    w->dn = (float*)p; w->dnf = (float*)p;
+    w->dn16 = exact_s ? nullptr : (uint16_t*)(p + (size_t)n * d * 4);
+    w->dn3 = (exact_s && d % 32 == 0 && agc_sim_x6()) ? (uint16_t*)p : nullptr;
+  }
+  // similarities: f32 [n][lds] (exact-S flow), or half [n][lds16] followed by the band list (one u32 per pair of the strict upper triangle at most)
+  const size_t list_cap = (size_t)n * (n - 1) / 2 + 64;
+  const size_t s16_bytes = al256((size_t)n * lds16 * 2), cl_bytes = al256((size_t)cap * 4);
+  p = take(exact_s ? (size_t)n * lds * 4 : s16_bytes + 2 * cl_bytes + list_cap * 4);
+  if (w) {
+    w->S = exact_s ? (float*)p : nullptr;
+    w->S16 = exact_s ? nullptr : (uint16_t*)p;
+    w->clist = exact_s ? nullptr : (uint32_t*)(p + s16_bytes);
+    w->ckey = exact_s ? nullptr : (uint32_t*)(p + s16_bytes + cl_bytes);
+    w->list = exact_s ? nullptr : (uint32_t*)(p + s16_bytes + 2 * cl_bytes);
+    w->list_cap = exact_s ? 0u : (uint32_t)list_cap;
+    w->clist_cap = exact_s ? 0u : (uint32_t)cap;
+    w->lds16 = lds16;
+  }
   p = take((size_t)n * nw * 8); if (w) w->bits = (uint64_t*)p;
   p = take(4096 * 4); if (w) w->hist = (uint32_t*)p;
   p = take(16); if (w) w->sel = (uint32_t*)p;
+  p = take(16); if (w) w->band = (uint32_t*)p;
   p = take((size_t)n * 4); if (w) w->deg = (int32_t*)p;
   p = take((size_t)n * 4); if (w) w->nn = (int32_t*)p;
   p = take((size_t)n * 4); if (w) w->label = (int32_t*)p;
@@ -745,7 +1209,11 @@ extern "C" size_t gims_agc_workspace_bytes(const gims_agc_image* images, int32_t
   using namespace gims;
   if (!images || n_images <= 0) return 0;
   size_t b = agc_batch_header(n_images);
-  for (int i = 0; i < n_images; ++i) b += agc_layout(images[i].n, images[i].d, images[i].max_edges_dir, nullptr, nullptr);
+  for (int i = 0; i < n_images; ++i) {        // (the flow is read from the environment per call: room for either)
+    const size_t a = agc_layout(images[i].n, images[i].d, images[i].max_edges_dir, false, nullptr, nullptr);
+    const size_t e = agc_layout(images[i].n, images[i].d, images[i].max_edges_dir, true, nullptr, nullptr);
+    b += a > e ? a : e;
+  }
   return b;
 }
 
@@ -760,6 +1228,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   char* base = (char*)work + agc_batch_header(n_images);
   int maxn = 0, maxnw = 0;
   bool all_x6 = true;
+  const bool exact_s = agc_exact_s();
   GIMS_LDS_ATTR((const void*)agc_cc_kernel, AGC_MAX_N * 8);
   GIMS_LDS_ATTR((const void*)agc_iso_seq_kernel, AGC_MAX_N * 4 + (AGC_MAX_N / 32 + 2) * 4);
   std::vector<AgcWs> hws(n_images);
@@ -768,9 +1237,14 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     const gims_agc_image& im = images[i];
     GIMS_CHECK_ARG(im.kpts && im.desc && im.kept && im.indptr && im.indices && im.info, "gims_agc_build: image %d has a null pointer", i);
     GIMS_CHECK_ARG(im.n >= 2 && im.n <= AGC_MAX_N, "gims_agc_build: image %d: n=%d out of range [2, %d]", i, im.n, AGC_MAX_N);
+    static_assert(AGC_MAX_N <= (1 << 14), "the band list packs a pair as i << 14 | j");
     GIMS_CHECK_ARG(im.d > 0 && (im.d % 32) == 0 && (im.ldd % 4) == 0, "gims_agc_build: image %d: d=%d must be a multiple of 32 (ldd %% 4 == 0)", i, im.d);
     AgcWs* w = &hws[i];
-    base += agc_layout(im.n, im.d, im.max_edges_dir, base, w);
+    {
+      const size_t a = agc_layout(im.n, im.d, im.max_edges_dir, false, nullptr, nullptr), e = agc_layout(im.n, im.d, im.max_edges_dir, true, nullptr, nullptr);
+      agc_layout(im.n, im.d, im.max_edges_dir, exact_s, base, w);
+      base += a > e ? a : e;
+    }
     w->kpts = im.kpts; w->desc = im.desc; w->ldd = im.ldd; w->kept = im.kept; w->indptr = im.indptr; w->indices = im.indices;
     w->info = im.info; w->max_edges_dir = im.max_edges_dir;
     // K2 rank: k = int(L * p / 100), clamped (agc.py:378-379)
@@ -803,22 +1277,43 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   const dim3 gw(cdiv(maxn, 4), B), g1(1, B);
   // K1
   hipLaunchKernelGGL(agc_normalize_kernel, gw, dim3(256), 0, s, dws);
-  int rc = gims_linear_batch(dla, B, maxn, maxn, all_x6 ? GIMS_PREC_BF16X6 : GIMS_PREC_F32, stream);
-  if (rc != GIMS_OK) return rc;
-  // K2
+  int rc = GIMS_OK;
   // ~4096 workgroups in total: each folds its LDS histogram into the global one with 256 atomics, so one workgroup per
   // ROW (65 536 workgroups at 64 images x 1024 rows) spent most of the pass on those 16 M global atomics
   int hgrid = 4096 / (B > 0 ? B : 1);
   hgrid = hgrid < 16 ? 16 : (hgrid > 1024 ? 1024 : hgrid);
   hgrid = hgrid < maxn ? hgrid : maxn;
-  hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 20, 12, 0);
-  hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 20, 12);
-  hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 8, 12, 1);
-  hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 8, 12);
-  hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 0, 8, 2);
-  hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 0, 8);
+  if (exact_s) {
+    rc = gims_linear_batch(dla, B, maxn, maxn, all_x6 ? GIMS_PREC_BF16X6 : GIMS_PREC_F32, stream);
+    if (rc != GIMS_OK) return rc;
+    // K2
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 20, 12, 0);
+    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 20, 12);
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 8, 12, 1);
+    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 8, 12);
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 0, 8, 2);
+    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 0, 8);
+  } else {
+    // approximate matrix (half, one MFMA pass) -> bracket of the k-th value -> band entries -> their exact values -> exact k-th among them
+    const int T = cdiv(maxn, S16_T);
+    hipLaunchKernelGGL(agc_sim16_kernel, dim3(T * (T + 1) / 2, B), dim3(256), 0, s, dws);
+    hipLaunchKernelGGL(agc_sweep16_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 0);
+    hipLaunchKernelGGL(agc_band_kernel, g1, dim3(256), 0, s, dws);
+    hipLaunchKernelGGL(agc_sweep16_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 1);
+    hipLaunchKernelGGL(agc_radius_kernel, dim3(cdiv(cdiv(maxn, 2), 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
+    const int egrid = 4096 / B < 32 ? 32 : (4096 / B > 512 ? 512 : 4096 / B);
+    hipLaunchKernelGGL(agc_exact_kernel, dim3(egrid, B), dim3(256), 0, s, dws);
+    const int lgrid = 1024 / B < 4 ? 4 : (1024 / B > 64 ? 64 : 1024 / B);
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 20, 12, 2);
+    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 20, 12);
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 8, 12, 2);
+    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 8, 12);
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 0, 8, 2);
+    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 0, 8);
+  }
   // K3
-  hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv(maxn, 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
+  if (exact_s) hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv(maxn, 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
+  else hipLaunchKernelGGL(agc_apply_kernel, dim3(16, B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 1);
   // K4
   hipLaunchKernelGGL(agc_iso_nn_kernel, gw, dim3(256), 0, s, dws);
@@ -832,7 +1327,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   hipLaunchKernelGGL(agc_cc_kernel, g1, dim3(1024), (size_t)maxn * 8, s, dws, min_size);
   // K6: component sizes -> offsets; members, centroids, nearest component, links
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 1);
-  hipLaunchKernelGGL(agc_members_kernel, dim3(cdiv(maxn, 4) < 64 ? cdiv(maxn, 4) : 64, B), dim3(256), 0, s, dws);
+  hipLaunchKernelGGL(agc_members_kernel, dim3(32, B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_nnc_kernel, gw, dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_link_kernel, dim3(maxn < 256 ? maxn : 256, B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_link_apply_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
