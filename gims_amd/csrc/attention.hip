@@ -369,6 +369,12 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   };
   load_tile(0);                                // in flight together with the Q fragments below
   bool tile0_requested = true;
+  // The epilogue's transposing slices (Es) and, in the half instance, the workgroup's Q rows (Qs) share one LDS array: Q is dead when the
+  // epilogue starts (a workgroup barrier separates them).  Half instance: the 32 registers of the Q fragments are needed for the reference
+  // blocks `nref` below, so Q lives in LDS (each wave its own 64 rows, 128 bytes each, 16-byte chunks swizzled like the K tile) and its
+  // fragments are re-read per key tile together with the K fragments.
+  __shared__ __attribute__((aligned(16))) uint16_t QE[ATT8_WAVES * 32 * 132];
+  static_assert(ATT8_WAVES * 32 * 132 >= 512 * DH, "the Q rows of a workgroup fit the epilogue staging array");
   bf16x8 qf[QP][4];
 #pragma unroll
   for (int qi = 0; qi < QP; ++qi) {
@@ -378,11 +384,21 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[qi][s] = *(const bf16x8*)(qp + 16 * s);
   }
+  if constexpr (F16) {
+#pragma unroll
+    for (int qi = 0; qi < QP; ++qi)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) *(bf16x8*)(QE + (wave * QWV) * DH + k_off(qi * QW + li, 2 * s + lh)) = qf[qi][s];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // wave-private rows: no workgroup barrier
+  }
   // Q must have LANDED before the tile loop: otherwise the compiler guards the first MFMAs of EVERY iteration with
   // s_waitcnt vmcnt(..0), and since vmcnt retires in order those waits also sit out the loads of the next K/V tile that
   // were issued a moment earlier (measured: ~1100 of the 1575 cycles of that phase)
   __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) only
   f32x16 o[QP][2];
+  // half instance: -reference of each query block, sixteen equal registers per block -- the C operand of the first MFMA of every S^T chain, so
+  // the scores arrive as S - ref and the exponentials need no subtraction (zero in the exact pass, whose softmax carries its own reference)
+  f32x16 nref[F16 ? QP : 1];
   constexpr float DEFER = 5.0f;
   const float defer_raw = DEFER / c;
   float m_run[QP], l_run[QP];
@@ -396,6 +412,27 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   bf16x8 pf[QP][4];
   auto seg_qk = [&](int kt) __attribute__((always_inline)) {                 // S^T = K Q^T of tile kt (16 MFMAs)
     const int buf = kt & 1;
+    if constexpr (F16) {
+      // K and Q fragments from LDS (sixteen reads in flight), every chain seeded with -ref: S^T - ref
+      bf16x8 kf[2][4], qh[QP][4];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[b][s] = *(const bf16x8*)(Ks[buf] + k_off(b * 32 + li, 2 * s + lh));
+#pragma unroll
+      for (int qi = 0; qi < QP; ++qi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qh[qi][s] = *(const bf16x8*)(QE + (wave * QWV) * DH + k_off(qi * QW + li, 2 * s + lh));
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int qi = 0; qi < QP; ++qi) sacc[qi][b] = mfma_16b<F16>(kf[b][s], qh[qi][s], s == 0 ? nref[qi] : sacc[qi][b]);
+      // (left to the compiler's order -- four reads, two MFMAs, ...: pinning all sixteen reads ahead of the MFMAs like the bf16 form below measured
+      // 324 us per launch against 316)
+      return;
+    }
 #pragma unroll
     for (int qi = 0; qi < QP; ++qi)
 #pragma unroll
@@ -438,67 +475,62 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     // (row sums outside [1e-30, 1e30] send the workgroup to the exact pass) -- 64 fewer VALU per wave and tile again.
     if constexpr (F16) {
       if (!exact) {
-        // IEEE half has range 65504, so P = exp2(S) cannot go unreferenced like the bf16 pass above.  LAZY reference: the row maximum of
-        // the first key tile, raised only when a tile turns out to hold a score more than ~10 octaves above it -- seen from the lane's
-        // partial row sum (32 scores: a sum below 2^15 bounds every P below 2^15, no comparison per score), in which case the tile's
-        // own maximum becomes the reference, O and l are rescaled and the tile's exponentials are taken again (wave-uniform, at most
-        // once per tile, rare after the first tiles).  The reference never exceeds the true row maximum, so the dominant keys always
-        // sit in half's normal range (11-bit significand); keys 2^-14 below the reference go subnormal at an absolute 2^-25.
-        // (Tried and measured out, round 4: straight-line softmax with the test behind it and the raise as an inlined cold path, the
-        // second block's softmax in one basic block with the first block's P V MFMAs -- 96-220 bytes of scratch per lane whose reloads
-        // put a vmcnt(0) behind the next tile's global loads: 400 us per launch against 315 for this loop form.)
-        if (kt == 0) {
-          float tmax = -1e30f;
+        // IEEE half has range 65504, so P = exp2(S) cannot go unreferenced like the bf16 pass below.  A row reference follows the running
+        // maximum with a deferred rescale (only when a tile's maximum exceeds the reference by more than 10 octaves: P stays below 2^10),
+        // and it costs NO instruction per score: it enters through the accumulator seed of the S^T chains (seg_qk), so the scores arrive
+        // as S - ref and P = exp2 of them as they are.  The only branch encloses the (rare) raise -- rescale of O and l, shift of this
+        // tile's scores, new seed -- NOT the exponentials: those stay in one basic block with the P V MFMAs that follow, like the bf16
+        // pass (the compiler interleaves them).  The first tile always sets the reference to its row maxima (they may lie far below the
+        // starting reference 0, where exp2(S) would flush to zero).  The reference never exceeds the true row maximum, so the dominant
+        // keys sit in half's normal range (11-bit significand); keys 2^-14 below the reference go subnormal at an absolute 2^-25.
+        // Cost against the reference-free bf16 pass (GIMS_ATTN_PROF=1, wave 4 of workgroup 0, 64 tiles): S^T segment 68 k cycles against 53 k (the
+        // Q fragments come from LDS: their registers hold the seeds), the two softmax segments + P V 177 k against 141 k (sixteen v_max3 and
+        // one wave-uniform test per query block and tile) -- 316 us per launch against 265.  (Measured out in round 4, all at 315 +- 2 us as
+        // well: the reference as a per-score subtraction (v_fma_f32, then v_pk_add_f32) with Q in registers and a lazy raise detected from
+        // the row sums, the exponentials inside a retry loop; and, 400 us, that retry as an inlined cold path: 96-220 bytes of scratch per
+        // lane whose reloads put a vmcnt(0) behind the next tile's global loads.)
+        constexpr float RAISE = 10.f;
+        float tmax = -1e30f;
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
-          m_run[qi] = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        }
-#pragma unroll 1
-        for (int round = 0; round < 2; ++round) {
-          const float mc = NOFMA ? m_run[qi] : m_run[qi] * c;
-          const f32x2 mc2 = {mc, mc};
-          f32x2 lsum2 = {0.f, 0.f};
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            float pv[16];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-              // the reference is subtracted two scores per issue (v_pk_add_f32): one VALU issue per score pair more than the bf16 pass
-              const f32x2 d = NOFMA ? f32x2{sacc[qi][b][r], sacc[qi][b][r + 1]} - mc2 : f32x2{sacc[qi][b][r], sacc[qi][b][r + 1]} * f32x2{c, c} - mc2;
-              pv[r] = __builtin_amdgcn_exp2f(d.x);
-              pv[r + 1] = __builtin_amdgcn_exp2f(d.y);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) lsum2 += f32x2{pv[r], pv[r + 1]};
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-              uint4 pk;
-              pk.x = pack_16b<F16>(pv[8 * h2 + 0], pv[8 * h2 + 1]);
-              pk.y = pack_16b<F16>(pv[8 * h2 + 2], pv[8 * h2 + 3]);
-              pk.z = pack_16b<F16>(pv[8 * h2 + 4], pv[8 * h2 + 5]);
-              pk.w = pack_16b<F16>(pv[8 * h2 + 6], pv[8 * h2 + 7]);
-              pf[qi][2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
-            }
-          }
-          const float lsum = lsum2.x + lsum2.y;
-          if (round == 1 || !__any(!(lsum < 32768.f))) { l_run[qi] += lsum; break; }
-          float tmax = -1e30f;
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-          const float m_new = fmaxf(m_run[qi], tmax);
-          const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
-          m_run[qi] = m_new;
+          for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qi][b][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        if (kt == 0 || __any(tmax * c > RAISE)) {
+          const float dmax = kt == 0 ? tmax : fmaxf(tmax, 0.f);                 // (after the first tile the reference only ever moves up)
+          const float alpha = __builtin_amdgcn_exp2f(-dmax * c);
+          m_run[qi] += dmax;
           l_run[qi] *= alpha;
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qi][i][r] *= alpha;
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[qi][b][r] -= dmax;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) nref[qi][r] = -m_run[qi];
         }
+        f32x2 lsum2 = {0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float pv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pv[r] = NOFMA ? __builtin_amdgcn_exp2f(sacc[qi][b][r]) : __builtin_amdgcn_exp2f(sacc[qi][b][r] * c);
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) lsum2 += f32x2{pv[r], pv[r + 1]};
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            uint4 pk;
+            pk.x = pack_16b<F16>(pv[8 * h2 + 0], pv[8 * h2 + 1]);
+            pk.y = pack_16b<F16>(pv[8 * h2 + 2], pv[8 * h2 + 3]);
+            pk.z = pack_16b<F16>(pv[8 * h2 + 4], pv[8 * h2 + 5]);
+            pk.w = pack_16b<F16>(pv[8 * h2 + 6], pv[8 * h2 + 7]);
+            pf[qi][2 * b + h2] = __builtin_bit_cast(bf16x8, pk);
+          }
+        }
+        l_run[qi] += lsum2.x + lsum2.y;
         return;
       }
     }
@@ -579,7 +611,13 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   constexpr bool exact = decltype(ex)::value;
 #pragma unroll
   for (int qi = 0; qi < QP; ++qi) {
-    m_run[qi] = (NOFMA && !exact) ? 0.f : -1e30f; l_run[qi] = 0.f;
+    m_run[qi] = (NOFMA && !exact && !F16) ? 0.f : -1e30f; l_run[qi] = 0.f;
+    if constexpr (F16) {
+      // first pass: start from reference 0 (a seed of 1e30 would absorb S); the first tile's softmax sets it to the tile's row maxima
+#pragma unroll
+      for (int r = 0; r < 16; ++r) nref[qi][r] = 0.f;
+      if (!exact) m_run[qi] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -625,7 +663,6 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   // keys).  For the split-bf16 output -- a head's 64 channels are 256 contiguous bytes of a row there, [32 hi|32 lo] x 2 --
   // each wave transposes one 32-query block at a time through a private LDS slice (264-byte pitch: the 8-byte writes of 16
   // lanes hit 32 distinct banks) and stores whole rows, 16 bytes per lane, 4 rows per instruction.
-  __shared__ __attribute__((aligned(16))) uint16_t Es[ATT8_WAVES][32 * 132];
   const bool row_stores = out_hi && !out && out_lo == out_hi + 32;
 #pragma unroll
   for (int qi = 0; qi < QP; ++qi) {
@@ -633,7 +670,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     const float inv = 1.f / l_tot;
     const int qr = q0 + wave * QWV + qi * QW + li;
     if (row_stores) {
-      uint16_t* es = Es[wave];
+      uint16_t* es = QE + wave * (32 * 132);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
