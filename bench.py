@@ -466,8 +466,10 @@ def main():
         if world == 1 and args.kpts is None:
             # BASELINE config 5: CAR-HyNet descriptors for both images + 2x8192-keypoint matching, 2 pairs per step
             try:
-                from tools.pipeline_bench import measure as pipeline_measure
+                from tools.pipeline_bench import measure as pipeline_measure, measure_from_images
                 res.setdefault("also", {})["pipeline_2x8192"] = pipeline_measure(8192, 2, 3)
+                # the same chain with SURVEY row f4 (patch extraction from a resident image + keypoints) inside the timed region
+                res["also"]["pipeline_2x8192"]["from_images"] = measure_from_images(8192, 2, 3)
             except Exception as e:   # noqa: BLE001
                 res.setdefault("also", {})["pipeline_2x8192"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and (args.latency or args.kpts is None):

@@ -664,62 +664,16 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
   dim3 grid(cdiv(a->n, BN), cdiv(a->m, BM));
   if (a->a0_lo) {
     // tile geometry: 256x256 (half the operand bytes per MFMA) when that still gives ~one workgroup per CU,
-    // else 128x128.  GIMS_X3P_TILE=128|256 forces one (experiments).
+    // else 128x128.  GIMS_X3P_TILE=128|256 forces one (A/B).
     using TS = X3P<128, 128, 2, 2, 2>;
     using TL = X3P<256, 256, 4, 2, 2>;
-    static int force = -1, qkv_tile = 3;
-    if (force < 0) {
-      const char* e = getenv("GIMS_X3P_TILE");
-      force = e ? atoi(e) : 0;
-      const char* eq = getenv("GIMS_X3P_QKV");
-      qkv_tile = eq ? atoi(eq) : 3;          // 0: 256 x 256 tiles for the one-pass GEMMs too; 2 / 3: 256 x 128, that many stages
-      const void* fs = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2>;
-      const void* fl = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2>;
-      const void* fs1 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 4, 1>;
-      const void* fl1 = (const void*)linear_x3p_kernel<256, 256, 4, 2, 4, 1>;
-      const void* fl2 = (const void*)linear_x3p_kernel<256, 256, 4, 2, 2, 2>;
-      const void* fs2 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 2, 2>;
-      constexpr int ls = TS::LDS_BYTES, ll = TL::LDS_BYTES;
-      GIMS_HIP(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
-      GIMS_HIP(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
-      using TSH0 = X3P<128, 128, 2, 2, 4, true>;
-      using TLH0 = X3P<256, 256, 4, 2, 4, true>;
-      constexpr int ls1 = TSH0::LDS_BYTES, ll1 = TLH0::LDS_BYTES;   // hi-only: 4-stage rings of half rows
-      GIMS_HIP(hipFuncSetAttribute(fs1, hipFuncAttributeMaxDynamicSharedMemorySize, ls1));
-      GIMS_HIP(hipFuncSetAttribute(fl1, hipFuncAttributeMaxDynamicSharedMemorySize, ll1));
-      GIMS_HIP(hipFuncSetAttribute(fl2, hipFuncAttributeMaxDynamicSharedMemorySize, ll));
-      GIMS_HIP(hipFuncSetAttribute(fs2, hipFuncAttributeMaxDynamicSharedMemorySize, ls));
-    }
+    static const int force = [] { const char* e = getenv("GIMS_X3P_TILE"); return e ? atoi(e) : 0; }();
+    // one-pass (Q/K/V) GEMMs: 0 = 256 x 256 tiles like the others; 2 / 3 = 256 x 128 tiles with that many ring stages (default 3)
+    static const int qkv_tile = [] { const char* e = getenv("GIMS_X3P_QKV"); return e ? atoi(e) : 3; }();
     const int big_blocks = cdiv(a->m, 256) * cdiv(a->n, 256);
     // the 256-wide tile only when it is not half empty (n = 64 / 128 layers of the keypoint encoder and GraphSAGE)
     const bool big = force == 256 || (force != 128 && big_blocks >= 192 && (a->n % 256 == 0 || a->n > 512));
-    if (force == 1288) {      // experiment: 128 x 128 tiles on EIGHT waves (two per SIMD) for small, latency-bound launches
-      using T8 = X3P<128, 128, 4, 2, 2>;
-      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 128, 4, 2, 2>, (int)T8::LDS_BYTES);
-      constexpr size_t lds = T8::LDS_BYTES;
-      hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 4, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(512), lds, s, *a);
-    } else if (force == 1283 || force == 1284 || force == 2563) {      // experimental ring geometries
-      using T3 = X3P<256, 128, 4, 2, 3>;
-      using T4 = X3P<128, 128, 2, 2, 4>;
-      using T5 = X3P<128, 128, 2, 2, 3>;
-      const void* f3 = (const void*)linear_x3p_kernel<256, 128, 4, 2, 3>;
-      const void* f4 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 4>;
-      const void* f5 = (const void*)linear_x3p_kernel<128, 128, 2, 2, 3>;
-      constexpr int l3 = T3::LDS_BYTES, l4 = T4::LDS_BYTES, l5 = T5::LDS_BYTES;
-      GIMS_LDS_ATTR(f3, l3);
-      GIMS_LDS_ATTR(f4, l4);
-      GIMS_LDS_ATTR(f5, l5);
-      if (force == 2563) {
-        constexpr size_t lds = T3::LDS_BYTES;
-        hipLaunchKernelGGL((linear_x3p_kernel<256, 128, 4, 2, 3>), dim3(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 128)), dim3(512), lds, s, *a);
-      } else if (force == 1284) {
-        constexpr size_t lds = T4::LDS_BYTES;
-        hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 4>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
-      } else {
-        constexpr size_t lds = T5::LDS_BYTES;
-        hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 3>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128)), dim3(256), lds, s, *a);
-      }
-    } else if (big && (a->flags & GIMS_LINEAR_HI_ONLY) && qkv_tile > 0) {
+    if (big && (a->flags & GIMS_LINEAR_HI_ONLY) && qkv_tile > 0) {
       // one-pass GEMMs with a short K (the Q/K/V projection: K = 256, 8 stages) are all prologue and epilogue: 256 x 128
       // tiles with 64 accumulator registers per wave let TWO workgroups share a CU, one's epilogue under the other's loads
       using TQ2 = X3P<256, 128, 4, 2, 2, true>;
@@ -732,6 +686,9 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
     } else if (big) {
       using TLH = X3P<256, 256, 4, 2, 4, true>;
       constexpr size_t lds = TL::LDS_BYTES, lds_h = TLH::LDS_BYTES;
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<256, 256, 4, 2, 4, 1>, (int)lds_h);
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<256, 256, 4, 2, 2, 2>, (int)lds);
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<256, 256, 4, 2, 2>, (int)lds);
       const dim3 g(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256));
       if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 4, 1>), g, dim3(512), lds_h, s, *a);
       else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2, 2>), g, dim3(512), lds, s, *a);
@@ -763,6 +720,9 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
     } else {
       using TSH = X3P<128, 128, 2, 2, 4, true>;
       constexpr size_t lds = TS::LDS_BYTES, lds_h = TSH::LDS_BYTES;
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 128, 2, 2, 4, 1>, (int)lds_h);
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 128, 2, 2, 2, 2>, (int)lds);
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 128, 2, 2, 2>, (int)lds);
       const dim3 g(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128));
       if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 4, 1>), g, dim3(256), lds_h, s, *a);
       else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2, 2>), g, dim3(256), lds, s, *a);

@@ -23,6 +23,80 @@ PEAK_BF16_TFLOPS = 2500.0
 CARHYNET_MFLOP_PER_PATCH = 84.5          # flop counter on the reference's CAR_HyNet, one 32x32x3 patch
 
 
+def measure_from_images(kpts=8192, pairs=2, reps=3):
+    """The same chain starting one stage earlier (SURVEY row f4 inside the timed region): a uint8 image + SIFT-style keypoints (position,
+    size, angle, packed octave / layer) per image, resident in HBM -> Gaussian pyramid + one 64x64 affine warp per keypoint + 2x2 halving
+    (gims_patch_extract) -> CAR-HyNet -> GMatcher.match_pairs.  Image 1 of a pair is image 0 itself with the keypoints permuted like the
+    matcher's synthetic pair (identity homography), so its patches -- and descriptors -- correlate with image 0's.  Detection (OpenCV SIFT in
+    the reference) stays outside: keypoints are inputs."""
+    from gims_amd import GMatcher, hip, synth
+    from gims_amd.carhynet import CARHyNet
+    torch.set_grad_enabled(False)
+    net = CARHyNet().eval()
+    net.load_state_dict(synth.make_carhynet_state_dict(321))
+    matcher = GMatcher({}).eval()
+    matcher.load_state_dict(synth.make_state_dict(123))
+    dev = "cuda"
+    work = []
+    for p in range(pairs):
+        pair = synth.make_pair(kpts, 1000 + p)
+        w, h = synth.canvas_for(kpts)
+        r = np.random.default_rng(70 + p)
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        img = np.clip(128 + 50 * np.sin(xx / 9)[..., None] * np.cos(yy / 7)[..., None] + r.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+        perm = pair["gt_perm"]
+        size0, ang0 = r.uniform(2, 10, kpts).astype(np.float32), r.uniform(0, 360, kpts).astype(np.float32)
+        oct0 = ((r.integers(-1, 3, kpts) & 0xFF) | (r.integers(0, 4, kpts) << 8)).astype(np.int32)
+        kp0 = np.concatenate([pair["keypoints0"][0], size0[:, None], ang0[:, None]], 1).astype(np.float32)
+        kp1 = np.empty_like(kp0); oct1 = np.empty_like(oct0)
+        kp1[perm] = kp0; oct1[perm] = oct0
+        kp1[:, :2] = pair["keypoints1"][0]                      # (image 0's keypoints, permuted and jittered by half a pixel)
+        d = {k: torch.from_numpy(v).to(dev) for k, v in pair.items() if k not in ("gt_perm", "image0", "image1", "descriptors0", "descriptors1")}
+        d["image0"], d["image1"] = pair["image0"], pair["image1"]
+        d.update(device=torch.device(dev), radius=15, percentile=2, min_size=7)
+        timg = torch.from_numpy(img).to(dev)
+        work.append((d, timg, [torch.from_numpy(k).to(dev) for k in (kp0, kp1)], [torch.from_numpy(o).to(dev) for o in (oct0, oct1)], perm))
+
+    def patches():
+        out = []
+        for _, timg, kps, octs, _ in work:
+            pyr, levels, dev_levels = hip.pyramid_build(timg)     # (both images of the pair are this image: one pyramid)
+            out.append([hip.patch_extract(pyr, dev_levels, len(levels), kps[i], octs[i])[0] for i in range(2)])
+        return out
+
+    def descriptors(pt):
+        return [[net._forward_nhwc(x)[0] for x in pp] for pp in pt]
+
+    def match(descs):
+        datas = []
+        for (d, _, _, _, _), (d0, d1) in zip(work, descs):
+            dd = dict(d)
+            dd["descriptors0"], dd["descriptors1"] = torch.cat([d0, d0], 1).t()[None], torch.cat([d1, d1], 1).t()[None]   # common.py:891
+            datas.append(dd)
+        return matcher.match_pairs(datas)
+
+    def timed(fn, *args):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = fn(*args)
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    for _ in range(3):
+        outs = match(descriptors(patches()))
+    t_pat = t_all = 0.0
+    for _ in range(reps):
+        _, dt = timed(patches); t_pat += dt
+        outs, dt = timed(lambda: match(descriptors(patches()))); t_all += dt
+    m0 = outs[0]["matches0"][0].cpu().numpy()
+    hh, ww = work[0][1].shape[:2]
+    return {"metric": f"image-pairs/sec at 2x{kpts} keypoints INCLUDING patch extraction and CAR-HyNet descriptors", "value": pairs * reps / t_all, "unit": "pairs/s",
+            "pairs_per_step": pairs, "steps": reps, "ms_per_pair": 1e3 * t_all / (pairs * reps), "ms_per_pair_patches_only": 1e3 * t_pat / (pairs * reps),
+            "matches_pair0": int((m0 >= 0).sum()), "data": "synthetic",
+            "config": {"workload": f"{pairs} pairs/step: uint8 image {hh}x{ww}x3 + 2x{kpts} keypoints with size / angle / octave -> "
+                                   "Gaussian pyramid + 64x64 affine warps + halving (gims_patch_extract) -> CAR-HyNet -> GMatcher.match_pairs; "
+                                   "keypoint detection is an input (OpenCV SIFT in the reference)"}}
+
+
 def measure(kpts=8192, pairs=2, reps=3):
     """The JSON block of one measurement (also embedded in bench.py's line as also["pipeline_2x8192"])."""
     from gims_amd import GMatcher, synth
@@ -95,7 +169,9 @@ def main():
     a = ap.parse_args()
     import __graft_entry__
     __graft_entry__.build()
-    print(json.dumps(measure(a.kpts, a.pairs, a.reps)))
+    res = measure(a.kpts, a.pairs, a.reps)
+    res["from_images"] = measure_from_images(a.kpts, a.pairs, a.reps)
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":
