@@ -279,21 +279,25 @@ __device__ __forceinline__ float agc_exact_sim8(const float* __restrict__ a, con
 // K in chunks of 128 (operands by LDS-DMA: 2 x 32 KB, 16-byte chunks XOR-swizzled with row & 15 on the source side); two workgroups per CU take
 // turns loading and multiplying.  The tile leaves as whole 256-byte row pieces through an LDS transpose.
 constexpr int S16_T = 128, S16_KC = 128, S16_EP = 136;        // tile, K chunk, epilogue pitch (halves)
+constexpr int S16_LDS_BYTES = 2 * S16_T * S16_KC * 2 + 4096 * 4;    // operand chunks (64 KB) + the workgroup's 12-bit histogram (16 KB): two workgroups per CU
 __global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restrict__ ws) {
   const AgcWs& w = ws[blockIdx.y];
-  const int n = w.n, d = w.d, T = (n + S16_T - 1) / S16_T;
-  // linear index -> (ti <= tj): rows of the upper triangle hold T, T - 1, ... tiles
-  int rem = blockIdx.x, ti = 0;
-  if (rem >= T * (T + 1) / 2) return;
-  while (rem >= T - ti) { rem -= T - ti; ++ti; }
-  const int tj = ti + rem;
-  const int i0 = ti * S16_T, j0 = tj * S16_T;
-  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * S16_T * S16_KC];        // 64 KB: A chunk | B chunk; epilogue: [128][136]
+  const int n = w.n, d = w.d, T = (n + S16_T - 1) / S16_T, ntiles = T * (T + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // A chunk | B chunk (epilogue: [128][136] halves) | histogram
   uint16_t* As = lds;
   uint16_t* Bs = lds + S16_T * S16_KC;
+  uint32_t* hist = (uint32_t*)(lds + 2 * S16_T * S16_KC);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wi = wave >> 1, wj = wave & 1, li = lane & 31, lh = lane >> 5;
+  for (int i = t; i < 4096; i += 256) hist[i] = 0u;
+  // persistent over the tiles of the upper triangle: the histogram of everything this workgroup produced is folded into the image's ONCE
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // linear index -> (ti <= tj): rows of the upper triangle hold T, T - 1, ... tiles
+  int rem = tile, ti = 0;
+  while (rem >= T - ti) { rem -= T - ti; ++ti; }
+  const int tj = ti + rem;
+  const int i0 = ti * S16_T, j0 = tj * S16_T;
   f32x16 acc[2][2];        // [jb][ib]: lane holds S[i = wi*64 + ib*32 + li][j = wj*64 + jb*32 + (r&3) + 8*(r>>2) + 4*lh]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restri
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  __syncthreads();                                             // (the previous tile's epilogue is done with the operand buffers)
   for (int k0 = 0; k0 < d; k0 += S16_KC) {
     const int kc = d - k0 < S16_KC ? d - k0 : S16_KC;       // multiple of 32
     const int cpr = kc / 8;                                  // 16-byte chunks per row of this K chunk (<= 16)
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restri
     }
     __syncthreads();
   }
-  // ---- epilogue: half values -> LDS [row i][col j] (pitch 136 halves), then whole row pieces out
+  // ---- epilogue: half values -> LDS [row i][col j] (pitch 136 halves), then whole row pieces out; the strict upper triangle is histogrammed
   uint16_t* es = lds;
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb)
@@ -347,7 +352,15 @@ __global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restri
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int i = wi * 64 + ib * 32 + li, j = wj * 64 + jb * 32 + 8 * g + 4 * lh;
-        *(uint2*)(es + i * S16_EP + j) = make_uint2(pack_h2_sat(acc[jb][ib][4 * g], acc[jb][ib][4 * g + 1]), pack_h2_sat(acc[jb][ib][4 * g + 2], acc[jb][ib][4 * g + 3]));
+        const uint32_t lo = pack_h2_sat(acc[jb][ib][4 * g], acc[jb][ib][4 * g + 1]), hi = pack_h2_sat(acc[jb][ib][4 * g + 2], acc[jb][ib][4 * g + 3]);
+        *(uint2*)(es + i * S16_EP + j) = make_uint2(lo, hi);
+        const int gi = i0 + i, gj = j0 + j;
+        if (gi < n) {
+          if (gj + 0 > gi && gj + 0 < n) atomicAdd(&hist[h16_key((uint16_t)(lo & 0xffffu)) >> 4], 1u);
+          if (gj + 1 > gi && gj + 1 < n) atomicAdd(&hist[h16_key((uint16_t)(lo >> 16)) >> 4], 1u);
+          if (gj + 2 > gi && gj + 2 < n) atomicAdd(&hist[h16_key((uint16_t)(hi & 0xffffu)) >> 4], 1u);
+          if (gj + 3 > gi && gj + 3 < n) atomicAdd(&hist[h16_key((uint16_t)(hi >> 16)) >> 4], 1u);
+        }
       }
   __syncthreads();
 #pragma unroll
@@ -356,6 +369,10 @@ __global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restri
     const int gi = i0 + i, gj = j0 + 8 * c;
     if (gi < n && gj < w.lds16) *(uint4*)(w.S16 + (int64_t)gi * w.lds16 + gj) = *(const uint4*)(es + i * S16_EP + 8 * c);
   }
+  }
+  __syncthreads();
+  for (int i = t; i < 4096; i += 256)
+    if (hist[i]) atomicAdd(&w.hist[i], hist[i]);
 }
 
 // 12-bit histogram (top bits of the 16-bit order-preserving key) of the strict upper triangle of S16 (collect == 0), or, collect == 1, the packed
@@ -1295,9 +1312,11 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 0, 8);
   } else {
     // approximate matrix (half, one MFMA pass) -> bracket of the k-th value -> band entries -> their exact values -> exact k-th among them
-    const int T = cdiv(maxn, S16_T);
-    hipLaunchKernelGGL(agc_sim16_kernel, dim3(T * (T + 1) / 2, B), dim3(256), 0, s, dws);
-    hipLaunchKernelGGL(agc_sweep16_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 0);
+    const int T = cdiv(maxn, S16_T), ntiles = T * (T + 1) / 2;
+    GIMS_LDS_ATTR((const void*)agc_sim16_kernel, S16_LDS_BYTES);
+    int sgrid = 1024 / B < 1 ? 1 : 1024 / B;                 // ~two workgroups per CU over the whole batch, each folding ONE histogram
+    sgrid = sgrid < ntiles ? sgrid : ntiles;
+    hipLaunchKernelGGL(agc_sim16_kernel, dim3(sgrid, B), dim3(256), S16_LDS_BYTES, s, dws);     // (the 12-bit histogram comes out of its epilogue)
     hipLaunchKernelGGL(agc_band_kernel, g1, dim3(256), 0, s, dws);
     hipLaunchKernelGGL(agc_sweep16_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 1);
     hipLaunchKernelGGL(agc_radius_kernel, dim3(cdiv(cdiv(maxn, 2), 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
