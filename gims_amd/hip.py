@@ -1129,6 +1129,7 @@ def softmax_rows_backward_(prob: torch.Tensor, dp: torch.Tensor, cols: int):
 
 
 _colsum_work = {}
+_colsum_retired = []
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor | None = None, beta=0.0):
@@ -1140,6 +1141,10 @@ def colsum(x: torch.Tensor, out: torch.Tensor | None = None, beta=0.0):
     key = (x.device, _stream())
     w = _colsum_work.get(key)
     if w is None or w.numel() < need:
+        if w is not None:
+            # a kernel enqueued on this (possibly non-torch) stream may still be reading the outgrown workspace, and torch's allocator orders
+            # re-use only against ITS streams: the old buffer is kept alive for the life of the process (regrowth is rare, the buffers small)
+            _colsum_retired.append(w)
         w = _colsum_work[key] = torch.zeros(max(need, 1 << 16), dtype=torch.float32, device=x.device)
         if getattr(_TLS, "pin", None) is not None:
             torch.cuda.current_stream(x.device).synchronize()      # the zero fill ran on torch's stream, the kernel may run on another (on_stream)

@@ -2,7 +2,7 @@
 # Run-to-run spread of the headline workload on ONE box (through gpurun):  tools/bench_20runs.sh r03
 # 20 consecutive processes; prints pairs/s, ms per step, host wall per step {median, max} and the number of on-chip Sinkhorn launches
 # that fell to the rescue (status 2) -- the bounded waits of ot_res2_kernel are the thing this file watches.
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out/refresh
 mkdir -p $O
 F=$O/${TAG}_bench_20runs.txt

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the round's measurement evidence on a GPU box (run through gpurun from the repo root):
-#   tools/refresh_profiles.sh r03
+#   tools/refresh_profiles.sh r04
 # Outputs land in gpurun_out/refresh/; copy what should be judged into profiles/ (tools/README.md).
 # Every rocprofv3 run is csv-only and wrapped in `timeout` (a run that builds the rocpd database can hang for minutes).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD
 O=$R/gpurun_out/refresh
 mkdir -p $O

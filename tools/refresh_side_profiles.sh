@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's evidence for the rows either side of the matcher: CAR-HyNet, descriptors + matcher, patch extraction, training step.
 #   tools/refresh_side_profiles.sh r03     (through gpurun from the repo root; outputs in gpurun_out/side/, copy into profiles/)
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD; O=$R/gpurun_out/side; mkdir -p $O
 python tools/carhynet_bench.py > $O/${TAG}_bench_carhynet_16384.json 2> $O/carhynet.err
 python tools/pipeline_bench.py --kpts 8192 --pairs 2 > $O/${TAG}_pipeline_8192x2.json 2> $O/pipe8192.err
