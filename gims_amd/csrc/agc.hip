@@ -72,6 +72,7 @@ __global__ void agc_init_kernel(const AgcWs* __restrict__ ws) {
     w.sel[0] = 0u; w.sel[1] = (uint32_t)(w.krank & 0xffffffffll); w.sel[2] = (uint32_t)(w.krank >> 32); w.sel[3] = 0u;
     for (int i = 0; i < 8; ++i) w.info[i] = 0;
     for (int i = 0; i < 16; ++i) w.counters[i] = 0;
+    for (int i = 0; i < 4; ++i) w.band[i] = 0u;
   }
   for (int i = threadIdx.x; i < 4096; i += blockDim.x) w.hist[i] = 0u;
 }
@@ -90,11 +91,21 @@ __global__ __launch_bounds__(256) void agc_normalize_kernel(const AgcWs* __restr
   s = wave_sum(s);
   const float nrm = fmaxf(sqrtf(s), 1e-12f);   // F.normalize: x / max(||x||, eps)
   if (w.dn16) {    // band-limited flow: the f32 quotient (exact evaluations) and its rounding to half (approximate GEMM)
+    // ... and the 2-norm of the row's rounding error (kept per row in deg, as float bits): the measured half of the error bound of the approximate similarities (agc_window_kernel).  A half that is subnormal counts as flushed to zero (some
+    // matrix cores do): the bound holds either way.
+    float e2 = 0.f;
     for (int j = lane; j < d; j += 64) {
       const float v = x[j] / nrm;
+      const uint16_t hb = (uint16_t)(pack_h2_sat(v, 0.f) & 0xffffu);
       w.dnf[(int64_t)row * d + j] = v;
-      w.dn16[(int64_t)row * d + j] = (uint16_t)(pack_h2_sat(v, 0.f) & 0xffffu);
+      w.dn16[(int64_t)row * d + j] = hb;
+      const float back = (float)__builtin_bit_cast(_Float16, hb);
+      float e = fabsf(v - back);
+      if ((hb & 0x7c00u) == 0u) e = fmaxf(e, fabsf(v));
+      e2 = fmaf(e, e, e2);
     }
+    e2 = wave_sum(e2);
+    if (lane == 0) w.deg[row] = (int32_t)__float_as_uint(sqrtf(e2) * 1.0001f);      // (deg is free until the adjacency exists; agc_window_kernel takes the maximum)
     return;
   }
   if (w.dn3) {     // exact three-way split of the f32 quotient (linear6.hip: SPL3 layout)
@@ -235,8 +246,18 @@ __global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__
 // elements below 2^-14 go subnormal at an absolute 2^-25, < 2^-21 over 256 of them), products exact in f32, 256 f32 additions
 // (< 2e-5), result rounded to half (<= 2^-11 for |S| <= 2).  0.000977 + 0.00002 + 0.00049 < 0.0016.
 constexpr float AGC_EPS = 0.0016f;
+// Placement of per-image work that re-reads the image's rows (similarity tiles, gathered exact dot products): block b runs on XCD b % 8
+// (observed; a speed assumption only), and the eight XCDs take the (image, part) units q = xcd, xcd + 8, ... in turn, with
+// nparts = 8 / gcd(n_images, 8) parts per image -- an image's rows are fetched into ONE XCD's 4-MB L2 (16 images: two per XCD, one after the
+// other) instead of into all eight.  Grids of these kernels are 1-D multiples of 8.
+__device__ __forceinline__ int agc_nparts(int n_images) {
+  int g = n_images & -n_images;
+  g = g > 8 ? 8 : g;
+  return 8 / g;
+}
 typedef _Float16 agc_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 agc_h2 __attribute__((ext_vector_type(2)));
+typedef float agc_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t h16_key(uint16_t h) { return (h & 0x8000u) ? (uint32_t)(uint16_t)~h : (uint32_t)(h | 0x8000u); }
 __device__ __forceinline__ float h16_val(uint32_t key) {      // inverse of h16_key, as f32
   const uint16_t h = (key & 0x8000u) ? (uint16_t)(key & 0x7fffu) : (uint16_t)~key;
@@ -275,14 +296,13 @@ __device__ __forceinline__ float agc_exact_sim8(const float* __restrict__ a, con
   return (float)acc;
 }
 
-// S16 = Dn16 Dn16^T, 128 x 128 tiles that touch the upper triangle, one MFMA pass on v_mfma_f32_32x32x16_f16.  4 waves (2 x 2), 64 x 64 per wave;
-// K in chunks of 128 (operands by LDS-DMA: 2 x 32 KB, 16-byte chunks XOR-swizzled with row & 15 on the source side); two workgroups per CU take
-// turns loading and multiplying.  The tile leaves as whole 256-byte row pieces through an LDS transpose.
+// Robust flow.  S16 = Dn16 Dn16^T, 128 x 128 tiles that touch the upper triangle, one MFMA pass on v_mfma_f32_32x32x16_f16.  4 waves (2 x 2),
+// 64 x 64 per wave; K in chunks of 128 (operands by LDS-DMA: 2 x 32 KB, 16-byte chunks XOR-swizzled with row & 15 on the source side); two
+// workgroups per CU take turns loading and multiplying.  The tile leaves in half as whole 256-byte row pieces through an LDS transpose and the
+// strict upper triangle is histogrammed on the 12-bit half key.
 constexpr int S16_T = 128, S16_KC = 128, S16_EP = 136;        // tile, K chunk, epilogue pitch (halves)
-constexpr int S16_LDS_BYTES = 2 * S16_T * S16_KC * 2 + 4096 * 4;    // operand chunks (64 KB) + the workgroup's 12-bit histogram (16 KB): two workgroups per CU
-__global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restrict__ ws) {
-  const AgcWs& w = ws[blockIdx.y];
-  const int n = w.n, d = w.d, T = (n + S16_T - 1) / S16_T, ntiles = T * (T + 1) / 2;
+constexpr int S16_LDS_BYTES = 2 * S16_T * S16_KC * 2 + 4096 * 4;    // operand chunks (64 KB) + the workgroup's histogram / staging buffer (16 KB): two workgroups per CU
+__global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restrict__ ws, int n_images) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // A chunk | B chunk (epilogue: [128][136] halves) | histogram
   uint16_t* As = lds;
   uint16_t* Bs = lds + S16_T * S16_KC;
@@ -291,8 +311,13 @@ __global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restri
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wi = wave >> 1, wj = wave & 1, li = lane & 31, lh = lane >> 5;
   for (int i = t; i < 4096; i += 256) hist[i] = 0u;
-  // persistent over the tiles of the upper triangle: the histogram of everything this workgroup produced is folded into the image's ONCE
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int nparts = agc_nparts(n_images);
+  for (int q = blockIdx.x & 7; q < n_images * nparts; q += 8) {
+  const AgcWs& w = ws[q / nparts];
+  const int n = w.n, d = w.d, T = (n + S16_T - 1) / S16_T;
+  const int ntiles = T * (T + 1) / 2;
+  // persistent over its share of the image's tiles: what this workgroup found for the image is folded into the image's ONCE
+  for (int tile = q % nparts + nparts * (int)(blockIdx.x >> 3); tile < ntiles; tile += nparts * (int)(gridDim.x >> 3)) {
   // linear index -> (ti <= tj): rows of the upper triangle hold T, T - 1, ... tiles
   int rem = tile, ti = 0;
   while (rem >= T - ti) { rem -= T - ti; ++ti; }
@@ -372,7 +397,345 @@ __global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restri
   }
   __syncthreads();
   for (int i = t; i < 4096; i += 256)
-    if (hist[i]) atomicAdd(&w.hist[i], hist[i]);
+    if (hist[i]) { atomicAdd(&w.hist[i], hist[i]); hist[i] = 0u; }
+  }
+}
+
+// Window flow: the approximate similarities (half operands, f32 MFMA accumulation) are looked at, never stored.  A workgroup of 4 waves (2 x 2,
+// 64 x 64 per wave) takes a unit = up to SW_SEG consecutive 128 x 128 tiles of one tile row.  Every wave keeps the MFMA fragments of ITS 64
+// rows for the whole K in REGISTERS for the unit (128 VGPRs): with both operands read from LDS a 64 x 64 wave tile needs exactly the LDS
+// bandwidth the CU has (1 KB per MFMA), and the column ring's DMA writes and the epilogue come on top; with the rows in registers it is half.
+// Only the column operand goes through LDS: K chunks of 64 in a two-buffer ring by LDS-DMA, the next chunk in flight under the MFMAs of the
+// current one.  48 KB of LDS and <= 256 VGPRs: two independent workgroups per CU, so one's epilogue runs under the other's MFMAs.  Units are
+// handed out by a per-image counter; an image's units run on ONE XCD (agc_nparts).  d % 64 == 0, d <= 256.
+//   SIM_SAMPLE   the rows i % stride == 0 against all columns: histogram of the strict upper triangle on 4096 LINEAR bins over [-1, 1) (stride 1 =
+//                every pair: small images);
+//   SIM_COLLECT  every pair: entries below the window [band[0], band[1]] are counted (counters[5]), entries inside it are appended to the list as
+//                (i << 14 | j) (LDS-staged: one global reservation per flush).
+constexpr int SIM_SAMPLE = 1, SIM_COLLECT = 2, SIM_STAGE = 4096;
+constexpr int AGC_SAMPLE_STRIDE = 8, AGC_SAMPLE_MIN_N = 1536;      // images of at most that many rows are "sampled" in full: their window is rigorous
+__host__ __device__ __forceinline__ int agc_sample_stride(int n) { return n > AGC_SAMPLE_MIN_N ? AGC_SAMPLE_STRIDE : 1; }
+__device__ __forceinline__ int agc_linear_bin(float v) {
+  int b = (int)((v + 1.f) * 2048.f);
+  b = b < 0 ? 0 : (b > 4095 ? 4095 : b);
+  return v == v ? b : 4095;
+}
+// LDS accesses of the epilogues as raw instructions: in front of every LDS access it can see, the compiler waits for ALL outstanding LDS-DMA
+// loads (vmcnt(0): it cannot tell that the column ring and the staging buffer do not overlap) -- that is the next tile's first chunk, in flight
+// on purpose -- and it turns an atomicAdd of per-lane counts on one address into a scalar loop over the lanes.
+__device__ __forceinline__ uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ uint32_t lds_add_rtn_raw(uint32_t off, uint32_t v) {
+  uint32_t r;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(off), "v"(v) : "memory");
+  return r;
+}
+__device__ __forceinline__ void lds_add_raw(uint32_t off, uint32_t v) { asm volatile("ds_add_u32 %0, %1" ::"v"(off), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_write_raw(uint32_t off, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(off), "v"(v) : "memory"); }
+__device__ __forceinline__ uint32_t lds_read_raw(uint32_t off) {
+  uint32_t r;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(off) : "memory");
+  return r;
+}
+constexpr int SW_T = 128, SW_KC = 64, SW_KMAX = 256, SW_SEG = 6;
+constexpr int SW_RING = 3;                                                 // column chunks in LDS: one under the MFMAs, two in flight (an L2 round trip is longer than a chunk's MFMAs)
+constexpr int SW_LDS_BYTES = SW_RING * SW_T * SW_KC * 2 + 4096 * 4;     // column ring 3 x 16 KB + histogram / staging 16 KB
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void agc_simw_kernel(const AgcWs* __restrict__ ws, int n_images) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  uint16_t* Bs = lds;                                  // SW_RING x [128][64] halves, 16-byte chunks at position chunk ^ ((row >> 1) & 7)
+  uint32_t* hist = (uint32_t*)(lds + SW_RING * SW_T * SW_KC);
+  __shared__ int s_unit;
+  __shared__ uint32_t nst, gbase;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wi = wave >> 1, wj = wave & 1, li = lane & 31, lh = lane >> 5;
+  const uint32_t hist_off = lds_off(hist), nst_off = lds_off(&nst);
+  if (MODE == SIM_SAMPLE)
+    for (int i = t; i < 4096; i += 256) hist[i] = 0u;
+  if (t == 0) nst = 0u;
+  const int nparts = agc_nparts(n_images);
+  for (int q = blockIdx.x & 7; q < n_images * nparts; q += 8) {
+    const AgcWs& w = ws[q / nparts];
+    const int n = w.n, d = w.d, T = (n + 127) / 128, kpc = d / SW_KC;
+    const int stride = MODE == SIM_SAMPLE ? agc_sample_stride(n) : 1;
+    int nunits = 0;                                     // tile row ti holds the tiles stride * ti .. T - 1, in segments of SW_SEG
+    for (int ti = 0; T - stride * ti > 0; ++ti) nunits += (T - stride * ti + SW_SEG - 1) / SW_SEG;
+    // window [band[0], band[1]] as centre and squared half width (an empty or NaN window lists next to nothing: agc_finish_kernel reports the
+    // miss; what is tested is |v - centre|^2 <= half^2 in f32, a few ulps off the interval -- the verification's slack is a hundred times that)
+    agc_f2 vC2 = {0.f, 0.f}, hsq2 = {0.f, 0.f};
+    if (MODE == SIM_COLLECT) {
+      const float vL = __uint_as_float(w.band[0]), vU = __uint_as_float(w.band[1]), hw = 0.5f * (vU - vL), vC = 0.5f * (vL + vU);
+      vC2 = agc_f2{vC, vC};
+      hsq2 = hw >= 0.f ? agc_f2{hw * hw, hw * hw} : agc_f2{-1.f, -1.f};
+    }
+    uint32_t below = 0u;
+    auto flush = [&]() __attribute__((always_inline)) {        // (called by the whole workgroup)
+      __syncthreads();
+      const uint32_t cnt = nst < (uint32_t)SIM_STAGE ? nst : (uint32_t)SIM_STAGE;
+      if (t == 0) gbase = cnt ? atomicAdd(&w.sel[3], cnt) : 0u;
+      __syncthreads();
+      const uint32_t base = gbase;
+      for (uint32_t i = t; i < cnt; i += 256)
+        if (base + i < w.list_cap) w.list[base + i] = hist[i];
+      __syncthreads();
+      if (t == 0) nst = 0u;
+      __syncthreads();
+    };
+    while (true) {
+      __syncthreads();                                  // (the previous unit is done with s_unit)
+      if (t == 0) s_unit = atomicAdd(&w.counters[MODE == SIM_SAMPLE ? 8 : 9], 1);
+      __syncthreads();
+      int rem = s_unit;
+      if (rem >= nunits) break;
+      int ti = 0, m_row = 0;
+      for (;; ++ti) {
+        m_row = T - stride * ti;
+        const int segs = (m_row + SW_SEG - 1) / SW_SEG;
+        if (rem < segs) break;
+        rem -= segs;
+      }
+      const int t0 = rem * SW_SEG, ntl = m_row - t0 < SW_SEG ? m_row - t0 : SW_SEG;
+      const int i0 = ti * SW_T, jbase = (stride * ti + t0) * SW_T;
+      // column chunk (tile tl, K chunk kc) -> ring buffer: 16 pieces of 1 KiB (8 rows of 128 bytes), 4 per wave
+      auto issue_b = [&](int tl, int kc, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+          const int piece = wave * 4 + pc;
+          const int row = 8 * piece + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+          int gr = jbase + tl * SW_T + row;
+          gr = gr < n ? gr : n - 1;
+          const uint16_t* src = w.dn16 + (int64_t)gr * d + kc * SW_KC + 8 * ch;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(Bs + buf * (SW_T * SW_KC) + piece * 512), 16, 0, 0);
+        }
+      };
+      // the wave's rows as MFMA fragments, whole K: lane (li, lh) holds for k step s the 8 halves at k = 16 s + 8 lh of rows ib * 32 + li
+      bf16x8 af[2][SW_KMAX / 16];
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        int gr = stride * (i0 + wi * 64 + ib * 32 + li);
+        gr = gr < n ? gr : n - 1;
+        const __attribute__((address_space(1))) uint16_t* src = (const __attribute__((address_space(1))) uint16_t*)(w.dn16 + (int64_t)gr * d + 8 * lh);
+#pragma unroll
+        for (int s = 0; s < SW_KMAX / 16; ++s) af[ib][s] = *(const __attribute__((address_space(1))) bf16x8*)(src + (16 * s < d ? 16 * s : 0));   // (32 loads in flight)
+      }
+      const int nchunks = ntl * kpc;
+      issue_b(0, 0, 0);
+      if (nchunks > 1) issue_b(kpc > 1 ? 0 : 1, kpc > 1 ? 1 : 0, 1);
+      // (the fragments are "used" here: the compiler's wait for their loads lands in front of the tile loop, once per unit, instead of in front
+      // of the first MFMA of every tile, where it would also wait for the chunks in flight)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int s = 0; s < SW_KMAX / 16; ++s) asm volatile("" : "+v"(af[ib][s]));
+      f32x16 acc[2][2];        // [jb][ib]: lane holds S[i = wi*64 + ib*32 + li][j = wj*64 + jb*32 + (r&3) + 8*(r>>2) + 4*lh]
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      int par = 0, cidx = 0;                            // ring slot and index of the chunk under the MFMAs
+      int tl2 = kpc > 2 ? 0 : (kpc == 2 ? 1 : 2), kc2 = kpc > 2 ? 2 : 0;       // (tile, K chunk) of chunk cidx + 2
+      for (int tl = 0; tl < ntl; ++tl) {
+#pragma unroll
+        for (int kc = 0; kc < SW_KMAX / SW_KC; ++kc) {
+          if (kc >= kpc) break;
+          // chunk cidx has landed when at most the 4 loads of chunk cidx + 1 are outstanding
+          if (cidx + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();                 // ... for every wave; every wave is done with chunk cidx - 1: its slot takes chunk cidx + 2
+                                                        // (the bare barrier: __syncthreads() would wait for the chunks in flight as well)
+          if (MODE == SIM_COLLECT && kc == 0 && tl > 0 && lds_read_raw(nst_off) > (uint32_t)SIM_STAGE / 2) flush();     // (uniform) room for a dense tile
+          if (cidx + 2 < nchunks) issue_b(tl2, kc2, par >= 1 ? par - 1 : 2);
+          if (++kc2 == kpc) { kc2 = 0; ++tl2; }
+          ++cidx;
+          const uint16_t* Bb = Bs + par * (SW_T * SW_KC);
+          par = par == SW_RING - 1 ? 0 : par + 1;
+#pragma unroll
+          for (int s = 0; s < SW_KC / 16; ++s) {
+            bf16x8 bf[2];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+              const int row = wj * 64 + jb * 32 + li;
+              bf[jb] = *(const bf16x8*)(Bb + row * SW_KC + (((2 * s + lh) ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+              for (int ib = 0; ib < 2; ++ib)
+                acc[jb][ib] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(agc_h8, bf[jb]), __builtin_bit_cast(agc_h8, af[ib][kc * (SW_KC / 16) + s]),
+                                                                     acc[jb][ib], 0, 0, 0);
+          }
+        }
+        // ---- the tile is complete (the first chunk of the next one is in flight).  The epilogue is written for instruction count: it runs
+        // 16 384 times per image of 4096 on every wave.
+        const int j0 = jbase + tl * SW_T;
+        const bool interior = stride * (i0 + SW_T - 1) < j0 && stride * (i0 + SW_T - 1) < n && j0 + SW_T <= n;      // every entry a pair i < j < n
+        const int jl = j0 + wj * 64 + 4 * lh;
+        if (MODE == SIM_SAMPLE) {
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+              const int gi = stride * (i0 + wi * 64 + ib * 32 + li);
+              // pairs that do not exist (j <= i, or past n):  0 <= gj - gi - 1 < n - gi - 1  in one unsigned compare
+              const uint32_t span = gi < n ? (uint32_t)(n - gi - 1) : 0u;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float v = acc[jb][ib][r];
+                acc[jb][ib][r] = 0.f;
+                if (interior || (uint32_t)(jl + jb * 32 + (r & 3) + 8 * (r >> 2) - gi - 1) < span) lds_add_raw(hist_off + 4u * (uint32_t)agc_linear_bin(v), 1u);
+              }
+            }
+        } else {
+          // u = v - vC, t = h^2 - u^2 (vC, h = centre and half width of the window): inside iff t >= 0, below iff outside and u < 0, above
+          // otherwise -- a partition whatever the rounding.  Only SIGN BITS are needed: two packed instructions per PAIR of entries
+          // (v_pk_add_f32, v_pk_fma_f32) and one v_alignbit per entry and mask that shifts the bit into a per-lane word; no compare.
+          uint32_t sgn[2] = {0u, 0u}, out[2] = {0u, 0u};      // entry 16 * ib + r of word jb sits at bit 31 - (16 * ib + r)
+          auto classify2 = [&](float v0, float v1, int jb) __attribute__((always_inline)) {
+            const agc_f2 u = agc_f2{v0, v1} - vC2;
+            const agc_f2 tt = __builtin_elementwise_fma(-u, u, hsq2);
+            sgn[jb] = __builtin_amdgcn_alignbit(sgn[jb], __float_as_uint(u[0]), 31);
+            sgn[jb] = __builtin_amdgcn_alignbit(sgn[jb], __float_as_uint(u[1]), 31);
+            out[jb] = __builtin_amdgcn_alignbit(out[jb], __float_as_uint(tt[0]), 31);
+            out[jb] = __builtin_amdgcn_alignbit(out[jb], __float_as_uint(tt[1]), 31);
+          };
+          if (interior) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+              for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                  classify2(acc[jb][ib][r], acc[jb][ib][r + 1], jb);
+                  acc[jb][ib][r] = 0.f; acc[jb][ib][r + 1] = 0.f;
+                }
+          } else {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+              for (int ib = 0; ib < 2; ++ib) {
+                const int gi = stride * (i0 + wi * 64 + ib * 32 + li);
+                const uint32_t span = gi < n ? (uint32_t)(n - gi - 1) : 0u;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {    // (a pair that does not exist is +inf: above every window)
+                  const int jo = jl + jb * 32 + (r & 3) + 8 * (r >> 2) - gi - 1;
+                  classify2((uint32_t)jo < span ? acc[jb][ib][r] : __builtin_inff(), (uint32_t)(jo + 1) < span ? acc[jb][ib][r + 1] : __builtin_inff(), jb);
+                  acc[jb][ib][r] = 0.f; acc[jb][ib][r + 1] = 0.f;
+                }
+              }
+          }
+          below += (uint32_t)(__builtin_popcount(sgn[0] & out[0]) + __builtin_popcount(sgn[1] & out[1]));
+          // the hits of this lane (a fifth of the lanes hold one per tile, almost none three): ONE reservation per lane that has any -- a single
+          // LDS instruction for the wave -- then the lane writes its entries
+          uint64_t m = (uint64_t)(~out[0]) | ((uint64_t)(~out[1]) << 32);
+          if (m != 0ull) {
+            uint32_t slot = lds_add_rtn_raw(nst_off, (uint32_t)__popcll(m));
+            do {
+              const int b6 = __builtin_ctzll(m);
+              m &= m - 1ull;
+              const int e = 31 - (b6 & 31), r = e & 15, ib = e >> 4, jb = b6 >> 5;
+              const uint32_t gi = (uint32_t)(stride * (i0 + wi * 64 + ib * 32 + li));
+              const uint32_t packed = (gi << 14) | (uint32_t)(jl + jb * 32 + (r & 3) + 8 * (r >> 2));
+              if (slot < (uint32_t)SIM_STAGE) lds_write_raw(hist_off + 4u * slot, packed);
+              else {                                          // staging buffer full inside one tile: straight to the list (degenerate inputs)
+                const uint32_t g = atomicAdd(&w.sel[3], 1u);
+                if (g < w.list_cap) w.list[g] = packed;
+              }
+              ++slot;
+            } while (m != 0ull);
+          }
+        }
+      }
+    }
+    if (MODE == SIM_COLLECT) {
+      flush();
+      for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o, 64);
+      if (lane == 0 && below) atomicAdd((uint32_t*)&w.counters[5], below);
+    } else {
+      __syncthreads();
+      for (int i = t; i < 4096; i += 256)
+        if (hist[i]) { atomicAdd(&w.hist[i], hist[i]); hist[i] = 0u; }
+    }
+  }
+}
+
+// Window flow: from the sample histogram (4096 linear bins, agc_simw_kernel<SIM_SAMPLE>) to the window of approximate values that must hold
+// the k-th smallest.  Sample ranks r_lo / r_hi bracket rank k by 3 % and five standard deviations of the sample count (none when the sample is
+// the whole triangle); the window is the span of their bins widened by 2 eps on either side, eps = the bound of |approximate - exact|:
+//   | sum a16 b16 (f32 MFMA accumulation) - fl32(sum a b in f64) |  <=  2 dmax + dmax^2  +  256 * 2^-24  +  2^-24,   dmax = the image's largest
+// row rounding error (band[3], agc_normalize_kernel; Cauchy-Schwarz on unit rows).  band = {vL, vU, eps_check, dmax}; the histogram, the list
+// length and the below-window counter are cleared.  The window is only a PREDICTION: agc_finish_kernel verifies
+// vL + eps <= threshold <= vU - eps and that rank k fell inside the list, else info[7] |= 2 and the caller repeats the build with the robust flow.
+__global__ __launch_bounds__(256) void agc_window_kernel(const AgcWs* __restrict__ ws, float test_shift) {
+  const AgcWs& w = ws[blockIdx.y];
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t ranks[2];
+  __shared__ int bsel[2];
+  __shared__ uint32_t s_dmax;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int per = 16;
+  uint64_t v = 0;
+  for (int q = 0; q < per; ++q) v += w.hist[t * per + q];
+  uint64_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  if (t == 0) { bsel[0] = 0; bsel[1] = 4095; s_dmax = 0u; }
+  __syncthreads();
+  for (int q = 0; q < wave; ++q) incl += wsum[q];
+  if (t == 255) {
+    const uint64_t ns = incl, k = (uint64_t)w.sel[1] | ((uint64_t)w.sel[2] << 32);
+    const uint64_t L = (uint64_t)w.n * (uint64_t)(w.n - 1) / 2;
+    uint64_t rlo = k, rhi = k;
+    if (ns != L) {
+      const double f = (double)ns / (double)L, p = ((double)k + 0.5) / (double)L;
+      const double sd = sqrt((double)ns * p * (1.0 - p));
+      const double lo = f * (double)k * 0.97 - 5.0 * sd - 1.0, hi = f * (double)(k + 1) * 1.03 + 5.0 * sd + 1.0;
+      rlo = lo > 0.0 ? (uint64_t)lo : 0ull;
+      rhi = (uint64_t)hi;
+    }
+    const uint64_t last = ns ? ns - 1 : 0;
+    ranks[0] = rlo < last ? rlo : last;
+    ranks[1] = rhi < last ? rhi : last;
+  }
+  __syncthreads();
+  const uint64_t excl0 = incl - v;
+  for (int e = 0; e < 2; ++e) {
+    const uint64_t r = ranks[e];
+    if (t < 255 ? (excl0 <= r && r < incl) : excl0 <= r) {
+      uint64_t excl = excl0;
+      int b = t * per;
+      for (int q = 0; q < per; ++q, ++b) {
+        const uint64_t c = w.hist[b];
+        if (r < excl + c || b == 4095) break;
+        excl += c;
+      }
+      bsel[e] = b;
+    }
+  }
+  __syncthreads();
+  {    // dmax = the largest row rounding error (positive floats order like their bits; a NaN row poisons the window: nothing lands in it -> miss)
+    uint32_t m = 0u;
+    for (int i = t; i < w.n; i += 256) { const uint32_t b = (uint32_t)w.deg[i]; m = b > m ? b : m; }
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, o, 64); m = y > m ? y : m; }
+    if (lane == 0) atomicMax(&s_dmax, m);
+  }
+  __syncthreads();
+  if (t == 0) {
+    const float dmax = __uint_as_float(s_dmax);
+    w.band[3] = s_dmax;
+    const float eps = 2.02f * dmax + dmax * dmax + 6e-5f, eps_check = 2.01f * dmax + dmax * dmax + 4e-5f;
+    const float vL = ((float)bsel[0] / 2048.f - 1.f) - 2.f * eps + test_shift, vU = ((float)(bsel[1] + 1) / 2048.f - 1.f) + 2.f * eps + test_shift;
+    w.band[0] = __float_as_uint(vL); w.band[1] = __float_as_uint(vU); w.band[2] = __float_as_uint(eps_check);
+    w.sel[3] = 0u;
+    w.counters[5] = 0;
+  }
+  for (int q = 0; q < per; ++q) w.hist[t * per + q] = 0;
 }
 
 // 12-bit histogram (top bits of the 16-bit order-preserving key) of the strict upper triangle of S16 (collect == 0), or, collect == 1, the packed
@@ -520,13 +883,24 @@ __global__ __launch_bounds__(256) void agc_band_kernel(const AgcWs* __restrict__
 
 // list[e] = (i << 14 | j)  ->  the order-preserving key of the exact similarity of rows i and j (in place); the same for the radius candidates
 // (clist -> ckey).  Eight lanes per entry.
-__global__ __launch_bounds__(256) void agc_exact_kernel(const AgcWs* __restrict__ ws) {
-  const AgcWs& w = ws[blockIdx.y];
+__global__ __launch_bounds__(256) void agc_exact_kernel(const AgcWs* __restrict__ ws, int n_images, int window) {
+  const int nparts = agc_nparts(n_images);
+  for (int u = blockIdx.x & 7; u < n_images * nparts; u += 8) {
+  const AgcWs& w = ws[u / nparts];
+  if (window && u % nparts == 0 && (blockIdx.x >> 3) == 0 && threadIdx.x == 0) {
+    // window flow: rank of the threshold AMONG the listed entries = k - (entries below the window); a rank outside the list is a missed window
+    const uint64_t k = (uint64_t)w.krank, below = (uint32_t)w.counters[5], nl0 = w.sel[3];
+    const bool hit = k >= below && k < below + nl0;
+    const uint64_t r = hit ? k - below : 0ull;
+    if (!hit) w.counters[7] = 1;
+    w.sel[0] = 0u; w.sel[1] = (uint32_t)r; w.sel[2] = (uint32_t)(r >> 32);
+  }
   const uint32_t nl = w.sel[3] < w.list_cap ? w.sel[3] : w.list_cap;
   const uint32_t nc = (uint32_t)w.counters[4] < w.clist_cap ? (uint32_t)w.counters[4] : w.clist_cap;
   const uint32_t nlp = (nl + 31u) & ~31u, total = nlp + ((nc + 31u) & ~31u);       // (whole waves stay in the loop: shuffles)
   const int q = threadIdx.x & 7;
-  for (uint32_t e = (blockIdx.x * 256 + threadIdx.x) >> 3; e < total; e += (gridDim.x * 256) >> 3) {
+  const uint32_t slot = (uint32_t)(u % nparts) + (uint32_t)nparts * (blockIdx.x >> 3), nslots = (uint32_t)nparts * (gridDim.x >> 3);
+  for (uint32_t e = (slot * 256 + threadIdx.x) >> 3; e < total; e += (nslots * 256) >> 3) {
     const bool band = e < nlp;
     const uint32_t idx = band ? e : e - nlp;
     const bool live = band ? idx < nl : idx < nc;
@@ -534,6 +908,7 @@ __global__ __launch_bounds__(256) void agc_exact_kernel(const AgcWs* __restrict_
     const int i = (int)(pk >> 14), j = (int)(pk & 0x3fffu);
     const float sim = agc_exact_sim8(w.dnf + (int64_t)i * w.d, w.dnf + (int64_t)j * w.d, w.d, q);
     if (live && q == 0) (band ? w.list : w.ckey)[idx] = f32_key(sim);
+  }
   }
 }
 
@@ -1126,7 +1501,7 @@ __global__ __launch_bounds__(256) void agc_link_apply_kernel(const AgcWs* __rest
   if (added) atomicAdd(&info[5], added);
 }
 
-__global__ void agc_finish_kernel(const AgcWs* __restrict__ ws) {
+__global__ void agc_finish_kernel(const AgcWs* __restrict__ ws, int window) {
   const AgcWs& w = ws[blockIdx.y];
   int32_t* info = w.info;
   const int max_edges_dir = w.max_edges_dir;
@@ -1136,6 +1511,10 @@ __global__ void agc_finish_kernel(const AgcWs* __restrict__ ws) {
   if (w.clist && (uint32_t)w.counters[4] > w.clist_cap) {       // more radius candidates than the list holds: like an edge overflow (the caller
     info[7] = 1;                                                // repeats the build with larger buffers), sized from the candidate count
     info[2] = w.counters[4];
+  }
+  if (window) {       // the window was a prediction (agc_window_kernel): the threshold it produced stands only if the window provably held rank k
+    const float thr = key_f32(w.sel[0]), vL = __uint_as_float(w.band[0]), vU = __uint_as_float(w.band[1]), eps = __uint_as_float(w.band[2]);
+    if (w.counters[7] || !(thr >= vL + eps && thr <= vU - eps)) info[7] |= 2;
   }
 }
 
@@ -1150,6 +1529,7 @@ __global__ __launch_bounds__(256) void agc_kept_deg_kernel(const AgcWs* __restri
 }
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 
 // The scratch CSR of the pre-removal graph gets the capacity the caller gives the final one (gims_agc_image::max_edges_dir,
 // at least 64 directed edges per node): a caller that sees the overflow flag repeats the build with larger output buffers.
@@ -1236,8 +1616,18 @@ extern "C" size_t gims_agc_workspace_bytes(const gims_agc_image* images, int32_t
 
 extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, double radius, double percentile,
                               int32_t min_size, void* work, size_t work_bytes, void* stream) {
+  return gims_agc_build_ex(images, n_images, radius, percentile, min_size, 0, work, work_bytes, stream);
+}
+
+extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images, double radius, double percentile,
+                                 int32_t min_size, int32_t flags, void* work, size_t work_bytes, void* stream) {
   using namespace gims;
   GIMS_CHECK_ARG(images && n_images > 0 && work, "gims_agc_build: null / empty arguments");
+  // GIMS_AGC_ROBUST=1 / GIMS_AGC_WINDOW_SHIFT=<x> (read per call: the tests switch flows and force a missed window)
+  const char* env_robust = getenv("GIMS_AGC_ROBUST");
+  bool robust = (flags & GIMS_AGC_ROBUST) != 0 || (env_robust && atoi(env_robust) != 0);
+  const char* env_shift = getenv("GIMS_AGC_WINDOW_SHIFT");
+  const float window_test_shift = env_shift ? (float)atof(env_shift) : 0.f;
   GIMS_CHECK_ARG(work_bytes >= gims_agc_workspace_bytes(images, n_images), "gims_agc_build: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   AgcWs* dws = (AgcWs*)work;
@@ -1280,6 +1670,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     la.m = im.n; la.n = im.n; la.k = im.d; la.k0 = im.d; la.act = GIMS_ACT_NONE; la.precision = x6 ? GIMS_PREC_BF16X6 : GIMS_PREC_F32; la.scale = 1.f;
     la.flags = GIMS_LINEAR_UPPER;    // only S[i][j], i < j, is ever read (threshold select and edge test)
     hla[i] = la;
+    if (im.d % SW_KC != 0 || im.d > SW_KMAX) robust = true;       // (the window kernels keep a tile row's whole K in LDS)
     maxn = im.n > maxn ? im.n : maxn;
     maxnw = w->nw > maxnw ? w->nw : maxnw;
   }
@@ -1311,17 +1702,29 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
     hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 0, 8, 2);
     hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 0, 8);
   } else {
-    // approximate matrix (half, one MFMA pass) -> bracket of the k-th value -> band entries -> their exact values -> exact k-th among them
     const int T = cdiv(maxn, S16_T), ntiles = T * (T + 1) / 2;
-    GIMS_LDS_ATTR((const void*)agc_sim16_kernel, S16_LDS_BYTES);
-    int sgrid = 1024 / B < 1 ? 1 : 1024 / B;                 // ~two workgroups per CU over the whole batch, each folding ONE histogram
-    sgrid = sgrid < ntiles ? sgrid : ntiles;
-    hipLaunchKernelGGL(agc_sim16_kernel, dim3(sgrid, B), dim3(256), S16_LDS_BYTES, s, dws);     // (the 12-bit histogram comes out of its epilogue)
-    hipLaunchKernelGGL(agc_band_kernel, g1, dim3(256), 0, s, dws);
-    hipLaunchKernelGGL(agc_sweep16_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 1);
+    if (robust) {
+      // approximate matrix (half, one MFMA pass, every entry histogrammed) -> bracket of the k-th value -> band entries
+      GIMS_LDS_ATTR((const void*)agc_sim16_kernel, S16_LDS_BYTES);
+      // two workgroups per CU, the images dealt to the XCDs (agc_nparts); a small batch of small images takes fewer workgroups
+      const int nparts = 8 / (((B & -B) > 8) ? 8 : (B & -B)), per_xcd = cdiv(B * nparts, 8) * cdiv(ntiles, nparts);
+      const int sgrid = 8 * (per_xcd < 2 * (device_cus() / 8) ? per_xcd : 2 * (device_cus() / 8));
+      hipLaunchKernelGGL(agc_sim16_kernel, dim3(sgrid), dim3(256), S16_LDS_BYTES, s, dws, B);
+      hipLaunchKernelGGL(agc_band_kernel, g1, dim3(256), 0, s, dws);
+      hipLaunchKernelGGL(agc_sweep16_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 1);
+    } else {
+      // a sample of the approximate similarities predicts the window that holds the k-th value; ONE pass over all of them counts what lies
+      // below it and lists what lies inside it; nothing of the N x N matrix is ever stored.  Two workgroups per CU.
+      GIMS_LDS_ATTR((const void*)agc_simw_kernel<SIM_SAMPLE>, SW_LDS_BYTES);
+      GIMS_LDS_ATTR((const void*)agc_simw_kernel<SIM_COLLECT>, SW_LDS_BYTES);
+      const int wgrid = 8 * 2 * (device_cus() / 8);
+      hipLaunchKernelGGL(agc_simw_kernel<SIM_SAMPLE>, dim3(wgrid), dim3(256), SW_LDS_BYTES, s, dws, B);
+      hipLaunchKernelGGL(agc_window_kernel, g1, dim3(256), 0, s, dws, window_test_shift);
+      hipLaunchKernelGGL(agc_simw_kernel<SIM_COLLECT>, dim3(wgrid), dim3(256), SW_LDS_BYTES, s, dws, B);
+    }
     hipLaunchKernelGGL(agc_radius_kernel, dim3(cdiv(cdiv(maxn, 2), 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
-    const int egrid = 4096 / B < 32 ? 32 : (4096 / B > 512 ? 512 : 4096 / B);
-    hipLaunchKernelGGL(agc_exact_kernel, dim3(egrid, B), dim3(256), 0, s, dws);
+    // the exact values of the listed entries and of the radius candidates, then the exact k-th among the former
+    hipLaunchKernelGGL(agc_exact_kernel, dim3(8 * 4 * (device_cus() / 8)), dim3(256), 0, s, dws, B, robust ? 0 : 1);
     const int lgrid = 1024 / B < 4 ? 4 : (1024 / B > 64 ? 64 : 1024 / B);
     hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 20, 12, 2);
     hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 20, 12);
@@ -1355,7 +1758,7 @@ extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, do
   hipLaunchKernelGGL(agc_kept_deg_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 2);
   hipLaunchKernelGGL(agc_fill_kernel, gw, dim3(256), 0, s, dws, 1);
-  hipLaunchKernelGGL(agc_finish_kernel, g1, dim3(1), 0, s, dws);
+  hipLaunchKernelGGL(agc_finish_kernel, g1, dim3(1), 0, s, dws, (!exact_s && !robust) ? 1 : 0);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

@@ -117,6 +117,7 @@ int lds_attr(const void* fn, int bytes);
 void* device_once(const char* key, size_t bytes, const void* init);
 void* pinned_once(const char* key, size_t bytes);
 int current_device();
+int device_cus();        // compute units of the current device (>= 8)
 // linear6.hip: exact-class bf16x6 GEMM on SPL3 operands (batched), and its operand split
 int linear_x6_batch_launch(const gims_linear_args* dev_args, int count, int max_m, int max_n, hipStream_t s);
 int split_spl3_launch(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int k, hipStream_t s);

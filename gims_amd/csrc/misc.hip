@@ -26,6 +26,12 @@ int current_device() {
   return dev;
 }
 
+int device_cus() {
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || n < 8) n = 8;
+  return n;
+}
+
 static std::mutex g_once_mu;
 
 int lds_attr(const void* fn, int bytes) {

@@ -458,8 +458,9 @@ class GMatcher(nn.Module):
         (2p, 2p+1) form pair p.  Every pair may keep a different number of keypoints (ragged batch)."""
         return self._run_rest(self._run_build(images, radius, percentile, min_size))
 
-    def _run_build(self, images, radius, percentile, min_size):
-        """Phase 1: enqueue the adaptive graph construction (asynchronous; no host sync)."""
+    def _run_build(self, images, radius, percentile, min_size, robust=False):
+        """Phase 1: enqueue the adaptive graph construction (asynchronous; no host sync).  robust: the graph build histograms every
+        similarity instead of predicting where the percentile lies (the repeat after a build reported a missed prediction)."""
         cfg = self.config
         dev = images[0]["kp"].device
         D = cfg['descriptor_dim']
@@ -482,7 +483,8 @@ class GMatcher(nn.Module):
             info_all = torch.empty((len(images), 8), dtype=torch.int32, device=dev)
             agc_imgs = hip.make_agc_images([dict(kpts=g["kp"], desc=g["de"], kept=g["kept"], indptr=g["indptr"],
                                                  indices=g["indices"], info=info_all[i]) for i, g in enumerate(images)])
-            hip.agc_build(agc_imgs, radius, percentile, min_size, self._buf("agc", hip.agc_workspace_bytes(agc_imgs)))
+            hip.agc_build(agc_imgs, radius, percentile, min_size, self._buf("agc", hip.agc_workspace_bytes(agc_imgs)),
+                          flags=hip.AGC_ROBUST if robust else 0)
             # everything of the next stage that does not depend on the kept counts is prepared NOW, while the GPU builds the
             # graphs: after the host sync only two cumsums stand between the counts and the next launch
             ptab = hip.pack_table([(g["kp"].data_ptr(), g["de"].data_ptr(), g["de"].stride(0), g["sc"].data_ptr(),
@@ -499,7 +501,8 @@ class GMatcher(nn.Module):
                         seg=torch.empty((n_up,), dtype=torch.int32, device=dev),
                         indptr=torch.empty((n_up + 1,), dtype=torch.int32, device=dev),
                         indices=torch.empty((ec * n_up + 1,), dtype=torch.int32, device=dev))
-        return dict(images=images, info_all=info_all, pool=pool, ptab=ptab, norm3=norm3, bufs=bufs, params=(radius, percentile, min_size))
+        return dict(images=images, info_all=info_all, pool=pool, ptab=ptab, norm3=norm3, bufs=bufs, params=(radius, percentile, min_size),
+                    robust=robust)
 
     _edge_cap = 64
 
@@ -522,7 +525,15 @@ class GMatcher(nn.Module):
         torch.cuda.current_stream().synchronize()
         infos = pin[:info_all.shape[0]].numpy().copy()
         self._sync_ms = 1e3 * (time.perf_counter() - ts0)
-        if infos[:, 7].any():
+        if (infos[:, 7] & hip.AGC_INFO_WINDOW_MISSED).any() and not (infos[:, 7] & hip.AGC_INFO_OVERFLOW).any():
+            # the percentile window predicted from the similarity sample did not provably hold the threshold (gims_agc_build_ex): the
+            # outputs of this build are void; the repeat histograms every similarity
+            if ctx.get("robust"):
+                raise hip.GimsHipError("adaptive graph: the robust flow reported a missed percentile window")
+            ctx["params"] = tuple(ctx["params"]) + (True,)
+            self._agc_window_misses = getattr(self, "_agc_window_misses", 0) + 1
+            return None
+        if (infos[:, 7] & hip.AGC_INFO_OVERFLOW).any():
             # more edges than the buffers hold: repeat the graph build of this batch with room for what it reported (the
             # directed-edge total of the densest image, rounded up to a power of two per node), and keep the larger capacity
             ns = np.asarray([g["kp"].shape[0] for g in images], dtype=np.float64)

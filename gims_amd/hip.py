@@ -176,6 +176,8 @@ _SIGNATURES = {
     "gims_agc_workspace_bytes": (C.c_size_t, [C.POINTER(AgcImage), C.c_int32]),
     "gims_agc_build": (C.c_int, [C.POINTER(AgcImage), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
+    "gims_agc_build_ex": (C.c_int, [C.POINTER(AgcImage), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
     "gims_ingest_images": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "gims_pack_graphs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
@@ -631,11 +633,16 @@ def agc_workspace_bytes(images) -> int:
     return int(load().gims_agc_workspace_bytes(images, len(images)))
 
 
-def agc_build(images, radius, percentile, min_size, work: torch.Tensor):
-    """Asynchronous adaptive-graph build for a batch of images; see include/gims_hip.h."""
+AGC_ROBUST = 1               # gims_agc_build_ex flags (include/gims_hip.h)
+AGC_INFO_OVERFLOW, AGC_INFO_WINDOW_MISSED = 1, 2     # bits of info[7]
+
+
+def agc_build(images, radius, percentile, min_size, work: torch.Tensor, flags=0):
+    """Asynchronous adaptive-graph build for a batch of images; see include/gims_hip.h.  An image whose info[7] has AGC_INFO_WINDOW_MISSED
+    set after the call must be rebuilt with flags=AGC_ROBUST."""
     lib = load()
-    _check(lib.gims_agc_build(images, len(images), float(radius), float(percentile), int(min_size), _p(work),
-                              work.numel() * work.element_size(), _stream()), "gims_agc_build")
+    _check(lib.gims_agc_build_ex(images, len(images), float(radius), float(percentile), int(min_size), int(flags), _p(work),
+                                 work.numel() * work.element_size(), _stream()), "gims_agc_build_ex")
 
 
 def _upload_structs(arr, device):

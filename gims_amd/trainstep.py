@@ -82,10 +82,11 @@ def _forward(model, data):
     # side-major image order: [b0 s0, b1 s0, ..., b0 s1, b1 s1, ...]
     images = model._ingest([(data['keypoints' + side][b], data['descriptors' + side][b], data['scores' + side][b], data['image' + side].shape)
                             for side in ("0", "1") for b in range(B)])
-    G = None
+    G, params = None, (radius, percentile, min_size)
     while G is None:
-        ctx = model._run_build(images, radius, percentile, min_size)
+        ctx = model._run_build(images, *params)
         G = model._gather(ctx)
+        params = ctx["params"]                      # (a build that has to be repeated says how: larger capacity, robust percentile flow)
     model._finish_graphs(images, G)
     dev = G["feat"].device
     for s in range(2):

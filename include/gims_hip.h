@@ -260,7 +260,8 @@ int gims_gather_rows(const float* src, int64_t lds, const int32_t* idx, int32_t 
  * Per image: kpts [n][2] f32, desc [n][d] f32 (point-major, un-normalised); outputs (device): kept[n]
  * (first n_kept entries: sorted original ids), indptr[n+1] (first n_kept+1 valid), indices[max_edges_dir]
  * in kept-relabelled ids, info[8] = {n_kept, n_dir_edges, n_coarse_edges, n_iso_added,
- * n_components_after_removal, n_link_added, threshold bits (f32), overflow flag}.
+ * n_components_after_removal, n_link_added, threshold bits (f32), flags: bit 0 = an edge / candidate buffer overflowed (repeat with a larger
+ * max_edges_dir), bit 1 = see gims_agc_build_ex}.
  * `work` is scratch of at least gims_agc_workspace_bytes(images, n_images) bytes.
  * Exact-distance ties in the two sequential fix-ups resolve to the lowest node index.
  * Asynchronous; read info[] after synchronising the stream.
@@ -273,6 +274,17 @@ typedef struct gims_agc_image {
 size_t gims_agc_workspace_bytes(const gims_agc_image* h_images /* HOST array */, int32_t n_images);
 int gims_agc_build(const gims_agc_image* h_images /* HOST array */, int32_t n_images, double radius, double percentile,
                    int32_t min_size, void* work, size_t work_bytes, void* stream);
+/* The same with flags.  The percentile threshold is exact in both flows (the k-th smallest of the similarities as the library evaluates
+ * them: float64 dot products of the normalised f32 rows, rounded once); they differ in how the entries that can decide it are found.
+ * Default: a sample of one-pass half-precision similarities predicts a window of values that holds rank k, one pass over all N^2/2 of
+ * them counts what lies below the window and lists what lies inside it, and only the listed entries (and the radius candidates) are
+ * evaluated exactly.  The prediction is VERIFIED on the device against a rigorous bound of the half-precision error; if it did not hold,
+ * bit 1 of info[7] is set (bit 0: edge capacity) and every other output of that image is to be discarded: repeat the call with
+ * GIMS_AGC_ROBUST, which histograms every entry instead of predicting (about 0.2 ms more per 16 images of 4096).  Images of at most 1536
+ * keypoints are "sampled" in full and never report bit 1. */
+#define GIMS_AGC_ROBUST 1
+int gims_agc_build_ex(const gims_agc_image* h_images /* HOST array */, int32_t n_images, double radius, double percentile,
+                      int32_t min_size, int32_t flags, void* work, size_t work_bytes, void* stream);
 
 /* Ingest a batch of images given in the reference's layout (descriptors channel-major (D,N), gmatcher.py:245) into
  * one row-concatenated point-major buffer: desc_out[row_off_i + n, :] = desc_i[:, n], same for keypoints and scores.

@@ -529,6 +529,26 @@ def test_train_loss_forward_vs_reference_golden(synth_sd, monkeypatch, name, sin
         m2(train_data(pairs, g, device="cuda"), mode="train")
 
 
+def test_missed_percentile_window_repeats_the_build(synth_sd, monkeypatch):
+    """The graph build predicts where the percentile threshold lies from a sample of the similarities and verifies the prediction on the device;
+    a build that reports a miss (forced here by GIMS_AGC_WINDOW_SHIFT) is repeated with the flow that histograms every similarity, inside the
+    same forward() -- the outputs equal those of an undisturbed call."""
+    pair = synth.make_pair(2048, 777)
+    m = GMatcher({}).eval()
+    m.load_state_dict(synth_sd)
+    m(pair_to_data(pair, 15, 2, 7, device="cuda"))               # (the first call of a model measures its attention layers at another precision)
+    d0 = pair_to_data(pair, 15, 2, 7, device="cuda")
+    ref = m(d0)
+    assert getattr(m, "_agc_window_misses", 0) == 0
+    monkeypatch.setenv("GIMS_AGC_WINDOW_SHIFT", "0.1")
+    d1 = pair_to_data(pair, 15, 2, 7, device="cuda")
+    out = m(d1)
+    assert m._agc_window_misses == 1
+    for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+        assert torch.equal(ref[k], out[k]), k
+    assert d0["kept_kpts0_indices"] == d1["kept_kpts0_indices"] and d0["kept_kpts1_indices"] == d1["kept_kpts1_indices"]
+
+
 def test_dense_keypoints_grow_the_graph_capacity(synth_sd):
     """Densely packed keypoints at the GMatcher DEFAULT radius / percentile (25 / 7: what train.py runs with, gmatcher.py:220-222)
     give ~100 neighbours per node -- more than the 64 directed edges per node the buffers start with.  The reference has no

@@ -893,10 +893,19 @@ def test_agc_band_limited_flow_equals_exact_flow(hip, monkeypatch, case):
     if case == "duplicates":
         de[100:400] = de[r.integers(0, 8, size=300)]             # 300 rows drawn from 8 prototypes: ~ 5 600 pairs with similarity 1
     outs = {}
-    for flow in ("1", "0"):
-        monkeypatch.setenv("GIMS_AGC_EXACT_S", flow)
+    for flow, env in (("exact", "GIMS_AGC_EXACT_S"), ("window", None), ("robust", "GIMS_AGC_ROBUST")):
+        for name in ("GIMS_AGC_EXACT_S", "GIMS_AGC_ROBUST"):
+            monkeypatch.delenv(name, raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
         outs[flow] = _run_agc(hip, kp, de, rad, pct, ms)
-    (k1, p1, i1, f1), (k0, p0, i0, f0) = outs["1"], outs["0"]
+    # the default flow (a window predicted from a sample, verified on the device) and the robust one (every entry histogrammed) are the same
+    # function of the inputs, bit for bit; the prediction held (info[7] bit 1 clear)
+    for a, b in zip(outs["window"][:3], outs["robust"][:3]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(outs["window"][3], outs["robust"][3])
+    assert int(outs["window"][3][7]) == 0
+    (k1, p1, i1, f1), (k0, p0, i0, f0) = outs["exact"], outs["window"]
     t1, t0 = np.array([f1[6], f0[6]], dtype=np.int32).view(np.float32)
     assert abs(float(t1) - float(t0)) < 1e-6, (t1, t0)
     if case != "duplicates":          # (with duplicated rows eight values within 1e-7 of each other straddle the threshold: the two evaluators may
@@ -930,6 +939,29 @@ def test_agc_band_limited_flow_equals_exact_flow(hip, monkeypatch, case):
     assert abs(float(t0) - float(vals[kk])) < 2e-7, (t0, vals[kk])
     n_edges = int((cand & (sim[iu] >= t0)).sum())
     assert abs(int(f0[2]) - n_edges) <= (3 if case == "duplicates" else 0), (int(f0[2]), n_edges)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [700, 4100])
+def test_agc_missed_window_is_reported(hip, monkeypatch, n):
+    """The default graph build PREDICTS the window of approximate similarities that holds the percentile threshold and verifies the prediction on
+    the device (gims_agc_build_ex).  GIMS_AGC_WINDOW_SHIFT moves the predicted window away from the threshold: the build must say so (bit 1 of
+    info[7]) -- for a sampled image (4100 rows: every 8th row) and for one that is histogrammed in full (700) -- and the robust repeat, which
+    is what gims_amd.GMatcher does on that bit, gives what the undisturbed default flow gives."""
+    r = _rng(29)
+    kp = (r.random(size=(n, 2)) * 25.0 * np.sqrt(n)).astype(np.float32)
+    de = r.normal(size=(n, 256)).astype(np.float32)
+    good = _run_agc(hip, kp, de, 15, 2, 7)
+    assert int(good[3][7]) == 0
+    for shift in ("0.25", "-0.25", "0.004", "-0.004"):
+        monkeypatch.setenv("GIMS_AGC_WINDOW_SHIFT", shift)
+        bad = _run_agc(hip, kp, de, 15, 2, 7)
+        assert int(bad[3][7]) & 2, (shift, bad[3])
+    monkeypatch.delenv("GIMS_AGC_WINDOW_SHIFT")
+    monkeypatch.setenv("GIMS_AGC_ROBUST", "1")
+    again = _run_agc(hip, kp, de, 15, 2, 7)
+    for a, b in zip(good, again):
+        np.testing.assert_array_equal(a, b)
 
 
 def test_agc_batched_ragged_equals_single(hip):

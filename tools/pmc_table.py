@@ -8,7 +8,7 @@ def main(path, *kernels):
     dur = defaultdict(lambda: [0, 0.0])
     seen = set()
     for r in csv.DictReader(open(path)):
-        k = re.sub(r"<.*", "", re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("gims::", ""))
+        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("gims::", "")
         if kernels and not any(x in k for x in kernels):
             continue
         a = acc[k][r["Counter_Name"]]
