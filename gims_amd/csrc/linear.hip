@@ -670,6 +670,7 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
     static const int force = [] { const char* e = getenv("GIMS_X3P_TILE"); return e ? atoi(e) : 0; }();
     // one-pass (Q/K/V) GEMMs: 0 = 256 x 256 tiles like the others; 2 / 3 = 256 x 128 tiles with that many ring stages (default 3)
     static const int qkv_tile = [] { const char* e = getenv("GIMS_X3P_QKV"); return e ? atoi(e) : 3; }();
+    static const int small_tiles = [] { const char* e = getenv("GIMS_X3P_SMALL"); return e ? atoi(e) : 128; }();      // 128 x 128 tiles at or below which a launch takes 64 x 64 ones (GIMS_X3P_SMALL=0: never)
     const int big_blocks = cdiv(a->m, 256) * cdiv(a->n, 256);
     // the 256-wide tile only when it is not half empty (n = 64 / 128 layers of the keypoint encoder and GraphSAGE)
     const bool big = force == 256 || (force != 128 && big_blocks >= 192 && (a->n % 256 == 0 || a->n > 512));
@@ -717,6 +718,17 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
         constexpr size_t lds = T64::LDS_BYTES;
         hipLaunchKernelGGL((linear_x3p_kernel<128, 64, 2, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 64)), dim3(256), lds, s, *a);
       }
+    } else if ((force == 64 || (force == 0 && cdiv(a->m, 128) * cdiv(a->n, 128) <= small_tiles)) && !(a->flags & GIMS_LINEAR_A1_HI_ONLY)) {
+      // launches that leave most of the chip idle at 128 x 128 (one pair through forward(): 32 ... 96 tiles at 2 x 1024 keypoints): 64 x 64 tiles
+      // on four waves -- four times the workgroups, the same K order per output element (bit-identical), and what a launch costs there is
+      // the latency of its K loop, not its matrix work
+      using T6 = X3P<64, 64, 2, 2, 3>;
+      using T6H = X3P<64, 64, 2, 2, 4, true>;
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<64, 64, 2, 2, 3>, (int)T6::LDS_BYTES);
+      GIMS_LDS_ATTR((const void*)linear_x3p_kernel<64, 64, 2, 2, 4, 1>, (int)T6H::LDS_BYTES);
+      const dim3 g(8 * cdiv(cdiv(a->m, 64), 8) * cdiv(a->n, 64));
+      if (a->flags & GIMS_LINEAR_HI_ONLY) { constexpr size_t lds = T6H::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<64, 64, 2, 2, 4, 1>), g, dim3(256), lds, s, *a); }
+      else { constexpr size_t lds = T6::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<64, 64, 2, 2, 3>), g, dim3(256), lds, s, *a); }
     } else {
       using TSH = X3P<128, 128, 2, 2, 4, true>;
       constexpr size_t lds = TS::LDS_BYTES, lds_h = TSH::LDS_BYTES;
