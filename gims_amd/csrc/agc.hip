@@ -25,6 +25,7 @@
 namespace gims {
 
 constexpr int AGC_MAX_N = 16384;
+constexpr int AGC_NB = 16384;  // hash buckets of the keypoint grid
 constexpr int ADJ_R = 4;      // rows per wave of the radius search: one load of point j serves four row tests (the loop is issue bound)
 
 struct AgcWs {
@@ -39,6 +40,8 @@ struct AgcWs {
   uint32_t* clist;      // radius candidates, packed (i << 14 | j) with i < j; ckey: the order-preserving keys of their exact similarities
   uint32_t* ckey;
   uint32_t list_cap, clist_cap; int lds16;
+  int32_t* cellptr;     // [AGC_NB + 1] bucket offsets of the keypoint grid (radius search); cellidx [n]: point ids sorted by bucket
+  int32_t* cellidx;
   uint64_t* bits;       // [n][nw]
   uint32_t* hist;       // [4096] histogram of the current radix digit
   uint32_t* sel;        // [4]: prefix, k_lo, k_hi, pad
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restri
 }
 
 // Window flow: the approximate similarities (half operands, f32 MFMA accumulation) are looked at, never stored.  A workgroup of 4 waves (2 x 2,
-// 64 x 64 per wave) takes a unit = up to SW_SEG consecutive 128 x 128 tiles of one tile row.  Every wave keeps the MFMA fragments of ITS 64
+// 64 x 64 per wave) takes a unit = up to eight (sample pass: three) consecutive 128 x 128 tiles of one tile row.  Every wave keeps the MFMA fragments of ITS 64
 // rows for the whole K in REGISTERS for the unit (128 VGPRs): with both operands read from LDS a 64 x 64 wave tile needs exactly the LDS
 // bandwidth the CU has (1 KB per MFMA), and the column ring's DMA writes and the epilogue come on top; with the rows in registers it is half.
 // Only the column operand goes through LDS: K chunks of 64 in a two-buffer ring by LDS-DMA, the next chunk in flight under the MFMAs of the
@@ -436,7 +439,10 @@ __device__ __forceinline__ uint32_t lds_read_raw(uint32_t off) {
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(off) : "memory");
   return r;
 }
-constexpr int SW_T = 128, SW_KC = 64, SW_KMAX = 256, SW_SEG = 6;
+constexpr int SW_T = 128, SW_KC = 64, SW_KMAX = 256;
+// tiles per unit: loading a unit's row fragments costs about one tile's time (205 us per collect pass at one tile per unit, 120 at eight); the
+// sample pass has few tile rows and wants more, shorter units
+template <int MODE> constexpr int sw_seg() { return MODE == 1 ? 3 : 8; }
 constexpr int SW_RING = 3;                                                 // column chunks in LDS: one under the MFMAs, two in flight (an L2 round trip is longer than a chunk's MFMAs)
 constexpr int SW_LDS_BYTES = SW_RING * SW_T * SW_KC * 2 + 4096 * 4;     // column ring 3 x 16 KB + histogram / staging 16 KB
 template <int MODE>
@@ -458,8 +464,8 @@ __global__ __launch_bounds__(256, 2) void agc_simw_kernel(const AgcWs* __restric
     const AgcWs& w = ws[q / nparts];
     const int n = w.n, d = w.d, T = (n + 127) / 128, kpc = d / SW_KC;
     const int stride = MODE == SIM_SAMPLE ? agc_sample_stride(n) : 1;
-    int nunits = 0;                                     // tile row ti holds the tiles stride * ti .. T - 1, in segments of SW_SEG
-    for (int ti = 0; T - stride * ti > 0; ++ti) nunits += (T - stride * ti + SW_SEG - 1) / SW_SEG;
+    int nunits = 0;                                     // tile row ti holds the tiles stride * ti .. T - 1, in segments of sw_seg<MODE>()
+    for (int ti = 0; T - stride * ti > 0; ++ti) nunits += (T - stride * ti + sw_seg<MODE>() - 1) / sw_seg<MODE>();
     // window [band[0], band[1]] as centre and squared half width (an empty or NaN window lists next to nothing: agc_finish_kernel reports the
     // miss; what is tested is |v - centre|^2 <= half^2 in f32, a few ulps off the interval -- the verification's slack is a hundred times that)
     agc_f2 vC2 = {0.f, 0.f}, hsq2 = {0.f, 0.f};
@@ -490,11 +496,11 @@ __global__ __launch_bounds__(256, 2) void agc_simw_kernel(const AgcWs* __restric
       int ti = 0, m_row = 0;
       for (;; ++ti) {
         m_row = T - stride * ti;
-        const int segs = (m_row + SW_SEG - 1) / SW_SEG;
+        const int segs = (m_row + sw_seg<MODE>() - 1) / sw_seg<MODE>();
         if (rem < segs) break;
         rem -= segs;
       }
-      const int t0 = rem * SW_SEG, ntl = m_row - t0 < SW_SEG ? m_row - t0 : SW_SEG;
+      const int t0 = rem * sw_seg<MODE>(), ntl = m_row - t0 < sw_seg<MODE>() ? m_row - t0 : sw_seg<MODE>();
       const int i0 = ti * SW_T, jbase = (stride * ti + t0) * SW_T;
       // column chunk (tile tl, K chunk kc) -> ring buffer: 16 pieces of 1 KiB (8 rows of 128 bytes), 4 per wave
       auto issue_b = [&](int tl, int kc, int buf) __attribute__((always_inline)) {
@@ -913,12 +919,106 @@ __global__ __launch_bounds__(256) void agc_exact_kernel(const AgcWs* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------- K3, band-limited flow
+constexpr int RAD_STAGE = 2048;
+// Keypoint grid for the radius search: cells of side 1.001 r (cell index = floor(x / side) in float64: two points within r of each other sit in
+// the same or in adjacent cells whatever the rounding), hashed into AGC_NB buckets; one workgroup per image counts, scans and scatters in LDS.
+__device__ __forceinline__ int agc_cell(float x, double inv_side) {
+  const double c = floor((double)x * inv_side);
+  return x == x ? (int)fmin(fmax(c, -1073741824.0), 1073741824.0) : 0;
+}
+__device__ __forceinline__ uint32_t agc_cell_hash(int cx, int cy) {
+  uint32_t h = (uint32_t)cx * 73856093u ^ (uint32_t)cy * 19349663u;
+  h ^= h >> 15;
+  return h & (uint32_t)(AGC_NB - 1);
+}
+__global__ __launch_bounds__(1024) void agc_grid_kernel(const AgcWs* __restrict__ ws, double inv_side) {
+  const AgcWs& w = ws[blockIdx.y];
+  extern __shared__ int cnt[];                  // [AGC_NB] counts, then running fill positions
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n = w.n;
+  for (int b = t; b < AGC_NB; b += 1024) cnt[b] = 0;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) atomicAdd(&cnt[agc_cell_hash(agc_cell(w.kpts[2 * i], inv_side), agc_cell(w.kpts[2 * i + 1], inv_side))], 1);
+  __syncthreads();
+  constexpr int per = AGC_NB / 1024;
+  int v = 0;
+  for (int q = 0; q < per; ++q) v += cnt[t * per + q];
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  for (int q = 0; q < wave; ++q) incl += wsum[q];
+  int excl = incl - v;
+  for (int q = 0; q < per; ++q) {
+    const int c = cnt[t * per + q];
+    w.cellptr[t * per + q] = excl;
+    cnt[t * per + q] = excl;
+    excl += c;
+  }
+  if (t == 1023) w.cellptr[AGC_NB] = excl;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) {
+    const int pos = atomicAdd(&cnt[agc_cell_hash(agc_cell(w.kpts[2 * i], inv_side), agc_cell(w.kpts[2 * i + 1], inv_side))], 1);
+    w.cellidx[pos] = i;
+  }
+}
+
+// Radius candidates through the grid (agc.py:435-447: ||xi - xj||^2 <= r^2 in float64, inclusive): point i looks at the buckets of its own and
+// the eight adjacent cells and takes the points j > i of exactly that cell (two cells may share a bucket: no pair twice) that pass the float64
+// test -- the same predicate on the same pairs as the all-pairs kernel below, which stays for degenerate radii.  A workgroup also clears the
+// adjacency rows of its points.  Candidates are staged in LDS (one global reservation per workgroup).
+__global__ __launch_bounds__(288) void agc_radius_grid_kernel(const AgcWs* __restrict__ ws, double r2, double inv_side) {
+  const AgcWs& w = ws[blockIdx.y];
+  const float* __restrict__ kpts = w.kpts;
+  __shared__ uint32_t st[RAD_STAGE];
+  __shared__ uint32_t nst, gbase;
+  if (threadIdx.x == 0) nst = 0;
+  __syncthreads();
+  // 32 points per workgroup, one thread per (point, cell of its 3 x 3 neighbourhood): the search is a chain of dependent loads (bucket bounds ->
+  // point id -> coordinates), so what it needs is many short chains in flight, not few long ones
+  const int n = w.n, i0 = blockIdx.x * 32, i = i0 + (int)threadIdx.x / 9, c = (int)threadIdx.x % 9;
+  {  // the adjacency rows of the workgroup's points start empty (one contiguous piece of 32 nw words)
+    const int64_t r0 = (int64_t)i0 * w.nw, rend = (int64_t)(n < i0 + 32 ? n : i0 + 32) * w.nw;
+    for (int64_t k = r0 + threadIdx.x; k < rend; k += 288) w.bits[k] = 0ull;
+  }
+  if (i < n) {
+    const float xi = kpts[2 * i], yi = kpts[2 * i + 1];
+    const int nx = agc_cell(xi, inv_side) + c % 3 - 1, ny = agc_cell(yi, inv_side) + c / 3 - 1;
+    const uint32_t h = agc_cell_hash(nx, ny);
+    const int e0 = w.cellptr[h], e1 = w.cellptr[h + 1];
+    for (int e = e0; e < e1; ++e) {
+      const int j = w.cellidx[e];
+      if (j <= i) continue;
+      const float xj = kpts[2 * j], yj = kpts[2 * j + 1];
+      if (agc_cell(xj, inv_side) != nx || agc_cell(yj, inv_side) != ny) continue;
+      const double ddx = (double)xi - (double)xj, ddy = (double)yi - (double)yj;
+      if (!(ddx * ddx + ddy * ddy <= r2)) continue;
+      const uint32_t packed = ((uint32_t)i << 14) | (uint32_t)j;
+      const uint32_t slot = atomicAdd(&nst, 1u);
+      if (slot < (uint32_t)RAD_STAGE) st[slot] = packed;
+      else {
+        const uint32_t g = atomicAdd((uint32_t*)&w.counters[4], 1u);
+        if (g < w.clist_cap) w.clist[g] = packed;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = nst < (uint32_t)RAD_STAGE ? nst : (uint32_t)RAD_STAGE;
+  if (threadIdx.x == 0) gbase = cnt ? atomicAdd((uint32_t*)&w.counters[4], cnt) : 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < cnt; k += 288)
+    if (gbase + k < w.clist_cap) w.clist[gbase + k] = st[k];
+}
+
 // Radius candidates (agc.py:435-447: ||xi - xj||^2 <= r^2 in float64, inclusive), every unordered pair tested ONCE (j > i) and appended to the
 // candidate list as i << 14 | j; their similarities are evaluated by agc_exact_kernel, agc_apply_kernel sets the adjacency bits of those at or
 // above the threshold.  A wave takes four rows from the top of the matrix and the four mirrored rows from the bottom (together n - 1 tests per
 // mirrored row pair whatever the position: equal work per wave), 64 columns per step, one load of point j serving four row tests; it also clears
 // the adjacency rows it owns.  Candidates are staged in LDS (one global reservation per workgroup).
-constexpr int RAD_STAGE = 2048;
 __global__ __launch_bounds__(256) void agc_radius_kernel(const AgcWs* __restrict__ ws, double r2) {
   const AgcWs& w = ws[blockIdx.y];
   const float* __restrict__ kpts = w.kpts;
@@ -1572,6 +1672,8 @@ static size_t agc_layout(int n, int d, int max_edges_dir, bool exact_s, char* ba
     w->clist_cap = exact_s ? 0u : (uint32_t)cap;
     w->lds16 = lds16;
   }
+  p = take((size_t)(AGC_NB + 1) * 4); if (w) w->cellptr = (int32_t*)p;
+  p = take((size_t)n * 4); if (w) w->cellidx = (int32_t*)p;
   p = take((size_t)n * nw * 8); if (w) w->bits = (uint64_t*)p;
   p = take(4096 * 4); if (w) w->hist = (uint32_t*)p;
   p = take(16); if (w) w->sel = (uint32_t*)p;
@@ -1722,7 +1824,17 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
       hipLaunchKernelGGL(agc_window_kernel, g1, dim3(256), 0, s, dws, window_test_shift);
       hipLaunchKernelGGL(agc_simw_kernel<SIM_COLLECT>, dim3(wgrid), dim3(256), SW_LDS_BYTES, s, dws, B);
     }
-    hipLaunchKernelGGL(agc_radius_kernel, dim3(cdiv(cdiv(maxn, 2), 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
+    // radius candidates: through the keypoint grid; all pairs for a radius that gives no usable cell side (GIMS_AGC_GRID=0: always all pairs)
+    const char* env_grid = getenv("GIMS_AGC_GRID");           // (read per call: the tests compare the two searches)
+    const bool no_grid = env_grid && atoi(env_grid) == 0;
+    const double side = radius * 1.001;
+    if (!no_grid && side > 1e-3 && side < 1e12) {
+      GIMS_LDS_ATTR((const void*)agc_grid_kernel, AGC_NB * 4);
+      hipLaunchKernelGGL(agc_grid_kernel, g1, dim3(1024), AGC_NB * 4, s, dws, 1.0 / side);
+      hipLaunchKernelGGL(agc_radius_grid_kernel, dim3(cdiv(maxn, 32), B), dim3(288), 0, s, dws, radius * radius, 1.0 / side);
+    } else {
+      hipLaunchKernelGGL(agc_radius_kernel, dim3(cdiv(cdiv(maxn, 2), 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
+    }
     // the exact values of the listed entries and of the radius candidates, then the exact k-th among the former
     hipLaunchKernelGGL(agc_exact_kernel, dim3(8 * 4 * (device_cus() / 8)), dim3(256), 0, s, dws, B, robust ? 0 : 1);
     const int lgrid = 1024 / B < 4 ? 4 : (1024 / B > 64 ? 64 : 1024 / B);

@@ -942,6 +942,36 @@ def test_agc_band_limited_flow_equals_exact_flow(hip, monkeypatch, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["random", "dense", "negative_and_far", "coincident", "tiny_radius"])
+def test_agc_grid_radius_search_equals_all_pairs(hip, monkeypatch, case):
+    """The radius candidates come from a hashed keypoint grid (cells of side 1.001 r, own + eight adjacent cells) instead of all N^2/2 pairs; the
+    predicate (float64, inclusive) is the same, so kept ids, CSR and every counter must equal those of the all-pairs search (GIMS_AGC_GRID=0) --
+    with few points per cell, with hundreds, with negative and far-away coordinates (cell indices around +-10^5), with coincident points (one cell
+    holds everything) and with a radius below the spacing."""
+    r = _rng(31)
+    n, rad, pct, ms = 1500, 15, 5, 4
+    kp = (r.random(size=(n, 2)) * 25.0 * np.sqrt(n)).astype(np.float32)
+    if case == "dense":
+        n, rad = 600, 11               # (about 20 neighbours per point; more would overflow this helper's 64 edges per node in both searches)
+        kp = (r.random(size=(n, 2)) * np.array([120, 90])).astype(np.float32)
+    elif case == "negative_and_far":
+        kp = kp - np.float32(400.0)
+        kp[n // 2:] += np.float32(2.0e6)
+    elif case == "coincident":
+        kp[200:260] = kp[200]         # (60 coincident points: 1770 pairs at distance 0, all in one cell)
+    elif case == "tiny_radius":
+        rad = 0.5
+    de = r.normal(size=(kp.shape[0], 256)).astype(np.float32)
+    monkeypatch.setenv("GIMS_AGC_GRID", "0")
+    ref = _run_agc(hip, kp, de, rad, pct, ms)
+    monkeypatch.delenv("GIMS_AGC_GRID")
+    got = _run_agc(hip, kp, de, rad, pct, ms)
+    assert int(ref[3][7]) == 0 and int(got[3][7]) == 0
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [700, 4100])
 def test_agc_missed_window_is_reported(hip, monkeypatch, n):
     """The default graph build PREDICTS the window of approximate similarities that holds the percentile threshold and verifies the prediction on
