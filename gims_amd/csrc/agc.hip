@@ -1177,17 +1177,21 @@ __global__ __launch_bounds__(256) void agc_deg_kernel(const AgcWs* __restrict__ 
   const AgcWs& w = ws[blockIdx.y];
   int32_t* deg = w.deg;
   int32_t* total = count_total ? w.counters + 0 : nullptr;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wave;
+  // sixteen lanes per row (four rows per wave, sixteen per workgroup): at 4096 points a row is 64 words, four per lane
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 15;
+  const int i = blockIdx.x * 16 + wave * 4 + (lane >> 4);
   int c = 0;
   if (i < w.n)
-    for (int k = lane; k < w.nw; k += 64) c += __popcll(w.bits[(int64_t)i * w.nw + k]);
+    for (int k = sub; k < w.nw; k += 16) c += __popcll(w.bits[(int64_t)i * w.nw + k]);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if (lane == 0 && i < w.n) deg[i] = c;
+  for (int o = 8; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (sub == 0 && i < w.n) deg[i] = c;
   if (total) {                          // one atomic per workgroup, not per row
     __shared__ int part[4];
-    if (lane == 0) part[wave] = c;
+    int cw = sub == 0 ? c : 0;
+    cw += __shfl_xor(cw, 16, 64);
+    cw += __shfl_xor(cw, 32, 64);
+    if (lane == 0) part[wave] = cw;
     __syncthreads();
     if (threadIdx.x == 0) {
       const int sum = part[0] + part[1] + part[2] + part[3];
@@ -1848,13 +1852,13 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
   // K3
   if (exact_s) hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv(maxn, 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
   else hipLaunchKernelGGL(agc_apply_kernel, dim3(16, B), dim3(256), 0, s, dws);
-  hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 1);
+  hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 1);
   // K4
   hipLaunchKernelGGL(agc_iso_nn_kernel, gw, dim3(256), 0, s, dws);
   const size_t iso_lds = (size_t)maxn * 4 + ((size_t)(maxn + 31) / 32 + 1) * 4;
   hipLaunchKernelGGL(agc_iso_seq_kernel, g1, dim3(1024), iso_lds, s, dws);
   // CSR of the pre-removal graph (original ids) for the component search
-  hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 0);
+  hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 0);
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 0);
   hipLaunchKernelGGL(agc_fill_kernel, gw, dim3(256), 0, s, dws, 0);
   // K5
@@ -1866,7 +1870,7 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
   hipLaunchKernelGGL(agc_link_kernel, dim3(maxn < 256 ? maxn : 256, B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_link_apply_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
   // K7: final CSR over the kept nodes, relabelled in sorted order
-  hipLaunchKernelGGL(agc_deg_kernel, gw, dim3(256), 0, s, dws, 0);
+  hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 0);
   hipLaunchKernelGGL(agc_kept_deg_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 2);
   hipLaunchKernelGGL(agc_fill_kernel, gw, dim3(256), 0, s, dws, 1);
