@@ -1328,23 +1328,25 @@ __global__ __launch_bounds__(256) void agc_fill_kernel(const AgcWs* __restrict__
   const int32_t* __restrict__ newid = final_pass ? w.newid : nullptr;
   int32_t* __restrict__ idx = final_pass ? w.indices : w.idx0;
   const int cap = final_pass ? w.max_edges_dir : w.cap;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wave;
-  if (i >= w.n) return;
-  if (newid && newid[i] < 0) return;
-  int off = ptr_by_row[newid ? newid[i] : i];
-  for (int k0 = 0; k0 < w.nw; k0 += 64) {
-    const int k = k0 + lane;
-    const uint64_t word = k < w.nw ? w.bits[(int64_t)i * w.nw + k] : 0ull;
-    int c = __popcll(word);
-    int x = c;
+  // sixteen lanes per row (four rows per wave): lane `sub` owns the words [sub * wpl, (sub + 1) * wpl) of the row, so the neighbours leave in
+  // ascending order; an exclusive scan of the lanes' counts places them
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 15;
+  const int i = blockIdx.x * 16 + wave * 4 + (lane >> 4);
+  const bool live = i < w.n && !(newid && newid[i] < 0);
+  const int wpl = (w.nw + 15) / 16, k0 = sub * wpl, k1 = k0 + wpl < w.nw ? k0 + wpl : w.nw;
+  int c = 0;
+  if (live)
+    for (int k = k0; k < k1; ++k) c += __popcll(w.bits[(int64_t)i * w.nw + k]);
+  int x = c;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(x, o, 64);
-      if (lane >= o) x += y;
-    }
-    int pos = off + x - c;
-    uint64_t m = word;
+  for (int o = 1; o < 16; o <<= 1) {
+    const int y = __shfl_up(x, o, 16);
+    if (sub >= o) x += y;
+  }
+  if (!live) return;
+  int pos = ptr_by_row[newid ? newid[i] : i] + x - c;
+  for (int k = k0; k < k1; ++k) {
+    uint64_t m = w.bits[(int64_t)i * w.nw + k];
     while (m) {
       const int b = __ffsll((unsigned long long)m) - 1;
       m &= m - 1;
@@ -1352,7 +1354,6 @@ __global__ __launch_bounds__(256) void agc_fill_kernel(const AgcWs* __restrict__
       if (pos < cap) idx[pos] = newid ? newid[j] : j;
       ++pos;
     }
-    off += __shfl(x, 63, 64);
   }
 }
 
@@ -1860,7 +1861,7 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
   // CSR of the pre-removal graph (original ids) for the component search
   hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 0);
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 0);
-  hipLaunchKernelGGL(agc_fill_kernel, gw, dim3(256), 0, s, dws, 0);
+  hipLaunchKernelGGL(agc_fill_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 0);
   // K5
   hipLaunchKernelGGL(agc_cc_kernel, g1, dim3(1024), (size_t)maxn * 8, s, dws, min_size);
   // K6: component sizes -> offsets; members, centroids, nearest component, links
@@ -1873,7 +1874,7 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
   hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 0);
   hipLaunchKernelGGL(agc_kept_deg_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 2);
-  hipLaunchKernelGGL(agc_fill_kernel, gw, dim3(256), 0, s, dws, 1);
+  hipLaunchKernelGGL(agc_fill_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 1);
   hipLaunchKernelGGL(agc_finish_kernel, g1, dim3(1), 0, s, dws, (!exact_s && !robust) ? 1 : 0);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
