@@ -679,6 +679,7 @@ __global__ __launch_bounds__(256) void agc_window_kernel(const AgcWs* __restrict
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t ranks[2];
   __shared__ int bsel[2];
+  __shared__ int s_open[2];
   __shared__ uint32_t s_dmax;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int per = 16;
@@ -706,6 +707,8 @@ __global__ __launch_bounds__(256) void agc_window_kernel(const AgcWs* __restrict
       rhi = (uint64_t)hi;
     }
     const uint64_t last = ns ? ns - 1 : 0;
+    s_open[0] = ns != L && rlo == 0;
+    s_open[1] = ns != L && rhi >= last;
     ranks[0] = rlo < last ? rlo : last;
     ranks[1] = rhi < last ? rhi : last;
   }
@@ -736,7 +739,10 @@ __global__ __launch_bounds__(256) void agc_window_kernel(const AgcWs* __restrict
     const float dmax = __uint_as_float(s_dmax);
     w.band[3] = s_dmax;
     const float eps = 2.02f * dmax + dmax * dmax + 6e-5f, eps_check = 2.01f * dmax + dmax * dmax + 4e-5f;
-    const float vL = ((float)bsel[0] / 2048.f - 1.f) - 2.f * eps + test_shift, vU = ((float)(bsel[1] + 1) / 2048.f - 1.f) + 2.f * eps + test_shift;
+    float vL = ((float)bsel[0] / 2048.f - 1.f) - 2.f * eps + test_shift, vU = ((float)(bsel[1] + 1) / 2048.f - 1.f) + 2.f * eps + test_shift;
+    // a bracket that ran into the end of the sample bounds nothing on that side (percentiles next to 0 or 100): the window is open there
+    if (s_open[0]) vL = -4.f + test_shift;
+    if (s_open[1]) vU = 4.f + test_shift;
     w.band[0] = __float_as_uint(vL); w.band[1] = __float_as_uint(vU); w.band[2] = __float_as_uint(eps_check);
     w.sel[3] = 0u;
     w.counters[5] = 0;

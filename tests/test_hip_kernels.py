@@ -972,6 +972,24 @@ def test_agc_grid_radius_search_equals_all_pairs(hip, monkeypatch, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pct", [0, 0.001, 99.999, 100])
+def test_agc_window_at_the_ends_of_the_distribution(hip, monkeypatch, pct):
+    """Percentiles next to 0 and 100 on a SAMPLED image (4100 rows): the rank bracket runs into the end of the sample, which bounds nothing on that
+    side -- the predicted window is open there instead of ending at the sample's extreme, so the build still verifies (no repeat) and equals the
+    robust flow."""
+    r = _rng(37)
+    n = 4100
+    kp = (r.random(size=(n, 2)) * 25.0 * np.sqrt(n)).astype(np.float32)
+    de = r.normal(size=(n, 256)).astype(np.float32)
+    got = _run_agc(hip, kp, de, 15, pct, 3)
+    assert int(got[3][7]) == 0
+    monkeypatch.setenv("GIMS_AGC_ROBUST", "1")
+    ref = _run_agc(hip, kp, de, 15, pct, 3)
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [700, 4100])
 def test_agc_missed_window_is_reported(hip, monkeypatch, n):
     """The default graph build PREDICTS the window of approximate similarities that holds the percentile threshold and verifies the prediction on
