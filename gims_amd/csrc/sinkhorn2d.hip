@@ -53,15 +53,26 @@ struct OtR2Dev {
 struct OtR2Args {
   const OtR2Dev* probs; const OtR2Block* blocks;
   float alpha; int iters, refresh, wt_local;
+  int stagger;         // NT = 256: the second workgroup of every CU starts its iterations this many 64-cycle sleeps late
   int init_inside;     // 1: the start potentials u0 = -max(alpha, row max of Z), v0 = 0 are formed in here (no ot_init_kernel sweep of Z)
   unsigned long long* prof;
 };
 
 constexpr int R2_CSEG = 132;                    // floats per (workgroup, buffer) of the column edge: 128 columns + dustbin + pad
-constexpr int R2_LDS_K = 16 * 512 * 4;          // 4 tile rows x 4 quads per thread, float4 each
-constexpr int R2_ROWST = 1028, R2_FACS = 1160, R2_GVEC = 132, R2_COLRED = 8 * 128, R2_PB = 1028, R2_PR = 132, R2_CSST = 132, R2_XRD = 4 * R2_CSEG;
-constexpr int R2_OWN = 2 * 132 + 2 * 132;      // v and G of the block's columns; u and F of the row slots this workgroup folds (rbf <= R2_FOLD = 132: r2_geom)
-constexpr int R2_LDS_FLOATS = R2_LDS_K + R2_ROWST + R2_FACS + R2_GVEC + R2_COLRED + R2_PB + R2_PR + R2_CSST + R2_XRD + 16 + R2_OWN;
+// LDS layout of a workgroup of NT threads (512: a <= 1024 x 128 block, one workgroup per CU; 256: a <= 512 x 128 block, TWO workgroups per CU --
+// of two different problems when a launch holds two, so that one's exchange waits run under the other's sweeps).  The K tile rows 12..15 of
+// every thread take 16 NT float4; the small arrays follow.  NT = 256 has 80 KB per workgroup to live in: the column-edge buffer xrd is laid
+// over rowst | colred, which are idle between the column pass and the next row pass.
+template <int NT> struct R2L {
+  static constexpr int NW = NT / 64;
+  static constexpr int K = 16 * NT * 4;             // 4 tile rows x 4 quads per thread, float4 each
+  static constexpr int NXMAX = NT == 512 ? 4 : 8;   // row groups of a problem (rb <= 2 NT rows each)
+  static constexpr int ROWST = NT == 512 ? 1028 : 544, FACS = NT == 512 ? 1160 : 648, GVEC = 132, COLRED = NW * 128, PB = 2 * NT + 4, PR = 132, CSST = 132;
+  static constexpr int XRD = NT == 512 ? 4 * R2_CSEG : 0;        // (256: aliased, ROWST + COLRED = 8 * R2_CSEG)
+  static constexpr int OWN = 2 * 132 + 2 * 132;     // v and G of the block's columns; u and F of the row slots this workgroup folds (rbf <= R2_FOLD = 132: r2_geom)
+  static constexpr int FLOATS = K + ROWST + FACS + GVEC + COLRED + PB + PR + CSST + XRD + 16 + OWN;
+  static_assert(NT == 512 || ROWST + COLRED >= NXMAX * R2_CSEG, "xrd does not fit its alias");
+};
 
 typedef float r2f2 __attribute__((ext_vector_type(2)));
 
@@ -86,9 +97,10 @@ __device__ __forceinline__ float r2_sum8(float x) {
   return r2_dpp_add<0x141>(x);  // row_half_mirror
 }
 
-template <bool PROF>
-__global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
+template <bool PROF, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void ot_res2_kernel(OtR2Args a) {
 #pragma clang fp contract(off)
+  using L = R2L<NT>;
   __shared__ int fail_flag;
   __shared__ unsigned long long prof_acc[8];
   unsigned long long prof_t = 0;
@@ -102,16 +114,16 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
   if (PROF && threadIdx.x < 8) prof_acc[threadIdx.x] = 0;
   if (threadIdx.x == 0) fail_flag = 0;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* klds = lds;                       // [16][512] float4: tile rows 12..15 of every thread
-  float* rowst = klds + R2_LDS_K;          // row sums of this block, by row slot (slot nrl of the last group: the dustbin row)
-  float* facs = rowst + R2_ROWST;          // F of the group's row slots
-  float* gvec = facs + R2_FACS;            // G of the block's columns (v ahead of a derivation); [128] = the dustbin column's
-  float* colred = gvec + R2_GVEC;          // [8 waves][128] column partials
-  float* pb = colred + R2_COLRED;          // dustbin-column entries of the group's rows (last column block only)
-  float* pr = pb + R2_PB;                  // dustbin-row entries of the block's columns (last row group only)
-  float* csst = pr + R2_PR;                // this block's column sums, staged for the 16-byte publish
-  float* xrd = csst + R2_CSST;             // [nx][R2_CSEG] column partials of all row groups
-  float* wred = xrd + R2_XRD;              // [16] per-wave partials of the small reductions
+  float* klds = lds;                       // [16][NT] float4: tile rows 12..15 of every thread
+  float* rowst = klds + L::K;              // row sums of this block, by row slot (slot nrl of the last group: the dustbin row)
+  float* colred = rowst + L::ROWST;        // [NW waves][128] column partials
+  float* facs = colred + L::COLRED;        // F of the group's row slots
+  float* gvec = facs + L::FACS;            // G of the block's columns (v ahead of a derivation); [128] = the dustbin column's
+  float* pb = gvec + L::GVEC;              // dustbin-column entries of the group's rows (last column block only)
+  float* pr = pb + L::PB;                  // dustbin-row entries of the block's columns (last row group only)
+  float* csst = pr + L::PR;                // this block's column sums, staged for the 16-byte publish
+  float* xrd = NT == 512 ? csst + L::CSST : rowst;      // [nx][R2_CSEG] column partials of all row groups (256: over rowst | colred)
+  float* wred = csst + L::CSST + L::XRD;   // [16] per-wave partials of the small reductions
   // state that lives across iterations in LDS rather than in registers (the 192 registers of P leave no room): v and the
   // cumulative factor G of the block's columns (owner: thread t < 128, thread 128 the dustbin column), u and the cumulative
   // factor F of the row slots this workgroup folds (owner: the fc == 0 lane of every fold group)
@@ -163,9 +175,10 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
   }
   // column duty: thread t < 128 owns column col0 + t, thread 128 of the last block the dustbin column
   if (threadIdx.x < 132) { vown_l[threadIdx.x] = 0.f; gown_l[threadIdx.x] = 1.f; }
-  for (int r = threadIdx.x; r < R2_ROWST; r += 512) { rowst[r] = 0.f; pb[r] = 0.f; }
-  for (int r = threadIdx.x; r < R2_FACS; r += 512) facs[r] = 1.f;
-  for (int r = threadIdx.x; r < R2_GVEC; r += 512) { gvec[r] = 0.f; pr[r] = 0.f; csst[r] = 0.f; }     // v0 = 0
+  for (int r = threadIdx.x; r < L::ROWST; r += NT) rowst[r] = 0.f;
+  for (int r = threadIdx.x; r < L::PB; r += NT) pb[r] = 0.f;
+  for (int r = threadIdx.x; r < L::FACS; r += NT) facs[r] = 1.f;
+  for (int r = threadIdx.x; r < L::GVEC; r += NT) { gvec[r] = 0.f; pr[r] = 0.f; csst[r] = 0.f; }     // v0 = 0
   __syncthreads();
 
   // ---------------- start potentials formed on chip (replaces ot_init_kernel's sweep of Z): u0_i = -max(alpha, max_j Z_ij), v0 = 0.
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
           }
         } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) ((f32x4*)klds)[((ib + i4 - 12) * 4 + k) * 512 + t] = zq[i4][k];
+          for (int k = 0; k < 4; ++k) ((f32x4*)klds)[((ib + i4 - 12) * 4 + k) * NT + t] = zq[i4][k];
         }
       }
 #pragma unroll
@@ -317,23 +330,28 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            f32x4 q = ((const f32x4*)klds)[((i - 12) * 4 + k) * 512 + t];
+            f32x4 q = ((const f32x4*)klds)[((i - 12) * 4 + k) * NT + t];
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[e] = __expf((q[e] + u4[i4]) + 0.f);
-            ((f32x4*)klds)[((i - 12) * 4 + k) * 512 + t] = q;
+            ((f32x4*)klds)[((i - 12) * 4 + k) * NT + t] = q;
           }
         }
       }
     }
     if (lastc)
-      for (int r = t; r < nslots; r += 512) pb[r] = __expf((alpha + facs[r]) + 0.f);       // (slot nrl: the corner)
+      for (int r = t; r < nslots; r += NT) pb[r] = __expf((alpha + facs[r]) + 0.f);       // (slot nrl: the corner)
     if (lastg && t < 128) pr[t] = t < ncl ? __expf((alpha + facs[nrl]) + 0.f) : 0.f;
     __syncthreads();
-    for (int r = t; r < R2_FACS; r += 512) facs[r] = 1.f;
-    for (int r = t; r < R2_GVEC; r += 512) gvec[r] = 1.f;
+    for (int r = t; r < L::FACS; r += NT) facs[r] = 1.f;
+    for (int r = t; r < L::GVEC; r += NT) gvec[r] = 1.f;
     __syncthreads();
   }
 
+  // Two workgroups share a CU (NT = 256), normally of two different problems.  Started together they would sweep together and wait together; the
+  // second one starts its iterations about half an iteration late, and since both take the same time per iteration the offset persists: one's
+  // exchange waits fall under the other's sweeps.
+  if (NT == 256 && blockIdx.x >= 256)
+    for (int d = 0; d < a.stagger; ++d) __builtin_amdgcn_s_sleep(1);
   for (int it = 0; it < a.iters; ++it) {
     // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration (as loop invariants the
     // compiler keeps their hoisted addresses alive next to the 192 registers of P)
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
             }
           } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ((f32x4*)klds)[((ib + i4 - 12) * 4 + k) * 512 + t] = kq[k];
+            for (int k = 0; k < 4; ++k) ((f32x4*)klds)[((ib + i4 - 12) * 4 + k) * NT + t] = kq[k];
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -408,13 +426,13 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
       // borders: dustbin column (last block) by row, dustbin row (last group) by column, corner where both
       const float vbin = gvec[128];
       if (lastc) {
-        for (int r = t; r < nrl; r += 512) pb[r] = __expf((alpha + __hip_atomic_load(usrc + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + vbin);
+        for (int r = t; r < nrl; r += NT) pb[r] = __expf((alpha + __hip_atomic_load(usrc + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + vbin);
         if (lastg && t == 0) pb[nrl] = __expf((alpha + u_bin_row) + vbin);
       }
       if (lastg && t < 128) pr[t] = t < ncl ? __expf((alpha + u_bin_row) + gvec[t]) : 0.f;
       __syncthreads();
-      for (int r = t; r < R2_FACS; r += 512) facs[r] = 1.f;
-      for (int r = t; r < R2_GVEC; r += 512) gvec[r] = 1.f;
+      for (int r = t; r < L::FACS; r += NT) facs[r] = 1.f;
+      for (int r = t; r < L::GVEC; r += NT) gvec[r] = 1.f;
       if (t < 132) { gown_l[t] = 1.f; fo_l[t] = 1.f; }
       __syncthreads();
     }
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
             s2 = r2f2{0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const f32x4 q = ((const f32x4*)klds)[((i - 12) * 4 + k) * 512 + t];
+              const f32x4 q = ((const f32x4*)klds)[((i - 12) * 4 + k) * NT + t];
               s2 = __builtin_elementwise_fma(r2f2{q[0], q[1]}, g2[2 * k], s2);
               s2 = __builtin_elementwise_fma(r2f2{q[2], q[3]}, g2[2 * k + 1], s2);
             }
@@ -600,7 +618,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const f32x4 q = ((const f32x4*)klds)[((i - 12) * 4 + k) * 512 + t];
+              const f32x4 q = ((const f32x4*)klds)[((i - 12) * 4 + k) * NT + t];
               cs2[2 * k] = __builtin_elementwise_fma(r2f2{q[0], q[1]}, f2, cs2[2 * k]);
               cs2[2 * k + 1] = __builtin_elementwise_fma(r2f2{q[2], q[3]}, f2, cs2[2 * k + 1]);
             }
@@ -626,7 +644,7 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
       }
       if (lastc) {              // dustbin column: sum_i F_i pb_i over the group's slots (the corner included: it sits in slot nrl)
         float s = 0.f;
-        for (int r = t; r < nslots; r += 512) s += facs[r] * pb[r];
+        for (int r = t; r < nslots; r += NT) s += facs[r] * pb[r];
         s = wave_sum(s);
         if (lane == 0) wred[wave] = s;
       }
@@ -635,12 +653,12 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
     float ctot = 0.f;                                                          // this row group's partial for the thread's column
     if (t < 128) {
 #pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) ctot += colred[w8 * 128 + t];
+      for (int w8 = 0; w8 < L::NW; ++w8) ctot += colred[w8 * 128 + t];
       if (lastg) ctot += facs[nrl] * pr[t];
       csst[t] = ctot;
     } else if (t == 128 && lastc) {
 #pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) ctot += wred[w8];
+      for (int w8 = 0; w8 < L::NW; ++w8) ctot += wred[w8];
       csst[128] = ctot;
     }
     stamp(5);
@@ -649,12 +667,15 @@ __global__ __launch_bounds__(512) void ot_res2_kernel(OtR2Args a) {
       __syncthreads();
       float* cmine = p.cpart + ((int64_t)(((it & 1) * p.nx + xr) * p.nc + cc)) * R2_CSEG;
       const auto xtg = [&](float x) { return __uint_as_float(__float_as_uint(x) | xtagbit); };
-      if (t < 33) {
+      if (t < 33) {         // (NT = 256: xrd lies over rowst | colred, whose last readers are behind the barrier above)
         const f32x4 q = *(const f32x4*)(csst + 4 * t);
         r2_st4_wt(cmine + 4 * t, f32x4{xtg(q[0]), xtg(q[1]), xtg(q[2]), xtg(q[3])});
         *(f32x4*)(xrd + xr * R2_CSEG + 4 * t) = q;
-      } else if (t >= 64 && t < 64 + 33 * (p.nx - 1)) {
-        const int o = (t - 64) / 33, qd = (t - 64) % 33;
+      }
+      // one (other row group, quad) pair per thread, from thread 64 on (the publishing wave does not also wait); with eight groups and 256
+      // threads the pairs wrap around once
+      for (int idx = t - 64 < 0 ? t - 64 + NT : t - 64; idx < 33 * (p.nx - 1); idx += NT) {
+        const int o = idx / 33, qd = idx % 33;
         const int xs = o < xr ? o : o + 1;                                    // the other row groups, in order
         const float* src = p.cpart + ((int64_t)(((it & 1) * p.nx + xs) * p.nc + cc)) * R2_CSEG + 4 * qd;
         unsigned vmask = 0;
@@ -741,11 +762,19 @@ static inline int r2_up4(int x) { return (x + 3) & ~3; }
 // a tall, narrow problem (m <= 512 with more than ~132 nc rows per group) otherwise indexes past those arrays.  nc = 32 always fits
 // (rbf <= 36).  false: no on-chip geometry (empty or oversized problem).
 constexpr int R2_FOLD = 132;
+// GIMS_OT_R2_HALF=1: 256-thread workgroups holding <= 512 rows, two per CU (of two different problems when a launch holds two), instead of
+// 512-thread workgroups holding <= 1024 rows, one per CU.  Built in round 4 to hide one problem's exchange waits under the other's sweeps; measured:
+// a lone wave per SIMD issues its sweep at about half the rate of two (row pass of 512 rows 2.3 k cycles against 2.7 k for 1024 rows on twice the
+// waves), so the two problems' chains stay as long as before -- 4096 x 2: 0.94 ms per launch against 0.92, 1024 x 32: 0.87 against 0.82, whatever
+// the start offset between the two workgroups (GIMS_OT_R2_STAGGER).  ONE 4096 problem does gain (0.87 -> 0.76 ms: it spreads over all 256
+// CUs), but the geometry has to be a function of the problem's own size, not of its batch.  Off by default; read per call (the tests run both).
+static bool r2_half() { return r2_env("GIMS_OT_R2_HALF", 0) != 0; }
+static inline int r2_rbmax() { return r2_half() ? 512 : 1024; }
 static inline bool r2_geom(int n, int m, int& nx, int& nc) {
   if (n < 1 || m < 1 || n > 4096 || m > 4096) return false;
   nc = 1;
   while (nc * 128 < m) nc *= 2;
-  nx = cdiv(n, 1024);
+  nx = cdiv(n, r2_rbmax());
   const int rb = cdiv(n, nx);
   while (nc < 32 && r2_up4(cdiv(rb + 1, nc)) > R2_FOLD) nc *= 2;
   return r2_up4(cdiv(rb + 1, nc)) <= R2_FOLD;
@@ -764,18 +793,18 @@ static OtR2Plan plan_class(const OtR2Host* pr, int np, int iters) {
     int nxi = 0, nci = 0;
     if (!r2_geom(pr[i].n, pr[i].m, nxi, nci) || nxi != nx || nci != nc) return P;
   }
-  const int units = 8 * (32 / nc);                                  // row groups one launch holds (each on the CUs of one XCD)
+  const int units = 8 * ((r2_half() ? 64 : 32) / nc);               // row groups one launch holds (each on the CUs of one XCD; two workgroups per CU with 256 threads)
   if (nx > units) return P;
   P.nx = nx; P.nc = nc;
   P.ppg = units / nx;
   P.ppg = P.ppg < np ? P.ppg : np;
   P.ngroups = cdiv(np, P.ppg);
   if (P.ngroups > 64) return P;
-  size_t b = r2_al(sizeof(OtR2Dev) * (size_t)np) + (size_t)P.ngroups * r2_al(sizeof(OtR2Block) * 256) + 256;
+  size_t b = r2_al(sizeof(OtR2Dev) * (size_t)np) + (size_t)P.ngroups * r2_al(sizeof(OtR2Block) * 512) + 256;
   for (int i = 0; i < np; ++i) {
     const int rb = cdiv(pr[i].n, nx);
     const int rbf = r2_up4(cdiv(rb + 1, nc)), rbs = nc * rbf;
-    if (rbf > R2_FOLD || rb > 1024 || r2_up4(cdiv(pr[i].m, nc)) > 128) return P;
+    if (rbf > R2_FOLD || rb > r2_rbmax() || r2_up4(cdiv(pr[i].m, nc)) > 128) return P;
     b += 2 * r2_al((size_t)nx * nc * rbs * 4) + r2_al((size_t)nx * 2 * rbs * 4) + r2_al((size_t)2 * nx * nc * R2_CSEG * 4);
   }
   P.bytes = b;
@@ -818,7 +847,7 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
 
 // per-device state of the launcher (created once per device under a lock)
 struct R2State { int resident_ok, wt_local; volatile int* h_place; hipEvent_t place_ev; };
-static R2State* r2_state(const void* kernel, size_t lds) {
+static R2State* r2_state(const void* kernel, int threads, int blocks, size_t lds) {
   static std::mutex mu;
   static std::map<int, R2State> states;
   const int dev = current_device();
@@ -827,9 +856,9 @@ static R2State* r2_state(const void* kernel, size_t lds) {
   if (it != states.end()) return &it->second;
   R2State st{};
   int per_cu = 0, cus = 0;
-  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, lds);
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds);
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-  st.resident_ok = (e == hipSuccess && per_cu * cus >= 256) ? 1 : 0;
+  st.resident_ok = (e == hipSuccess && per_cu * cus >= blocks) ? 1 : 0;
   st.wt_local = r2_env("GIMS_OT_R2_WT", 0) ? 1 : 0;
   st.h_place = (volatile int*)pinned_once("ot_res2_place", 256);
   if (!st.h_place || hipEventCreateWithFlags(&st.place_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -878,14 +907,18 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
   GIMS_HIP(hipMemsetAsync(dplace, 0, 256, s));
   int rc = upload_table(hd.data(), sizeof(OtR2Dev) * (size_t)np, dprob, s);
   if (rc != GIMS_OK) return rc;
-  constexpr size_t lds = R2_LDS_FLOATS * sizeof(float);
-  GIMS_LDS_ATTR((const void*)ot_res2_kernel<false>, (int)lds);
-  GIMS_LDS_ATTR((const void*)ot_res2_kernel<true>, (int)lds);
-  R2State* st = r2_state((const void*)ot_res2_kernel<false>, lds);
+  const bool half = r2_half();
+  const int nthreads = half ? 256 : 512, nblocks = half ? 512 : 256;
+  const size_t lds = (half ? R2L<256>::FLOATS : R2L<512>::FLOATS) * sizeof(float);
+  GIMS_LDS_ATTR((const void*)ot_res2_kernel<false, 512>, (int)(R2L<512>::FLOATS * sizeof(float)));
+  GIMS_LDS_ATTR((const void*)ot_res2_kernel<true, 512>, (int)(R2L<512>::FLOATS * sizeof(float)));
+  GIMS_LDS_ATTR((const void*)ot_res2_kernel<false, 256>, (int)(R2L<256>::FLOATS * sizeof(float)));
+  GIMS_LDS_ATTR((const void*)ot_res2_kernel<true, 256>, (int)(R2L<256>::FLOATS * sizeof(float)));
+  R2State* st = r2_state(half ? (const void*)ot_res2_kernel<false, 256> : (const void*)ot_res2_kernel<false, 512>, nthreads, nblocks, lds);
   if (!st) { set_error("ot_res2_run: no per-device state"); return GIMS_EHIP; }
-  // all 256 workgroups wait on each other: they must be co-resident (one per CU) -- checked once per device against the occupancy query
+  // all workgroups of a launch wait on each other: they must be co-resident (one / two per CU) -- checked once per device against the occupancy query
   if (!st->resident_ok) {
-    set_error("the on-chip Sinkhorn kernel does not fit: 256 workgroups of 512 threads with %zu bytes of LDS are not co-resident on this device", lds);
+    set_error("the on-chip Sinkhorn kernel does not fit: %d workgroups of %d threads with %zu bytes of LDS are not co-resident on this device", nblocks, nthreads, lds);
     return GIMS_EHIP;
   }
   // write-through stores on the local edges as well when the dispatcher was seen to place blocks elsewhere than XCD b % 8 (sticky per
@@ -895,24 +928,27 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
   const int refresh = r2_env("GIMS_OT_REFRESH", 50);
   const int prof = r2_env("GIMS_OT_PROF", 0);
   for (int gi = 0; gi < P.ngroups; ++gi) {
-    OtR2Block* dblk = (OtR2Block*)(base + off); off += r2_al(sizeof(OtR2Block) * 256);
-    OtR2Block hb[256];
-    for (int b = 0; b < 256; ++b) hb[b] = OtR2Block{-1, 0, 0, 0};
+    OtR2Block* dblk = (OtR2Block*)(base + off); off += r2_al(sizeof(OtR2Block) * 512);
+    OtR2Block hb[512];
+    for (int b = 0; b < 512; ++b) hb[b] = OtR2Block{-1, 0, 0, 0};
     const int p0 = gi * P.ppg, p1 = (p0 + P.ppg < np) ? p0 + P.ppg : np;
+    // unit (problem q, row group xr) -> XCD unit % 8, slot unit / 8 of that XCD's CUs; with two workgroups per CU the slots past the first
+    // 32 / nc are the SECOND workgroup of the same CUs: two problems of eight row groups share every CU
     for (int q = 0; q < p1 - p0; ++q)
       for (int xr = 0; xr < P.nx; ++xr) {
         const int unit = q * P.nx + xr, xcd = unit % 8, slot = unit / 8;
         for (int c = 0; c < P.nc; ++c) hb[8 * (slot * P.nc + c) + xcd] = OtR2Block{p0 + q, xr, c, 0};
       }
-    rc = upload_table(hb, sizeof(hb), dblk, s);
+    rc = upload_table(hb, sizeof(OtR2Block) * (size_t)nblocks, dblk, s);
     if (rc != GIMS_OK) return rc;
     OtR2Args a{};
-    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local; a.init_inside = init_inside;
+    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local; a.init_inside = init_inside; a.stagger = r2_env("GIMS_OT_R2_STAGGER", 100);
     if (prof) {
       unsigned long long* dprof = (unsigned long long*)device_once("ot_res2_prof", 8 * sizeof(unsigned long long), nullptr);
       GIMS_CHECK_ARG(dprof, "ot_res2_run: no profile buffer");
       a.prof = dprof;
-      hipLaunchKernelGGL(ot_res2_kernel<true>, dim3(256), dim3(512), lds, s, a);
+      if (half) hipLaunchKernelGGL((ot_res2_kernel<true, 256>), dim3(512), dim3(256), lds, s, a);
+      else hipLaunchKernelGGL((ot_res2_kernel<true, 512>), dim3(256), dim3(512), lds, s, a);
       GIMS_LAUNCH_CHECK();
       unsigned long long h[8];
       GIMS_HIP(hipStreamSynchronize(s));
@@ -923,7 +959,8 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
       for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.0f;", names[i], (double)h[i] / iters);
       fprintf(stderr, "\n");
     } else {
-      hipLaunchKernelGGL(ot_res2_kernel<false>, dim3(256), dim3(512), lds, s, a);
+      if (half) hipLaunchKernelGGL((ot_res2_kernel<false, 256>), dim3(512), dim3(256), lds, s, a);
+      else hipLaunchKernelGGL((ot_res2_kernel<false, 512>), dim3(256), dim3(512), lds, s, a);
       GIMS_LAUNCH_CHECK();
     }
   }
