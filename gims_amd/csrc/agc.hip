@@ -58,6 +58,7 @@ struct AgcWs {
   double* cent;         // [n][2]
   int32_t* ptr0;        // [n+1] CSR of the pre-removal graph (original ids)
   int32_t* idx0;        // [cap]
+  int32_t* esrc;        // [cap] source row of every entry of idx0 (the component search walks the edge list, not the rows)
   int32_t* counters;    // [16] scratch counters: 0 coarse directed edges, 1 components, 2 pre-removal directed edges
   int32_t* coff2;       // [n+1] component offsets (scan of sizes)
   int32_t* degk;        // [n] degree by kept id
@@ -1357,7 +1358,10 @@ __global__ __launch_bounds__(256) void agc_fill_kernel(const AgcWs* __restrict__
       const int b = __ffsll((unsigned long long)m) - 1;
       m &= m - 1;
       const int j = k * 64 + b;
-      if (pos < cap) idx[pos] = newid ? newid[j] : j;
+      if (pos < cap) {
+        idx[pos] = newid ? newid[j] : j;
+        if (!final_pass) w.esrc[pos] = i;
+      }
       ++pos;
     }
   }
@@ -1392,16 +1396,28 @@ __global__ __launch_bounds__(1024) void agc_cc_kernel(const AgcWs* __restrict__ 
   // meanwhile).  Roots only ever move to smaller indices, so a component's final root is its smallest node whatever the interleaving -- the
   // labels are the same as the min-label propagation this replaces, which rescanned all edges until a pass changed nothing (three scans of
   // ~50 us each at 4096 nodes: 160 -> 65 us).
-  for (int u = t; u < n; u += 1024) {
-    const int beg = w.ptr0[u], end = w.ptr0[u + 1] < w.cap ? w.ptr0[u + 1] : w.cap;
-    for (int e = beg; e < end; ++e) {
-      const int v = w.idx0[e];
-      if (v < u) continue;   // each undirected edge once
-      for (;;) {
-        const int ru = find(u), rv = find(v);
-        if (ru == rv) break;
-        const int hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
-        if (atomicCAS(&parent[hi], hi, lo) == hi) break;     // hi was still a root: hooked
+  // ... over the EDGE LIST (source row, neighbour), four entries per thread and step with their loads in flight together: walking the rows
+  // (ptr0 -> idx0 -> union, a chain of dependent global loads per edge) was 80 us per image of 4096, most of it memory latency
+  {
+    const int E = w.ptr0[n] < w.cap ? w.ptr0[n] : w.cap;
+    for (int e0 = t; e0 < E; e0 += 4 * 1024) {
+      int us[4], vs[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q * 1024;
+        us[q] = e < E ? w.esrc[e] : 0;
+        vs[q] = e < E ? w.idx0[e] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int u = us[q], v = vs[q];
+        if (v <= u) continue;   // each undirected edge once (and the padding of the last step)
+        for (;;) {
+          const int ru = find(u), rv = find(v);
+          if (ru == rv) break;
+          const int hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
+          if (atomicCAS(&parent[hi], hi, lo) == hi) break;     // hi was still a root: hooked
+        }
       }
     }
   }
@@ -1702,6 +1718,7 @@ static size_t agc_layout(int n, int d, int max_edges_dir, bool exact_s, char* ba
   p = take((size_t)n * 16); if (w) w->cent = (double*)p;
   p = take((size_t)(n + 1) * 4); if (w) w->ptr0 = (int32_t*)p;
   p = take((size_t)cap * 4); if (w) w->idx0 = (int32_t*)p;
+  p = take((size_t)cap * 4); if (w) w->esrc = (int32_t*)p;
   p = take(64); if (w) w->counters = (int32_t*)p;
   p = take((size_t)(n + 1) * 4); if (w) w->coff2 = (int32_t*)p;
   p = take((size_t)n * 4); if (w) w->degk = (int32_t*)p;
