@@ -506,6 +506,20 @@ class GMatcher(nn.Module):
 
     _edge_cap = 64
 
+    @staticmethod
+    def _agc_retry(flags, robust):
+        """What to do with the flag words (info[7]) of a graph build: 'robust' -- some image's predicted percentile window was missed: ALL its
+        outputs are void, its overflow bit included (a void threshold can keep any number of edges), so this comes first; 'grow' -- an edge
+        buffer overflowed; None -- the build stands.  A robust build cannot report a miss."""
+        flags = np.asarray(flags)
+        if (flags & hip.AGC_INFO_WINDOW_MISSED).any():
+            if robust:
+                raise hip.GimsHipError("adaptive graph: the robust flow reported a missed percentile window")
+            return "robust"
+        if (flags & hip.AGC_INFO_OVERFLOW).any():
+            return "grow"
+        return None
+
     def _gather(self, ctx):
         """Read the kept counts (the one host sync of a batch) and compact the kept keypoints of all images into merged
         row-major arrays + one merged CSR (gmatcher.py:244-249).  Returns None after growing the edge capacity (the caller
@@ -525,15 +539,14 @@ class GMatcher(nn.Module):
         torch.cuda.current_stream().synchronize()
         infos = pin[:info_all.shape[0]].numpy().copy()
         self._sync_ms = 1e3 * (time.perf_counter() - ts0)
-        if (infos[:, 7] & hip.AGC_INFO_WINDOW_MISSED).any() and not (infos[:, 7] & hip.AGC_INFO_OVERFLOW).any():
+        action = self._agc_retry(infos[:, 7], bool(ctx.get("robust")))
+        if action == "robust":
             # the percentile window predicted from the similarity sample did not provably hold the threshold (gims_agc_build_ex): the
             # outputs of this build are void; the repeat histograms every similarity
-            if ctx.get("robust"):
-                raise hip.GimsHipError("adaptive graph: the robust flow reported a missed percentile window")
-            ctx["params"] = tuple(ctx["params"]) + (True,)
+            ctx["params"] = tuple(ctx["params"][:3]) + (True,)
             self._agc_window_misses = getattr(self, "_agc_window_misses", 0) + 1
             return None
-        if (infos[:, 7] & hip.AGC_INFO_OVERFLOW).any():
+        if action == "grow":
             # more edges than the buffers hold: repeat the graph build of this batch with room for what it reported (the
             # directed-edge total of the densest image, rounded up to a power of two per node), and keep the larger capacity
             ns = np.asarray([g["kp"].shape[0] for g in images], dtype=np.float64)

@@ -274,3 +274,20 @@ def test_auto_attention_routes_on_the_tail_and_the_range():
     mean3 = mean2.copy(); mean3[1, 2] = 0.3
     modes3 = feed(mean3, np.zeros((L, H)), rng3)
     assert modes3[1] == "bf16x3" and m.attention_report()["switched"] == [1]
+
+
+def test_graph_build_flag_words_decide_the_repeat():
+    """info[7] of a graph build (include/gims_hip.h): bit 1 = the predicted percentile window was missed -- every output of that image is void,
+    its overflow bit too, so the repeat with the robust flow comes before any capacity growth; bit 0 alone = grow the edge buffers; a robust
+    build that reports a miss is an error (it predicts nothing)."""
+    import numpy as np
+    import pytest
+    from gims_amd import GMatcher, hip
+    R = GMatcher._agc_retry
+    assert R(np.array([0, 0, 0]), False) is None
+    assert R(np.array([0, 1, 0]), False) == "grow"
+    assert R(np.array([0, 2, 0]), False) == "robust"
+    assert R(np.array([1, 3, 0]), False) == "robust"          # a missed image may also claim an overflow: void
+    assert R(np.array([1, 0, 0]), True) == "grow"
+    with pytest.raises(hip.GimsHipError):
+        R(np.array([0, 2]), True)
