@@ -279,7 +279,7 @@ int gims_agc_build(const gims_agc_image* h_images /* HOST array */, int32_t n_im
  * Default: a sample of one-pass half-precision similarities predicts a window of values that holds rank k, one pass over all N^2/2 of
  * them counts what lies below the window and lists what lies inside it, and only the listed entries (and the radius candidates) are
  * evaluated exactly.  The prediction is VERIFIED on the device against a rigorous bound of the half-precision error; if it did not hold,
- * bit 1 of info[7] is set (bit 0: edge capacity) and every other output of that image is to be discarded: repeat the call with
+ * bit 1 of info[7] is set (bit 0: edge capacity) and every other output of that image -- bit 0 included -- is to be discarded: repeat the call with
  * GIMS_AGC_ROBUST, which histograms every entry instead of predicting (about 0.2 ms more per 16 images of 4096).  Images of at most 1536
  * keypoints are "sampled" in full and never report bit 1. */
 #define GIMS_AGC_ROBUST 1
