@@ -291,3 +291,31 @@ def test_graph_build_flag_words_decide_the_repeat():
     assert R(np.array([1, 0, 0]), True) == "grow"
     with pytest.raises(hip.GimsHipError):
         R(np.array([0, 2]), True)
+
+
+def test_bench_line_is_compact_and_parses_from_the_stored_tail():
+    """The driver keeps the last 8000 characters of stdout and parses the last line: bench.py's line must stay under 4 KB
+    whatever the full record holds (round 4 lost its measurement to a 24-KB line), also with 8 ranks and every extra block."""
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r04_bench_default.json")))        # a real 24-KB record
+    assert len(json.dumps(full)) > 20000
+    full["n_gpus"], full["world_size_seen"] = 8, 8
+    full["ranks"] = [{"rank": r, "device": r, "device_name": "AMD Instinct MI355X", "backend": "nccl", "pid": 1000 + r} for r in range(8)]
+    full["also"]["readme_boat_15k"] = dict(full["also"]["2x4096_eval_setting"], agc_ms_per_image=3.21)
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line) < bench.LINE_LIMIT <= 4096
+    stdout = "x" * 20000 + "\n" + line + "\n"
+    got = json.loads(stdout[-8000:].strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "cross_attention", "world_size_seen", "ranks"):
+        assert k in got, k
+    assert set(got["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"}
+    assert set(got["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert got["config"]["workload"] and got["also"]["2x1024"]["value"] > 0
+    assert abs(got["value"] - full["value"]) / full["value"] < 1e-3
+    # a record that is still too long sheds its optional parts instead of the contract's keys
+    full["config"]["workload"] = "w" * 3000
+    line = bench.compact_line(full)
+    assert len(line) < bench.LINE_LIMIT and "roofline" in json.loads(line) and "cpu_baseline" in json.loads(line)
