@@ -6,15 +6,15 @@
 //        (one MFMA pass, |error| <= AGC_EPS by Cauchy-Schwarz on unit rows); a 12-bit histogram of it brackets the k-th value; only the
 //        entries inside a rigorous error band around that bracket (~0.3 %) and the radius candidates (~19 k per image) are re-evaluated
 //        exactly (f32 operands, float64 accumulation in a fixed order), and the exact k-th value is selected among the band entries
-//        with the exact count below the band.  GIMS_AGC_EXACT_S=1: the earlier flow (all N^2 similarities at f32-GEMM accuracy,
-//        radix select over the whole matrix) as the cross-check.
+//        with the exact count below the band.  (The flow of rounds 1-3 -- all N^2 similarities at f32-GEMM accuracy, radix select over the
+//        whole matrix -- left the library in round 5; the reference goldens and the CPU restatement in the tests are the cross-check.)
 //   K3 radius candidates (float64, inclusive) AND sim >= thr  (agc.py:435-447) -> adjacency BIT MATRIX
 //   K4 connect_isolated_nodes, sequential semantics           (agc.py:476-495)
 //   K5 connected components (min-label union-find in LDS) + small-component removal (agc.py:497-516)
 //   K6 fast_connect_components, one round                     (agc.py:518-565)
 //   K7 sorted relabel + bidirectional CSR                     (dgl.from_networkx, agc.py:704)
 //
-// Everything here is integer / byte / latency-bound work (N <= 16384 nodes, a few 10^4 edges) except K1/K2,
+// Everything here is integer / byte / latency-bound work (N <= 32768 nodes, a few 10^4 edges) except K1/K2,
 // which stream the N x N similarity matrix (HBM-bound).  The adjacency lives in an N x N bit matrix so that
 // the sequential fix-ups only flip bits and the CSR falls out of popcounts in ascending neighbour order.
 #include "common.h"
@@ -24,20 +24,24 @@
 
 namespace gims {
 
-constexpr int AGC_MAX_N = 16384;
+// Largest image: 32768 keypoints (the reference has no limit -- agc.py:413-449 is NumPy -- and publishes runs with up to 21 163 kept
+// keypoints, tools/files/rgbd1/record.txt:635).  What bounds it here: a pair of node ids is packed into one 32-bit word (i << 16 | j), the
+// sequential isolated-node walk keeps its ordered list in LDS (4 bytes per node + a bit: 135 KB of the 160 KB at 32768), and the band list
+// reserves one word per pair of the strict upper triangle (2 GB per image at 32768).  Up to AGC_CC_LDS_N nodes the component search runs in LDS,
+// above it in global memory (slower, same labels).
+constexpr int AGC_MAX_N = 32768;
+constexpr int AGC_PK_SHIFT = 16;
+constexpr uint32_t AGC_PK_MASK = 0xffffu;
+constexpr int AGC_CC_LDS_N = 16384;
 constexpr int AGC_NB = 16384;  // hash buckets of the keypoint grid
-constexpr int ADJ_R = 4;      // rows per wave of the radius search: one load of point j serves four row tests (the loop is issue bound)
 
 struct AgcWs {
-  float* dn;            // [n][d] normalised descriptors (f32 GEMM) -- or, as dn3, their SPL3 three-way bf16 split [n][3d]
-  uint16_t* dn3;        // non-null: the similarity GEMM runs as GIMS_PREC_BF16X6
-  float* S;             // [n][lds]  (GIMS_AGC_EXACT_S=1 flow only)
   float* dnf;           // [n][d] normalised descriptors in f32: operands of the exact evaluations
-  uint16_t* dn16;       // [n][d] the same rounded to IEEE half: operands of the approximate similarity GEMM (null: exact-S flow)
+  uint16_t* dn16;       // [n][d] the same rounded to IEEE half: operands of the approximate similarity GEMM
   uint16_t* S16;        // [n][lds16] approximate similarities in half; tiles that touch the upper triangle are valid
-  uint32_t* list;       // band entries: packed (i << 14 | j), overwritten in place by the order-preserving keys of their exact values
+  uint32_t* list;       // band entries: packed (i << 16 | j), overwritten in place by the order-preserving keys of their exact values
   uint32_t* band;       // [4]: first and last 12-bit bin of the band, pad
-  uint32_t* clist;      // radius candidates, packed (i << 14 | j) with i < j; ckey: the order-preserving keys of their exact similarities
+  uint32_t* clist;      // radius candidates, packed (i << 16 | j) with i < j; ckey: the order-preserving keys of their exact similarities
   uint32_t* ckey;
   uint32_t list_cap, clist_cap; int lds16;
   int32_t* cellptr;     // [AGC_NB + 1] bucket offsets of the keypoint grid (radius search); cellidx [n]: point ids sorted by bucket
@@ -66,7 +70,7 @@ struct AgcWs {
   const float* kpts; const float* desc; int64_t ldd;
   int32_t* kept; int32_t* indptr; int32_t* indices; int32_t* info;
   int64_t krank;        // percentile rank k (agc.py:378-379)
-  int n, d, lds, nw, cap, max_edges_dir;
+  int n, d, nw, cap, max_edges_dir;
 };
 
 // per-image reset of the select state and counters (descriptors are already in device memory, see upload_table)
@@ -85,7 +89,6 @@ __global__ void agc_init_kernel(const AgcWs* __restrict__ ws) {
 __global__ __launch_bounds__(256) void agc_normalize_kernel(const AgcWs* __restrict__ ws) {
   const AgcWs& w = ws[blockIdx.y];
   const int n = w.n, d = w.d;
-  float* dn = w.dn;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   if (row >= n) return;
@@ -94,116 +97,45 @@ __global__ __launch_bounds__(256) void agc_normalize_kernel(const AgcWs* __restr
   for (int j = lane; j < d; j += 64) s = fmaf(x[j], x[j], s);
   s = wave_sum(s);
   const float nrm = fmaxf(sqrtf(s), 1e-12f);   // F.normalize: x / max(||x||, eps)
-  if (w.dn16) {    // band-limited flow: the f32 quotient (exact evaluations) and its rounding to half (approximate GEMM)
-    // ... and the 2-norm of the row's rounding error (kept per row in deg, as float bits): the measured half of the error bound of the approximate similarities (agc_window_kernel).  A half that is subnormal counts as flushed to zero (some
-    // matrix cores do): the bound holds either way.
-    float e2 = 0.f;
-    for (int j = lane; j < d; j += 64) {
-      const float v = x[j] / nrm;
-      const uint16_t hb = (uint16_t)(pack_h2_sat(v, 0.f) & 0xffffu);
-      w.dnf[(int64_t)row * d + j] = v;
-      w.dn16[(int64_t)row * d + j] = hb;
-      const float back = (float)__builtin_bit_cast(_Float16, hb);
-      float e = fabsf(v - back);
-      if ((hb & 0x7c00u) == 0u) e = fmaxf(e, fabsf(v));
-      e2 = fmaf(e, e, e2);
-    }
-    e2 = wave_sum(e2);
-    if (lane == 0) w.deg[row] = (int32_t)__float_as_uint(sqrtf(e2) * 1.0001f);      // (deg is free until the adjacency exists; agc_window_kernel takes the maximum)
-    return;
+  // the f32 quotient (exact evaluations) and its rounding to half (approximate GEMM)
+  // ... and the 2-norm of the row's rounding error (kept per row in deg, as float bits): the measured half of the error bound of the approximate
+  // similarities (agc_window_kernel, agc_band_kernel).  A half that is subnormal counts as flushed to zero (some matrix cores do): the bound
+  // holds either way.
+  float e2 = 0.f;
+  for (int j = lane; j < d; j += 64) {
+    const float v = x[j] / nrm;
+    const uint16_t hb = (uint16_t)(pack_h2_sat(v, 0.f) & 0xffffu);
+    w.dnf[(int64_t)row * d + j] = v;
+    w.dn16[(int64_t)row * d + j] = hb;
+    const float back = (float)__builtin_bit_cast(_Float16, hb);
+    float e = fabsf(v - back);
+    if ((hb & 0x7c00u) == 0u) e = fmaxf(e, fabsf(v));
+    e2 = fmaf(e, e, e2);
   }
-  if (w.dn3) {     // exact three-way split of the f32 quotient (linear6.hip: SPL3 layout)
-    uint16_t* o = w.dn3 + (int64_t)row * 3 * d;
-    for (int j = lane; j < d; j += 64) {
-      const float v = x[j] / nrm;
-      const uint16_t h1 = f2bf(v);
-      const float r1 = v - bf2f(h1);
-      const uint16_t h2 = f2bf(r1);
-      uint16_t* q = o + (j >> 5) * 96 + (j & 31);
-      q[0] = h1; q[32] = h2; q[64] = f2bf(r1 - bf2f(h2));
-    }
-    return;
-  }
-  for (int j = lane; j < d; j += 64) dn[(int64_t)row * d + j] = x[j] / nrm;
+  e2 = wave_sum(e2);
+  if (lane == 0) w.deg[row] = (int32_t)__float_as_uint(sqrtf(e2) * 1.0001f);      // (deg is free until the adjacency exists; the window / band kernels take the maximum)
 }
 
 // ---------------------------------------------------------------------------------------------- K2 radix select
-// Exact k-th smallest of the strict upper triangle (agc.py:367-380) by radix select on order-preserving keys in THREE digits
-// (12 + 12 + 8 bits) and TWO sweeps of the N x N matrix instead of four: the second sweep, which only looks at the entries whose
-// top 12 bits equal the selected prefix (about 1 % of them for cosine similarities), also appends those keys to a candidate
-// list (the adjacency-bit buffer, not in use yet), and the last digit is counted from that list.  mode 0: count from S;
-// mode 1: count from S and append the matching keys; mode 2: count from the list (from S if the list overflowed).
-// The order of the list depends on the run; the selected VALUE does not.
-constexpr int AGC_CAND_LDS = 1024;      // (with the 16-KB histogram: 20 KB of LDS per workgroup, eight workgroups per CU -- 32 KB halved the occupancy and cost 60 %)
-__global__ __launch_bounds__(256) void agc_hist_kernel(const AgcWs* __restrict__ ws, int shift, int bits, int mode) {
+// Exact k-th smallest among the listed keys (the exact similarities of the band / window entries) by radix select on order-preserving keys
+// in THREE digits (12 + 12 + 8 bits): one histogram pass over the list per digit, restricted to the keys that share the prefix selected so far.
+__global__ __launch_bounds__(256) void agc_hist_kernel(const AgcWs* __restrict__ ws, int shift, int bits) {
   const AgcWs& w = ws[blockIdx.y];
   __shared__ uint32_t h[4096];
-  __shared__ uint32_t cand[AGC_CAND_LDS];
-  __shared__ uint32_t ncand, gbase;
   const int nb = 1 << bits;
   for (int i = threadIdx.x; i < nb; i += 256) h[i] = 0;
-  if (threadIdx.x == 0) ncand = 0;
   __syncthreads();
   const uint32_t prefix = w.sel[0];
   const uint32_t himask = shift + bits >= 32 ? 0u : (0xffffffffu << (shift + bits));
   const uint32_t dmask = (uint32_t)nb - 1u;
-  uint32_t* list = w.list ? w.list : (uint32_t*)w.bits;
-  const uint32_t cap = w.list ? w.list_cap : (uint32_t)((int64_t)w.n * w.nw * 2);
-  const uint32_t nlist = w.sel[3];
-  if (mode == 2 && nlist <= cap) {                 // the candidates of the previous sweep (they share the prefix of THAT sweep)
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) {
-      const uint32_t k = list[i];
-      if ((k & himask) == (prefix & himask)) atomicAdd(&h[(k >> shift) & dmask], 1u);
-    }
-  } else {
-    for (int i = blockIdx.x; i < w.n; i += gridDim.x) {
-      const float* row = w.S + (int64_t)i * w.lds;
-      // 16-byte loads over the strict upper triangle of row i (rows are 16-byte aligned: lds % 4 == 0), four in flight per thread
-      for (int j0 = ((i + 1) & ~3) + 4 * threadIdx.x; j0 < w.n; j0 += 4 * 4 * 256) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j4 = j0 + u * 4 * 256;
-          const f32x4 q4 = j4 < w.n ? __builtin_nontemporal_load((const f32x4*)(row + j4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-          v[u] = make_float4(q4[0], q4[1], q4[2], q4[3]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j4 = j0 + u * 4 * 256;
-          const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = j4 + q;
-            if (j > i && j < w.n) {
-              const uint32_t k = f32_key(x[q]);
-              if ((k & himask) == (prefix & himask)) {
-                atomicAdd(&h[(k >> shift) & dmask], 1u);
-                if (mode == 1) {
-                  const uint32_t slot = atomicAdd(&ncand, 1u);
-                  if (slot < AGC_CAND_LDS) cand[slot] = k;
-                }
-              }
-            }
-          }
-        }
-      }
-    }
+  const uint32_t nlist = w.sel[3] < w.list_cap ? w.sel[3] : w.list_cap;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) {
+    const uint32_t k = w.list[i];
+    if ((k & himask) == (prefix & himask)) atomicAdd(&h[(k >> shift) & dmask], 1u);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nb; i += 256)
     if (h[i]) atomicAdd(&w.hist[i], h[i]);
-  if (mode == 1) {
-    const uint32_t nc = ncand;
-    if (threadIdx.x == 0) {
-      // one reservation per workgroup; a workgroup whose LDS buffer ran over, or a list that would, marks the list unusable
-      gbase = nc <= AGC_CAND_LDS ? atomicAdd(&w.sel[3], nc) : 0xffffffffu;
-      if (nc > AGC_CAND_LDS) atomicOr(&w.sel[3], 0x80000000u);
-    }
-    __syncthreads();
-    const uint32_t base = gbase;
-    if (base != 0xffffffffu && base + nc <= cap)
-      for (uint32_t i = threadIdx.x; i < nc; i += 256) list[base + i] = cand[i];
-  }
 }
 
 // the bin holding rank k: parallel inclusive scan of the counts (thread t owns nb / 256 consecutive bins)
@@ -249,7 +181,6 @@ __global__ __launch_bounds__(256) void agc_pick_kernel(const AgcWs* __restrict__
 // |S - S16| <= AGC_EPS for unit rows: operands rounded to half (unit roundoff 2^-11 each: <= 2 * 2^-11 + 2^-22 by Cauchy-Schwarz;
 // elements below 2^-14 go subnormal at an absolute 2^-25, < 2^-21 over 256 of them), products exact in f32, 256 f32 additions
 // (< 2e-5), result rounded to half (<= 2^-11 for |S| <= 2).  0.000977 + 0.00002 + 0.00049 < 0.0016.
-constexpr float AGC_EPS = 0.0016f;
 // Placement of per-image work that re-reads the image's rows (similarity tiles, gathered exact dot products): block b runs on XCD b % 8
 // (observed; a speed assumption only), and the eight XCDs take the (image, part) units q = xcd, xcd + 8, ... in turn, with
 // nparts = 8 / gcd(n_images, 8) parts per image -- an image's rows are fetched into ONE XCD's 4-MB L2 (16 images: two per XCD, one after the
@@ -415,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void agc_sim16_kernel(const AgcWs* __restri
 //   SIM_SAMPLE   the rows i % stride == 0 against all columns: histogram of the strict upper triangle on 4096 LINEAR bins over [-1, 1) (stride 1 =
 //                every pair: small images);
 //   SIM_COLLECT  every pair: entries below the window [band[0], band[1]] are counted (counters[5]), entries inside it are appended to the list as
-//                (i << 14 | j) (LDS-staged: one global reservation per flush).
+//                (i << 16 | j) (LDS-staged: one global reservation per flush).
 constexpr int SIM_SAMPLE = 1, SIM_COLLECT = 2, SIM_STAGE = 4096;
 constexpr int AGC_SAMPLE_STRIDE = 8, AGC_SAMPLE_MIN_N = 1536;      // images of at most that many rows are "sampled" in full: their window is rigorous
 __host__ __device__ __forceinline__ int agc_sample_stride(int n) { return n > AGC_SAMPLE_MIN_N ? AGC_SAMPLE_STRIDE : 1; }
@@ -553,7 +484,11 @@ __global__ __launch_bounds__(256, 2) void agc_simw_kernel(const AgcWs* __restric
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();                 // ... for every wave; every wave is done with chunk cidx - 1: its slot takes chunk cidx + 2
                                                         // (the bare barrier: __syncthreads() would wait for the chunks in flight as well)
-          if (MODE == SIM_COLLECT && kc == 0 && tl > 0 && lds_read_raw(nst_off) > (uint32_t)SIM_STAGE / 2) flush();     // (uniform) room for a dense tile
+          if (MODE == SIM_COLLECT && kc == 0 && tl > 0) {     // room for a dense tile.  nst is read by every wave between two barriers with no epilogue
+            const uint32_t cur = lds_read_raw(nst_off);       // in between: with kpc > 1 the next one is the barrier of chunk kc = 1; with a single K chunk
+            if (kpc == 1) __builtin_amdgcn_s_barrier();       // per tile the next barrier would come AFTER this tile's epilogue, so one is added here
+            if (cur > (uint32_t)SIM_STAGE / 2) flush();       // (uniform: flush() holds barriers)
+          }
           if (cidx + 2 < nchunks) issue_b(tl2, kc2, par >= 1 ? par - 1 : 2);
           if (++kc2 == kpc) { kc2 = 0; ++tl2; }
           ++cidx;
@@ -644,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void agc_simw_kernel(const AgcWs* __restric
               m &= m - 1ull;
               const int e = 31 - (b6 & 31), r = e & 15, ib = e >> 4, jb = b6 >> 5;
               const uint32_t gi = (uint32_t)(stride * (i0 + wi * 64 + ib * 32 + li));
-              const uint32_t packed = (gi << 14) | (uint32_t)(jl + jb * 32 + (r & 3) + 8 * (r >> 2));
+              const uint32_t packed = (gi << AGC_PK_SHIFT) | (uint32_t)(jl + jb * 32 + (r & 3) + 8 * (r >> 2));
               if (slot < (uint32_t)SIM_STAGE) lds_write_raw(hist_off + 4u * slot, packed);
               else {                                          // staging buffer full inside one tile: straight to the list (degenerate inputs)
                 const uint32_t g = atomicAdd(&w.sel[3], 1u);
@@ -752,7 +687,7 @@ __global__ __launch_bounds__(256) void agc_window_kernel(const AgcWs* __restrict
 }
 
 // 12-bit histogram (top bits of the 16-bit order-preserving key) of the strict upper triangle of S16 (collect == 0), or, collect == 1, the packed
-// indices (i << 14 | j) of the entries whose bin lies in the band [band[0], band[1]] appended to the list (LDS-staged: one global reservation per
+// indices (i << 16 | j) of the entries whose bin lies in the band [band[0], band[1]] appended to the list (LDS-staged: one global reservation per
 // flush).  Rows are walked with 16-byte loads (8 entries), four in flight per thread.
 constexpr int AGC_STAGE = 4096;
 __global__ __launch_bounds__(256) void agc_sweep16_kernel(const AgcWs* __restrict__ ws, int collect) {
@@ -808,7 +743,7 @@ __global__ __launch_bounds__(256) void agc_sweep16_kernel(const AgcWs* __restric
             if (!collect) atomicAdd(&h[bin], 1u);
             else if (bin >= blo && bin <= bhi) {
               const uint32_t slot = atomicAdd(&nst, 1u);
-              const uint32_t packed = ((uint32_t)i << 14) | (uint32_t)j;
+              const uint32_t packed = ((uint32_t)i << AGC_PK_SHIFT) | (uint32_t)j;
               if (slot < (uint32_t)AGC_STAGE) h[slot] = packed;
               else {                                          // staging buffer full inside one unit: straight to the list (rare)
                 const uint32_t g = atomicAdd(&w.sel[3], 1u);
@@ -819,9 +754,11 @@ __global__ __launch_bounds__(256) void agc_sweep16_kernel(const AgcWs* __restric
         }
       }
     }
-    if (collect) {                                            // between units (uniform for the workgroup): keep room for a dense one
+    if (collect) {                                            // between units: keep room for a dense one.  The decision is taken on ONE value of nst:
+      __syncthreads();                                        // every thread reads it between two barriers (a wave that ran ahead into the next unit
+      const uint32_t cur = nst;                               // would bump it under the others' eyes, and flush() holds barriers)
       __syncthreads();
-      if (nst > (uint32_t)AGC_STAGE / 2) flush();
+      if (cur > (uint32_t)AGC_STAGE / 2) flush();
     }
   }
   if (collect) { flush(); return; }
@@ -836,7 +773,7 @@ __global__ __launch_bounds__(256) void agc_band_kernel(const AgcWs* __restrict__
   const AgcWs& w = ws[blockIdx.y];
   __shared__ uint64_t wsum[4];
   __shared__ int bstar;
-  __shared__ unsigned int s_lo, s_hi;
+  __shared__ unsigned int s_lo, s_hi, s_dmax;
   __shared__ unsigned long long below;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int per = 16;
@@ -849,7 +786,7 @@ __global__ __launch_bounds__(256) void agc_band_kernel(const AgcWs* __restrict__
     if (lane >= o) incl += up;
   }
   if (lane == 63) wsum[wave] = incl;
-  if (t == 0) { s_lo = 4095u; s_hi = 0u; below = 0ull; bstar = 4095; }
+  if (t == 0) { s_lo = 4095u; s_hi = 0u; below = 0ull; bstar = 4095; s_dmax = 0u; }
   __syncthreads();
   for (int q = 0; q < wave; ++q) incl += wsum[q];
   const uint64_t k = (uint64_t)w.sel[1] | ((uint64_t)w.sel[2] << 32);
@@ -863,9 +800,19 @@ __global__ __launch_bounds__(256) void agc_band_kernel(const AgcWs* __restrict__
     }
     bstar = b;
   }
+  {    // dmax = the largest row rounding error of the image (agc_normalize_kernel; positive floats order like their bits)
+    uint32_t m = 0u;
+    for (int i = t; i < w.n; i += 256) { const uint32_t b = (uint32_t)w.deg[i]; m = b > m ? b : m; }
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, o, 64); m = y > m ? y : m; }
+    if (lane == 0) atomicMax(&s_dmax, m);
+  }
   __syncthreads();
   const int bs = bstar;
-  const float lo_val = h16_val((uint32_t)bs << 4) - 2.f * AGC_EPS, hi_val = h16_val(((uint32_t)bs << 4) | 15u) + 2.f * AGC_EPS;
+  // |S16 - exact| <= eps: operand rounding 2 dmax + dmax^2 (Cauchy-Schwarz on unit rows, MEASURED -- subnormal halves counted as flushed),
+  // 256 f32 additions + the final rounding of the exact value (< 6e-5), the stored result rounded to half (|S| < 2: <= 2^-11)
+  const float dmax = __uint_as_float(s_dmax);
+  const float eps = 2.02f * dmax + dmax * dmax + 6e-5f + 0.0005f;
+  const float lo_val = h16_val((uint32_t)bs << 4) - 2.f * eps, hi_val = h16_val(((uint32_t)bs << 4) | 15u) + 2.f * eps;
   // a bin belongs to the band iff its value range [v(b << 4), v(b << 4 | 15)] meets [lo_val, hi_val]; NaN bins (keys past the infinities) never do
   unsigned long long mybelow = 0;
   unsigned int mlo = 4095u, mhi = 0u;
@@ -888,13 +835,16 @@ __global__ __launch_bounds__(256) void agc_band_kernel(const AgcWs* __restrict__
   if (t == 0) {
     const uint64_t r = k - below;
     w.band[0] = blo; w.band[1] = bhi;
+    // the k-th exact value lies within eps of the k-th approximate one, i.e. of bin b*'s range: agc_finish_kernel checks the selected threshold
+    // against [band[2], band[3]] (NaN bounds -- a NaN row -- fail the check)
+    w.band[2] = __float_as_uint(h16_val((uint32_t)bs << 4) - eps); w.band[3] = __float_as_uint(h16_val(((uint32_t)bs << 4) | 15u) + eps);
     w.sel[0] = 0u; w.sel[1] = (uint32_t)r; w.sel[2] = (uint32_t)(r >> 32); w.sel[3] = 0u;
   }
   __syncthreads();
   for (int q = 0; q < per; ++q) w.hist[t * per + q] = 0;
 }
 
-// list[e] = (i << 14 | j)  ->  the order-preserving key of the exact similarity of rows i and j (in place); the same for the radius candidates
+// list[e] = (i << 16 | j)  ->  the order-preserving key of the exact similarity of rows i and j (in place); the same for the radius candidates
 // (clist -> ckey).  Eight lanes per entry.
 __global__ __launch_bounds__(256) void agc_exact_kernel(const AgcWs* __restrict__ ws, int n_images, int window) {
   const int nparts = agc_nparts(n_images);
@@ -908,6 +858,11 @@ __global__ __launch_bounds__(256) void agc_exact_kernel(const AgcWs* __restrict_
     if (!hit) w.counters[7] = 1;
     w.sel[0] = 0u; w.sel[1] = (uint32_t)r; w.sel[2] = (uint32_t)(r >> 32);
   }
+  if (!window && u % nparts == 0 && (blockIdx.x >> 3) == 0 && threadIdx.x == 0) {
+    // robust flow: the rank among the band entries (agc_band_kernel) must fall inside the collected list, and the list must have fitted
+    const uint64_t r = (uint64_t)w.sel[1] | ((uint64_t)w.sel[2] << 32);
+    if (!(r < (uint64_t)w.sel[3]) || w.sel[3] > w.list_cap) w.counters[7] = 1;
+  }
   const uint32_t nl = w.sel[3] < w.list_cap ? w.sel[3] : w.list_cap;
   const uint32_t nc = (uint32_t)w.counters[4] < w.clist_cap ? (uint32_t)w.counters[4] : w.clist_cap;
   const uint32_t nlp = (nl + 31u) & ~31u, total = nlp + ((nc + 31u) & ~31u);       // (whole waves stay in the loop: shuffles)
@@ -918,7 +873,7 @@ __global__ __launch_bounds__(256) void agc_exact_kernel(const AgcWs* __restrict_
     const uint32_t idx = band ? e : e - nlp;
     const bool live = band ? idx < nl : idx < nc;
     const uint32_t pk = live ? (band ? w.list[idx] : w.clist[idx]) : 0u;
-    const int i = (int)(pk >> 14), j = (int)(pk & 0x3fffu);
+    const int i = (int)(pk >> AGC_PK_SHIFT), j = (int)(pk & AGC_PK_MASK);
     const float sim = agc_exact_sim8(w.dnf + (int64_t)i * w.d, w.dnf + (int64_t)j * w.d, w.d, q);
     if (live && q == 0) (band ? w.list : w.ckey)[idx] = f32_key(sim);
   }
@@ -1004,7 +959,7 @@ __global__ __launch_bounds__(288) void agc_radius_grid_kernel(const AgcWs* __res
       if (agc_cell(xj, inv_side) != nx || agc_cell(yj, inv_side) != ny) continue;
       const double ddx = (double)xi - (double)xj, ddy = (double)yi - (double)yj;
       if (!(ddx * ddx + ddy * ddy <= r2)) continue;
-      const uint32_t packed = ((uint32_t)i << 14) | (uint32_t)j;
+      const uint32_t packed = ((uint32_t)i << AGC_PK_SHIFT) | (uint32_t)j;
       const uint32_t slot = atomicAdd(&nst, 1u);
       if (slot < (uint32_t)RAD_STAGE) st[slot] = packed;
       else {
@@ -1021,86 +976,6 @@ __global__ __launch_bounds__(288) void agc_radius_grid_kernel(const AgcWs* __res
     if (gbase + k < w.clist_cap) w.clist[gbase + k] = st[k];
 }
 
-// Radius candidates (agc.py:435-447: ||xi - xj||^2 <= r^2 in float64, inclusive), every unordered pair tested ONCE (j > i) and appended to the
-// candidate list as i << 14 | j; their similarities are evaluated by agc_exact_kernel, agc_apply_kernel sets the adjacency bits of those at or
-// above the threshold.  A wave takes four rows from the top of the matrix and the four mirrored rows from the bottom (together n - 1 tests per
-// mirrored row pair whatever the position: equal work per wave), 64 columns per step, one load of point j serving four row tests; it also clears
-// the adjacency rows it owns.  Candidates are staged in LDS (one global reservation per workgroup).
-__global__ __launch_bounds__(256) void agc_radius_kernel(const AgcWs* __restrict__ ws, double r2) {
-  const AgcWs& w = ws[blockIdx.y];
-  const float* __restrict__ kpts = w.kpts;
-  __shared__ uint32_t st[RAD_STAGE];
-  __shared__ uint32_t nst, gbase;
-  if (threadIdx.x == 0) nst = 0;
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = w.n, v = blockIdx.x * 4 + wave;              // wave v: rows 4v .. 4v+3 and n-4-4v .. n-1-4v (those not already in the first set)
-  const float r2f = (float)(r2 * 1.00002);
-  const bool al8 = ((uintptr_t)kpts & 7) == 0;
-  if (8 * v < n + 7) {
-#pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
-      int rows[ADJ_R];
-      float xif[ADJ_R], yif[ADJ_R];
-      int rmin = n;
-#pragma unroll
-      for (int r = 0; r < ADJ_R; ++r) {
-        // row i belongs to the top set of wave i / 4 and to the bottom set of wave (n - 1 - i) / 4: the smaller wave index owns it (top on a tie)
-        int i = side == 0 ? 4 * v + r : n - 1 - 4 * v - r;
-        if (i < 0 || i >= n) i = -1;
-        else if (side == 0 ? (i / 4 > (n - 1 - i) / 4) : ((n - 1 - i) / 4 >= i / 4)) i = -1;
-        rows[r] = i;
-        const int ic = i >= 0 ? i : 0;
-        xif[r] = kpts[2 * ic];
-        yif[r] = kpts[2 * ic + 1];
-        if (i >= 0) {
-          rmin = i < rmin ? i : rmin;
-          for (int k = lane; k < w.nw; k += 64) w.bits[(int64_t)i * w.nw + k] = 0ull;        // the adjacency row starts empty
-        }
-      }
-      if (rmin >= n) continue;
-      for (int j0 = ((rmin + 1) >> 6) << 6; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        const int jc = j < n ? j : n - 1;
-        float xj, yj;
-        if (al8) { const float2 pj = *(const float2*)(kpts + 2 * jc); xj = pj.x; yj = pj.y; }
-        else { xj = kpts[2 * jc]; yj = kpts[2 * jc + 1]; }
-#pragma unroll
-        for (int r = 0; r < ADJ_R; ++r) {
-          // f32 screen first (relative error of dxf^2 + dyf^2 <= 3e-7, margin 2e-5): only the pairs it cannot rule out take the float64 test that decides
-          const float dxf = xif[r] - xj, dyf = yif[r] - yj;
-          bool pred = false;
-          if (rows[r] >= 0 && j < n && j > rows[r] && !(dxf * dxf + dyf * dyf > r2f)) {
-            const double dx = (double)xif[r] - (double)xj, dy = (double)yif[r] - (double)yj;
-            pred = dx * dx + dy * dy <= r2;
-          }
-          const uint64_t mask = __ballot(pred);
-          if (mask) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&nst, (uint32_t)__popcll(mask));
-            base = __shfl(base, 0, 64);
-            if (pred) {
-              const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-              const uint32_t packed = ((uint32_t)rows[r] << 14) | (uint32_t)j;
-              if (slot < (uint32_t)RAD_STAGE) st[slot] = packed;
-              else {
-                const uint32_t g = atomicAdd((uint32_t*)&w.counters[4], 1u);
-                if (g < w.clist_cap) w.clist[g] = packed;
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const uint32_t cnt = nst < (uint32_t)RAD_STAGE ? nst : (uint32_t)RAD_STAGE;
-  if (threadIdx.x == 0) gbase = cnt ? atomicAdd((uint32_t*)&w.counters[4], cnt) : 0u;
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < cnt; i += 256)
-    if (gbase + i < w.clist_cap) w.clist[gbase + i] = st[i];
-}
-
 // adjacency bits of the candidates whose exact similarity reaches the threshold (the reference tests sim_matrix[i, j] >= thr, agc.py:445-446)
 __global__ __launch_bounds__(256) void agc_apply_kernel(const AgcWs* __restrict__ ws) {
   const AgcWs& w = ws[blockIdx.y];
@@ -1109,77 +984,13 @@ __global__ __launch_bounds__(256) void agc_apply_kernel(const AgcWs* __restrict_
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < nc; e += gridDim.x * 256) {
     if (!(key_f32(w.ckey[e]) >= thr)) continue;
     const uint32_t pk = w.clist[e];
-    const int i = (int)(pk >> 14), j = (int)(pk & 0x3fffu);
+    const int i = (int)(pk >> AGC_PK_SHIFT), j = (int)(pk & AGC_PK_MASK);
     atomicOr((unsigned long long*)&w.bits[(int64_t)i * w.nw + (j >> 6)], 1ull << (j & 63));
     atomicOr((unsigned long long*)&w.bits[(int64_t)j * w.nw + (i >> 6)], 1ull << (i & 63));
   }
 }
 
-// ---------------------------------------------------------------------------------------------- K3 adjacency bits
-// one wave per row i, walking its 64-column words: bit j set iff j != i, ||xi-xj||^2 <= r^2 in float64 (inclusive),
-// and S[min(i,j)][max(i,j)] >= thr  (the reference tests sim_matrix[i,j] with i<j, agc.py:445-446).  (One wave per WORD
-// was 4 M one-shot waves per batch at 4096 keypoints; with the S read inside the column loop every in-radius pair cost the
-// wave a full memory round trip, ~9 per row.)
-__global__ __launch_bounds__(256) void agc_adj_kernel(const AgcWs* __restrict__ ws, double r2) {
-  const AgcWs& w = ws[blockIdx.y];
-  const float* __restrict__ kpts = w.kpts;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i0 = (blockIdx.x * 4 + wave) * ADJ_R;
-  if (i0 >= w.n) return;
-  const float thr = key_f32(w.sel[0]);
-  float xif[ADJ_R], yif[ADJ_R];
-#pragma unroll
-  for (int r = 0; r < ADJ_R; ++r) {
-    const int i = i0 + r < w.n ? i0 + r : w.n - 1;
-    xif[r] = kpts[2 * i];
-    yif[r] = kpts[2 * i + 1];
-  }
-  const float r2f = (float)(r2 * 1.00002);
-  const bool al8 = ((uintptr_t)kpts & 7) == 0;
-  for (int w0 = 0; w0 < w.nw; w0 += 64) {
-    const int wend = w.nw - w0 < 64 ? w.nw - w0 : 64;
-    uint64_t mine[ADJ_R];                       // lane q keeps word w0 + q of each row: one coalesced store per 64 words
-#pragma unroll
-    for (int r = 0; r < ADJ_R; ++r) mine[r] = 0;
-    for (int q = 0; q < wend; ++q) {
-      const int j = (w0 + q) * 64 + lane;
-      const int jc = j < w.n ? j : w.n - 1;
-      float xj, yj;                             // one 8-byte load per lane when the table allows it
-      if (al8) { const float2 pj = *(const float2*)(kpts + 2 * jc); xj = pj.x; yj = pj.y; }
-      else { xj = kpts[2 * jc]; yj = kpts[2 * jc + 1]; }
-#pragma unroll
-      for (int r = 0; r < ADJ_R; ++r) {
-        // f32 screen first (relative error of dxf^2 + dyf^2 <= 3e-7, margin 2e-5): only the pairs it cannot rule out take
-        // the float64 test that decides -- ~99 % of the pairs are far outside the radius
-        const float dxf = xif[r] - xj, dyf = yif[r] - yj;
-        bool pred = false;
-        if (j < w.n && j != i0 + r && !(dxf * dxf + dyf * dyf > r2f)) {
-          const double dx = (double)xif[r] - (double)xj, dy = (double)yif[r] - (double)yj;
-          pred = dx * dx + dy * dy <= r2;
-        }
-        const uint64_t mask = __ballot(pred);
-        if (lane == q) mine[r] = mask;
-      }
-    }
-    // similarity test of the (few) pairs inside the radius
-#pragma unroll
-    for (int r = 0; r < ADJ_R; ++r) {
-      const int i = i0 + r;
-      if (i >= w.n) break;
-      uint64_t cand = mine[r];
-      // lane q walks the candidates of ITS word, so the dependent, scattered reads of S of a row are in flight together
-      while (cand) {
-        const int bit = __ffsll((unsigned long long)cand) - 1;
-        cand &= cand - 1;
-        const int j = (w0 + lane) * 64 + bit;
-        const int a = i < j ? i : j, b = i < j ? j : i;
-        if (!(w.S[(int64_t)a * w.lds + b] >= thr)) mine[r] &= ~(1ull << bit);
-      }
-      if (lane < wend) w.bits[(int64_t)i * w.nw + w0 + lane] = mine[r];
-    }
-  }
-}
-
+// ---------------------------------------------------------------------------------------------- degrees
 __global__ __launch_bounds__(256) void agc_deg_kernel(const AgcWs* __restrict__ ws, int count_total) {
   const AgcWs& w = ws[blockIdx.y];
   int32_t* deg = w.deg;
@@ -1368,19 +1179,25 @@ __global__ __launch_bounds__(256) void agc_fill_kernel(const AgcWs* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------- K5 components
-// single workgroup; LDS: parent[n], count[n]
+// single workgroup; parent[n], count[n] in LDS -- or, GLOBAL (images of more than AGC_CC_LDS_N nodes), in the members / nnc arrays, which are free
+// until the linking step: every access to them is then a device-scope atomic or a volatile access (the workgroup's L1 is never trusted)
+template <bool GLOBAL>
 __global__ __launch_bounds__(1024) void agc_cc_kernel(const AgcWs* __restrict__ ws, int min_size) {
   const AgcWs& w = ws[blockIdx.y];
   int32_t* __restrict__ kept = w.kept;
   int32_t* info = w.info;
   extern __shared__ int32_t sm[];
-  int32_t* parent = sm;
-  int32_t* count = sm + w.n;
+  int32_t* parent = GLOBAL ? w.members : sm;
+  int32_t* count = GLOBAL ? w.nnc : sm + w.n;
+  auto cnt_of = [&](int x) { return __hip_atomic_load(&count[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   __shared__ int wsum[16];
   __shared__ int carry[2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n = w.n;
-  for (int u = t; u < n; u += 1024) { parent[u] = u; count[u] = 0; }
+  for (int u = t; u < n; u += 1024) {
+    __hip_atomic_store(&parent[u], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&count[u], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
   volatile int32_t* vp = parent;
   auto find = [&](int x) {
@@ -1436,7 +1253,7 @@ __global__ __launch_bounds__(1024) void agc_cc_kernel(const AgcWs* __restrict__ 
     bool al = false, root = false;
     if (u < n) {
       const int l = w.label[u];
-      al = count[l] >= min_size;
+      al = cnt_of(l) >= min_size;
       root = al && l == u;
       w.alive[u] = al ? 1 : 0;
     }
@@ -1463,7 +1280,7 @@ __global__ __launch_bounds__(1024) void agc_cc_kernel(const AgcWs* __restrict__ 
   // component offsets (size of each alive component, in rank order)
   for (int u = t; u < n; u += 1024) {
     const int r = w.crank[u];
-    if (r >= 0) w.coff[r] = count[u];   // temporarily sizes
+    if (r >= 0) w.coff[r] = cnt_of(u);   // temporarily sizes
   }
   if (t == 0) {
     info[0] = carry[0];
@@ -1474,7 +1291,8 @@ __global__ __launch_bounds__(1024) void agc_cc_kernel(const AgcWs* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------- K6 linking
 // members of each alive component in ascending node order + float64 centroid (one wave per component)
-__global__ __launch_bounds__(256) void agc_members_kernel(const AgcWs* __restrict__ ws) {
+template <int NWV>      // waves per workgroup: 4 up to 16384 nodes, 8 above (a wave's share is at most 64 chunks of 64 nodes: one mask word)
+__global__ __launch_bounds__(64 * NWV) void agc_members_kernel(const AgcWs* __restrict__ ws) {
   const AgcWs& w = ws[blockIdx.y];
   const float* __restrict__ kpts = w.kpts;
   const int32_t* __restrict__ coff = w.coff2;
@@ -1484,9 +1302,9 @@ __global__ __launch_bounds__(256) void agc_members_kernel(const AgcWs* __restric
   // each -- a single wave walking all nodes with three dependent loads per chunk (alive -> label -> rank) was 67 us of pure latency per image.
   // Pass 1 finds the members of the quarter (kept as one bit per chunk and lane) and counts them, the counts give every wave its offset, pass 2
   // writes the members in ascending order and sums their coordinates in float64.
-  __shared__ int wcnt[4];
-  __shared__ double part[4][2];
-  const int per = ((w.n + 3) / 4 + 63) & ~63;                 // nodes per wave, a multiple of 64 (<= 4096: at most 64 chunks)
+  __shared__ int wcnt[NWV];
+  __shared__ double part[NWV][2];
+  const int per = ((w.n + NWV - 1) / NWV + 63) & ~63;         // nodes per wave, a multiple of 64 (<= 4096: at most 64 chunks)
   const int u0 = wave * per, u1 = (u0 + per < w.n) ? u0 + per : w.n;
   for (int c = blockIdx.x; c < C; c += gridDim.x) {
     uint64_t mine = 0;                                         // bit k: node u0 + 64 k + lane belongs to component c
@@ -1511,7 +1329,9 @@ __global__ __launch_bounds__(256) void agc_members_kernel(const AgcWs* __restric
     __syncthreads();
     int off = coff[c];
     for (int q = 0; q < wave; ++q) off += wcnt[q];
-    const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) total += wcnt[q];
     double sx = 0.0, sy = 0.0;
     for (int base = u0, k = 0; base < u1; base += 64, ++k) {
       const bool mem = (mine >> k) & 1ull;
@@ -1529,8 +1349,11 @@ __global__ __launch_bounds__(256) void agc_members_kernel(const AgcWs* __restric
     if (lane == 0) { part[wave][0] = sx; part[wave][1] = sy; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      w.cent[2 * c] = (((part[0][0] + part[1][0]) + part[2][0]) + part[3][0]) / (double)total;
-      w.cent[2 * c + 1] = (((part[0][1] + part[1][1]) + part[2][1]) + part[3][1]) / (double)total;
+      double sx4 = part[0][0], sy4 = part[0][1];          // left to right
+#pragma unroll
+      for (int q = 1; q < NWV; ++q) { sx4 += part[q][0]; sy4 += part[q][1]; }
+      w.cent[2 * c] = sx4 / (double)total;
+      w.cent[2 * c + 1] = sy4 / (double)total;
     }
     __syncthreads();
   }
@@ -1635,13 +1458,16 @@ __global__ void agc_finish_kernel(const AgcWs* __restrict__ ws, int window) {
   info[2] = w.counters[0] / 2;
   info[6] = (int32_t)__float_as_uint(key_f32(w.sel[0]));
   info[7] = (info[1] > max_edges_dir || w.counters[0] > w.cap || w.counters[2] > w.cap) ? 1 : 0;
-  if (w.clist && (uint32_t)w.counters[4] > w.clist_cap) {       // more radius candidates than the list holds: like an edge overflow (the caller
+  if ((uint32_t)w.counters[4] > w.clist_cap) {       // more radius candidates than the list holds: like an edge overflow (the caller
     info[7] = 1;                                                // repeats the build with larger buffers), sized from the candidate count
     info[2] = w.counters[4];
   }
   if (window) {       // the window was a prediction (agc_window_kernel): the threshold it produced stands only if the window provably held rank k
     const float thr = key_f32(w.sel[0]), vL = __uint_as_float(w.band[0]), vU = __uint_as_float(w.band[1]), eps = __uint_as_float(w.band[2]);
     if (w.counters[7] || !(thr >= vL + eps && thr <= vU - eps)) info[7] |= 2;
+  } else {            // robust flow: the same post-check against the measured error bound (agc_band_kernel); a failure here is an error, not a retry
+    const float thr = key_f32(w.sel[0]);
+    if (w.counters[7] || !(thr >= __uint_as_float(w.band[2]) && thr <= __uint_as_float(w.band[3]))) info[7] |= 2;
   }
 }
 
@@ -1662,41 +1488,27 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // at least 64 directed edges per node): a caller that sees the overflow flag repeats the build with larger output buffers.
 constexpr int AGC_MIN_CAP_PER_NODE = 64;
 
-static bool agc_sim_x6() {
-  static const int v = [] { const char* e = getenv("GIMS_SIM_PREC"); return (e && !strcmp(e, "f32")) ? 0 : 1; }();
-  return v != 0;
-}
-// GIMS_AGC_EXACT_S=1: every similarity at f32-GEMM accuracy and the select over the whole matrix (the flow of rounds 1-3), else band-limited
-static bool agc_exact_s() {
-  const char* e = getenv("GIMS_AGC_EXACT_S");           // read per call: the tests switch flows
-  return e && atoi(e) != 0;
-}
-
-static size_t agc_layout(int n, int d, int max_edges_dir, bool exact_s, char* base, AgcWs* w) {
-  const int lds = (n + 3) & ~3, nw = (n + 63) / 64, lds16 = (n + 7) & ~7;
+static size_t agc_layout(int n, int d, int max_edges_dir, char* base, AgcWs* w) {
+  const int nw = (n + 63) / 64, lds16 = (n + 7) & ~7;
   const int cap = max_edges_dir > n * AGC_MIN_CAP_PER_NODE ? max_edges_dir : n * AGC_MIN_CAP_PER_NODE;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return base ? base + o : (char*)nullptr; };
   char* p;
-  // descriptors: [n][d] f32 followed by [n][d] half (band-limited flow), or the SPL3 / f32 operand of the exact-S GEMM -- 6 n d bytes either way
+  // descriptors: [n][d] f32 followed by [n][d] half
   p = take((size_t)n * d * 6);
-  if (w) {
-    w->dn = (float*)p; w->dnf = (float*)p;
-    w->dn16 = exact_s ? nullptr : (uint16_t*)(p + (size_t)n * d * 4);
-    w->dn3 = (exact_s && d % 32 == 0 && agc_sim_x6()) ? (uint16_t*)p : nullptr;
-  }
-  // similarities: f32 [n][lds] (exact-S flow), or half [n][lds16] followed by the band list (one u32 per pair of the strict upper triangle at most)
+  if (w) { w->dnf = (float*)p; w->dn16 = (uint16_t*)(p + (size_t)n * d * 4); }
+  // approximate similarities in half [n][lds16] (robust flow only: the window flow never stores them), the radius candidates and their keys, and the
+  // band list (one u32 per pair of the strict upper triangle at most)
   const size_t list_cap = (size_t)n * (n - 1) / 2 + 64;
   const size_t s16_bytes = al256((size_t)n * lds16 * 2), cl_bytes = al256((size_t)cap * 4);
-  p = take(exact_s ? (size_t)n * lds * 4 : s16_bytes + 2 * cl_bytes + list_cap * 4);
+  p = take(s16_bytes + 2 * cl_bytes + list_cap * 4);
   if (w) {
-    w->S = exact_s ? (float*)p : nullptr;
-    w->S16 = exact_s ? nullptr : (uint16_t*)p;
-    w->clist = exact_s ? nullptr : (uint32_t*)(p + s16_bytes);
-    w->ckey = exact_s ? nullptr : (uint32_t*)(p + s16_bytes + cl_bytes);
-    w->list = exact_s ? nullptr : (uint32_t*)(p + s16_bytes + 2 * cl_bytes);
-    w->list_cap = exact_s ? 0u : (uint32_t)list_cap;
-    w->clist_cap = exact_s ? 0u : (uint32_t)cap;
+    w->S16 = (uint16_t*)p;
+    w->clist = (uint32_t*)(p + s16_bytes);
+    w->ckey = (uint32_t*)(p + s16_bytes + cl_bytes);
+    w->list = (uint32_t*)(p + s16_bytes + 2 * cl_bytes);
+    w->list_cap = (uint32_t)list_cap;
+    w->clist_cap = (uint32_t)cap;
     w->lds16 = lds16;
   }
   p = take((size_t)(AGC_NB + 1) * 4); if (w) w->cellptr = (int32_t*)p;
@@ -1722,13 +1534,11 @@ static size_t agc_layout(int n, int d, int max_edges_dir, bool exact_s, char* ba
   p = take(64); if (w) w->counters = (int32_t*)p;
   p = take((size_t)(n + 1) * 4); if (w) w->coff2 = (int32_t*)p;
   p = take((size_t)n * 4); if (w) w->degk = (int32_t*)p;
-  if (w) { w->n = n; w->d = d; w->lds = lds; w->nw = nw; w->cap = cap; }
+  if (w) { w->n = n; w->d = d; w->nw = nw; w->cap = cap; }
   return off;
 }
 
-static size_t agc_batch_header(int n_images) {
-  return al256(sizeof(AgcWs) * (size_t)n_images) + al256(sizeof(gims_linear_args) * (size_t)n_images);
-}
+static size_t agc_batch_header(int n_images) { return al256(sizeof(AgcWs) * (size_t)n_images); }
 
 }  // namespace gims
 
@@ -1736,13 +1546,11 @@ extern "C" size_t gims_agc_workspace_bytes(const gims_agc_image* images, int32_t
   using namespace gims;
   if (!images || n_images <= 0) return 0;
   size_t b = agc_batch_header(n_images);
-  for (int i = 0; i < n_images; ++i) {        // (the flow is read from the environment per call: room for either)
-    const size_t a = agc_layout(images[i].n, images[i].d, images[i].max_edges_dir, false, nullptr, nullptr);
-    const size_t e = agc_layout(images[i].n, images[i].d, images[i].max_edges_dir, true, nullptr, nullptr);
-    b += a > e ? a : e;
-  }
+  for (int i = 0; i < n_images; ++i) b += agc_layout(images[i].n, images[i].d, images[i].max_edges_dir, nullptr, nullptr);
   return b;
 }
+
+extern "C" int32_t gims_agc_max_keypoints(void) { return gims::AGC_MAX_N; }
 
 extern "C" int gims_agc_build(const gims_agc_image* images, int32_t n_images, double radius, double percentile,
                               int32_t min_size, void* work, size_t work_bytes, void* stream) {
@@ -1761,27 +1569,19 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
   GIMS_CHECK_ARG(work_bytes >= gims_agc_workspace_bytes(images, n_images), "gims_agc_build: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   AgcWs* dws = (AgcWs*)work;
-  gims_linear_args* dla = (gims_linear_args*)((char*)work + al256(sizeof(AgcWs) * (size_t)n_images));
   char* base = (char*)work + agc_batch_header(n_images);
   int maxn = 0, maxnw = 0;
-  bool all_x6 = true;
-  const bool exact_s = agc_exact_s();
-  GIMS_LDS_ATTR((const void*)agc_cc_kernel, AGC_MAX_N * 8);
+  GIMS_LDS_ATTR((const void*)agc_cc_kernel<false>, AGC_CC_LDS_N * 8);
   GIMS_LDS_ATTR((const void*)agc_iso_seq_kernel, AGC_MAX_N * 4 + (AGC_MAX_N / 32 + 2) * 4);
   std::vector<AgcWs> hws(n_images);
-  std::vector<gims_linear_args> hla(n_images);
   for (int i = 0; i < n_images; ++i) {
     const gims_agc_image& im = images[i];
     GIMS_CHECK_ARG(im.kpts && im.desc && im.kept && im.indptr && im.indices && im.info, "gims_agc_build: image %d has a null pointer", i);
-    GIMS_CHECK_ARG(im.n >= 2 && im.n <= AGC_MAX_N, "gims_agc_build: image %d: n=%d out of range [2, %d]", i, im.n, AGC_MAX_N);
-    static_assert(AGC_MAX_N <= (1 << 14), "the band list packs a pair as i << 14 | j");
+    GIMS_CHECK_ARG(im.n >= 2 && im.n <= AGC_MAX_N, "gims_agc_build: image %d: n=%d out of range [2, %d] (gims_agc_max_keypoints)", i, im.n, AGC_MAX_N);
+    static_assert(AGC_MAX_N <= (1 << AGC_PK_SHIFT), "the band list packs a pair as i << 16 | j");
     GIMS_CHECK_ARG(im.d > 0 && (im.d % 32) == 0 && (im.ldd % 4) == 0, "gims_agc_build: image %d: d=%d must be a multiple of 32 (ldd %% 4 == 0)", i, im.d);
     AgcWs* w = &hws[i];
-    {
-      const size_t a = agc_layout(im.n, im.d, im.max_edges_dir, false, nullptr, nullptr), e = agc_layout(im.n, im.d, im.max_edges_dir, true, nullptr, nullptr);
-      agc_layout(im.n, im.d, im.max_edges_dir, exact_s, base, w);
-      base += a > e ? a : e;
-    }
+    base += agc_layout(im.n, im.d, im.max_edges_dir, base, w);
     w->kpts = im.kpts; w->desc = im.desc; w->ldd = im.ldd; w->kept = im.kept; w->indptr = im.indptr; w->indices = im.indices;
     w->info = im.info; w->max_edges_dir = im.max_edges_dir;
     // K2 rank: k = int(L * p / 100), clamped (agc.py:378-379)
@@ -1790,48 +1590,20 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
     if (k >= L) k = L - 1;
     if (k < 0) k = 0;
     w->krank = k;
-    // K1 GEMM descriptor: S = Dn Dn^T in exact f32
-    gims_linear_args la = {};
-    // (GIMS_PREC_BF16X6: three-way split operands, six bf16 MFMAs per product -- f32-GEMM accuracy at 6/16 of the exact-f32
-    // MFMA cost; GIMS_SIM_PREC=f32 in the environment selects the exact-f32 MFMA kernel)
-    const bool x6 = w->dn3 != nullptr;
-    all_x6 = all_x6 && x6;
-    la.a0 = x6 ? (const float*)w->dn3 : w->dn; la.lda0 = x6 ? 3 * im.d : im.d; la.w = la.a0; la.ldw = la.lda0; la.out_f32 = w->S; la.ldc = w->lds;
-    la.m = im.n; la.n = im.n; la.k = im.d; la.k0 = im.d; la.act = GIMS_ACT_NONE; la.precision = x6 ? GIMS_PREC_BF16X6 : GIMS_PREC_F32; la.scale = 1.f;
-    la.flags = GIMS_LINEAR_UPPER;    // only S[i][j], i < j, is ever read (threshold select and edge test)
-    hla[i] = la;
-    if (im.d % SW_KC != 0 || im.d > SW_KMAX) robust = true;       // (the window kernels keep a tile row's whole K in LDS)
+    if (im.d % SW_KC != 0 || im.d > SW_KMAX) robust = true;       // (the window kernels keep a tile row's whole K in registers)
     maxn = im.n > maxn ? im.n : maxn;
     maxnw = w->nw > maxnw ? w->nw : maxnw;
   }
   const int B = n_images;
   {
-    int rc = upload_table(hws.data(), sizeof(AgcWs) * (size_t)B, dws, s);
-    if (rc != GIMS_OK) return rc;
-    rc = upload_table(hla.data(), sizeof(gims_linear_args) * (size_t)B, dla, s);
+    const int rc = upload_table(hws.data(), sizeof(AgcWs) * (size_t)B, dws, s);
     if (rc != GIMS_OK) return rc;
     hipLaunchKernelGGL(agc_init_kernel, dim3(1, B), dim3(256), 0, s, dws);
   }
   const dim3 gw(cdiv(maxn, 4), B), g1(1, B);
   // K1
   hipLaunchKernelGGL(agc_normalize_kernel, gw, dim3(256), 0, s, dws);
-  int rc = GIMS_OK;
-  // ~4096 workgroups in total: each folds its LDS histogram into the global one with 256 atomics, so one workgroup per
-  // ROW (65 536 workgroups at 64 images x 1024 rows) spent most of the pass on those 16 M global atomics
-  int hgrid = 4096 / (B > 0 ? B : 1);
-  hgrid = hgrid < 16 ? 16 : (hgrid > 1024 ? 1024 : hgrid);
-  hgrid = hgrid < maxn ? hgrid : maxn;
-  if (exact_s) {
-    rc = gims_linear_batch(dla, B, maxn, maxn, all_x6 ? GIMS_PREC_BF16X6 : GIMS_PREC_F32, stream);
-    if (rc != GIMS_OK) return rc;
-    // K2
-    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 20, 12, 0);
-    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 20, 12);
-    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 8, 12, 1);
-    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 8, 12);
-    hipLaunchKernelGGL(agc_hist_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 0, 8, 2);
-    hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 0, 8);
-  } else {
+  {
     const int T = cdiv(maxn, S16_T), ntiles = T * (T + 1) / 2;
     if (robust) {
       // approximate matrix (half, one MFMA pass, every entry histogrammed) -> bracket of the k-th value -> band entries
@@ -1839,6 +1611,10 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
       // two workgroups per CU, the images dealt to the XCDs (agc_nparts); a small batch of small images takes fewer workgroups
       const int nparts = 8 / (((B & -B) > 8) ? 8 : (B & -B)), per_xcd = cdiv(B * nparts, 8) * cdiv(ntiles, nparts);
       const int sgrid = 8 * (per_xcd < 2 * (device_cus() / 8) ? per_xcd : 2 * (device_cus() / 8));
+      // ~4096 workgroups in total for the sweep: each folds its LDS staging buffer into the global list
+      int hgrid = 4096 / B;
+      hgrid = hgrid < 16 ? 16 : (hgrid > 1024 ? 1024 : hgrid);
+      hgrid = hgrid < maxn ? hgrid : maxn;
       hipLaunchKernelGGL(agc_sim16_kernel, dim3(sgrid), dim3(256), S16_LDS_BYTES, s, dws, B);
       hipLaunchKernelGGL(agc_band_kernel, g1, dim3(256), 0, s, dws);
       hipLaunchKernelGGL(agc_sweep16_kernel, dim3(hgrid, B), dim3(256), 0, s, dws, 1);
@@ -1852,30 +1628,25 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
       hipLaunchKernelGGL(agc_window_kernel, g1, dim3(256), 0, s, dws, window_test_shift);
       hipLaunchKernelGGL(agc_simw_kernel<SIM_COLLECT>, dim3(wgrid), dim3(256), SW_LDS_BYTES, s, dws, B);
     }
-    // radius candidates: through the keypoint grid; all pairs for a radius that gives no usable cell side (GIMS_AGC_GRID=0: always all pairs)
-    const char* env_grid = getenv("GIMS_AGC_GRID");           // (read per call: the tests compare the two searches)
-    const bool no_grid = env_grid && atoi(env_grid) == 0;
-    const double side = radius * 1.001;
-    if (!no_grid && side > 1e-3 && side < 1e12) {
-      GIMS_LDS_ATTR((const void*)agc_grid_kernel, AGC_NB * 4);
-      hipLaunchKernelGGL(agc_grid_kernel, g1, dim3(1024), AGC_NB * 4, s, dws, 1.0 / side);
-      hipLaunchKernelGGL(agc_radius_grid_kernel, dim3(cdiv(maxn, 32), B), dim3(288), 0, s, dws, radius * radius, 1.0 / side);
-    } else {
-      hipLaunchKernelGGL(agc_radius_kernel, dim3(cdiv(cdiv(maxn, 2), 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
-    }
+    // radius candidates through the keypoint grid.  Cell side 1.001 |r|, never below 1e-3 (a larger cell only costs tests); an infinite radius
+    // puts every point into one cell (every pair is tested: what the predicate asks for), a NaN radius keeps no pair (agc.py:443: d2 <= r2 is False)
+    double side = fabs(radius) * 1.001;
+    if (!(side >= 1e-3)) side = 1e-3;
+    GIMS_LDS_ATTR((const void*)agc_grid_kernel, AGC_NB * 4);
+    hipLaunchKernelGGL(agc_grid_kernel, g1, dim3(1024), AGC_NB * 4, s, dws, 1.0 / side);
+    hipLaunchKernelGGL(agc_radius_grid_kernel, dim3(cdiv(maxn, 32), B), dim3(288), 0, s, dws, radius * radius, 1.0 / side);
     // the exact values of the listed entries and of the radius candidates, then the exact k-th among the former
     hipLaunchKernelGGL(agc_exact_kernel, dim3(8 * 4 * (device_cus() / 8)), dim3(256), 0, s, dws, B, robust ? 0 : 1);
     const int lgrid = 1024 / B < 4 ? 4 : (1024 / B > 64 ? 64 : 1024 / B);
-    hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 20, 12, 2);
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 20, 12);
     hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 20, 12);
-    hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 8, 12, 2);
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 8, 12);
     hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 8, 12);
-    hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 0, 8, 2);
+    hipLaunchKernelGGL(agc_hist_kernel, dim3(lgrid, B), dim3(256), 0, s, dws, 0, 8);
     hipLaunchKernelGGL(agc_pick_kernel, g1, dim3(256), 0, s, dws, 0, 8);
   }
   // K3
-  if (exact_s) hipLaunchKernelGGL(agc_adj_kernel, dim3(cdiv(maxn, 4 * ADJ_R), B), dim3(256), 0, s, dws, radius * radius);
-  else hipLaunchKernelGGL(agc_apply_kernel, dim3(16, B), dim3(256), 0, s, dws);
+  hipLaunchKernelGGL(agc_apply_kernel, dim3(16, B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_deg_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 1);
   // K4
   hipLaunchKernelGGL(agc_iso_nn_kernel, gw, dim3(256), 0, s, dws);
@@ -1886,10 +1657,12 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 0);
   hipLaunchKernelGGL(agc_fill_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 0);
   // K5
-  hipLaunchKernelGGL(agc_cc_kernel, g1, dim3(1024), (size_t)maxn * 8, s, dws, min_size);
+  if (maxn <= AGC_CC_LDS_N) hipLaunchKernelGGL(agc_cc_kernel<false>, g1, dim3(1024), (size_t)maxn * 8, s, dws, min_size);
+  else hipLaunchKernelGGL(agc_cc_kernel<true>, g1, dim3(1024), 0, s, dws, min_size);
   // K6: component sizes -> offsets; members, centroids, nearest component, links
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 1);
-  hipLaunchKernelGGL(agc_members_kernel, dim3(32, B), dim3(256), 0, s, dws);
+  if (maxn <= 16384) hipLaunchKernelGGL(agc_members_kernel<4>, dim3(32, B), dim3(256), 0, s, dws);
+  else hipLaunchKernelGGL(agc_members_kernel<8>, dim3(32, B), dim3(512), 0, s, dws);
   hipLaunchKernelGGL(agc_nnc_kernel, gw, dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_link_kernel, dim3(maxn < 256 ? maxn : 256, B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_link_apply_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
@@ -1898,7 +1671,7 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
   hipLaunchKernelGGL(agc_kept_deg_kernel, dim3(cdiv(maxn, 256), B), dim3(256), 0, s, dws);
   hipLaunchKernelGGL(agc_scan_kernel, g1, dim3(1024), 0, s, dws, 2);
   hipLaunchKernelGGL(agc_fill_kernel, dim3(cdiv(maxn, 16), B), dim3(256), 0, s, dws, 1);
-  hipLaunchKernelGGL(agc_finish_kernel, g1, dim3(1), 0, s, dws, (!exact_s && !robust) ? 1 : 0);
+  hipLaunchKernelGGL(agc_finish_kernel, g1, dim3(1), 0, s, dws, robust ? 0 : 1);
   GIMS_LAUNCH_CHECK();
   return GIMS_OK;
 }

@@ -737,7 +737,11 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
     int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
-    unsigned long long* __restrict__ stat) {
+    unsigned long long* __restrict__ stat, gims_attn_guard guard) {
+  if (guard.stat) {          // guarded launch (include/gims_hip.h): the redo of a layer whose cheap tier did not suffice -- or nothing
+    if (!attn_guard_fires(guard)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) guard.stat[4 * guard.n_heads + 3] = 1ull;
+  }
   extern __shared__ __attribute__((aligned(16))) uint16_t x3_lds[];
   // [plane p = hi/lo][buffer]: K tiles then V^T tiles
   auto Ks = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + (p * 2 + buf) * (KB * DH); };
@@ -942,7 +946,11 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
     int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
-    unsigned long long* __restrict__ stat) {
+    unsigned long long* __restrict__ stat, gims_attn_guard guard) {
+  if (guard.stat) {          // guarded launch: see attention_x3_kernel
+    if (!attn_guard_fires(guard)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) guard.stat[4 * guard.n_heads + 3] = 1ull;
+  }
   constexpr int X3W_QW = QW * X3W_QP, X3W_QB = X3W_QW * ATT_WAVES;
   extern __shared__ __attribute__((aligned(16))) uint16_t x3_lds[];
   auto Ks = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + (p * 2 + buf) * (KB * DH); };
@@ -1616,6 +1624,27 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
                                    const gims_attn_problem* problems, int32_t n_problems, int32_t max_n_q,
                                    int32_t n_heads, float* out, int64_t ld_out, uint16_t* out_hi, uint16_t* out_lo,
                                    int64_t ld_split, int32_t flags, uint64_t* stat_u64, void* stream) {
+  gims_attn_args a = {};
+  a.qkv = qkv; a.ld = ld; a.q_col = q_col; a.k_col = k_col; a.v_col = v_col; a.problems = problems; a.n_problems = n_problems; a.max_n_q = max_n_q;
+  a.n_heads = n_heads; a.out = out; a.ld_out = ld_out; a.out_hi = out_hi; a.out_lo = out_lo; a.ld_split = ld_split; a.flags = flags; a.stat = stat_u64;
+  return gims_attention_ex(&a, stream);
+}
+
+extern "C" int gims_attention_ex(const gims_attn_args* args, void* stream) {
+  GIMS_CHECK_ARG(args, "gims_attention_ex: null arguments");
+  const uint16_t* qkv = args->qkv;
+  const int64_t ld = args->ld, ld_out = args->ld_out, ld_split = args->ld_split;
+  const int32_t q_col = args->q_col, k_col = args->k_col, v_col = args->v_col, n_problems = args->n_problems, max_n_q = args->max_n_q, n_heads = args->n_heads,
+                flags = args->flags;
+  const gims_attn_problem* problems = args->problems;
+  float* out = args->out;
+  uint16_t* out_hi = args->out_hi;
+  uint16_t* out_lo = args->out_lo;
+  uint64_t* stat_u64 = args->stat;
+  const gims_attn_guard guard = args->guard;
+  GIMS_CHECK_ARG(!guard.stat || ((flags & GIMS_ATTN_X3) && !stat_u64 && (guard.kind == GIMS_GUARD_PEAKED || guard.kind == GIMS_GUARD_RANGE) &&
+                                 guard.n_heads > 0 && guard.n_heads <= 64 && (((uintptr_t)guard.stat) & 7) == 0),
+                 "gims_attention_ex: a guard goes with GIMS_ATTN_X3, without a statistic of its own, kind GIMS_GUARD_*, 8-byte aligned stat");
   using namespace gims;
   GIMS_CHECK_ARG((((uintptr_t)stat_u64) & 7) == 0, "gims_attention_stat: stat must be 8-byte aligned");
   unsigned long long* stat = (unsigned long long*)stat_u64;
@@ -1656,16 +1685,16 @@ extern "C" int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_co
       const int qp = wide == 2 ? 2 : 4, n_qtw = cdiv(max_n_q, qp * QB);
       if (qp == 4)
         hipLaunchKernelGGL(attention_x3w_kernel<4>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat);
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard);
       else
         hipLaunchKernelGGL(attention_x3w_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat);
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard);
       GIMS_LAUNCH_CHECK();
       return GIMS_OK;
     }
     const int n_qt = cdiv(max_n_q, QB);
     hipLaunchKernelGGL(attention_x3_kernel, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard);
     GIMS_LAUNCH_CHECK();
     return GIMS_OK;
   }

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int m0 = ((slot / nt_n) * 8 + xcd) * TM, n0 = (slot % nt_n) * TN;
   if (m0 >= p.m) return;
+  if (p.guard.stat && !attn_guard_fires(p.guard)) return;      // guarded launch (uniform for the grid): nothing to redo
   // probe (tools/gemm_probe.py): flag 0x1000 starts the workgroups of the odd slots conv_reserved x 3.4 us late, so that the
   // HBM-bound epilogues of one half of the CUs fall into the L2-bound K loops of the other half
   if ((p.flags & 0x1000) && (slot & 1))
@@ -602,6 +603,9 @@ static int linear_validate(const gims_linear_args* a) {
   GIMS_CHECK_ARG(a->k0 == a->k || a->a1 != nullptr, "gims_linear: second A segment missing");
   GIMS_CHECK_ARG(a->out_f32 || a->out_bf16 || a->out_hi, "gims_linear: no output");
   GIMS_CHECK_ARG((a->out_hi == nullptr) == (a->out_lo == nullptr), "gims_linear: out_hi and out_lo come together");
+  GIMS_CHECK_ARG(!a->guard.stat || (a->a0_lo && (a->guard.kind == GIMS_GUARD_PEAKED || a->guard.kind == GIMS_GUARD_RANGE) && a->guard.n_heads > 0 &&
+                                    a->guard.n_heads <= 64 && (((uintptr_t)a->guard.stat) & 7) == 0),
+                 "gims_linear: a guard goes with pre-split operands, kind GIMS_GUARD_*, 8-byte aligned stat");
   if (a->precision == GIMS_PREC_BF16X6) {   // SPL3 operands, batched launches only: C = scale * A W^T, f32 out
     GIMS_CHECK_ARG((a->k % 32) == 0 && a->k0 == a->k, "gims_linear(bf16x6): K=%d must be a multiple of 32, one A segment", a->k);
     GIMS_CHECK_ARG(a->lda0 >= 3 * (int64_t)a->k && a->ldw >= 3 * (int64_t)a->k && (a->lda0 % 8) == 0 && (a->ldw % 8) == 0,

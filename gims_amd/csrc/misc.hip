@@ -304,9 +304,7 @@ extern "C" int gims_run_ops(const gims_op* ops, int32_t n_ops, void* stream) {
     if (ops[i].kind == GIMS_OP_LINEAR) {
       rc = gims_linear(&ops[i].u.lin, stream);
     } else if (ops[i].kind == GIMS_OP_ATTENTION) {
-      const gims_attn_args& a = ops[i].u.att;
-      rc = gims_attention_stat(a.qkv, a.ld, a.q_col, a.k_col, a.v_col, a.problems, a.n_problems, a.max_n_q, a.n_heads, a.out, a.ld_out, a.out_hi,
-                               a.out_lo, a.ld_split, a.flags, a.stat, stream);
+      rc = gims_attention_ex(&ops[i].u.att, stream);
     } else {
       GIMS_CHECK_ARG(false, "gims_run_ops: op %d has unknown kind %d", i, ops[i].kind);
     }

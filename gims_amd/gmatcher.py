@@ -102,13 +102,19 @@ class GMatcher(nn.Module):
         # one-hot rows among diffuse ones), and max |Q|, |K|, |V| as stored.  The first batch after the weights change runs every
         # layer at 'bf16x3' and measures; from then on a layer runs in plain bf16 while every head stays below
         # `attention_auto_threshold` (mean) and `attention_auto_tail` (fraction), in half above that while its operands stay
-        # below `attention_f16_range` (half's finite range is 65504), else at 'bf16x3'.  Every `attention_monitor_period`-th batch
-        # is measured again and a layer only ever moves UP (bf16 -> f16 -> bf16x3), for good.
+        # below `attention_f16_range` (half's finite range is 65504), else at 'bf16x3'.  EVERY batch is measured (round 5;
+        # `attention_monitor_period` = 1) and the verdict is drawn ON THE DEVICE inside the same batch: behind every bf16 / half
+        # attention launch of the table sit two GUARDED launches (gims_attn_guard) -- the 3-pass Q/K/V projection and the
+        # split-bf16 attention of that layer -- that do nothing unless the statistic the cheap launch just produced is over the
+        # thresholds (bf16 layer: peaked; half layer: out of range), and otherwise REDO the layer at f32-class accuracy before the
+        # MLP consumes the message.  So the results of a batch never carry the cheap tier's error of a layer that sharpened on
+        # THAT batch; the host reads the same statistic behind the next synchronisation and moves the layer up for good
+        # (bf16 -> f16 -> bf16x3), after which the redo no longer fires.  Cost when nothing fires: 36 empty launches per batch.
         'attention_precision': 'auto',
         'attention_auto_threshold': 0.08,
         'attention_auto_tail': 0.02,
         'attention_f16_range': 3.0e4,
-        'attention_monitor_period': 8,
+        'attention_monitor_period': 1,
         'train_precision': 'bf16x6',      # products of the training step (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
         'verbose': False,               # the reference prints '>> ...' timing lines; off by default here
         # fold the attention 'merge' conv into the first MLP conv at load time:
@@ -328,7 +334,7 @@ class GMatcher(nn.Module):
         if st is None or st["gen"] != P["gen"]:      # new weights: measure every layer at the accurate precision first
             st = self.__dict__["_attn_auto"] = dict(gen=P["gen"], mode=[2] * L, calibrated=False, peak=np.zeros((L, self._heads)),
                                                     peak_max=np.zeros((L, self._heads)), tail=np.zeros((L, self._heads)),
-                                                    range=np.zeros((L, 3)), switched=[], batches={})
+                                                    range=np.zeros((L, 3)), switched=[], batches={}, redone=np.zeros(L, dtype=np.int64))
         n_b = st["batches"][self._lane] = st["batches"].get(self._lane, -1) + 1
         if st["calibrated"] and n_b % max(1, int(self.config['attention_monitor_period'])) != 0:
             return list(st["mode"]), None              # not a measured batch
@@ -372,6 +378,7 @@ class GMatcher(nn.Module):
             st["tail"] = np.where(seen, tail, st["tail"])
             st["peak_max"] = np.maximum(st["peak_max"], np.where(seen, host[:, :, 2] / hip.ATTN_STAT_SCALE, 0.0))
             st["range"] = np.maximum(st["range"], np.where(np.isfinite(rng), rng, np.inf))
+            st["redone"] += (raw[:, H, 3] != 0)          # layers the device redid at split-bf16 inside that batch (guarded launches)
             hot = (mean > float(self.config['attention_auto_threshold'])).any(axis=1) | (tail > float(self.config['attention_auto_tail'])).any(axis=1)
             wide = (st["range"] > float(self.config['attention_f16_range'])).any(axis=1)
             want = np.where(hot, np.where(wide, 2, 1), 0)
@@ -384,6 +391,14 @@ class GMatcher(nn.Module):
                     st["mode"][l] = int(want[l])
                     st["switched"].append(int(l))
 
+    def _keep_attention_tiers(self, device):
+        """TEST HOOK: carry the settled per-layer tier table over a change of the weights (which normally starts a new calibration), so that a
+        test can hand a model whose layers all sit on plain bf16 a batch whose attention is peaked -- the situation the device-side redo exists
+        for (a trained model meeting an input that sharpens a layer)."""
+        st = self.__dict__.get("_attn_auto")
+        assert st is not None and st["calibrated"], "settle the model first"
+        st["gen"] = self._packed(device)["gen"]
+
     def attention_report(self):
         """What 'auto' decided: per layer 'bf16' / 'f16' / 'bf16x3', the last measured peakedness (mean row maximum) and tail
         fraction (row maximum above 1/2) per (layer, head), max |Q|, |K|, |V| per layer, layers moved up after the first measurement.
@@ -394,6 +409,7 @@ class GMatcher(nn.Module):
             return None
         return dict(modes=[self._MODE_NAMES[v] for v in st["mode"]], calibrated=st["calibrated"], peak=st["peak"].copy(),
                     peak_max=st["peak_max"].copy(), tail=st["tail"].copy(), range=st["range"].copy(), switched=list(st["switched"]),
+                    redone=st["redone"].copy(),
                     threshold=float(self.config['attention_auto_threshold']), tail_threshold=float(self.config['attention_auto_tail']))
 
     # ------------------------------------------------------------------ stage timing (HIP events on the launch stream)
@@ -558,6 +574,7 @@ class GMatcher(nn.Module):
             if cap > 16384 or cap <= self._edge_cap:
                 raise hip.GimsHipError(f"adaptive graph exceeded the edge capacity ({self._edge_cap} directed edges per node) and cannot grow further")
             self._edge_cap = cap
+            ctx["params"] = tuple(ctx["params"][:3]) + (bool(ctx.get("robust")),)      # a robust build stays robust when it is repeated for room
             return None
         if (infos[:, 0] == 0).any():
             raise ValueError("need at least one array to concatenate")               # np.vstack([]) in agc.py:701
@@ -669,6 +686,7 @@ class GMatcher(nn.Module):
         # per-layer choice of the attention kernel family (0 bf16, 1 half, 2 split-bf16) and, in 'auto' mode, the accumulator its
         # statistic goes to
         amode, stat = self._attention_modes(P, dev)
+        st_calibrated = bool(self.__dict__.get("_attn_auto", {}).get("calibrated"))
         ax3 = [a == 2 for a in amode]
         # bf16 / half attention: Q|K|V as one 16-bit buffer [rows][768] (a layer writes and reads it in its own format); x3 attention:
         # the same three matrices as SPL32 hi/lo planes
@@ -679,6 +697,17 @@ class GMatcher(nn.Module):
         qkv_out_of = lambda l: (dict(out_split=qkv_s) if amode[l] == 2 else                                 # noqa: E731
                                 dict(out_bf16=qkv_b, flags=hip.LINEAR_OUT_F16) if amode[l] == 1 else dict(out_bf16=qkv_b, flags=self._qkv_flags))
         stat_of = lambda l: None if stat is None else stat[l]                                               # noqa: E731
+        # the device-side verdict of 'auto' (see default_config): the guard of layer l's redo launches, None for a layer that needs none
+        guarded = stat is not None and cfg['attention_precision'] == 'auto' and st_calibrated
+        if guarded and qkv_s is None:
+            qkv_s = self._act("qkv6", n_tot, 6 * D, torch.bfloat16)
+
+        def guard_of(l):
+            if not guarded or amode[l] == 2:
+                return None
+            if amode[l] == 0:
+                return hip.attn_guard(stat[l], hip.GUARD_PEAKED, self._heads, mean_thr=cfg['attention_auto_threshold'], tail_thr=cfg['attention_auto_tail'])
+            return hip.attn_guard(stat[l], hip.GUARD_RANGE, self._heads, range_limit=cfg['attention_f16_range'])
         sfx = lambda l: ("", "_f16", "_x3")[amode[l]]      # stage-timer labels tell the attention kernels apart       # noqa: E731
         if x3:
             # all GEMM operands travel as split-bf16 SPL32 buffers written by the producing kernel's epilogue; only the
@@ -694,6 +723,7 @@ class GMatcher(nn.Module):
                 key = (P["gen"], n_tot, max_nq, dpl.data_ptr(), mpl.data_ptr(), hpl.data_ptr(), desc.data_ptr(),
                        0 if qkv_b is None else qkv_b.data_ptr(), 0 if qkv_s is None else qkv_s.data_ptr(),
                        0 if stat is None else stat.data_ptr(),
+                       (float(cfg['attention_auto_threshold']), float(cfg['attention_auto_tail']), float(cfg['attention_f16_range'])) if guarded else None,
                        self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags, tuple(amode))
                 cache = self.__dict__.setdefault("_ops_cache", {})
                 ops = cache.get(key)
@@ -705,6 +735,11 @@ class GMatcher(nn.Module):
                         lst.append(la(L["qkv"], dpl, **qkv_out_of(l)))
                         lst.append(hip.op_attention(qkv_of(l), cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D,
                                                     out_split=mpl, q_prescaled=True, x3=ax3[l], f16=amode[l] == 1, stat=stat_of(l)))
+                        gd = guard_of(l)
+                        if gd is not None:      # the redo of this layer at split-bf16, launched always, executed only when the guard fires
+                            lst.append(la(L["qkv"], dpl, out_split=qkv_s, guard=gd))
+                            lst.append(hip.op_attention(qkv_s, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D,
+                                                        out_split=mpl, q_prescaled=True, x3=True, guard=gd))
                         lst.append(la(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl, flags=self._msg_flags))
                         lst.append(la(L["mlp1"], hpl, residual=desc, out=desc, out_split=dpl))
                     if len(cache) > 8:
@@ -712,7 +747,8 @@ class GMatcher(nn.Module):
                     # table, HIP graph, uses, and references to every tensor whose address is baked into the table
                     ops = cache[key] = [hip.make_ops(lst), None, 0, (P, dpl, mpl, hpl, desc, qkv_b, qkv_s, stat, self_pr, cross_pr),
                                         [lab for l, L in enumerate(P["layers"])
-                                         for lab in ("qkv" + sfx(l), ("attn_cross" if L["cross"] else "attn_self") + sfx(l), "mlp", "mlp")]]
+                                         for lab in (("qkv" + sfx(l), ("attn_cross" if L["cross"] else "attn_self") + sfx(l))
+                                                     + (("guard", "guard") if guard_of(l) is not None else ()) + ("mlp", "mlp"))]]
                 # first use: plain replay (first-use initialisation inside the library); from the second use on a non-default
                 # stream, if GIMS_OPS_GRAPH=1: ONE graph launch
                 ops[2] += 1
@@ -732,6 +768,12 @@ class GMatcher(nn.Module):
                 with St(("attn_cross" if L["cross"] else "attn_self") + sfx(l)):
                     hip.attention(qkv_of(l), cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl,
                                   q_prescaled=True, x3=ax3[l], f16=amode[l] == 1, stat=stat_of(l))
+                gd = guard_of(l)
+                if gd is not None:
+                    with St("guard"):
+                        self._lin(L["qkv"], dpl, out_split=qkv_s, guard=gd)
+                        hip.attention(qkv_s, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl,
+                                      q_prescaled=True, x3=True, guard=gd)
                 with St("mlp"):
                     if ln:        # LayerNorm between the two MLP convs: hidden activations in f32, normalised + split by the norm kernel
                         if hid_ln is None:
@@ -970,6 +1012,11 @@ class GMatcher(nn.Module):
                 raise ValueError("match_pairs takes single-pair dicts (B == 1)")
         d0 = datas[0]
         params = (d0.get('radius', 25), d0.get('percentile', 7), d0.get('min_size', 8))
+        for i, data in enumerate(datas):        # one graph-build launch serves the whole batch: its parameters are the batch's
+            if (data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)) != params:
+                raise ValueError(f"match_pairs: pair {i} asks for radius / percentile / min_size = "
+                                 f"{(data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8))}, pair 0 for {params}; "
+                                 "all pairs of one call share the adaptive-graph parameters (call match_pairs once per setting)")
         cur = torch.cuda.current_stream()
         if n_lanes > 1:
             # independent sub-batches on separate HIP streams: the HBM-bound stages of one lane (Sinkhorn, epilogues) overlap

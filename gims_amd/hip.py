@@ -27,6 +27,20 @@ class GimsHipError(RuntimeError):
     pass
 
 
+class AttnGuard(C.Structure):
+    """gims_attn_guard (include/gims_hip.h): a launch that only runs when the statistic of the launch before it asks for the redo."""
+    _fields_ = [("stat", C.c_void_p), ("mean_thr", C.c_double), ("tail_thr", C.c_double), ("range_limit", C.c_double),
+                ("n_heads", C.c_int32), ("kind", C.c_int32)]
+
+
+GUARD_PEAKED, GUARD_RANGE = 1, 2
+
+
+def attn_guard(stat, kind, n_heads, mean_thr=0.0, tail_thr=0.0, range_limit=0.0) -> AttnGuard:
+    assert stat.dtype == torch.int64 and stat.is_cuda and stat.is_contiguous() and stat.numel() >= 4 * (n_heads + 1)
+    return AttnGuard(stat.data_ptr(), float(mean_thr), float(tail_thr), float(range_limit), int(n_heads), int(kind))
+
+
 class LinearArgs(C.Structure):
     _fields_ = [("a0", C.c_void_p), ("lda0", C.c_int64), ("a1", C.c_void_p), ("lda1", C.c_int64),
                 ("w", C.c_void_p), ("w_lo", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
@@ -35,14 +49,15 @@ class LinearArgs(C.Structure):
                 ("k", C.c_int32), ("k0", C.c_int32), ("act", C.c_int32), ("precision", C.c_int32),
                 ("scale", C.c_float), ("a0_lo", C.c_void_p), ("a1_lo", C.c_void_p), ("out_hi", C.c_void_p),
                 ("out_lo", C.c_void_p), ("ld_split", C.c_int64), ("flags", C.c_int32),
-                ("conv_h", C.c_int32), ("conv_w", C.c_int32), ("conv_stride", C.c_int32), ("conv_reserved", C.c_int32)]
+                ("conv_h", C.c_int32), ("conv_w", C.c_int32), ("conv_stride", C.c_int32), ("conv_reserved", C.c_int32),
+                ("guard", AttnGuard)]
 
 
 class AttnArgs(C.Structure):
     _fields_ = [("qkv", C.c_void_p), ("ld", C.c_int64), ("q_col", C.c_int32), ("k_col", C.c_int32), ("v_col", C.c_int32),
                 ("problems", C.c_void_p), ("n_problems", C.c_int32), ("max_n_q", C.c_int32), ("n_heads", C.c_int32),
                 ("out", C.c_void_p), ("ld_out", C.c_int64), ("out_hi", C.c_void_p), ("out_lo", C.c_void_p),
-                ("ld_split", C.c_int64), ("flags", C.c_int32), ("stat", C.c_void_p)]
+                ("ld_split", C.c_int64), ("flags", C.c_int32), ("stat", C.c_void_p), ("guard", AttnGuard)]
 
 
 class _OpU(C.Union):
@@ -157,6 +172,7 @@ _SIGNATURES = {
     "gims_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_int32, C.c_void_p]),
+    "gims_attention_ex": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gims_attention_stat": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int32, C.c_void_p, C.c_void_p]),
@@ -174,6 +190,7 @@ _SIGNATURES = {
     "gims_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
     "gims_agc_workspace_bytes": (C.c_size_t, [C.POINTER(AgcImage), C.c_int32]),
+    "gims_agc_max_keypoints": (C.c_int32, []),
     "gims_agc_build": (C.c_int, [C.POINTER(AgcImage), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
     "gims_agc_build_ex": (C.c_int, [C.POINTER(AgcImage), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p,
@@ -252,6 +269,9 @@ def load(path: str | None = None):
     if path is None:
         _lib = lib
     return lib
+
+
+GIMS_OK, GIMS_EINVAL, GIMS_EHIP, GIMS_ENUMERIC = 0, -1, -2, -3          # include/gims_hip.h
 
 
 def _check(rc: int, what: str):
@@ -340,7 +360,7 @@ def _dev(t: torch.Tensor, dtype=None):
 
 
 def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
-                precision=PREC_F32, scale=1.0, n=None, spl=False, out_split=None, flags=0, conv=None, m=None):
+                precision=PREC_F32, scale=1.0, n=None, spl=False, out_split=None, flags=0, conv=None, m=None, guard=None):
     """Build the C struct.
     spl=False: a0/a1 f32 [m,k*]; w f32 [n,K] (PREC_F32) or bf16 hi plane with w_lo (PREC_BF16X3).
     spl=True : a0/a1/w are SPL32 bf16 buffers [rows, 2*k] (see include/gims_hip.h), precision BF16X3.
@@ -386,7 +406,8 @@ def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None
                       out.stride(0) if out is not None else 0, _p(out_bf16),
                       out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale),
                       _p(a0_lo), _p(a1_lo), _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
-                      out_split.stride(0) if out_split is not None else 0, int(flags), 0, 0, 0, 0)
+                      out_split.stride(0) if out_split is not None else 0, int(flags), 0, 0, 0, 0,
+                      guard if guard is not None else AttnGuard())
 
 
 def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):
@@ -436,12 +457,13 @@ def _attn_flags(q_prescaled, x3, f16):
 
 
 def op_attention(qkv, problems, max_n_q, n_heads, out=None, q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False,
-                 stat=None, f16=False) -> Op:
+                 stat=None, f16=False, guard=None) -> Op:
     o = Op()
     o.kind = 1
     o.u.att = AttnArgs(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0], max_n_q, n_heads, _p(out),
                        out.stride(0) if out is not None else 0, _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
-                       out_split.stride(0) if out_split is not None else 0, _attn_flags(q_prescaled, x3, f16), _p(stat))
+                       out_split.stride(0) if out_split is not None else 0, _attn_flags(q_prescaled, x3, f16), _p(stat),
+                       guard if guard is not None else AttnGuard())
     return o
 
 
@@ -539,7 +561,7 @@ ATTN_STAT_SCALE = float(1 << 24)       # fixed point of the row maxima in gims_a
 
 
 def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: int, out=None,
-              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False, stat=None, f16=False):
+              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False, stat=None, f16=False, guard=None):
     """qkv bf16 [rows, ld]; problems int32 [P,4] (q_off, n_q, kv_off, n_kv) on device; out f32 [rows, ld_out]
     and/or out_split = SPL32 bf16 buffer [rows, >= 512].  q_prescaled: Q already carries ATTN_Q_SCALE.
     x3: qkv is the SPL32 split-bf16 buffer [rows, >= 1536] of the 3-pass projection (GIMS_ATTN_X3).
@@ -550,6 +572,10 @@ def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: 
     assert qkv.dtype == torch.bfloat16 and problems.dtype == torch.int32 and problems.is_cuda
     if stat is not None:
         assert stat.dtype == torch.int64 and stat.is_contiguous() and stat.numel() >= 4 * (n_heads + 1) and stat.is_cuda
+    if guard is not None:       # guarded launch (x3 only): a no-op unless the guard's statistic asks for the redo
+        op = op_attention(qkv, problems, max_n_q, n_heads, out, q_col, k_col, v_col, out_split, q_prescaled, x3, stat, f16, guard)
+        _check(lib.gims_attention_ex(C.byref(op.u.att), _stream()), "gims_attention_ex")
+        return out if out is not None else out_split
     _check(lib.gims_attention_stat(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0],
                                    max_n_q, n_heads, _p(out), out.stride(0) if out is not None else 0, _p(out_split),
                                    (out_split.data_ptr() + 64) if out_split is not None else None,
@@ -629,7 +655,16 @@ def make_agc_images(items):
     return arr
 
 
+def agc_max_keypoints() -> int:
+    """Largest image the graph build takes (32768; include/gims_hip.h says what bounds it)."""
+    return int(load().gims_agc_max_keypoints())
+
+
 def agc_workspace_bytes(images) -> int:
+    nmax = max(int(im.n) for im in images)
+    if nmax > agc_max_keypoints():
+        raise GimsHipError(f"adaptive graph: an image has {nmax} keypoints, more than the library's limit of {agc_max_keypoints()} per image "
+                           "(gims_agc_max_keypoints; the reference has none) -- reduce max_keypoints or split the image")
     return int(load().gims_agc_workspace_bytes(images, len(images)))
 
 
@@ -733,7 +768,7 @@ def sinkhorn_rescues() -> int:
     """On-chip solves of this process that gave up and were re-solved by a rescue path on the current device (synchronises)."""
     n = int(load().gims_sinkhorn_rescues())
     if n < 0:
-        _check(GIMS_EHIP if "GIMS_EHIP" in globals() else 2, "gims_sinkhorn_rescues")
+        _check(GIMS_EHIP, "gims_sinkhorn_rescues")
     return n
 
 

@@ -130,6 +130,46 @@ def make_pair(n: int, seed: int, canvas=None, pos_noise=0.5, desc_noise=0.03, ou
     }
 
 
+def make_pair_unbalanced(n0: int, n1: int, n_common: int, seed: int, canvas=None, pos_noise=0.5, desc_noise=0.03):
+    """An UNBALANCED pair (n0 != n1) in the same layout as make_pair: image 1 holds the partners of ``n_common`` of image 0's keypoints
+    (position and descriptor noise as in make_pair) plus ``n1 - n_common`` fresh outliers, in a shuffled order; the other
+    ``n0 - n_common`` keypoints of image 0 have no partner.  The shape of a real pair: the reference's README run has 15 382 / 14 870
+    keypoints (README.md:143-163).  gt_perm[i] = index in image 1 of keypoint i's partner, or -1."""
+    assert 0 <= n_common <= min(n0, n1)
+    w, h = canvas if canvas is not None else canvas_for(max(n0, n1))
+    xy0 = np.stack([uniform(seed, 1, n0) * w, uniform(seed, 2, n0) * h], axis=1).astype(np.float32)
+    d0 = _l2n(normal(seed, 3, n0 * 128).reshape(n0, 128))
+    s0 = uniform(seed, 4, n0).astype(np.float32)
+    common = permutation(seed, 5, n0)[:n_common]               # image-0 keypoints that reappear
+    slots = permutation(seed, 9, n1)                           # image-1 slots: the first n_common take the partners, the rest outliers
+    xy1 = np.empty((n1, 2), dtype=np.float64)
+    d1 = np.empty((n1, 128), dtype=np.float64)
+    xy1[slots[:n_common]] = xy0[common].astype(np.float64) + pos_noise * normal(seed, 6, 2 * n_common).reshape(n_common, 2)
+    d1[slots[:n_common]] = d0[common].astype(np.float64) + desc_noise * normal(seed, 7, n_common * 128).reshape(n_common, 128)
+    n_out = n1 - n_common
+    xy1[slots[n_common:]] = np.stack([uniform(seed, 10, n_out) * w, uniform(seed, 11, n_out) * h], axis=1)
+    d1[slots[n_common:]] = normal(seed, 12, n_out * 128).reshape(n_out, 128)
+    xy1[:, 0] = np.clip(xy1[:, 0], 0.0, float(w))
+    xy1[:, 1] = np.clip(xy1[:, 1], 0.0, float(h))
+    xy1 = xy1.astype(np.float32)
+    d1 = _l2n(d1)
+    s1 = uniform(seed, 8, n1).astype(np.float32)
+    gt = -np.ones(n0, dtype=np.int64)
+    gt[common] = slots[:n_common]
+
+    def dup(d):  # (N,128) -> (1,256,N)
+        return np.ascontiguousarray(np.concatenate([d, d], axis=1).T[None]).astype(np.float32)
+
+    return {
+        "keypoints0": xy0[None].copy(), "keypoints1": xy1[None].copy(),
+        "descriptors0": dup(d0), "descriptors1": dup(d1),
+        "scores0": s0[None].copy(), "scores1": s1[None].copy(),
+        "image0": np.zeros((1, h, w, 3), dtype=np.uint8),
+        "image1": np.zeros((1, h, w, 3), dtype=np.uint8),
+        "gt_perm": gt,
+    }
+
+
 # ----------------------------------------------------------------------------- weights
 
 GAINS = {"kenc": 0.5, "gnn_encoder": 3.0, "gnn": 0.3, "final_proj": 1.0}

@@ -65,6 +65,23 @@ int gims_upload_table(const void* host, int64_t bytes, void* dev, void* stream);
 #define GIMS_ACT_NONE 0
 #define GIMS_ACT_RELU 1
 
+/* Device-side guard of a launch (attention_precision='auto' of the host shell: a layer that ran on cheap operands is REDONE at f32-class accuracy
+ * inside the same batch when the statistic of the cheap launch says the operands did not suffice -- no host round trip, so the results of a
+ * batch never leave with the cheap tier's error).  A launch whose args carry a guard with stat != NULL is a no-op unless the guard FIRES; every
+ * workgroup evaluates it at entry from `stat`, the accumulator a preceding gims_attention_stat launch of the same stream filled:
+ *   GIMS_GUARD_PEAKED: some head's mean row maximum (stat[h][0] / stat[h][1] / 2^24) exceeds mean_thr, or its share of rows with a maximum above
+ *                      1/2 (stat[h][3] / stat[h][1]) exceeds tail_thr                              (guards a plain-bf16 attention layer);
+ *   GIMS_GUARD_RANGE : max |Q|, |K| or |V| as stored (stat[n_heads][0..2]) exceeds range_limit, or is not finite   (guards an IEEE-half layer).
+ * A guarded gims_attention launch that fires stores 1 into stat[n_heads][3] (the host's record that the layer was redone).  The comparisons
+ * are done in float64 exactly as written here, so a host that reads `stat` back reaches the same verdict.  stat == NULL: unconditional. */
+#define GIMS_GUARD_PEAKED 1
+#define GIMS_GUARD_RANGE 2
+typedef struct gims_attn_guard {
+  uint64_t* stat;                        /* [n_heads + 1][4], see gims_attention_stat; NULL = no guard */
+  double mean_thr, tail_thr, range_limit;
+  int32_t n_heads, kind;                 /* GIMS_GUARD_* */
+} gims_attn_guard;
+
 typedef struct gims_linear_args {
   const float* a0; int64_t lda0;
   const float* a1; int64_t lda1;       /* may be NULL when k0 == K */
@@ -93,6 +110,7 @@ typedef struct gims_linear_args {
    * grid, and K block (tap, c0..c0+31) of its operand row is read straight from input pixel
    * (yo*stride + ky - 1, xo*stride + kx - 1), or from the 128 zero bytes at a1 when that lies outside: no im2col buffer. */
   int32_t conv_h, conv_w, conv_stride, conv_reserved;
+  gims_attn_guard guard;               /* pre-split operands (a0_lo != NULL) only: the launch is a no-op unless the guard fires; zero = always run */
 } gims_linear_args;
 #define GIMS_LINEAR_UPPER 1
   /* GIMS_LINEAR_HI_ONLY (pre-split operands): multiply the hi planes only -- a plain bf16 product (2^-9 relative per
@@ -170,6 +188,10 @@ int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t 
                         uint16_t* out_hi /* may be NULL */, uint16_t* out_lo, int64_t ld_split, int32_t flags,
                         uint64_t* stat /* device, may be NULL */, void* stream);
 
+/* gims_attention_stat with its arguments in a struct, plus the guard (see gims_attn_guard): what an op of gims_run_ops executes. */
+struct gims_attn_args;
+int gims_attention_ex(const struct gims_attn_args* args, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * A recorded sequence of launches replayed by ONE call: the 18 layers of AttentionalGNN.forward (gmatcher.py:127-143) are
  * 72 launches whose arguments only change when the batch geometry does, and a caller in an interpreted language pays for
@@ -181,6 +203,7 @@ typedef struct gims_attn_args {
   const gims_attn_problem* problems; int32_t n_problems, max_n_q, n_heads;
   float* out; int64_t ld_out; uint16_t* out_hi; uint16_t* out_lo; int64_t ld_split; int32_t flags;
   uint64_t* stat;                      /* gims_attention_stat's peakedness accumulator, or NULL */
+  gims_attn_guard guard;               /* GIMS_ATTN_X3 launches only: no-op unless the guard fires; zero = always run */
 } gims_attn_args;
 #define GIMS_OP_LINEAR 0
 #define GIMS_OP_ATTENTION 1
@@ -263,6 +286,11 @@ int gims_gather_rows(const float* src, int64_t lds, const int32_t* idx, int32_t 
  * n_components_after_removal, n_link_added, threshold bits (f32), flags: bit 0 = an edge / candidate buffer overflowed (repeat with a larger
  * max_edges_dir), bit 1 = see gims_agc_build_ex}.
  * `work` is scratch of at least gims_agc_workspace_bytes(images, n_images) bytes.
+ * LIMIT: 2 <= n <= gims_agc_max_keypoints() = 32768 keypoints per image (GIMS_EINVAL above it; the reference -- NumPy / SciPy -- has no
+ * limit and publishes runs with up to 21 163 kept keypoints, tools/files/rgbd1/record.txt:635).  What bounds it: a pair of node ids is one
+ * packed 32-bit word (i << 16 | j), the sequential isolated-node walk keeps its ordered list in LDS (135 KB of 160 KB at 32768), and the
+ * workspace reserves one word per pair of the strict upper triangle (n^2 * 2 bytes: 0.9 GB per image at 21 163, 2.1 GB at 32768).  Images
+ * above 16384 keypoints run the component search in global memory instead of LDS (same labels).
  * Exact-distance ties in the two sequential fix-ups resolve to the lowest node index.
  * Asynchronous; read info[] after synchronising the stream.
  */
@@ -272,6 +300,7 @@ typedef struct gims_agc_image {
 } gims_agc_image;
 
 size_t gims_agc_workspace_bytes(const gims_agc_image* h_images /* HOST array */, int32_t n_images);
+int32_t gims_agc_max_keypoints(void);
 int gims_agc_build(const gims_agc_image* h_images /* HOST array */, int32_t n_images, double radius, double percentile,
                    int32_t min_size, void* work, size_t work_bytes, void* stream);
 /* The same with flags.  The percentile threshold is exact in both flows (the k-th smallest of the similarities as the library evaluates

@@ -313,6 +313,62 @@ def test_attention_f16_reference_follows_late_spikes(hip, monkeypatch, kernel):
     assert err.max() < 3e-3, f"worst row {int(err.argmax())}: {err.max():.3e}"
 
 
+@pytest.mark.parametrize("kind", ["peaked", "range"])
+@pytest.mark.parametrize("sharp", [1.0, 6.0])
+def test_attention_guarded_redo(hip, kind, sharp):
+    """gims_attn_guard: a launch that runs only when the statistic of the launch before it asks for it (the device-side verdict of
+    attention_precision='auto').  A cheap attention launch (bf16 for the PEAKED guard, IEEE half for the RANGE guard) fills the statistic; the
+    guarded 3-pass projection and the guarded split-bf16 attention behind it must then either leave their outputs untouched (sentinel intact,
+    stat[H][3] == 0) or produce exactly what the unguarded launches produce (and set stat[H][3] = 1) -- and which of the two must be what the
+    host derives from the same statistic with the header's arithmetic."""
+    r = _rng(77)
+    nq, nk, H = 520, 900, 4
+    rows = nq + nk
+    x = r.normal(size=(rows, 256)).astype(np.float32)
+    w = (r.normal(size=(768, 256)) / 16.0).astype(np.float32)
+    w[:512] *= sharp                                              # larger query / key projections: peaked softmax rows, wider operands
+    xs, ws = hip.split_spl32(_dev(x)), hip.split_spl32(_dev(w))
+    pr = torch.tensor([(0, nq, nq, nk)], dtype=torch.int32, device="cuda")
+    stat = torch.zeros((H + 1, 4), dtype=torch.int64, device="cuda")
+    qkv16 = torch.empty((rows, 768), dtype=torch.bfloat16, device="cuda")
+    msg = torch.zeros((rows, 512), dtype=torch.bfloat16, device="cuda")
+    f16 = kind == "range"
+    hip.linear(xs, ws, out_bf16=qkv16, precision=hip.PREC_BF16X3, spl=True, flags=hip.LINEAR_OUT_F16 if f16 else hip.LINEAR_HI_ONLY)
+    hip.attention(qkv16, pr, nq, H, None, out_split=msg, f16=f16, stat=stat)
+    st = stat.cpu().numpy()
+    mean = st[:H, 0] / np.maximum(st[:H, 1], 1) / hip.ATTN_STAT_SCALE
+    tail = st[:H, 3] / np.maximum(st[:H, 1], 1)
+    rng = st[H, :3].astype(np.uint32).view(np.float32)
+    if kind == "peaked":
+        thr = dict(mean_thr=0.08, tail_thr=0.02)
+        expect = bool((mean > 0.08).any() or (tail > 0.02).any())
+        guard = hip.attn_guard(stat, hip.GUARD_PEAKED, H, **thr)
+    else:
+        limit = 12.0                                              # (between the operand ranges of the two cases: about 5 and about 30)
+        expect = bool((rng > limit).any())
+        guard = hip.attn_guard(stat, hip.GUARD_RANGE, H, range_limit=limit)
+    assert expect == (sharp > 1.0), (mean, tail, rng)
+    sentinel = 0x7fc0                                             # bf16 NaN pattern
+    qkv6 = torch.full((rows, 1536), sentinel, dtype=torch.int16, device="cuda").view(torch.bfloat16)
+    msg_g = msg.clone()
+    hip.linear(xs, ws, out_split=qkv6, precision=hip.PREC_BF16X3, spl=True, guard=guard)
+    if not expect:
+        assert (qkv6.view(torch.int16) == sentinel).all()
+    hip.attention(qkv6, pr, nq, H, None, out_split=msg_g, x3=True, guard=guard)
+    st2 = stat.cpu().numpy()
+    assert int(st2[H, 3]) == int(expect) and (st2[:H] == st[:H]).all() and (st2[H, :3] == st[H, :3]).all()
+    if not expect:
+        assert torch.equal(msg_g.view(torch.int16), msg.view(torch.int16))            # the cheap tier's message stands
+        return
+    ref6 = torch.empty((rows, 1536), dtype=torch.bfloat16, device="cuda")
+    ref_msg = torch.zeros((rows, 512), dtype=torch.bfloat16, device="cuda")
+    hip.linear(xs, ws, out_split=ref6, precision=hip.PREC_BF16X3, spl=True)
+    hip.attention(ref6, pr, nq, H, None, out_split=ref_msg, x3=True)
+    assert torch.equal(qkv6.view(torch.int16), ref6.view(torch.int16))
+    assert torch.equal(msg_g.view(torch.int16)[:nq], ref_msg.view(torch.int16)[:nq])
+    assert not torch.equal(msg_g.view(torch.int16)[:nq], msg.view(torch.int16)[:nq])      # ... and it is not the cheap tier's
+
+
 @pytest.mark.parametrize("kernel", ["4wave", "4wave2", "8", "split", "split4", "x3", "x3w2", "x3w4", "4wave2_f16", "8_f16", "split_f16"])
 @pytest.mark.parametrize("sharp", [1.0, 4.0])
 def test_attention_peak_statistic(hip, monkeypatch, kernel, sharp):
@@ -875,14 +931,39 @@ def test_agc_vs_reference_golden(hip, name):
             assert (np.diff(row) > 0).all()
 
 
+def _agc_definition(kp, de, rad, pct):
+    """The band-limited flow's own definition, on the host: similarities = f32(dot in float64, in the summation order of agc_exact_sim8) of the f32
+    rows normalised in f32; threshold = k-th smallest over the strict upper triangle (agc.py:378-380); radius pairs in float64, inclusive."""
+    n = de.shape[0]
+    x = de.astype(np.float32)
+    dn = (x / np.maximum(np.sqrt(np.sum(x * x, axis=1, dtype=np.float32)), np.float32(1e-12))[:, None]).astype(np.float32)
+    part = []
+    for q in range(8):
+        acc = np.zeros((n, n))
+        for k in range(4 * q, 256, 32):
+            for e in range(4):
+                col = dn[:, k + e].astype(np.float64)
+                acc = acc + col[:, None] * col[None, :]               # (products of two f32 are exact in float64: this IS the fma chain)
+        part.append(acc)
+    sim = (((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]))).astype(np.float32)
+    iu = np.triu_indices(n, 1)
+    vals = np.sort(sim[iu])
+    kk = min(max(int(len(vals) * pct / 100.0), 0), len(vals) - 1)
+    d2 = ((kp[:, None, :].astype(np.float64) - kp[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    return sim[iu], vals[kk], (d2 <= float(rad) ** 2)[iu]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["random_700", "n1000_p50", "duplicates", "n130", "n4100"])
-def test_agc_band_limited_flow_equals_exact_flow(hip, monkeypatch, case):
-    """Round 4: the graph build forms the N x N similarity matrix only APPROXIMATELY (IEEE half, one MFMA pass) and re-evaluates exactly (f32
-    operands, float64 accumulation) the entries inside a rigorous error band around the percentile threshold and the radius candidates.
-    Against the earlier flow (GIMS_AGC_EXACT_S=1: every similarity at f32-GEMM accuracy, select over the whole matrix): the threshold agrees to
-    f32 rounding of the two evaluators (1e-6), and kept ids, CSR and the stage counters are identical.  Cases: sizes that are no multiple of the
-    128-wide tile, the median as percentile (the band sits where the density is highest), and descriptors with many exact duplicates (similarities
-    pile up at 1.0: the band holds thousands of equal values and the rank inside it decides)."""
+def test_agc_window_flow_equals_robust_flow_and_its_definition(hip, monkeypatch, case):
+    """The graph build forms the N x N similarity matrix only APPROXIMATELY (IEEE half, one MFMA pass) and re-evaluates exactly (f32 operands,
+    float64 accumulation) the entries inside an error band around the percentile threshold and the radius candidates.  The default flow (a window
+    predicted from a sample, verified on the device) and the robust one (every entry histogrammed, band from the measured error bound, verified on
+    the device as well) are the same function of the inputs, bit for bit; and both equal the flow's definition evaluated on the host.  Cases: sizes
+    that are no multiple of the 128-wide tile, the median as percentile (the band sits where the density is highest), and descriptors with many
+    exact duplicates (similarities pile up at 1.0: the band holds thousands of equal values and the rank inside it decides).  (Until round 4 a
+    third flow -- every similarity at f32-GEMM accuracy -- lived in the library as the cross-check; the reference goldens and the oracle
+    (test_agc_vs_reference_golden, test_agc_odd_sizes_vs_oracle) have that role now.)"""
     r = _rng(23)
     if case == "random_700":
         n, rad, pct, ms = 700, 14, 5, 5
@@ -900,66 +981,41 @@ def test_agc_band_limited_flow_equals_exact_flow(hip, monkeypatch, case):
     if case == "duplicates":
         de[100:400] = de[r.integers(0, 8, size=300)]             # 300 rows drawn from 8 prototypes: ~ 5 600 pairs with similarity 1
     outs = {}
-    for flow, env in (("exact", "GIMS_AGC_EXACT_S"), ("window", None), ("robust", "GIMS_AGC_ROBUST")):
-        for name in ("GIMS_AGC_EXACT_S", "GIMS_AGC_ROBUST"):
-            monkeypatch.delenv(name, raising=False)
+    for flow, env in (("window", None), ("robust", "GIMS_AGC_ROBUST")):
+        monkeypatch.delenv("GIMS_AGC_ROBUST", raising=False)
         if env:
             monkeypatch.setenv(env, "1")
         outs[flow] = _run_agc(hip, kp, de, rad, pct, ms)
-    # the default flow (a window predicted from a sample, verified on the device) and the robust one (every entry histogrammed) are the same
-    # function of the inputs, bit for bit; the prediction held (info[7] bit 1 clear)
+    monkeypatch.delenv("GIMS_AGC_ROBUST", raising=False)
     for a, b in zip(outs["window"][:3], outs["robust"][:3]):
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(outs["window"][3], outs["robust"][3])
-    assert int(outs["window"][3][7]) == 0
-    (k1, p1, i1, f1), (k0, p0, i0, f0) = outs["exact"], outs["window"]
-    t1, t0 = np.array([f1[6], f0[6]], dtype=np.int32).view(np.float32)
-    assert abs(float(t1) - float(t0)) < 1e-6, (t1, t0)
-    if case != "duplicates":          # (with duplicated rows eight values within 1e-7 of each other straddle the threshold: the two evaluators may
-        np.testing.assert_array_equal(k0, k1)      # legitimately order them differently; the band logic itself is checked exactly below)
-        np.testing.assert_array_equal(p0, p1)
-        np.testing.assert_array_equal(i0, i1)
-        np.testing.assert_array_equal(f0[:6], f1[:6])
+    assert int(outs["window"][3][7]) == 0                    # the prediction held, and the robust flow's own post-check passed
     if n > 1100:
         return
-    # the band-limited flow against its own definition, BIT FOR BIT: threshold = k-th smallest (agc.py:378-380) over the strict upper triangle of
-    # f32(dot in float64, summation order of agc_exact_sim8), coarse edges = radius pairs (float64, inclusive) at or above it
-    x = de.astype(np.float32)
-    # the device normalises in f32 with its own summation order: take ITS rows instead of re-deriving them -- what is checked here is the selection
-    dn = (x / np.maximum(np.sqrt(np.sum(x * x, axis=1, dtype=np.float32)), np.float32(1e-12))[:, None]).astype(np.float32)
-    part = []
-    for q in range(8):
-        acc = np.zeros((n, n))
-        for k in range(4 * q, 256, 32):
-            for e in range(4):
-                col = dn[:, k + e].astype(np.float64)
-                acc = acc + col[:, None] * col[None, :]               # (products of two f32 are exact in float64: this IS the fma chain)
-        part.append(acc)
-    sim = (((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]))).astype(np.float32)
-    iu = np.triu_indices(n, 1)
-    vals = np.sort(sim[iu])
-    kk = min(max(int(len(vals) * pct / 100.0), 0), len(vals) - 1)
-    d2 = ((kp[:, None, :].astype(np.float64) - kp[None, :, :].astype(np.float64)) ** 2).sum(-1)
-    cand = (d2 <= float(rad) ** 2)[iu]
-    # the device's f32 row norms may differ from numpy's in the last bit (summation order): accept the threshold if it equals the reference value
-    # computed from rows within one ulp -- in practice it is bit-equal; assert closeness to 1e-7 and the edge count at the device's own threshold
-    assert abs(float(t0) - float(vals[kk])) < 2e-7, (t0, vals[kk])
-    n_edges = int((cand & (sim[iu] >= t0)).sum())
+    f0 = outs["window"][3]
+    t0 = np.array([f0[6]], dtype=np.int32).view(np.float32)[0]
+    sims, kth, cand = _agc_definition(kp, de, rad, pct)
+    # the device's f32 row norms may differ from numpy's in the last bit (summation order): in practice the threshold is bit-equal; assert closeness
+    # to 2e-7 and the edge count at the device's own threshold
+    assert abs(float(t0) - float(kth)) < 2e-7, (t0, kth)
+    n_edges = int((cand & (sims >= t0)).sum())
     assert abs(int(f0[2]) - n_edges) <= (3 if case == "duplicates" else 0), (int(f0[2]), n_edges)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["random", "dense", "negative_and_far", "coincident", "tiny_radius"])
-def test_agc_grid_radius_search_equals_all_pairs(hip, monkeypatch, case):
-    """The radius candidates come from a hashed keypoint grid (cells of side 1.001 r, own + eight adjacent cells) instead of all N^2/2 pairs; the
-    predicate (float64, inclusive) is the same, so kept ids, CSR and every counter must equal those of the all-pairs search (GIMS_AGC_GRID=0) --
-    with few points per cell, with hundreds, with negative and far-away coordinates (cell indices around +-10^5), with coincident points (one cell
-    holds everything) and with a radius below the spacing."""
+@pytest.mark.parametrize("case", ["random", "dense", "negative_and_far", "coincident", "tiny_radius", "zero_radius", "huge_radius", "nan_radius"])
+def test_agc_grid_radius_search_equals_all_pairs(hip, case):
+    """The radius candidates come from a hashed keypoint grid (cells of side 1.001 r, own + eight adjacent cells); the predicate is the reference's
+    (float64, inclusive, agc.py:435-447).  The coarse edge count must equal the one of ALL N^2/2 pairs evaluated on the host with the same
+    predicate at the device's threshold -- with few points per cell, with hundreds, with negative and far-away coordinates (cell indices around
+    +-10^5), with coincident points (one cell holds everything), with a radius below the spacing, and with the degenerate radii that the
+    all-pairs kernel used to serve (0: only coincident points; 1e30: every pair; NaN: none)."""
     r = _rng(31)
-    n, rad, pct, ms = 1500, 15, 5, 4
+    n, rad, pct, ms = 1100, 15, 5, 4
     kp = (r.random(size=(n, 2)) * 25.0 * np.sqrt(n)).astype(np.float32)
     if case == "dense":
-        n, rad = 600, 11               # (about 20 neighbours per point; more would overflow this helper's 64 edges per node in both searches)
+        n, rad = 600, 11               # (about 20 neighbours per point; more would overflow this helper's 64 edges per node)
         kp = (r.random(size=(n, 2)) * np.array([120, 90])).astype(np.float32)
     elif case == "negative_and_far":
         kp = kp - np.float32(400.0)
@@ -968,14 +1024,25 @@ def test_agc_grid_radius_search_equals_all_pairs(hip, monkeypatch, case):
         kp[200:260] = kp[200]         # (60 coincident points: 1770 pairs at distance 0, all in one cell)
     elif case == "tiny_radius":
         rad = 0.5
+    elif case == "zero_radius":
+        rad = 0.0
+        kp[200:230] = kp[200]
+    elif case == "huge_radius":
+        rad, pct, n = 1e30, 90, 100    # every pair is a candidate (4950 < the helper's 6400-candidate room): the percentile keeps 10 % of them
+        kp = kp[:n]
+    elif case == "nan_radius":
+        rad = float("nan")
     de = r.normal(size=(kp.shape[0], 256)).astype(np.float32)
-    monkeypatch.setenv("GIMS_AGC_GRID", "0")
-    ref = _run_agc(hip, kp, de, rad, pct, ms)
-    monkeypatch.delenv("GIMS_AGC_GRID")
     got = _run_agc(hip, kp, de, rad, pct, ms)
-    assert int(ref[3][7]) == 0 and int(got[3][7]) == 0
-    for a, b in zip(ref, got):
-        np.testing.assert_array_equal(a, b)
+    assert int(got[3][7]) == 0
+    t0 = np.array([got[3][6]], dtype=np.int32).view(np.float32)[0]
+    sims, kth, cand = _agc_definition(kp, de, rad if rad == rad else 0.0, pct)
+    if rad != rad:
+        cand[:] = False
+    assert abs(float(t0) - float(kth)) < 2e-7
+    margin = np.abs(sims[cand] - t0).min() if cand.any() else 1.0
+    if margin > 1e-6:
+        assert int(got[3][2]) == int((cand & (sims >= t0)).sum())
 
 
 @pytest.mark.gpu
@@ -1065,6 +1132,33 @@ def test_agc_odd_sizes_vs_oracle(hip, n):
     np.testing.assert_array_equal(kept, ref["kept"])
     np.testing.assert_array_equal(indptr, ref["indptr"])
     np.testing.assert_array_equal(indices, ref["indices"])
+
+
+@pytest.mark.parametrize("n", [16385, 21163])
+def test_agc_above_16384_keypoints_vs_oracle(hip, n):
+    """Images above the former 16 384-keypoint cap (round 5: pairs packed i << 16 | j, component search in global memory above 16 384 nodes, eight
+    waves in the member walk): just past the switch, and the largest kept count the reference publishes (21 163, tools/files/rgbd1/record.txt:635).
+    Density-matched canvas, r / p / m = 15 / 2 / 7; kept ids and CSR equal to the oracle's.  The limit itself (32 768) is reported by
+    gims_agc_max_keypoints and anything above it is refused by name."""
+    r = _rng(500 + n)
+    side = 25.0 * np.sqrt(n)
+    kp = (r.random(size=(n, 2)) * np.array([side * 1.15, side / 1.15])).astype(np.float32)
+    kp[:300] = kp[:300] * 0.02 + np.array([side * 2, side * 2], dtype=np.float32)     # a far-away clump: its own component(s), linked or removed
+    de = r.normal(size=(n, 256)).astype(np.float32)
+    ref = O.agc_build(kp, de, 15, 2, 7)
+    kept, indptr, indices, inf = _run_agc(hip, kp, de, 15, 2, 7)
+    assert int(inf[7]) == 0
+    assert ref["n_coarse"] == int(inf[2])
+    np.testing.assert_array_equal(kept, ref["kept"])
+    np.testing.assert_array_equal(indptr, ref["indptr"])
+    np.testing.assert_array_equal(indices, ref["indices"])
+    assert int(inf[5]) == len(ref["link_edges"])
+    assert hip.agc_max_keypoints() == 32768
+    with pytest.raises(hip.GimsHipError, match="32768"):
+        big = dict(kpts=torch.zeros(32769, 2, device="cuda"), desc=torch.zeros(32769, 32, device="cuda"), kept=torch.empty(1, dtype=torch.int32, device="cuda"),
+                   indptr=torch.empty(1, dtype=torch.int32, device="cuda"), indices=torch.empty(1, dtype=torch.int32, device="cuda"),
+                   info=torch.empty(8, dtype=torch.int32, device="cuda"))
+        hip.agc_workspace_bytes(hip.make_agc_images([big]))
 
 
 @pytest.mark.parametrize("resident", ["0", "2", "2h"])

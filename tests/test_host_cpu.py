@@ -26,15 +26,25 @@ def test_library_exports_every_declared_symbol():
     assert hip.load().gims_abi_version() == 1
 
 
-def test_struct_layouts_match_header():
-    # sizes the C compiler produces for the structs in include/gims_hip.h (LP64)
-    assert ctypes.sizeof(hip.LinearArgs) == 13 * 8 + 6 * 4 + 4 + 4 + 5 * 8 + 4 + 4 * 4 + 4   # + 4 plane pointers + ld_split + flags + conv geometry (padded)
-    assert ctypes.sizeof(hip.OtProblem) == 8 + 8 + 4 + 4 + 5 * 8
-    assert ctypes.sizeof(hip.AgcImage) == 3 * 8 + 2 * 4 + 3 * 8 + 8 + 8      # max_edges_dir is padded to 8
-    assert ctypes.sizeof(hip.PackImage) == 7 * 8 + 4 * 4
-    assert ctypes.sizeof(hip.IngestImage) == 4 * 8 + 2 * 4
-    assert ctypes.sizeof(hip.AttnArgs) == 8 + 8 + 3 * 4 + 4 + 8 + 3 * 4 + 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8      # ... flags, pad, stat
-    assert ctypes.sizeof(hip.Op) == 8 + ctypes.sizeof(hip.LinearArgs)                         # the union is as large as its linear arm
+def test_struct_layouts_match_header(tmp_path):
+    """Sizes and field offsets of the ctypes mirrors against what a C compiler makes of include/gims_hip.h (gcc, LP64)."""
+    import subprocess
+    pairs = [("gims_linear_args", hip.LinearArgs, ["a0", "w", "bias", "out_f32", "m", "act", "scale", "a0_lo", "out_hi", "ld_split", "flags", "conv_h", "guard"]),
+             ("gims_attn_guard", hip.AttnGuard, ["stat", "mean_thr", "range_limit", "n_heads", "kind"]),
+             ("gims_attn_args", hip.AttnArgs, ["qkv", "q_col", "problems", "n_heads", "out", "ld_split", "flags", "stat", "guard"]),
+             ("gims_ot_problem", hip.OtProblem, []), ("gims_agc_image", hip.AgcImage, ["kept", "max_edges_dir", "info"]),
+             ("gims_pack_image", hip.PackImage, []), ("gims_ingest_image", hip.IngestImage, []), ("gims_op", hip.Op, ["u"])]
+    body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (c, c) + "".join('printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (c, f, c, f) for f in fs)
+                   for c, _, fs in pairs)
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gims_hip.h"\nint main(void) {\n' + body + "return 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for c, py, fs in pairs:
+        assert int(got[c]) == ctypes.sizeof(py), (c, got[c], ctypes.sizeof(py))
+        for f in fs:
+            assert int(got[f"{c}.{f}"]) == getattr(py, f).offset, (c, f)
 
 
 def test_pyramid_layout_equals_the_reference_schedule(golden_dir):

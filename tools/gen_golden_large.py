@@ -17,7 +17,12 @@ matches, scores, the top-1/top-2 gaps of the OT matrix, per-image AGC stages.
     attention_precision='auto' really holds a launch table with different kernel families in one pass; and ONE sharpened head
     (head 2 of layers 4-6 at 3 x, of layers 7-9 at 6 x the default gain 0.3) next to diffuse ones in the same layers.
 
-    python tools/gen_golden_large.py [--only sharp|mixed|4096|8192]
+  * UNBALANCED pairs (round 5): n0 != n1, image 1 = partners of a subset of image 0's keypoints + fresh outliers
+    (synth.make_pair_unbalanced) -- every fixture above is an n = m permutation pair.  Two small ones (1500 / 900 and 300 / 520) for every
+    precision x Sinkhorn-path parametrisation, and the reference's one PUBLISHED configuration: 15 382 / 14 870 keypoints at the eval
+    scripts' setting (20 iterations, threshold 0.02; README.md:143-163).
+
+    python tools/gen_golden_large.py [--only sharp|mixed|4096|8192|unbalanced|readme]
 """
 import os
 import sys
@@ -72,6 +77,20 @@ def one(name, model, n, seed, rad, pct, ms, iters, thr, with_agc=True, extra=Non
     print(f"  ({time.time() - t0:.1f} s, {int((r['matches0'] >= 0).sum())} matches)", flush=True)
 
 
+def one_unbalanced(name, model, n0, n1, nc, seed, rad, pct, ms, iters, thr):
+    t0 = time.time()
+    pair = synth.make_pair_unbalanced(n0, n1, nc, seed)
+    r = G.run_reference(model, pair, rad, pct, ms)
+    arrs = {"out/" + k: v for k, v in r.items()}
+    for s in ("0", "1"):
+        st = G.agc_stages(pair, s, rad, pct, ms)
+        arrs.update({f"agc{s}/" + k: v for k, v in st.items()})
+    arrs["meta"] = np.asarray([n0, n1, nc, seed, rad, pct, ms, iters], dtype=np.int64)
+    arrs["match_threshold"] = np.float64(thr)
+    G.save(name, **arrs)
+    print(f"  ({time.time() - t0:.1f} s, kept {len(r['kept0'])}/{len(r['kept1'])}, {int((r['matches0'] >= 0).sum())} matches)", flush=True)
+
+
 def main():
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     sd = synth.make_state_dict(123)
@@ -93,6 +112,11 @@ def main():
             one(f"{kind}e2e_n1024_s1021_r15p2m7_i20", m20, 1024, 1021, 15, 2, 7, 20, 0.02, with_agc=False)
     m100 = G.ref_model(sd, {})
     m20 = G.ref_model(sd, {"sinkhorn_iterations": 20, "match_threshold": 0.02})
+    if only in (None, "unbalanced"):
+        one_unbalanced("ube2e_n1500_900_c700_s3001_r15p2m7_i100", m100, 1500, 900, 700, 3001, 15, 2, 7, 100, 0.2)
+        one_unbalanced("ube2e_n300_520_c200_s3002_r15p2m7_i20", m20, 300, 520, 200, 3002, 15, 2, 7, 20, 0.02)
+    if only in (None, "readme"):
+        one_unbalanced("ube2e_n15382_14870_c12000_s3003_r15p2m7_i20", m20, 15382, 14870, 12000, 3003, 15, 2, 7, 20, 0.02)
     if only in (None, "4096"):
         one("e2e_n4096_s1000_r15p2m7_i100", m100, 4096, 1000, 15, 2, 7, 100, 0.2)
         one("e2e_n4096_s1001_r15p2m7_i20", m20, 4096, 1001, 15, 2, 7, 20, 0.02)
