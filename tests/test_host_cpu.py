@@ -255,7 +255,7 @@ def test_auto_attention_routes_on_the_tail_and_the_range():
     m = GMatcher({}).eval()
     L, H = m.n_layers, 4
     st = m.__dict__["_attn_auto"] = dict(gen=7, mode=[2] * L, calibrated=False, peak=np.zeros((L, H)), peak_max=np.zeros((L, H)),
-                                         tail=np.zeros((L, H)), range=np.zeros((L, 3)), switched=[], batches={})
+                                         tail=np.zeros((L, H)), range=np.zeros((L, 3)), switched=[], batches={}, redone=np.zeros(L, dtype=np.int64))
 
     class Ev:
         def synchronize(self):
@@ -284,6 +284,11 @@ def test_auto_attention_routes_on_the_tail_and_the_range():
     mean3 = mean2.copy(); mean3[1, 2] = 0.3
     modes3 = feed(mean3, np.zeros((L, H)), rng3)
     assert modes3[1] == "bf16x3" and m.attention_report()["switched"] == [1]
+    # the device's record of a redo (stat[H][3], set by a guarded attention launch that fired) is counted per layer
+    raw = np.zeros((L, H + 1, 4), dtype=np.int64)
+    raw[5, H, 3] = 1
+    m.__dict__["_attn_pending"] = {0: [torch.from_numpy(raw), Ev(), 7]}
+    assert m.attention_report()["redone"].tolist() == [0] * 5 + [1] + [0] * (L - 6)
 
 
 def test_graph_build_flag_words_decide_the_repeat():
