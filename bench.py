@@ -483,6 +483,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=None, help="image pairs per step per GPU (default 8 at 4096, 32 otherwise)")
     ap.add_argument("--sinkhorn-iters", type=int, default=100)
     ap.add_argument("--linear-precision", default="bf16x3", choices=["bf16x3", "f32"])
+    ap.add_argument("--attention-precision", default="auto", choices=["auto", "bf16", "f16", "bf16x3"],
+                    help="'auto' (default): per-layer tiers decided from measured softmax statistics, with the device-side redo; the others fix one tier")
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches per step on separate HIP streams (1 = single stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU-oracle work per workload")
@@ -525,7 +527,7 @@ def main():
     from gims_amd import GMatcher, synth
 
     model = GMatcher({"sinkhorn_iterations": args.sinkhorn_iters, "linear_precision": args.linear_precision,
-                      "streams": args.streams}).eval()
+                      "streams": args.streams, "attention_precision": args.attention_precision}).eval()
     model.load_state_dict(synth.make_state_dict(123))
 
     if args.kpts is not None:

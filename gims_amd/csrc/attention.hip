@@ -1643,7 +1643,7 @@ extern "C" int gims_attention_ex(const gims_attn_args* args, void* stream) {
   uint64_t* stat_u64 = args->stat;
   const gims_attn_guard guard = args->guard;
   GIMS_CHECK_ARG(!guard.stat || ((flags & GIMS_ATTN_X3) && !stat_u64 && (guard.kind == GIMS_GUARD_PEAKED || guard.kind == GIMS_GUARD_RANGE) &&
-                                 guard.n_heads > 0 && guard.n_heads <= 64 && (((uintptr_t)guard.stat) & 7) == 0),
+                                 guard.n_heads > 0 && guard.n_heads <= 15 && (((uintptr_t)guard.stat) & 7) == 0),
                  "gims_attention_ex: a guard goes with GIMS_ATTN_X3, without a statistic of its own, kind GIMS_GUARD_*, 8-byte aligned stat");
   using namespace gims;
   GIMS_CHECK_ARG((((uintptr_t)stat_u64) & 7) == 0, "gims_attention_stat: stat must be 8-byte aligned");

@@ -104,25 +104,25 @@ __device__ __forceinline__ void ot_raise_status(float* status, float code) {
   __hip_atomic_fetch_max((int*)status, __float_as_int(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// gims_attn_guard (include/gims_hip.h): does the statistic of the guarded launch ask for the redo?  Evaluated by every workgroup of a guarded
-// launch at entry (the accumulator is final: the launch that filled it precedes this one on the stream); float64 arithmetic as the header states.
+// gims_attn_guard (include/gims_hip.h): does the statistic of the guarded launch ask for the redo?  Evaluated by every WAVE of a guarded launch at
+// entry (the accumulator is final: the launch that filled it precedes this one on the stream); float64 arithmetic as the header states.  ONE
+// load per lane -- lane i takes word i of the [n_heads + 1][4] table (n_heads <= 15) -- and shuffles: an unfired launch costs every wave a single
+// L2 round trip (a per-head loop of dependent loads cost four).
 __device__ __forceinline__ bool attn_guard_fires(const gims_attn_guard& g) {
   const unsigned long long* st = (const unsigned long long*)g.stat;
-  bool fire = false;
+  const int lane = threadIdx.x & 63, nw = 4 * (g.n_heads + 1);
+  const unsigned long long v = lane < nw ? __builtin_nontemporal_load(st + lane) : 0ull;
+  bool mine = false;
   if (g.kind == GIMS_GUARD_PEAKED) {
-    for (int h = 0; h < g.n_heads; ++h) {
-      const unsigned long long sum = st[4 * h], cnt = st[4 * h + 1], tail = st[4 * h + 3];
-      if (cnt == 0) continue;
-      const double mean = (double)sum / (double)cnt / 16777216.0, tl = (double)tail / (double)cnt;
-      fire = fire || mean > g.mean_thr || tl > g.tail_thr;
+    const unsigned long long cnt = __shfl(v, (lane & ~3) + 1, 64), tail = __shfl(v, (lane & ~3) + 3, 64);      // (lane 4h: v = the head's sum)
+    if ((lane & 3) == 0 && lane < 4 * g.n_heads && cnt != 0) {
+      const double mean = (double)v / (double)cnt / 16777216.0, tl = (double)tail / (double)cnt;
+      mine = mean > g.mean_thr || tl > g.tail_thr;
     }
-  } else {
-    for (int i = 0; i < 3; ++i) {
-      const double v = (double)__uint_as_float((uint32_t)st[4 * g.n_heads + i]);
-      fire = fire || !(v <= g.range_limit);
-    }
+  } else if (lane >= 4 * g.n_heads && lane < 4 * g.n_heads + 3) {
+    mine = !((double)__uint_as_float((uint32_t)v) <= g.range_limit);
   }
-  return fire;
+  return __ballot(mine) != 0ull;
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

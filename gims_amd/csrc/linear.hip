@@ -604,7 +604,7 @@ static int linear_validate(const gims_linear_args* a) {
   GIMS_CHECK_ARG(a->out_f32 || a->out_bf16 || a->out_hi, "gims_linear: no output");
   GIMS_CHECK_ARG((a->out_hi == nullptr) == (a->out_lo == nullptr), "gims_linear: out_hi and out_lo come together");
   GIMS_CHECK_ARG(!a->guard.stat || (a->a0_lo && (a->guard.kind == GIMS_GUARD_PEAKED || a->guard.kind == GIMS_GUARD_RANGE) && a->guard.n_heads > 0 &&
-                                    a->guard.n_heads <= 64 && (((uintptr_t)a->guard.stat) & 7) == 0),
+                                    a->guard.n_heads <= 15 && (((uintptr_t)a->guard.stat) & 7) == 0),
                  "gims_linear: a guard goes with pre-split operands, kind GIMS_GUARD_*, 8-byte aligned stat");
   if (a->precision == GIMS_PREC_BF16X6) {   // SPL3 operands, batched launches only: C = scale * A W^T, f32 out
     GIMS_CHECK_ARG((a->k % 32) == 0 && a->k0 == a->k, "gims_linear(bf16x6): K=%d must be a multiple of 32, one A segment", a->k);

@@ -397,6 +397,9 @@ class GMatcher(nn.Module):
         for (a trained model meeting an input that sharpens a layer)."""
         st = self.__dict__.get("_attn_auto")
         assert st is not None and st["calibrated"], "settle the model first"
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:        # (the pack is keyed by the full device name the batches arrive on)
+            device = torch.device("cuda", torch.cuda.current_device())
         st["gen"] = self._packed(device)["gen"]
 
     def attention_report(self):
