@@ -87,8 +87,9 @@ def compact_line(res):
     line["host_step_ms"] = res.get("host_step_ms")
     line["attention_layers"] = _pick(res.get("attention"), ("precision", "layers_bf16", "layers_f16", "layers_bf16x3"))
     line["world_size_seen"] = res.get("world_size_seen", 1)
-    if res.get("ranks"):
-        line["ranks"] = [[r["rank"], r["device"], r["backend"]] for r in res["ranks"]]
+    line.update(_pick(res, ("stats_rows_gathered", "matches_pair0")))
+    if res.get("ranks"):               # proof of the N > 1 launch: [rank, device index, collective backend, pid] of every rank
+        line["ranks"] = [[r["rank"], r["device"], r["backend"], r["pid"]] for r in res["ranks"]]
     also = {}
     for name, blk in (res.get("also") or {}).items():
         if "error" in blk:
@@ -121,7 +122,7 @@ def compact_line(res):
     line = _r(line)
     out = json.dumps(line, separators=(",", ":"))
     if len(out) >= LINE_LIMIT:            # never lose the line to its own size: shed the optional parts, largest first
-        for k in ("also", "stage_ms_per_step", "attention_layers", "ranks", "host_step_ms"):
+        for k in ("also", "stage_ms_per_step", "attention_layers", "ranks", "host_step_ms", "matches_pair0"):
             line.pop(k, None)
             out = json.dumps(line, separators=(",", ":"))
             if len(out) < LINE_LIMIT:

@@ -310,12 +310,89 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(
 constexpr int ATT8_WAVES = 8;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// ---------------------------------------------------------------------------------------------- peakedness of a SAMPLE of rows
+// The 8-wave kernel's optimistic softmax never looks at a maximum, so it cannot report the row maxima of P; making some of its workgroups
+// take the exact pass instead cost 17 % of the launch (they become the tail of a two-round grid).  A SAMPLE is measured instead, by extra
+// workgroups of the SAME launch (round 5: every batch is measured -- as a launch of its own the sample cost 16 us per layer at 2 x 4096 x 8, in
+// the first workgroups of the attention grid it runs under the main workgroups): per (problem, head) group one workgroup takes 32 queries
+// spread evenly over the group's queries and walks ALL keys -- wave w the 32-key tiles w, w + NW, ... -- with S^T = K Q^T on the matrix cores
+// (K fragments straight from global memory: a lane's MFMA operand is one 16-byte piece of a key row), an exact online (maximum, sum) per
+// query, and a merge of the partial pairs per query through LDS (xm, xl: [NW][64] floats each).  Row maximum of P = 1 / (sum of exp2(s - max)).
+constexpr int PS_Q = 32;
+template <bool F16, int NW>
+__device__ __forceinline__ void attention_peak_sample_wg(const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, const gims_attn_problem pr,
+                                                         int head, float c, unsigned long long* __restrict__ stat, float* xm, float* xl) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int n_s = pr.n_q < PS_Q ? pr.n_q : PS_Q;                        // sampled queries: j -> row j * n_q / n_s
+  if (n_s <= 0 || pr.n_kv <= 0) return;
+  bf16x8 qf[4];
+  {
+    const int j = li < n_s ? li : n_s - 1;
+    const int qr = (int)(((long long)j * pr.n_q) / n_s);
+    const uint16_t* qp = qkv + (int64_t)(pr.q_off + qr) * ld + q_col + head * DH + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+  }
+  const int n_tiles = (pr.n_kv + 31) / 32;
+  float m_run = -1e30f, l_run = 0.f;
+  constexpr int TB = 4;                                                   // tiles in flight per wave (16 x 16-byte loads)
+  for (int t0 = wave; t0 < n_tiles; t0 += NW * TB) {
+    bf16x8 kf[TB][4];
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int t = t0 + b * NW;
+      int kr = t * 32 + li;
+      kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
+      const uint16_t* kp = qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * lh;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[b][s] = *(const bf16x8*)(kp + 16 * s);
+    }
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int t = t0 + b * NW;
+      if (t >= n_tiles) break;                                            // wave-uniform
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sacc = mfma_16b<F16>(kf[b][s], qf[s], sacc);
+      float tmax = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= pr.n_kv) sacc[r] = -1e30f;
+        tmax = fmaxf(tmax, sacc[r]);
+      }
+      const float m_new = fmaxf(m_run, tmax);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f((sacc[r] - m_new) * c);
+      l_run = l_run * __builtin_amdgcn_exp2f((m_run - m_new) * c) + sum;
+      m_run = m_new;
+    }
+  }
+  xm[wave * 64 + lane] = m_run;
+  xl[wave * 64 + lane] = l_run;
+  __syncthreads();
+  if (wave == 0) {
+    float m = -1e30f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m = fmaxf(m, fmaxf(xm[w * 64 + li], xm[w * 64 + li + 32]));
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)                                           // fixed order
+      l += xl[w * 64 + li] * __builtin_amdgcn_exp2f((xm[w * 64 + li] - m) * c) + xl[w * 64 + li + 32] * __builtin_amdgcn_exp2f((xm[w * 64 + li + 32] - m) * c);
+    emit_peak_stat(stat, head, 1.f / l, lh == 0 && li < n_s);
+  }
+}
+
 template <bool PROF, bool NOFMA, bool F16 = false>     // NOFMA: Q carries the softmax scale (c == 1): the optimistic pass is P = exp2(S), reference 0
 __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
     int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, unsigned long long* prof,
-    int exact_only, float c) {
+    int exact_only, float c, unsigned long long* __restrict__ stat, int n_sample) {
   // diagnostics (GIMS_ATTN_PROF=1): cycles of wave 0 (group A) and wave 4 (group B) of workgroup 0 per phase, split into
   // work (phase start -> barrier reached) and wait (inside the barrier)
   unsigned long long pt = 0, pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -341,7 +418,16 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   __shared__ __attribute__((aligned(16))) uint16_t Vs[2][KB * VROW];
   constexpr int QP = 2, QWV = QW * QP, QBK = QWV * ATT8_WAVES;   // 64 queries per wave, 512 per workgroup
 
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  // measured launches (stat != NULL): the first n_sample workgroups (a multiple of 8: the XCD mapping of the others is unchanged) measure the
+  // peakedness of a sample of rows, one (problem, head) group each, and are gone long before the main workgroups finish
+  if (stat != nullptr && (int)blockIdx.x < n_sample) {
+    if ((int)blockIdx.x < n_groups)
+      attention_peak_sample_wg<F16, ATT8_WAVES>(qkv, ld, q_col, k_col, problems[blockIdx.x / n_heads], (int)blockIdx.x % n_heads, c, stat, (float*)&Ks[0][0],
+                                                (float*)&Ks[1][0]);
+    return;
+  }
+  const int bid = (int)blockIdx.x - (stat != nullptr ? n_sample : 0);
+  const int xcd = bid & 7, slot = bid >> 3;
   const int group = (slot / n_qt) * 8 + xcd;
   if (group >= n_groups) return;
   const gims_attn_problem pr = problems[group / n_heads];
@@ -655,7 +741,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   };
   // (__syncthreads_or is also the barrier that lets the second pass overwrite the last tiles in LDS)
   if ((exact_only & 1) || __syncthreads_or(pass(std::false_type{}))) pass(std::true_type{});
-  if (PROF && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
+  if (PROF && bid == 0 && (wave == 0 || wave == 4) && lane == 0)
     for (int i = 0; i < 10; ++i) prof[(wave >> 2) * 10 + i] = pacc[i];
 
   // ---- normalise and store.  In the MFMA layout a lane owns 4 consecutive channels of ONE query, so direct stores scatter
@@ -713,7 +799,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
         }
     }
   }
-  if (PROF && blockIdx.x == 0 && wave == 0 && lane == 0) {      // spans of wave 0: prologue, tile loop, epilogue (shader cycles) and the whole kernel on the 100-MHz counter
+  if (PROF && bid == 0 && wave == 0 && lane == 0) {      // spans of wave 0: prologue, tile loop, epilogue (shader cycles) and the whole kernel on the 100-MHz counter
     const unsigned long long t_exit = __builtin_readcyclecounter(), r_exit = __builtin_amdgcn_s_memrealtime();
     prof[20] = t_loop0 - t_entry; prof[21] = t_loop1 - t_loop0; prof[22] = t_exit - t_loop1; prof[23] = r_exit - r_entry;
   }
@@ -1383,89 +1469,6 @@ __global__ __launch_bounds__(256 * NS) void attention_split_kernel(
       }
   }
 }
-// ---------------------------------------------------------------------------------------------- peakedness of a SAMPLE of rows
-// The 8-wave kernel's optimistic softmax never looks at a maximum, so it cannot report the row maxima of P; making some of
-// its workgroups take the exact pass instead cost 17 % of the launch (they become the tail of a two-round grid).  This
-// kernel measures a sample on the side: per (problem, head) group ONE workgroup of 16 waves takes 32 queries spread evenly
-// over the group's queries and walks ALL keys -- wave w the 32-key tiles w, w + 16, ... -- with S^T = K Q^T on the matrix
-// cores (K fragments straight from global memory: a lane's MFMA operand is one 16-byte piece of a key row), an exact online
-// (maximum, sum) per query, and a merge of the 32 partial pairs per query through LDS.  Row maximum of P = 1 / (sum of
-// exp2(s - max)).  A few microseconds per layer; the Python shell asks for it on every n-th batch only.
-constexpr int PS_WAVES = 16, PS_Q = 32;
-template <bool F16>
-__global__ __launch_bounds__(64 * PS_WAVES) void attention_peak_sample_kernel(
-    const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads,
-    float c, unsigned long long* __restrict__ stat) {
-  __shared__ float xm[PS_WAVES][64], xl[PS_WAVES][64];
-  const int group = blockIdx.x;
-  if (group >= n_groups) return;
-  const gims_attn_problem pr = problems[group / n_heads];
-  const int head = group % n_heads;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 31, lh = lane >> 5;
-  const int n_s = pr.n_q < PS_Q ? pr.n_q : PS_Q;                        // sampled queries: j -> row j * n_q / n_s
-  if (n_s <= 0 || pr.n_kv <= 0) return;
-  bf16x8 qf[4];
-  {
-    const int j = li < n_s ? li : n_s - 1;
-    const int qr = (int)(((long long)j * pr.n_q) / n_s);
-    const uint16_t* qp = qkv + (int64_t)(pr.q_off + qr) * ld + q_col + head * DH + 8 * lh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
-  }
-  const int n_tiles = (pr.n_kv + 31) / 32;
-  float m_run = -1e30f, l_run = 0.f;
-  constexpr int TB = 4;                                                   // tiles in flight per wave (16 x 16-byte loads)
-  for (int t0 = wave; t0 < n_tiles; t0 += PS_WAVES * TB) {
-    bf16x8 kf[TB][4];
-#pragma unroll
-    for (int b = 0; b < TB; ++b) {
-      const int t = t0 + b * PS_WAVES;
-      int kr = t * 32 + li;
-      kr = kr < pr.n_kv ? kr : pr.n_kv - 1;
-      const uint16_t* kp = qkv + (int64_t)(pr.kv_off + kr) * ld + k_col + head * DH + 8 * lh;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) kf[b][s] = *(const bf16x8*)(kp + 16 * s);
-    }
-#pragma unroll
-    for (int b = 0; b < TB; ++b) {
-      const int t = t0 + b * PS_WAVES;
-      if (t >= n_tiles) break;                                            // wave-uniform
-      f32x16 sacc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) sacc = mfma_16b<F16>(kf[b][s], qf[s], sacc);
-      float tmax = -1e30f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (key >= pr.n_kv) sacc[r] = -1e30f;
-        tmax = fmaxf(tmax, sacc[r]);
-      }
-      const float m_new = fmaxf(m_run, tmax);
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f((sacc[r] - m_new) * c);
-      l_run = l_run * __builtin_amdgcn_exp2f((m_run - m_new) * c) + sum;
-      m_run = m_new;
-    }
-  }
-  xm[wave][lane] = m_run;
-  xl[wave][lane] = l_run;
-  __syncthreads();
-  if (wave == 0) {
-    float m = -1e30f;
-#pragma unroll
-    for (int w = 0; w < PS_WAVES; ++w) m = fmaxf(m, fmaxf(xm[w][li], xm[w][li + 32]));
-    float l = 0.f;
-#pragma unroll
-    for (int w = 0; w < PS_WAVES; ++w)                                     // fixed order
-      l += xl[w][li] * __builtin_amdgcn_exp2f((xm[w][li] - m) * c) + xl[w][li + 32] * __builtin_amdgcn_exp2f((xm[w][li + 32] - m) * c);
-    emit_peak_stat(stat, head, 1.f / l, lh == 0 && li < n_s);
-  }
-}
-
 template <int NS> constexpr int SPLIT_LDS_BYTES = NS * 2 * (KB * DH + KB * VR_LD) * 2;     // >= the (NS - 1) x 35 KB of the merge exchange
 static_assert(SPLIT_LDS_BYTES<2> >= 1 * 4 * 35 * 64 * 4 && SPLIT_LDS_BYTES<4> >= 3 * 4 * 35 * 64 * 4, "merge exchange must fit the staging buffers");
 
@@ -1572,10 +1575,10 @@ static int attention_16b_launch(const uint16_t* qkv, int64_t ld, int q_col, int 
       GIMS_CHECK_ARG(dprof, "gims_attention: no profile buffer");
       if (prescaled)
         hipLaunchKernelGGL((attention8_bf16_kernel<true, true, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c, nullptr, 0);
       else
         hipLaunchKernelGGL((attention8_bf16_kernel<true, false, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c);
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, dprof, exact_only, c, nullptr, 0);
       GIMS_HIP(hipStreamSynchronize(stream));
       unsigned long long h[24];
       GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
@@ -1586,17 +1589,15 @@ static int attention_16b_launch(const uint16_t* qkv, int64_t ld, int q_col, int 
                 "load_tile %llu, barrier wait %llu\n", 4 * g, h[g * 10 + 0], h[g * 10 + 2], h[g * 10 + 4], h[g * 10 + 8], h[g * 10 + 9], h[g * 10 + 6],
                 h[g * 10 + 7]);
     } else {
+      // the optimistic 8-wave kernel tracks no maximum: measured launches carry 8 * ceil(n_groups / 8) extra workgroups in front that measure
+      // a sample of the rows (attention_peak_sample_wg)
+      const int n_sample = stat ? 8 * cdiv(n_groups, 8) : 0;
       if (prescaled)
-        hipLaunchKernelGGL((attention8_bf16_kernel<false, true, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c);
+        hipLaunchKernelGGL((attention8_bf16_kernel<false, true, F16>), dim3(n_sample + 8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c, stat, n_sample);
       else
-        hipLaunchKernelGGL((attention8_bf16_kernel<false, false, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c);
-    }
-    if (stat) {          // the optimistic 8-wave kernel tracks no maximum: a sample of the rows is measured on the side
-      GIMS_LAUNCH_CHECK();
-      hipLaunchKernelGGL(attention_peak_sample_kernel<F16>, dim3(n_groups), dim3(64 * PS_WAVES), 0, stream, qkv, ld, q_col, k_col, problems,
-                         n_groups, n_heads, c, stat);
+        hipLaunchKernelGGL((attention8_bf16_kernel<false, false, F16>), dim3(n_sample + 8 * cdiv(n_groups, 8) * n_qt8), dim3(512), 0, stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c, stat, n_sample);
     }
   } else if (two) {
     const int n_qt = cdiv(max_n_q, 2 * QB);

@@ -24,10 +24,12 @@ def test_bench_self_launch_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]              # rank 0 prints ONE JSON line; the other rank's stdout is dropped
+    assert r.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096       # the LAST stdout line, compact (what the driver parses)
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["world_size_seen"] == 2
     assert res["stats_rows_gathered"] == 4                 # 2 pairs per rank, all-gathered
-    assert sorted(x["rank"] for x in res["ranks"]) == [0, 1] and all(x["backend"] == "gloo" for x in res["ranks"])
-    assert len({x["pid"] for x in res["ranks"]}) == 2      # two processes, neither of them the launcher
+    # the compact line carries [rank, device index, backend, pid] per rank (the full record is in bench_extra.json)
+    assert sorted(x[0] for x in res["ranks"]) == [0, 1] and all(x[2] == "gloo" for x in res["ranks"])
+    assert len({x[3] for x in res["ranks"]}) == 2          # two processes, neither of them the launcher
     assert res["scaling"] == "weak" and res["value"] > 0 and res["steps"] == 2 and res["warmup"] == 1
     assert res["matches_pair0"]["matched"] > 128
