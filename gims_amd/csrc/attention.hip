@@ -584,7 +584,9 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         if (kt == 0 || __any(tmax * c > RAISE)) {
           const float dmax = kt == 0 ? tmax : fmaxf(tmax, 0.f);                 // (after the first tile the reference only ever moves up)
-          const float alpha = __builtin_amdgcn_exp2f(-dmax * c);
+          // (first tile: the sums and the output are still zero -- nothing to rescale; exp2 of a first-tile maximum below -128 octaves would be
+          // +inf, 0 * inf = NaN in l_run and o, and the whole workgroup would repeat in the exact pass: a hidden 2 x on large-magnitude logits)
+          const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-dmax * c);
           m_run[qi] += dmax;
           l_run[qi] *= alpha;
 #pragma unroll

@@ -53,25 +53,25 @@ struct OtR2Dev {
 struct OtR2Args {
   const OtR2Dev* probs; const OtR2Block* blocks;
   float alpha; int iters, refresh, wt_local;
-  int stagger;         // NT = 256: the second workgroup of every CU starts its iterations this many 64-cycle sleeps late
   int init_inside;     // 1: the start potentials u0 = -max(alpha, row max of Z), v0 = 0 are formed in here (no ot_init_kernel sweep of Z)
   unsigned long long* prof;
 };
 
 constexpr int R2_CSEG = 132;                    // floats per (workgroup, buffer) of the column edge: 128 columns + dustbin + pad
-// LDS layout of a workgroup of NT threads (512: a <= 1024 x 128 block, one workgroup per CU; 256: a <= 512 x 128 block, TWO workgroups per CU --
-// of two different problems when a launch holds two, so that one's exchange waits run under the other's sweeps).  The K tile rows 12..15 of
-// every thread take 16 NT float4; the small arrays follow.  NT = 256 has 80 KB per workgroup to live in: the column-edge buffer xrd is laid
-// over rowst | colred, which are idle between the column pass and the next row pass.
-template <int NT> struct R2L {
-  static constexpr int NW = NT / 64;
-  static constexpr int K = 16 * NT * 4;             // 4 tile rows x 4 quads per thread, float4 each
-  static constexpr int NXMAX = NT == 512 ? 4 : 8;   // row groups of a problem (rb <= 2 NT rows each)
-  static constexpr int ROWST = NT == 512 ? 1028 : 544, FACS = NT == 512 ? 1160 : 648, GVEC = 132, COLRED = NW * 128, PB = 2 * NT + 4, PR = 132, CSST = 132;
-  static constexpr int XRD = NT == 512 ? 4 * R2_CSEG : 0;        // (256: aliased, ROWST + COLRED = 8 * R2_CSEG)
+// LDS layout of a workgroup of R2_NT = 512 threads (a <= 1024 x 128 block, one workgroup per CU).  The K tile rows 12..15 of every thread take
+// 16 R2_NT float4; the small arrays follow.  (A 256-thread geometry -- <= 512 x 128 blocks, two workgroups of two different problems per CU, so
+// that one's exchange waits run under the other's sweeps -- was built in round 4, measured and removed in round 5: a lone wave per SIMD issues
+// its sweep at about half the rate of two, so the two problems' chains stay as long as before: 4096 x 2 0.94 ms per launch against 0.92,
+// 1024 x 32 0.87 against 0.82, whatever the start offset between the two workgroups.)
+constexpr int R2_NT = 512;
+struct R2L {
+  static constexpr int NW = R2_NT / 64;
+  static constexpr int K = 16 * R2_NT * 4;          // 4 tile rows x 4 quads per thread, float4 each
+  static constexpr int NXMAX = 4;                   // row groups of a problem (rb <= 2 R2_NT rows each)
+  static constexpr int ROWST = 1028, FACS = 1160, GVEC = 132, COLRED = NW * 128, PB = 2 * R2_NT + 4, PR = 132, CSST = 132;
+  static constexpr int XRD = 4 * R2_CSEG;
   static constexpr int OWN = 2 * 132 + 2 * 132;     // v and G of the block's columns; u and F of the row slots this workgroup folds (rbf <= R2_FOLD = 132: r2_geom)
   static constexpr int FLOATS = K + ROWST + FACS + GVEC + COLRED + PB + PR + CSST + XRD + 16 + OWN;
-  static_assert(NT == 512 || ROWST + COLRED >= NXMAX * R2_CSEG, "xrd does not fit its alias");
 };
 
 typedef float r2f2 __attribute__((ext_vector_type(2)));
@@ -97,10 +97,11 @@ __device__ __forceinline__ float r2_sum8(float x) {
   return r2_dpp_add<0x141>(x);  // row_half_mirror
 }
 
-template <bool PROF, int NT>
-__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void ot_res2_kernel(OtR2Args a) {
+template <bool PROF>
+__global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
 #pragma clang fp contract(off)
-  using L = R2L<NT>;
+  using L = R2L;
+  constexpr int NT = R2_NT;
   __shared__ int fail_flag;
   __shared__ unsigned long long prof_acc[8];
   unsigned long long prof_t = 0;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void ot_res2_kernel(OtR2Args
   float* pb = gvec + L::GVEC;              // dustbin-column entries of the group's rows (last column block only)
   float* pr = pb + L::PB;                  // dustbin-row entries of the block's columns (last row group only)
   float* csst = pr + L::PR;                // this block's column sums, staged for the 16-byte publish
-  float* xrd = NT == 512 ? csst + L::CSST : rowst;      // [nx][R2_CSEG] column partials of all row groups (256: over rowst | colred)
+  float* xrd = csst + L::CSST;             // [nx][R2_CSEG] column partials of all row groups
   float* wred = csst + L::CSST + L::XRD;   // [16] per-wave partials of the small reductions
   // state that lives across iterations in LDS rather than in registers (the 192 registers of P leave no room): v and the
   // cumulative factor G of the block's columns (owner: thread t < 128, thread 128 the dustbin column), u and the cumulative
@@ -347,11 +348,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void ot_res2_kernel(OtR2Args
     __syncthreads();
   }
 
-  // Two workgroups share a CU (NT = 256), normally of two different problems.  Started together they would sweep together and wait together; the
-  // second one starts its iterations about half an iteration late, and since both take the same time per iteration the offset persists: one's
-  // exchange waits fall under the other's sweeps.
-  if (NT == 256 && blockIdx.x >= 256)
-    for (int d = 0; d < a.stagger; ++d) __builtin_amdgcn_s_sleep(1);
   for (int it = 0; it < a.iters; ++it) {
     // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration (as loop invariants the
     // compiler keeps their hoisted addresses alive next to the 192 registers of P)
@@ -667,7 +663,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void ot_res2_kernel(OtR2Args
       __syncthreads();
       float* cmine = p.cpart + ((int64_t)(((it & 1) * p.nx + xr) * p.nc + cc)) * R2_CSEG;
       const auto xtg = [&](float x) { return __uint_as_float(__float_as_uint(x) | xtagbit); };
-      if (t < 33) {         // (NT = 256: xrd lies over rowst | colred, whose last readers are behind the barrier above)
+      if (t < 33) {
         const f32x4 q = *(const f32x4*)(csst + 4 * t);
         r2_st4_wt(cmine + 4 * t, f32x4{xtg(q[0]), xtg(q[1]), xtg(q[2]), xtg(q[3])});
         *(f32x4*)(xrd + xr * R2_CSEG + 4 * t) = q;
@@ -762,14 +758,7 @@ static inline int r2_up4(int x) { return (x + 3) & ~3; }
 // a tall, narrow problem (m <= 512 with more than ~132 nc rows per group) otherwise indexes past those arrays.  nc = 32 always fits
 // (rbf <= 36).  false: no on-chip geometry (empty or oversized problem).
 constexpr int R2_FOLD = 132;
-// GIMS_OT_R2_HALF=1: 256-thread workgroups holding <= 512 rows, two per CU (of two different problems when a launch holds two), instead of
-// 512-thread workgroups holding <= 1024 rows, one per CU.  Built in round 4 to hide one problem's exchange waits under the other's sweeps; measured:
-// a lone wave per SIMD issues its sweep at about half the rate of two (row pass of 512 rows 2.3 k cycles against 2.7 k for 1024 rows on twice the
-// waves), so the two problems' chains stay as long as before -- 4096 x 2: 0.94 ms per launch against 0.92, 1024 x 32: 0.87 against 0.82, whatever
-// the start offset between the two workgroups (GIMS_OT_R2_STAGGER).  ONE 4096 problem does gain (0.87 -> 0.76 ms: it spreads over all 256
-// CUs), but the geometry has to be a function of the problem's own size, not of its batch.  Off by default; read per call (the tests run both).
-static bool r2_half() { return r2_env("GIMS_OT_R2_HALF", 0) != 0; }
-static inline int r2_rbmax() { return r2_half() ? 512 : 1024; }
+static inline int r2_rbmax() { return 1024; }
 static inline bool r2_geom(int n, int m, int& nx, int& nc) {
   if (n < 1 || m < 1 || n > 4096 || m > 4096) return false;
   nc = 1;
@@ -793,7 +782,7 @@ static OtR2Plan plan_class(const OtR2Host* pr, int np, int iters) {
     int nxi = 0, nci = 0;
     if (!r2_geom(pr[i].n, pr[i].m, nxi, nci) || nxi != nx || nci != nc) return P;
   }
-  const int units = 8 * ((r2_half() ? 64 : 32) / nc);               // row groups one launch holds (each on the CUs of one XCD; two workgroups per CU with 256 threads)
+  const int units = 8 * (32 / nc);                                  // row groups one launch holds (each on the CUs of one XCD)
   if (nx > units) return P;
   P.nx = nx; P.nc = nc;
   P.ppg = units / nx;
@@ -907,14 +896,11 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
   GIMS_HIP(hipMemsetAsync(dplace, 0, 256, s));
   int rc = upload_table(hd.data(), sizeof(OtR2Dev) * (size_t)np, dprob, s);
   if (rc != GIMS_OK) return rc;
-  const bool half = r2_half();
-  const int nthreads = half ? 256 : 512, nblocks = half ? 512 : 256;
-  const size_t lds = (half ? R2L<256>::FLOATS : R2L<512>::FLOATS) * sizeof(float);
-  GIMS_LDS_ATTR((const void*)ot_res2_kernel<false, 512>, (int)(R2L<512>::FLOATS * sizeof(float)));
-  GIMS_LDS_ATTR((const void*)ot_res2_kernel<true, 512>, (int)(R2L<512>::FLOATS * sizeof(float)));
-  GIMS_LDS_ATTR((const void*)ot_res2_kernel<false, 256>, (int)(R2L<256>::FLOATS * sizeof(float)));
-  GIMS_LDS_ATTR((const void*)ot_res2_kernel<true, 256>, (int)(R2L<256>::FLOATS * sizeof(float)));
-  R2State* st = r2_state(half ? (const void*)ot_res2_kernel<false, 256> : (const void*)ot_res2_kernel<false, 512>, nthreads, nblocks, lds);
+  const int nthreads = R2_NT, nblocks = 256;
+  const size_t lds = R2L::FLOATS * sizeof(float);
+  GIMS_LDS_ATTR((const void*)ot_res2_kernel<false>, (int)(R2L::FLOATS * sizeof(float)));
+  GIMS_LDS_ATTR((const void*)ot_res2_kernel<true>, (int)(R2L::FLOATS * sizeof(float)));
+  R2State* st = r2_state((const void*)ot_res2_kernel<false>, nthreads, nblocks, lds);
   if (!st) { set_error("ot_res2_run: no per-device state"); return GIMS_EHIP; }
   // all workgroups of a launch wait on each other: they must be co-resident (one / two per CU) -- checked once per device against the occupancy query
   if (!st->resident_ok) {
@@ -942,13 +928,12 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
     rc = upload_table(hb, sizeof(OtR2Block) * (size_t)nblocks, dblk, s);
     if (rc != GIMS_OK) return rc;
     OtR2Args a{};
-    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local; a.init_inside = init_inside; a.stagger = r2_env("GIMS_OT_R2_STAGGER", 100);
+    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local; a.init_inside = init_inside;
     if (prof) {
       unsigned long long* dprof = (unsigned long long*)device_once("ot_res2_prof", 8 * sizeof(unsigned long long), nullptr);
       GIMS_CHECK_ARG(dprof, "ot_res2_run: no profile buffer");
       a.prof = dprof;
-      if (half) hipLaunchKernelGGL((ot_res2_kernel<true, 256>), dim3(512), dim3(256), lds, s, a);
-      else hipLaunchKernelGGL((ot_res2_kernel<true, 512>), dim3(256), dim3(512), lds, s, a);
+      hipLaunchKernelGGL((ot_res2_kernel<true>), dim3(256), dim3(R2_NT), lds, s, a);
       GIMS_LAUNCH_CHECK();
       unsigned long long h[8];
       GIMS_HIP(hipStreamSynchronize(s));
@@ -959,8 +944,7 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
       for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.0f;", names[i], (double)h[i] / iters);
       fprintf(stderr, "\n");
     } else {
-      if (half) hipLaunchKernelGGL((ot_res2_kernel<false, 256>), dim3(512), dim3(256), lds, s, a);
-      else hipLaunchKernelGGL((ot_res2_kernel<false, 512>), dim3(256), dim3(512), lds, s, a);
+      hipLaunchKernelGGL((ot_res2_kernel<false>), dim3(256), dim3(R2_NT), lds, s, a);
       GIMS_LAUNCH_CHECK();
     }
   }

@@ -589,11 +589,8 @@ def test_attention_optimistic_overflow_falls_back(hip, monkeypatch, kernel, pres
 @pytest.mark.parametrize("n,m,iters,scale", [(37, 53, 20, 3.0), (2, 2, 100, 1.0), (200, 180, 100, 5.0), (1025, 1000, 100, 8.0),
                                               (64, 64, 0, 3.0), (5, 300, 1, 2.0), (300, 1111, 50, 30.0), (130, 4500, 10, 4.0),
                                               (40, 9000, 5, 4.0)])
-@pytest.mark.parametrize("resident", ["0", "2", "2h"])      # streamed kernels / on-chip resident kernel (forced where it fits) / its 256-thread geometry
+@pytest.mark.parametrize("resident", ["0", "2"])      # streamed kernels / on-chip resident kernel (forced where it fits)
 def test_sinkhorn_match(hip, monkeypatch, n, m, iters, scale, resident):
-    if resident == "2h":
-        monkeypatch.setenv("GIMS_OT_R2_HALF", "1")
-        resident = "2"
     monkeypatch.setenv("GIMS_OT_RESIDENT", resident)
     r = _rng(n * 1000 + m)
     z = (r.normal(size=(n, m)) * scale).astype(np.float32)
@@ -635,11 +632,7 @@ def test_sinkhorn_match(hip, monkeypatch, n, m, iters, scale, resident):
                                              ("2", [(600, 300), (1024, 500), (300, 100), (900, 130), (1024, 5), (4096, 2), (2049, 129)]),
                                              # empty trailing column blocks (m just over a multiple of the block width) and single rows / columns
                                              ("2", [(2100, 2049), (2, 2), (2, 700), (700, 2), (513, 2108)])])
-@pytest.mark.parametrize("half", ["0", "1"])
-def test_sinkhorn_batched_ragged(hip, monkeypatch, resident, shapes, half):
-    if half == "1" and resident != "2":
-        pytest.skip("the 256-thread geometry concerns the on-chip kernel only")
-    monkeypatch.setenv("GIMS_OT_R2_HALF", half)
+def test_sinkhorn_batched_ragged(hip, monkeypatch, resident, shapes):
     monkeypatch.setenv("GIMS_OT_RESIDENT", resident)
     rescues0 = hip.sinkhorn_rescues()
     r = _rng(9)
@@ -1161,11 +1154,8 @@ def test_agc_above_16384_keypoints_vs_oracle(hip, n):
         hip.agc_workspace_bytes(hip.make_agc_images([big]))
 
 
-@pytest.mark.parametrize("resident", ["0", "2", "2h"])
+@pytest.mark.parametrize("resident", ["0", "2"])
 def test_sinkhorn_full_size_marginals(hip, monkeypatch, resident):
-    if resident == "2h":                       # the 256-thread geometry: eight row groups, two workgroups per CU
-        monkeypatch.setenv("GIMS_OT_R2_HALF", "1")
-        resident = "2"
     """BASELINE size (4096 x 4096, 100 iterations), too large for the CPU oracle in a test: size-independent property of the
     recurrence instead -- the last update is the column one, so the column marginals of exp(Z + u + v) equal nu exactly
     (to f32 summation noise) and the row marginals equal mu up to the convergence residual; both Sinkhorn paths."""
