@@ -693,6 +693,301 @@ __global__ __launch_bounds__(512) void ch_conv_block_kernel(const uint16_t* __re
       frn_block_body<COUT, HOUT, NT>(lds + pp * G::FRN_FLOATS, fw, fb, eps, g, tau, y, ysp, ldsp, (patch + pp) * G::NPIX, first.prof, stage_gates ? gl : nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------- the same block, TWO workgroups per CU (round 5)
+// The 32 x 32 layers of ch_conv_block_kernel hold a whole patch twice over in LDS -- the split-bf16 input image (128 KB) and, over it, the raw
+// convolution output (128 KB as f32) -- so ONE workgroup fits a CU and its phases (patch load at the HBM rate, matrix phase, statistic / gate /
+// apply passes at LDS latency, store) run back to back with nothing under them: a patch costs 64 k cycles of CU time for 19 k of matrix time.
+// Here the patch goes through LDS in two HALVES of 16 (stride 2: 8) output rows each: input rows r0 .. r0 + 16 of the half (one halo row re-read
+// from L2), the half's accumulators stay in registers while the second half's input replaces the first in LDS, and the FRN (+ CoordAtt) + TLU
+// block runs on half images as well -- the accumulators are dumped a half at a time, once for the statistics and pools and once more (from the
+// registers they never left) for the apply pass.  <= 76 KB of LDS and <= 128 registers: two workgroups per CU, each other's load and store
+// phases under the other's arithmetic.  Same products in the same order per output pixel as ch_conv_block_kernel (K steps ascending, the three
+// passes per step in the same order); the statistic sums run over the same pixels in a different association (two halves), i.e. the outputs
+// agree with the one-workgroup kernel to f32 rounding of the FRN statistic, not bit for bit.
+template <int CIN, int COUT, int STRIDE>
+struct HalfGeom {
+  static constexpr int HIN = 32, NT = 512, WAVES = 8;
+  static constexpr int HOUT = (HIN - 1) / STRIDE + 1, NPIX = HOUT * HOUT, HPIX = NPIX / 2, HROWS = HOUT / 2;     // output pixels / rows per half
+  static constexpr int IH = 17;                                        // input rows per half: r0 = 0 (rows 0..16) and r0 = 15 (rows 15..31), both strides
+  static constexpr int PXB = CIN * 4, CPP = PXB / 16, ZQ = IH * HIN;   // bytes / chunks per pixel record, index of the all-zero record
+  static constexpr int IN_BYTES = (IH * HIN + 1) * PXB;
+  static constexpr int MBH = HPIX / 32, NB = COUT / 32, KS = CIN / 16;
+  static constexpr int TW = MBH * NB / WAVES;                          // tiles per wave and half (32 -> 32: 2, 32 -> 64 stride 2: 1)
+  static_assert(MBH * NB == WAVES * TW && (WAVES / NB) * TW == MBH, "tiles divide over the waves");
+  static constexpr int GRP = NT / COUT;
+  // FRN arrays (floats): xbh [HPIX][COUT] | red [GRP][COUT] | sc [COUT] | ph [HOUT][COUT] | pw [HOUT][COUT]; the gate weights and `mid` lie over xbh
+  static constexpr int XBH = HPIX * COUT, RED = GRP * COUT, FRN_FLOATS = XBH + RED + COUT + 2 * HOUT * COUT;
+  static constexpr int GATE_FLOATS = 26 * COUT + 8 + 16 * HOUT;
+  static_assert(GATE_FLOATS <= XBH, "gate weights + mid fit over the half image");
+  static constexpr int LDS_BYTES = IN_BYTES > FRN_FLOATS * 4 ? IN_BYTES : FRN_FLOATS * 4;
+  static constexpr int HB = (CIN < 32 ? CIN : 32) / 8;
+  __device__ static __forceinline__ int swz(int q) { return CIN == 16 ? ((q >> 2) & 3) : (CIN == 32 ? ((q >> 1) & 7) : (q & 15)); }
+  __device__ static __forceinline__ int chunk(int ks, int lh) { return (ks / (HB / 2)) * (2 * HB) + 2 * (ks % (HB / 2)) + lh; }
+};
+
+template <int CIN, int COUT, int STRIDE>
+__global__ __launch_bounds__(512, 4) void ch_conv_block_half_kernel(const uint16_t* __restrict__ xin, int64_t ldx, const uint16_t* __restrict__ wpk,
+                                                                    const float* __restrict__ bias, const float* __restrict__ fw, const float* __restrict__ fb,
+                                                                    float eps, ChGateW g, const float* __restrict__ tau, float* __restrict__ y,
+                                                                    uint16_t* __restrict__ ysp, int64_t ldsp, int stagger, int first_wave,
+                                                                    unsigned long long* prof) {
+  using G = HalfGeom<CIN, COUT, STRIDE>;
+  constexpr int NT = G::NT, HIN = G::HIN, ZQ = G::ZQ, PXB = G::PXB, CPP = G::CPP, HOUT = G::HOUT, HPIX = G::HPIX, HROWS = G::HROWS, TW = G::TW, KS = G::KS,
+                NB = G::NB, C = COUT, QPP = C / 4, GRP = G::GRP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* img = (char*)lds;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t patch = blockIdx.x;
+  ch_stagger(stagger, first_wave);
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (prof && blockIdx.x == gridDim.x / 2 && t == 0) prof[k] = __builtin_readcyclecounter(); };
+  stamp(0);
+  const uint16_t* src = xin + patch * (HIN * HIN) * ldx;
+
+  // this wave's tiles: n-block nb0, local m-blocks mbl0 .. mbl0 + TW - 1 of either half
+  const int nb0 = wave % NB, mbl0 = (wave / NB) * TW;
+  f32x16 acc[2][TW];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int m = 0; m < TW; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][m][r] = 0.f;
+  const uint16_t* wl = wpk + lane * 8;
+  auto wfrag = [&](int step, int plane) __attribute__((always_inline)) {
+    return *(const bf16x8*)(wl + (((int64_t)step * NB + nb0) * 2 + plane) * 512);
+  };
+  constexpr int STEPS = 9 * KS;
+  constexpr int WD = KS <= 2 ? 3 : 4, UNR = KS == 1 ? 9 : (KS == 2 ? 6 : KS);
+  static_assert(STEPS % UNR == 0 && UNR % WD == 0, "ring geometry");
+
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r0 = h == 0 ? 0 : 15;                               // first input row of the half's LDS image
+    if (h == 1) __syncthreads();                                  // every wave is done with the first half's image
+    if (t < CPP) *(uint4*)(img + ZQ * PXB + t * 16) = make_uint4(0u, 0u, 0u, 0u);
+    {
+      constexpr int TOT = G::IH * HIN * CPP;                      // 17 rows x 32 pixels x chunks: not a multiple of LPT * NT -> guarded tail
+      constexpr int LPT = 8;
+#pragma unroll
+      for (int i0 = t; i0 < TOT; i0 += LPT * NT) {
+        uint4 v[LPT];
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+          const int i = i0 + u * NT;
+          const int ic = i < TOT ? i : TOT - 1;
+          v[u] = *(const uint4*)(src + (int64_t)(r0 * HIN + ic / CPP) * ldx + (ic % CPP) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+          const int i = i0 + u * NT;
+          if (i < TOT) {
+            const int q = i / CPP, ch = i % CPP;
+            *(uint4*)(img + q * PXB + ((ch ^ G::swz(q)) * 16)) = v[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    stamp(1 + 2 * h);
+    // input coordinates of tap (0, 0) of this lane's output pixels: global row (may be -1) and column
+    int y0[TW], x0[TW];
+#pragma unroll
+    for (int m = 0; m < TW; ++m) {
+      const int p = h * HPIX + (mbl0 + m) * 32 + li;
+      y0[m] = (p / HOUT) * STRIDE - 1;
+      x0[m] = (p % HOUT) * STRIDE - 1;
+    }
+    auto compute = [&](int step, const bf16x8& wh, const bf16x8& wlo) __attribute__((always_inline)) {
+      const int tap = step / KS, ks = step % KS;
+      const int ky = tap / 3, kx = tap % 3;
+      const int chunk = G::chunk(ks, lh);
+      bf16x8 ah[TW], al[TW];
+#pragma unroll
+      for (int m = 0; m < TW; ++m) {
+        const int iy = y0[m] + ky, ix = x0[m] + kx;
+        const int q = ((unsigned)iy < (unsigned)HIN && (unsigned)ix < (unsigned)HIN) ? (iy - r0) * HIN + ix : ZQ;
+        const int sw = G::swz(q);
+        ah[m] = *(const bf16x8*)(img + q * PXB + ((chunk ^ sw) * 16));
+        al[m] = *(const bf16x8*)(img + q * PXB + (((chunk + G::HB) ^ sw) * 16));
+      }
+#pragma unroll
+      for (int m = 0; m < TW; ++m) acc[h][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, ah[m], acc[h][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TW; ++m) acc[h][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al[m], acc[h][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TW; ++m) acc[h][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah[m], acc[h][m], 0, 0, 0);
+    };
+    bf16x8 rh[WD], rl[WD];
+#pragma unroll
+    for (int s0 = 0; s0 < WD - 1; ++s0) { rh[s0] = wfrag(s0, 0); rl[s0] = wfrag(s0, 1); }
+#pragma unroll 1
+    for (int s0 = 0; s0 < STEPS; s0 += UNR) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int step = s0 + u;
+        if (step + WD - 1 < STEPS) { rh[(u + WD - 1) % WD] = wfrag(step + WD - 1, 0); rl[(u + WD - 1) % WD] = wfrag(step + WD - 1, 1); }
+        compute(step, rh[u % WD], rl[u % WD]);
+      }
+    }
+    stamp(2 + 2 * h);
+  }
+  {                                                               // + bias, once (the accumulators are dumped twice)
+    const int c0 = nb0 * 32 + 4 * lh;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const float4 b4 = *(const float4*)(bias + c0 + 8 * gq);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = 0; m < TW; ++m) { acc[h][m][4 * gq] += b4.x; acc[h][m][4 * gq + 1] += b4.y; acc[h][m][4 * gq + 2] += b4.z; acc[h][m][4 * gq + 3] += b4.w; }
+    }
+  }
+  __syncthreads();                                                // the input image is dead: the FRN arrays take its place
+
+  // ---------------- FRN (+ CoordAtt) + TLU on half images
+  float* xbh = lds;                       // [HPIX][C], quads swizzled by the local pixel index (frn_slot)
+  float* red = xbh + G::XBH;              // [GRP][C]
+  float* sc = red + G::RED;               // [C]
+  float* ph = sc + C;                     // [HOUT][C]: raw row means -> FRN-mapped -> a_h
+  float* pw = ph + HOUT * C;              // [HOUT][C]: raw column sums -> FRN-mapped means -> a_w
+  float* gl = xbh;                        // gate weights [w1 8C][b1 8][wh 8C][ww 8C][bh C][bw C] and mid [2 HOUT][8]: over xbh between the two dump rounds
+  float* mid = gl + 26 * C + 8;
+  const bool coord = g.w1 != nullptr;
+  // gate weights: requested now, written to LDS after the statistics (their latency runs under the two dump rounds)
+  float gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (coord) {
+    if (t < 8 * C) { gv[0] = g.w1[t]; gv[1] = g.wh[t]; gv[2] = g.ww[t]; }
+    if (t < C) { gv[3] = g.bh[t]; gv[4] = g.bw[t]; }
+    if (t < 8) gv[5] = g.b1[t];
+  }
+  auto dump = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < TW; ++m) {
+      const int pl = (mbl0 + m) * 32 + li, c0 = nb0 * 32 + 4 * lh;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *(float4*)(xbh + frn_slot(pl, c0 + 8 * gq, C)) = make_float4(acc[h][m][4 * gq], acc[h][m][4 * gq + 1], acc[h][m][4 * gq + 2], acc[h][m][4 * gq + 3]);
+    }
+  };
+  float ssq = 0.f;                        // this thread's share of the FRN statistic: channel t % C, pixels t / C + k GRP of both halves
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);      // (column item of this thread, summed over the two halves)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    dump(h);
+    __syncthreads();
+    {
+      const int c = t % C, gq = t / C;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      static_assert((HPIX / GRP) % 4 == 0, "four partial sums per thread");
+#pragma unroll 2
+      for (int pix = gq; pix < HPIX; pix += 4 * GRP) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float v = xbh[frn_slot(pix + u * GRP, c, C)]; s4[u] = fmaf(v, v, s4[u]); }
+      }
+      ssq += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+    if (coord) {
+      // items: [0, HROWS QPP): row means of this half's rows; [HROWS QPP, (HROWS + HOUT) QPP): column sums over this half's rows
+      static_assert((HROWS + HOUT) * QPP <= NT, "one pool item per thread");
+      if (t < (HROWS + HOUT) * QPP) {
+        const bool over_x = t < HROWS * QPP;
+        const int j = over_x ? t : t - HROWS * QPP, line = j / QPP, q = j % QPP;
+        constexpr int NK = HOUT;                                  // row length; a column holds HROWS = NK / 2 pixels of this half
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        const int nk = over_x ? NK : HROWS;
+        for (int k = 0; k < nk; k += 2) {
+          const int p0 = over_x ? line * HOUT + k : k * HOUT + line, p1 = over_x ? p0 + 1 : p0 + HOUT;
+          const float4 v0 = *(const float4*)(xbh + p0 * C + ((q ^ (p0 & 7)) << 2)), v1 = *(const float4*)(xbh + p1 * C + ((q ^ (p1 & 7)) << 2));
+          a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+          a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        }
+        if (over_x) *(float4*)(ph + (h * HROWS + line) * C + 4 * q) = make_float4((a0.x + a1.x) / (float)HOUT, (a0.y + a1.y) / (float)HOUT,
+                                                                                 (a0.z + a1.z) / (float)HOUT, (a0.w + a1.w) / (float)HOUT);
+        else { colsum.x += a0.x + a1.x; colsum.y += a0.y + a1.y; colsum.z += a0.z + a1.z; colsum.w += a0.w + a1.w; }
+      }
+    }
+    __syncthreads();                                              // the half image is read; the next dump may overwrite it
+  }
+  stamp(5);
+  red[(t / C) * C + t % C] = ssq;
+  if (coord && t >= HROWS * QPP && t < (HROWS + HOUT) * QPP) {
+    const int j = t - HROWS * QPP;
+    *(float4*)(pw + (j / QPP) * C + 4 * (j % QPP)) = make_float4(colsum.x / (float)HOUT, colsum.y / (float)HOUT, colsum.z / (float)HOUT, colsum.w / (float)HOUT);
+  }
+  if (coord) {                                                    // gate weights over the (dead) half image
+    if (t < 8 * C) { gl[t] = gv[0]; gl[8 * C + 8 + t] = gv[1]; gl[16 * C + 8 + t] = gv[2]; }
+    if (t < C) { gl[24 * C + 8 + t] = gv[3]; gl[25 * C + 8 + t] = gv[4]; }
+    if (t < 8) gl[8 * C + t] = gv[5];
+  }
+  __syncthreads();
+  if (t < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < GRP; ++q) s += red[q * C + t];
+    sc[t] = fw[t] * rsqrtf(s / (float)G::NPIX + eps);
+  }
+  __syncthreads();
+  if (coord) {
+    const float *g_w1 = gl, *g_b1 = gl + 8 * C, *g_wh = gl + 8 * C + 8, *g_ww = gl + 16 * C + 8, *g_bh = gl + 24 * C + 8, *g_bw = gl + 25 * C + 8;
+    // pools of the FRN output = FRN affine map of the raw pools
+    for (int i = t; i < 2 * HOUT * C; i += NT) ph[i] = fmaf(ph[i], sc[i % C], fb[i % C]);       // (ph and pw are contiguous)
+    __syncthreads();
+    for (int i = t; i < 2 * HOUT * 8; i += NT) {
+      const int r = i >> 3, m = i & 7;
+      const float* srcp = ph + r * C;                             // rows 0 .. HOUT - 1: ph, HOUT .. 2 HOUT - 1: pw
+      float a4[4] = {g_b1[m], 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int k = 0; k < C; k += 4) {
+        const float4 wv = *(const float4*)(g_w1 + m * C + k), xv = *(const float4*)(srcp + k);
+        a4[0] = fmaf(xv.x, wv.x, a4[0]); a4[1] = fmaf(xv.y, wv.y, a4[1]); a4[2] = fmaf(xv.z, wv.z, a4[2]); a4[3] = fmaf(xv.w, wv.w, a4[3]);
+      }
+      const float av = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      mid[i] = av * (fminf(fmaxf(av + 3.f, 0.f), 6.f) / 6.f);
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * HOUT * C; i += NT) {
+      const bool is_h = i < HOUT * C;
+      const int j = is_h ? i : i - HOUT * C, r = j / C, ch = j % C;
+      const float* wt = (is_h ? g_wh : g_ww) + ch * 8;
+      const float* mr = mid + (is_h ? r : HOUT + r) * 8;
+      const float4 w0 = *(const float4*)wt, w1v = *(const float4*)(wt + 4), m0 = *(const float4*)mr, m1 = *(const float4*)(mr + 4);
+      float av = (is_h ? g_bh : g_bw)[ch];
+      av = fmaf(m0.x, w0.x, av); av = fmaf(m0.y, w0.y, av); av = fmaf(m0.z, w0.z, av); av = fmaf(m0.w, w0.w, av);
+      av = fmaf(m1.x, w1v.x, av); av = fmaf(m1.y, w1v.y, av); av = fmaf(m1.z, w1v.z, av); av = fmaf(m1.w, w1v.w, av);
+      ph[i] = 1.f / (1.f + __expf(-av));
+    }
+    __syncthreads();                                              // gates final; the gate weights over xbh are dead
+  }
+  stamp(6);
+  const int64_t pbase = patch * G::NPIX;
+  constexpr int NQ = HPIX * QPP / NT;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    dump(h);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int i = t + NT * j, pix = i / QPP, ch = 4 * (i % QPP), yy = h * HROWS + pix / HOUT, xx = pix % HOUT;
+      const float4 v = *(const float4*)(xbh + frn_slot(pix, ch, C));
+      const float4 s4 = *(const float4*)(sc + ch), b4 = *(const float4*)(fb + ch);
+      float r[4] = {fmaf(v.x, s4.x, b4.x), fmaf(v.y, s4.y, b4.y), fmaf(v.z, s4.z, b4.z), fmaf(v.w, s4.w, b4.w)};
+      if (coord) {
+        const float4 g1 = *(const float4*)(ph + yy * C + ch), g2 = *(const float4*)(pw + xx * C + ch);
+        r[0] = r[0] * g2.x * g1.x; r[1] = r[1] * g2.y * g1.y; r[2] = r[2] * g2.z * g1.z; r[3] = r[3] * g2.w * g1.w;
+      }
+      const float4 t4 = *(const float4*)(tau + ch);
+      r[0] = fmaxf(r[0], t4.x); r[1] = fmaxf(r[1], t4.y); r[2] = fmaxf(r[2], t4.z); r[3] = fmaxf(r[3], t4.w);
+      const int64_t gp = pbase + h * HPIX + pix;
+      if (y) *(float4*)(y + gp * C + ch) = make_float4(r[0], r[1], r[2], r[3]);
+      if (ysp) store_split4(ysp + gp * ldsp + spl_col(ch), r);
+    }
+    if (h == 0) __syncthreads();
+  }
+  stamp(7);
+}
+
 // ---------------------------------------------------------------------------------------------- fused SandGlass block
 // One workgroup per patch, the whole block of models.py:182-235 (+ the outer residual of 383-389) with the patch's activation
 // resident in LDS (H * W * C = 32768 floats = 128 KiB: 32x32x32 or 16x16x64):
@@ -1178,6 +1473,41 @@ static int conv_block_launch(const uint16_t* x, int64_t ldx, int64_t patches, co
   return GIMS_OK;
 }
 
+// the two-workgroups-per-CU form of the 32 x 32 layers (ch_conv_block_half_kernel); GIMS_CH_HALF=0: the one-workgroup kernel (the cross-check)
+template <int CIN, int COUT, int STRIDE>
+static int conv_block_half_launch(const uint16_t* x, int64_t ldx, int64_t patches, const uint16_t* w, const float* bias, const float* fw, const float* fb, float eps,
+                                  gims::ChGateW G, const float* tau, float* y, uint16_t* ysp, int64_t ldsp, hipStream_t st) {
+  using namespace gims;
+  using Geo = HalfGeom<CIN, COUT, STRIDE>;
+  GIMS_LDS_ATTR((const void*)ch_conv_block_half_kernel<CIN, COUT, STRIDE>, Geo::LDS_BYTES);
+  static const int stagger = getenv("GIMS_CH_STAGGER") ? atoi(getenv("GIMS_CH_STAGGER")) : 8000;
+  static const bool prof_on = getenv("GIMS_CH_PROF") != nullptr;      // diagnostics: cycle stamps of one workgroup per launch (synchronous)
+  unsigned long long* dprof = nullptr;
+  if (prof_on) {
+    dprof = (unsigned long long*)device_once("ch_conv_half_prof", 8 * sizeof(unsigned long long), nullptr);
+    GIMS_CHECK_ARG(dprof, "gims_ch_conv_block: no profile buffer");
+  }
+  // GIMS_CH_HALF_LDS=<bytes>: pad the dynamic LDS (diagnostics: > 80 KB leaves ONE workgroup per CU -- what the co-residency is worth)
+  static const int pad = getenv("GIMS_CH_HALF_LDS") ? atoi(getenv("GIMS_CH_HALF_LDS")) : 0;
+  const int lds = pad > Geo::LDS_BYTES ? pad : Geo::LDS_BYTES;
+  if (pad) GIMS_LDS_ATTR((const void*)ch_conv_block_half_kernel<CIN, COUT, STRIDE>, lds);
+  hipLaunchKernelGGL((ch_conv_block_half_kernel<CIN, COUT, STRIDE>), dim3((unsigned)patches), dim3(512), lds, st, x, ldx, w, bias, fw, fb, eps, G, tau, y,
+                     ysp, ldsp, stagger, 2 * device_cus(), dprof);
+  GIMS_LAUNCH_CHECK();
+  if (prof_on) {
+    unsigned long long h[8];
+    GIMS_HIP(hipStreamSynchronize(st));
+    GIMS_HIP(hipMemcpy(h, dprof, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "ch_conv_block_half<%d,%d,%d> x %lld: load0 %llu  mfma0 %llu  load1 %llu  mfma1 %llu  dumps+stats+pools %llu  gates %llu  dumps+apply+store %llu  total %llu (cycles of one workgroup)\n",
+            CIN, COUT, STRIDE, (long long)patches, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
+  }
+  return GIMS_OK;
+}
+static bool ch_half() {
+  const char* e = getenv("GIMS_CH_HALF");         // read per call: the tests compare the two forms
+  return !e || atoi(e) != 0;
+}
+
 extern "C" int gims_ch_conv_block_first(const float* patches, int64_t n, const float* frn0_weight, const float* frn0_bias, float eps0, const float* tau0,
                                         const uint16_t* w_packed, const float* bias, const float* frn_weight, const float* frn_bias, float eps,
                                         const float* const* gate_w, const float* tau, float* y, uint16_t* y_split, int64_t ld_split, void* stream) {
@@ -1210,8 +1540,12 @@ extern "C" int gims_ch_conv_block(const uint16_t* x_split, int64_t ldx, int64_t 
   hipStream_t st = (hipStream_t)stream;
   const int key = hin * 1000000 + cin * 10000 + cout * 10 + stride;
   switch (key) {
-    case 32 * 1000000 + 32 * 10000 + 32 * 10 + 1: return conv_block_launch<32, 32, 32, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
-    case 32 * 1000000 + 32 * 10000 + 64 * 10 + 2: return conv_block_launch<32, 64, 32, 2>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+    case 32 * 1000000 + 32 * 10000 + 32 * 10 + 1:
+      if (ch_half()) return conv_block_half_launch<32, 32, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+      return conv_block_launch<32, 32, 32, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+    case 32 * 1000000 + 32 * 10000 + 64 * 10 + 2:
+      if (ch_half()) return conv_block_half_launch<32, 64, 2>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
+      return conv_block_launch<32, 64, 32, 2>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
     case 16 * 1000000 + 64 * 10000 + 64 * 10 + 1: return conv_block_launch<64, 64, 16, 1>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
     case 16 * 1000000 + 64 * 10000 + 128 * 10 + 2: return conv_block_launch<64, 128, 16, 2, false, CH_PP5>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);
     case 8 * 1000000 + 128 * 10000 + 128 * 10 + 1: return conv_block_launch<128, 128, 8, 1, false, CH_PP6>(x_split, ldx, patches, w_packed, bias, frn_weight, frn_bias, eps, G, tau, y, y_split, ld_split, st);

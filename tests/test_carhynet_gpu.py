@@ -108,6 +108,44 @@ def test_conv_block_layer_vs_conv2d():
         assert err < 2e-5, (hin, cin, cout, stride, err)
 
 
+@pytest.mark.parametrize("geom", [(32, 32, 1, True), (32, 32, 1, False), (32, 64, 2, False)])
+def test_conv_block_two_per_cu_equals_one_per_cu(monkeypatch, geom):
+    """The 32 x 32 layers in their two-workgroups-per-CU form (ch_conv_block_half_kernel: the patch goes through LDS in two halves, the FRN /
+    CoordAtt / TLU block runs on half images) against the one-workgroup kernel (GIMS_CH_HALF=0): same products in the same order; the FRN
+    statistic and the column pools are summed over the two halves in a different association, so agreement is to f32 rounding (1e-5 of values
+    of order 1), with and without CoordAtt gates, f32 and split-bf16 outputs, and a patch count that leaves workgroups of the last wave idle."""
+    from gims_amd import hip
+    cin, cout, stride, gates = geom
+    r = np.random.default_rng(17)
+    n, hin = 37, 32
+    ho = (hin - 1) // stride + 1
+    x = r.normal(size=(n, hin, hin, cin)).astype(np.float32)
+    x[3] *= 40.0                                                       # one patch of a very different scale (per-patch statistics must not mix)
+    w = (r.normal(size=(cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).cuda()      # noqa: E731
+    L = dict(wp=hip.pack_conv3_fragments(torch.from_numpy(w)).cuda(), b=dev(r.normal(size=cout) * 0.1))
+    F = dict(w=dev(1 + 0.2 * r.normal(size=cout)), b=dev(0.1 * r.normal(size=cout)), eps=1e-6)
+    tau = dev(-1 + 0.3 * r.normal(size=cout))
+    G = None
+    if gates:
+        G = dict(w1=dev(r.normal(size=(8, cout)) / 6), b1=dev(r.normal(size=8) * 0.1), wh=dev(r.normal(size=(cout, 8)) / 3), bh=dev(r.normal(size=cout) * 0.1),
+                 ww=dev(r.normal(size=(cout, 8)) / 3), bw=dev(r.normal(size=cout) * 0.1))
+    xs = hip.split_spl32(torch.from_numpy(x.reshape(-1, cin)).cuda())
+    outs = {}
+    for half in ("0", "1"):
+        monkeypatch.setenv("GIMS_CH_HALF", half)
+        y = torch.full((n, ho, ho, cout), float("nan"), dtype=torch.float32, device="cuda")
+        ysp = torch.zeros((n * ho * ho, 2 * cout), dtype=torch.bfloat16, device="cuda")
+        hip.ch_conv_block(xs, n, hin, cin, cout, stride, L, F, tau, G, y=y)
+        hip.ch_conv_block(xs, n, hin, cin, cout, stride, L, F, tau, G, y_split=ysp)
+        hi, lo = hip.spl32_planes(ysp)
+        outs[half] = (y.cpu().numpy(), (hi.float() + lo.float()).cpu().numpy().reshape(n, ho, ho, cout))
+    scale = np.abs(outs["0"][0]).max(axis=(1, 2, 3), keepdims=True)
+    assert np.isfinite(outs["1"][0]).all()
+    assert (np.abs(outs["1"][0] - outs["0"][0]) / scale).max() < 1e-5
+    assert (np.abs(outs["1"][1] - outs["1"][0]) <= np.abs(outs["1"][0]) * 2.0 ** -15 + 1e-30).all()      # the split output carries the same values
+
+
 def test_full_size_properties():
     """BASELINE config 5's size (descriptors for 2 x 8192 keypoints), where the CPU restatement is too slow: every patch is
     processed independently, so (1) the result does not depend on how the batch is chunked -- bit for bit --, (2) a patch
