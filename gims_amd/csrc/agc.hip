@@ -1571,8 +1571,6 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
   AgcWs* dws = (AgcWs*)work;
   char* base = (char*)work + agc_batch_header(n_images);
   int maxn = 0, maxnw = 0;
-  GIMS_LDS_ATTR((const void*)agc_cc_kernel<false>, AGC_CC_LDS_N * 8);
-  GIMS_LDS_ATTR((const void*)agc_iso_seq_kernel, AGC_MAX_N * 4 + (AGC_MAX_N / 32 + 2) * 4);
   std::vector<AgcWs> hws(n_images);
   for (int i = 0; i < n_images; ++i) {
     const gims_agc_image& im = images[i];
@@ -1594,6 +1592,9 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
     maxn = im.n > maxn ? im.n : maxn;
     maxnw = w->nw > maxnw ? w->nw : maxnw;
   }
+  // (every argument is validated before the first call into the HIP runtime)
+  GIMS_LDS_ATTR((const void*)agc_cc_kernel<false>, AGC_CC_LDS_N * 8);
+  GIMS_LDS_ATTR((const void*)agc_iso_seq_kernel, AGC_MAX_N * 4 + (AGC_MAX_N / 32 + 2) * 4);
   const int B = n_images;
   {
     const int rc = upload_table(hws.data(), sizeof(AgcWs) * (size_t)B, dws, s);

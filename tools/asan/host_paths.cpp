@@ -39,6 +39,43 @@ int main() {
   for (size_t i = 0; i < im.size(); ++i) { memset(&im[i], 0, sizeof(im[i])); im[i].n = 100 + 900 * (int)i; im[i].d = 256; im[i].ldd = 256; im[i].max_edges_dir = 64 * im[i].n; }
   EXPECT(gims_agc_workspace_bytes(im.data(), (int)im.size()) > 0);
   EXPECT(gims_agc_build(nullptr, 0, 15.0, 2.0, 7, nullptr, 0, nullptr) != GIMS_OK);
+  {   // rounds 4-5: gims_agc_build_ex (flags), the keypoint limit by name, workspace arithmetic at the largest published size and at the limit
+    EXPECT(gims_agc_max_keypoints() == 32768);
+    EXPECT(gims_agc_build_ex(nullptr, 0, 15.0, 2.0, 7, GIMS_AGC_ROBUST, nullptr, 0, nullptr) != GIMS_OK);
+    gims_agc_image big; memset(&big, 0, sizeof(big));
+    big.d = 256; big.ldd = 256;
+    for (int n : {2, 16384, 16385, 21163, 32768}) {
+      big.n = n; big.max_edges_dir = 64 * n;
+      const size_t wb = gims_agc_workspace_bytes(&big, 1);
+      EXPECT(wb > (size_t)n * (size_t)(n - 1) * 2);                                   // one word per pair of the strict upper triangle is in there
+    }
+    big.n = 32769; big.max_edges_dir = 64;                                             // over the limit: refused with the limit in the message
+    big.kpts = (const float*)0x1000; big.desc = (const float*)0x2000; big.kept = (int32_t*)0x3000; big.indptr = (int32_t*)0x4000;
+    big.indices = (int32_t*)0x5000; big.info = (int32_t*)0x6000;
+    EXPECT(gims_agc_build_ex(&big, 1, 15.0, 2.0, 7, 0, (void*)0x7000, (size_t)1 << 40, nullptr) == GIMS_EINVAL);
+    EXPECT(strstr(gims_last_error(), "32768") != nullptr);
+    big.n = 100; big.d = 48;                                                           // descriptor width not a multiple of 32
+    EXPECT(gims_agc_build_ex(&big, 1, 15.0, 2.0, 7, 0, (void*)0x7000, (size_t)1 << 40, nullptr) == GIMS_EINVAL);
+    big.d = 256;                                                                       // a workspace that is too small
+    EXPECT(gims_agc_build_ex(&big, 1, 15.0, 2.0, 7, GIMS_AGC_ROBUST, (void*)0x7000, 64, nullptr) == GIMS_EINVAL);
+  }
+  {   // round 5: guarded launches (gims_attn_guard) -- validation only
+    gims_attn_args aa; memset(&aa, 0, sizeof(aa));
+    EXPECT(gims_attention_ex(nullptr, nullptr) == GIMS_EINVAL);
+    EXPECT(gims_attention_ex(&aa, nullptr) == GIMS_EINVAL);
+    aa.qkv = (const uint16_t*)0x1000; aa.ld = 1536; aa.k_col = 256; aa.v_col = 512; aa.problems = (const gims_attn_problem*)0x2000; aa.n_problems = 1;
+    aa.max_n_q = 64; aa.n_heads = 4; aa.out = (float*)0x3000; aa.ld_out = 256;
+    aa.guard.stat = (uint64_t*)0x4000; aa.guard.kind = GIMS_GUARD_PEAKED; aa.guard.n_heads = 4;
+    EXPECT(gims_attention_ex(&aa, nullptr) == GIMS_EINVAL);                            // a guard without GIMS_ATTN_X3
+    aa.flags = GIMS_ATTN_X3; aa.guard.kind = 7;
+    EXPECT(gims_attention_ex(&aa, nullptr) == GIMS_EINVAL);                            // unknown guard kind
+    aa.guard.kind = GIMS_GUARD_RANGE; aa.guard.n_heads = 16;
+    EXPECT(gims_attention_ex(&aa, nullptr) == GIMS_EINVAL);                            // more heads than one wave evaluates
+    gims_linear_args lg; memset(&lg, 0, sizeof(lg));
+    lg.a0 = (const float*)0x1000; lg.w = (const void*)0x2000; lg.out_f32 = (float*)0x3000; lg.m = lg.n = lg.k = lg.k0 = 64; lg.lda0 = lg.ldw = lg.ldc = 64;
+    lg.guard.stat = (uint64_t*)0x4000; lg.guard.kind = GIMS_GUARD_PEAKED; lg.guard.n_heads = 4;
+    EXPECT(gims_linear(&lg, nullptr) == GIMS_EINVAL);                                  // a guard on a launch without pre-split operands
+  }
   // ---- evaluation: workspace arithmetic
   std::vector<gims_eval_pair> ep(3);
   for (size_t i = 0; i < ep.size(); ++i) { memset(&ep[i], 0, sizeof(ep[i])); ep[i].n0 = 500 + (int)i; ep[i].n1 = 400; ep[i].height = 480; ep[i].width = 640; }
