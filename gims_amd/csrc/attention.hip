@@ -1666,7 +1666,7 @@ extern "C" int gims_attention_ex(const gims_attn_args* args, void* stream) {
   // (environment read per call, not cached: the tests switch kernels with it)
   const bool f16 = (flags & GIMS_ATTN_F16) != 0;
   GIMS_CHECK_ARG(!(f16 && (flags & GIMS_ATTN_X3)), "gims_attention: GIMS_ATTN_F16 and GIMS_ATTN_X3 exclude each other");
-  if (stat && (flags & (GIMS_ATTN_X3 | GIMS_ATTN_F16))) {   // range of the operands as stored (measured launches of the half / calibration tiers: bf16 has f32's range)
+  if (stat && (flags & (GIMS_ATTN_X3 | GIMS_ATTN_F16)) && !(flags & GIMS_ATTN_NO_RANGE)) {   // range of the operands as stored (measured launches of the half / calibration tiers: bf16 has f32's range)
     const int rc = attention_range_launch(qkv, ld, q_col, k_col, v_col, problems, n_problems, n_heads, (flags & GIMS_ATTN_X3) ? 2 : (f16 ? 1 : 0), stat,
                                           (hipStream_t)stream);
     if (rc != GIMS_OK) return rc;

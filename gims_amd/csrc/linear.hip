@@ -480,6 +480,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   constexpr int ITERS = 32 / RPI;
   float* ep = (float*)smem + wave * (32 * PITCH);
   const int c8 = (lane % LPR) * 8, rsub = lane / LPR;
+  float rmax[3] = {0.f, 0.f, 0.f};                    // GIMS_LINEAR_OUT_F16 + range_stat: max |stored value| per 256-column block (Q | K | V)
 #pragma unroll
   for (int mi = 0; mi < T::MI; ++mi) {
 #pragma unroll
@@ -538,6 +539,14 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
           if (p.flags & GIMS_LINEAR_OUT_F16) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[e] = pack_h2_sat(v[2 * e], v[2 * e + 1]);
+            if (p.range_stat) {          // range of what the half attention will read (eight columns of ONE 256-column block: col % 8 == 0)
+              const float m8 = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                                     full ? fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))) : 0.f);
+              const int blk = col >> 8;
+              rmax[0] = blk == 0 ? fmaxf(rmax[0], m8) : rmax[0];
+              rmax[1] = blk == 1 ? fmaxf(rmax[1], m8) : rmax[1];
+              rmax[2] = blk == 2 ? fmaxf(rmax[2], m8) : rmax[2];
+            }
           }
           if (full && (p.ldc_bf16 & 7) == 0) *(uint4*)o = make_uint4(q[0], q[1], q[2], q[3]);
           else {
@@ -559,6 +568,18 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read-back complete before the slice is overwritten
    }
+  }
+  if ((p.flags & GIMS_LINEAR_OUT_F16) && p.range_stat) {
+    // one candidate per wave and block; the atomic only when it beats what is already there (a stale read can only be too small: the atomic then
+    // happens needlessly, never the other way round) -- positive floats order like their bit patterns
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float m = wave_max(rmax[b]);
+      if (lane == 0 && m > 0.f) {
+        unsigned long long* dst = (unsigned long long*)p.range_stat + b;
+        if ((unsigned long long)__float_as_uint(m) > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, (unsigned long long)__float_as_uint(m));
+      }
+    }
   }
 }
 
@@ -603,6 +624,8 @@ static int linear_validate(const gims_linear_args* a) {
   GIMS_CHECK_ARG(a->k0 == a->k || a->a1 != nullptr, "gims_linear: second A segment missing");
   GIMS_CHECK_ARG(a->out_f32 || a->out_bf16 || a->out_hi, "gims_linear: no output");
   GIMS_CHECK_ARG((a->out_hi == nullptr) == (a->out_lo == nullptr), "gims_linear: out_hi and out_lo come together");
+  GIMS_CHECK_ARG(!a->range_stat || (a->a0_lo && (a->flags & GIMS_LINEAR_OUT_F16) && a->out_bf16 && a->n <= 768 && (((uintptr_t)a->range_stat) & 7) == 0),
+                 "gims_linear: range_stat goes with pre-split operands, GIMS_LINEAR_OUT_F16, out_bf16, n <= 768, 8-byte aligned");
   GIMS_CHECK_ARG(!a->guard.stat || (a->a0_lo && (a->guard.kind == GIMS_GUARD_PEAKED || a->guard.kind == GIMS_GUARD_RANGE) && a->guard.n_heads > 0 &&
                                     a->guard.n_heads <= 15 && (((uintptr_t)a->guard.stat) & 7) == 0),
                  "gims_linear: a guard goes with pre-split operands, kind GIMS_GUARD_*, 8-byte aligned stat");

@@ -358,9 +358,11 @@ class GMatcher(nn.Module):
         """Fold the read-back of `lane` (None: of every lane) into the per-layer decision.  Called by a lane right after the
         host synchronisation of its next batch's graph build -- its previous batch, read-back included, has finished by then,
         so WHEN a measurement takes effect does not depend on timing -- and after forward()'s final synchronisation.
-        Decisions only ever move UP (bf16 -> f16 -> bf16x3) once the first measurement is in."""
+        Decisions only ever move UP (bf16 -> f16 -> bf16x3) once the first measurement is in.  Returns the number of layers a SETTLED table
+        moved up by in this call (forward() repeats its batch then; match_pairs' batches were redone on the device already)."""
         st = self.__dict__.get("_attn_auto")
         H = self._heads
+        moved = 0
         for ln, slot in list(self.__dict__.get("_attn_pending", {}).items()):
             if slot[1] is None or (lane is not None and ln != lane):
                 continue
@@ -390,6 +392,8 @@ class GMatcher(nn.Module):
                 for l in np.nonzero(want > np.asarray(st["mode"]))[0]:
                     st["mode"][l] = int(want[l])
                     st["switched"].append(int(l))
+                    moved += 1
+        return moved
 
     def _keep_attention_tiers(self, device):
         """TEST HOOK: carry the settled per-layer tier table over a change of the weights (which normally starts a new calibration), so that a
@@ -697,11 +701,16 @@ class GMatcher(nn.Module):
         qkv_s = self._act("qkv6", n_tot, 6 * D, torch.bfloat16) if any(ax3) else None
         qkv_of = lambda l: qkv_s if ax3[l] else qkv_b                                                       # noqa: E731
         # the half tier rounds the THREE-pass projection (f32 class) to half in the epilogue; the bf16 tier multiplies hi planes only
+        # (a settled split-bf16 layer is the top tier: nothing left to decide, nothing measured; a half layer's operand range is reported by
+        # its projection's epilogue -- range_stat -- instead of a scan of the Q | K | V buffer, 25 us per layer at 2 x 4096 x 8)
+        stat_of = lambda l: None if (stat is None or (st_calibrated and amode[l] == 2)) else stat[l]       # noqa: E731
         qkv_out_of = lambda l: (dict(out_split=qkv_s) if amode[l] == 2 else                                 # noqa: E731
-                                dict(out_bf16=qkv_b, flags=hip.LINEAR_OUT_F16) if amode[l] == 1 else dict(out_bf16=qkv_b, flags=self._qkv_flags))
-        stat_of = lambda l: None if stat is None else stat[l]                                               # noqa: E731
+                                dict(out_bf16=qkv_b, flags=hip.LINEAR_OUT_F16, range_stat=None if stat_of(l) is None else stat[l][self._heads])
+                                if amode[l] == 1 else dict(out_bf16=qkv_b, flags=self._qkv_flags))
         # the device-side verdict of 'auto' (see default_config): the guard of layer l's redo launches, None for a layer that needs none
-        guarded = stat is not None and cfg['attention_precision'] == 'auto' and st_calibrated
+        # (match_pairs returns without a host synchronisation: its verdict is drawn on the device, by guarded launches; forward() ends in one and
+        # repeats the batch itself when the statistic it reads back there moved a layer up -- no extra launches on the latency path)
+        guarded = stat is not None and cfg['attention_precision'] == 'auto' and st_calibrated and self.__dict__.get("_device_guards", False)
         if guarded and qkv_s is None:
             qkv_s = self._act("qkv6", n_tot, 6 * D, torch.bfloat16)
 
@@ -737,7 +746,7 @@ class GMatcher(nn.Module):
                     for l, L in enumerate(P["layers"]):
                         lst.append(la(L["qkv"], dpl, **qkv_out_of(l)))
                         lst.append(hip.op_attention(qkv_of(l), cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D,
-                                                    out_split=mpl, q_prescaled=True, x3=ax3[l], f16=amode[l] == 1, stat=stat_of(l)))
+                                                    out_split=mpl, q_prescaled=True, x3=ax3[l], f16=amode[l] == 1, stat=stat_of(l), no_range=amode[l] == 1))
                         gd = guard_of(l)
                         if gd is not None:      # the redo of this layer at split-bf16, launched always, executed only when the guard fires
                             lst.append(la(L["qkv"], dpl, out_split=qkv_s, guard=gd))
@@ -770,7 +779,7 @@ class GMatcher(nn.Module):
                     self._lin(L["qkv"], dpl, **qkv_out_of(l))
                 with St(("attn_cross" if L["cross"] else "attn_self") + sfx(l)):
                     hip.attention(qkv_of(l), cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D, out_split=mpl,
-                                  q_prescaled=True, x3=ax3[l], f16=amode[l] == 1, stat=stat_of(l))
+                                  q_prescaled=True, x3=ax3[l], f16=amode[l] == 1, stat=stat_of(l), no_range=amode[l] == 1)
                 gd = guard_of(l)
                 if gd is not None:
                     with St("guard"):
@@ -915,10 +924,9 @@ class GMatcher(nn.Module):
         with hip.pinned_stream():                 # one stream lookup for the ~150 launches of a call
             return self._forward_eval(data, **kwargs)
 
-    @torch.no_grad()
-    def _forward_eval(self, data, **kwargs):
-        radius, percentile, min_size = data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)
-        B = data['keypoints0'].shape[0]
+    def _forward_once(self, data, B, radius, percentile, min_size, last_attempt):
+        """One pass of forward()'s batch up to its host synchronisation.  None: the statistic this batch produced moved a layer of a SETTLED
+        'auto' table up -- the batch ran that layer on operands that did not suffice and the caller repeats it on the new table."""
         images = self._ingest([(data['keypoints' + side][b], data['descriptors' + side][b], data['scores' + side][b],
                                 data['image' + side].shape) for b in range(B) for side in ("0", "1")])
         items, pairs, mdesc = self._run(images, radius, percentile, min_size)
@@ -940,9 +948,28 @@ class GMatcher(nn.Module):
         for i, so in enumerate(self._status_offs.tolist()):        # (an index tensor would be a pageable upload in the middle of the stream)
             st[i:i + 1].copy_(uv[so:so + 1], non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        self._attention_stats_consume(self._lane)   # ('auto' attention: the first call's measurement decides the next call's kernels)
+        # 'auto' attention: the statistic of THIS batch is in (the first call's measurement decides the next call's kernels)
+        if self._attention_stats_consume(self._lane) and not last_attempt:
+            return None
         if (st.numpy() == 2.0).any():        # cannot happen (rescued inside gims_sinkhorn_match); never return silently wrong
             raise hip.GimsHipError("the Sinkhorn solve of this batch gave up and was not rescued")
+        return images, items, pairs, mdesc, views
+
+    @torch.no_grad()
+    def _forward_eval(self, data, **kwargs):
+        radius, percentile, min_size = data.get('radius', 25), data.get('percentile', 7), data.get('min_size', 8)
+        B = data['keypoints0'].shape[0]
+        # forward() ends in a host synchronisation, so its 'auto' verdict is drawn THERE (no guarded launches on the latency path): a batch
+        # whose statistic moves a settled layer up is repeated on the new table before anything is returned.  Tiers only move up, twice per
+        # layer at most: the loop is short and a repeat is rare (a layer sharpening for the first time).
+        self._device_guards = False
+        done = None
+        for attempt in range(4):
+            done = self._forward_once(data, B, radius, percentile, min_size, attempt == 3)
+            if done is not None:
+                break
+            self._attn_forward_repeats = getattr(self, "_attn_forward_repeats", 0) + 1
+        images, items, pairs, mdesc, views = done
         # the reference's in-place dict mutation (gmatcher.py:244-252); torch.stack raises for ragged B>1, as there
         for s, side in enumerate(("0", "1")):
             gs = [images[2 * b + s]["graph"] for b in range(B)]
@@ -1003,6 +1030,7 @@ class GMatcher(nn.Module):
         ``forward`` can only stack equal-sized pairs, gmatcher.py:244-249).  Each dict is mutated like ``forward``
         does and a list of per-pair result dicts (same keys as ``forward``) is returned."""
         tm0 = time.perf_counter()
+        self._device_guards = True          # no host synchronisation at the end of this call: the 'auto' verdict is drawn on the device
         n_lanes = int(self.config.get('streams', 1))
         if n_lanes < 2 or len(datas) < 2 * n_lanes:
             n_lanes = 1

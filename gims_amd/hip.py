@@ -50,7 +50,7 @@ class LinearArgs(C.Structure):
                 ("scale", C.c_float), ("a0_lo", C.c_void_p), ("a1_lo", C.c_void_p), ("out_hi", C.c_void_p),
                 ("out_lo", C.c_void_p), ("ld_split", C.c_int64), ("flags", C.c_int32),
                 ("conv_h", C.c_int32), ("conv_w", C.c_int32), ("conv_stride", C.c_int32), ("conv_reserved", C.c_int32),
-                ("guard", AttnGuard)]
+                ("guard", AttnGuard), ("range_stat", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -360,7 +360,7 @@ def _dev(t: torch.Tensor, dtype=None):
 
 
 def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None, out_bf16=None, act=ACT_NONE,
-                precision=PREC_F32, scale=1.0, n=None, spl=False, out_split=None, flags=0, conv=None, m=None, guard=None):
+                precision=PREC_F32, scale=1.0, n=None, spl=False, out_split=None, flags=0, conv=None, m=None, guard=None, range_stat=None):
     """Build the C struct.
     spl=False: a0/a1 f32 [m,k*]; w f32 [n,K] (PREC_F32) or bf16 hi plane with w_lo (PREC_BF16X3).
     spl=True : a0/a1/w are SPL32 bf16 buffers [rows, 2*k] (see include/gims_hip.h), precision BF16X3.
@@ -407,7 +407,7 @@ def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None
                       out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale),
                       _p(a0_lo), _p(a1_lo), _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
                       out_split.stride(0) if out_split is not None else 0, int(flags), 0, 0, 0, 0,
-                      guard if guard is not None else AttnGuard())
+                      guard if guard is not None else AttnGuard(), _p(range_stat))
 
 
 def linear_batch(arg_list, dev_args: torch.Tensor, precision=PREC_F32):
@@ -451,18 +451,18 @@ def op_linear(args: LinearArgs) -> Op:
     return o
 
 
-def _attn_flags(q_prescaled, x3, f16):
+def _attn_flags(q_prescaled, x3, f16, no_range=False):
     assert not (x3 and f16)
-    return (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0) | (ATTN_F16 if f16 else 0)
+    return (1 if q_prescaled else 0) | (ATTN_X3 if x3 else 0) | (ATTN_F16 if f16 else 0) | (ATTN_NO_RANGE if no_range else 0)
 
 
 def op_attention(qkv, problems, max_n_q, n_heads, out=None, q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False,
-                 stat=None, f16=False, guard=None) -> Op:
+                 stat=None, f16=False, guard=None, no_range=False) -> Op:
     o = Op()
     o.kind = 1
     o.u.att = AttnArgs(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0], max_n_q, n_heads, _p(out),
                        out.stride(0) if out is not None else 0, _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
-                       out_split.stride(0) if out_split is not None else 0, _attn_flags(q_prescaled, x3, f16), _p(stat),
+                       out_split.stride(0) if out_split is not None else 0, _attn_flags(q_prescaled, x3, f16, no_range), _p(stat),
                        guard if guard is not None else AttnGuard())
     return o
 
@@ -554,6 +554,7 @@ ATTN_Q_SCALE = 0.125 * 1.4426950408889634      # log2(e) / sqrt(64): what q_pres
 
 
 ATTN_X3 = 2
+ATTN_NO_RANGE = 8   # a measured launch leaves the range row alone (the projection reported it: linear_args(range_stat=...))
 ATTN_F16 = 4        # qkv holds IEEE half (gims_linear with LINEAR_OUT_F16); v_mfma_f32_32x32x16_f16 kernels
 
 
@@ -561,7 +562,7 @@ ATTN_STAT_SCALE = float(1 << 24)       # fixed point of the row maxima in gims_a
 
 
 def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: int, out=None,
-              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False, stat=None, f16=False, guard=None):
+              q_col=0, k_col=256, v_col=512, out_split=None, q_prescaled=False, x3=False, stat=None, f16=False, guard=None, no_range=False):
     """qkv bf16 [rows, ld]; problems int32 [P,4] (q_off, n_q, kv_off, n_kv) on device; out f32 [rows, ld_out]
     and/or out_split = SPL32 bf16 buffer [rows, >= 512].  q_prescaled: Q already carries ATTN_Q_SCALE.
     x3: qkv is the SPL32 split-bf16 buffer [rows, >= 1536] of the 3-pass projection (GIMS_ATTN_X3).
@@ -573,14 +574,14 @@ def attention(qkv: torch.Tensor, problems: torch.Tensor, max_n_q: int, n_heads: 
     if stat is not None:
         assert stat.dtype == torch.int64 and stat.is_contiguous() and stat.numel() >= 4 * (n_heads + 1) and stat.is_cuda
     if guard is not None:       # guarded launch (x3 only): a no-op unless the guard's statistic asks for the redo
-        op = op_attention(qkv, problems, max_n_q, n_heads, out, q_col, k_col, v_col, out_split, q_prescaled, x3, stat, f16, guard)
+        op = op_attention(qkv, problems, max_n_q, n_heads, out, q_col, k_col, v_col, out_split, q_prescaled, x3, stat, f16, guard, no_range)
         _check(lib.gims_attention_ex(C.byref(op.u.att), _stream()), "gims_attention_ex")
         return out if out is not None else out_split
     _check(lib.gims_attention_stat(_p(qkv), qkv.stride(0), q_col, k_col, v_col, _p(problems), problems.shape[0],
                                    max_n_q, n_heads, _p(out), out.stride(0) if out is not None else 0, _p(out_split),
                                    (out_split.data_ptr() + 64) if out_split is not None else None,
                                    out_split.stride(0) if out_split is not None else 0,
-                                   _attn_flags(q_prescaled, x3, f16), _p(stat), _stream()),
+                                   _attn_flags(q_prescaled, x3, f16, no_range), _p(stat), _stream()),
            "gims_attention")
     return out if out is not None else out_split
 

@@ -111,6 +111,11 @@ typedef struct gims_linear_args {
    * (yo*stride + ky - 1, xo*stride + kx - 1), or from the 128 zero bytes at a1 when that lies outside: no im2col buffer. */
   int32_t conv_h, conv_w, conv_stride, conv_reserved;
   gims_attn_guard guard;               /* pre-split operands (a0_lo != NULL) only: the launch is a no-op unless the guard fires; zero = always run */
+  /* pre-split operands with GIMS_LINEAR_OUT_F16 only: the launch also reports max |value| of what it stores into out_bf16, per block of
+   * 256 output columns (Q | K | V of the projection in front of a GIMS_ATTN_F16 launch): range_stat[b] = max(range_stat[b], float bits of
+   * the maximum) for column block b = col / 256 < 3, by integer atomics on the f32 bit patterns -- the range row of gims_attention_stat's
+   * accumulator (pass stat + 4 * n_heads), measured where the values are produced instead of by a scan of the buffer.  NULL: not measured. */
+  uint64_t* range_stat;
 } gims_linear_args;
 #define GIMS_LINEAR_UPPER 1
   /* GIMS_LINEAR_HI_ONLY (pre-split operands): multiply the hi planes only -- a plain bf16 product (2^-9 relative per
@@ -167,6 +172,9 @@ int gims_split_spl32(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, 
  * peaked softmaxes, where bf16 operands miss the reference's 1e-4 score bar; |Q|, |K|, |V| must stay below 65504 (the statistic of
  * gims_attention_stat reports them).  Not together with GIMS_ATTN_X3. */
 #define GIMS_ATTN_F16 4
+/* GIMS_ATTN_NO_RANGE: a measured launch (stat != NULL) leaves the range row of the accumulator alone -- the projection in front of it reported it
+ * (gims_linear_args.range_stat), or the caller has no use for it */
+#define GIMS_ATTN_NO_RANGE 8
 typedef struct gims_attn_problem { int32_t q_off, n_q, kv_off, n_kv; } gims_attn_problem;
 
 int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,

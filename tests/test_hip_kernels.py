@@ -313,6 +313,38 @@ def test_attention_f16_reference_follows_late_spikes(hip, monkeypatch, kernel):
     assert err.max() < 3e-3, f"worst row {int(err.argmax())}: {err.max():.3e}"
 
 
+def test_linear_reports_the_range_of_its_half_output(hip):
+    """gims_linear_args.range_stat: the 3-pass projection with a half epilogue reports max |stored value| per 256-column block (Q | K | V) into the
+    range row of the attention statistic -- the same numbers the scan of the buffer (attention_range_kernel, a measured GIMS_ATTN_F16 launch)
+    finds, without reading the buffer again."""
+    r = _rng(91)
+    rows, H = 3000, 4
+    x = r.normal(size=(rows, 256)).astype(np.float32)
+    w = (r.normal(size=(768, 256)) / 16.0).astype(np.float32)
+    w[256:512] *= 3.0
+    w[512:] *= 0.25
+    xs, ws = hip.split_spl32(_dev(x)), hip.split_spl32(_dev(w))
+    bias = _dev(r.normal(size=768).astype(np.float32))
+    stat_a = torch.zeros((H + 1, 4), dtype=torch.int64, device="cuda")
+    stat_b = torch.zeros((H + 1, 4), dtype=torch.int64, device="cuda")
+    qkv16 = torch.empty((rows, 768), dtype=torch.bfloat16, device="cuda")
+    hip.linear(xs, ws, bias=bias, out_bf16=qkv16, precision=hip.PREC_BF16X3, spl=True, flags=hip.LINEAR_OUT_F16, range_stat=stat_a[H])
+    pr = torch.tensor([(0, rows, 0, rows)], dtype=torch.int32, device="cuda")
+    out = torch.empty((rows, 256), dtype=torch.float32, device="cuda")
+    hip.attention(qkv16, pr, rows, H, out, f16=True, stat=stat_b)                   # the scan
+    a = stat_a.cpu().numpy()[H, :3].astype(np.uint32).view(np.float32)
+    b = stat_b.cpu().numpy()[H, :3].astype(np.uint32).view(np.float32)
+    vals = qkv16.view(torch.float16).float().abs().cpu().numpy()
+    ref = np.array([vals[:, :256].max(), vals[:, 256:512].max(), vals[:, 512:].max()])
+    np.testing.assert_array_equal(b, ref.astype(np.float32))
+    assert (a >= b).all() and (a <= b * (1 + 2.0 ** -10)).all(), (a, b)            # (the epilogue sees the f32 value, the scan its rounding to half)
+    assert (stat_a.cpu().numpy()[:H] == 0).all() and stat_a.cpu().numpy()[H, 3] == 0
+    stat_c = torch.zeros((H + 1, 4), dtype=torch.int64, device="cuda")
+    hip.attention(qkv16, pr, rows, H, out, f16=True, stat=stat_c, no_range=True)    # measured, but the range row is the producer's business
+    c = stat_c.cpu().numpy()
+    assert (c[H] == 0).all() and (c[:H, 1] > 0).all()
+
+
 @pytest.mark.parametrize("kind", ["peaked", "range"])
 @pytest.mark.parametrize("sharp", [1.0, 6.0])
 def test_attention_guarded_redo(hip, kind, sharp):

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header(tmp_path):
     """Sizes and field offsets of the ctypes mirrors against what a C compiler makes of include/gims_hip.h (gcc, LP64)."""
     import subprocess
-    pairs = [("gims_linear_args", hip.LinearArgs, ["a0", "w", "bias", "out_f32", "m", "act", "scale", "a0_lo", "out_hi", "ld_split", "flags", "conv_h", "guard"]),
+    pairs = [("gims_linear_args", hip.LinearArgs, ["a0", "w", "bias", "out_f32", "m", "act", "scale", "a0_lo", "out_hi", "ld_split", "flags", "conv_h", "guard", "range_stat"]),
              ("gims_attn_guard", hip.AttnGuard, ["stat", "mean_thr", "range_limit", "n_heads", "kind"]),
              ("gims_attn_args", hip.AttnArgs, ["qkv", "q_col", "problems", "n_heads", "out", "ld_split", "flags", "stat", "guard"]),
              ("gims_ot_problem", hip.OtProblem, []), ("gims_agc_image", hip.AgcImage, ["kept", "max_edges_dir", "info"]),
