@@ -43,4 +43,5 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[
     print(f"{k:34s} {cnt[(k, 'SQ_BUSY_CYCLES')]:5d} {b:16.0f} {m:16.0f} {m / b if b else 0:8.3f}")
 PY
 rm -rf $O/sq
+cp $R/bench_extra.json $O/${TAG}_bench_extra.json 2>/dev/null
 cat $O/${TAG}_bench_default.json | head -c 600
