@@ -11,6 +11,7 @@ mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 # the driver's command: headline 2x4096x8 + the 2x1024x32 block, CPU baseline included
 python bench.py --steps 20 --warmup 3 > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+cp $R/bench_extra.json $O/${TAG}_bench_extra.json 2>/dev/null      # the full record of THAT run (later runs of this script overwrite bench_extra.json)
 cd /tmp && export TMPDIR=/tmp
 # kernel stats of the SAME command (no CPU baseline: it only adds host time)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_default -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/ks_default.log 2>&1
@@ -43,5 +44,4 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[
     print(f"{k:34s} {cnt[(k, 'SQ_BUSY_CYCLES')]:5d} {b:16.0f} {m:16.0f} {m / b if b else 0:8.3f}")
 PY
 rm -rf $O/sq
-cp $R/bench_extra.json $O/${TAG}_bench_extra.json 2>/dev/null
 cat $O/${TAG}_bench_default.json | head -c 600
