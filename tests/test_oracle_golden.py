@@ -88,6 +88,27 @@ def test_e2e(name, synth_sd):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("name", [n for n in golden_names("ube2e_") if "n15382" not in n])
+def test_e2e_unbalanced(name, synth_sd):
+    """The oracle against the reference on UNBALANCED pairs (n0 != n1: image 1 = partners of a subset of image 0's keypoints + fresh outliers,
+    synth.make_pair_unbalanced): graph stages of both images, kept ids, matches, scores.  (The 15 382 / 14 870 fixture of the reference's README
+    configuration takes the reference four minutes on this CPU and is checked on the GPU only.)"""
+    g = load_golden(name)
+    n0, n1, nc, seed, rad, pct, ms, iters = [int(x) for x in g["meta"]]
+    pair = synth.make_pair_unbalanced(n0, n1, nc, seed)
+    assert pair["keypoints0"].shape[1] == n0 != pair["keypoints1"].shape[1] == n1 and int((pair["gt_perm"] >= 0).sum()) == nc
+    _check_agc(g, pair, rad, pct, ms)
+    data = pair_to_data(pair, rad, pct, ms)
+    out = O.gmatcher_forward(synth_sd, data, {"sinkhorn_iterations": iters, "match_threshold": float(g["match_threshold"])})
+    np.testing.assert_array_equal(np.asarray(data["kept_kpts0_indices"][0]), g["out/kept0"])
+    np.testing.assert_array_equal(np.asarray(data["kept_kpts1_indices"][0]), g["out/kept1"])
+    np.testing.assert_array_equal(out["matches0"][0].numpy(), g["out/matches0"])
+    np.testing.assert_array_equal(out["matches1"][0].numpy(), g["out/matches1"])
+    np.testing.assert_allclose(out["matching_scores0"][0].numpy(), g["out/matching_scores0"], atol=5e-5)
+    np.testing.assert_allclose(out["matching_scores1"][0].numpy(), g["out/matching_scores1"], atol=5e-5)
+    assert (g["out/matches0"] < 0).any() and (g["out/matches1"] < 0).any()      # rows AND columns end in the dustbin
+
+
 @pytest.mark.parametrize("name", golden_names("full_"))
 def test_full_with_intermediates(name, synth_sd):
     g = load_golden(name)
