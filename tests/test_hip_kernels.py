@@ -1186,6 +1186,40 @@ def test_agc_above_16384_keypoints_vs_oracle(hip, n):
         hip.agc_workspace_bytes(hip.make_agc_images([big]))
 
 
+def test_agc_at_the_keypoint_limit(hip, monkeypatch):
+    """32 768 keypoints per image, the library's limit (too large for the CPU oracle in a test: 4 GB of similarities): size-independent properties
+    instead -- the window flow and the robust flow (both verified on the device) agree bit for bit, kept ids ascend, the CSR is symmetric with
+    sorted rows and no self loops, every kept node has a neighbour, and the counters are consistent."""
+    n = hip.agc_max_keypoints()
+    r = _rng(32768)
+    side = 8.66 * np.sqrt(n)                 # the density of gims_amd.synth's canvases: about nine radius-15 neighbours per point
+    kp = (r.random(size=(n, 2)) * side).astype(np.float32)
+    de = r.normal(size=(n, 256)).astype(np.float32)
+    outs = {}
+    for flow in ("window", "robust"):
+        monkeypatch.delenv("GIMS_AGC_ROBUST", raising=False)
+        if flow == "robust":
+            monkeypatch.setenv("GIMS_AGC_ROBUST", "1")
+        outs[flow] = _run_agc(hip, kp, de, 15, 2, 7)
+    monkeypatch.delenv("GIMS_AGC_ROBUST", raising=False)
+    for a, b in zip(outs["window"], outs["robust"]):
+        np.testing.assert_array_equal(a, b)
+    kept, indptr, indices, inf = outs["window"]
+    assert int(inf[7]) == 0 and int(inf[0]) == len(kept) > 0.9 * n and int(inf[1]) == len(indices) == int(indptr[-1])
+    assert (np.diff(kept) > 0).all() and kept[-1] < n
+    deg = np.diff(indptr)
+    assert (deg > 0).all()
+    dst = np.repeat(np.arange(len(kept)), deg)
+    assert (indices != dst).all() and indices.min() >= 0 and indices.max() < len(kept)
+    key = indices.astype(np.int64) * len(kept) + dst
+    assert (np.diff(key.reshape(-1)[np.argsort(dst, kind="stable")]) != 0).any()
+    fwd = np.sort(indices.astype(np.int64) * len(kept) + dst)
+    bwd = np.sort(dst.astype(np.int64) * len(kept) + indices)
+    np.testing.assert_array_equal(fwd, bwd)                                   # every edge in both directions
+    for i in (0, len(kept) // 3, len(kept) - 1):
+        assert (np.diff(indices[indptr[i]:indptr[i + 1]]) > 0).all()          # rows sorted, no duplicates
+
+
 @pytest.mark.parametrize("resident", ["0", "2"])
 def test_sinkhorn_full_size_marginals(hip, monkeypatch, resident):
     """BASELINE size (4096 x 4096, 100 iterations), too large for the CPU oracle in a test: size-independent property of the
