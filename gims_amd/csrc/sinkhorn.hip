@@ -342,10 +342,10 @@ __device__ __forceinline__ void ot_argmax_step(float& bv, int& bi) {
   if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
 }
 
-template <int CPT>
+template <int CPT, int RS = OT_R>      // RS rows per slab (8; 2 for the 8-quad instance of problems wider than 16 384 columns: registers)
 __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict__ probs) {
-  __shared__ float rv[16][OT_R];
-  __shared__ int ri[16][OT_R];
+  __shared__ float rv[16][RS];
+  __shared__ int ri[16][RS];
   const OtDev p = probs[blockIdx.y];
   if ((int)blockIdx.x >= p.G) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
@@ -361,15 +361,15 @@ __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict
     cb[s] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     cbi[s] = make_int4(0, 0, 0, 0);
   }
-  const int n_slabs = (p.n + OT_R - 1) / OT_R;
-  // all OT_R x CPT row pieces of a slab are requested before the first one is used (clamped rows: unconditional loads), and the NEXT slab's
+  const int n_slabs = (p.n + RS - 1) / RS;
+  // all RS x CPT row pieces of a slab are requested before the first one is used (clamped rows: unconditional loads), and the NEXT slab's
   // pieces are requested before this slab's reductions: row by row the kernel paid one HBM latency per row (12.8 us per 8-row slab, 2.7 TB/s)
-  float4 zs[OT_R][CPT], zn[OT_R][CPT];
-  float us[OT_R], un[OT_R];
-  auto request = [&](int slab, float4 (&zd)[OT_R][CPT], float (&ud)[OT_R]) __attribute__((always_inline)) {
-    const int r0 = slab * OT_R;
+  float4 zs[RS][CPT], zn[RS][CPT];
+  float us[RS], un[RS];
+  auto request = [&](int slab, float4 (&zd)[RS][CPT], float (&ud)[RS]) __attribute__((always_inline)) {
+    const int r0 = slab * RS;
 #pragma unroll
-    for (int r = 0; r < OT_R; ++r) {
+    for (int r = 0; r < RS; ++r) {
       int rowc = r0 + r < p.n ? r0 + r : p.n - 1;
       rowc = rowc < 0 ? 0 : rowc;
       ud[r] = p.u[rowc];
@@ -382,16 +382,16 @@ __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict
   };
   if ((int)blockIdx.x < n_slabs) request(blockIdx.x, zn, un);
   for (int slab = blockIdx.x; slab < n_slabs; slab += p.G) {
-    const int r0 = slab * OT_R;
+    const int r0 = slab * RS;
 #pragma unroll
-    for (int r = 0; r < OT_R; ++r) {
+    for (int r = 0; r < RS; ++r) {
       us[r] = un[r];
 #pragma unroll
       for (int s = 0; s < CPT; ++s) zs[r][s] = zn[r][s];
     }
     if (slab + p.G < n_slabs) request(slab + p.G, zn, un);
 #pragma unroll
-    for (int r = 0; r < OT_R; ++r) {
+    for (int r = 0; r < RS; ++r) {
       const int row = r0 + r;
       float bv = -INFINITY;
       int bi = 0x7fffffff;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict
       }
     }
     __syncthreads();
-    if (t < OT_R && r0 + t < p.n) {
+    if (t < RS && r0 + t < p.n) {
       float bv = rv[0][t];
       int bi = ri[0][t];
       for (int w = 1; w < nw; ++w) {
@@ -1124,7 +1124,7 @@ static void ot_launch_shape(const gims_ot_problem* pr, int np, int& threads, int
 // workgroups per problem.  Large workgroups (one resident per CU) run persistent-style: ~256 in total, each
 // walking several slabs with the prefetch above; small workgroups want ~4 per CU for latency hiding.
 static int ot_G(int n, int np, int threads, int cpt) {
-  const int rows = cpt >= 4 ? 2 : (cpt == 2 ? 4 : OT_R);   // rows per slab of ot_iter_kernel<CPT, R>
+  const int rows = cpt > 4 ? 1 : (cpt >= 3 ? 2 : (cpt == 2 ? 4 : OT_R));   // rows per slab of ot_iter_kernel<CPT, R>
   const int total = threads >= 1024 ? 256 : (threads >= 512 ? 512 : 1024);
   int cap = total / (np > 0 ? np : 1);
   if (cap < 4) cap = 4;
@@ -1169,7 +1169,7 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   hipStream_t s = (hipStream_t)stream;
   int threads, cpt, maxn, maxm;
   ot_launch_shape(pr, np, threads, cpt, maxn, maxm);
-  GIMS_CHECK_ARG(cpt <= 4, "gims_sinkhorn_match: m=%d too large (max 16384)", maxm);
+  GIMS_CHECK_ARG(cpt <= 8, "gims_sinkhorn_match: m=%d too large (max 32768 columns: a thread of the streamed kernels owns at most 8 column quads)", maxm);
   std::vector<OtDev> hprob(np);
   char* base = (char*)work;
   size_t off = al256(sizeof(OtDev) * (size_t)np);
@@ -1213,7 +1213,8 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     for (int it = 0; it < iters; ++it) {
       if (cpt == 1) hipLaunchKernelGGL((ot_iter_kernel<1, 8>), gi, dim3(threads), 0, s, dp, alpha, rescue);
       else if (cpt == 2) hipLaunchKernelGGL((ot_iter_kernel<2, 4>), gi, dim3(threads), 0, s, dp, alpha, rescue);
-      else hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha, rescue);
+      else if (cpt <= 4) hipLaunchKernelGGL((ot_iter_kernel<4, 2>), gi, dim3(threads), 0, s, dp, alpha, rescue);
+      else hipLaunchKernelGGL((ot_iter_kernel<8, 1>), gi, dim3(threads), 0, s, dp, alpha, rescue);      // 16 384 < m <= 32 768 (round 5: the graph build's limit)
       hipLaunchKernelGGL(ot_colreduce_kernel, gc, dim3(1024), 0, s, dp, -1, rescue);
     }
   };
@@ -1255,7 +1256,9 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
   }
   if (cpt == 1) hipLaunchKernelGGL(ot_select_kernel<1>, gi, dim3(threads), 0, s, dp);
   else if (cpt == 2) hipLaunchKernelGGL(ot_select_kernel<2>, gi, dim3(threads), 0, s, dp);
-  else hipLaunchKernelGGL(ot_select_kernel<4>, gi, dim3(threads), 0, s, dp);
+  // (two rows per slab for the 4- and 8-quad instances: with eight, the two slabs' worth of staged rows are 256-512 registers per lane: 1.1 KB of scratch)
+  else if (cpt <= 4) hipLaunchKernelGGL((ot_select_kernel<4, 2>), gi, dim3(threads), 0, s, dp);
+  else hipLaunchKernelGGL((ot_select_kernel<8, 2>), gi, dim3(threads), 0, s, dp);
   hipLaunchKernelGGL(ot_colbest_kernel, dim3(cdiv(maxm, 32), np), dim3(256), 0, s, dp);
   const int mx = maxn > maxm ? maxn : maxm;
   hipLaunchKernelGGL(ot_mutual_kernel, dim3(cdiv(mx, 256), np), dim3(256), 0, s, dp, match_threshold);
