@@ -417,6 +417,30 @@ def test_match_pairs_ragged_equals_forward(models):
         assert d["keypoints0"].shape[1] == o["matches0"].shape[1]
 
 
+def test_match_pairs_extreme_shapes_equal_forward(models):
+    """One ragged batch holding very different problems -- 6000 / 300 and 300 / 6000 keypoints (tall and wide score matrices: the on-chip Sinkhorn
+    geometry, the attention launch shapes and the score GEMM all see n0 >> n1 and n1 >> n0), a 64 / 64 pair, a 9000 / 8000 pair (streamed
+    Sinkhorn) next to pairs that solve on chip -- against forward() on each pair alone: indices equal, scores within 5e-5 (the attention kernel a
+    launch takes depends on the batch, so the bits need not be)."""
+    m = models[("bf16x3", 20)]
+    # (radius 25 / min_size 3: the 300-keypoint images lie on the 6000-keypoint canvas, a twentieth of the usual density)
+    specs = [(6000, 300, 250, 3201), (300, 6000, 250, 3202), (64, 64, 50, 3203), (9000, 8000, 7000, 3204), (1500, 900, 700, 3001)]
+    pairs = [synth.make_pair_unbalanced(a, b, c, sd, canvas=synth.canvas_for(max(a, b))) for a, b, c, sd in specs]
+    singles = [m(pair_to_data(p, 25, 2, 3, device="cuda")) for p in pairs]
+    outs = m.match_pairs([pair_to_data(p, 25, 2, 3, device="cuda") for p in pairs])
+    torch.cuda.synchronize()
+    assert (m.sinkhorn_status() == 0).all()
+    for (a, b, c, sd), o, s1 in zip(specs, outs, singles):
+        m0, r0 = o["matches0"].cpu().numpy(), s1["matches0"].cpu().numpy()
+        sc, rs = o["matching_scores0"].cpu().numpy(), s1["matching_scores0"].cpu().numpy()
+        assert m0.shape == r0.shape, (a, b)
+        # rows whose decision is conditioned worse than the tolerance between two attention kernels may flip; there are next to none
+        differ = m0 != r0
+        assert differ.mean() < 2e-3, (a, b, int(differ.sum()))
+        assert np.abs(sc - rs)[~differ].max() < 5e-5, (a, b)
+        assert (m0 >= 0).sum() > 0.5 * c * (0.2 if min(a, b) < 1000 else 1.0), (a, b, int((m0 >= 0).sum()))
+
+
 def test_errors_like_reference():
     m = GMatcher({}).eval()
     pair = synth.make_pair(64, 1000)
