@@ -17,8 +17,18 @@
 // So the two wide edges (32 participants) never leave the XCD, and the one edge that crosses XCDs has 4 participants and
 // 0.5 KB -- no all-gather of G at all, because a workgroup only ever needs G for its own columns.
 // Numerics: the lazy-scaling form of ot_resident_kernel (K of the last derivation is never rewritten, transport matrix =
-// diag(F) K diag(G), u and v accumulated in the log domain, K re-derived from Z, u, v every `refresh` iterations and on the
-// last one), fixed summation orders everywhere: bitwise deterministic.
+// diag(F) K diag(G), u and v accumulated in the log domain, K re-derived from Z, u, v on the last iteration and WHEN NEEDED before it),
+// fixed summation orders everywhere: bitwise deterministic.
+// When a derivation is needed (round 5).  K = exp(Z + u + v) is formed in f32: an entry below e^-87 at the derivation is zero from then on,
+// whatever the factors do to it later.  That is harmless while the entry stays negligible -- and wrong once F_i G_j has grown by enough to make
+// it matter: the dustbin column of a SPARSE pair (u up by 55, v_bin up by 37 over 100 iterations: entries that started at e^-120 end as the
+// dominant terms of their rows) cost 1e-2 on the scores without a mid-solve derivation, while dense pairs (growth <= 41) lose nothing.  A fixed
+// period of 50 served both at the price of one sweep of Z per solve; now every workgroup flags the iteration at whose end one of ITS factors
+// exceeds a bound (log F > 32 or log G > 20: an entry can then have grown by <= 52 + what the lag adds, i.e. anything that can matter, >= e^-26
+// of a row total, was >= e^-87 when K was formed), and every fourth iteration is a candidate: it re-derives iff a flag was raised in the
+// iterations (max(c - 8, last derivation), c - 4].  The decision is the same in every workgroup of the problem: a workgroup that has finished
+// iteration k has, through the two exchanges of that iteration, seen data that every other workgroup published after finishing iteration k - 1
+// (its flag store, fenced, precedes that), so flags of iterations <= c - 3 are final when anybody reads them at the top of iteration c - 1.
 // Exchange protocol: no barrier; every exchanged value is >= +0 and carries the parity of its iteration in the sign bit,
 // readers re-read until it matches (bounded: a wait that runs out flags status 2 and the caller's rescue re-solves).
 // The column edge is double-buffered by iteration parity (its readers are not ordered against its next writer).
@@ -49,10 +59,11 @@ struct OtR2Dev {
   float* cpart;        // [2][nx][nc][R2_CSEG]  partial column sums (slot 128 = the dustbin column, last block only)
   float* mpart;        // [nx][nc][rbs]  partial row maxima of Z (start potentials, exchanged once)
   int* placement;      // [1] set to 1 by any workgroup whose XCC id is not blockIdx % 8
+  int* rflag;          // [iters + 8] adaptive re-derivation: rflag[s] != 0 <=> at the end of iteration s some cumulative factor had grown past its bound
 };
 struct OtR2Args {
   const OtR2Dev* probs; const OtR2Block* blocks;
-  float alpha; int iters, refresh, wt_local;
+  float alpha; int iters, refresh, wt_local;      // refresh > 0: fixed period; 0: adaptive (rflag); < 0: the final derivation only
   int init_inside;     // 1: the start potentials u0 = -max(alpha, row max of Z), v0 = 0 are formed in here (no ot_init_kernel sweep of Z)
   unsigned long long* prof;
 };
@@ -348,14 +359,34 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
     __syncthreads();
   }
 
+  __shared__ int nf_lds;                                     // the candidate's verdict (adaptive re-derivation), workgroup-uniform
+  int last_fresh = 0;                                        // iteration of the last derivation (the start potentials count as one)
+  bool pend_fresh = false;                                   // next_fresh of the previous iteration
+  constexpr float R2_F_BOUND = 7.9e13f, R2_G_BOUND = 4.85e8f;      // e^32, e^20 (see the header)
   for (int it = 0; it < a.iters; ++it) {
     // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration (as loop invariants the
     // compiler keeps their hoisted addresses alive next to the 192 registers of P)
     int tq = threadIdx.x;
     asm volatile("" : "+v"(tq));
     const int t = tq, lane = t & 63, wave = t >> 6, cg = t & 7, rg = t >> 3;
-    const bool fresh = (it == 0 && !a.init_inside) || (it > 0 && (it == a.iters - 1 || (a.refresh > 0 && it % a.refresh == 0)));
-    const bool next_fresh = it + 1 < a.iters && (it + 2 == a.iters || (a.refresh > 0 && (it + 1) % a.refresh == 0));
+    const bool fresh = (it == 0 && !a.init_inside) || (it > 0 && (it == a.iters - 1 || pend_fresh));
+    bool next_fresh = it + 1 < a.iters && (it + 2 == a.iters || (a.refresh > 0 && (it + 1) % a.refresh == 0));
+    if (fresh) last_fresh = it;
+    if (a.refresh == 0 && !next_fresh && ((it + 1) & 3) == 0 && it + 1 >= 8 && it + 2 < a.iters) {
+      // candidate c = it + 1: flags of the iterations c - 7 .. c - 4 that lie behind the last derivation (uniform in the workgroup and, by the
+      // argument in the header, in the problem)
+      const int c = it + 1;
+      if (t < 64) {
+        const int sidx = c - 4 - (t & 3);
+        const int f = (t < 4 && sidx > last_fresh) ? __hip_atomic_load(p.rflag + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const unsigned long long any = __ballot(f != 0);
+        if (t == 0) nf_lds = any != 0ull ? 1 : 0;
+      }
+      __syncthreads();
+      next_fresh = nf_lds != 0;
+      __syncthreads();                                       // (nf_lds is rewritten four iterations later at the earliest; this keeps the read and that write apart without relying on it)
+    }
+    pend_fresh = next_fresh;
     const unsigned tagbit = (unsigned)(it & 1) << 31;
     const unsigned xtagbit = (unsigned)((it >> 1) & 1) << 31;
     auto tg = [&](float x) { return __uint_as_float(__float_as_uint(x) | tagbit); };
@@ -552,6 +583,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
         for (int e = 0; e < 4; ++e) tot[e] += __shfl_xor(tot[e], 16, 64);
       }
       if (fc == 0 && vmask) {
+        bool fgrow = false;
         f32x4 fw, uo = *(const f32x4*)(uo_l + 4 * fq), fo = *(const f32x4*)(fo_l + 4 * fq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -565,11 +597,16 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
             const float du = (s < nrl ? p.norm : p.log_mu_bin) - logf(tr);
             uo[e] += du;
             fo[e] *= __expf(du);
+            if (fo[e] > R2_F_BOUND) fgrow = true;
           }
           fw[e] = tg(fo[e]);
         }
         *(f32x4*)(uo_l + 4 * fq) = uo;
         *(f32x4*)(fo_l + 4 * fq) = fo;
+        if (a.refresh == 0 && fgrow) {                                       // (before this iteration's publishes of this lane: they order it for the readers)
+          __hip_atomic_store(p.rflag + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __threadfence();
+        }
         if (next_fresh) {                                                    // u first, acknowledged, then the tagged F readers wait on
           if (wt) r2_st4_wt(fb + p.rbs + fs0, uo); else r2_st4_plain(fb + p.rbs + fs0, uo);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -714,6 +751,10 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
         gown *= __expf(dv);
         vown_l[t] = vown;
         gown_l[t] = gown;
+        if (a.refresh == 0 && gown > R2_G_BOUND) {
+          __hip_atomic_store(p.rflag + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __threadfence();
+        }
       }
       gvec[t] = own ? (next_fresh ? vown : gown) : (next_fresh ? 0.f : 1.f);
     }
@@ -798,6 +839,7 @@ static OtR2Plan plan_class(const OtR2Host* pr, int np, int iters) {
     const int rbf = r2_up4(cdiv(rb + 1, nc)), rbs = nc * rbf;
     if (rbf > R2_FOLD || rb > r2_rbmax() || r2_up4(cdiv(pr[i].m, nc)) > 128) return P;
     b += 2 * r2_al((size_t)nx * nc * rbs * 4) + r2_al((size_t)nx * 2 * rbs * 4) + r2_al((size_t)2 * nx * nc * R2_CSEG * 4);
+    b += r2_al((size_t)(iters + 8) * 4);                               // rflag
   }
   P.bytes = b;
   P.ok = true;
@@ -896,6 +938,11 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
   }
   // exchange buffers start with every sign bit set: iteration 0 waits for sign 0
   GIMS_HIP(hipMemsetAsync(base + ex0, 0xFF, off - ex0, s));
+  {   // the re-derivation flags of all problems, zeroed (behind the exchange buffers)
+    const size_t rf0 = off, rfb = r2_al((size_t)(iters + 8) * 4);
+    for (int i = 0; i < np; ++i) { hd[i].rflag = (int*)(base + off); off += rfb; }
+    GIMS_HIP(hipMemsetAsync(base + rf0, 0, off - rf0, s));
+  }
   GIMS_HIP(hipMemsetAsync(dplace, 0, 256, s));
   int rc = upload_table(hd.data(), sizeof(OtR2Dev) * (size_t)np, dprob, s);
   if (rc != GIMS_OK) return rc;
@@ -914,12 +961,8 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
   // device; read back lazily: the flag of call k is looked at by call k + 1, without a synchronisation of its own)
   if (*st->h_place) st->wt_local = 1;
   const int wt_local = st->wt_local;
-  // K is re-derived from Z, u, v on the last iteration and every `refresh` iterations before it: that bounds the dynamic range of the cumulative
-  // factors F, G.  Measured in round 5: without the mid-solve derivation (period 100) the stage is 0.18 ms shorter at 2 x 4096 x 8 and every
-  // golden of 256 ... 15 382 keypoints is unchanged -- but a SPARSE pair (45 kept keypoints, most rows and columns ending in the dustbin: the
-  // potentials move by tens of nats) loses 1e-2 on its scores: factors near e^-80 push the products into f32's subnormals, sums that are wrong
-  // but still inside (0, 3e38), which no range guard sees.  The period stays 50.
-  const int refresh = r2_env("GIMS_OT_REFRESH", 50);
+  // GIMS_OT_REFRESH: k > 0 = a derivation every k iterations (rounds 2-4: 50); 0 (default) = adaptive, see the header; -1 = the final one only
+  const int refresh = r2_env("GIMS_OT_REFRESH", 0);
   const int prof = r2_env("GIMS_OT_PROF", 0);
   for (int gi = 0; gi < P.ngroups; ++gi) {
     OtR2Block* dblk = (OtR2Block*)(base + off); off += r2_al(sizeof(OtR2Block) * 512);

@@ -721,6 +721,46 @@ def test_sinkhorn_history_of_a_ragged_batch(hip):
         np.testing.assert_allclose(full, ref, atol=1e-3)
 
 
+@pytest.mark.parametrize("n,m,scale", [(45, 28, 25.0), (307, 305, 25.0), (1200, 700, 20.0), (2100, 1900, 20.0), (4096, 4096, 12.0), (900, 130, 30.0)])
+def test_sinkhorn_adaptive_rederivation(hip, monkeypatch, n, m, scale):
+    """The on-chip kernel re-derives K = exp(Z + u + v) mid-solve only when a cumulative factor has grown past its bound (round 5; a fixed period of 50
+    before).  Score matrices with a wide range and FEW strong partners -- most rows and columns end in the dustbin, the potentials move by tens of nats
+    over 100 iterations (the regime of test_sparse_graph_few_kept_vs_oracle, where a solve WITHOUT any mid-solve derivation is off by 1e-1 on the
+    potentials) -- at sizes with one and with several row groups and column blocks: the adaptive solve, the fixed-period solve and the streamed
+    log-domain solve agree, and the adaptive solve neither runs out a bounded wait (a workgroup deriving while its neighbours do not would hang the exchange) nor trips
+    the numeric range guard."""
+    r = _rng(n * 7 + m)
+    z = (r.normal(size=(n, m)) * scale + 60.0).astype(np.float32)
+    k = max(2, min(n, m) // 6)
+    z[r.permutation(n)[:k], r.permutation(m)[:k]] += 3.0 * scale                  # a sixth of the rows have a partner
+    ld = (m + 3) // 4 * 4
+    outs, rescued = {}, {}
+    for mode, refresh in (("0", "50"), ("2", "50"), ("2", "0")):
+        before = hip.sinkhorn_rescues()
+        monkeypatch.setenv("GIMS_OT_RESIDENT", mode)
+        monkeypatch.setenv("GIMS_OT_REFRESH", refresh)
+        zs = torch.zeros((n, ld), dtype=torch.float32, device="cuda")
+        zs[:, :m] = _dev(z)
+        it = dict(scores=zs, n=n, m=m, matches0=torch.empty(n, dtype=torch.int64, device="cuda"), matches1=torch.empty(m, dtype=torch.int64, device="cuda"),
+                  mscores0=torch.empty(n, device="cuda"), mscores1=torch.empty(m, device="cuda"), uv=torch.empty(n + m + 3, device="cuda"))
+        probs = hip.make_ot_problems([it])
+        work = torch.empty(hip.sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device="cuda")
+        assert (hip.sinkhorn_plan(probs, 100) > 0) == (mode == "2")
+        hip.sinkhorn_match(probs, 1.0, 100, 0.2, work)
+        outs[(mode, refresh)] = (it["uv"].cpu().numpy(), it["matches0"].cpu().numpy(), it["mscores0"].cpu().numpy())
+        rescued[(mode, refresh)] = hip.sinkhorn_rescues() - before
+    # the fixed period lets a factor leave the fp32 range between two derivations on the 900 x 130 case (its range guard then hands the problem
+    # to the streamed solve: correct, but slow); the adaptive rule derives before that happens
+    assert rescued[("2", "0")] == 0 and rescued[("0", "50")] == 0, rescued
+    ref = outs[("0", "50")]
+    for key in (("2", "50"), ("2", "0")):
+        uv, m0, s0 = outs[key]
+        assert uv[-1] == 0.0
+        assert np.abs(uv[:-1] - ref[0][:-1]).max() < 3e-4, (key, float(np.abs(uv[:-1] - ref[0][:-1]).max()))
+        np.testing.assert_array_equal(m0, ref[1])
+        assert np.abs(s0 - ref[2]).max() < 2e-5
+
+
 def test_sinkhorn_resident_matches_streamed(hip, monkeypatch):
     """The two Sinkhorn implementations (streamed log-domain sweeps / on-chip multiplicative scaling with periodic
     re-derivation) must agree on the potentials to f32 noise and on every match, at the bench's problem shape."""

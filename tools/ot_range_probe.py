@@ -34,3 +34,26 @@ for name, pair in (("dense 1024", synth.make_pair(1024, 1000)), ("sparse 512 on 
     for key in (("2", "50"), ("2", "100")):
         uu, vv, ss = res[key]
         print(f"   on-chip refresh {key[1]}: max |u - streamed| {np.abs(uu - u).max():.2e}, |v - streamed| {np.abs(vv - v).max():.2e}, |score - streamed| {np.abs(ss - s).max():.2e}")
+
+# ---- where does the on-chip solve WITHOUT a mid-solve derivation leave the streamed solve?  iteration sweep on the sparse pair's score matrix
+os.environ["GIMS_OT_RESIDENT"], os.environ["GIMS_OT_REFRESH"] = "0", "50"
+m(data(synth.make_pair(512, 2000, canvas=(800, 600))))
+it0 = m._last["items"][0]
+n, mm = it0["n"], it0["m"]
+zs = it0["scores"].clone()
+def solve(mode, refresh, iters):
+    os.environ["GIMS_OT_RESIDENT"], os.environ["GIMS_OT_REFRESH"] = mode, str(refresh)
+    item = dict(scores=zs, n=n, m=mm, matches0=torch.empty(n, dtype=torch.int64, device="cuda"), matches1=torch.empty(mm, dtype=torch.int64, device="cuda"),
+                mscores0=torch.empty(n, device="cuda"), mscores1=torch.empty(mm, device="cuda"), uv=torch.empty(n + mm + 3, device="cuda"))
+    probs = hip.make_ot_problems([item])
+    work = torch.empty(hip.sinkhorn_workspace_bytes(probs), dtype=torch.uint8, device="cuda")
+    hip.sinkhorn_match(probs, alpha, iters, 0.2, work)
+    return item["uv"].cpu().numpy()
+print("iters: max |u - streamed|, |v - streamed| of the on-chip solve with refresh -1 (final only) / 50 / 0 (adaptive)")
+for iters in (5, 10, 20, 30, 40, 50, 60, 80, 100):
+    ref = solve("0", 50, iters)
+    row = []
+    for refresh in (-1, 50, 0):
+        uv = solve("2", refresh, iters)
+        row.append(f"{np.abs(uv[:n + 1] - ref[:n + 1]).max():.1e}/{np.abs(uv[n + 1:n + mm + 2] - ref[n + 1:n + mm + 2]).max():.1e}")
+    print(f"  {iters:3d}: " + "   ".join(row) + f"   |u| range [{ref[:n+1].min():.1f}, {ref[:n+1].max():.1f}]  v [{ref[n+1:n+mm+2].min():.1f}, {ref[n+1:n+mm+2].max():.1f}]")
