@@ -16,17 +16,19 @@
 //                and updates v and the cumulative column factor G for its own columns, redundantly and identically.
 // So the two wide edges (32 participants) never leave the XCD, and the one edge that crosses XCDs has 4 participants and
 // 0.5 KB -- no all-gather of G at all, because a workgroup only ever needs G for its own columns.
-// Numerics: the lazy-scaling form of ot_resident_kernel (K of the last derivation is never rewritten, transport matrix =
-// diag(F) K diag(G), u and v accumulated in the log domain, K re-derived from Z, u, v on the last iteration and WHEN NEEDED before it),
-// fixed summation orders everywhere: bitwise deterministic.
+// Numerics: the lazy-scaling form of ot_resident_kernel: K of the last derivation is never rewritten, the transport matrix is
+// diag(F) K diag(G) with F_i = mu_i / sum_j K_ij G_j and G_j = nu_j / sum_i F_i K_ij taken from the CURRENT iteration's sums alone, and
+// u = u(last derivation) + log F, v likewise -- nothing is accumulated from one iteration to the next, so the potentials are one rounding
+// away from the factors the iteration balances, and K is re-derived from Z, u, v only WHEN NEEDED.  Fixed summation orders everywhere:
+// bitwise deterministic.
 // When a derivation is needed (round 5).  K = exp(Z + u + v) is formed in f32: an entry below e^-87 at the derivation is zero from then on,
 // whatever the factors do to it later.  That is harmless while the entry stays negligible -- and wrong once F_i G_j has grown by enough to make
 // it matter: the dustbin column of a SPARSE pair (u up by 55, v_bin up by 37 over 100 iterations: entries that started at e^-120 end as the
 // dominant terms of their rows) cost 1e-2 on the scores without a mid-solve derivation, while dense pairs (growth <= 41) lose nothing.  A fixed
 // period of 50 served both at the price of one sweep of Z per solve; now every workgroup flags the iteration at whose end one of ITS factors
 // exceeds a bound (log F > 32 or log G > 20: an entry can then have grown by <= 52 + what the lag adds, i.e. anything that can matter, >= e^-26
-// of a row total, was >= e^-87 when K was formed), and every fourth iteration is a candidate: it re-derives iff a flag was raised in the
-// iterations (max(c - 8, last derivation), c - 4].  The decision is the same in every workgroup of the problem: a workgroup that has finished
+// of a row total, was >= e^-87 when K was formed), and every fourth iteration and the last one are candidates: a candidate c re-derives iff a
+// flag was raised in the iterations (max(c - 8, last derivation), c - 4].  A dense pair derives K once, from the start potentials.  The decision is the same in every workgroup of the problem: a workgroup that has finished
 // iteration k has, through the two exchanges of that iteration, seen data that every other workgroup published after finishing iteration k - 1
 // (its flag store, fenced, precedes that), so flags of iterations <= c - 3 are final when anybody reads them at the top of iteration c - 1.
 // Exchange protocol: no barrier; every exchanged value is >= +0 and carries the parity of its iteration in the sign bit,
@@ -51,6 +53,7 @@ struct OtR2Dev {
   const float* z; int64_t ld; int n, m;
   float* u; float* v; float* status;
   float norm, log_mu_bin, log_nu_bin;
+  float mu, mu_bin, nu_bin;       // exp of the three: the marginals themselves (uniform values the kernel keeps in scalar registers)
   int nx, nc;          // row groups, column blocks (workgroups per row group)
   int rb, cb;          // rows per row group (<= 1024), columns per block (<= 128, multiple of 4)
   int rbf, rbs;        // row slots folded per workgroup (multiple of 4), row slots per group = nc * rbf >= rb + 1
@@ -139,10 +142,10 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
   // state that lives across iterations in LDS rather than in registers (the 192 registers of P leave no room): v and the
   // cumulative factor G of the block's columns (owner: thread t < 128, thread 128 the dustbin column), u and the cumulative
   // factor F of the row slots this workgroup folds (owner: the fc == 0 lane of every fold group)
-  float* vown_l = wred + 16;               // [132]
-  float* gown_l = vown_l + 132;            // [132]
-  float* uo_l = gown_l + 132;              // [132]
-  float* fo_l = uo_l + 132;                // [132]
+  float* vown_l = wred + 16;               // [132]  v of the own columns AT THE LAST DERIVATION
+  float* gown_l = vown_l + 132;            // [132]  v of the own columns now (= vown_l + log G)
+  float* uo_l = gown_l + 132;              // [132]  u of the folded row slots AT THE LAST DERIVATION
+  float* fo_l = uo_l + 132;                // [132]  u of the folded row slots now (= uo_l + log F)
 
   const OtR2Block bk = a.blocks[blockIdx.x];
   if (bk.prob < 0) return;
@@ -181,12 +184,12 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
       for (int e = 0; e < 4; ++e) {
         const int s = fs0 + e;
         uo_l[4 * fq + e] = a.init_inside ? 0.f : (s < nrl ? p.u[row0 + s] : (s == nrl && lastg ? p.u[p.n] : 0.f));
-        fo_l[4 * fq + e] = 1.f;
+        fo_l[4 * fq + e] = uo_l[4 * fq + e];
       }
     }
   }
   // column duty: thread t < 128 owns column col0 + t, thread 128 of the last block the dustbin column
-  if (threadIdx.x < 132) { vown_l[threadIdx.x] = 0.f; gown_l[threadIdx.x] = 1.f; }
+  if (threadIdx.x < 132) { vown_l[threadIdx.x] = 0.f; gown_l[threadIdx.x] = 0.f; }
   for (int r = threadIdx.x; r < L::ROWST; r += NT) rowst[r] = 0.f;
   for (int r = threadIdx.x; r < L::PB; r += NT) pb[r] = 0.f;
   for (int r = threadIdx.x; r < L::FACS; r += NT) facs[r] = 1.f;
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) u0[e] = fs0 + e < nrl ? -fmaxf(alpha, mx[e]) : -alpha;      // (slot nrl of the last group: the dustbin row)
         *(f32x4*)(uo_l + 4 * fq) = u0;
+        *(f32x4*)(fo_l + 4 * fq) = u0;
         if (wt) r2_st4_wt(fb + p.rbs + fs0, u0); else r2_st4_plain(fb + p.rbs + fs0, u0);
       }
     }
@@ -363,16 +367,17 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
   int last_fresh = 0;                                        // iteration of the last derivation (the start potentials count as one)
   bool pend_fresh = false;                                   // next_fresh of the previous iteration
   constexpr float R2_F_BOUND = 7.9e13f, R2_G_BOUND = 4.85e8f;      // e^32, e^20 (see the header)
+  const bool force_last = a.refresh > 0 || a.refresh == -1;      // fixed period / "final only": derive on the last iteration whatever happened
   for (int it = 0; it < a.iters; ++it) {
     // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration (as loop invariants the
     // compiler keeps their hoisted addresses alive next to the 192 registers of P)
     int tq = threadIdx.x;
     asm volatile("" : "+v"(tq));
     const int t = tq, lane = t & 63, wave = t >> 6, cg = t & 7, rg = t >> 3;
-    const bool fresh = (it == 0 && !a.init_inside) || (it > 0 && (it == a.iters - 1 || pend_fresh));
-    bool next_fresh = it + 1 < a.iters && (it + 2 == a.iters || (a.refresh > 0 && (it + 1) % a.refresh == 0));
+    const bool fresh = (it == 0 && !a.init_inside) || (it > 0 && pend_fresh);
+    bool next_fresh = it + 1 < a.iters && ((force_last && it + 2 == a.iters) || (a.refresh > 0 && (it + 1) % a.refresh == 0));
     if (fresh) last_fresh = it;
-    if (a.refresh == 0 && !next_fresh && ((it + 1) & 3) == 0 && it + 1 >= 8 && it + 2 < a.iters) {
+    if (a.refresh == 0 && (((it + 1) & 3) == 0 || it + 2 == a.iters) && it + 1 >= 8 && it + 1 < a.iters) {
       // candidate c = it + 1: flags of the iterations c - 7 .. c - 4 that lie behind the last derivation (uniform in the workgroup and, by the
       // argument in the header, in the problem)
       const int c = it + 1;
@@ -460,7 +465,6 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
       __syncthreads();
       for (int r = t; r < L::FACS; r += NT) facs[r] = 1.f;
       for (int r = t; r < L::GVEC; r += NT) gvec[r] = 1.f;
-      if (t < 132) { gown_l[t] = 1.f; fo_l[t] = 1.f; }
       __syncthreads();
     }
     stamp(0);
@@ -583,26 +587,29 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
         for (int e = 0; e < 4; ++e) tot[e] += __shfl_xor(tot[e], 16, 64);
       }
       if (fc == 0 && vmask) {
-        bool fgrow = false;
-        f32x4 fw, uo = *(const f32x4*)(uo_l + 4 * fq), fo = *(const f32x4*)(fo_l + 4 * fq);
+        // F_i = mu_i / sum_j K_ij G_j and u_i = u_i(last derivation) + log F_i, both from THIS iteration's sum alone: nothing is accumulated
+        // from iteration to iteration (u += du at |u| ~ 100 lost half an ulp, 4e-6, per iteration against F *= exp(du): 4e-5 on the
+        // marginals after 100 iterations unless K was re-derived from u at the end).  Branch-free over the four slots: this is the middle of
+        // the iteration's longest dependency chain.
+        // A sum outside f32's range: the cumulative factors F, G of this multiplicative form ran out of range (or the input is not finite).
+        // Status 2 = "gave up": the caller's rescue re-solves the problem with the log-domain kernels, which decide whether the marginals
+        // themselves are finite (status 1) -- the lazy factors never cost a pair its matches
+        bool fgrow = false, bad = false;
+        f32x4 fw, uo = *(const f32x4*)(uo_l + 4 * fq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int s = fs0 + e;
-          if (s < nslots) {
-            const float tr = fo[e] * tot[e];                                  // true row sum F_i sum_j K_ij G_j
-            // a sum outside f32's range: the cumulative factors F, G of this multiplicative form ran out of range (or the input is not
-            // finite).  Status 2 = "gave up": the caller's rescue re-solves the problem with the log-domain kernels, which decide whether
-            // the marginals themselves are finite (status 1) -- the lazy factors never cost a pair its matches
-            if (!(tr > 0.f) || !(tr < 3.0e38f)) ot_raise_status(p.status, 2.f);
-            const float du = (s < nrl ? p.norm : p.log_mu_bin) - logf(tr);
-            uo[e] += du;
-            fo[e] *= __expf(du);
-            if (fo[e] > R2_F_BOUND) fgrow = true;
-          }
-          fw[e] = tg(fo[e]);
+          const bool val = s < nslots, real = s < nrl;
+          const float tt = val ? tot[e] : 1.f;
+          const float fn = val ? (real ? p.mu : p.mu_bin) * __builtin_amdgcn_rcpf(tt) : 1.f;
+          bad |= !(tt > 0.f) || !(tt < 3.0e38f) || !(fn < 3.0e38f);
+          uo[e] += val ? (real ? p.norm : p.log_mu_bin) - logf(tt) : 0.f;
+          fgrow |= fn > R2_F_BOUND;
+          fw[e] = tg(fn);
         }
-        *(f32x4*)(uo_l + 4 * fq) = uo;
-        *(f32x4*)(fo_l + 4 * fq) = fo;
+        if (bad) ot_raise_status(p.status, 2.f);
+        *(f32x4*)(fo_l + 4 * fq) = uo;
+        if (next_fresh) *(f32x4*)(uo_l + 4 * fq) = uo;
         if (a.refresh == 0 && fgrow) {                                       // (before this iteration's publishes of this lane: they order it for the readers)
           __hip_atomic_store(p.rflag + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __threadfence();
@@ -742,15 +749,13 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
     // ---------------- v += log g, G *= g for the block's own columns
     if (t <= 128) {
       const bool own = t < ncl || (t == 128 && lastc);
-      float vown = vown_l[t], gown = gown_l[t];
+      float vown = vown_l[t], gown = 1.f;
       if (own) {
-        const float tr = gown * ctot;                                           // true column sum G_j sum_i F_i K_ij
-        if (!(tr > 0.f) || !(tr < 3.0e38f)) ot_raise_status(p.status, 2.f);             // (see the row update)
-        const float dv = (t < 128 ? p.norm : p.log_nu_bin) - logf(tr);
-        vown += dv;
-        gown *= __expf(dv);
-        vown_l[t] = vown;
-        gown_l[t] = gown;
+        gown = (t < 128 ? p.mu : p.nu_bin) * __builtin_amdgcn_rcpf(ctot);       // G_j = nu_j / sum_i F_i K_ij (see the row update)
+        if (!(ctot > 0.f) || !(ctot < 3.0e38f) || !(gown < 3.0e38f)) ot_raise_status(p.status, 2.f);
+        vown += (t < 128 ? p.norm : p.log_nu_bin) - logf(ctot);
+        gown_l[t] = vown;
+        if (next_fresh) vown_l[t] = vown;
         if (a.refresh == 0 && gown > R2_G_BOUND) {
           __hip_atomic_store(p.rflag + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __threadfence();
@@ -774,14 +779,14 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int s = fs0 + e;
-        if (s < nrl) p.u[row0 + s] = uo_l[4 * fq + e];
-        else if (s == nrl && lastg) p.u[p.n] = uo_l[4 * fq + e];
+        if (s < nrl) p.u[row0 + s] = fo_l[4 * fq + e];
+        else if (s == nrl && lastg) p.u[p.n] = fo_l[4 * fq + e];
       }
     }
   }
   if (xr == 0) {
-    if ((int)threadIdx.x < ncl) p.v[col0 + threadIdx.x] = vown_l[threadIdx.x];
-    else if (threadIdx.x == 128 && lastc) p.v[p.m] = vown_l[128];
+    if ((int)threadIdx.x < ncl) p.v[col0 + threadIdx.x] = gown_l[threadIdx.x];
+    else if (threadIdx.x == 128 && lastc) p.v[p.m] = gown_l[128];
   }
 }
 
@@ -924,6 +929,7 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
     OtR2Dev q{};
     q.z = d.z; q.ld = d.ld; q.n = d.n; q.m = d.m; q.u = d.u; q.v = d.v; q.status = d.status;
     q.norm = d.norm; q.log_mu_bin = d.log_mu_bin; q.log_nu_bin = d.log_nu_bin;
+    q.mu = (float)exp((double)d.norm); q.mu_bin = (float)exp((double)d.log_mu_bin); q.nu_bin = (float)exp((double)d.log_nu_bin);
     q.nx = P.nx; q.nc = P.nc;
     q.rb = cdiv(d.n, P.nx);
     q.cb = r2_up4(cdiv(d.m, P.nc));
