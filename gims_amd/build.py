@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgims_hip.so")
-SOURCES = ["linear.hip", "linear6.hip", "carhynet.hip", "attention.hip", "sinkhorn.hip", "sinkhorn2d.hip", "misc.hip", "agc.hip", "eval.hip", "patches.hip", "train.hip", "optim.hip"]
+SOURCES = ["linear.hip", "linear6.hip", "carhynet.hip", "attention.hip", "sinkhorn.hip", "sinkhorn2d.hip", "misc.hip", "agc.hip", "eval.hip", "patches.hip", "train.hip", "train_attn.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 # per-file extras: keep MFMA accumulators in VGPRs (gfx950 has a unified VGPR/AGPR file) -- the softmax reads S
 # straight out of the MFMA result registers instead of through v_accvgpr_read copies

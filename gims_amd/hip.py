@@ -7,6 +7,7 @@ raises -- the product path never routes around the HIP kernels.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 
 import torch
@@ -107,6 +108,16 @@ class Gemm(C.Structure):
                 ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("batch", C.c_int32),
                 ("ta", C.c_int32), ("tb", C.c_int32), ("act", C.c_int32), ("flags", C.c_int32),
                 ("alpha", C.c_float), ("beta", C.c_float), ("work", C.c_void_p), ("work_floats", C.c_int64), ("splits", C.c_int32), ("precision", C.c_int32)]
+
+
+class TrainAttnProblem(C.Structure):
+    _fields_ = [("q_off", C.c_int32), ("nq", C.c_int32), ("k_off", C.c_int32), ("nk", C.c_int32)]
+
+
+class TrainAttnArgs(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("ld", C.c_int64), ("rows", C.c_int64), ("d", C.c_int32), ("heads", C.c_int32), ("scale", C.c_float),
+                ("n_problems", C.c_int32), ("problems", C.POINTER(TrainAttnProblem)), ("o", C.c_void_p), ("ldo", C.c_int64), ("lse", C.c_void_p),
+                ("d_o", C.c_void_p), ("lddo", C.c_int64), ("d_qkv", C.c_void_p), ("lddq", C.c_int64), ("work", C.c_void_p), ("work_floats", C.c_size_t)]
 
 
 class Segments(C.Structure):
@@ -234,6 +245,9 @@ _SIGNATURES = {
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gims_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "gims_softmax_rows_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "gims_train_attention_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "gims_train_attention_forward": (C.c_int, [C.POINTER(TrainAttnArgs), C.c_void_p]),
+    "gims_train_attention_backward": (C.c_int, [C.POINTER(TrainAttnArgs), C.c_void_p]),
     "gims_colsum_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
     "gims_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gims_elementwise": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float,
@@ -1169,6 +1183,53 @@ def softmax_rows_backward_(prob: torch.Tensor, dp: torch.Tensor, cols: int):
     _check(load().gims_softmax_rows_backward(_p(prob), _p(dp), prob.stride(1), prob.shape[1], int(cols), prob.shape[0], prob.stride(0), _stream()),
            "gims_softmax_rows_backward")
     return dp
+
+
+_tattn_work = {}
+
+
+def train_attn_problems(problems):
+    """[(q_off, nq, k_off, nk)] -> (ctypes array, n): problem i attends the query rows [q_off, q_off + nq) to the source rows [k_off, k_off + nk)."""
+    arr = (TrainAttnProblem * len(problems))()
+    for i, (qo, nq, ko, nk) in enumerate(problems):
+        arr[i].q_off, arr[i].nq, arr[i].k_off, arr[i].nk = int(qo), int(nq), int(ko), int(nk)
+    return arr, len(problems)
+
+
+def _train_attn_args(qkv, problems, heads, o, lse, d_o=None, d_qkv=None):
+    rows, d = qkv.shape[0], qkv.shape[1] // 3
+    assert qkv.dtype == torch.float32 and qkv.stride(1) == 1 and o.stride(1) == 1 and lse.is_contiguous() and lse.shape == (heads, rows)
+    need = int(load().gims_train_attention_workspace_floats(rows, heads))
+    key = (qkv.device, _stream())
+    w = _tattn_work.get(key)
+    if w is None or w.numel() < need:
+        if w is not None:
+            _colsum_retired.append(w)                 # (see colsum: a launch on a non-torch stream may still read the outgrown buffer)
+        w = _tattn_work[key] = torch.empty(need, dtype=torch.float32, device=qkv.device)
+    arr, n = problems if isinstance(problems, tuple) else train_attn_problems(problems)
+    g = TrainAttnArgs(qkv.data_ptr(), qkv.stride(0), rows, d, heads, 1.0 / math.sqrt(d // heads), n, arr, o.data_ptr(), o.stride(0), lse.data_ptr(),
+                      _p(d_o), d_o.stride(0) if d_o is not None else 0, _p(d_qkv), d_qkv.stride(0) if d_qkv is not None else 0, w.data_ptr(), w.numel())
+    return g, arr
+
+
+def train_attention_forward(qkv: torch.Tensor, problems, heads: int, o: torch.Tensor | None = None, lse: torch.Tensor | None = None):
+    """o = softmax(Q K^T / sqrt(64)) V for every problem and head of one layer (qkv [rows, 3 d]: packed Q | K | V, heads contiguous), and the
+    row statistic lse [heads, rows] the reverse pass recomputes the probabilities from.  Returns (o, lse)."""
+    rows, d = qkv.shape[0], qkv.shape[1] // 3
+    o = torch.empty((rows, d), dtype=torch.float32, device=qkv.device) if o is None else o
+    lse = torch.empty((heads, rows), dtype=torch.float32, device=qkv.device) if lse is None else lse
+    g, keep = _train_attn_args(qkv, problems, heads, o, lse)
+    _check(load().gims_train_attention_forward(C.byref(g), _stream()), "gims_train_attention_forward")
+    return o, lse
+
+
+def train_attention_backward(qkv, o, lse, d_o, problems, heads: int, d_qkv: torch.Tensor | None = None):
+    """d_qkv [rows, 3 d] from the gradient d_o of train_attention_forward's output."""
+    d_qkv = torch.empty_like(qkv) if d_qkv is None else d_qkv
+    assert d_o.stride(1) == 1 and d_qkv.stride(1) == 1
+    g, keep = _train_attn_args(qkv, problems, heads, o, lse, d_o, d_qkv)
+    _check(load().gims_train_attention_backward(C.byref(g), _stream()), "gims_train_attention_backward")
+    return d_qkv
 
 
 _colsum_work = {}

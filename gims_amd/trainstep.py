@@ -7,8 +7,9 @@ and graph aggregations in the kernels of csrc/train.hip, the Sinkhorn solve and 
 Layout: rows of all images SIDE-major ([image 0 of every batch element | image 1 of every batch element]), activations
 row-major f32 [rows][channels].  The linear layers of a GNN layer run once over all rows (both sides share the weights,
 gmatcher.py:139-141); BatchNorm statistics are per side (= per call of the module in the reference); attention runs per
-image with the probabilities P kept for the reverse pass (4 x n x m f32 per image and layer: 2.4 GB at 2 x 2048 keypoints
--- HBM is 288 GB; nothing is recomputed).  Heads are made contiguous by permuting the projection weights on the way in
+image WITHOUT stored probabilities (one call per layer for all images and heads, csrc/train_attn.hip: the forward keeps the row
+statistic max + log(sum), the reverse pass recomputes P from it; rounds 1-4 kept P, 2.4 GB at 2 x 2048 keypoints, and ran seven
+products and two softmax passes per image and layer over it).  Heads are made contiguous by permuting the projection weights on the way in
 (reference: channel = d * heads + h, gmatcher.py:108-113) and the weight gradients on the way out (gims_head_pack: one launch per
 layer and direction).
 """
@@ -167,6 +168,9 @@ def _forward(model, data):
 
     # ---- attentional GNN (gmatcher.py:99-143)
     S.layers = []
+    # problem tables of the two layer kinds: every image attends to itself ('self') or to the other image of its pair ('cross')
+    S.attn_problems = {cross: hip.train_attn_problems([(*rows[b][s], *rows[b][1 - s if cross else s]) for b in range(B) for s in range(2)])
+                       for cross in (False, True)}
     for l, name in enumerate(cfg['transformer_layers']):
         pre = f"gnn.layers.{l}."
         wqkv = torch.empty((3 * D, D), dtype=torch.float32, device=dev)
@@ -176,27 +180,15 @@ def _forward(model, data):
                       P[pre + "attn.merge.weight"], wqkv, bqkv, wm, HEADS, to_params=False)
         xm = xm_cur                                  # [x | msg] of this layer; desc is its left half
         qkv = hip.gemm(desc, wqkv, bias=bqkv)
-        o = torch.empty((n_tot, D), dtype=torch.float32, device=dev)
-        probs = []
-        for b in range(B):
-            for s in range(2):
-                (oq, nq), (os_, ns) = rows[b][s], rows[b][s if name != 'cross' else 1 - s]
-                ld = (ns + 3) // 4 * 4
-                pm = torch.empty((HEADS, nq, ld), dtype=torch.float32, device=dev)
-                qh = qkv[oq:oq + nq, 0:D].view(nq, HEADS, D // HEADS).permute(1, 0, 2)
-                kh = qkv[os_:os_ + ns, D:2 * D].view(ns, HEADS, D // HEADS).permute(1, 0, 2)
-                vh = qkv[os_:os_ + ns, 2 * D:3 * D].view(ns, HEADS, D // HEADS).permute(1, 0, 2)
-                hip.gemm(qh, kh, pm[:, :, :ns], alpha=1.0 / math.sqrt(D // HEADS))
-                hip.softmax_rows_(pm, ns)
-                hip.gemm(pm[:, :, :ns], vh.transpose(1, 2), o[oq:oq + nq].view(nq, HEADS, D // HEADS).permute(1, 0, 2))
-                probs.append(pm)
+        # attention of all images and heads in one call; the reverse pass recomputes the probabilities from lse (csrc/train_attn.hip)
+        o, lse = hip.train_attention_forward(qkv, S.attn_problems[name == 'cross'], HEADS)
         msg = hip.gemm(o, wm, xm[:, D:], bias=P[pre + "attn.merge.bias"])
         w0, w3 = _w2(P[pre + "mlp.0.weight"]), _w2(P[pre + "mlp.3.weight"])
         hpre = hip.gemm(xm, w0, bias=P[pre + "mlp.0.bias"])
         hid, save = bn(pre + "mlp.1", hpre)
         xm_next = torch.empty((n_tot, 2 * D), dtype=torch.float32, device=dev)
         nxt = hip.gemm(hid, w3, xm_next[:, :D], bias=P[pre + "mlp.3.bias"], residual=desc)       # desc + delta (gmatcher.py:142)
-        S.layers.append(dict(x=desc, xm=xm, wqkv=wqkv, wm=wm, qkv=qkv, o=o, probs=probs, msg=msg, hpre=hpre, save=save, hid=hid, cross=name == 'cross'))
+        S.layers.append(dict(x=desc, xm=xm, wqkv=wqkv, wm=wm, qkv=qkv, o=o, lse=lse, msg=msg, hpre=hpre, save=save, hid=hid, cross=name == 'cross'))
         desc, xm_cur = nxt, xm_next
     S.desc = desc
 
@@ -225,6 +217,11 @@ def _forward(model, data):
 
 
 # ------------------------------------------------------------------------------------------------ backward
+def _xprec(name):
+    v = os.environ.get(name)
+    return None if not v else {"x3": hip.PREC_BF16X3, "x6": hip.PREC_BF16X6}[v]
+
+
 _SIDE_STREAM = os.environ.get("GIMS_TRAIN_SIDE_STREAM", "1") != "0"      # A/B switch: 0 = parameter gradients on the main stream
 _side_streams = {}
 
@@ -250,6 +247,7 @@ def _backward(model, S, w_pos: float, w_neg: float):
     D, B, n_tot, rows, sg, G = S.D, S.B, S.n_tot, S.rows, S.sg, S.G
     dev = S.mdesc.device
     grads = {}
+    PW, PG = _xprec("GIMS_TRAIN_PREC_WGRAD"), _xprec("GIMS_TRAIN_PREC_AGRAD")
 
     def put(name, g):
         grads[name] = g.view(P[name].shape)
@@ -296,57 +294,33 @@ def _backward(model, S, w_pos: float, w_neg: float):
         hip.gemm(dscores[b], S.mdesc[o1:o1 + n1].t(), dm[o0:o0 + n0], alpha=inv)
         hip.gemm(dscores[b].t(), S.mdesc[o0:o0 + n0].t(), dm[o1:o1 + n1], alpha=inv)
     wf = _w2(P["final_proj.weight"])
-    aside(lambda: (put("final_proj.weight", hip.gemm(dm.t(), S.desc.t())), put("final_proj.bias", hip.colsum(dm))), dm, S.desc)
-    dx = hip.gemm(dm, wf.t())                                     # gradient w.r.t. the residual stream after the last layer
+    aside(lambda: (put("final_proj.weight", hip.gemm(dm.t(), S.desc.t(), precision=PW)), put("final_proj.bias", hip.colsum(dm))), dm, S.desc)
+    dx = hip.gemm(dm, wf.t(), precision=PG)                                     # gradient w.r.t. the residual stream after the last layer
 
     # ---- GNN layers in reverse
-    max_p = max(p.numel() for L in S.layers for p in L["probs"])
-    dp_buf = torch.empty(max_p, dtype=torch.float32, device=dev)
-    dh = D // HEADS
     for l in range(len(S.layers) - 1, -1, -1):
         L = S.layers[l]
         pre = f"gnn.layers.{l}."
         w0, w3 = _w2(P[pre + "mlp.0.weight"]), _w2(P[pre + "mlp.3.weight"])
         # delta = mlp(cat[x, msg]); x_next = x + delta: dx is d/dx_next = d/ddelta
-        aside(lambda dx=dx, L=L: (put(pre + "mlp.3.weight", hip.gemm(dx.t(), L["hid"].t())), put(pre + "mlp.3.bias", hip.colsum(dx))), dx, L["hid"])
-        dhid = hip.gemm(dx, w3.t())
+        aside(lambda dx=dx, L=L: (put(pre + "mlp.3.weight", hip.gemm(dx.t(), L["hid"].t(), precision=PW)), put(pre + "mlp.3.bias", hip.colsum(dx))), dx, L["hid"])
+        dhid = hip.gemm(dx, w3.t(), precision=PG)
         dhpre = norm_backward(pre + "mlp.1", L["hpre"], dhid, L["save"])
-        aside(lambda: (put(pre + "mlp.0.weight", hip.gemm(dhpre.t(), L["xm"].t())), put(pre + "mlp.0.bias", hip.colsum(dhpre))), dhpre, L["xm"])
-        dx = hip.gemm(dhpre, w0[:, :D].t(), residual=dx)          # dx + dhpre W0[:, :D]   (x enters the MLP directly); a fresh tensor: see aside
-        dmsg = hip.gemm(dhpre, w0[:, D:].t())
+        aside(lambda: (put(pre + "mlp.0.weight", hip.gemm(dhpre.t(), L["xm"].t(), precision=PW)), put(pre + "mlp.0.bias", hip.colsum(dhpre))), dhpre, L["xm"])
+        dx = hip.gemm(dhpre, w0[:, :D].t(), residual=dx, precision=PG)          # dx + dhpre W0[:, :D]   (x enters the MLP directly); a fresh tensor: see aside
+        dmsg = hip.gemm(dhpre, w0[:, D:].t(), precision=PG)
         # merge
-        dwm = aside(lambda: hip.gemm(dmsg.t(), L["o"].t()), dmsg, L["o"])   # in the packed (head-contiguous) layout; unpacked with the projections below
+        dwm = aside(lambda: hip.gemm(dmsg.t(), L["o"].t(), precision=PW), dmsg, L["o"])   # in the packed (head-contiguous) layout; unpacked with the projections below
         aside(lambda: put(pre + "attn.merge.bias", hip.colsum(dmsg)))
-        do = hip.gemm(dmsg, L["wm"].t())
-        dqkv = torch.empty((n_tot, 3 * D), dtype=torch.float32, device=dev)
-        # attention, image by image (every image's rows are queries once and sources once per layer: dqkv is written exactly once)
-        qkv = L["qkv"]
-        pi = 0
-        for b in range(B):
-            for s in range(2):
-                (oq, nq), (os_, ns) = rows[b][s], rows[b][1 - s if L["cross"] else s]
-                pm = L["probs"][pi]
-                pi += 1
-                ld = pm.shape[2]
-                dp = dp_buf[:pm.numel()].view(HEADS, nq, ld)
-                qh = qkv[oq:oq + nq, 0:D].view(nq, HEADS, dh).permute(1, 0, 2)
-                kh = qkv[os_:os_ + ns, D:2 * D].view(ns, HEADS, dh).permute(1, 0, 2)
-                vh = qkv[os_:os_ + ns, 2 * D:3 * D].view(ns, HEADS, dh).permute(1, 0, 2)
-                doh = do[oq:oq + nq].view(nq, HEADS, dh).permute(1, 0, 2)
-                dqh = dqkv[oq:oq + nq, 0:D].view(nq, HEADS, dh).permute(1, 0, 2)
-                dkh = dqkv[os_:os_ + ns, D:2 * D].view(ns, HEADS, dh).permute(1, 0, 2)
-                dvh = dqkv[os_:os_ + ns, 2 * D:3 * D].view(ns, HEADS, dh).permute(1, 0, 2)
-                hip.gemm(pm[:, :, :ns].transpose(1, 2), doh.transpose(1, 2), dvh)                    # dV = P^T dO
-                hip.gemm(doh, vh, dp[:, :, :ns])                                                     # dP = dO V^T
-                hip.softmax_rows_backward_(pm, dp, ns)                                               # dS
-                hip.gemm(dp[:, :, :ns], kh.transpose(1, 2), dqh, alpha=1.0 / math.sqrt(dh))          # dQ = dS K / sqrt(dh)
-                hip.gemm(dp[:, :, :ns].transpose(1, 2), qh.transpose(1, 2), dkh, alpha=1.0 / math.sqrt(dh))   # dK = dS^T Q / sqrt(dh)
+        do = hip.gemm(dmsg, L["wm"].t(), precision=PG)
+        # attention of all images and heads (every image's rows are queries once and sources once per layer: dqkv is written exactly once)
+        dqkv = hip.train_attention_backward(L["qkv"], L["o"], L["lse"], do, S.attn_problems[L["cross"]], HEADS)
         gw = [torch.empty_like(P[pre + f"attn.proj.{j}.weight"]) for j in range(3)]
         gb = [torch.empty_like(P[pre + f"attn.proj.{j}.bias"]) for j in range(3)]
         gm = torch.empty_like(P[pre + "attn.merge.weight"])
 
         def qkv_grads(dqkv=dqkv, L=L, dwm=dwm, gw=gw, gb=gb, gm=gm):
-            dwqkv = hip.gemm(dqkv.t(), L["x"].t())
+            dwqkv = hip.gemm(dqkv.t(), L["x"].t(), precision=PW)
             dbqkv = hip.colsum(dqkv)
             hip.head_pack(gw, gb, gm, dwqkv, dbqkv, dwm, HEADS, to_params=True)
             hold.extend((dwqkv, dbqkv))
@@ -355,7 +329,7 @@ def _backward(model, S, w_pos: float, w_neg: float):
             put(pre + f"attn.proj.{j}.weight", gw[j])
             put(pre + f"attn.proj.{j}.bias", gb[j])
         put(pre + "attn.merge.weight", gm)
-        dx = hip.gemm(dqkv, L["wqkv"].t(), residual=dx)           # dx + dQKV Wqkv
+        dx = hip.gemm(dqkv, L["wqkv"].t(), residual=dx, precision=PG)           # dx + dQKV Wqkv
         S.layers[l] = None                                        # this layer's activations are no longer needed
 
     # ---- keypoint encoder (dx is now d/d(sage + kenc))
@@ -366,7 +340,7 @@ def _backward(model, S, w_pos: float, w_neg: float):
         idx = K["conv"]
         if "pre" in K:           # conv idx -> BN idx+1 -> ReLU: g is the gradient of the ReLU output
             g = norm_backward(f"kenc.encoder.{idx + 1}", K["pre"], g, K["save"])
-        aside(lambda g=g, K=K, idx=idx: (put(f"kenc.encoder.{idx}.weight", hip.gemm(g.t(), K["x"].t())), put(f"kenc.encoder.{idx}.bias", hip.colsum(g))), g, K["x"])
+        aside(lambda g=g, K=K, idx=idx: (put(f"kenc.encoder.{idx}.weight", hip.gemm(g.t(), K["x"].t(), precision=PW)), put(f"kenc.encoder.{idx}.bias", hip.colsum(g))), g, K["x"])
         if i > 0:
             g = hip.gemm(g, _w2(P[f"kenc.encoder.{idx}.weight"]).t())
 
@@ -378,16 +352,16 @@ def _backward(model, S, w_pos: float, w_neg: float):
         ws, wn = P[pre + "fc_self.weight"], P[pre + "fc_neigh.weight"]
         if i < 2:                 # ReLU after layers 0 and 1
             g = hip.elementwise(hip.EW_RELU_MASK, torch.empty_like(g), g, L["out"])
-        aside(lambda g=g, L=L, pre=pre, i=i: (put(pre + "fc_self.weight", hip.gemm(g.t(), L["h"].t())), put(_sage_bias(P, i), hip.colsum(g))), g, L["h"])
+        aside(lambda g=g, L=L, pre=pre, i=i: (put(pre + "fc_self.weight", hip.gemm(g.t(), L["h"].t(), precision=PW)), put(_sage_bias(P, i), hip.colsum(g))), g, L["h"])
         if L["before"]:           # out = h Ws^T + b + mean(h Wn^T)
             dxn = hip.sage_mean_transposed(g, G["indptr_all"], G["indices_all"])
-            aside(lambda dxn=dxn, L=L, pre=pre: put(pre + "fc_neigh.weight", hip.gemm(dxn.t(), L["h"].t())), dxn, L["h"])
+            aside(lambda dxn=dxn, L=L, pre=pre: put(pre + "fc_neigh.weight", hip.gemm(dxn.t(), L["h"].t(), precision=PW)), dxn, L["h"])
             if i > 0:
                 gh = hip.gemm(g, ws.t())
                 hip.gemm(dxn, wn.t(), gh, beta=1.0)
                 g = gh
         else:                     # out = h Ws^T + b + mean(h) Wn^T
-            aside(lambda g=g, L=L, pre=pre: put(pre + "fc_neigh.weight", hip.gemm(g.t(), L["agg"].t())), g, L["agg"])
+            aside(lambda g=g, L=L, pre=pre: put(pre + "fc_neigh.weight", hip.gemm(g.t(), L["agg"].t(), precision=PW)), g, L["agg"])
             if i > 0:
                 dagg = hip.gemm(g, wn.t())
                 gh = hip.gemm(g, ws.t())

@@ -630,6 +630,38 @@ int gims_batchnorm_train_backward(const float* x, int64_t ld, const float* dy, i
  * (gims_colsum) are the gradients of b_2 and a_2. */
 int gims_layernorm_backward(const float* x, int64_t ldx, const float* dy, int64_t ldd, int64_t rows, int32_t c, const float* a2, const float* b2,
                             float eps, int32_t relu, float* dx, int64_t ldo, float* g_bias, float* g_scale, void* stream);
+/* Attention of the training step for all images and heads of one GNN layer, without the probability matrices (gmatcher.py:35-39 inside
+ * forward_train, :309-386; replaces, per image: the scores product, gims_softmax_rows and the product with V, and in the reverse pass four products
+ * and gims_softmax_rows_backward).  qkv [rows][ld]: the packed projections Q | K | V (each d = 64 * heads columns, head h in columns 64 h ..
+ * 64 h + 63 of its third: gims_head_pack's layout).  problems: a HOST array; problem i attends the query rows [q_off, q_off + nq) to the source
+ * rows [k_off, k_off + nk) (self: the same image, cross: the other one).
+ * forward: o [rows][ldo] = softmax(scale * Q K^T) V and lse [heads][rows] = max + log(sum) of every score row (what the reverse pass needs
+ * instead of P).  backward: d_qkv [rows][lddq] from d_o, o, lse (every row must be a query row of exactly one problem and a source row of exactly
+ * one for d_qkv to be written completely).  Exact f32 on the matrix cores (v_mfma_f32_32x32x2_f32), fixed summation orders.  work:
+ * gims_train_attention_workspace_floats(rows, heads) floats, 16-byte aligned. */
+typedef struct gims_train_attn_problem {
+  int32_t q_off, nq, k_off, nk;
+} gims_train_attn_problem;
+typedef struct gims_train_attn_args {
+  const float* qkv;
+  int64_t ld, rows;
+  int32_t d, heads;
+  float scale;                               /* 1 / sqrt(64) */
+  int32_t n_problems;
+  const gims_train_attn_problem* problems;   /* host memory */
+  float* o;
+  int64_t ldo;
+  float* lse;
+  const float* d_o;                          /* backward only */
+  int64_t lddo;
+  float* d_qkv;                              /* backward only */
+  int64_t lddq;
+  float* work;
+  size_t work_floats;
+} gims_train_attn_args;
+size_t gims_train_attention_workspace_floats(int64_t rows, int32_t heads);
+int gims_train_attention_forward(const gims_train_attn_args* args, void* stream);
+int gims_train_attention_backward(const gims_train_attn_args* args, void* stream);
 /* softmax over the last dimension of `batch` matrices [rows][cols] (pitch ld, matrix stride `stride`), in place
  * (gmatcher.py:37), and its backward: dp <- prob * (dp - rowsum(dp * prob)), in place on dp. */
 int gims_softmax_rows(float* s, int64_t ld, int64_t rows, int32_t cols, int32_t batch, int64_t stride, void* stream);

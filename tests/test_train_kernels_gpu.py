@@ -169,3 +169,66 @@ def test_head_pack_roundtrip():
     gw, gb, gm = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb], torch.empty_like(mw)
     hip.head_pack(gw, gb, gm, wqkv, bqkv, wm, H, to_params=True)
     assert all(torch.equal(a, b) for a, b in zip(gw, pw)) and all(torch.equal(a, b) for a, b in zip(gb, pb)) and torch.equal(gm, mw)
+
+
+def _attention_reference(qkv, do, problems, heads):
+    """float64 torch: o, lse and the gradient of sum(o * do) with respect to qkv, problem by problem and head by head (gmatcher.py:35-39)."""
+    rows, d3 = qkv.shape
+    d, dh = d3 // 3, d3 // 3 // heads
+    with torch.enable_grad():
+        x = qkv.double().requires_grad_(True)
+        o = torch.zeros((rows, d), dtype=torch.float64, device=qkv.device)
+        lse = torch.zeros((heads, rows), dtype=torch.float64, device=qkv.device)
+        outs = []
+        for qo, nq, ko, nk in problems:
+            q = x[qo:qo + nq, 0:d].view(nq, heads, dh).permute(1, 0, 2)
+            k = x[ko:ko + nk, d:2 * d].view(nk, heads, dh).permute(1, 0, 2)
+            v = x[ko:ko + nk, 2 * d:].view(nk, heads, dh).permute(1, 0, 2)
+            s = q @ k.transpose(1, 2) / dh ** 0.5
+            oo = (torch.softmax(s, -1) @ v).permute(1, 0, 2).reshape(nq, d)
+            outs.append((qo, nq, oo))
+            lse[:, qo:qo + nq] = torch.logsumexp(s, -1).detach()
+        loss = sum((oo * do[qo:qo + nq].double()).sum() for qo, nq, oo in outs)
+        loss.backward()
+        for qo, nq, oo in outs:
+            o[qo:qo + nq] = oo.detach()
+    return o, lse, x.grad
+
+
+@pytest.mark.parametrize("splits", [None, 1, 3, 8])
+@pytest.mark.parametrize("n0,n1,cross", [(300, 517, False), (300, 517, True), (33, 64, True), (1, 5, True), (128, 128, False), (2048, 1900, True)])
+def test_train_attention_forward_backward_vs_float64(n0, n1, cross, splits, monkeypatch):
+    """gims_train_attention_forward / _backward (flash-style, exact-f32 MFMA, no stored probabilities) against float64 autograd: self and cross
+    problems of two images of different sizes, ragged tiles (sizes that are no multiples of 32 or 128), one-row images, peaked and diffuse rows in
+    the same matrix; every split count of the streamed dimension (None = the library's own choice)."""
+    if splits is not None:
+        monkeypatch.setenv("GIMS_TRAIN_ATTN_SPLITS", str(splits))
+    heads, d = 4, 256
+    rows = n0 + n1
+    qkv = _rand(rows, 3 * d, seed=n0 + n1, scale=1.0)
+    qkv[:, :d] *= torch.linspace(0.3, 6.0, rows, device=DEV)[:, None]          # query norms from diffuse to sharply peaked rows
+    do = _rand(rows, d, seed=7)
+    problems = [(0, n0, n0, n1), (n0, n1, 0, n0)] if cross else [(0, n0, 0, n0), (n0, n1, n0, n1)]
+    o, lse = hip.train_attention_forward(qkv, problems, heads)
+    dqkv = hip.train_attention_backward(qkv, o, lse, do, problems, heads)
+    ro, rlse, rg = _attention_reference(qkv, do, problems, heads)
+    assert float((o.double() - ro).abs().max()) < 3e-6 * float(ro.abs().max())
+    assert float((lse.double() - rlse).abs().max()) < 2e-6 + 4e-7 * float(rlse.abs().max())          # (a few ulp of the largest score)
+    for j, name in enumerate("qkv"):
+        g, r = dqkv[:, j * d:(j + 1) * d].double(), rg[:, j * d:(j + 1) * d]
+        # (dS = P (dP - D) cancels completely where a row has one dominant source: the f32 rounding of dP and D, ~1e-6 of |dP|, is what is left)
+        assert float((g - r).abs().max()) < 3e-5 * float(r.abs().max()), name
+    # deterministic: the same bits again
+    o2, lse2 = hip.train_attention_forward(qkv, problems, heads)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    assert torch.equal(dqkv, hip.train_attention_backward(qkv, o, lse, do, problems, heads))
+
+
+def test_train_attention_rejects_bad_arguments():
+    qkv = _rand(64, 768, seed=1)
+    with pytest.raises(hip.GimsHipError):
+        hip.train_attention_forward(qkv, [(0, 64, 0, 65)], 4)                 # sources beyond the rows
+    with pytest.raises(hip.GimsHipError):
+        hip.train_attention_forward(qkv, [(0, 0, 0, 64)], 4)                  # no queries
+    with pytest.raises(hip.GimsHipError):
+        hip.train_attention_forward(qkv[:, :384].contiguous(), [(0, 64, 0, 64)], 4)      # head dimension 32
