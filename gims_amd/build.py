@@ -14,7 +14,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # straight out of the MFMA result registers instead of through v_accvgpr_read copies
 # sinkhorn.hip: no SLP packing -- v_pk_*_f32 wants aligned register pairs and, next to the 192 registers the resident
 # Sinkhorn kernel pins for its slab of the transport matrix, the pairing copies push that kernel into scratch spills
-EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "sinkhorn.hip": ["-fno-slp-vectorize"], "sinkhorn2d.hip": ["-fno-slp-vectorize"]}
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "train_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "sinkhorn.hip": ["-fno-slp-vectorize"], "sinkhorn2d.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale() -> bool:

@@ -81,6 +81,25 @@ __device__ __forceinline__ void ta_put_s(float* lds, const f32x4 (&reg)[2]) {   
 
 #define TA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// The A operands of a chain of 16 products, read from LDS AHEAD of the chain that uses them: one ds_read per product issued right in front of it
+// left every pair of products waiting ~120 cycles for LDS behind a 64-cycle product (62 % of the f32 matrix rate); with the reads of the NEXT
+// 16 products in flight under the current 16 the pipe only waits for itself.  Stages are fenced with sched_barrier so that the compiler keeps
+// the reads where they are written.
+//   transposed tile [d][row]: operand i of the chain over d = (2 i + hf, ln)
+__device__ __forceinline__ void ta_ops_t(float (&r)[16], const float* lds, int i0, int hf, int ln) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = lds[(2 * (i0 + i) + hf) * TA_TP + ln];
+}
+//   row-major tile [row][d]: operands (row of register j, d = ln) and (.., d = 32 + ln) for j = j0 .. j0 + 7
+__device__ __forceinline__ void ta_ops_s(float (&r)[16], const float* lds, int j0, int hf, int ln) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    r[2 * j] = lds[ta_row_of(j0 + j, hf) * TA_SP + ln];
+    r[2 * j + 1] = lds[ta_row_of(j0 + j, hf) * TA_SP + 32 + ln];
+  }
+}
+#define TA_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void ta_fwd_kernel(TaK a) {
   __shared__ __attribute__((aligned(16))) float kt[64 * TA_TP];
@@ -119,11 +138,21 @@ __global__ __launch_bounds__(256) void ta_fwd_kernel(TaK a) {
       ta_fetch(kbase, a.ld, (tile + 1) * 32, pr.nk, kr);
       ta_fetch(vbase, a.ld, (tile + 1) * 32, pr.nk, vr);
     }
+    float pa[16], pb[16];
+    ta_ops_t(pa, kt, 0, hf, ln);
+    ta_ops_t(pb, kt, 16, hf, ln);
+    TA_FENCE();
     f32x16 s;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s[j] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) s = TA_MFMA(kt[(2 * i + hf) * TA_TP + ln], qf[i], s);
+    for (int i = 0; i < 16; ++i) s = TA_MFMA(pa[i], qf[i], s);
+    ta_ops_s(pa, vs, 0, hf, ln);                    // (the rows of V the second product starts with: in flight under the rest of the first)
+    TA_FENCE();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s = TA_MFMA(pb[i], qf[16 + i], s);
+    ta_ops_s(pb, vs, 8, hf, ln);
+    TA_FENCE();
     if (tile * 32 + 32 > pr.nk) {
 #pragma unroll
       for (int j = 0; j < 16; ++j)
@@ -144,13 +173,19 @@ __global__ __launch_bounds__(256) void ta_fwd_kernel(TaK a) {
     ps += ta_other_half(ps);
     l = l * alpha + ps;
     m = mn;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {       // (the running maximum settles after the first tiles: most tiles rescale nothing)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { o0[j] *= alpha; o1[j] *= alpha; }
+      for (int j = 0; j < 16; ++j) { o0[j] *= alpha; o1[j] *= alpha; }
+    }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float* vrow = vs + ta_row_of(j, hf) * TA_SP + ln;
-      o0 = TA_MFMA(vrow[0], s[j], o0);
-      o1 = TA_MFMA(vrow[32], s[j], o1);
+    for (int j = 0; j < 8; ++j) {
+      o0 = TA_MFMA(pa[2 * j], s[j], o0);
+      o1 = TA_MFMA(pa[2 * j + 1], s[j], o1);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o0 = TA_MFMA(pb[2 * j], s[8 + j], o0);
+      o1 = TA_MFMA(pb[2 * j + 1], s[8 + j], o1);
     }
   }
   if (qrow >= pr.nq) return;
@@ -259,13 +294,29 @@ __global__ __launch_bounds__(256) void ta_bwd_q_kernel(TaK a) {
       ta_fetch(kbase, a.ld, (tile + 1) * 32, pr.nk, kr);
       ta_fetch(vbase, a.ld, (tile + 1) * 32, pr.nk, vr);
     }
+    float pa[16], pb[16];
+    ta_ops_t(pa, kt, 0, hf, ln);
+    ta_ops_t(pb, kt, 16, hf, ln);
+    TA_FENCE();
     f32x16 s, dp;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s[j] = dp[j] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) s = TA_MFMA(kt[(2 * i + hf) * TA_TP + ln], qf[i], s);
+    for (int i = 0; i < 16; ++i) s = TA_MFMA(pa[i], qf[i], s);
+    ta_ops_t(pa, vt, 0, hf, ln);
+    TA_FENCE();
 #pragma unroll
-    for (int i = 0; i < 32; ++i) dp = TA_MFMA(vt[(2 * i + hf) * TA_TP + ln], dof[i], dp);
+    for (int i = 0; i < 16; ++i) s = TA_MFMA(pb[i], qf[16 + i], s);
+    ta_ops_t(pb, vt, 16, hf, ln);
+    TA_FENCE();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dp = TA_MFMA(pa[i], dof[i], dp);
+    ta_ops_s(pa, ks, 0, hf, ln);
+    TA_FENCE();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dp = TA_MFMA(pb[i], dof[16 + i], dp);
+    ta_ops_s(pb, ks, 8, hf, ln);
+    TA_FENCE();
     const bool ragged = tile * 32 + 32 > pr.nk;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -274,10 +325,14 @@ __global__ __launch_bounds__(256) void ta_bwd_q_kernel(TaK a) {
       s[j] = p * (dp[j] - dsum) * a.scale;                 // dS^T, with the 1/sqrt(d_head) of dQ = dS K / sqrt(d_head)
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float* krow = ks + ta_row_of(j, hf) * TA_SP + ln;
-      g0 = TA_MFMA(krow[0], s[j], g0);
-      g1 = TA_MFMA(krow[32], s[j], g1);
+    for (int j = 0; j < 8; ++j) {
+      g0 = TA_MFMA(pa[2 * j], s[j], g0);
+      g1 = TA_MFMA(pa[2 * j + 1], s[j], g1);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      g0 = TA_MFMA(pb[2 * j], s[8 + j], g0);
+      g1 = TA_MFMA(pb[2 * j + 1], s[8 + j], g1);
     }
   }
   if (qrow >= pr.nq) return;
@@ -291,7 +346,7 @@ __global__ __launch_bounds__(256) void ta_bwd_q_kernel(TaK a) {
 }
 
 // ------------------------------------------------------------------------------------------------ reverse pass: dK, dV
-__global__ __launch_bounds__(256) void ta_bwd_kv_kernel(TaK a) {
+__global__ __launch_bounds__(256, 2) void ta_bwd_kv_kernel(TaK a) {
   __shared__ __attribute__((aligned(16))) float qt[64 * TA_TP];
   __shared__ __attribute__((aligned(16))) float qs[32 * TA_SP];
   __shared__ __attribute__((aligned(16))) float dt[64 * TA_TP];
@@ -350,13 +405,29 @@ __global__ __launch_bounds__(256) void ta_bwd_kv_kernel(TaK a) {
       ta_fetch(dbase, a.lddo, (tile + 1) * 32, pr.nq, dr);
       fetch_stat(tile + 1);
     }
+    float pa[16], pb[16];
+    ta_ops_t(pa, qt, 0, hf, ln);
+    ta_ops_t(pb, qt, 16, hf, ln);
+    TA_FENCE();
     f32x16 s, dp;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s[j] = dp[j] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) s = TA_MFMA(qt[(2 * i + hf) * TA_TP + ln], kf[i], s);          // S[q][key]
+    for (int i = 0; i < 16; ++i) s = TA_MFMA(pa[i], kf[i], s);                                   // S[q][key]
+    ta_ops_t(pa, dt, 0, hf, ln);
+    TA_FENCE();
 #pragma unroll
-    for (int i = 0; i < 32; ++i) dp = TA_MFMA(dt[(2 * i + hf) * TA_TP + ln], vf[i], dp);        // dP[q][key]
+    for (int i = 0; i < 16; ++i) s = TA_MFMA(pb[i], kf[16 + i], s);
+    ta_ops_t(pb, dt, 16, hf, ln);
+    TA_FENCE();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dp = TA_MFMA(pa[i], vf[i], dp);                                 // dP[q][key]
+    ta_ops_s(pa, ds_, 0, hf, ln);
+    TA_FENCE();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dp = TA_MFMA(pb[i], vf[16 + i], dp);
+    ta_ops_s(pb, ds_, 8, hf, ln);
+    TA_FENCE();
     const bool ragged = tile * 32 + 32 > pr.nq;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -367,12 +438,28 @@ __global__ __launch_bounds__(256) void ta_bwd_kv_kernel(TaK a) {
       dp[j] = p * (dp[j] - dsum_s[q]);                     // dS[q][key]
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int q = ta_row_of(j, hf);
-      gv0 = TA_MFMA(ds_[q * TA_SP + ln], s[j], gv0);
-      gv1 = TA_MFMA(ds_[q * TA_SP + 32 + ln], s[j], gv1);
-      gk0 = TA_MFMA(qs[q * TA_SP + ln], dp[j], gk0);
-      gk1 = TA_MFMA(qs[q * TA_SP + 32 + ln], dp[j], gk1);
+    for (int j = 0; j < 8; ++j) {
+      gv0 = TA_MFMA(pa[2 * j], s[j], gv0);
+      gv1 = TA_MFMA(pa[2 * j + 1], s[j], gv1);
+    }
+    ta_ops_s(pa, qs, 0, hf, ln);
+    TA_FENCE();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gv0 = TA_MFMA(pb[2 * j], s[8 + j], gv0);
+      gv1 = TA_MFMA(pb[2 * j + 1], s[8 + j], gv1);
+    }
+    ta_ops_s(pb, qs, 8, hf, ln);
+    TA_FENCE();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gk0 = TA_MFMA(pa[2 * j], dp[j], gk0);
+      gk1 = TA_MFMA(pa[2 * j + 1], dp[j], gk1);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gk0 = TA_MFMA(pb[2 * j], dp[8 + j], gk0);
+      gk1 = TA_MFMA(pb[2 * j + 1], dp[8 + j], gk1);
     }
   }
   if (krow >= pr.nk) return;

@@ -115,7 +115,8 @@ class GMatcher(nn.Module):
         'attention_auto_tail': 0.02,
         'attention_f16_range': 3.0e4,
         'attention_monitor_period': 1,
-        'train_precision': 'bf16x6',      # products of the training step (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
+        'train_precision': 'bf16x6',      # products of the training step's forward (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
+        'train_backward_precision': 'bf16x3',      # products of its reverse pass (linear in its operands: no accuracy lost, trainstep.py)
         'verbose': False,               # the reference prints '>> ...' timing lines; off by default here
         # fold the attention 'merge' conv into the first MLP conv at load time:
         #   W0 [x ; Wm o + bm] + b0  ==  W0x x + (W0m Wm) o + (W0m bm + b0)        (gmatcher.py:114,125)

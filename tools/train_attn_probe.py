@@ -11,7 +11,7 @@ qkv = torch.randn(2 * n, 3 * d, generator=g).cuda()
 do = torch.randn(2 * n, d, generator=g).cuda()
 for cross in (False, True):
     problems = hip.train_attn_problems([(0, n, n, n), (n, n, 0, n)] if cross else [(0, n, 0, n), (n, n, n, n)])
-    for splits in ("1", "2", "4", "8"):
+    for splits in os.environ.get("PROBE_SPLITS", "1,2,4,8").split(","):
         os.environ["GIMS_TRAIN_ATTN_SPLITS"] = splits
         o, lse = hip.train_attention_forward(qkv, problems, heads)
         dq = hip.train_attention_backward(qkv, o, lse, do, problems, heads)
