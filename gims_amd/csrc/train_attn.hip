@@ -481,6 +481,276 @@ __global__ __launch_bounds__(256, 2) void ta_bwd_kv_kernel(TaK a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ reverse pass in three bf16 passes
+// The same two kernels on v_mfma_f32_32x32x16_bf16 (32 cycles per 32 x 32 x 16 step instead of 64 per 32 x 32 x 2): every operand is split into
+// hi = bf16(x), lo = bf16(x - hi) and a product is lo*hi + hi*lo + hi*hi (small terms first).  The reverse pass is LINEAR in its operands -- no
+// ReLU decides anything there -- and on every trainstep_* fixture the gradient errors with 16-bit-mantissa reverse products equal those of the
+// exact ones to three digits (trainstep.py:_backward_precision).  Tile products per 32 x 32 tile: 12 steps instead of 32, i.e. 384 matrix
+// cycles instead of 2048.
+// Streamed tiles sit in LDS ROW-MAJOR as two bf16 images [32][64] (pitch 72 elements = 144 B: sixteen lanes reading 16 B of sixteen rows touch
+// every bank once).  A tile is read two ways: as the A operand of a product over d (lane <-> row, 8 consecutive d: one ds_read_b128) and, for
+// the products that contract over the tile's ROWS, transposed by ds_read_b64_tr_b16 (lane <-> d, k-slots = rows 16 s + 8 (j >> 2) + 4 (lane >> 5)
+// + (j & 3): exactly the rows the accumulator registers 8 s .. 8 s + 7 of the score tile stand for -- the addressing of attention.hip's V^T
+// fragments, tools/probes/tr16_probe.hip).
+constexpr int TB_P = 72;
+typedef short s16x4t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float tb_hi_lo16(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float tb_hi_hi16(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+// two f32 -> packed bf16 hi pair and packed bf16 lo pair
+__device__ __forceinline__ void tb_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf2(x0, x1);
+  lo = pack_bf2(x0 - tb_hi_lo16(hi), x1 - tb_hi_hi16(hi));
+}
+__device__ __forceinline__ void tb_frag8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+  uint4 h, l;
+  tb_split2(x[0], x[1], h.x, l.x);
+  tb_split2(x[2], x[3], h.y, l.y);
+  tb_split2(x[4], x[5], h.z, l.z);
+  tb_split2(x[6], x[7], h.w, l.w);
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+// registers 8 s .. 8 s + 7 of a score tile as the B operand of step s of a product over the tile's rows
+__device__ __forceinline__ void tb_frag_acc(const f32x16& x, int s, bf16x8& hi, bf16x8& lo) {
+  const float v[8] = {x[8 * s], x[8 * s + 1], x[8 * s + 2], x[8 * s + 3], x[8 * s + 4], x[8 * s + 5], x[8 * s + 6], x[8 * s + 7]};
+  tb_frag8(v, hi, lo);
+}
+__device__ __forceinline__ void tb_put(uint16_t* hi_t, uint16_t* lo_t, const f32x4 (&reg)[2]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int idx = threadIdx.x + 256 * r, row = idx >> 4, c4 = idx & 15;
+    uint2 h, l;
+    tb_split2(reg[r][0], reg[r][1], h.x, l.x);
+    tb_split2(reg[r][2], reg[r][3], h.y, l.y);
+    *(uint2*)(hi_t + row * TB_P + 4 * c4) = h;
+    *(uint2*)(lo_t + row * TB_P + 4 * c4) = l;
+  }
+}
+__device__ __forceinline__ bf16x8 tb_row_op(const uint16_t* tile, int st, int ln, int hf) { return *(const bf16x8*)(tile + ln * TB_P + 16 * st + 8 * hf); }
+__device__ __forceinline__ bf16x8 tb_tr_op(const uint16_t* tile, int s, int i, int lane) {
+  const uint16_t* p = tile + (4 * (lane >> 5) + ((lane & 15) >> 2)) * TB_P + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + 16 * s * TB_P + 32 * i;
+  const s16x4t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4t __attribute__((address_space(3)))*)(p));
+  const s16x4t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4t __attribute__((address_space(3)))*)(p + 8 * TB_P));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+#define TB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// c += (ah + al)(bh + bl) without the lo * lo term, small terms first
+#define TB_MFMA3(ah, al, bh, bl, c) \
+  do {                              \
+    (c) = TB_MFMA((al), (bh), (c)); \
+    (c) = TB_MFMA((ah), (bl), (c)); \
+    (c) = TB_MFMA((ah), (bh), (c)); \
+  } while (0)
+
+// 8 consecutive floats of a row as a resident B fragment (optionally scaled by a power of two)
+__device__ __forceinline__ void tb_load8(const float* p, float scale, float (&x)[8]) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { x[e] = a[e] * scale; x[4 + e] = b[e] * scale; }
+}
+
+__global__ __launch_bounds__(256, 2) void tb_bwd_q_kernel(TaK a) {
+  __shared__ __attribute__((aligned(16))) uint16_t kh[32 * TB_P], kl[32 * TB_P], vh[32 * TB_P], vl[32 * TB_P];
+  const gims_train_attn_problem pr = a.pr[blockIdx.z];
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= pr.nq) return;
+  const int h = blockIdx.y / a.splits, sp = blockIdx.y % a.splits;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hf = lane >> 5;
+  const int ntile = (pr.nk + 31) >> 5;
+  const int t_lo = (int)((int64_t)sp * ntile / a.splits), t_hi = (int)((int64_t)(sp + 1) * ntile / a.splits);
+  const int qrow = q0 + wave * 32 + ln;
+  const int64_t row = pr.q_off + (qrow < pr.nq ? qrow : pr.nq - 1);
+  const float* kbase = a.qkv + (int64_t)pr.k_off * a.ld + a.d + h * 64;
+  const float* vbase = kbase + a.d;
+  bf16x8 qhi[4], qlo[4], dohi[4], dolo[4];
+  float dsum = 0.f;
+  {
+    const float* qp = a.qkv + row * a.ld + h * 64 + 8 * hf;
+    const float* dp = a.dout + row * a.lddo + h * 64 + 8 * hf;
+    const float* op = a.o + row * a.ldo + h * 64 + 8 * hf;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float q8[8], d8[8], o8[8];
+      tb_load8(qp + 16 * st, a.scale, q8);
+      tb_load8(dp + 16 * st, 1.f, d8);
+      tb_load8(op + 16 * st, 1.f, o8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum = fmaf(d8[e], o8[e], dsum);
+      tb_frag8(q8, qhi[st], qlo[st]);
+      tb_frag8(d8, dohi[st], dolo[st]);
+    }
+    dsum += ta_other_half(dsum);
+  }
+  const float lse = a.lse[(int64_t)h * a.rows + row];
+  if (sp == 0 && hf == 0 && qrow < pr.nq) a.part[(int64_t)h * a.rows + row] = dsum;
+  f32x16 g0, g1;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) g0[j] = g1[j] = 0.f;
+  f32x4 kr[2], vr[2];
+  if (t_lo < t_hi) {
+    ta_fetch(kbase, a.ld, t_lo * 32, pr.nk, kr);
+    ta_fetch(vbase, a.ld, t_lo * 32, pr.nk, vr);
+  }
+  for (int tile = t_lo; tile < t_hi; ++tile) {
+    __syncthreads();
+    tb_put(kh, kl, kr);
+    tb_put(vh, vl, vr);
+    __syncthreads();
+    if (tile + 1 < t_hi) {
+      ta_fetch(kbase, a.ld, (tile + 1) * 32, pr.nk, kr);
+      ta_fetch(vbase, a.ld, (tile + 1) * 32, pr.nk, vr);
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = dp[j] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {                       // S^T[key][q], dP^T[key][q]
+      const bf16x8 ah = tb_row_op(kh, st, ln, hf), al = tb_row_op(kl, st, ln, hf);
+      TB_MFMA3(ah, al, qhi[st], qlo[st], s);
+      const bf16x8 bh = tb_row_op(vh, st, ln, hf), bl = tb_row_op(vl, st, ln, hf);
+      TB_MFMA3(bh, bl, dohi[st], dolo[st], dp);
+    }
+    const bool ragged = tile * 32 + 32 > pr.nk;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float p = __expf(s[j] - lse);
+      if (ragged && tile * 32 + ta_row_of(j, hf) >= pr.nk) p = 0.f;
+      s[j] = p * (dp[j] - dsum) * a.scale;                 // dS^T, with the 1/sqrt(d_head) of dQ = dS K / sqrt(d_head)
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 sh, sl;
+      tb_frag_acc(s, s2, sh, sl);
+      {
+        const bf16x8 ah = tb_tr_op(kh, s2, 0, lane), al = tb_tr_op(kl, s2, 0, lane);
+        TB_MFMA3(ah, al, sh, sl, g0);
+      }
+      {
+        const bf16x8 ah = tb_tr_op(kh, s2, 1, lane), al = tb_tr_op(kl, s2, 1, lane);
+        TB_MFMA3(ah, al, sh, sl, g1);
+      }
+    }
+  }
+  if (qrow >= pr.nq) return;
+  float* gp = a.splits == 1 ? a.dqkv + row * a.lddq + h * 64
+                            : a.part + ta_dfloats(a.heads, a.rows) + (((int64_t)sp * a.heads + h) * a.rows + row) * 64;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    *(f32x4*)(gp + 8 * jj + 4 * hf) = f32x4{g0[4 * jj], g0[4 * jj + 1], g0[4 * jj + 2], g0[4 * jj + 3]};
+    *(f32x4*)(gp + 32 + 8 * jj + 4 * hf) = f32x4{g1[4 * jj], g1[4 * jj + 1], g1[4 * jj + 2], g1[4 * jj + 3]};
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void tb_bwd_kv_kernel(TaK a) {
+  __shared__ __attribute__((aligned(16))) uint16_t qh[32 * TB_P], ql[32 * TB_P], dh[32 * TB_P], dl[32 * TB_P];
+  __shared__ float lse_s[32], dsum_s[32];
+  const gims_train_attn_problem pr = a.pr[blockIdx.z];
+  const int k0 = blockIdx.x * 128;
+  if (k0 >= pr.nk) return;
+  const int h = blockIdx.y / a.splits, sp = blockIdx.y % a.splits;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 31, hf = lane >> 5;
+  const int ntile = (pr.nq + 31) >> 5;
+  const int t_lo = (int)((int64_t)sp * ntile / a.splits), t_hi = (int)((int64_t)(sp + 1) * ntile / a.splits);
+  const int krow = k0 + wave * 32 + ln;
+  const int64_t row = pr.k_off + (krow < pr.nk ? krow : pr.nk - 1);
+  const float* qbase = a.qkv + (int64_t)pr.q_off * a.ld + h * 64;
+  const float* dbase = a.dout + (int64_t)pr.q_off * a.lddo + h * 64;
+  const float* lbase = a.lse + (int64_t)h * a.rows + pr.q_off;
+  const float* sbase = a.part + (int64_t)h * a.rows + pr.q_off;
+  bf16x8 khi[4], klo[4], vhi[4], vlo[4];
+  {
+    const float* kp = a.qkv + row * a.ld + a.d + h * 64 + 8 * hf;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float k8[8], v8[8];
+      tb_load8(kp + 16 * st, a.scale, k8);
+      tb_load8(kp + a.d + 16 * st, 1.f, v8);
+      tb_frag8(k8, khi[st], klo[st]);
+      tb_frag8(v8, vhi[st], vlo[st]);
+    }
+  }
+  f32x16 gk0, gk1, gv0, gv1;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) gk0[j] = gk1[j] = gv0[j] = gv1[j] = 0.f;
+  f32x4 qr[2], dr[2];
+  float st_ = 0.f;                                         // threads 0..31: lse of the tile's queries, 32..63: D
+  auto fetch_stat = [&](int tile) {
+    if (threadIdx.x < 64) {
+      int q = tile * 32 + (threadIdx.x & 31);
+      q = q < pr.nq ? q : pr.nq - 1;
+      st_ = threadIdx.x < 32 ? lbase[q] : sbase[q];
+    }
+  };
+  if (t_lo < t_hi) {
+    ta_fetch(qbase, a.ld, t_lo * 32, pr.nq, qr);
+    ta_fetch(dbase, a.lddo, t_lo * 32, pr.nq, dr);
+    fetch_stat(t_lo);
+  }
+  for (int tile = t_lo; tile < t_hi; ++tile) {
+    __syncthreads();
+    tb_put(qh, ql, qr);
+    tb_put(dh, dl, dr);
+    if (threadIdx.x < 32) lse_s[threadIdx.x] = st_;
+    else if (threadIdx.x < 64) dsum_s[threadIdx.x - 32] = st_;
+    __syncthreads();
+    if (tile + 1 < t_hi) {
+      ta_fetch(qbase, a.ld, (tile + 1) * 32, pr.nq, qr);
+      ta_fetch(dbase, a.lddo, (tile + 1) * 32, pr.nq, dr);
+      fetch_stat(tile + 1);
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = dp[j] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {                       // S[q][key], dP[q][key]
+      const bf16x8 ah = tb_row_op(qh, st, ln, hf), al = tb_row_op(ql, st, ln, hf);
+      TB_MFMA3(ah, al, khi[st], klo[st], s);
+      const bf16x8 bh = tb_row_op(dh, st, ln, hf), bl = tb_row_op(dl, st, ln, hf);
+      TB_MFMA3(bh, bl, vhi[st], vlo[st], dp);
+    }
+    const bool ragged = tile * 32 + 32 > pr.nq;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int q = ta_row_of(j, hf);
+      float p = __expf(s[j] - lse_s[q]);
+      if (ragged && tile * 32 + q >= pr.nq) p = 0.f;
+      s[j] = p;
+      dp[j] = p * (dp[j] - dsum_s[q]);                     // dS[q][key]
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 ph, pl, sh, sl;
+      tb_frag_acc(s, s2, ph, pl);
+      tb_frag_acc(dp, s2, sh, sl);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 ah = tb_tr_op(dh, s2, i, lane), al = tb_tr_op(dl, s2, i, lane);
+        if (i == 0) TB_MFMA3(ah, al, ph, pl, gv0); else TB_MFMA3(ah, al, ph, pl, gv1);
+        const bf16x8 bh = tb_tr_op(qh, s2, i, lane), bl = tb_tr_op(ql, s2, i, lane);
+        if (i == 0) TB_MFMA3(bh, bl, sh, sl, gk0); else TB_MFMA3(bh, bl, sh, sl, gk1);
+      }
+    }
+  }
+  if (krow >= pr.nk) return;
+  float *kp, *vp;
+  if (a.splits == 1) {
+    kp = a.dqkv + row * a.lddq + a.d + h * 64;
+    vp = kp + a.d;
+  } else {
+    const int64_t blk = (int64_t)a.splits * a.heads * a.rows * 64;
+    kp = a.part + ta_dfloats(a.heads, a.rows) + blk + (((int64_t)sp * a.heads + h) * a.rows + row) * 64;
+    vp = kp + blk;
+  }
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    *(f32x4*)(kp + 8 * jj + 4 * hf) = f32x4{gk0[4 * jj], gk0[4 * jj + 1], gk0[4 * jj + 2], gk0[4 * jj + 3]} * a.scale;
+    *(f32x4*)(kp + 32 + 8 * jj + 4 * hf) = f32x4{gk1[4 * jj], gk1[4 * jj + 1], gk1[4 * jj + 2], gk1[4 * jj + 3]} * a.scale;
+    *(f32x4*)(vp + 8 * jj + 4 * hf) = f32x4{gv0[4 * jj], gv0[4 * jj + 1], gv0[4 * jj + 2], gv0[4 * jj + 3]};
+    *(f32x4*)(vp + 32 + 8 * jj + 4 * hf) = f32x4{gv1[4 * jj], gv1[4 * jj + 1], gv1[4 * jj + 2], gv1[4 * jj + 3]};
+  }
+}
+
 // fold of the reverse partials, in split order: which = 0 (dQ, over the problem's query rows), 1 / 2 (dK / dV, over its source rows)
 __global__ __launch_bounds__(256) void ta_bwd_merge_kernel(TaK a) {
   const gims_train_attn_problem pr = a.pr[blockIdx.z];
@@ -525,6 +795,9 @@ static int ta_check(const gims_train_attn_args* g, const char* who, bool reverse
     GIMS_CHECK_ARG(p.nq >= 1 && p.nk >= 1 && p.q_off >= 0 && p.k_off >= 0 && (int64_t)p.q_off + p.nq <= g->rows && (int64_t)p.k_off + p.nk <= g->rows,
                    "%s: problem %d (queries %d + %d, sources %d + %d) does not lie inside the %lld rows", who, i, p.q_off, p.nq, p.k_off, p.nk, (long long)g->rows);
   }
+  if (reverse)
+    GIMS_CHECK_ARG(g->reverse_precision == GIMS_TRAIN_ATTN_REVERSE_F32 || g->reverse_precision == GIMS_TRAIN_ATTN_REVERSE_BF16X3,
+                   "%s: unknown reverse_precision %d", who, g->reverse_precision);
   if (reverse)
     GIMS_CHECK_ARG(g->d_o && g->d_qkv && g->lddo >= g->d && g->lddq >= 3 * g->d && (g->lddo & 3) == 0 && (g->lddq & 3) == 0 && ((uintptr_t)g->d_o & 15) == 0 &&
                        ((uintptr_t)g->d_qkv & 15) == 0,
@@ -586,10 +859,17 @@ extern "C" int gims_train_attention_backward(const gims_train_attn_args* g, void
       maxq = std::max(maxq, k.pr[i].nq);
       maxk = std::max(maxk, k.pr[i].nk);
     }
-    hipLaunchKernelGGL(ta_bwd_q_kernel, dim3(cdiv(maxq, 128), g->heads * splits, count), dim3(256), 0, s, k);
-    GIMS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ta_bwd_kv_kernel, dim3(cdiv(maxk, 128), g->heads * splits, count), dim3(256), 0, s, k);
-    GIMS_LAUNCH_CHECK();
+    if (g->reverse_precision == GIMS_TRAIN_ATTN_REVERSE_F32) {
+      hipLaunchKernelGGL(ta_bwd_q_kernel, dim3(cdiv(maxq, 128), g->heads * splits, count), dim3(256), 0, s, k);
+      GIMS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ta_bwd_kv_kernel, dim3(cdiv(maxk, 128), g->heads * splits, count), dim3(256), 0, s, k);
+      GIMS_LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL(tb_bwd_q_kernel, dim3(cdiv(maxq, 128), g->heads * splits, count), dim3(256), 0, s, k);
+      GIMS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(tb_bwd_kv_kernel, dim3(cdiv(maxk, 128), g->heads * splits, count), dim3(256), 0, s, k);
+      GIMS_LAUNCH_CHECK();
+    }
     if (splits > 1) {
       hipLaunchKernelGGL(ta_bwd_merge_kernel, dim3(cdiv((int64_t)std::max(maxq, maxk) * g->heads * 16, 256), 3, count), dim3(256), 0, s, k);
       GIMS_LAUNCH_CHECK();

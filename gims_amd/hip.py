@@ -117,7 +117,7 @@ class TrainAttnProblem(C.Structure):
 class TrainAttnArgs(C.Structure):
     _fields_ = [("qkv", C.c_void_p), ("ld", C.c_int64), ("rows", C.c_int64), ("d", C.c_int32), ("heads", C.c_int32), ("scale", C.c_float),
                 ("n_problems", C.c_int32), ("problems", C.POINTER(TrainAttnProblem)), ("o", C.c_void_p), ("ldo", C.c_int64), ("lse", C.c_void_p),
-                ("d_o", C.c_void_p), ("lddo", C.c_int64), ("d_qkv", C.c_void_p), ("lddq", C.c_int64), ("work", C.c_void_p), ("work_floats", C.c_size_t)]
+                ("d_o", C.c_void_p), ("lddo", C.c_int64), ("d_qkv", C.c_void_p), ("lddq", C.c_int64), ("work", C.c_void_p), ("work_floats", C.c_size_t), ("reverse_precision", C.c_int32)]
 
 
 class Segments(C.Structure):
@@ -1196,7 +1196,10 @@ def train_attn_problems(problems):
     return arr, len(problems)
 
 
-def _train_attn_args(qkv, problems, heads, o, lse, d_o=None, d_qkv=None):
+TRAIN_ATTN_REVERSE_F32, TRAIN_ATTN_REVERSE_BF16X3 = 0, 1
+
+
+def _train_attn_args(qkv, problems, heads, o, lse, d_o=None, d_qkv=None, reverse_precision=1):
     rows, d = qkv.shape[0], qkv.shape[1] // 3
     assert qkv.dtype == torch.float32 and qkv.stride(1) == 1 and o.stride(1) == 1 and lse.is_contiguous() and lse.shape == (heads, rows)
     need = int(load().gims_train_attention_workspace_floats(rows, heads))
@@ -1208,7 +1211,8 @@ def _train_attn_args(qkv, problems, heads, o, lse, d_o=None, d_qkv=None):
         w = _tattn_work[key] = torch.empty(need, dtype=torch.float32, device=qkv.device)
     arr, n = problems if isinstance(problems, tuple) else train_attn_problems(problems)
     g = TrainAttnArgs(qkv.data_ptr(), qkv.stride(0), rows, d, heads, 1.0 / math.sqrt(d // heads), n, arr, o.data_ptr(), o.stride(0), lse.data_ptr(),
-                      _p(d_o), d_o.stride(0) if d_o is not None else 0, _p(d_qkv), d_qkv.stride(0) if d_qkv is not None else 0, w.data_ptr(), w.numel())
+                      _p(d_o), d_o.stride(0) if d_o is not None else 0, _p(d_qkv), d_qkv.stride(0) if d_qkv is not None else 0, w.data_ptr(), w.numel(),
+                      int(reverse_precision))
     return g, arr
 
 
@@ -1223,11 +1227,15 @@ def train_attention_forward(qkv: torch.Tensor, problems, heads: int, o: torch.Te
     return o, lse
 
 
-def train_attention_backward(qkv, o, lse, d_o, problems, heads: int, d_qkv: torch.Tensor | None = None):
-    """d_qkv [rows, 3 d] from the gradient d_o of train_attention_forward's output."""
+def train_attention_backward(qkv, o, lse, d_o, problems, heads: int, d_qkv: torch.Tensor | None = None, precision=None):
+    """d_qkv [rows, 3 d] from the gradient d_o of train_attention_forward's output.  precision: PREC_BF16X3 (three bf16 passes; also the default
+    inside a gemm_precision(PREC_BF16X3) block, as the training step's reverse pass is) or anything else = exact f32 products."""
+    if precision is None:
+        precision = getattr(_TLS, "gemm_prec", None)
+    rp = TRAIN_ATTN_REVERSE_BF16X3 if precision == PREC_BF16X3 else TRAIN_ATTN_REVERSE_F32
     d_qkv = torch.empty_like(qkv) if d_qkv is None else d_qkv
     assert d_o.stride(1) == 1 and d_qkv.stride(1) == 1
-    g, keep = _train_attn_args(qkv, problems, heads, o, lse, d_o, d_qkv)
+    g, keep = _train_attn_args(qkv, problems, heads, o, lse, d_o, d_qkv, rp)
     _check(load().gims_train_attention_backward(C.byref(g), _stream()), "gims_train_attention_backward")
     return d_qkv
 

@@ -637,7 +637,8 @@ int gims_layernorm_backward(const float* x, int64_t ldx, const float* dy, int64_
  * rows [k_off, k_off + nk) (self: the same image, cross: the other one).
  * forward: o [rows][ldo] = softmax(scale * Q K^T) V and lse [heads][rows] = max + log(sum) of every score row (what the reverse pass needs
  * instead of P).  backward: d_qkv [rows][lddq] from d_o, o, lse (every row must be a query row of exactly one problem and a source row of exactly
- * one for d_qkv to be written completely).  Exact f32 on the matrix cores (v_mfma_f32_32x32x2_f32), fixed summation orders.  work:
+ * one for d_qkv to be written completely).  The forward is exact f32 on the matrix cores (v_mfma_f32_32x32x2_f32); the reverse pass -- linear in
+ * its operands -- as reverse_precision says.  Fixed summation orders.  work:
  * gims_train_attention_workspace_floats(rows, heads) floats, 16-byte aligned. */
 typedef struct gims_train_attn_problem {
   int32_t q_off, nq, k_off, nk;
@@ -658,7 +659,10 @@ typedef struct gims_train_attn_args {
   int64_t lddq;
   float* work;
   size_t work_floats;
+  int32_t reverse_precision;                 /* backward only: GIMS_TRAIN_ATTN_REVERSE_* */
 } gims_train_attn_args;
+#define GIMS_TRAIN_ATTN_REVERSE_F32 0     /* exact f32 products (v_mfma_f32_32x32x2_f32), like the forward */
+#define GIMS_TRAIN_ATTN_REVERSE_BF16X3 1  /* operands split into two bf16 parts, three passes (v_mfma_f32_32x32x16_bf16): 16-bit-mantissa products */
 size_t gims_train_attention_workspace_floats(int64_t rows, int32_t heads);
 int gims_train_attention_forward(const gims_train_attn_args* args, void* stream);
 int gims_train_attention_backward(const gims_train_attn_args* args, void* stream);

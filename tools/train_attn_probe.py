@@ -16,16 +16,19 @@ for cross in (False, True):
         o, lse = hip.train_attention_forward(qkv, problems, heads)
         dq = hip.train_attention_backward(qkv, o, lse, do, problems, heads)
         torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         reps = 20
         ev[0].record()
         for _ in range(reps):
             hip.train_attention_forward(qkv, problems, heads, o, lse)
         ev[1].record()
         for _ in range(reps):
-            hip.train_attention_backward(qkv, o, lse, do, problems, heads, dq)
+            hip.train_attention_backward(qkv, o, lse, do, problems, heads, dq, precision=hip.PREC_F32)
         ev[2].record()
+        for _ in range(reps):
+            hip.train_attention_backward(qkv, o, lse, do, problems, heads, dq, precision=hip.PREC_BF16X3)
+        ev[3].record()
         torch.cuda.synchronize()
-        f, b = ev[0].elapsed_time(ev[1]) / reps * 1e3, ev[1].elapsed_time(ev[2]) / reps * 1e3
-        fl = 2 * heads * 2 * n * n * 64 * 2 / 1e12          # two products, both images: TFLOP
-        print(f"n={n} cross={int(cross)} splits={splits}: forward {f:7.1f} us ({2 * fl / (f * 1e-6):6.1f} TFLOP/s)  backward {b:7.1f} us ({7 * fl / (b * 1e-6):6.1f} TFLOP/s over 7 products)", flush=True)
+        f, b, b3 = (ev[i].elapsed_time(ev[i + 1]) / reps * 1e3 for i in range(3))
+        fl = 2 * heads * n * n * 64 * 2 / 1e12          # one product, both images: TFLOP
+        print(f"n={n} cross={int(cross)} splits={splits}: forward {f:7.1f} us ({2 * fl / (f * 1e-6):6.1f} TFLOP/s f32)  backward f32 {b:7.1f} us ({7 * fl / (b * 1e-6):6.1f} TFLOP/s over 7 products)  backward bf16x3 {b3:7.1f} us", flush=True)
