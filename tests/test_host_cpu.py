@@ -32,6 +32,8 @@ def test_struct_layouts_match_header(tmp_path):
     pairs = [("gims_linear_args", hip.LinearArgs, ["a0", "w", "bias", "out_f32", "m", "act", "scale", "a0_lo", "out_hi", "ld_split", "flags", "conv_h", "guard", "range_stat"]),
              ("gims_attn_guard", hip.AttnGuard, ["stat", "mean_thr", "range_limit", "n_heads", "kind"]),
              ("gims_attn_args", hip.AttnArgs, ["qkv", "q_col", "problems", "n_heads", "out", "ld_split", "flags", "stat", "guard"]),
+             ("gims_train_attn_problem", hip.TrainAttnProblem, ["nk"]),
+             ("gims_train_attn_args", hip.TrainAttnArgs, ["qkv", "rows", "d", "scale", "problems", "o", "lse", "d_o", "d_qkv", "work", "work_floats", "reverse_precision"]),
              ("gims_ot_problem", hip.OtProblem, []), ("gims_agc_image", hip.AgcImage, ["kept", "max_edges_dir", "info"]),
              ("gims_pack_image", hip.PackImage, []), ("gims_ingest_image", hip.IngestImage, []), ("gims_op", hip.Op, ["u"])]
     body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (c, c) + "".join('printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (c, f, c, f) for f in fs)

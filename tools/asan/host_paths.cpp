@@ -76,6 +76,37 @@ int main() {
     lg.guard.stat = (uint64_t*)0x4000; lg.guard.kind = GIMS_GUARD_PEAKED; lg.guard.n_heads = 4;
     EXPECT(gims_linear(&lg, nullptr) == GIMS_EINVAL);                                  // a guard on a launch without pre-split operands
   }
+  {   // round 5: training attention (gims_train_attention_*) -- argument validation and workspace arithmetic (no launch)
+    EXPECT(gims_train_attention_workspace_floats(0, 4) == 0);
+    EXPECT(gims_train_attention_workspace_floats(4096, 4) >= (size_t)4096 * 4 * (1 + 3 * 64));
+    EXPECT(gims_train_attention_workspace_floats(3, 3) % 4 == 0 || gims_train_attention_workspace_floats(3, 3) > 9);      // D block rounded to 16 bytes
+    std::vector<gims_train_attn_problem> tp(40);
+    for (int i = 0; i < 40; ++i) { tp[i].q_off = 100 * i; tp[i].nq = 100; tp[i].k_off = 100 * (i ^ 1); tp[i].nk = 100; }
+    gims_train_attn_args ta; memset(&ta, 0, sizeof(ta));
+    EXPECT(gims_train_attention_forward(nullptr, nullptr) == GIMS_EINVAL);
+    EXPECT(gims_train_attention_forward(&ta, nullptr) == GIMS_EINVAL);
+    ta.qkv = (const float*)0x10000; ta.ld = 768; ta.rows = 4000; ta.d = 256; ta.heads = 4; ta.scale = 0.125f; ta.n_problems = 40; ta.problems = tp.data();
+    ta.o = (float*)0x20000; ta.ldo = 256; ta.lse = (float*)0x30000;
+    ta.heads = 8;
+    EXPECT(gims_train_attention_forward(&ta, nullptr) == GIMS_EINVAL);                 // head dimension 32
+    ta.heads = 4; ta.ld = 767;
+    EXPECT(gims_train_attention_forward(&ta, nullptr) == GIMS_EINVAL);                 // pitch
+    ta.ld = 768; tp[38].nk = 101;
+    EXPECT(gims_train_attention_forward(&ta, nullptr) == GIMS_EINVAL);                 // sources beyond the rows
+    EXPECT(strstr(gims_last_error(), "problem 38") != nullptr);
+    tp[38].nk = 100; tp[7].nq = 0;
+    EXPECT(gims_train_attention_forward(&ta, nullptr) == GIMS_EINVAL);                 // an empty problem
+    tp[7].nq = 100;
+    EXPECT(gims_train_attention_forward(&ta, nullptr) == GIMS_EINVAL);                 // several key ranges and no workspace
+    ta.work = (float*)0x40004;
+    EXPECT(gims_train_attention_forward(&ta, nullptr) == GIMS_EINVAL);                 // misaligned workspace
+    ta.work = (float*)0x40000; ta.work_floats = 16;
+    EXPECT(gims_train_attention_forward(&ta, nullptr) == GIMS_EINVAL);                 // too small
+    ta.work_floats = gims_train_attention_workspace_floats(ta.rows, ta.heads);
+    EXPECT(gims_train_attention_backward(&ta, nullptr) == GIMS_EINVAL);                // no gradient tensors
+    ta.d_o = (const float*)0x50000; ta.lddo = 256; ta.d_qkv = (float*)0x60000; ta.lddq = 768; ta.reverse_precision = 5;
+    EXPECT(gims_train_attention_backward(&ta, nullptr) == GIMS_EINVAL);                // unknown reverse precision
+  }
   // ---- evaluation: workspace arithmetic
   std::vector<gims_eval_pair> ep(3);
   for (size_t i = 0; i < ep.size(); ++i) { memset(&ep[i], 0, sizeof(ep[i])); ep[i].n0 = 500 + (int)i; ep[i].n1 = 400; ep[i].height = 480; ep[i].width = 640; }
