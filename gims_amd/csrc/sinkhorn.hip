@@ -1361,6 +1361,10 @@ extern "C" int gims_sinkhorn_history(const gims_ot_problem* pr, int32_t np, floa
   const int rc = upload_table(hprob.data(), sizeof(OtDev) * (size_t)np, work, s);
   if (rc != GIMS_OK) return rc;
   const OtDev* dp = (const OtDev*)work;
+  // (Round 5 measured the recorded solve on chip -- ot_res2_kernel writing u and v after every iteration, 3 launches instead of 2 x iters --
+  // and took it out again: its potentials are consistent with the K it ROUNDED at the last derivation, the reverse sweep recomputes
+  // exp(Z + u_k + v_k-1) afresh, and that 1e-5 inconsistency per iteration is amplified by the cancellation in d loss / d bin_score:
+  // 7.9e-2 on the 2 x 2048 fixture against a bar of 2e-2; every other gradient was unaffected.)
   hipLaunchKernelGGL(ot_init_kernel, dim3(cdiv(maxn, 4), np), dim3(256), 0, s, dp, alpha, 0, 0);
   dim3 gi(maxG, np), gc(cdiv(maxm + 1, 64), np);
   for (int it = 0; it < iters; ++it) {        // the streamed kernels, one iteration at a time

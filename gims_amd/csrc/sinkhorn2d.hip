@@ -71,6 +71,7 @@ struct OtR2Args {
   unsigned long long* prof;
 };
 
+constexpr int R2_FLAG_ITERS = 1024;             // iterations the adaptive re-derivation has flags for (workspace: 4 KB per problem)
 constexpr int R2_CSEG = 132;                    // floats per (workgroup, buffer) of the column edge: 128 columns + dustbin + pad
 // LDS layout of a workgroup of R2_NT = 512 threads (a <= 1024 x 128 block, one workgroup per CU).  The K tile rows 12..15 of every thread take
 // 16 R2_NT float4; the small arrays follow.  (A 256-thread geometry -- <= 512 x 128 blocks, two workgroups of two different problems per CU, so
@@ -844,7 +845,7 @@ static OtR2Plan plan_class(const OtR2Host* pr, int np, int iters) {
     const int rbf = r2_up4(cdiv(rb + 1, nc)), rbs = nc * rbf;
     if (rbf > R2_FOLD || rb > r2_rbmax() || r2_up4(cdiv(pr[i].m, nc)) > 128) return P;
     b += 2 * r2_al((size_t)nx * nc * rbs * 4) + r2_al((size_t)nx * 2 * rbs * 4) + r2_al((size_t)2 * nx * nc * R2_CSEG * 4);
-    b += r2_al((size_t)(iters + 8) * 4);                               // rflag
+    b += r2_al((size_t)(R2_FLAG_ITERS + 8) * 4);                       // rflag: a fixed capacity -- the caller's workspace query does not know the iteration count
   }
   P.bytes = b;
   P.ok = true;
@@ -945,7 +946,7 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
   // exchange buffers start with every sign bit set: iteration 0 waits for sign 0
   GIMS_HIP(hipMemsetAsync(base + ex0, 0xFF, off - ex0, s));
   {   // the re-derivation flags of all problems, zeroed (behind the exchange buffers)
-    const size_t rf0 = off, rfb = r2_al((size_t)(iters + 8) * 4);
+    const size_t rf0 = off, rfb = r2_al((size_t)(R2_FLAG_ITERS + 8) * 4);
     for (int i = 0; i < np; ++i) { hd[i].rflag = (int*)(base + off); off += rfb; }
     GIMS_HIP(hipMemsetAsync(base + rf0, 0, off - rf0, s));
   }
@@ -968,7 +969,8 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
   if (*st->h_place) st->wt_local = 1;
   const int wt_local = st->wt_local;
   // GIMS_OT_REFRESH: k > 0 = a derivation every k iterations (rounds 2-4: 50); 0 (default) = adaptive, see the header; -1 = the final one only
-  const int refresh = r2_env("GIMS_OT_REFRESH", 0);
+  int refresh = r2_env("GIMS_OT_REFRESH", 0);
+  if (refresh == 0 && iters > R2_FLAG_ITERS) refresh = 50;       // more iterations than flags: the fixed period of rounds 2-4
   const int prof = r2_env("GIMS_OT_PROF", 0);
   for (int gi = 0; gi < P.ngroups; ++gi) {
     OtR2Block* dblk = (OtR2Block*)(base + off); off += r2_al(sizeof(OtR2Block) * 512);

@@ -266,15 +266,27 @@ def _backward(model, S, w_pos: float, w_neg: float):
     side = _side_stream(dev) if _SIDE_STREAM else None
     hold = []
 
+    pending = []
+
     def aside(fn, *inputs):
+        """Queue a parameter-gradient job.  Jobs are submitted in batches (flush): one event per batch instead of one per job -- record + wait
+        cost 7 us of host time each, 110 of them per step, on a step that is bound by its host side."""
         if side is None:
-            return fn()
+            fn()
+            return
+        hold.extend(inputs)
+        pending.append(fn)
+
+    def flush():
+        if not pending:
+            return
         ev = torch.cuda.Event()
         ev.record(main)
         side.wait_event(ev)
-        hold.extend(inputs)
         with hip.on_stream(side.cuda_stream):
-            return fn()
+            for fn in pending:
+                fn()
+        pending.clear()
 
     def norm_backward(prefix, x_pre, g, save):
         """Reverse pass of the norm + ReLU behind a convolution: returns the gradient of the convolution's output and stores
@@ -308,15 +320,14 @@ def _backward(model, S, w_pos: float, w_neg: float):
         pre = f"gnn.layers.{l}."
         w0, w3 = _w2(P[pre + "mlp.0.weight"]), _w2(P[pre + "mlp.3.weight"])
         # delta = mlp(cat[x, msg]); x_next = x + delta: dx is d/dx_next = d/ddelta
-        aside(lambda dx=dx, L=L: (put(pre + "mlp.3.weight", hip.gemm(dx.t(), L["hid"].t())), put(pre + "mlp.3.bias", hip.colsum(dx))), dx, L["hid"])
+        aside(lambda dx=dx, L=L, pre=pre: (put(pre + "mlp.3.weight", hip.gemm(dx.t(), L["hid"].t())), put(pre + "mlp.3.bias", hip.colsum(dx))), dx, L["hid"])
         dhid = hip.gemm(dx, w3.t())
         dhpre = norm_backward(pre + "mlp.1", L["hpre"], dhid, L["save"])
-        aside(lambda: (put(pre + "mlp.0.weight", hip.gemm(dhpre.t(), L["xm"].t())), put(pre + "mlp.0.bias", hip.colsum(dhpre))), dhpre, L["xm"])
+        aside(lambda dhpre=dhpre, L=L, pre=pre: (put(pre + "mlp.0.weight", hip.gemm(dhpre.t(), L["xm"].t())), put(pre + "mlp.0.bias", hip.colsum(dhpre))), dhpre, L["xm"])
         dx = hip.gemm(dhpre, w0[:, :D].t(), residual=dx)          # dx + dhpre W0[:, :D]   (x enters the MLP directly); a fresh tensor: see aside
         dmsg = hip.gemm(dhpre, w0[:, D:].t())
         # merge
-        dwm = aside(lambda: hip.gemm(dmsg.t(), L["o"].t()), dmsg, L["o"])   # in the packed (head-contiguous) layout; unpacked with the projections below
-        aside(lambda: put(pre + "attn.merge.bias", hip.colsum(dmsg)))
+        aside(lambda dmsg=dmsg, pre=pre: put(pre + "attn.merge.bias", hip.colsum(dmsg)), dmsg)
         do = hip.gemm(dmsg, L["wm"].t())
         # attention of all images and heads (every image's rows are queries once and sources once per layer: dqkv is written exactly once)
         dqkv = hip.train_attention_backward(L["qkv"], L["o"], L["lse"], do, S.attn_problems[L["cross"]], HEADS)
@@ -324,18 +335,20 @@ def _backward(model, S, w_pos: float, w_neg: float):
         gb = [torch.empty_like(P[pre + f"attn.proj.{j}.bias"]) for j in range(3)]
         gm = torch.empty_like(P[pre + "attn.merge.weight"])
 
-        def qkv_grads(dqkv=dqkv, L=L, dwm=dwm, gw=gw, gb=gb, gm=gm):
+        def qkv_grads(dqkv=dqkv, dmsg=dmsg, L=L, gw=gw, gb=gb, gm=gm):
+            dwm = hip.gemm(dmsg.t(), L["o"].t())      # in the packed (head-contiguous) layout; unpacked with the projections
             dwqkv = hip.gemm(dqkv.t(), L["x"].t())
             dbqkv = hip.colsum(dqkv)
             hip.head_pack(gw, gb, gm, dwqkv, dbqkv, dwm, HEADS, to_params=True)
-            hold.extend((dwqkv, dbqkv))
-        aside(qkv_grads, dqkv, L["x"], dwm)
+            hold.extend((dwm, dwqkv, dbqkv))
+        aside(qkv_grads, dqkv, L["x"], dmsg, L["o"])
         for j in range(3):
             put(pre + f"attn.proj.{j}.weight", gw[j])
             put(pre + f"attn.proj.{j}.bias", gb[j])
         put(pre + "attn.merge.weight", gm)
         dx = hip.gemm(dqkv, L["wqkv"].t(), residual=dx)           # dx + dQKV Wqkv
-        S.layers[l] = None                                        # this layer's activations are no longer needed
+        flush()
+        S.layers[l] = None                                        # this layer's activations are no longer needed (the queued jobs hold what they read)
 
     # ---- keypoint encoder (dx is now d/d(sage + kenc))
     ddesc = dx
@@ -372,6 +385,7 @@ def _backward(model, S, w_pos: float, w_neg: float):
                 gh = hip.gemm(g, ws.t())
                 hip.elementwise(hip.EW_ACC, gh, hip.sage_mean_transposed(dagg, G["indptr_all"], G["indices_all"]), alpha=1.0)
                 g = gh
+    flush()
     if side is not None:                                          # join: the caller (and the allocator's reuse of everything held) comes after the side jobs
         ev = torch.cuda.Event()
         ev.record(side)

@@ -721,6 +721,26 @@ def test_sinkhorn_history_of_a_ragged_batch(hip):
         np.testing.assert_allclose(full, ref, atol=1e-3)
 
 
+def test_sinkhorn_workspace_is_not_overrun(hip):
+    """The workspace query does not know the iteration count: nothing behind gims_sinkhorn_workspace_bytes bytes may be touched whatever the
+    count (the flags of the adaptive re-derivation were sized by it for one round-5 build: 256 B per problem past the end at 100 iterations)."""
+    r = _rng(5)
+    items = []
+    for n, m in [(700, 650), (300, 310), (1024, 1000)]:
+        zs = torch.zeros((n, (m + 3) // 4 * 4), dtype=torch.float32, device="cuda")
+        zs[:, :m] = _dev((r.normal(size=(n, m)) * 3).astype(np.float32))
+        items.append(dict(scores=zs, n=n, m=m, matches0=torch.empty(n, dtype=torch.int64, device="cuda"), matches1=torch.empty(m, dtype=torch.int64, device="cuda"),
+                          mscores0=torch.empty(n, device="cuda"), mscores1=torch.empty(m, device="cuda"), uv=torch.empty(n + m + 3, device="cuda")))
+    probs = hip.make_ot_problems(items)
+    need = hip.sinkhorn_workspace_bytes(probs)
+    guard = 1 << 16
+    buf = torch.full((need + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    for iters in (1, 100, 1000, 1500):
+        hip.sinkhorn_match(probs, 1.0, iters, 0.2, buf[:need])
+        torch.cuda.synchronize()
+        assert bool((buf[need:] == 0x5A).all()), iters
+
+
 @pytest.mark.parametrize("n,m,scale", [(45, 28, 25.0), (307, 305, 25.0), (1200, 700, 20.0), (2100, 1900, 20.0), (4096, 4096, 12.0), (900, 130, 30.0)])
 def test_sinkhorn_adaptive_rederivation(hip, monkeypatch, n, m, scale):
     """The on-chip kernel re-derives K = exp(Z + u + v) mid-solve only when a cumulative factor has grown past its bound (round 5; a fixed period of 50

@@ -32,5 +32,5 @@ prof.disable()
 r = np.median(np.asarray(rec), axis=0) * 1e3
 print(f"forward: host {r[0]:.2f} ms, drained {r[1]:.2f} ms | backward: host {r[2]:.2f} ms, drained {r[3]:.2f} ms | optimizer: host {r[4]:.2f}, drained {r[5]:.2f} ms")
 s = io.StringIO()
-pstats.Stats(prof, stream=s).sort_stats("tottime").print_stats(28)
-print("\n".join(s.getvalue().splitlines()[:60]))
+pstats.Stats(prof, stream=s).sort_stats(os.environ.get("PROBE_SORT", "tottime")).print_stats(45)
+print("\n".join(l[:150] for l in s.getvalue().splitlines()[:75]))
