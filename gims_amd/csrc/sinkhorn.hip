@@ -612,7 +612,7 @@ __global__ __launch_bounds__(1024) void train_loss_reduce_kernel(const float* __
 // thread the columns j = t, t + 256, ...: phase 1 reduces sum_j gv[j] C_ij per row over the workgroup (gu_k[i] is final right
 // after its own row's reduction); phase 2 recomputes C, adds the row-step term gu_k[i] R_ij, updates dZc once and keeps the
 // column sums of the row-step terms of its 8 rows -> colpart[slab][j]; ot_bwd_colsum_kernel folds the slabs in order -> gv_{k-1}.
-constexpr int BW_ROWS = 8;
+constexpr int BW_ROWS = 4;
 template <bool INIT>
 __global__ __launch_bounds__(256) void ot_bwd_fused_kernel(const OtBwd* __restrict__ probs, float alpha, int k, int first) {
   const OtBwd p = probs[blockIdx.y];
@@ -845,26 +845,37 @@ __global__ __launch_bounds__(512) void ot_bwd_reduce_kernel(const OtBwd* __restr
   }
 }
 
-// gv_rec[slot][j] = sign * sum over slabs of colpart[slab][j]
-__global__ __launch_bounds__(256) void ot_bwd_colsum_rec_kernel(const OtBwd* __restrict__ probs, float sign, int slot) {
+// gv_rec[slot][j] = sign * sum over slabs of colpart[slab][j].  16 columns x 64 slab groups per workgroup: every thread issues its (<= 8 per trip)
+// loads back to back, so the fold of ~500 slabs is one memory round trip (32 columns x 8 groups walked 16 dependent trips: 8.4 us per launch
+// once the slabs were 4 rows), and the grid has m / 16 workgroups instead of m / 32.
+__global__ __launch_bounds__(1024) void ot_bwd_colsum_rec_kernel(const OtBwd* __restrict__ probs, float sign, int slot) {
   const OtBwd p = probs[blockIdx.y];
-  __shared__ float red[8][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, j = blockIdx.x * 32 + tx;
+  __shared__ float red[64][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, j = blockIdx.x * 16 + tx;
+  if (blockIdx.x * 16 > p.m) return;
   const int ns = (p.n + BW_ROWS) / BW_ROWS, ldz = p.m + 1;
   float s = 0.f;
   if (j <= p.m)
-    for (int b = ty; b < ns; b += 32) {                    // four independent loads per trip (a chain of 33 dependent ones ran at L2 latency)
-      float x[4];
+    for (int b0 = ty; b0 < ns; b0 += 512) {
+      float x[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) x[q] = b + 8 * q < ns ? p.colpart[(int64_t)(b + 8 * q) * ldz + j] : 0.f;
-      s += (x[0] + x[1]) + (x[2] + x[3]);
+      for (int q = 0; q < 8; ++q) x[q] = b0 + 64 * q < ns ? p.colpart[(int64_t)(b0 + 64 * q) * ldz + j] : 0.f;
+      s += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
     }
   red[ty][tx] = s;
+  __syncthreads();
+  if (ty < 16) {                                             // 64 groups -> 16 -> 1, fixed order
+    const float a = (red[ty][tx] + red[ty + 16][tx]) + (red[ty + 32][tx] + red[ty + 48][tx]);
+    __syncthreads();
+    red[ty][tx] = a;
+  } else {
+    __syncthreads();
+  }
   __syncthreads();
   if (ty == 0 && j <= p.m) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += red[i][tx];
+    for (int i = 0; i < 16; ++i) t += red[i][tx];
     p.gv_rec[(int64_t)slot * ldz + j] = sign * t;
   }
 }
@@ -1391,7 +1402,7 @@ extern "C" size_t gims_sinkhorn_backward_workspace_bytes(const gims_ot_problem* 
   if (!pr || np <= 0) return 0;
   size_t b = al256(sizeof(OtBwd) * (size_t)np);
   for (int i = 0; i < np; ++i)
-    b += al256((size_t)(pr[i].n + 1) * 4) + 2 * al256((size_t)(pr[i].m + 1) * 4) + al256((size_t)((pr[i].n + 8) / 8) * (size_t)(pr[i].m + 1) * 4) +
+    b += al256((size_t)(pr[i].n + 1) * 4) + 2 * al256((size_t)(pr[i].m + 1) * 4) + al256((size_t)((pr[i].n + BW_ROWS) / BW_ROWS) * (size_t)(pr[i].m + 1) * 4) +
          ot_bwd_lowrank_bytes(pr[i].n, pr[i].m, OT_BWD_MAX_ITERS);
   return b;
 }
@@ -1416,7 +1427,7 @@ extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, flo
     b.gu = (float*)(base + off); off += al256((size_t)(q.n + 1) * 4);
     b.gv = (float*)(base + off); off += al256((size_t)(q.m + 1) * 4);
     b.gv2 = (float*)(base + off); off += al256((size_t)(q.m + 1) * 4);
-    b.colpart = (float*)(base + off); off += al256((size_t)((q.n + 8) / 8) * (size_t)(q.m + 1) * 4);
+    b.colpart = (float*)(base + off); off += al256((size_t)((q.n + BW_ROWS) / BW_ROWS) * (size_t)(q.m + 1) * 4);
     {
       const int it = iters <= OT_BWD_MAX_ITERS ? iters : 0;          // 0: the low-rank buffers are not used
       b.iters = iters;
@@ -1438,17 +1449,17 @@ extern "C" int gims_sinkhorn_backward(const gims_ot_problem* pr, int32_t np, flo
   const int mx = maxn > maxm ? maxn : maxm;
   if (iters <= OT_BWD_MAX_ITERS && cdiv(maxm + 1, 512) <= 9 && !ot_env("GIMS_OT_BWD_INPLACE", 0)) {
     // low-rank form: reductions only per iteration, one K = 2 iters product at the end
-    const dim3 gs(cdiv(maxn + 1, BW_ROWS), np), gc(cdiv(maxm + 1, 32), np);
+    const dim3 gs(cdiv(maxn + 1, BW_ROWS), np), gc(cdiv(maxm + 1, 16), np);
     const int cpt = cdiv(maxm + 1, 512);
     hipLaunchKernelGGL(ot_bwd_fused_kernel<true>, gs, dim3(256), 0, s, dp, alpha, 0, 0);
-    hipLaunchKernelGGL(ot_bwd_colsum_rec_kernel, gc, dim3(256), 0, s, dp, 1.f, iters);
+    hipLaunchKernelGGL(ot_bwd_colsum_rec_kernel, gc, dim3(1024), 0, s, dp, 1.f, iters);
     for (int k = iters; k >= 1; --k) {
       const int first = k == iters ? 1 : 0;
       if (cpt <= 1) hipLaunchKernelGGL((ot_bwd_reduce_kernel<1>), gs, dim3(512), 0, s, dp, alpha, k, first);
       else if (cpt <= 3) hipLaunchKernelGGL((ot_bwd_reduce_kernel<3>), gs, dim3(512), 0, s, dp, alpha, k, first);
       else if (cpt <= 5) hipLaunchKernelGGL((ot_bwd_reduce_kernel<5>), gs, dim3(512), 0, s, dp, alpha, k, first);
       else hipLaunchKernelGGL((ot_bwd_reduce_kernel<9>), gs, dim3(512), 0, s, dp, alpha, k, first);
-      hipLaunchKernelGGL(ot_bwd_colsum_rec_kernel, gc, dim3(256), 0, s, dp, -1.f, k - 1);
+      hipLaunchKernelGGL(ot_bwd_colsum_rec_kernel, gc, dim3(1024), 0, s, dp, -1.f, k - 1);
     }
     const int64_t fmax = (int64_t)(maxn + 1 + maxm + 1) * iters;
     hipLaunchKernelGGL(ot_bwd_shift_kernel, dim3(cdiv(mx + 1, 256), np), dim3(256), 0, s, dp);          // (gu, gv2 are free after the loop)
