@@ -190,11 +190,13 @@ class GMatcher(nn.Module):
         self.__dict__.pop("_ops_cache", None)
         self.__dict__.pop("_plist", None)
         self.__dict__.pop("_train_params", None)
+        self.__dict__.pop("_train_buffers", None)
         return super().load_state_dict(sd, strict=strict, **kw)
 
     def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .half() replace the parameter tensors
         self.__dict__.pop("_plist", None)
         self.__dict__.pop("_train_params", None)
+        self.__dict__.pop("_train_buffers", None)
         self._pack = None
         return super()._apply(fn, *a, **kw)
 
