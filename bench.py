@@ -87,7 +87,7 @@ def compact_line(res):
     line["host_step_ms"] = res.get("host_step_ms")
     line["attention_layers"] = _pick(res.get("attention"), ("precision", "layers_bf16", "layers_f16", "layers_bf16x3"))
     line["world_size_seen"] = res.get("world_size_seen", 1)
-    line.update(_pick(res, ("stats_rows_gathered", "matches_pair0")))
+    line.update(_pick(res, ("stats_rows_gathered", "matches_pair0", "sinkhorn_rescues")))
     if res.get("ranks"):               # proof of the N > 1 launch: [rank, device index, collective backend, pid] of every rank
         line["ranks"] = [[r["rank"], r["device"], r["backend"], r["pid"]] for r in res["ranks"]]
     also = {}
@@ -462,6 +462,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
         "stage_ms_per_step": stage_ms,
         "host_step_ms": {"median": float(np.median(steps_ms)), "max": float(steps_ms.max())},
         "matches_pair0": {"matched": int(v.sum()), "correct_vs_planted": correct},
+        "sinkhorn_rescues": int(__import__("gims_amd.hip", fromlist=["hip"]).sinkhorn_rescues()),       # on-chip solves of this process that gave up and were re-solved (0 on a quiet GPU)
         "stats_rows_gathered": int(st.shape[0]), "stat_fields": list(shard.STAT_FIELDS),
         "world_size_seen": dist.get_world_size() if world > 1 else 1,
         "ranks": [{"rank": r[0], "device": r[1], "device_name": r[2], "backend": r[3], "pid": r[4]} for r in ranks_seen] if ranks_seen else None,

@@ -85,6 +85,46 @@ __device__ __forceinline__ float wave_reduce_rows(float (&v)[R], int lane, int& 
   return x;
 }
 
+// The same butterfly for (value, index) pairs under "larger value, then smaller index wins": on return lane l holds the winner of row
+// ((l>>5)&1)*R/2 + ((l>>4)&1)*R/4 + ...; lanes with the low (6 - log2 R) bits clear are the writers.
+template <int R>
+__device__ __forceinline__ void wave_argmax_rows(float (&v)[R], int (&ix)[R], int lane, int& row_out, float& v_out, int& i_out) {
+  float cv[R];
+  int ci[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) { cv[i] = v[i]; ci[i] = ix[i]; }
+  int n = R, bit = 32, row = 0;
+#pragma unroll
+  for (; n > 1; n >>= 1, bit >>= 1) {
+    const bool up = lane & bit;
+    const int h = n >> 1;
+#pragma unroll
+    for (int i = 0; i < h; ++i) {
+      const float sv = up ? cv[i] : cv[i + h];
+      const int si = up ? ci[i] : ci[i + h];
+      const float mv = up ? cv[i + h] : cv[i];
+      const int mi = up ? ci[i + h] : ci[i];
+      const float ov = __shfl_xor(sv, bit, 64);
+      const int oi = __shfl_xor(si, bit, 64);
+      const bool take = ov > mv || (ov == mv && oi < mi);
+      cv[i] = take ? ov : mv;
+      ci[i] = take ? oi : mi;
+    }
+    row += up ? h : 0;
+  }
+  float x = cv[0];
+  int xi = ci[0];
+#pragma unroll
+  for (; bit > 0; bit >>= 1) {
+    const float ov = __shfl_xor(x, bit, 64);
+    const int oi = __shfl_xor(xi, bit, 64);
+    if (ov > x || (ov == x && oi < xi)) { x = ov; xi = oi; }
+  }
+  row_out = row;
+  v_out = x;
+  i_out = xi;
+}
+
 // ---------------------------------------------------------------------------------------------- init
 // rescue = 1 (the streamed re-solve of a given-up on-chip solve, see ot_rescue_begin_kernel): only problems whose status word is 3
 // are touched, and the status word is left alone
@@ -335,13 +375,6 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const OtDev* __restr
 // ---------------------------------------------------------------------------------------------- selection
 // t_ij = ((Z_ij + u_i) + v_j) - norm on the inner block (gmatcher.py:47,68,284): row max/argmax directly,
 // column max/argmax through per-workgroup partials (rows visited in ascending order; ties -> lower index).
-template <int CTRL>
-__device__ __forceinline__ void ot_argmax_step(float& bv, int& bi) {
-  const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bv), CTRL, 0xf, 0xf, true));
-  const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, true);
-  if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-}
-
 template <int CPT, int RS = OT_R>      // RS rows per slab (8; 2 for the 8-quad instance of problems wider than 16 384 columns: registers)
 __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict__ probs) {
   __shared__ float rv[16][RS];
@@ -390,6 +423,8 @@ __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict
       for (int s = 0; s < CPT; ++s) zs[r][s] = zn[r][s];
     }
     if (slab + p.G < n_slabs) request(slab + p.G, zn, un);
+    float rbv[RS];
+    int rbi[RS];
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
       const int row = r0 + r;
@@ -415,25 +450,19 @@ __global__ __launch_bounds__(1024) void ot_select_kernel(const OtDev* __restrict
           }
         }
       }
-      // wave argmax (ties -> lower column).  The comparison is a strict total order, so the result does not depend on the combination order:
-      // four DPP steps inside every 16-lane row, then lanes 0 / 16 / 32 / 48 are read back and folded.  (The butterfly of twelve __shfl_xor
-      // = ds_bpermute per row made this kernel LDS-permute bound: 1 536 of them per 8-row slab and CU, 205 us per 8 x 4096^2 against ~110 us of
-      // HBM time.)
-      ot_argmax_step<0xB1>(bv, bi);      // quad_perm [1,0,3,2]
-      ot_argmax_step<0x4E>(bv, bi);      // quad_perm [2,3,0,1]
-      ot_argmax_step<0x141>(bv, bi);     // row_half_mirror
-      ot_argmax_step<0x140>(bv, bi);     // row_mirror
-      {
-        float fv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 0));
-        int fi = __builtin_amdgcn_readlane(bi, 0);
-#pragma unroll
-        for (int q = 1; q < 4; ++q) {
-          const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 16 * q));
-          const int oi = __builtin_amdgcn_readlane(bi, 16 * q);
-          if (ov > fv || (ov == fv && oi < fi)) { fv = ov; fi = oi; }
-        }
-        if (lane == 0) { rv[wave][r] = fv; ri[wave][r] = fi; }
-      }
+      rbv[r] = bv;
+      rbi[r] = bi;
+    }
+    // wave argmax of all RS rows at once (ties -> lower column; the comparison is a strict total order, so the result does not depend on the
+    // combination order): a reduce-scatter butterfly -- log2 RS steps halve the rows a lane still carries, the rest fold the survivor --
+    // RS - 1 + (6 - log2 RS) exchanges of a (value, index) pair instead of RS x (4 DPP steps + 3 readlane folds): the per-row form was 30 of
+    // this kernel's 158 us at 8 x 4096^2.
+    {
+      int rrow;
+      float fv;
+      int fi;
+      wave_argmax_rows<RS>(rbv, rbi, lane, rrow, fv, fi);
+      if ((lane & (64 / RS - 1)) == 0) { rv[wave][rrow] = fv; ri[wave][rrow] = fi; }
     }
     __syncthreads();
     if (t < RS && r0 + t < p.n) {
