@@ -227,6 +227,27 @@ def test_train_attention_forward_backward_vs_float64(n0, n1, cross, splits, reve
     assert torch.equal(dqkv, hip.train_attention_backward(qkv, o, lse, do, problems, heads, precision=prec))
 
 
+def test_train_attention_more_problems_than_one_launch_takes():
+    """34 problems (17 pairs of small images, cross): the problem table travels in the kernel arguments 32 at a time, so this call is two rounds
+    of launches sharing one workspace."""
+    heads, d = 4, 256
+    sizes = [37 + 3 * i for i in range(34)]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    rows = int(offs[-1])
+    qkv = _rand(rows, 3 * d, seed=99)
+    do = _rand(rows, d, seed=98)
+    problems = []
+    for b in range(17):
+        i0, i1 = 2 * b, 2 * b + 1
+        problems += [(int(offs[i0]), sizes[i0], int(offs[i1]), sizes[i1]), (int(offs[i1]), sizes[i1], int(offs[i0]), sizes[i0])]
+    o, lse = hip.train_attention_forward(qkv, problems, heads)
+    ro, rlse, rg = _attention_reference(qkv, do, problems, heads)
+    assert float((o.double() - ro).abs().max()) < 3e-6 * float(ro.abs().max())
+    for prec, tol in ((hip.PREC_F32, 3e-5), (hip.PREC_BF16X3, 2e-4)):
+        dqkv = hip.train_attention_backward(qkv, o, lse, do, problems, heads, precision=prec)
+        assert float((dqkv.double() - rg).abs().max()) < tol * float(rg.abs().max())
+
+
 def test_train_attention_rejects_bad_arguments():
     qkv = _rand(64, 768, seed=1)
     with pytest.raises(hip.GimsHipError):
