@@ -305,8 +305,7 @@ struct X3P {
   __device__ static __forceinline__ int off(int row, int chunk) { return row * ROWE + ((chunk ^ swz(row)) << 3); }
 };
 
-// HI_ONLY: 1 = GIMS_LINEAR_HI_ONLY (one MFMA pass, hi planes), 2 = GIMS_LINEAR_A1_HI_ONLY (that for the second K segment only),
-// 4 = GIMS_LINEAR_CONV3 (all three passes; the A rows are gathered from the 3x3 neighbourhood of an NHWC activation)
+// HI_ONLY: 1 = GIMS_LINEAR_HI_ONLY (one MFMA pass, hi planes), 4 = GIMS_LINEAR_CONV3 (all three passes; the A rows are gathered from the 3x3 neighbourhood of an NHWC activation)
 template <int TM, int TN, int WM, int WN, int S, int HI_ONLY = 0>
 __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_args p) {
   using T = X3P<TM, TN, WM, WN, S, HI_ONLY == 1>;
@@ -418,7 +417,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
     // step 0 -> step 1.  Left alone the compiler emits read-a-few / wait-for-ALL / multiply-a-few, eight exposed LDS round
     // trips per stage; more than 15 reads in flight cannot be counted by lgkmcnt either, hence two groups.
     constexpr bool LO = HI_ONLY != 1;
-    const bool lo_pass = HI_ONLY == 0 || HI_ONLY == 4 || (HI_ONLY == 2 && kt * BK < p.k0);
+    const bool lo_pass = HI_ONLY == 0 || HI_ONLY == 4;
     bf16x8 ah[2][T::MI], al[2][T::MI], wh[2][T::NI], wl[2][T::NI];
     auto rd = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
@@ -719,7 +718,6 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       GIMS_LDS_ATTR((const void*)linear_x3p_kernel<256, 256, 4, 2, 2>, (int)lds);
       const dim3 g(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256));
       if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 4, 1>), g, dim3(512), lds_h, s, *a);
-      else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2, 2>), g, dim3(512), lds, s, *a);
       else hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), g, dim3(512), lds, s, *a);
     } else if (a->flags & GIMS_LINEAR_CONV3) {
       using T32 = X3P<128, 32, 4, 1, 2>;
@@ -731,7 +729,7 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       if (a->n <= 32) { constexpr size_t lds = T32::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<128, 32, 4, 1, 2, 4>), dim3(mt * cdiv(a->n, 32)), dim3(256), lds, s, *a); }
       else if (a->n <= 64) { constexpr size_t lds = T64::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<128, 64, 2, 2, 2, 4>), dim3(mt * cdiv(a->n, 64)), dim3(256), lds, s, *a); }
       else { constexpr size_t lds = TS::LDS_BYTES; hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2, 4>), dim3(mt * cdiv(a->n, 128)), dim3(256), lds, s, *a); }
-    } else if (a->n <= 64 && !(a->flags & (GIMS_LINEAR_HI_ONLY | GIMS_LINEAR_A1_HI_ONLY)) && force == 0) {
+    } else if (a->n <= 64 && !(a->flags & GIMS_LINEAR_HI_ONLY) && force == 0) {
       // narrow outputs (the 32- and 64-channel convolutions of the descriptor network, millions of rows): 128 x 32 / 128 x 64
       // tiles instead of wasting three quarters / half of a 128-wide one
       using T32 = X3P<128, 32, 4, 1, 2>;
@@ -745,7 +743,7 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
         constexpr size_t lds = T64::LDS_BYTES;
         hipLaunchKernelGGL((linear_x3p_kernel<128, 64, 2, 2, 2>), dim3(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 64)), dim3(256), lds, s, *a);
       }
-    } else if ((force == 64 || (force == 0 && cdiv(a->m, 128) * cdiv(a->n, 128) <= small_tiles)) && !(a->flags & GIMS_LINEAR_A1_HI_ONLY)) {
+    } else if (force == 64 || (force == 0 && cdiv(a->m, 128) * cdiv(a->n, 128) <= small_tiles)) {
       // launches that leave most of the chip idle at 128 x 128 (one pair through forward(): 32 ... 96 tiles at 2 x 1024 keypoints): 64 x 64 tiles
       // on four waves -- four times the workgroups, the same K order per output element (bit-identical), and what a launch costs there is
       // the latency of its K loop, not its matrix work
@@ -764,7 +762,6 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       GIMS_LDS_ATTR((const void*)linear_x3p_kernel<128, 128, 2, 2, 2>, (int)lds);
       const dim3 g(8 * cdiv(cdiv(a->m, 128), 8) * cdiv(a->n, 128));
       if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 4, 1>), g, dim3(256), lds_h, s, *a);
-      else if (a->flags & GIMS_LINEAR_A1_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2, 2>), g, dim3(256), lds, s, *a);
       else if (force == 128 || cdiv(a->m, 128) * cdiv(a->n, 128) > 256)      // more than one tile per CU (or GIMS_X3P_TILE=128): the 4-wave tile, two workgroups per CU
         hipLaunchKernelGGL((linear_x3p_kernel<128, 128, 2, 2, 2>), g, dim3(256), lds, s, *a);
       else {

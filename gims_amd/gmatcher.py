@@ -303,7 +303,6 @@ class GMatcher(nn.Module):
     # 2.7e-5 against 1.1e-5 / 2.1e-5 with the split-bf16x3 projection (bar 1e-4).  GIMS_QKV_PREC=x3 restores the latter.
     _qkv_flags = 0 if os.environ.get("GIMS_QKV_PREC", "bf16") == "x3" else hip.LINEAR_HI_ONLY
 
-    _msg_flags = hip.LINEAR_A1_HI_ONLY if os.environ.get("GIMS_MSG_PREC", "x3") == "bf16" else 0
 
     _use_graph = os.environ.get("GIMS_OPS_GRAPH", "0") == "1"      # opt-in: measured gain <= 3 % (tools/graph_probe.py)
 
@@ -739,7 +738,7 @@ class GMatcher(nn.Module):
                        0 if qkv_b is None else qkv_b.data_ptr(), 0 if qkv_s is None else qkv_s.data_ptr(),
                        0 if stat is None else stat.data_ptr(),
                        (float(cfg['attention_auto_threshold']), float(cfg['attention_auto_tail']), float(cfg['attention_f16_range'])) if guarded else None,
-                       self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, self._msg_flags, tuple(amode))
+                       self_pr.data_ptr(), cross_pr.data_ptr(), self_pr.shape[0], cross_pr.shape[0], self._qkv_flags, tuple(amode))
                 cache = self.__dict__.setdefault("_ops_cache", {})
                 ops = cache.get(key)
                 if ops is None:
@@ -755,7 +754,7 @@ class GMatcher(nn.Module):
                             lst.append(la(L["qkv"], dpl, out_split=qkv_s, guard=gd))
                             lst.append(hip.op_attention(qkv_s, cross_pr if L["cross"] else self_pr, max_nq, self._heads, None, 0, D, 2 * D,
                                                         out_split=mpl, q_prescaled=True, x3=True, guard=gd))
-                        lst.append(la(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl, flags=self._msg_flags))
+                        lst.append(la(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl))
                         lst.append(la(L["mlp1"], hpl, residual=desc, out=desc, out_split=dpl))
                     if len(cache) > 8:
                         cache.clear()
@@ -800,7 +799,7 @@ class GMatcher(nn.Module):
                             self._lin(L["mlp0"], dpl, a1=gpl, out=hid_ln)
                         hip.layernorm_act(hid_ln, *L["ln"], out_split=hpl)
                     elif L["mlp0_fused"] is not None:
-                        self._lin(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl, flags=self._msg_flags)
+                        self._lin(L["mlp0_fused"], dpl, a1=mpl, act=hip.ACT_RELU, out_split=hpl)
                     else:
                         self._lin(L["merge"], mpl, out_split=gpl)
                         self._lin(L["mlp0"], dpl, a1=gpl, act=hip.ACT_RELU, out_split=hpl)

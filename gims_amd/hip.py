@@ -18,7 +18,6 @@ LIB_PATH = os.path.join(_HERE, "libgims_hip.so")
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
 LINEAR_UPPER = 1
 LINEAR_HI_ONLY = 2
-LINEAR_A1_HI_ONLY = 4
 LINEAR_CONV3 = 8
 LINEAR_OUT_F16 = 16      # out_bf16 receives IEEE half (saturated) instead of bf16
 ACT_NONE, ACT_RELU = 0, 1

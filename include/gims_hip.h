@@ -121,9 +121,8 @@ typedef struct gims_linear_args {
   /* GIMS_LINEAR_HI_ONLY (pre-split operands): multiply the hi planes only -- a plain bf16 product (2^-9 relative per
    * operand) at a third of the matrix work, for results that are rounded to bf16 anyway (the Q/K/V projection) */
 #define GIMS_LINEAR_HI_ONLY 2
-  /* GIMS_LINEAR_A1_HI_ONLY: the same for the SECOND A segment (a1, columns k0..k) only -- for an operand that was computed
-   * from bf16 data and carries no information below bf16 precision (the attention message in MLP0) */
-#define GIMS_LINEAR_A1_HI_ONLY 4
+  /* (flag value 4 was GIMS_LINEAR_A1_HI_ONLY until round 5: the hi-planes-only product for the second A segment -- the attention message in MLP0 --
+   * measured +1.5 % pairs/s at 6.4e-5 of the 1e-4 score bar and was removed) */
 #define GIMS_LINEAR_CONV3 8
   /* GIMS_LINEAR_OUT_F16: out_bf16 receives IEEE half instead of bf16 (round to nearest even, saturated to +-65504 so that no
    * infinity is ever stored) -- the Q/K/V projection in front of the GIMS_ATTN_F16 attention kernels */
