@@ -317,13 +317,13 @@ __global__ __launch_bounds__(256) void ta_bwd_q_kernel(TaK a) {
     for (int i = 0; i < 16; ++i) dp = TA_MFMA(pb[i], dof[16 + i], dp);
     ta_ops_s(pb, ks, 8, hf, ln);
     TA_FENCE();
-    const bool ragged = tile * 32 + 32 > pr.nk;
+    if (tile * 32 + 32 > pr.nk) {                          // the last, ragged tile only (a uniform branch, not sixteen selects per tile): P = e^-inf = 0
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      float p = __expf(s[j] - lse);
-      if (ragged && tile * 32 + ta_row_of(j, hf) >= pr.nk) p = 0.f;
-      s[j] = p * (dp[j] - dsum) * a.scale;                 // dS^T, with the 1/sqrt(d_head) of dQ = dS K / sqrt(d_head)
+      for (int j = 0; j < 16; ++j)
+        if (tile * 32 + ta_row_of(j, hf) >= pr.nk) s[j] = -INFINITY;
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = __expf(s[j] - lse) * (dp[j] - dsum) * a.scale;      // dS^T, with the 1/sqrt(d_head) of dQ = dS K / sqrt(d_head)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       g0 = TA_MFMA(pa[2 * j], s[j], g0);
@@ -428,12 +428,15 @@ __global__ __launch_bounds__(256, 2) void ta_bwd_kv_kernel(TaK a) {
     for (int i = 0; i < 16; ++i) dp = TA_MFMA(pb[i], vf[16 + i], dp);
     ta_ops_s(pb, ds_, 8, hf, ln);
     TA_FENCE();
-    const bool ragged = tile * 32 + 32 > pr.nq;
+    if (tile * 32 + 32 > pr.nq) {                          // the last, ragged tile only: P = e^-inf = 0 for the rows past the queries
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (tile * 32 + ta_row_of(j, hf) >= pr.nq) s[j] = -INFINITY;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int q = ta_row_of(j, hf);
-      float p = __expf(s[j] - lse_s[q]);
-      if (ragged && tile * 32 + q >= pr.nq) p = 0.f;
+      const float p = __expf(s[j] - lse_s[q]);
       s[j] = p;
       dp[j] = p * (dp[j] - dsum_s[q]);                     // dS[q][key]
     }
@@ -601,35 +604,49 @@ __global__ __launch_bounds__(256, 2) void tb_bwd_q_kernel(TaK a) {
       ta_fetch(kbase, a.ld, (tile + 1) * 32, pr.nk, kr);
       ta_fetch(vbase, a.ld, (tile + 1) * 32, pr.nk, vr);
     }
+    // Operand fragments are read ONE product group ahead of the group that multiplies them (two register sets, fenced: left to the compiler
+    // every group was "4 LDS reads, wait for all of them, 3 MFMAs" -- the matrix pipe idle for an LDS round trip per 96 cycles of work).
     f32x16 s, dp;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s[j] = dp[j] = 0.f;
+    bf16x8 xh, xl, yh, yl;
+    xh = tb_row_op(kh, 0, ln, hf); xl = tb_row_op(kl, 0, ln, hf);
 #pragma unroll
     for (int st = 0; st < 4; ++st) {                       // S^T[key][q], dP^T[key][q]
-      const bf16x8 ah = tb_row_op(kh, st, ln, hf), al = tb_row_op(kl, st, ln, hf);
-      TB_MFMA3(ah, al, qhi[st], qlo[st], s);
-      const bf16x8 bh = tb_row_op(vh, st, ln, hf), bl = tb_row_op(vl, st, ln, hf);
-      TB_MFMA3(bh, bl, dohi[st], dolo[st], dp);
+      yh = tb_row_op(vh, st, ln, hf); yl = tb_row_op(vl, st, ln, hf);
+      TA_FENCE();
+      TB_MFMA3(xh, xl, qhi[st], qlo[st], s);
+      TA_FENCE();
+      if (st < 3) { xh = tb_row_op(kh, st + 1, ln, hf); xl = tb_row_op(kl, st + 1, ln, hf); }
+      else { xh = tb_tr_op(kh, 0, 0, lane); xl = tb_tr_op(kl, 0, 0, lane); }       // the first fragments of the product over the keys
+      TA_FENCE();
+      TB_MFMA3(yh, yl, dohi[st], dolo[st], dp);
+      TA_FENCE();
     }
-    const bool ragged = tile * 32 + 32 > pr.nk;
+    if (tile * 32 + 32 > pr.nk) {                          // the last, ragged tile only (a uniform branch, not sixteen selects per tile): P = e^-inf = 0
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      float p = __expf(s[j] - lse);
-      if (ragged && tile * 32 + ta_row_of(j, hf) >= pr.nk) p = 0.f;
-      s[j] = p * (dp[j] - dsum) * a.scale;                 // dS^T, with the 1/sqrt(d_head) of dQ = dS K / sqrt(d_head)
+      for (int j = 0; j < 16; ++j)
+        if (tile * 32 + ta_row_of(j, hf) >= pr.nk) s[j] = -INFINITY;
     }
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int j = 0; j < 16; ++j) s[j] = __expf(s[j] - lse) * (dp[j] - dsum) * a.scale;      // dS^T, with the 1/sqrt(d_head) of dQ = dS K / sqrt(d_head)
+    {
       bf16x8 sh, sl;
-      tb_frag_acc(s, s2, sh, sl);
-      {
-        const bf16x8 ah = tb_tr_op(kh, s2, 0, lane), al = tb_tr_op(kl, s2, 0, lane);
-        TB_MFMA3(ah, al, sh, sl, g0);
-      }
-      {
-        const bf16x8 ah = tb_tr_op(kh, s2, 1, lane), al = tb_tr_op(kl, s2, 1, lane);
-        TB_MFMA3(ah, al, sh, sl, g1);
-      }
+      tb_frag_acc(s, 0, sh, sl);
+      yh = tb_tr_op(kh, 0, 1, lane); yl = tb_tr_op(kl, 0, 1, lane);
+      TA_FENCE();
+      TB_MFMA3(xh, xl, sh, sl, g0);
+      TA_FENCE();
+      xh = tb_tr_op(kh, 1, 0, lane); xl = tb_tr_op(kl, 1, 0, lane);
+      TA_FENCE();
+      TB_MFMA3(yh, yl, sh, sl, g1);
+      TA_FENCE();
+      tb_frag_acc(s, 1, sh, sl);
+      yh = tb_tr_op(kh, 1, 1, lane); yl = tb_tr_op(kl, 1, 1, lane);
+      TA_FENCE();
+      TB_MFMA3(xh, xl, sh, sl, g0);
+      TA_FENCE();
+      TB_MFMA3(yh, yl, sh, sl, g1);
     }
   }
   if (qrow >= pr.nq) return;
@@ -699,22 +716,33 @@ __global__ __launch_bounds__(256, 2) void tb_bwd_kv_kernel(TaK a) {
       ta_fetch(dbase, a.lddo, (tile + 1) * 32, pr.nq, dr);
       fetch_stat(tile + 1);
     }
+    // (operand fragments one product group ahead, like tb_bwd_q_kernel)
     f32x16 s, dp;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s[j] = dp[j] = 0.f;
+    bf16x8 xh, xl, yh, yl;
+    xh = tb_row_op(qh, 0, ln, hf); xl = tb_row_op(ql, 0, ln, hf);
 #pragma unroll
     for (int st = 0; st < 4; ++st) {                       // S[q][key], dP[q][key]
-      const bf16x8 ah = tb_row_op(qh, st, ln, hf), al = tb_row_op(ql, st, ln, hf);
-      TB_MFMA3(ah, al, khi[st], klo[st], s);
-      const bf16x8 bh = tb_row_op(dh, st, ln, hf), bl = tb_row_op(dl, st, ln, hf);
-      TB_MFMA3(bh, bl, vhi[st], vlo[st], dp);
+      yh = tb_row_op(dh, st, ln, hf); yl = tb_row_op(dl, st, ln, hf);
+      TA_FENCE();
+      TB_MFMA3(xh, xl, khi[st], klo[st], s);
+      TA_FENCE();
+      if (st < 3) { xh = tb_row_op(qh, st + 1, ln, hf); xl = tb_row_op(ql, st + 1, ln, hf); }
+      else { xh = tb_tr_op(dh, 0, 0, lane); xl = tb_tr_op(dl, 0, 0, lane); }       // the first fragments of the products over the queries
+      TA_FENCE();
+      TB_MFMA3(yh, yl, vhi[st], vlo[st], dp);
+      TA_FENCE();
     }
-    const bool ragged = tile * 32 + 32 > pr.nq;
+    if (tile * 32 + 32 > pr.nq) {                          // the last, ragged tile only: P = e^-inf = 0 for the rows past the queries
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (tile * 32 + ta_row_of(j, hf) >= pr.nq) s[j] = -INFINITY;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int q = ta_row_of(j, hf);
-      float p = __expf(s[j] - lse_s[q]);
-      if (ragged && tile * 32 + q >= pr.nq) p = 0.f;
+      const float p = __expf(s[j] - lse_s[q]);
       s[j] = p;
       dp[j] = p * (dp[j] - dsum_s[q]);                     // dS[q][key]
     }
@@ -723,13 +751,22 @@ __global__ __launch_bounds__(256, 2) void tb_bwd_kv_kernel(TaK a) {
       bf16x8 ph, pl, sh, sl;
       tb_frag_acc(s, s2, ph, pl);
       tb_frag_acc(dp, s2, sh, sl);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bf16x8 ah = tb_tr_op(dh, s2, i, lane), al = tb_tr_op(dl, s2, i, lane);
-        if (i == 0) TB_MFMA3(ah, al, ph, pl, gv0); else TB_MFMA3(ah, al, ph, pl, gv1);
-        const bf16x8 bh = tb_tr_op(qh, s2, i, lane), bl = tb_tr_op(ql, s2, i, lane);
-        if (i == 0) TB_MFMA3(bh, bl, sh, sl, gk0); else TB_MFMA3(bh, bl, sh, sl, gk1);
-      }
+      yh = tb_tr_op(qh, s2, 0, lane); yl = tb_tr_op(ql, s2, 0, lane);
+      TA_FENCE();
+      TB_MFMA3(xh, xl, ph, pl, gv0);                       // dV^T[d][key] += dO^T[d][q] P[q][key]
+      TA_FENCE();
+      xh = tb_tr_op(dh, s2, 1, lane); xl = tb_tr_op(dl, s2, 1, lane);
+      TA_FENCE();
+      TB_MFMA3(yh, yl, sh, sl, gk0);                       // dK^T[d][key] += Q^T[d][q] dS[q][key]
+      TA_FENCE();
+      yh = tb_tr_op(qh, s2, 1, lane); yl = tb_tr_op(ql, s2, 1, lane);
+      TA_FENCE();
+      TB_MFMA3(xh, xl, ph, pl, gv1);
+      TA_FENCE();
+      if (s2 == 0) { xh = tb_tr_op(dh, 1, 0, lane); xl = tb_tr_op(dl, 1, 0, lane); }
+      TA_FENCE();
+      TB_MFMA3(yh, yl, sh, sl, gk1);
+      TA_FENCE();
     }
   }
   if (krow >= pr.nk) return;
