@@ -1,5 +1,6 @@
 // Attention of the training step (models/gmatcher.py:35-39 inside forward_train, :309-386, and its reverse pass) without the probability
-// matrices: one call per GNN layer and direction for ALL images and heads, in exact f32 on the matrix cores.
+// matrices: one call per GNN layer and direction for ALL images and heads; the forward in exact f32 on the matrix cores, the reverse pass in
+// exact f32 or (default of the training step) in three bf16 passes -- the second half of this file.
 //
 // What it replaces.  trainstep.py ran, per image and layer, a batched split-bf16 product Q K^T that wrote the 4 x n x m scores, a softmax pass
 // over them, a second product with V (+ its split-K fold) -- and kept P (67 MB per image and layer at 2048 keypoints) for a reverse pass of four
