@@ -368,12 +368,16 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
   int last_fresh = 0;                                        // iteration of the last derivation (the start potentials count as one)
   bool pend_fresh = false;                                   // next_fresh of the previous iteration
   constexpr float R2_F_BOUND = 7.9e13f, R2_G_BOUND = 4.85e8f;      // e^32, e^20 (see the header)
+  int nslots_s = __builtin_amdgcn_readfirstlane(nslots);
   const bool force_last = a.refresh > 0 || a.refresh == -1;      // fixed period / "final only": derive on the last iteration whatever happened
   for (int it = 0; it < a.iters; ++it) {
     // thread-dependent indices are re-derived from an opaque copy of the thread id every iteration (as loop invariants the
     // compiler keeps their hoisted addresses alive next to the 192 registers of P)
     int tq = threadIdx.x;
     asm volatile("" : "+v"(tq));
+    // the uniform slot count lives in a SCALAR register inside the loop: as a (spilled) vector register it was reloaded from scratch in front of
+    // five compares per iteration, each on the critical path of an exchange
+    asm volatile("" : "+s"(nslots_s));
     const int t = tq, lane = t & 63, wave = t >> 6, cg = t & 7, rg = t >> 3;
     const bool fresh = (it == 0 && !a.init_inside) || (it > 0 && pend_fresh);
     bool next_fresh = it + 1 < a.iters && ((force_last && it + 2 == a.iters) || (a.refresh > 0 && (it + 1) % a.refresh == 0));
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
     }
     stamp(1);
     // ---------------- publish the row partials (16-byte stores; stay in this XCD's L2 unless wt)
-    if (4 * t < nslots) {
+    if (4 * t < nslots_s) {
       f32x4 q = *(const f32x4*)(rowst + 4 * t);
       if (lastc) {
         const f32x4 b4 = *(const f32x4*)(pb + 4 * t);
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
       f32x4 q = {0.f, 0.f, 0.f, 0.f};
       unsigned vmask = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vmask |= (fs0 + e < nslots ? 1u : 0u) << e;
+      for (int e = 0; e < 4; ++e) vmask |= (fs0 + e < nslots_s ? 1u : 0u) << e;
       if (vmask) {
         const float* src = rpart_grp + (int64_t)fc * p.rbs + fs0;
         int spins = 0;
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int s = fs0 + e;
-          const bool val = s < nslots, real = s < nrl;
+          const bool val = s < nslots_s, real = s < nrl;
           const float tt = val ? tot[e] : 1.f;
           const float fn = val ? (real ? p.mu : p.mu_bin) * __builtin_amdgcn_rcpf(tt) : 1.f;
           bad |= !(tt > 0.f) || !(tt < 3.0e38f) || !(fn < 3.0e38f);
@@ -624,11 +628,11 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
     }
     stamp(3);
     // ---------------- gather the group's F
-    if (4 * t < nslots) {
+    if (4 * t < nslots_s) {
       f32x4 q;
       unsigned vmask = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vmask |= (4 * t + e < nslots ? 1u : 0u) << e;
+      for (int e = 0; e < 4; ++e) vmask |= (4 * t + e < nslots_s ? 1u : 0u) << e;
       int spins = 0;
       for (;;) {
         r2_ld4_issue(q, fb + 4 * t);
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
       }
       if (lastc) {              // dustbin column: sum_i F_i pb_i over the group's slots (the corner included: it sits in slot nrl)
         float s = 0.f;
-        for (int r = t; r < nslots; r += NT) s += facs[r] * pb[r];
+        for (int r = t; r < nslots_s; r += NT) s += facs[r] * pb[r];
         s = wave_sum(s);
         if (lane == 0) wred[wave] = s;
       }
