@@ -1295,7 +1295,7 @@ extern "C" int gims_sinkhorn_match(const gims_ot_problem* pr, int32_t np, float 
     streamed_iterations(0);
   }
   if (cpt == 1) hipLaunchKernelGGL(ot_select_kernel<1>, gi, dim3(threads), 0, s, dp);
-  else if (cpt == 2) hipLaunchKernelGGL(ot_select_kernel<2>, gi, dim3(threads), 0, s, dp);
+  else if (cpt == 2) hipLaunchKernelGGL((ot_select_kernel<2, 4>), gi, dim3(threads), 0, s, dp);      // (four-row slabs: eight staged 364 B of the row pieces in scratch)
   // (two rows per slab for the 4- and 8-quad instances: with eight, the two slabs' worth of staged rows are 256-512 registers per lane: 1.1 KB of scratch)
   else if (cpt <= 4) hipLaunchKernelGGL((ot_select_kernel<4, 2>), gi, dim3(threads), 0, s, dp);
   else hipLaunchKernelGGL((ot_select_kernel<8, 2>), gi, dim3(threads), 0, s, dp);
