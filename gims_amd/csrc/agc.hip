@@ -1488,7 +1488,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // at least 64 directed edges per node): a caller that sees the overflow flag repeats the build with larger output buffers.
 constexpr int AGC_MIN_CAP_PER_NODE = 64;
 
-static size_t agc_layout(int n, int d, int max_edges_dir, char* base, AgcWs* w) {
+static size_t agc_layout(int n, int d, int max_edges_dir, bool with_s16, char* base, AgcWs* w) {
   const int nw = (n + 63) / 64, lds16 = (n + 7) & ~7;
   const int cap = max_edges_dir > n * AGC_MIN_CAP_PER_NODE ? max_edges_dir : n * AGC_MIN_CAP_PER_NODE;
   size_t off = 0;
@@ -1500,10 +1500,10 @@ static size_t agc_layout(int n, int d, int max_edges_dir, char* base, AgcWs* w) 
   // approximate similarities in half [n][lds16] (robust flow only: the window flow never stores them), the radius candidates and their keys, and the
   // band list (one u32 per pair of the strict upper triangle at most)
   const size_t list_cap = (size_t)n * (n - 1) / 2 + 64;
-  const size_t s16_bytes = al256((size_t)n * lds16 * 2), cl_bytes = al256((size_t)cap * 4);
+  const size_t s16_bytes = with_s16 ? al256((size_t)n * lds16 * 2) : 0, cl_bytes = al256((size_t)cap * 4);
   p = take(s16_bytes + 2 * cl_bytes + list_cap * 4);
   if (w) {
-    w->S16 = (uint16_t*)p;
+    w->S16 = with_s16 ? (uint16_t*)p : nullptr;
     w->clist = (uint32_t*)(p + s16_bytes);
     w->ckey = (uint32_t*)(p + s16_bytes + cl_bytes);
     w->list = (uint32_t*)(p + s16_bytes + 2 * cl_bytes);
@@ -1542,12 +1542,26 @@ static size_t agc_batch_header(int n_images) { return al256(sizeof(AgcWs) * (siz
 
 }  // namespace gims
 
-extern "C" size_t gims_agc_workspace_bytes(const gims_agc_image* images, int32_t n_images) {
+// which flow a call takes: the robust one when asked for (flag or GIMS_AGC_ROBUST=1) or when an image's descriptor width does not fit the
+// window kernels (they keep a tile row's whole K in registers); only that flow stores the half similarity matrix
+static bool agc_takes_robust_flow(const gims_agc_image* images, int n_images, int flags) {
+  const char* env_robust = getenv("GIMS_AGC_ROBUST");          // read per call: the tests switch flows
+  bool robust = (flags & GIMS_AGC_ROBUST) != 0 || (env_robust && atoi(env_robust) != 0);
+  for (int i = 0; i < n_images; ++i) robust = robust || images[i].d % gims::SW_KC != 0 || images[i].d > gims::SW_KMAX;
+  return robust;
+}
+
+extern "C" size_t gims_agc_workspace_bytes_ex(const gims_agc_image* images, int32_t n_images, int32_t flags) {
   using namespace gims;
   if (!images || n_images <= 0) return 0;
+  const bool robust = agc_takes_robust_flow(images, n_images, flags);
   size_t b = agc_batch_header(n_images);
-  for (int i = 0; i < n_images; ++i) b += agc_layout(images[i].n, images[i].d, images[i].max_edges_dir, nullptr, nullptr);
+  for (int i = 0; i < n_images; ++i) b += agc_layout(images[i].n, images[i].d, images[i].max_edges_dir, robust, nullptr, nullptr);
   return b;
+}
+
+extern "C" size_t gims_agc_workspace_bytes(const gims_agc_image* images, int32_t n_images) {
+  return gims_agc_workspace_bytes_ex(images, n_images, GIMS_AGC_ROBUST);        // enough for either flow
 }
 
 extern "C" int32_t gims_agc_max_keypoints(void) { return gims::AGC_MAX_N; }
@@ -1562,11 +1576,12 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
   using namespace gims;
   GIMS_CHECK_ARG(images && n_images > 0 && work, "gims_agc_build: null / empty arguments");
   // GIMS_AGC_ROBUST=1 / GIMS_AGC_WINDOW_SHIFT=<x> (read per call: the tests switch flows and force a missed window)
-  const char* env_robust = getenv("GIMS_AGC_ROBUST");
-  bool robust = (flags & GIMS_AGC_ROBUST) != 0 || (env_robust && atoi(env_robust) != 0);
+  const bool robust = agc_takes_robust_flow(images, n_images, flags);
   const char* env_shift = getenv("GIMS_AGC_WINDOW_SHIFT");
   const float window_test_shift = env_shift ? (float)atof(env_shift) : 0.f;
-  GIMS_CHECK_ARG(work_bytes >= gims_agc_workspace_bytes(images, n_images), "gims_agc_build: workspace too small");
+  GIMS_CHECK_ARG(work_bytes >= gims_agc_workspace_bytes_ex(images, n_images, robust ? GIMS_AGC_ROBUST : 0),
+                 "gims_agc_build: workspace too small (%zu bytes; gims_agc_workspace_bytes_ex asks for %zu for the %s flow)", work_bytes,
+                 gims_agc_workspace_bytes_ex(images, n_images, robust ? GIMS_AGC_ROBUST : 0), robust ? "robust" : "window");
   hipStream_t s = (hipStream_t)stream;
   AgcWs* dws = (AgcWs*)work;
   char* base = (char*)work + agc_batch_header(n_images);
@@ -1579,7 +1594,7 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
     static_assert(AGC_MAX_N <= (1 << AGC_PK_SHIFT), "the band list packs a pair as i << 16 | j");
     GIMS_CHECK_ARG(im.d > 0 && (im.d % 32) == 0 && (im.ldd % 4) == 0, "gims_agc_build: image %d: d=%d must be a multiple of 32 (ldd %% 4 == 0)", i, im.d);
     AgcWs* w = &hws[i];
-    base += agc_layout(im.n, im.d, im.max_edges_dir, base, w);
+    base += agc_layout(im.n, im.d, im.max_edges_dir, robust, base, w);
     w->kpts = im.kpts; w->desc = im.desc; w->ldd = im.ldd; w->kept = im.kept; w->indptr = im.indptr; w->indices = im.indices;
     w->info = im.info; w->max_edges_dir = im.max_edges_dir;
     // K2 rank: k = int(L * p / 100), clamped (agc.py:378-379)
@@ -1588,7 +1603,6 @@ extern "C" int gims_agc_build_ex(const gims_agc_image* images, int32_t n_images,
     if (k >= L) k = L - 1;
     if (k < 0) k = 0;
     w->krank = k;
-    if (im.d % SW_KC != 0 || im.d > SW_KMAX) robust = true;       // (the window kernels keep a tile row's whole K in registers)
     maxn = im.n > maxn ? im.n : maxn;
     maxnw = w->nw > maxnw ? w->nw : maxnw;
   }

@@ -21,6 +21,7 @@
 //     grows by more than 2^5 in probability units -- after the first tiles the accumulators stay in place.
 #include "common.h"
 
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1578,6 +1579,11 @@ static int attention_range_launch(const uint16_t* qkv, int64_t ld, int q_col, in
   return GIMS_OK;
 }
 
+// which kernel served a launch, counted per process (gims_attention_launch_counts: the parity tests assert that a batch ran on the
+// kernel it is meant to pin -- the 8-wave kernel of the timed batches is only taken by launches that fill the chip)
+static std::atomic<uint64_t> g_launch_counts[GIMS_ATTN_KERNEL_KINDS];
+static inline void count_launch(int kind) { g_launch_counts[kind].fetch_add(1, std::memory_order_relaxed); }
+
 // launch of the one-pass 16-bit kernels (F16 = false: bf16 operands, true: IEEE half), by launch shape
 template <bool F16>
 static int attention_16b_launch(const uint16_t* qkv, int64_t ld, int q_col, int k_col, int v_col, const gims_attn_problem* problems, int n_groups, int max_n_q,
@@ -1600,6 +1606,7 @@ static int attention_16b_launch(const uint16_t* qkv, int64_t ld, int q_col, int 
     { const char* e = getenv("GIMS_ATTN_SPLIT"); ns_env = e ? atoi(e) : 0; }
     // four key parts (sixteen waves) when the launch is at most one workgroup per CU and the keys are many
     const bool four = ns_env == 4 || (ns_env != 2 && wgs <= 256 && max_n_q >= 2048);
+    count_launch(GIMS_ATTN_KERNEL_SPLIT);
     if (four)
       hipLaunchKernelGGL((attention_split_kernel<4, F16>), dim3(wgs), dim3(1024), SPLIT_LDS_BYTES<4>, stream, qkv, ld, q_col, k_col, v_col, problems,
                          n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
@@ -1607,6 +1614,7 @@ static int attention_16b_launch(const uint16_t* qkv, int64_t ld, int q_col, int 
       hipLaunchKernelGGL((attention_split_kernel<2, F16>), dim3(wgs), dim3(512), SPLIT_LDS_BYTES<2>, stream, qkv, ld, q_col, k_col, v_col, problems,
                          n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
   } else if (eight) {
+    count_launch(F16 ? GIMS_ATTN_KERNEL_WAVE8_F16 : GIMS_ATTN_KERNEL_WAVE8);
     int exact_only = 0;                         // GIMS_ATTN_EXACT=1: running-maximum softmax only (no optimistic pass)
     { const char* e = getenv("GIMS_ATTN_EXACT"); exact_only = e ? atoi(e) : 0; }
     static int prof = -1;
@@ -1641,10 +1649,12 @@ static int attention_16b_launch(const uint16_t* qkv, int64_t ld, int q_col, int 
                            q_col, k_col, v_col, problems, n_groups, n_heads, n_qt8, out, ld_out, out_hi, out_lo, ld_split, nullptr, exact_only, c, stat, n_sample);
     }
   } else if (two) {
+    count_launch(GIMS_ATTN_KERNEL_WAVE4);
     const int n_qt = cdiv(max_n_q, 2 * QB);
     hipLaunchKernelGGL((attention_bf16_kernel<2, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, stream, qkv, ld,
                        q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
   } else {
+    count_launch(GIMS_ATTN_KERNEL_WAVE4);
     const int n_qt = cdiv(max_n_q, QB);
     hipLaunchKernelGGL((attention_bf16_kernel<1, F16>), dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), 0, stream, qkv, ld,
                        q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat);
@@ -1653,6 +1663,14 @@ static int attention_16b_launch(const uint16_t* qkv, int64_t ld, int q_col, int 
   return GIMS_OK;
 }
 }  // namespace gims
+
+extern "C" int gims_attention_launch_counts(uint64_t* counts, int32_t n, int32_t reset) {
+  GIMS_CHECK_ARG(counts || n == 0, "gims_attention_launch_counts: null pointer");
+  for (int i = 0; i < n && i < GIMS_ATTN_KERNEL_KINDS; ++i) counts[i] = gims::g_launch_counts[i].load(std::memory_order_relaxed);
+  for (int i = GIMS_ATTN_KERNEL_KINDS; i < n; ++i) counts[i] = 0;
+  if (reset) for (auto& c : gims::g_launch_counts) c.store(0, std::memory_order_relaxed);
+  return GIMS_OK;
+}
 
 extern "C" int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col, int32_t v_col,
                               const gims_attn_problem* problems, int32_t n_problems, int32_t max_n_q,
@@ -1721,6 +1739,7 @@ extern "C" int gims_attention_ex(const gims_attn_args* args, void* stream) {
     // else the 32-query-per-wave kernel.  Measured with K and V staged by LDS-DMA in all of them (32-query / QP = 2 / QP = 4):
     // 16 x 4096 keys 912 / 730 / 867 us, 32 x 2048 460 / 398 / 504, 40 x 1500 298 / 274 / 337, 64 x 1022 206 / 197 / 236, 8 x 700 26 / 41 / 76.
     if (wide < 0) wide = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB) >= 512 ? 2 : 0;
+    count_launch(guard.stat ? GIMS_ATTN_KERNEL_X3_GUARDED : GIMS_ATTN_KERNEL_X3);
     if (wide) {
       GIMS_LDS_ATTR((const void*)attention_x3w_kernel<4>, X3W_LDS_BYTES);
       GIMS_LDS_ATTR((const void*)attention_x3w_kernel<2>, X3W_LDS_BYTES);

@@ -539,8 +539,13 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[e] = pack_h2_sat(v[2 * e], v[2 * e + 1]);
             if (p.range_stat) {          // range of what the half attention will read (eight columns of ONE 256-column block: col % 8 == 0)
-              const float m8 = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
-                                     full ? fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))) : 0.f);
+              float m8 = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                               full ? fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))) : 0.f);
+              // fmaxf drops NaN operands: a NaN in what the half attention will read must reach the range row as "not finite" (+inf), or the
+              // range guard would pass it (x - x is 0 for finite x, NaN for NaN and inf: one sum finds either)
+              const float nf = ((v[0] - v[0]) + (v[1] - v[1])) + ((v[2] - v[2]) + (v[3] - v[3]))
+                               + (full ? ((v[4] - v[4]) + (v[5] - v[5])) + ((v[6] - v[6]) + (v[7] - v[7])) : 0.f);
+              m8 = nf == 0.f ? m8 : INFINITY;
               const int blk = col >> 8;
               rmax[0] = blk == 0 ? fmaxf(rmax[0], m8) : rmax[0];
               rmax[1] = blk == 1 ? fmaxf(rmax[1], m8) : rmax[1];

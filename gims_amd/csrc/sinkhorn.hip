@@ -893,13 +893,10 @@ __global__ __launch_bounds__(1024) void ot_bwd_colsum_rec_kernel(const OtBwd* __
     }
   red[ty][tx] = s;
   __syncthreads();
-  if (ty < 16) {                                             // 64 groups -> 16 -> 1, fixed order
-    const float a = (red[ty][tx] + red[ty + 16][tx]) + (red[ty + 32][tx] + red[ty + 48][tx]);
-    __syncthreads();
-    red[ty][tx] = a;
-  } else {
-    __syncthreads();
-  }
+  float a = 0.f;                                             // 64 groups -> 16 -> 1, fixed order
+  if (ty < 16) a = (red[ty][tx] + red[ty + 16][tx]) + (red[ty + 32][tx] + red[ty + 48][tx]);
+  __syncthreads();                                           // (every thread reaches both barriers: none sits in a divergent branch)
+  if (ty < 16) red[ty][tx] = a;
   __syncthreads();
   if (ty == 0 && j <= p.m) {
     float t = 0.f;

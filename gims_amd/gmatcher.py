@@ -508,8 +508,8 @@ class GMatcher(nn.Module):
             info_all = torch.empty((len(images), 8), dtype=torch.int32, device=dev)
             agc_imgs = hip.make_agc_images([dict(kpts=g["kp"], desc=g["de"], kept=g["kept"], indptr=g["indptr"],
                                                  indices=g["indices"], info=info_all[i]) for i, g in enumerate(images)])
-            hip.agc_build(agc_imgs, radius, percentile, min_size, self._buf("agc", hip.agc_workspace_bytes(agc_imgs)),
-                          flags=hip.AGC_ROBUST if robust else 0)
+            aflags = hip.AGC_ROBUST if robust else 0        # (the default flow never stores the N x N half matrix: half the workspace)
+            hip.agc_build(agc_imgs, radius, percentile, min_size, self._buf("agc", hip.agc_workspace_bytes(agc_imgs, aflags)), flags=aflags)
             # everything of the next stage that does not depend on the kept counts is prepared NOW, while the GPU builds the
             # graphs: after the host sync only two cumsums stand between the counts and the next launch
             ptab = hip.pack_table([(g["kp"].data_ptr(), g["de"].data_ptr(), g["de"].stride(0), g["sc"].data_ptr(),
@@ -964,9 +964,11 @@ class GMatcher(nn.Module):
         # forward() ends in a host synchronisation, so its 'auto' verdict is drawn THERE (no guarded launches on the latency path): a batch
         # whose statistic moves a settled layer up is repeated on the new table before anything is returned.  Tiers only move up, twice per
         # layer at most: the loop is short and a repeat is rare (a layer sharpening for the first time).
-        self._device_guards = False
         done = None
         for attempt in range(4):
+            # the LAST attempt cannot be repeated: it runs with the device-side guards (like match_pairs), so a layer whose statistic moves up
+            # once more inside it is redone at f32-class accuracy on the device -- no batch is ever returned from an under-precision tier
+            self._device_guards = attempt == 3
             done = self._forward_once(data, B, radius, percentile, min_size, attempt == 3)
             if done is not None:
                 break

@@ -200,6 +200,7 @@ _SIGNATURES = {
     "gims_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
     "gims_agc_workspace_bytes": (C.c_size_t, [C.POINTER(AgcImage), C.c_int32]),
+    "gims_agc_workspace_bytes_ex": (C.c_size_t, [C.POINTER(AgcImage), C.c_int32, C.c_int32]),
     "gims_agc_max_keypoints": (C.c_int32, []),
     "gims_agc_build": (C.c_int, [C.POINTER(AgcImage), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
@@ -216,6 +217,7 @@ _SIGNATURES = {
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "gims_sinkhorn_plan_ex": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_int32, C.c_int32]),
     "gims_sinkhorn_rescues": (C.c_int64, []),
+    "gims_attention_launch_counts": (C.c_int, [C.POINTER(C.c_uint64), C.c_int32, C.c_int32]),
     "gims_sinkhorn_match_ex": (C.c_int, [C.POINTER(OtProblem), C.c_int32, C.c_float, C.c_int32, C.c_float,
                                          C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "gims_eval_workspace_bytes": (C.c_size_t, [C.POINTER(EvalPair), C.c_int32, C.c_int32]),
@@ -674,12 +676,15 @@ def agc_max_keypoints() -> int:
     return int(load().gims_agc_max_keypoints())
 
 
-def agc_workspace_bytes(images) -> int:
+def agc_workspace_bytes(images, flags=None) -> int:
+    """Scratch bytes of agc_build(images, ..., flags=flags); flags=None: enough for either flow (the robust one stores the half N x N matrix)."""
     nmax = max(int(im.n) for im in images)
     if nmax > agc_max_keypoints():
         raise GimsHipError(f"adaptive graph: an image has {nmax} keypoints, more than the library's limit of {agc_max_keypoints()} per image "
                            "(gims_agc_max_keypoints; the reference has none) -- reduce max_keypoints or split the image")
-    return int(load().gims_agc_workspace_bytes(images, len(images)))
+    if flags is None:
+        return int(load().gims_agc_workspace_bytes(images, len(images)))
+    return int(load().gims_agc_workspace_bytes_ex(images, len(images), int(flags)))
 
 
 AGC_ROBUST = 1               # gims_agc_build_ex flags (include/gims_hip.h)
@@ -776,6 +781,16 @@ OT_STREAMED = 1      # flag of sinkhorn_plan / sinkhorn_match: never an on-chip 
 def sinkhorn_plan(problems, iters: int, flags: int = 0) -> int:
     """0: streamed kernels (one launch per iteration); k > 0: on-chip resident kernel in k launches."""
     return int(load().gims_sinkhorn_plan_ex(problems, len(problems), int(iters), int(flags)))
+
+
+ATTN_KERNEL_KINDS = ("wave4", "split", "wave8", "wave8_f16", "x3", "x3_guarded")
+
+
+def attention_launch_counts(reset: bool = False) -> dict:
+    """Attention launches of this process per kernel family since the last reset (include/gims_hip.h GIMS_ATTN_KERNEL_*)."""
+    buf = (C.c_uint64 * len(ATTN_KERNEL_KINDS))()
+    _check(load().gims_attention_launch_counts(buf, len(ATTN_KERNEL_KINDS), int(reset)), "gims_attention_launch_counts")
+    return dict(zip(ATTN_KERNEL_KINDS, (int(x) for x in buf)))
 
 
 def sinkhorn_rescues() -> int:

@@ -195,6 +195,19 @@ int gims_attention_stat(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t 
                         uint16_t* out_hi /* may be NULL */, uint16_t* out_lo, int64_t ld_split, int32_t flags,
                         uint64_t* stat /* device, may be NULL */, void* stream);
 
+/* Which kernel served the attention launches of this process so far (host-side counters, one per kernel family; thread-safe):
+ * counts[k] for k < min(n, GIMS_ATTN_KERNEL_KINDS), the rest zero; reset != 0 clears them afterwards.  The launcher picks a kernel
+ * from the launch shape (a batch that fills the chip takes the 8-wave kernel, one pair alone the split-key / 4-wave kernels):
+ * parity tests use this to assert that a fixture went through the kernel it is meant to pin.  Test / diagnostic hook. */
+#define GIMS_ATTN_KERNEL_WAVE4 0       /* attention_bf16_kernel<QP, F16>: 4 waves, running maximum */
+#define GIMS_ATTN_KERNEL_SPLIT 1       /* attention_split_kernel<NS, F16>: key range split over wave groups */
+#define GIMS_ATTN_KERNEL_WAVE8 2       /* attention8_bf16_kernel, bf16 operands (the kernel of the timed batches) */
+#define GIMS_ATTN_KERNEL_WAVE8_F16 3   /* attention8_bf16_kernel, IEEE-half operands */
+#define GIMS_ATTN_KERNEL_X3 4          /* attention_x3_kernel / attention_x3w_kernel, unguarded */
+#define GIMS_ATTN_KERNEL_X3_GUARDED 5  /* the same behind a gims_attn_guard (the device-side redo of 'auto') */
+#define GIMS_ATTN_KERNEL_KINDS 6
+int gims_attention_launch_counts(uint64_t* counts /* host */, int32_t n, int32_t reset);
+
 /* gims_attention_stat with its arguments in a struct, plus the guard (see gims_attn_guard): what an op of gims_run_ops executes. */
 struct gims_attn_args;
 int gims_attention_ex(const struct gims_attn_args* args, void* stream);
@@ -296,7 +309,8 @@ int gims_gather_rows(const float* src, int64_t lds, const int32_t* idx, int32_t 
  * LIMIT: 2 <= n <= gims_agc_max_keypoints() = 32768 keypoints per image (GIMS_EINVAL above it; the reference -- NumPy / SciPy -- has no
  * limit and publishes runs with up to 21 163 kept keypoints, tools/files/rgbd1/record.txt:635).  What bounds it: a pair of node ids is one
  * packed 32-bit word (i << 16 | j), the sequential isolated-node walk keeps its ordered list in LDS (135 KB of 160 KB at 32768), and the
- * workspace reserves one word per pair of the strict upper triangle (n^2 * 2 bytes: 0.9 GB per image at 21 163, 2.1 GB at 32768).  Images
+ * workspace reserves one word per pair of the strict upper triangle (n^2 * 2 bytes: 0.9 GB per image at 21 163, 2.1 GB at 32768) -- and
+ * the ROBUST flow as much again for the half similarity matrix it stores (gims_agc_workspace_bytes_ex: 1.8 GB / 4.3 GB).  Images
  * above 16384 keypoints run the component search in global memory instead of LDS (same labels).
  * Exact-distance ties in the two sequential fix-ups resolve to the lowest node index.
  * Asynchronous; read info[] after synchronising the stream.
@@ -306,7 +320,11 @@ typedef struct gims_agc_image {
   int32_t* kept; int32_t* indptr; int32_t* indices; int32_t max_edges_dir; int32_t* info;
 } gims_agc_image;
 
-size_t gims_agc_workspace_bytes(const gims_agc_image* h_images /* HOST array */, int32_t n_images);
+size_t gims_agc_workspace_bytes(const gims_agc_image* h_images /* HOST array */, int32_t n_images);   /* enough for either flow of gims_agc_build_ex */
+/* Scratch bytes of gims_agc_build_ex(..., flags, ...): the default (window) flow never stores the N x N half similarity matrix, which is half of
+ * the robust flow's workspace -- a batch of README-size images (15 k keypoints) asks for 0.5 GB per image instead of 0.9.  A call whose
+ * images force the robust flow (d % 64 != 0 or d > 256; GIMS_AGC_ROBUST=1 in the environment) is sized for it whatever the flags say. */
+size_t gims_agc_workspace_bytes_ex(const gims_agc_image* h_images /* HOST array */, int32_t n_images, int32_t flags);
 int32_t gims_agc_max_keypoints(void);
 int gims_agc_build(const gims_agc_image* h_images /* HOST array */, int32_t n_images, double radius, double percentile,
                    int32_t min_size, void* work, size_t work_bytes, void* stream);

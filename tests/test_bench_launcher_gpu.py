@@ -33,3 +33,32 @@ def test_bench_self_launch_two_ranks():
     assert len({x[3] for x in res["ranks"]}) == 2          # two processes, neither of them the launcher
     assert res["scaling"] == "weak" and res["value"] > 0 and res["steps"] == 2 and res["warmup"] == 1
     assert res["matches_pair0"]["matched"] > 128
+
+
+def test_bench_two_ranks_over_rccl_on_one_gpu_succeeds_or_fails_cleanly():
+    """The N > 1 branch with the REAL backend (`init_process_group("nccl", device_id=...)`, bench.py main) on the one GPU of the test box: two
+    ranks on the same device.  RCCL may refuse that (its duplicate-device check) -- then the launcher must exit non-zero, with the backend's
+    message on stderr, within the time limit: never a hang, never a JSON line that claims two GPUs.  If RCCL accepts it, the line must carry both
+    ranks with backend 'nccl'.  (One rank per GPU over xGMI is what an 8-GPU node runs: `python bench.py --gpus 8`)"""
+    env = dict(os.environ, GIMS_OT_RESIDENT="0", HSA_ENABLE_IPC_MODE_LEGACY="0", TORCH_NCCL_ASYNC_ERROR_HANDLING="1", NCCL_DEBUG="WARN")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GIMS_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--kpts", "256", "--pairs", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=420)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(p.pid, signal.SIGKILL)          # the launcher and both ranks (its own session): nothing of this test survives it
+        p.communicate()
+        pytest.fail("bench.py --gpus 2 over RCCL on one GPU hung (no exit within 420 s)")
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if p.returncode == 0:
+        res = json.loads(lines[-1])
+        assert res["n_gpus"] == 2 and res["world_size_seen"] == 2 and res["stats_rows_gathered"] == 4
+        assert sorted(x[0] for x in res["ranks"]) == [0, 1] and all(x[2] == "nccl" for x in res["ranks"])
+        assert res["host_threads_per_rank"] >= 1
+    else:
+        assert not lines, "a failed multi-rank launch must not print a result line"
+        assert any(w in err for w in ("NCCL", "nccl", "RCCL", "Duplicate GPU", "DistBackendError")), err[-2000:]

@@ -9,7 +9,7 @@ import torch
 
 from gims_amd import GMatcher, Matching, synth
 from oracle import gims_oracle as O
-from tests.helpers import check_score_gradients, golden_names, load_golden, pair_to_data, safe_rows, train_data, train_pairs
+from tests.helpers import compare_with_golden as _compare, check_score_gradients, golden_names, load_golden, pair_to_data, safe_rows, train_data, train_pairs
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -33,33 +33,6 @@ def _settle(m):
     decides; tests that compare calls with each other start from the settled state."""
     m(pair_to_data(synth.make_pair(256, 1002), 15, 2, 7, device="cuda"))
     assert m.attention_report() is None or m.attention_report()["calibrated"]
-
-
-def _compare(out, data, g, thr):
-    np.testing.assert_array_equal(np.asarray(data["kept_kpts0_indices"][0]), g["out/kept0"])
-    np.testing.assert_array_equal(np.asarray(data["kept_kpts1_indices"][0]), g["out/kept1"])
-    m0, m1 = out["matches0"][0].cpu().numpy(), out["matches1"][0].cpu().numpy()
-    s0, s1 = out["matching_scores0"][0].cpu().numpy(), out["matching_scores1"][0].cpu().numpy()
-    assert out["matches0"].dtype == torch.int64 and out["matching_scores0"].dtype == torch.float32
-    r0, r1, rs0, rs1 = g["out/matches0"], g["out/matches1"], g["out/matching_scores0"], g["out/matching_scores1"]
-    safe0 = (g["out/gap0"] > 1e-3) & (np.abs(rs0 - thr) > 1e-3)
-    # a row is also unsafe when its partner column's argmax is ill-conditioned (mutual check)
-    col_unsafe = g["out/gap1"] <= 1e-3
-    partner = np.where(r0 >= 0, r0, 0)
-    safe0 &= ~col_unsafe[partner] | (r0 < 0)
-    assert safe0.mean() > 0.97, f"fixture too ill-conditioned: {safe0.mean():.3f}"
-    bad = np.nonzero((m0 != r0) & safe0)[0]
-    assert len(bad) == 0, f"{len(bad)} well-conditioned match indices differ, e.g. rows {bad[:5]}: {m0[bad[:5]]} vs {r0[bad[:5]]}"
-    same = m0 == r0
-    err = np.abs(s0 - rs0)[same & (r0 >= 0)].max()
-    assert err < 1e-4, f"matching_scores0 max err {err:.3e}"
-    # ... and in practice EVERY row agrees, ill-conditioned ones included: asserted, so that a regression on those rows is
-    # seen (a failure here with zero well-conditioned mismatches means a reference decision flipped on a sub-1e-3 margin)
-    mismatched_unsafe = int((m0 != r0).sum())
-    assert mismatched_unsafe == 0, f"{mismatched_unsafe} ill-conditioned rows differ from the reference: {np.nonzero(m0 != r0)[0][:8]}"
-    np.testing.assert_array_equal(m1, r1)
-    assert np.abs(s1 - rs1).max() < 1e-4
-    return dict(n=len(m0), mismatched_unsafe=mismatched_unsafe, score_err=float(err))
 
 
 @pytest.mark.parametrize("sinkhorn", ["streamed", "resident"])     # both Sinkhorn implementations against the reference

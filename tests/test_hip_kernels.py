@@ -345,6 +345,29 @@ def test_linear_reports_the_range_of_its_half_output(hip):
     assert (c[H] == 0).all() and (c[:H, 1] > 0).all()
 
 
+@pytest.mark.parametrize("poison", ["nan_row", "inf_bias"])
+def test_linear_range_report_propagates_non_finite_values(hip, poison):
+    """include/gims_hip.h: the range guard fires when max |operand| "exceeds range_limit, or is not finite".  fmaxf drops NaN operands, so a NaN the
+    half-tier projection produces has to be turned into +inf on its way into the range row: a NaN input row poisons all three column
+    blocks, an infinite bias on one K column only the K block."""
+    r = _rng(92)
+    rows, H = 700, 4
+    x = r.normal(size=(rows, 256)).astype(np.float32)
+    w = (r.normal(size=(768, 256)) / 16.0).astype(np.float32)
+    bias = r.normal(size=768).astype(np.float32)
+    if poison == "nan_row":
+        x[433, 7] = np.nan
+    else:
+        bias[256 + 77] = np.inf
+    xs, ws = hip.split_spl32(_dev(x)), hip.split_spl32(_dev(w))
+    stat = torch.zeros((H + 1, 4), dtype=torch.int64, device="cuda")
+    qkv16 = torch.empty((rows, 768), dtype=torch.bfloat16, device="cuda")
+    hip.linear(xs, ws, bias=_dev(bias), out_bf16=qkv16, precision=hip.PREC_BF16X3, spl=True, flags=hip.LINEAR_OUT_F16, range_stat=stat[H])
+    got = stat.cpu().numpy()[H, :3].astype(np.uint32).view(np.float32)
+    want_inf = [True, True, True] if poison == "nan_row" else [False, True, False]
+    assert [bool(np.isinf(v)) for v in got] == want_inf, got
+
+
 @pytest.mark.parametrize("kind", ["peaked", "range"])
 @pytest.mark.parametrize("sharp", [1.0, 6.0])
 def test_attention_guarded_redo(hip, kind, sharp):

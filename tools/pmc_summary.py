@@ -37,6 +37,9 @@ def main(fetch_csv, write_csv, key, out_json):
     except Exception:
         allr = {}
     allr[key] = res
+    import os
+    if os.environ.get("GIMS_HEAD"):          # the commit the counters were taken on (tools/refresh_profiles.sh <tag> <head>): a stale table is visible in the bench line
+        allr["_meta"] = {"head": os.environ["GIMS_HEAD"]}
     json.dump(allr, open(out_json, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
         print(f"{k:32s} n={v['launches_profiled']:5d} fetch(raw KiB)={v['fetch_kib_raw']:12.1f} write(KiB)={v['write_kib_raw']:12.1f} "

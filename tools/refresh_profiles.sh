@@ -4,7 +4,8 @@
 # Outputs land in gpurun_out/refresh/; copy what should be judged into profiles/ (tools/README.md).
 # Every rocprofv3 run is csv-only and wrapped in `timeout` (a run that builds the rocpd database can hang for minutes).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r06}
+export GIMS_HEAD=${2:-unknown}        # commit the profiles are taken on (no .git on the GPU box: pass $(git rev-parse --short HEAD))
 R=$PWD
 O=$R/gpurun_out/refresh
 mkdir -p $O
