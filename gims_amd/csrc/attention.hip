@@ -858,22 +858,18 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
 constexpr int X3W_VR = VR_LD;              // row-major V tiles of the split-bf16 kernels
 constexpr int X3_LDS_BYTES = 2 * 2 * (KB * DH + KB * X3W_VR) * 2;      // 72 KB: hi and lo planes of the double-buffered K and V tiles
 
-__global__ __launch_bounds__(256) void attention_x3_kernel(
+__device__ __forceinline__ void attention_x3_block(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
     int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
-    unsigned long long* __restrict__ stat, gims_attn_guard guard) {
-  if (guard.stat) {          // guarded launch (include/gims_hip.h): the redo of a layer whose cheap tier did not suffice -- or nothing
-    if (!attn_guard_fires(guard)) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) guard.stat[4 * guard.n_heads + 3] = 1ull;
-  }
+    unsigned long long* __restrict__ stat, const int bid) {
   extern __shared__ __attribute__((aligned(16))) uint16_t x3_lds[];
   // [plane p = hi/lo][buffer]: K tiles then V^T tiles
   auto Ks = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + (p * 2 + buf) * (KB * DH); };
   // V tiles row-major [key][d], 160-byte pitch, filled by LDS-DMA and read transposed (see attention_x3w_kernel)
   auto Vr = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + 4 * (KB * DH) + (p * 2 + buf) * (KB * X3W_VR); };
 
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
   const int group = (slot / n_qt) * 8 + xcd;
   if (group >= n_groups) return;
   const gims_attn_problem pr = problems[group / n_heads];
@@ -1056,6 +1052,21 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
       }
   }
 }
+__global__ __launch_bounds__(256) void attention_x3_kernel(
+    const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
+    const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
+    unsigned long long* __restrict__ stat, gims_attn_guard guard, int n_blocks) {
+  if (guard.stat) {          // guarded launch (include/gims_hip.h): the redo of a layer whose cheap tier did not suffice -- or nothing
+    if (!attn_guard_fires(guard)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) guard.stat[4 * guard.n_heads + 3] = 1ull;
+  }
+  for (int bid = (int)blockIdx.x; bid < n_blocks; bid += (int)gridDim.x) {      // (one tile per workgroup unless the launch is guarded: see attention_x3w_kernel)
+    attention_x3_block(qkv, ld, q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat, bid);
+    if (bid + (int)gridDim.x < n_blocks) __syncthreads();
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------- split-bf16 (x3), wide form
 // attention_x3_kernel above gives a wave 32 queries and runs two workgroups per CU: per 64-key tile a wave reads 16 KB of K fragments and 16 KB of
@@ -1066,16 +1077,12 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(
 // the staging stores and barriers per query).  Same arithmetic, same tile order and the same running-maximum rule per query block as
 // attention_x3_kernel: the outputs are bit-identical to it.
 constexpr int X3W_LDS_BYTES = X3_LDS_BYTES;
-template <int X3W_QP>      // 32-query blocks per wave: 4 (one workgroup per CU, the whole register file) or 2 (two workgroups per CU, <= 256 registers)
-__global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel(
+template <int X3W_QP>      // 32-query blocks per wave: 2 (two workgroups per CU, <= 256 registers; a QP = 4 instance with the whole register file was slower and left in round 6)
+__device__ __forceinline__ void attention_x3w_block(
     const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
     const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
     int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
-    unsigned long long* __restrict__ stat, gims_attn_guard guard) {
-  if (guard.stat) {          // guarded launch: see attention_x3_kernel
-    if (!attn_guard_fires(guard)) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) guard.stat[4 * guard.n_heads + 3] = 1ull;
-  }
+    unsigned long long* __restrict__ stat, const int bid) {
   constexpr int X3W_QW = QW * X3W_QP, X3W_QB = X3W_QW * ATT_WAVES;
   extern __shared__ __attribute__((aligned(16))) uint16_t x3_lds[];
   auto Ks = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + (p * 2 + buf) * (KB * DH); };
@@ -1083,7 +1090,7 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
   // four key rows of a transposing read land on disjoint quarters of the 64 banks at this pitch, like the 192-byte pitch of attention8_bf16_kernel)
   auto Vr = [&](int p, int buf) __attribute__((always_inline)) { return x3_lds + 4 * (KB * DH) + (p * 2 + buf) * (KB * X3W_VR); };
 
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
   const int group = (slot / n_qt) * 8 + xcd;
   if (group >= n_groups) return;
   const gims_attn_problem pr = problems[group / n_heads];
@@ -1294,6 +1301,28 @@ __global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel
             *(uint2*)(out_lo + grow * ld_split + spl_col(col)) = make_uint2(l01, l23);
           }
         }
+    }
+  }
+}
+// One query tile per workgroup, or -- GUARDED launches that would need more than one dispatch round -- a strided walk over the tiles from ONE
+// round of workgroups: a guarded launch that does not fire then costs one round of early exits instead of four (the device-side redo of
+// attention_precision='auto' sits behind every bf16 / half layer of a match_pairs batch: 18 such launches per batch).  Same arithmetic per tile.
+template <int X3W_QP, bool WALK>      // WALK: guarded launches only (the loop around the body costs the 256-register instance 48 more bytes of scratch per lane)
+__global__ __launch_bounds__(256, X3W_QP == 2 ? 2 : 1) void attention_x3w_kernel(
+    const uint16_t* __restrict__ qkv, int64_t ld, int q_col, int k_col, int v_col,
+    const gims_attn_problem* __restrict__ problems, int n_groups, int n_heads, int n_qt, float* __restrict__ out,
+    int64_t ld_out, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int64_t ld_split, float c,
+    unsigned long long* __restrict__ stat, gims_attn_guard guard, int n_blocks) {
+  if (guard.stat) {          // guarded launch: see attention_x3_kernel
+    if (!attn_guard_fires(guard)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) guard.stat[4 * guard.n_heads + 3] = 1ull;
+  }
+  if constexpr (!WALK) {
+    attention_x3w_block<X3W_QP>(qkv, ld, q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat, (int)blockIdx.x);
+  } else {
+    for (int bid = (int)blockIdx.x; bid < n_blocks; bid += (int)gridDim.x) {
+      attention_x3w_block<X3W_QP>(qkv, ld, q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat, bid);
+      if (bid + (int)gridDim.x < n_blocks) __syncthreads();      // the next tile's LDS-DMA overwrites the K / V buffers
     }
   }
 }
@@ -1732,30 +1761,33 @@ extern "C" int gims_attention_ex(const gims_attn_args* args, void* stream) {
     GIMS_CHECK_ARG((q_col % 32) == 0 && (k_col % 32) == 0 && (v_col % 32) == 0 && (ld % 64) == 0,
                    "gims_attention: GIMS_ATTN_X3 takes logical column offsets that are multiples of 32 and an SPL32 pitch (multiple of 64)");
     GIMS_LDS_ATTR((const void*)attention_x3_kernel, X3_LDS_BYTES);
-    // wide form (128 queries per wave, one workgroup per CU) when its 512-query workgroups still fill the chip; GIMS_ATTN_X3W=0/1 forces
+    // wide form (64 queries per wave in a pair that shares every K / V fragment; 256-query workgroups, two per CU) when they fill the chip, else
+    // the 32-query-per-wave kernel; GIMS_ATTN_X3W=0/2 forces.  Measured with K and V staged by LDS-DMA (32-query / wide; a 128-query-per-wave
+    // form with the whole register file, QP = 4, was third everywhere -- 912 / 730 / 867 us at 16 x 4096 keys -- and left the library in round 6):
+    // 32 x 2048 460 / 398, 40 x 1500 298 / 274, 64 x 1022 206 / 197, 8 x 700 26 / 41.
     int wide = -1;
     { const char* e = getenv("GIMS_ATTN_X3W"); if (e) wide = atoi(e); }
-    // 256-query workgroups (64 queries per wave in a pair that shares every K / V fragment; two workgroups per CU) when they fill the chip,
-    // else the 32-query-per-wave kernel.  Measured with K and V staged by LDS-DMA in all of them (32-query / QP = 2 / QP = 4):
-    // 16 x 4096 keys 912 / 730 / 867 us, 32 x 2048 460 / 398 / 504, 40 x 1500 298 / 274 / 337, 64 x 1022 206 / 197 / 236, 8 x 700 26 / 41 / 76.
     if (wide < 0) wide = 8 * cdiv(n_groups, 8) * cdiv(max_n_q, 2 * QB) >= 512 ? 2 : 0;
     count_launch(guard.stat ? GIMS_ATTN_KERNEL_X3_GUARDED : GIMS_ATTN_KERNEL_X3);
     if (wide) {
-      GIMS_LDS_ATTR((const void*)attention_x3w_kernel<4>, X3W_LDS_BYTES);
-      GIMS_LDS_ATTR((const void*)attention_x3w_kernel<2>, X3W_LDS_BYTES);
-      const int qp = wide == 2 ? 2 : 4, n_qtw = cdiv(max_n_q, qp * QB);
-      if (qp == 4)
-        hipLaunchKernelGGL(attention_x3w_kernel<4>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard);
+      GIMS_LDS_ATTR((const void*)(attention_x3w_kernel<2, false>), X3W_LDS_BYTES);
+      GIMS_LDS_ATTR((const void*)(attention_x3w_kernel<2, true>), X3W_LDS_BYTES);
+      const int n_qtw = cdiv(max_n_q, 2 * QB);
+      // guarded launches: one dispatch round of workgroups (two per CU), a strided walk over the tiles when the guard fires
+      const int n_blocks = 8 * cdiv(n_groups, 8) * n_qtw, round = 2 * (device_cus() & ~7);
+      if (guard.stat && n_blocks > round && !(getenv("GIMS_GUARD_WALK") && atoi(getenv("GIMS_GUARD_WALK")) == 0))
+        hipLaunchKernelGGL((attention_x3w_kernel<2, true>), dim3(round), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard, n_blocks);
       else
-        hipLaunchKernelGGL(attention_x3w_kernel<2>, dim3(8 * cdiv(n_groups, 8) * n_qtw), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
-                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard);
+        hipLaunchKernelGGL((attention_x3w_kernel<2, false>), dim3(n_blocks), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
+                           q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard, n_blocks);
       GIMS_LAUNCH_CHECK();
       return GIMS_OK;
     }
     const int n_qt = cdiv(max_n_q, QB);
-    hipLaunchKernelGGL(attention_x3_kernel, dim3(8 * cdiv(n_groups, 8) * n_qt), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, qkv, ld,
-                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard);
+    const int n_blocks = 8 * cdiv(n_groups, 8) * n_qt, round = 2 * (device_cus() & ~7);
+    hipLaunchKernelGGL(attention_x3_kernel, dim3(guard.stat && n_blocks > round ? round : n_blocks), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, qkv, ld,
+                       q_col, k_col, v_col, problems, n_groups, n_heads, n_qt, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard, n_blocks);
     GIMS_LAUNCH_CHECK();
     return GIMS_OK;
   }

@@ -306,8 +306,10 @@ struct X3P {
 };
 
 // HI_ONLY: 1 = GIMS_LINEAR_HI_ONLY (one MFMA pass, hi planes), 4 = GIMS_LINEAR_CONV3 (all three passes; the A rows are gathered from the 3x3 neighbourhood of an NHWC activation)
-template <int TM, int TN, int WM, int WN, int S, int HI_ONLY = 0>
-__global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_args p) {
+// The body of one output tile (`bid` = the tile's slot in the XCD-aware order).  linear_x3p_kernel runs it once per workgroup; the
+// persistent form below walks a strided list of tiles.
+template <int TM, int TN, int WM, int WN, int S, int HI_ONLY>
+__device__ __forceinline__ void linear_x3p_tile(const gims_linear_args& p, const int bid) {
   using T = X3P<TM, TN, WM, WN, S, HI_ONLY == 1>;
   constexpr int BK = T::BK;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -318,10 +320,9 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   // its own L2.  All column tiles of one row panel of A are therefore given consecutive slots on ONE XCD, so the
   // panel is fetched from HBM once instead of once per column tile.
   const int nt_n = (p.n + TN - 1) / TN;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
   const int m0 = ((slot / nt_n) * 8 + xcd) * TM, n0 = (slot % nt_n) * TN;
   if (m0 >= p.m) return;
-  if (p.guard.stat && !attn_guard_fires(p.guard)) return;      // guarded launch (uniform for the grid): nothing to redo
   // probe (tools/gemm_probe.py): flag 0x1000 starts the workgroups of the odd slots conv_reserved x 3.4 us late, so that the
   // HBM-bound epilogues of one half of the CUs fall into the L2-bound K loops of the other half
   if ((p.flags & 0x1000) && (slot & 1))
@@ -587,6 +588,24 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_ar
   }
 }
 
+template <int TM, int TN, int WM, int WN, int S, int HI_ONLY = 0>
+__global__ __launch_bounds__(64 * WM * WN) void linear_x3p_kernel(gims_linear_args p) {
+  if (p.guard.stat && !attn_guard_fires(p.guard)) return;      // guarded launch (uniform for the grid): nothing to redo
+  linear_x3p_tile<TM, TN, WM, WN, S, HI_ONLY>(p, (int)blockIdx.x);
+}
+// GUARDED launches of the big tile (the device-side redo of attention_precision='auto', include/gims_hip.h gims_attn_guard): a launch that does
+// not fire used to dispatch every workgroup of the full grid -- 1536 workgroups with 128 KB of LDS each, six rounds per CU, 7 us -- just to
+// have them all return.  Here ONE round of workgroups is dispatched (gridDim.x <= CUs); a launch that fires walks its tiles with that stride
+// (same tile -> XCD mapping: the stride is a multiple of 8; same arithmetic per tile: bit-identical to the unguarded launch).
+template <int TM, int TN, int WM, int WN, int S, int HI_ONLY = 0>
+__global__ __launch_bounds__(64 * WM * WN) void linear_x3p_guarded_kernel(gims_linear_args p, int n_tiles) {
+  if (p.guard.stat && !attn_guard_fires(p.guard)) return;
+  for (int bid = (int)blockIdx.x; bid < n_tiles; bid += (int)gridDim.x) {
+    linear_x3p_tile<TM, TN, WM, WN, S, HI_ONLY>(p, bid);
+    __syncthreads();                                            // the next tile's LDS-DMA overwrites the ring / the epilogue slices
+  }
+}
+
 __global__ void put_linear_args_kernel(gims_linear_args a, gims_linear_args* __restrict__ dst) { *dst = a; }
 
 // ------------------------------------------------------------------------------------------ split kernel
@@ -723,7 +742,10 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       GIMS_LDS_ATTR((const void*)linear_x3p_kernel<256, 256, 4, 2, 2>, (int)lds);
       const dim3 g(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256));
       if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 4, 1>), g, dim3(512), lds_h, s, *a);
-      else hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), g, dim3(512), lds, s, *a);
+      else if (a->guard.stat && (int)g.x > device_cus() && !(getenv("GIMS_GUARD_WALK") && atoi(getenv("GIMS_GUARD_WALK")) == 0)) {      // guarded: one round of workgroups (see linear_x3p_guarded_kernel)
+        GIMS_LDS_ATTR((const void*)linear_x3p_guarded_kernel<256, 256, 4, 2, 2>, (int)lds);
+        hipLaunchKernelGGL((linear_x3p_guarded_kernel<256, 256, 4, 2, 2>), dim3(device_cus() & ~7), dim3(512), lds, s, *a, (int)g.x);
+      } else hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), g, dim3(512), lds, s, *a);
     } else if (a->flags & GIMS_LINEAR_CONV3) {
       using T32 = X3P<128, 32, 4, 1, 2>;
       using T64 = X3P<128, 64, 2, 2, 2>;

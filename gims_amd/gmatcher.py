@@ -116,7 +116,11 @@ class GMatcher(nn.Module):
         'attention_f16_range': 3.0e4,
         'attention_monitor_period': 1,
         'train_precision': 'bf16x6',      # products of the training step's forward (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
-        'train_backward_precision': 'bf16x3',      # products of its reverse pass (linear in its operands: no accuracy lost, trainstep.py)
+        'train_backward_precision': 'bf16x3',      # products of its reverse pass: 'bf16x3' (default) or 'f32'.  The pass is linear in its operands, but the
+                                                   # attention scores it recomputes carry 16 mantissa bits against the forward's exact-f32 lse: the error of
+                                                   # the attention gradients grows with the logit magnitude, about 2.2e-6 |S| of the largest entry (6e-5 at
+                                                   # |S| = 33, 6e-4 at 268: tests/test_train_kernels_gpu.py::test_train_attention_reverse_precision_at_large_logits);
+                                                   # 'f32' keeps 2e-5 at any magnitude at 2.7 x the attention reverse time -- the setting for sharply peaked trained attention
         'verbose': False,               # the reference prints '>> ...' timing lines; off by default here
         # fold the attention 'merge' conv into the first MLP conv at load time:
         #   W0 [x ; Wm o + bm] + b0  ==  W0x x + (W0m Wm) o + (W0m bm + b0)        (gmatcher.py:114,125)

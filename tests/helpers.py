@@ -9,6 +9,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def make_rare_pair(n, seed, n_hot, gain):
+    """The input of the raree2e_* fixtures (tools/gen_golden_rare.py): synth.make_pair(n, seed) in which `n_hot` keypoints of image 0 and their
+    partners in image 1 carry descriptors scaled by `gain` -- a few sharply peaked attention rows inside otherwise diffuse layers."""
+    from gims_amd import synth
+    pair = synth.make_pair(n, seed)
+    rng = np.random.default_rng(seed + 7)
+    hot0 = np.sort(rng.choice(n, n_hot, replace=False))
+    hot1 = pair["gt_perm"][hot0]
+    pair["descriptors0"] = pair["descriptors0"].copy()
+    pair["descriptors1"] = pair["descriptors1"].copy()
+    pair["descriptors0"][0][:, hot0] *= np.float32(gain)          # (1, D, N) channel-major, like the reference's callers pass them
+    pair["descriptors1"][0][:, hot1] *= np.float32(gain)
+    return pair, hot0, hot1
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     return {k: z[k] for k in z.files}

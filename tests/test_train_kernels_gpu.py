@@ -227,6 +227,39 @@ def test_train_attention_forward_backward_vs_float64(n0, n1, cross, splits, reve
     assert torch.equal(dqkv, hip.train_attention_backward(qkv, o, lse, do, problems, heads, precision=prec))
 
 
+@pytest.mark.parametrize("gain", [6.0, 24.0, 48.0])
+def test_train_attention_reverse_precision_at_large_logits(gain):
+    """the default reverse pass ('bf16x3') recomputes S from split-bf16 operand pairs (16 mantissa bits each) while lse comes from the
+    exact-f32 forward, so P = exp(S' - lse) carries a relative error of about 2^-16 sum |q_i k_i|, which grows with the logit magnitude -- harmless
+    on the fixtures (queries scaled up to 6 x), not bounded by them.  This test walks the magnitude up (|S| to about 25, 100 and 200 natural units)
+    and pins what the two reverse precisions deliver against float64 autograd: exact-f32 products stay at 3e-5 of the largest gradient entry
+    whatever the magnitude (measured 1.5e-6 / 1.3e-5 / 1.8e-5); the three-pass products deliver about 2.2e-6 |S| (5.8e-5 / 3.0e-4 / 5.8e-4: bounds
+    below = twice the measured values) -- LINEAR in the logit magnitude, as the operand precision predicts.  train_backward_precision='f32' is the setting for sharply peaked trained attention."""
+    heads, d, n0, n1 = 4, 256, 300, 517
+    rows = n0 + n1
+    qkv = _rand(rows, 3 * d, seed=4242, scale=1.0)
+    qkv[:, :d] *= gain
+    do = _rand(rows, d, seed=7)
+    problems = [(0, n0, n0, n1), (n0, n1, 0, n0)]
+    o, lse = hip.train_attention_forward(qkv, problems, heads)
+    ro, rlse, rg = _attention_reference(qkv, do, problems, heads)
+    s_mag = float(rlse.abs().max())
+    # (the forward is exact-f32 arithmetic: its error against float64 is the f32 rounding of the scores themselves, a few ulp of |S| in the exponent)
+    assert float((o.double() - ro).abs().max()) < max(3e-6, 2.5e-7 * s_mag) * float(ro.abs().max())
+    errs = {}
+    for prec, label in ((hip.PREC_F32, "f32"), (hip.PREC_BF16X3, "bf16x3")):
+        dqkv = hip.train_attention_backward(qkv, o, lse, do, problems, heads, precision=prec)
+        assert torch.isfinite(dqkv).all()
+        errs[label] = float((dqkv.double() - rg).abs().max()) / float(rg.abs().max())
+    print(f"gain {gain}: largest |lse| {s_mag:.1f}; reverse-pass error / largest gradient entry: f32 {errs['f32']:.2e}, bf16x3 {errs['bf16x3']:.2e}")
+    assert errs["f32"] < 3e-5
+    assert errs["bf16x3"] < BF16X3_REVERSE_BOUND[gain]
+
+
+# measured on MI355X (round 6): 5.8e-5 / 3.0e-4 / 5.8e-4 at |S| = 33 / 134 / 268 -- about 2.2e-6 |S|; bounds = twice that
+BF16X3_REVERSE_BOUND = {6.0: 1.2e-4, 24.0: 6e-4, 48.0: 1.2e-3}
+
+
 def test_train_attention_more_problems_than_one_launch_takes():
     """34 problems (17 pairs of small images, cross): the problem table travels in the kernel arguments 32 at a time, so this call is two rounds
     of launches sharing one workspace."""

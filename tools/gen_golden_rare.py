@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Reference golden for RARE peaked attention rows (build container only; imports the reference through tools/gen_golden.py).
+
+attention_precision='auto' decides a layer's operand tier from the layer's mean softmax row maximum and the FRACTION of rows above 1/2; launches of
+the 8-wave bf16 kernel measure both on a 32-query sample per (image, head).  A handful of keypoints whose rows are sharply peaked inside an
+otherwise diffuse layer stay under both thresholds (and mostly outside the sample): they run on plain bf16 operands.  This fixture pins what
+that costs: a 2 x 1024 pair in which `n_hot` keypoints of image 0 (and their partners in image 1) carry descriptors scaled by `gain` -- their
+query rows then have logits `gain` times larger -- run through the UNMODIFIED reference.  The fixture stores the reference's outputs, the ids of
+the hot keypoints, and the reference's own per-layer row maxima for them (so the test can show they were peaked).
+
+    python tools/gen_golden_rare.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen_golden as G  # noqa: E402  (sets up the reference import path and the stubs)
+from gims_amd import synth  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))
+from tests.helpers import make_rare_pair  # noqa: E402  (the pair construction is shared with the GPU test)
+
+
+def main():
+    sd = synth.make_state_dict(123)
+    for n, seed, n_hot, gain, iters, thr in ((1024, 1050, 2, 6.0, 100, 0.2), (1024, 1051, 1, 10.0, 20, 0.02)):
+        model = G.ref_model(sd, {"sinkhorn_iterations": iters, "match_threshold": thr})
+        pair, hot0, hot1 = make_rare_pair(n, seed, n_hot, gain)
+        rowmax = []                                               # per attention call: the largest softmax probability of every query row, per head
+        orig = G.RG.attention
+
+        def spy(q, k, v):
+            out, prob = orig(q, k, v)
+            rowmax.append(prob.max(dim=-1).values[0].numpy().copy())      # (heads, n_q)
+            return out, prob
+        G.RG.attention = spy
+        try:
+            r = G.run_reference(model, pair, 15, 2, 7)
+        finally:
+            G.RG.attention = orig
+        arrs = {"out/" + k: v for k, v in r.items()}
+        arrs["meta"] = np.asarray([n, seed, 15, 2, 7, iters], dtype=np.int64)
+        arrs["match_threshold"] = np.float64(thr)
+        arrs["hot0"], arrs["hot1"], arrs["gain"] = hot0, hot1, np.float64(gain)
+        # calls alternate image 0 / image 1 per layer (gmatcher.py:139-141): 36 calls
+        k0 = r["kept0"]
+        pos0 = np.searchsorted(k0, hot0)
+        assert (k0[pos0] == hot0).all(), "a hot keypoint was dropped by the graph build"
+        rm0 = np.stack([rowmax[2 * l] for l in range(18)])        # (18, heads, n0)
+        arrs["hot_rowmax0"] = rm0[:, :, pos0]                     # (18, heads, n_hot): the hot rows' maxima
+        arrs["layer_mean_rowmax0"] = rm0.mean(axis=2)             # (18, heads)
+        arrs["layer_tail0"] = (rm0 > 0.5).mean(axis=2)
+        name = f"raree2e_n{n}_s{seed}_h{n_hot}g{int(gain)}_r15p2m7_i{iters}"
+        G.save(name, **arrs)
+        print(name, "hot rows' largest probability per layer (max over heads):", np.round(arrs["hot_rowmax0"].max(axis=1).max(axis=1), 3))
+        print("   layer mean row maximum (max over heads):", np.round(arrs["layer_mean_rowmax0"].max(axis=1), 4))
+        print("   layer tail fraction (max over heads):", np.round(arrs["layer_tail0"].max(axis=1), 4))
+        m0 = r["matches0"]
+        print("   matches of the hot keypoints:", m0[pos0], "expected", np.searchsorted(r["kept1"], hot1), "scores", r["matching_scores0"][pos0])
+
+
+if __name__ == "__main__":
+    main()
