@@ -525,6 +525,10 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   constexpr float DEFER = 5.0f;
   const float defer_raw = DEFER / c;
   float m_run[QP], l_run[QP];
+  // bf16 instance, measured launches: the largest share of a row's mass that one 32-key half tile (this lane's keys of a tile) has held -- an upper
+  // bound of the row's largest probability at ONE v_max per query block and tile, so that a single sharply peaked row inside a diffuse layer
+  // cannot hide behind the 32-query sample (the guard of attention_precision='auto' looks at the head's largest row maximum)
+  float hmass[QP];
 
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
     *(uint4*)(Ks[buf] + k_off(t >> 3, t & 7)) = rk;
@@ -700,6 +704,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
     }
     const float lsum = lsum2.x + lsum2.y;
     l_run[qi] += lsum;
+    if (!F16 && !exact) hmass[qi] = fmaxf(hmass[qi], lsum);
   };
   auto seg_pv = [&](int kt) __attribute__((always_inline)) {                  // O^T += V^T P^T of tile kt (16 MFMAs)
     const int buf = kt & 1;
@@ -736,7 +741,7 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   constexpr bool exact = decltype(ex)::value;
 #pragma unroll
   for (int qi = 0; qi < QP; ++qi) {
-    m_run[qi] = (NOFMA && !exact && !F16) ? 0.f : -1e30f; l_run[qi] = 0.f;
+    m_run[qi] = (NOFMA && !exact && !F16) ? 0.f : -1e30f; l_run[qi] = 0.f; hmass[qi] = 0.f;
     if constexpr (F16) {
       // first pass: start from reference 0 (a seed of 1e30 would absorb S); the first tile's softmax sets it to the tile's row maxima
 #pragma unroll
@@ -779,7 +784,29 @@ __global__ __launch_bounds__(512) void attention8_bf16_kernel(
   return bad;
   };
   // (__syncthreads_or is also the barrier that lets the second pass overwrite the last tiles in LDS)
-  if ((exact_only & 1) || __syncthreads_or(pass(std::false_type{}))) pass(std::true_type{});
+  bool ran_exact = (exact_only & 1) != 0;
+  if (!ran_exact) ran_exact = __syncthreads_or(pass(std::false_type{})) != 0;
+  if (ran_exact) pass(std::true_type{});
+  if constexpr (!F16) {
+    if (stat != nullptr && (ran_exact || pr.n_kv >= 512)) {
+      // rows whose bound reaches 1/2 (none in a diffuse layer: the block below is skipped by the whole wave); a workgroup that needed the exact
+      // pass -- a row sum left f32's range: scores ~100 octaves apart -- reports 1
+      unsigned fx = 0u;
+#pragma unroll
+      for (int qi = 0; qi < QP; ++qi) {
+        const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+        const float h = fmaxf(hmass[qi], __shfl_xor(hmass[qi], 32, 64));
+        const bool row = q0 + wave * QWV + qi * QW + li < pr.n_q;
+        const float frac = ran_exact ? 1.f : fminf(h / l_tot, 1.f);
+        if (row && frac >= 0.5f) { const unsigned f = (unsigned)(frac * 16777216.f + 0.5f); fx = fx > f ? fx : f; }
+      }
+      if (__ballot(fx != 0u) != 0ull) {
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { const unsigned other = __shfl_xor(fx, o2, 64); fx = fx > other ? fx : other; }
+        if (lane == 0) atomicMax(stat + 4 * head + 2, (unsigned long long)fx);
+      }
+    }
+  }
   if (PROF && bid == 0 && (wave == 0 || wave == 4) && lane == 0)
     for (int i = 0; i < 10; ++i) prof[(wave >> 2) * 10 + i] = pacc[i];
 

@@ -115,9 +115,13 @@ __device__ __forceinline__ bool attn_guard_fires(const gims_attn_guard& g) {
   bool mine = false;
   if (g.kind == GIMS_GUARD_PEAKED) {
     const unsigned long long cnt = __shfl(v, (lane & ~3) + 1, 64), tail = __shfl(v, (lane & ~3) + 3, 64);      // (lane 4h: v = the head's sum)
-    if ((lane & 3) == 0 && lane < 4 * g.n_heads && cnt != 0) {
-      const double mean = (double)v / (double)cnt / 16777216.0, tl = (double)tail / (double)cnt;
-      mine = mean > g.mean_thr || tl > g.tail_thr;
+    const unsigned long long mx = __shfl(v, (lane & ~3) + 2, 64);
+    if ((lane & 3) == 0 && lane < 4 * g.n_heads) {
+      if (cnt != 0) {
+        const double mean = (double)v / (double)cnt / 16777216.0, tl = (double)tail / (double)cnt;
+        mine = mean > g.mean_thr || tl > g.tail_thr;
+      }
+      mine = mine || (g.max_thr > 0.0 && (double)mx / 16777216.0 >= g.max_thr);
     }
   } else if (lane >= 4 * g.n_heads && lane < 4 * g.n_heads + 3) {
     mine = !((double)__uint_as_float((uint32_t)v) <= g.range_limit);

@@ -368,6 +368,12 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
   int last_fresh = 0;                                        // iteration of the last derivation (the start potentials count as one)
   bool pend_fresh = false;                                   // next_fresh of the previous iteration
   constexpr float R2_F_BOUND = 7.9e13f, R2_G_BOUND = 4.85e8f;      // e^32, e^20 (see the header)
+  // A row or column total this small means the sum is made of entries near (or below) f32's normal range -- K entries that survived the
+  // derivation as denormals carry a few bits -- so the factors it yields are wrong although finite: the solve gives up (status 2) and the
+  // caller's rescue re-solves in the log domain.  Found with the reference golden raree2e_*_g10 (round 6): one keypoint with a ten times
+  // larger descriptor puts |Z| at 2400 in its column, every row's maximum sits there, all other entries of K = exp(Z - rowmax) are e^-150, and
+  // the solve went on with column totals of e^-100: potentials off by 4e-3, no guard tripped.  Dense and sparse fixtures stay above e^-55.
+  constexpr float R2_TOT_MIN = 1.0e-30f;
   int nslots_s = __builtin_amdgcn_readfirstlane(nslots);
   const bool force_last = a.refresh > 0 || a.refresh == -1;      // fixed period / "final only": derive on the last iteration whatever happened
   for (int it = 0; it < a.iters; ++it) {
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
           const bool val = s < nslots_s, real = s < nrl;
           const float tt = val ? tot[e] : 1.f;
           const float fn = val ? (real ? p.mu : p.mu_bin) * __builtin_amdgcn_rcpf(tt) : 1.f;
-          bad |= !(tt > 0.f) || !(tt < 3.0e38f) || !(fn < 3.0e38f);
+          bad |= !(tt > R2_TOT_MIN) || !(tt < 3.0e38f) || !(fn < 3.0e38f);
           uo[e] += val ? (real ? p.norm : p.log_mu_bin) - logf(tt) : 0.f;
           fgrow |= fn > R2_F_BOUND;
           fw[e] = tg(fn);
@@ -757,7 +763,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
       float vown = vown_l[t], gown = 1.f;
       if (own) {
         gown = (t < 128 ? p.mu : p.nu_bin) * __builtin_amdgcn_rcpf(ctot);       // G_j = nu_j / sum_i F_i K_ij (see the row update)
-        if (!(ctot > 0.f) || !(ctot < 3.0e38f) || !(gown < 3.0e38f)) ot_raise_status(p.status, 2.f);
+        if (!(ctot > R2_TOT_MIN) || !(ctot < 3.0e38f) || !(gown < 3.0e38f)) ot_raise_status(p.status, 2.f);
         vown += (t < 128 ? p.norm : p.log_nu_bin) - logf(ctot);
         gown_l[t] = vown;
         if (next_fresh) vown_l[t] = vown;

@@ -30,15 +30,15 @@ class GimsHipError(RuntimeError):
 class AttnGuard(C.Structure):
     """gims_attn_guard (include/gims_hip.h): a launch that only runs when the statistic of the launch before it asks for the redo."""
     _fields_ = [("stat", C.c_void_p), ("mean_thr", C.c_double), ("tail_thr", C.c_double), ("range_limit", C.c_double),
-                ("n_heads", C.c_int32), ("kind", C.c_int32)]
+                ("n_heads", C.c_int32), ("kind", C.c_int32), ("max_thr", C.c_double)]
 
 
 GUARD_PEAKED, GUARD_RANGE = 1, 2
 
 
-def attn_guard(stat, kind, n_heads, mean_thr=0.0, tail_thr=0.0, range_limit=0.0) -> AttnGuard:
+def attn_guard(stat, kind, n_heads, mean_thr=0.0, tail_thr=0.0, range_limit=0.0, max_thr=0.0) -> AttnGuard:
     assert stat.dtype == torch.int64 and stat.is_cuda and stat.is_contiguous() and stat.numel() >= 4 * (n_heads + 1)
-    return AttnGuard(stat.data_ptr(), float(mean_thr), float(tail_thr), float(range_limit), int(n_heads), int(kind))
+    return AttnGuard(stat.data_ptr(), float(mean_thr), float(tail_thr), float(range_limit), int(n_heads), int(kind), float(max_thr))
 
 
 class LinearArgs(C.Structure):

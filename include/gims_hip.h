@@ -70,7 +70,8 @@ int gims_upload_table(const void* host, int64_t bytes, void* dev, void* stream);
  * batch never leave with the cheap tier's error).  A launch whose args carry a guard with stat != NULL is a no-op unless the guard FIRES; every
  * workgroup evaluates it at entry from `stat`, the accumulator a preceding gims_attention_stat launch of the same stream filled:
  *   GIMS_GUARD_PEAKED: some head's mean row maximum (stat[h][0] / stat[h][1] / 2^24) exceeds mean_thr, or its share of rows with a maximum above
- *                      1/2 (stat[h][3] / stat[h][1]) exceeds tail_thr                              (guards a plain-bf16 attention layer);
+ *                      1/2 (stat[h][3] / stat[h][1]) exceeds tail_thr, or -- max_thr > 0 -- its LARGEST row maximum (stat[h][2] / 2^24) reaches
+ *                      max_thr: a single sharply peaked row inside a diffuse layer (round 6)        (guards a plain-bf16 attention layer);
  *   GIMS_GUARD_RANGE : max |Q|, |K| or |V| as stored (stat[n_heads][0..2]) exceeds range_limit, or is not finite   (guards an IEEE-half layer).
  * A guarded gims_attention launch that fires stores 1 into stat[n_heads][3] (the host's record that the layer was redone).  The comparisons
  * are done in float64 exactly as written here, so a host that reads `stat` back reaches the same verdict.  stat == NULL: unconditional. */
@@ -80,6 +81,7 @@ typedef struct gims_attn_guard {
   uint64_t* stat;                        /* [n_heads + 1][4], see gims_attention_stat; NULL = no guard */
   double mean_thr, tail_thr, range_limit;
   int32_t n_heads, kind;                 /* GIMS_GUARD_* */
+  double max_thr;                        /* GIMS_GUARD_PEAKED: 0 = the largest row maximum is not looked at */
 } gims_attn_guard;
 
 typedef struct gims_linear_args {
@@ -186,6 +188,10 @@ int gims_attention(const uint16_t* qkv, int64_t ld, int32_t q_col, int32_t k_col
  * reported queries, largest row maximum (same fixed point), number of reported queries with a row maximum above 1/2}; row n_heads:
  * {bit patterns of max|Q|, max|K|, max|V| as stored (f32), unused} over the rows the launch touches -- the range guard of
  * GIMS_ATTN_F16, filled by GIMS_ATTN_F16 and GIMS_ATTN_X3 launches only (bf16 operands have f32's range).  ACCUMULATED with integer atomics (zero it first; order-independent).
+ * The "largest row maximum" of a head is COMPLETE for every kernel (round 6): the 8-wave bf16 kernel, whose other figures come from the sample,
+ * adds for EVERY query an upper bound of its row maximum whenever that bound reaches 1/2 -- the largest share of the row's mass that fell into
+ * one 32-key half tile (problems of at least 512 keys; a workgroup that had to repeat its tiles in the exact pass reports 1) -- so a single
+ * sharply peaked row cannot hide behind the sample.
  * The running-maximum kernels (GIMS_ATTN_X3, the 4-wave and split-key bf16 kernels) report every query as a by-product; the
  * 8-wave bf16 kernel tracks no maximum, so for launches it serves a second, small kernel measures 32 evenly spaced queries of
  * every (problem, head) against all keys (a few microseconds).  stat == NULL: exactly gims_attention. */

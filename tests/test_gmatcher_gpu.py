@@ -267,7 +267,14 @@ def test_rare_peaked_rows_inside_diffuse_layers_vs_reference_golden(synth_sd, mo
     sharply peaked (descriptors scaled by 6 / 10: the reference's own row maxima for them reach 0.8 - 1.0, stored in the fixture) inside layers
     whose mean row maximum stays near 0.01 and whose tail fraction is 1e-3 -- far under the 0.08 / 0.02 thresholds, and one row in a thousand is
     mostly outside the 32-query sample of the 8-wave kernel too.  Those rows run on plain bf16 operands.  The fixture is the unmodified reference on
-    the same pair (tools/gen_golden_rare.py): EVERY match index equal, EVERY score within 1e-4 -- the hot keypoints' included, asserted separately."""
+    the same pair (tools/gen_golden_rare.py): EVERY match index equal, EVERY score within 1e-4 -- the hot keypoints' included, asserted separately.
+    Round 6 answers these rows with the guard's LARGEST-ROW-MAXIMUM criterion (attention_auto_rowmax: the layer is redone on the device for this
+    batch, not moved up): gain 6 holds the bar without it (5e-5), gain 8 and 10 need it (plain bf16: 6e-4 on neighbouring rows).
+    The gain-10 fixture is also a RANGE stress: both partners' descriptors are ten times larger, the score matrix reaches |Z| = 2429 in their
+    column, every row's maximum sits there, and the potentials end at |u| = 2308 -- one f32 ulp of which is 2.4e-4, so two correct f32 evaluations
+    of that solve differ by more than the 1e-4 bar (our streamed log-domain solve, the arithmetic closest to the reference's, is 1.33e-4 from the
+    golden).  It found a real defect: the on-chip Sinkhorn went on with column totals of e^-100 (denormal survivors of K) and was 4.4e-4 off without
+    tripping a guard; it now gives up on totals below 1e-30 and the rescue re-solves.  Bar for that fixture: 2.5e-4, matched rows."""
     g = load_golden(name)
     n, seed, rad, pct, ms, iters = [int(x) for x in g["meta"]]
     thr = float(g["match_threshold"])
@@ -289,14 +296,18 @@ def test_rare_peaked_rows_inside_diffuse_layers_vs_reference_golden(synth_sd, mo
         out = m.match_pairs([data] + [pair_to_data(synth.make_pair(n, 1000 + i), rad, pct, ms, device="cuda") for i in range(7)])[0]
         assert hip_counts.attention_launch_counts()["wave8"] >= 1
     torch.cuda.synchronize()
-    stats = _compare(out, data, g, thr)
+    tol = 2.5e-4 if float(g["gain"]) >= 10 else 1e-4
+    stats = _compare(out, data, g, thr, score_tol=tol)
     k0 = data["kept_kpts0_indices"][0]
     k0 = k0.cpu().numpy() if torch.is_tensor(k0) else np.asarray(k0)
     pos = np.searchsorted(k0, hot0)
-    err_hot = np.abs(out["matching_scores0"][0].cpu().numpy()[pos] - g["out/matching_scores0"][pos]).max()
+    matched = g["out/matches0"][pos] >= 0
+    err_hot = np.abs(out["matching_scores0"][0].cpu().numpy()[pos] - g["out/matching_scores0"][pos])[matched].max() if matched.any() else 0.0
     rep = m.attention_report()
-    print(name, api, stats, "hot rows' score error", float(err_hot), "tiers", rep["modes"], "redone", rep["redone"].tolist())
-    assert err_hot < 1e-4
+    print(name, api, stats, "hot rows' score error", float(err_hot), "tiers", rep["modes"], "redone", rep["redone"].tolist(), "rare", rep["rare"].tolist())
+    assert err_hot < tol
+    if float(g["gain"]) >= 8:
+        assert rep["rare"].sum() > 0 and rep["modes"].count("bf16") >= 15          # answered per batch: the layers were not moved up for one outlier
 
 
 @pytest.mark.parametrize("api", ["forward", "match_pairs"])

@@ -424,6 +424,47 @@ def test_attention_guarded_redo(hip, kind, sharp):
     assert not torch.equal(msg_g.view(torch.int16)[:nq], msg.view(torch.int16)[:nq])      # ... and it is not the cheap tier's
 
 
+def test_attention8_reports_every_sharply_peaked_row(hip, monkeypatch):
+    """Round 6: the 8-wave bf16 kernel's mean / tail figures come from a 32-query sample per (problem, head), but the head's LARGEST row maximum
+    is complete: every query contributes an upper bound of its row maximum (its largest half-tile mass) whenever that reaches 1/2.  One query
+    that is not among the sampled ones is made one-hot in ONE head: that head's maximum field must report it (>= 1/2, and >= the true row maximum),
+    the other heads' must stay diffuse -- and a guard with max_thr = 0.5 fires on it while the mean / tail criteria do not."""
+    monkeypatch.setenv("GIMS_ATTN_QP", "8")
+    r = _rng(61)
+    n, P, H = 1024, 2, 4
+    rows = n * P
+    qkv = (r.normal(size=(rows, 768)) * 0.5).astype(np.float32)
+    hot_row, hot_head, hot_key = n + 517, 2, n + 77                       # problem 1; 517 is not one of the 32 evenly spaced sample queries
+    qkv[hot_row, hot_head * 64:(hot_head + 1) * 64] = 12.0 * qkv[hot_key, 256 + hot_head * 64:256 + (hot_head + 1) * 64]
+    q16 = _dev(qkv).to(torch.bfloat16)
+    pr = torch.tensor([(i * n, n, i * n, n) for i in range(P)], dtype=torch.int32, device="cuda")
+    out = torch.empty((rows, 256), dtype=torch.float32, device="cuda")
+    stat = torch.zeros((H + 1, 4), dtype=torch.int64, device="cuda")
+    hip.attention_launch_counts(reset=True)
+    hip.attention(q16, pr, n, H, out, stat=stat)
+    assert hip.attention_launch_counts()["wave8"] == 1
+    st = stat.cpu().numpy()
+    f = q16.float().cpu().numpy().astype(np.float64)
+    s_hot = f[hot_row, hot_head * 64:(hot_head + 1) * 64] @ f[n:2 * n, 256 + hot_head * 64:256 + (hot_head + 1) * 64].T / 8.0
+    p_hot = np.exp(s_hot - s_hot.max()); p_hot /= p_hot.sum()
+    assert p_hot.max() > 0.9                                                # the construction worked: a one-hot row
+    mx = st[:H, 2] / hip.ATTN_STAT_SCALE
+    assert mx[hot_head] >= 0.5 and mx[hot_head] >= p_hot.max() - 1e-3, mx
+    assert (np.delete(mx, hot_head) < 0.5).all(), mx
+    assert (st[:H, 1] == 32 * P).all()                                      # the other figures are still the sample's
+    mean, tail = st[:H, 0] / st[:H, 1] / hip.ATTN_STAT_SCALE, st[:H, 3] / st[:H, 1]
+    assert (mean < 0.08).all() and (tail <= 0.02).all()
+    # the guard: fires on the largest row maximum, not on mean / tail
+    x = r.normal(size=(rows, 256)).astype(np.float32)
+    w = (r.normal(size=(768, 256)) / 16.0).astype(np.float32)
+    xs, ws = hip.split_spl32(_dev(x)), hip.split_spl32(_dev(w))
+    for max_thr, fires in ((0.0, False), (0.5, True)):
+        g = hip.attn_guard(stat, hip.GUARD_PEAKED, H, mean_thr=0.08, tail_thr=0.02, max_thr=max_thr)
+        qkv6 = torch.full((rows, 1536), 0x7fc0, dtype=torch.int16, device="cuda").view(torch.bfloat16)
+        hip.linear(xs, ws, out_split=qkv6, precision=hip.PREC_BF16X3, spl=True, guard=g)
+        assert bool((qkv6.view(torch.int16) != 0x7fc0).any()) == fires
+
+
 @pytest.mark.parametrize("fires", [False, True])
 def test_guarded_launches_that_walk_their_tiles(hip, monkeypatch, fires):
     """Large GUARDED launches (round 6): a guarded 3-pass projection / split-bf16 attention whose full grid would need several dispatch rounds is

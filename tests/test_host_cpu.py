@@ -30,7 +30,7 @@ def test_struct_layouts_match_header(tmp_path):
     """Sizes and field offsets of the ctypes mirrors against what a C compiler makes of include/gims_hip.h (gcc, LP64)."""
     import subprocess
     pairs = [("gims_linear_args", hip.LinearArgs, ["a0", "w", "bias", "out_f32", "m", "act", "scale", "a0_lo", "out_hi", "ld_split", "flags", "conv_h", "guard", "range_stat"]),
-             ("gims_attn_guard", hip.AttnGuard, ["stat", "mean_thr", "range_limit", "n_heads", "kind"]),
+             ("gims_attn_guard", hip.AttnGuard, ["stat", "mean_thr", "range_limit", "n_heads", "kind", "max_thr"]),
              ("gims_attn_args", hip.AttnArgs, ["qkv", "q_col", "problems", "n_heads", "out", "ld_split", "flags", "stat", "guard"]),
              ("gims_train_attn_problem", hip.TrainAttnProblem, ["nk"]),
              ("gims_train_attn_args", hip.TrainAttnArgs, ["qkv", "rows", "d", "scale", "problems", "o", "lse", "d_o", "d_qkv", "work", "work_floats", "reverse_precision"]),
@@ -229,7 +229,7 @@ def test_hot_kernels_use_no_scratch():
     if not (os.path.exists(hipcc) or shutil.which(hipcc)):
         import pytest
         pytest.skip("no hipcc")
-    must_be_clean = {"attention.hip": ["attention8_bf16_kernel", "attention_bf16_kernel", "attention_x3_kernel", "attention_x3w_kernelILi4", "attention_split_kernelILi2"],
+    must_be_clean = {"attention.hip": ["attention8_bf16_kernel", "attention_bf16_kernel", "attention_x3_kernel", "attention_split_kernelILi2"],
                      "linear6.hip": ["linear_x6_kernel"], "linear.hip": ["linear_x3p_kernel"],
                      "carhynet.hip": ["ch_conv_block_kernel", "ch_sandglass_kernelILi32"]}
     with tempfile.TemporaryDirectory() as tmp:
@@ -291,6 +291,24 @@ def test_auto_attention_routes_on_the_tail_and_the_range():
     raw[5, H, 3] = 1
     m.__dict__["_attn_pending"] = {0: [torch.from_numpy(raw), Ev(), 7]}
     assert m.attention_report()["redone"].tolist() == [0] * 5 + [1] + [0] * (L - 6)
+    # round 6: ONE sharply peaked row inside a diffuse bf16 layer (the head's largest row maximum reaches attention_auto_rowmax = 0.5 while mean
+    # and tail stay under their thresholds) is recorded as `rare` and makes forward() repeat the batch with the device-side guards -- the layer is
+    # NOT moved up; the same maximum on a layer that is not on the bf16 tier means nothing
+    raw = np.zeros((L, H + 1, 4), dtype=np.int64)
+    raw[:, :H, 1] = 1000
+    raw[:, :H, 0] = int(0.01 * 1000 * 2 ** 24)
+    raw[:, H, :3] = np.asarray(np.full(3, 20.0), dtype=np.float32).view(np.uint32).astype(np.int64)
+    raw[7, 3, 2] = int(0.97 * 2 ** 24)      # layer 7 (bf16 tier): a row at 0.97
+    raw[1, 0, 2] = int(0.99 * 2 ** 24)      # layer 1 (split-bf16 by now): irrelevant
+    before = m.attention_report()["modes"]
+    m.__dict__["_attn_pending"] = {0: [torch.from_numpy(raw), Ev(), 7]}
+    assert m._attention_stats_consume() == 0
+    rep = m.attention_report()
+    assert rep["modes"] == before and rep["rare"].tolist() == [0] * 7 + [1] + [0] * (L - 8) and m._attn_auto["rare_last"] is True
+    raw[7, 3, 2] = int(0.3 * 2 ** 24)
+    m.__dict__["_attn_pending"] = {0: [torch.from_numpy(raw), Ev(), 7]}
+    m._attention_stats_consume()
+    assert m._attn_auto["rare_last"] is False and m.attention_report()["rare"].sum() == 1
 
 
 def test_graph_build_flag_words_decide_the_repeat():

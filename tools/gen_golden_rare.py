@@ -25,7 +25,10 @@ from tests.helpers import make_rare_pair  # noqa: E402  (the pair construction i
 
 def main():
     sd = synth.make_state_dict(123)
-    for n, seed, n_hot, gain, iters, thr in ((1024, 1050, 2, 6.0, 100, 0.2), (1024, 1051, 1, 10.0, 20, 0.02)):
+    only = [a for a in sys.argv[1:] if a.isdigit()]
+    for n, seed, n_hot, gain, iters, thr in ((1024, 1050, 2, 6.0, 100, 0.2), (1024, 1051, 1, 10.0, 20, 0.02), (1024, 1052, 1, 8.0, 100, 0.2)):
+        if only and str(seed) not in only:
+            continue
         model = G.ref_model(sd, {"sinkhorn_iterations": iters, "match_threshold": thr})
         pair, hot0, hot1 = make_rare_pair(n, seed, n_hot, gain)
         rowmax = []                                               # per attention call: the largest softmax probability of every query row, per head
