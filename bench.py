@@ -583,6 +583,10 @@ def main():
     import torch
     if host_threads:
         torch.set_num_threads(host_threads)
+    elif world == 1:
+        # the timed loop has no CPU-parallel work; an intra-op pool as wide as a 256-core host only adds spinning threads next to the launch thread
+        host_threads = min(16, len(full_affinity) if full_affinity else (os.cpu_count() or 1))
+        torch.set_num_threads(host_threads)
     if world != args.gpus:
         log(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     import torch.distributed as dist
