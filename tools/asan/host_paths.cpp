@@ -58,6 +58,18 @@ int main() {
     EXPECT(gims_agc_build_ex(&big, 1, 15.0, 2.0, 7, 0, (void*)0x7000, (size_t)1 << 40, nullptr) == GIMS_EINVAL);
     big.d = 256;                                                                       // a workspace that is too small
     EXPECT(gims_agc_build_ex(&big, 1, 15.0, 2.0, 7, GIMS_AGC_ROBUST, (void*)0x7000, 64, nullptr) == GIMS_EINVAL);
+    // round 6: per-flow workspace sizes -- the default flow does not hold the half N x N matrix; a descriptor width that forces the robust flow
+    // is sized for it whatever the flags say; a workspace sized for the default flow is refused by a robust build
+    for (int n : {1000, 21163}) {
+      big.n = n; big.d = 256; big.max_edges_dir = 64 * n;
+      const size_t w0 = gims_agc_workspace_bytes_ex(&big, 1, 0), w1 = gims_agc_workspace_bytes_ex(&big, 1, GIMS_AGC_ROBUST);
+      EXPECT(w1 == gims_agc_workspace_bytes(&big, 1) && w1 >= w0 + (size_t)n * (size_t)n * 2 && w0 > (size_t)n * (size_t)(n - 1) * 2);
+    }
+    big.n = 1000; big.d = 96; big.max_edges_dir = 64000;
+    EXPECT(gims_agc_workspace_bytes_ex(&big, 1, 0) == gims_agc_workspace_bytes_ex(&big, 1, GIMS_AGC_ROBUST));
+    big.d = 256;
+    EXPECT(gims_agc_build_ex(&big, 1, 15.0, 2.0, 7, GIMS_AGC_ROBUST, (void*)0x7000, gims_agc_workspace_bytes_ex(&big, 1, 0), nullptr) == GIMS_EINVAL);
+    EXPECT(gims_agc_workspace_bytes_ex(nullptr, 0, 0) == 0);
   }
   {   // round 5: guarded launches (gims_attn_guard) -- validation only
     gims_attn_args aa; memset(&aa, 0, sizeof(aa));
@@ -147,6 +159,17 @@ int main() {
   EXPECT(gims_attention_stat(nullptr, 0, 0, 0, 0, nullptr, 0, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, nullptr) == GIMS_EINVAL);
   EXPECT(gims_attention_stat((const uint16_t*)0x1000, 768, 0, 256, 512, (const gims_attn_problem*)0x2000, 1, 64, 4, (float*)0x3000, 256, nullptr, nullptr, 0, 0,
                              (uint64_t*)0x4004, nullptr) == GIMS_EINVAL);      // misaligned statistics accumulator
+  {   // round 6: the launch counters (host-side state only)
+    uint64_t cnt[8] = {9, 9, 9, 9, 9, 9, 9, 9};
+    EXPECT(gims_attention_launch_counts(cnt, 8, 1) == GIMS_OK && cnt[GIMS_ATTN_KERNEL_KINDS] == 0 && cnt[7] == 0);
+    EXPECT(gims_attention_launch_counts(cnt, 3, 0) == GIMS_OK && cnt[0] == 0 && cnt[2] == 0);
+    EXPECT(gims_attention_launch_counts(nullptr, 4, 0) == GIMS_EINVAL && gims_attention_launch_counts(nullptr, 0, 0) == GIMS_OK);
+    gims_attn_args aa; memset(&aa, 0, sizeof(aa));                                    // a guard without GIMS_ATTN_X3 is refused before anything is launched
+    aa.qkv = (const uint16_t*)0x1000; aa.ld = 1536; aa.k_col = 256; aa.v_col = 512; aa.problems = (const gims_attn_problem*)0x2000; aa.n_problems = 1;
+    aa.max_n_q = 64; aa.n_heads = 4; aa.out = (float*)0x3000; aa.ld_out = 256; aa.guard.stat = (uint64_t*)0x4000; aa.guard.kind = GIMS_GUARD_PEAKED;
+    aa.guard.n_heads = 4; aa.guard.max_thr = 0.5;
+    EXPECT(gims_attention_ex(&aa, nullptr) == GIMS_EINVAL);
+  }
   EXPECT(gims_patch_affine(nullptr, nullptr, 3, nullptr, nullptr, nullptr) == GIMS_EINVAL);
   EXPECT(gims_patch_affine(nullptr, nullptr, 0, nullptr, nullptr, nullptr) == GIMS_OK);          // nothing to do
   EXPECT(gims_sinkhorn_plan_ex(pr.data(), (int)pr.size(), 100, GIMS_OT_STREAMED) == 0);           // streamed on request, whatever the sizes
