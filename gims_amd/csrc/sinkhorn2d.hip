@@ -403,6 +403,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
       __syncthreads();                                       // (nf_lds is rewritten four iterations later at the earliest; this keeps the read and that write apart without relying on it)
     }
     pend_fresh = next_fresh;
+    const bool need_u = next_fresh || it + 1 == a.iters;       // the potentials themselves are wanted (workgroup-uniform)
     const unsigned tagbit = (unsigned)(it & 1) << 31;
     const unsigned xtagbit = (unsigned)((it >> 1) & 1) << 31;
     auto tg = [&](float x) { return __uint_as_float(__float_as_uint(x) | tagbit); };
@@ -481,6 +482,15 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
     stamp(0);
     // ---------------- row pass: sum_j K_ij G_j over the block's columns
     {
+      // the dustbin row of the last group, sum_j pr_j G_j (its corner entry is added at the publish like every row's dustbin-column entry): wave 0
+      // forms it FIRST, into a word of its own that the publisher puts into slot nrl -- behind the sweep it cost the last group's workgroups a
+      // barrier, a wave reduction and another barrier (~800 cycles) on the path every other workgroup of the problem waits for (round 6; formed
+      // branch-free by every wave so that the scheduler could thread it through the sweep: 600 cycles MORE for every workgroup)
+      if (lastg && wave == 0) {
+        float s = pr[lane] * gvec[lane] + pr[lane + 64] * gvec[lane + 64];
+        s = wave_sum(s);
+        if (lane == 0) wred[8] = s;
+      }
       r2f2 g2[8];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -520,14 +530,6 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
         for (int i4 = 0; i4 < 4; ++i4) s4[i4] = r2_dpp_add<0x141>(s4[i4]);
         if (cg == 0) *(f32x4*)(rowst + rg * 16 + ib) = f32x4{s4[0], s4[1], s4[2], s4[3]};
       }
-      if (lastg) {        // the dustbin row: sum_j pr_j G_j (the corner is its dustbin-column entry: added at the publish like every row's)
-        __syncthreads();  // (slot nrl is a real-row slot of some thread above when nrl < 1024: it wrote a zero there, overwritten here)
-        if (wave == 0) {
-          float s = pr[lane] * gvec[lane] + pr[lane + 64] * gvec[lane + 64];
-          s = wave_sum(s);
-          if (lane == 0) rowst[nrl] = s;
-        }
-      }
     }
     __syncthreads();
     if (fail_flag) {
@@ -538,6 +540,11 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
     // ---------------- publish the row partials (16-byte stores; stay in this XCD's L2 unless wt)
     if (4 * t < nslots_s) {
       f32x4 q = *(const f32x4*)(rowst + 4 * t);
+      if (lastg) {
+        const float rbin = wred[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = 4 * t + e == nrl ? rbin : q[e];
+      }
       if (lastc) {
         const f32x4 b4 = *(const f32x4*)(pb + 4 * t);
         const float gbin = gvec[128];
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
         // Status 2 = "gave up": the caller's rescue re-solves the problem with the log-domain kernels, which decide whether the marginals
         // themselves are finite (status 1) -- the lazy factors never cost a pair its matches
         bool fgrow = false, bad = false;
-        f32x4 fw, uo = *(const f32x4*)(uo_l + 4 * fq);
+        f32x4 fw;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int s = fs0 + e;
@@ -614,13 +621,23 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
           const float tt = val ? tot[e] : 1.f;
           const float fn = val ? (real ? p.mu : p.mu_bin) * __builtin_amdgcn_rcpf(tt) : 1.f;
           bad |= !(tt > R2_TOT_MIN) || !(tt < 3.0e38f) || !(fn < 3.0e38f);
-          uo[e] += val ? (real ? p.norm : p.log_mu_bin) - logf(tt) : 0.f;
           fgrow |= fn > R2_F_BOUND;
           fw[e] = tg(fn);
         }
         if (bad) ot_raise_status(p.status, 2.f);
-        *(f32x4*)(fo_l + 4 * fq) = uo;
-        if (next_fresh) *(f32x4*)(uo_l + 4 * fq) = uo;
+        // u itself is only read by the next derivation and by the output: since nothing is accumulated (u = u(last derivation) + log F of THIS
+        // iteration), its four logarithms leave the critical path of every other iteration (round 6: ~800 of the fold's 1840 cycles)
+        f32x4 uo = *(const f32x4*)(uo_l + 4 * fq);
+        if (need_u) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int s = fs0 + e;
+            const bool val = s < nslots_s, real = s < nrl;
+            uo[e] += val ? (real ? p.norm : p.log_mu_bin) - logf(tot[e]) : 0.f;
+          }
+          *(f32x4*)(fo_l + 4 * fq) = uo;
+          if (next_fresh) *(f32x4*)(uo_l + 4 * fq) = uo;
+        }
         if (a.refresh == 0 && fgrow) {                                       // (before this iteration's publishes of this lane: they order it for the readers)
           __hip_atomic_store(p.rflag + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __threadfence();
@@ -764,9 +781,11 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
       if (own) {
         gown = (t < 128 ? p.mu : p.nu_bin) * __builtin_amdgcn_rcpf(ctot);       // G_j = nu_j / sum_i F_i K_ij (see the row update)
         if (!(ctot > R2_TOT_MIN) || !(ctot < 3.0e38f) || !(gown < 3.0e38f)) ot_raise_status(p.status, 2.f);
-        vown += (t < 128 ? p.norm : p.log_nu_bin) - logf(ctot);
-        gown_l[t] = vown;
-        if (next_fresh) vown_l[t] = vown;
+        if (need_u) {                                                            // (v like u: only ahead of a derivation and on the last iteration)
+          vown += (t < 128 ? p.norm : p.log_nu_bin) - logf(ctot);
+          gown_l[t] = vown;
+          if (next_fresh) vown_l[t] = vown;
+        }
         if (a.refresh == 0 && gown > R2_G_BOUND) {
           __hip_atomic_store(p.rflag + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __threadfence();
