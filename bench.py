@@ -87,7 +87,7 @@ def compact_line(res):
     line["host_step_ms"] = res.get("host_step_ms")
     line["attention_layers"] = _pick(res.get("attention"), ("precision", "layers_bf16", "layers_f16", "layers_bf16x3"))
     line["world_size_seen"] = res.get("world_size_seen", 1)
-    line.update(_pick(res, ("stats_rows_gathered", "matches_pair0", "sinkhorn_rescues", "host_threads_per_rank")))
+    line.update(_pick(res, ("stats_rows_gathered", "matches_pair0", "sinkhorn_rescues", "host_threads_per_rank", "attention_launches_per_step")))
     par = lambda blk: [_pick(p, ("golden", "rows_equal", "rows", "max_score_err")) for p in (blk.get("parity_vs_reference") or [])]    # noqa: E731
     if par(res):               # the timed batch against the reference's own output for its pair 0 (tests/golden, bench.golden_parity)
         line["parity_pair0"] = par(res)[0]
@@ -127,7 +127,7 @@ def compact_line(res):
     line = _r(line)
     out = json.dumps(line, separators=(",", ":"))
     if len(out) >= LINE_LIMIT:            # never lose the line to its own size: shed the optional parts, largest first
-        for k in ("also", "stage_ms_per_step", "attention_layers", "ranks", "host_step_ms", "matches_pair0", "parity_pair0"):
+        for k in ("also", "stage_ms_per_step", "attention_layers", "attention_launches_per_step", "ranks", "host_step_ms", "matches_pair0", "parity_pair0"):
             line.pop(k, None)
             out = json.dumps(line, separators=(",", ":"))
             if len(out) < LINE_LIMIT:
@@ -312,6 +312,8 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    from gims_amd import hip as _hip
+    _hip.attention_launch_counts(reset=True)          # which attention kernel serves the TIMED steps (host-side counters of the library)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         outs, stats = step()
@@ -319,6 +321,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    attn_counts = {k: v / args.steps for k, v in _hip.attention_launch_counts().items() if v}
     gc.enable()
     et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -526,6 +529,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
         "host_step_ms": {"median": float(np.median(steps_ms)), "max": float(steps_ms.max())},
         "matches_pair0": {"matched": int(v.sum()), "correct_vs_planted": correct},
         "parity_vs_reference": parity,
+        "attention_launches_per_step": attn_counts,        # e.g. {"wave8": 18, "x3_guarded": 18}: the 8-wave bf16 kernel + the guarded redo launches
         "sinkhorn_rescues": int(__import__("gims_amd.hip", fromlist=["hip"]).sinkhorn_rescues()),       # on-chip solves of this process that gave up and were re-solved (0 on a quiet GPU)
         "stats_rows_gathered": int(st.shape[0]), "stat_fields": list(shard.STAT_FIELDS),
         "world_size_seen": dist.get_world_size() if world > 1 else 1,
