@@ -1802,7 +1802,7 @@ extern "C" int gims_attention_ex(const gims_attn_args* args, void* stream) {
       const int n_qtw = cdiv(max_n_q, 2 * QB);
       // guarded launches: one dispatch round of workgroups (two per CU), a strided walk over the tiles when the guard fires
       const int n_blocks = 8 * cdiv(n_groups, 8) * n_qtw, round = 2 * (device_cus() & ~7);
-      if (guard.stat && n_blocks > round && !(getenv("GIMS_GUARD_WALK") && atoi(getenv("GIMS_GUARD_WALK")) == 0))
+      if (guard.stat && n_blocks > round && guard_walk_enabled())
         hipLaunchKernelGGL((attention_x3w_kernel<2, true>), dim3(round), dim3(256), X3W_LDS_BYTES, (hipStream_t)stream, qkv, ld,
                            q_col, k_col, v_col, problems, n_groups, n_heads, n_qtw, out, ld_out, out_hi, out_lo, ld_split, c, stat, guard, n_blocks);
       else

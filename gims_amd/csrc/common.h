@@ -130,6 +130,9 @@ __device__ __forceinline__ bool attn_guard_fires(const gims_attn_guard& g) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// GIMS_GUARD_WALK=0: guarded launches take the full grid instead of one dispatch round of workgroups that walk the tiles (read per call: the
+// cross-check of tests/test_hip_kernels.py::test_guarded_launches_that_walk_their_tiles switches it)
+static inline bool guard_walk_enabled() { const char* e = getenv("GIMS_GUARD_WALK"); return !(e && atoi(e) == 0); }
 
 // Host descriptor table -> device memory through KERNEL ARGUMENTS (chunks of <= 3968 bytes per launch): asynchronous on
 // the stream, no staging buffer whose lifetime would need a synchronisation, no pageable-memory pinning by the runtime.

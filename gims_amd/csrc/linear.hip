@@ -742,7 +742,7 @@ extern "C" int gims_linear(const gims_linear_args* a, void* stream) {
       GIMS_LDS_ATTR((const void*)linear_x3p_kernel<256, 256, 4, 2, 2>, (int)lds);
       const dim3 g(8 * cdiv(cdiv(a->m, 256), 8) * cdiv(a->n, 256));
       if (a->flags & GIMS_LINEAR_HI_ONLY) hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 4, 1>), g, dim3(512), lds_h, s, *a);
-      else if (a->guard.stat && (int)g.x > device_cus() && !(getenv("GIMS_GUARD_WALK") && atoi(getenv("GIMS_GUARD_WALK")) == 0)) {      // guarded: one round of workgroups (see linear_x3p_guarded_kernel)
+      else if (a->guard.stat && (int)g.x > device_cus() && guard_walk_enabled()) {      // guarded: one round of workgroups (see linear_x3p_guarded_kernel)
         GIMS_LDS_ATTR((const void*)linear_x3p_guarded_kernel<256, 256, 4, 2, 2>, (int)lds);
         hipLaunchKernelGGL((linear_x3p_guarded_kernel<256, 256, 4, 2, 2>), dim3(device_cus() & ~7), dim3(512), lds, s, *a, (int)g.x);
       } else hipLaunchKernelGGL((linear_x3p_kernel<256, 256, 4, 2, 2>), g, dim3(512), lds, s, *a);
