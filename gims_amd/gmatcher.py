@@ -115,10 +115,13 @@ class GMatcher(nn.Module):
         # raree2e_*_g10 shows 6e-4 of score error on plain bf16 operands).  That redo is per batch: the layer is NOT moved up (one outlier does
         # not cost every later batch the faster tier); forward() repeats such a batch with the device-side guards on.  The figure is complete
         # for every kernel (the 8-wave kernel bounds every row's maximum by its largest half-tile mass); 0 switches the criterion off.
+        # `attention_auto_rare_batches`: a layer whose rows did that on this many batches is no outlier any more -- redoing it at three times the
+        # matrix work every batch costs more than the half tier's 1.2 x -- and IS moved up (0: never).
         'attention_precision': 'auto',
         'attention_auto_threshold': 0.08,
         'attention_auto_tail': 0.02,
         'attention_auto_rowmax': 0.5,
+        'attention_auto_rare_batches': 3,
         'attention_f16_range': 3.0e4,
         'attention_monitor_period': 1,
         'train_precision': 'bf16x6',      # products of the training step's forward (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
@@ -400,6 +403,9 @@ class GMatcher(nn.Module):
             rare = (~hot) & (np.asarray(st["mode"]) == 0) & ((host[:, :, 2] / hip.ATTN_STAT_SCALE >= rmx).any(axis=1) if rmx > 0 else False)
             st["rare"] = st.get("rare", np.zeros(len(hot), dtype=np.int64)) + rare
             st["rare_last"] = bool(np.any(rare)) and st["calibrated"]
+            nb = int(self.config['attention_auto_rare_batches'])
+            if nb > 0 and st["calibrated"]:          # no outlier any more: such a layer goes to the half tier like a sharpened one
+                hot = hot | (rare & (st["rare"] >= nb))
             wide = (st["range"] > float(self.config['attention_f16_range'])).any(axis=1)
             want = np.where(hot, np.where(wide, 2, 1), 0)
             if not st["calibrated"]:

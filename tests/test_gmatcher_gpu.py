@@ -310,6 +310,33 @@ def test_rare_peaked_rows_inside_diffuse_layers_vs_reference_golden(synth_sd, mo
         assert rep["rare"].sum() > 0 and rep["modes"].count("bf16") >= 15          # answered per batch: the layers were not moved up for one outlier
 
 
+def test_repeated_rare_rows_move_the_layer_up(synth_sd):
+    """attention_auto_rare_batches = 3: a layer whose rows reach the row-maximum criterion on three batches is no outlier -- a per-batch redo on
+    the split-bf16 kernels (3 x the matrix work) costs more than the half tier (1.2 x) -- so it is moved to the half tier for good; the batches
+    before and after that all meet the reference golden (raree2e_*_g8: the unmodified reference on the same pair)."""
+    name = "raree2e_n1024_s1052_h1g8_r15p2m7_i100"
+    g = load_golden(name)
+    n, seed, rad, pct, ms, iters = [int(x) for x in g["meta"]]
+    pair, hot0, _ = make_rare_pair(n, seed, len(g["hot0"]), float(g["gain"]))
+    m = GMatcher({}).eval()
+    m.load_state_dict(synth_sd)
+    _settle(m)
+    seen = []
+    for k in range(5):
+        data = pair_to_data(pair, rad, pct, ms, device="cuda")
+        out = m.match_pairs([data])[0]
+        torch.cuda.synchronize()
+        _compare(out, data, g, 0.2)
+        rep = m.attention_report()
+        seen.append((rep["modes"].count("f16"), int(rep["redone"].sum())))
+    print(seen)
+    (f0, r0), (f1, r1), (f2, r2), (f3, r3), (f4, r4) = seen
+    assert f0 == f1 == 0 and r0 > 0 and r1 > r0                     # batches 1-2: redone per batch, no layer moved
+    assert f2 > 0 and f3 == f2 and f4 == f2                          # the third batch moved the repeat offenders up, once
+    assert r4 - r3 < r1 - r0                                         # ... and what is left to redo per batch is less than before
+    assert "bf16" in rep["modes"]                                    # layers without such rows stay on the fast tier
+
+
 @pytest.mark.parametrize("api", ["forward", "match_pairs"])
 @pytest.mark.parametrize("name", ["peakede2e_n1024_s1010_r15p2m7_i100", "peakede2e_n1024_s1011_r15p2m7_i20"])
 def test_auto_attention_holds_the_bar_on_the_first_sharpened_batch(name, api):

@@ -309,6 +309,13 @@ def test_auto_attention_routes_on_the_tail_and_the_range():
     m.__dict__["_attn_pending"] = {0: [torch.from_numpy(raw), Ev(), 7]}
     m._attention_stats_consume()
     assert m._attn_auto["rare_last"] is False and m.attention_report()["rare"].sum() == 1
+    # ... but a layer that does it on attention_auto_rare_batches (3) batches is no outlier: it moves to the half tier (cheaper than a redo per batch)
+    raw[7, 3, 2] = int(0.9 * 2 ** 24)
+    for k in (2, 3):
+        m.__dict__["_attn_pending"] = {0: [torch.from_numpy(raw), Ev(), 7]}
+        moved = m._attention_stats_consume()
+        assert m.attention_report()["rare"][7] == k and moved == (1 if k == 3 else 0)
+    assert m.attention_report()["modes"][7] == "f16" and m.attention_report()["modes"][8] == "bf16"
 
 
 def test_graph_build_flag_words_decide_the_repeat():
