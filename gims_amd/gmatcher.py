@@ -658,12 +658,15 @@ class GMatcher(nn.Module):
             if x3:
                 # split-bf16 operands for the LDS-DMA GEMM: h and mean(h) as SPL32 planes (the producing GEMM writes the
                 # planes of the next layer's h itself; the aggregation reads h in f32)
-                h_spl = hip.split_spl32(h)
+                # (intermediates live in the per-lane arena: nothing of them is handed to the caller, and a dozen allocator calls per
+                # call are host time the single-pair path feels; `sage` itself -- kept in _last for the intermediates tests -- stays fresh)
+                h_spl = hip.split_spl32(h, out=self._act("sage_hs0", n_tot, 2 * h.shape[1], torch.bfloat16))
                 for i, e in enumerate(P["sage"]):
-                    agg_spl = hip.sage_mean_split(h, indptr_all, indices_all, self._spl(n_tot, h.shape[1], dev))
+                    agg_spl = hip.sage_mean_split(h, indptr_all, indices_all, self._act("sage_agg", n_tot, 2 * h.shape[1], torch.bfloat16))
                     last = i == len(P["sage"]) - 1
-                    h_next = torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev)
-                    h_spl_next = None if last else self._spl(n_tot, e["n"], dev)
+                    h_next = (torch.empty((n_tot, e["n"]), dtype=torch.float32, device=dev) if last
+                              else self._act("sage_h%d" % (i & 1), n_tot, e["n"], torch.float32))
+                    h_spl_next = None if last else self._act("sage_hs%d" % ((i + 1) & 1), n_tot, 2 * e["n"], torch.bfloat16)
                     self._lin(e, h_spl, a1=agg_spl, act=hip.ACT_NONE if last else hip.ACT_RELU, out=h_next, out_split=h_spl_next)
                     h, h_spl = h_next, h_spl_next
             else:
@@ -675,20 +678,20 @@ class GMatcher(nn.Module):
         # ---- keypoint encoder (gmatcher.py:26-33, 87-97) ; desc = sage + kenc (gmatcher.py:270-271)
         with St("kenc"):
             ln = P["ln"]
-            x = torch.empty((n_tot, P["kenc_w1"].shape[0]), dtype=torch.float32, device=dev)
+            x = self._act("kenc_x", n_tot, P["kenc_w1"].shape[0], torch.float32)
             hip.kenc_first(kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], x, relu=not ln)
             if ln:      # use_layernorm=True: conv -> LayerNorm -> ReLU (gmatcher.py:17-23), the norm as its own kernel
                 hip.layernorm_act(x, *P["kenc_ln"][0], out=x)
             dpl = self._act("dpl", n_tot, 2 * D, torch.bfloat16) if x3 else None     # split-bf16 (SPL32) copy of the residual stream
             if x3 and not ln:
-                xs = hip.split_spl32(x)                              # the hidden activations only ever exist as SPL32 planes
+                xs = hip.split_spl32(x, out=self._act("kenc_xs0", n_tot, 2 * x.shape[1], torch.bfloat16))      # the hidden activations only ever exist as SPL32 planes
                 for i, e in enumerate(P["kenc"]):
                     last = i == len(P["kenc"]) - 1
                     if last:
                         x = self._act("desc", n_tot, e["n"], torch.float32)
                         self._lin(e, xs, residual=sage, out=x, out_split=dpl)
                     else:
-                        nxt = self._spl(n_tot, e["n"], dev)
+                        nxt = self._act("kenc_xs%d" % ((i + 1) & 1), n_tot, 2 * e["n"], torch.bfloat16)
                         self._lin(e, xs, act=hip.ACT_RELU, out_split=nxt)
                         xs = nxt
             else:
@@ -707,8 +710,9 @@ class GMatcher(nn.Module):
         # (problem tables and layer activations live in per-lane arenas: stable addresses let the launch sequence be replayed)
         spr = np.asarray([[o, n, o, n] for pr in pairs for (o, n) in pr], dtype=np.int32)
         cpr = np.asarray([q for (o0, n0), (o1, n1) in pairs for q in ((o0, n0, o1, n1), (o1, n1, o0, n0))], dtype=np.int32)
-        self_pr = hip.upload(spr, dev, out=self._buf("self_pr", spr.nbytes + 32))
-        cross_pr = hip.upload(cpr, dev, out=self._buf("cross_pr", cpr.nbytes + 32))
+        # (ONE upload for both tables: a launch and ~15 us of host time less per call on the single-pair path)
+        both = hip.upload(np.concatenate([spr, cpr]), dev, out=self._buf("attn_pr", spr.nbytes + cpr.nbytes + 32))
+        self_pr, cross_pr = both[:spr.shape[0]], both[spr.shape[0]:]
         max_nq = max(g["n_kept"] for g in images)
         if cfg['attention_precision'] not in ('auto', 'bf16', 'f16', 'bf16x3'):
             raise ValueError("attention_precision must be 'auto', 'bf16', 'f16' or 'bf16x3'")

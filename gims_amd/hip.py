@@ -403,24 +403,33 @@ def linear_args(a0, w, *, bias=None, a1=None, w_lo=None, residual=None, out=None
         k0 = a0.shape[1] // 2
         k = k0 + (a1.shape[1] // 2 if a1 is not None else 0)
         assert w.shape[1] == 2 * k, (w.shape, k)
-        a0_lo, a1_lo, w_lo = a0[:, 32:], (a1[:, 32:] if a1 is not None else None), w[:, 32:]
+        # (the lo planes sit 32 elements = 64 bytes behind the hi planes of the same buffers: plain pointer arithmetic -- a sliced view per
+        # operand cost a single-pair forward() ~8 us of Python per GEMM launch)
+        p_a0, p_a1, p_w = a0.data_ptr(), (a1.data_ptr() if a1 is not None else None), w.data_ptr()
+        return _linear_struct(p_a0, a0.stride(0), p_a1, a1.stride(0) if a1 is not None else 0, p_w, p_w + 64, w, bias, residual, out, out_bf16, m, n,
+                              k, k0, act, precision, scale, p_a0 + 64, (p_a1 + 64) if p_a1 is not None else None, out_split, flags, guard, range_stat)
     else:
         _dev(a0, torch.float32)
         k0 = a0.shape[1]
         k = k0 + (a1.shape[1] if a1 is not None else 0)
         assert w.shape[1] == k, (w.shape, k)
         a0_lo = a1_lo = None
+    return _linear_struct(_p(a0), a0.stride(0), _p(a1), a1.stride(0) if a1 is not None else 0, _p(w), _p(w_lo), w, bias, residual, out, out_bf16, m, n,
+                          k, k0, act, precision, scale, _p(a0_lo), _p(a1_lo), out_split, flags, guard, range_stat)
+
+
+def _linear_struct(p_a0, lda0, p_a1, lda1, p_w, p_w_lo, w, bias, residual, out, out_bf16, m, n, k, k0, act, precision, scale, p_a0_lo, p_a1_lo, out_split,
+                   flags, guard, range_stat) -> LinearArgs:
     n = w.shape[0] if n is None else n
-    assert a0.stride(1) == 1 and w.stride(1) == 1
+    assert w.stride(1) == 1
     if residual is not None:
         assert out is not None and residual.stride(0) == out.stride(0)
     if out_split is not None:
         assert out_split.dtype == torch.bfloat16 and out_split.shape[1] >= 2 * n and out_split.stride(1) == 1
-    return LinearArgs(_p(a0), a0.stride(0), _p(a1), a1.stride(0) if a1 is not None else 0,
-                      _p(w), _p(w_lo), w.stride(0), _p(bias), _p(residual), _p(out),
+    return LinearArgs(p_a0, lda0, p_a1, lda1, p_w, p_w_lo, w.stride(0), _p(bias), _p(residual), _p(out),
                       out.stride(0) if out is not None else 0, _p(out_bf16),
                       out_bf16.stride(0) if out_bf16 is not None else 0, m, n, k, k0, act, precision, float(scale),
-                      _p(a0_lo), _p(a1_lo), _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
+                      p_a0_lo, p_a1_lo, _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
                       out_split.stride(0) if out_split is not None else 0, int(flags), 0, 0, 0, 0,
                       guard if guard is not None else AttnGuard(), _p(range_stat))
 
