@@ -279,14 +279,15 @@ def load(path: str | None = None):
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.gims_abi_version() != 1:
-        raise GimsHipError(f"ABI version mismatch: library {lib.gims_abi_version()} != binding 1")
+    if lib.gims_abi_version() != ABI_VERSION:
+        raise GimsHipError(f"ABI version mismatch: library {lib.gims_abi_version()} != binding {ABI_VERSION} (rebuild: python -m gims_amd.build)")
     if path is None:
         _lib = lib
     return lib
 
 
 GIMS_OK, GIMS_EINVAL, GIMS_EHIP, GIMS_ENUMERIC = 0, -1, -2, -3          # include/gims_hip.h
+ABI_VERSION = 2                     # GIMS_ABI_VERSION of the header these ctypes mirrors were written against
 
 
 def _check(rc: int, what: str):

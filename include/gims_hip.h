@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GIMS_ABI_VERSION 1
+#define GIMS_ABI_VERSION 2   /* 2 (round 6): gims_attn_guard grew `max_thr` (so did gims_linear_args / gims_attn_args, which embed it); + gims_attention_launch_counts, gims_agc_workspace_bytes_ex */
 
 #define GIMS_OK 0
 #define GIMS_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.load().gims_abi_version() == 1
+    assert hip.load().gims_abi_version() == hip.ABI_VERSION == 2
 
 
 def test_struct_layouts_match_header(tmp_path):
