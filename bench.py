@@ -232,6 +232,17 @@ def golden_parity(kpts, iters, thr, pair_ids, outs, datas):
     return recs or None
 
 
+def rank_affinity(cores, local_rank, local_world):
+    """The slice of the inherited CPU set that rank `local_rank` of `local_world` ranks on this node keeps to: contiguous, equal shares, disjoint
+    between the ranks; None (leave the affinity alone) when a share would be a single core."""
+    cores = sorted(cores)
+    share = len(cores) // max(1, local_world)
+    if share < 2:
+        return None
+    r = local_rank % max(1, local_world)
+    return cores[r * share:(r + 1) * share]
+
+
 # ------------------------------------------------------------------------------------------------ self-launch
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU) and wait.
@@ -577,12 +588,10 @@ def main():
     full_affinity = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
     host_threads = None
     if world > 1 and full_affinity and os.environ.get("GIMS_BENCH_NO_PIN") is None:
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        share = len(full_affinity) // max(1, local_world)
-        if share >= 2:
-            mine = full_affinity[(local_rank % local_world) * share:(local_rank % local_world + 1) * share]
+        mine = rank_affinity(full_affinity, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+        if mine:
             os.sched_setaffinity(0, mine)
-            host_threads = min(share, 16)
+            host_threads = min(len(mine), 16)
             os.environ.setdefault("OMP_NUM_THREADS", str(host_threads))
     import torch
     if host_threads:

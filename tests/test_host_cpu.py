@@ -361,3 +361,22 @@ def test_bench_line_is_compact_and_parses_from_the_stored_tail():
     full["config"]["workload"] = "w" * 3000
     line = bench.compact_line(full)
     assert len(line) < bench.LINE_LIMIT and "roofline" in json.loads(line) and "cpu_baseline" in json.loads(line)
+
+
+def test_bench_ranks_keep_to_disjoint_core_slices():
+    """bench.py N > 1: every rank restricts itself to its own slice of the inherited CPU set before it touches the GPU (the step is host-bound within
+    ~1 % of the GPU time: N interpreters must not share cores).  Equal contiguous shares, disjoint, inside the inherited set, whatever that set
+    looks like (a cgroup may hand out a sparse one); too few cores -> the affinity is left alone."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for cores, world in ((range(256), 8), (range(0, 128, 2), 4), ([3, 4, 5, 9, 10, 11, 12, 40], 2), (range(96), 8)):
+        cores = list(cores)
+        parts = [bench.rank_affinity(cores, r, world) for r in range(world)]
+        assert all(p is not None and len(p) == len(cores) // world for p in parts)
+        flat = [c for p in parts for c in p]
+        assert len(set(flat)) == len(flat) and set(flat) <= set(cores)
+        assert all(p == sorted(p) for p in parts)
+    assert bench.rank_affinity(range(8), 3, 8) is None and bench.rank_affinity(range(15), 0, 8) is None
+    assert bench.rank_affinity(range(64), 9, 8) == list(range(8, 16))          # (a global rank used as local rank wraps instead of running off the set)
