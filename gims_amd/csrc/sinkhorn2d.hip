@@ -65,7 +65,8 @@ struct OtR2Dev {
   int* rflag;          // [iters + 8] adaptive re-derivation: rflag[s] != 0 <=> at the end of iteration s some cumulative factor had grown past its bound
 };
 struct OtR2Args {
-  const OtR2Dev* probs; const OtR2Block* blocks;
+  const OtR2Dev* probs;
+  int p0, pcount, nx, nc;      // this launch holds problems p0 .. p0 + pcount - 1 of the class's geometry (nx row groups x nc column blocks each)
   float alpha; int iters, refresh, wt_local;      // refresh > 0: fixed period; 0: adaptive (rflag); < 0: the final derivation only
   int init_inside;     // 1: the start potentials u0 = -max(alpha, row max of Z), v0 = 0 are formed in here (no ot_init_kernel sweep of Z)
   unsigned long long* prof;
@@ -148,7 +149,17 @@ __global__ __launch_bounds__(R2_NT, 1) void ot_res2_kernel(OtR2Args a) {
   float* uo_l = gown_l + 132;              // [132]  u of the folded row slots AT THE LAST DERIVATION
   float* fo_l = uo_l + 132;                // [132]  u of the folded row slots now (= uo_l + log F)
 
-  const OtR2Block bk = a.blocks[blockIdx.x];
+  // workgroup -> (problem, row group, column block) by arithmetic (round 6: it was an 8-KB table uploaded per launch -- three stream-ordered upload
+  // launches each): unit (problem q, row group xr) sits on XCD unit % 8 in slot unit / 8 of that XCD's workgroups, its nc column blocks on the
+  // workgroups 8 (slot nc + c) + xcd -- block b runs on XCD b % 8 (checked below; speed only)
+  OtR2Block bk;
+  {
+    const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3, slot = j / a.nc, unit = slot * 8 + xcd, q = unit / a.nx;
+    bk.prob = q < a.pcount ? a.p0 + q : -1;
+    bk.xr = unit - q * a.nx;
+    bk.cc = j - slot * a.nc;
+    bk.pad = 0;
+  }
   if (bk.prob < 0) return;
   const OtR2Dev p = a.probs[bk.prob];
   const int xr = bk.xr, cc = bk.cc;
@@ -1002,21 +1013,10 @@ static int run_class(const OtR2Plan& P, const OtR2Host* hp, int np, float alpha,
   if (refresh == 0 && iters > R2_FLAG_ITERS) refresh = 50;       // more iterations than flags: the fixed period of rounds 2-4
   const int prof = r2_env("GIMS_OT_PROF", 0);
   for (int gi = 0; gi < P.ngroups; ++gi) {
-    OtR2Block* dblk = (OtR2Block*)(base + off); off += r2_al(sizeof(OtR2Block) * 512);
-    OtR2Block hb[512];
-    for (int b = 0; b < 512; ++b) hb[b] = OtR2Block{-1, 0, 0, 0};
     const int p0 = gi * P.ppg, p1 = (p0 + P.ppg < np) ? p0 + P.ppg : np;
-    // unit (problem q, row group xr) -> XCD unit % 8, slot unit / 8 of that XCD's CUs; with two workgroups per CU the slots past the first
-    // 32 / nc are the SECOND workgroup of the same CUs: two problems of eight row groups share every CU
-    for (int q = 0; q < p1 - p0; ++q)
-      for (int xr = 0; xr < P.nx; ++xr) {
-        const int unit = q * P.nx + xr, xcd = unit % 8, slot = unit / 8;
-        for (int c = 0; c < P.nc; ++c) hb[8 * (slot * P.nc + c) + xcd] = OtR2Block{p0 + q, xr, c, 0};
-      }
-    rc = upload_table(hb, sizeof(OtR2Block) * (size_t)nblocks, dblk, s);
-    if (rc != GIMS_OK) return rc;
+    // (unit (problem q, row group xr) -> XCD unit % 8, slot unit / 8 of that XCD's workgroups: computed in the kernel from p0, pcount, nx, nc)
     OtR2Args a{};
-    a.probs = dprob; a.blocks = dblk; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local; a.init_inside = init_inside;
+    a.probs = dprob; a.p0 = p0; a.pcount = p1 - p0; a.nx = P.nx; a.nc = P.nc; a.alpha = alpha; a.iters = iters; a.refresh = refresh; a.wt_local = wt_local; a.init_inside = init_inside;
     if (prof) {
       unsigned long long* dprof = (unsigned long long*)device_once("ot_res2_prof", 8 * sizeof(unsigned long long), nullptr);
       GIMS_CHECK_ARG(dprof, "ot_res2_run: no profile buffer");
