@@ -328,6 +328,18 @@ extern "C" int gims_run_ops(const gims_op* ops, int32_t n_ops, void* stream) {
       rc = gims_linear(&ops[i].u.lin, stream);
     } else if (ops[i].kind == GIMS_OP_ATTENTION) {
       rc = gims_attention_ex(&ops[i].u.att, stream);
+    } else if (ops[i].kind == GIMS_OP_AUX) {
+      const gims_aux_args& x = ops[i].u.aux;
+      if (x.fn == GIMS_AUX_SPLIT_SPL32)
+        rc = gims_split_spl32((const float*)x.p[0], x.i[0], (uint16_t*)x.p[1], x.i[1], x.i[2], (int32_t)x.i[3], stream);
+      else if (x.fn == GIMS_AUX_SAGE_MEAN_SPLIT)
+        rc = gims_sage_mean_split((const float*)x.p[0], x.i[0], (const int32_t*)x.p[1], (const int32_t*)x.p[2], (int32_t)x.i[1], (int32_t)x.i[2],
+                                  (uint16_t*)x.p[3], x.i[3], stream);
+      else if (x.fn == GIMS_AUX_KENC_FIRST)
+        rc = gims_kenc_first((const float*)x.p[0], (const float*)x.p[1], (const int32_t*)x.p[2], (const float*)x.p[3], (const float*)x.p[4],
+                             (int32_t)x.i[0], (float*)x.p[5], x.i[1], stream);
+      else
+        GIMS_CHECK_ARG(false, "gims_run_ops: op %d: unknown auxiliary function %d", i, x.fn);
     } else {
       GIMS_CHECK_ARG(false, "gims_run_ops: op %d has unknown kind %d", i, ops[i].kind);
     }

@@ -653,9 +653,16 @@ class GMatcher(nn.Module):
         indptr_all, indices_all, norm3, n_tot = G["indptr_all"], G["indices_all"], G["norm3"], G["n_tot"]
         # ---- GraphSAGE over the merged CSR of all images (gmatcher.py:145-162, 268-269)
         x3 = P["x3"]
+        enc = None
+        if (x3 and not P["ln"] and not self._stepwise and os.environ.get("GIMS_NO_REPLAY") is None
+                and D % 32 == 0 and P["kenc_w1"].shape[0] % 32 == 0):
+            # the encoder stage as ONE replayed call (the stepwise code below is its definition and its cross-check)
+            enc = self._encoder_replay(P, feat, kpts_all, seg, indptr_all, indices_all, norm3, n_tot)
         with St("sage"):
             h = feat
-            if x3:
+            if enc is not None:
+                h = enc[0]
+            elif x3:
                 # split-bf16 operands for the LDS-DMA GEMM: h and mean(h) as SPL32 planes (the producing GEMM writes the
                 # planes of the next layer's h itself; the aggregation reads h in f32)
                 # (intermediates live in the per-lane arena: nothing of them is handed to the caller, and a dozen allocator calls per
@@ -678,12 +685,15 @@ class GMatcher(nn.Module):
         # ---- keypoint encoder (gmatcher.py:26-33, 87-97) ; desc = sage + kenc (gmatcher.py:270-271)
         with St("kenc"):
             ln = P["ln"]
-            x = self._act("kenc_x", n_tot, P["kenc_w1"].shape[0], torch.float32)
-            hip.kenc_first(kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], x, relu=not ln)
-            if ln:      # use_layernorm=True: conv -> LayerNorm -> ReLU (gmatcher.py:17-23), the norm as its own kernel
-                hip.layernorm_act(x, *P["kenc_ln"][0], out=x)
+            if enc is None:
+                x = self._act("kenc_x", n_tot, P["kenc_w1"].shape[0], torch.float32)
+                hip.kenc_first(kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], x, relu=not ln)
+                if ln:      # use_layernorm=True: conv -> LayerNorm -> ReLU (gmatcher.py:17-23), the norm as its own kernel
+                    hip.layernorm_act(x, *P["kenc_ln"][0], out=x)
             dpl = self._act("dpl", n_tot, 2 * D, torch.bfloat16) if x3 else None     # split-bf16 (SPL32) copy of the residual stream
-            if x3 and not ln:
+            if enc is not None:
+                x = enc[1]
+            elif x3 and not ln:
                 xs = hip.split_spl32(x, out=self._act("kenc_xs0", n_tot, 2 * x.shape[1], torch.bfloat16))      # the hidden activations only ever exist as SPL32 planes
                 for i, e in enumerate(P["kenc"]):
                     last = i == len(P["kenc"]) - 1
@@ -896,6 +906,93 @@ class GMatcher(nn.Module):
                           flat=dict(matches0=m0_all, scores0=s0_all, n0=[n0 for (_, n0), _ in pairs], n1=[n1 for _, (_, n1) in pairs]),
                           outputs=[m0_all, m1_all, s0_all, s1_all, uv_all, mdesc, feat, kpts_all, score_all, ctx["pool"]])
         return items, pairs, mdesc
+
+    def _encoder_replay(self, P, feat, kpts_all, seg, indptr_all, indices_all, norm3, n_tot):
+        """GraphSAGE + keypoint encoder (the stepwise code in _run_rest, default precision, no LayerNorm) as ONE call into the library: 15 launches
+        recorded as a table of gims_op structs that is CACHED -- every intermediate lives in the per-lane arena, so its address does not change
+        from call to call -- and PATCHED per call with what does change: the row count and the six pointers of the batch (kept descriptors, CSR,
+        keypoints, image index per row, normalisation constants).  Between a batch's one host synchronisation and its layers the device waits
+        for the host: a dozen crossings of the ABI with their argument marshalling were most of that wait.
+        Returns (sage, desc); dpl (the SPL32 copy of desc) is self._act('dpl')."""
+        D = self.config['descriptor_dim']
+        bf, f32 = torch.bfloat16, torch.float32
+        c1 = P["kenc_w1"].shape[0]
+        A = lambda name, cols, dt: self._act(name, n_tot, cols, dt)                     # noqa: E731
+        dims = [D] + [e["n"] for e in P["sage"]]                                         # 256, 128, 128, 256
+        wmax = max(dims)                                                                 # (one width per arena buffer: the widest layer that uses it)
+        hs = [A("sage_hs0", 2 * wmax, bf), A("sage_hs1", 2 * wmax, bf)]
+        agg = A("sage_agg", 2 * wmax, bf)
+        hf = [A("sage_h0", wmax, f32), A("sage_h1", wmax, f32)]
+        sage = A("sage_out", dims[-1], f32)
+        kd = [c1] + [e["n"] for e in P["kenc"]]                                          # 32, 64, 128, 256, 256
+        xk = A("kenc_x", c1, f32)
+        xs = [A("kenc_xs0", 2 * max(kd), bf), A("kenc_xs1", 2 * max(kd), bf)]
+        desc, dpl = A("desc", kd[-1], f32), A("dpl", 2 * D, bf)
+        key = (P["gen"],) + tuple(t.data_ptr() for t in (hs[0], hs[1], agg, hf[0], hf[1], sage, xk, xs[0], xs[1], desc, dpl))
+        cache = self.__dict__.setdefault("_enc_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            V = lambda t, cols: t[:, :cols]                                              # noqa: E731  (a view of the arena slice with the layer's width)
+            lst, labels = [], []
+
+            def la(e, a0, **kw):
+                return hip.op_linear(hip.linear_args(a0, e["w"], w_lo=e["w_lo"], bias=e["b"], precision=e["prec"], spl=e["spl"], **kw))
+            # GraphSAGE: h as SPL32 planes, then per layer mean(h) as planes and the GEMM on [h | mean(h)]
+            lst.append(hip.op_aux(hip.AUX_SPLIT_SPL32, [feat, hs[0]], [feat.stride(0), hs[0].stride(0), n_tot, dims[0]])); labels.append("sage")
+            h, hspl = feat, V(hs[0], 2 * dims[0])
+            mean_ops = []
+            for i, e in enumerate(P["sage"]):
+                last = i == len(P["sage"]) - 1
+                aggv = V(agg, 2 * dims[i])
+                mean_ops.append(len(lst))
+                lst.append(hip.op_aux(hip.AUX_SAGE_MEAN_SPLIT, [h, indptr_all, indices_all, aggv], [h.stride(0), n_tot, dims[i], agg.stride(0)])); labels.append("sage")
+                h_next = sage if last else V(hf[i & 1], dims[i + 1])
+                hs_next = None if last else V(hs[(i + 1) & 1], 2 * dims[i + 1])
+                lst.append(la(e, hspl, a1=aggv, act=hip.ACT_NONE if last else hip.ACT_RELU, out=h_next, out_split=hs_next)); labels.append("sage")
+                h, hspl = h_next, hs_next
+            # keypoint encoder: first layer on normalised coordinates, then the MLP on SPL32 planes; the last layer adds `sage` and writes desc + dpl
+            k_first = len(lst)
+            lst.append(hip.op_aux(hip.AUX_KENC_FIRST, [kpts_all, norm3, seg, P["kenc_w1"], P["kenc_b1"], xk], [c1, n_tot])); labels.append("kenc")
+            lst.append(hip.op_aux(hip.AUX_SPLIT_SPL32, [xk, xs[0]], [xk.stride(0), xs[0].stride(0), n_tot, c1])); labels.append("kenc")
+            cur = V(xs[0], 2 * c1)
+            for i, e in enumerate(P["kenc"]):
+                last = i == len(P["kenc"]) - 1
+                if last:
+                    lst.append(la(e, cur, residual=sage, out=desc, out_split=dpl))
+                else:
+                    nxt = V(xs[(i + 1) & 1], 2 * e["n"])
+                    lst.append(la(e, cur, act=hip.ACT_RELU, out_split=nxt))
+                    cur = nxt
+                labels.append("kenc")
+            if len(cache) > 4:
+                cache.clear()
+            ent = cache[key] = dict(ops=hip.make_ops(lst), labels=labels, mean_ops=mean_ops, k_first=k_first, keep=(P, hs, agg, hf, sage, xk, xs, desc, dpl))
+        ops = ent["ops"]
+        # ---- per-call patches: row counts, and the pointers that belong to this batch
+        for o in ops:
+            if o.kind == 0:
+                o.u.lin.m = n_tot
+            elif o.u.aux.fn == hip.AUX_SPLIT_SPL32:
+                o.u.aux.i[2] = n_tot
+            else:
+                o.u.aux.i[1] = n_tot
+        ops[0].u.aux.p[0] = feat.data_ptr()
+        ops[0].u.aux.i[0] = feat.stride(0)
+        for j, k in enumerate(ent["mean_ops"]):
+            if j == 0:
+                ops[k].u.aux.p[0] = feat.data_ptr()
+                ops[k].u.aux.i[0] = feat.stride(0)
+            ops[k].u.aux.p[1] = indptr_all.data_ptr()
+            ops[k].u.aux.p[2] = indices_all.data_ptr()
+        kf = ops[ent["k_first"]].u.aux
+        kf.p[0], kf.p[1], kf.p[2] = kpts_all.data_ptr(), norm3.data_ptr(), seg.data_ptr()
+        if self._timers is not None:
+            pool = hip.EventPool(len(ops) + 1)
+            hip.run_ops_timed(ops, pool)
+            self._timers.setdefault("_ops", []).append((pool, ent["labels"]))
+        else:
+            hip.run_ops(ops)
+        return sage, desc
 
     def _ingest(self, raw):
         """raw: list of (kp (N,2), desc (D,N) channel-major, scores (N,), image shape).  ONE launch transposes the whole

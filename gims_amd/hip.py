@@ -60,8 +60,16 @@ class AttnArgs(C.Structure):
                 ("ld_split", C.c_int64), ("flags", C.c_int32), ("stat", C.c_void_p), ("guard", AttnGuard)]
 
 
+class AuxArgs(C.Structure):
+    """gims_aux_args: one of the small encoder-stage kernels as an op of gims_run_ops (fn = AUX_*; p / i in the entry point's argument order)."""
+    _fields_ = [("fn", C.c_int32), ("reserved", C.c_int32), ("p", C.c_void_p * 6), ("i", C.c_int64 * 4)]
+
+
+AUX_SPLIT_SPL32, AUX_SAGE_MEAN_SPLIT, AUX_KENC_FIRST = 0, 1, 2
+
+
 class _OpU(C.Union):
-    _fields_ = [("lin", LinearArgs), ("att", AttnArgs)]
+    _fields_ = [("lin", LinearArgs), ("att", AttnArgs), ("aux", AuxArgs)]
 
 
 class Op(C.Structure):
@@ -489,6 +497,18 @@ def op_attention(qkv, problems, max_n_q, n_heads, out=None, q_col=0, k_col=256, 
                        out.stride(0) if out is not None else 0, _p(out_split), (out_split.data_ptr() + 64) if out_split is not None else None,
                        out_split.stride(0) if out_split is not None else 0, _attn_flags(q_prescaled, x3, f16, no_range), _p(stat),
                        guard if guard is not None else AttnGuard())
+    return o
+
+
+def op_aux(fn: int, ptrs, ints) -> Op:
+    """One small encoder-stage kernel as an op (include/gims_hip.h GIMS_OP_AUX): ptrs = tensors or raw addresses (None -> NULL), ints = integers."""
+    o = Op()
+    o.kind = 2
+    o.u.aux.fn = int(fn)
+    for k, t in enumerate(ptrs):
+        o.u.aux.p[k] = t if (t is None or isinstance(t, int)) else t.data_ptr()
+    for k, v in enumerate(ints):
+        o.u.aux.i[k] = int(v)
     return o
 
 

@@ -221,7 +221,7 @@ int gims_attention_ex(const struct gims_attn_args* args, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * A recorded sequence of launches replayed by ONE call: the 18 layers of AttentionalGNN.forward (gmatcher.py:127-143) are
  * 72 launches whose arguments only change when the batch geometry does, and a caller in an interpreted language pays for
- * every crossing of the ABI.  ops: HOST array; each op is exactly one gims_linear or gims_attention call, in order, on
+ * every crossing of the ABI.  ops: HOST array; each op is exactly one gims_linear, gims_attention or (GIMS_OP_AUX) small-kernel call, in order, on
  * `stream`.  Stops at (and returns) the first error.
  */
 typedef struct gims_attn_args {
@@ -233,7 +233,19 @@ typedef struct gims_attn_args {
 } gims_attn_args;
 #define GIMS_OP_LINEAR 0
 #define GIMS_OP_ATTENTION 1
-typedef struct gims_op { int32_t kind; int32_t reserved; union { gims_linear_args lin; gims_attn_args att; } u; } gims_op;
+/* GIMS_OP_AUX (round 6): the small kernels of the encoder stage in front of the layers (GraphSAGE, gmatcher.py:145-162, 268-269; keypoint encoder,
+ * gmatcher.py:87-97, 270-271), so that that stage replays from a table like the layers do -- between the one host synchronisation of a batch and
+ * the layers the device waits for the host, and a dozen calls across the ABI were most of that wait.  fn selects the entry point, p / i are its
+ * pointer and integer arguments in declaration order:
+ *   GIMS_AUX_SPLIT_SPL32      gims_split_spl32     p = {src, dst}                              i = {lds, ldd, rows, k}
+ *   GIMS_AUX_SAGE_MEAN_SPLIT  gims_sage_mean_split p = {h, indptr, indices, out_spl}           i = {ldh, n, c, ld_spl}
+ *   GIMS_AUX_KENC_FIRST       gims_kenc_first      p = {kpts, norm3, seg_of_row, w1, b1, out}  i = {c1, n} */
+#define GIMS_OP_AUX 2
+#define GIMS_AUX_SPLIT_SPL32 0
+#define GIMS_AUX_SAGE_MEAN_SPLIT 1
+#define GIMS_AUX_KENC_FIRST 2
+typedef struct gims_aux_args { int32_t fn, reserved; const void* p[6]; int64_t i[4]; } gims_aux_args;
+typedef struct gims_op { int32_t kind; int32_t reserved; union { gims_linear_args lin; gims_attn_args att; gims_aux_args aux; } u; } gims_op;
 int gims_run_ops(const gims_op* ops /* HOST */, int32_t n_ops, void* stream);
 /* The same replay with a HIP event recorded on `stream` before the first op and after every op: events is a HOST array of
  * n_ops + 1 event handles from gims_events_create.  gims_events_elapsed (after the stream has been synchronised) returns the

@@ -534,10 +534,32 @@ def test_replayed_layers_equal_stepwise(synth_sd):
         torch.cuda.synchronize()
         res.append([(o["matches0"].cpu().numpy(), o["matching_scores0"].cpu().numpy()) for o in outs])
     assert m.__dict__.get("_ops_cache"), "the replay path did not run"
+    assert m.__dict__.get("_enc_cache"), "the encoder stage (GraphSAGE + keypoint encoder) did not replay"
     for other in res[1:]:
         for (m0, s0), (m1, s1) in zip(res[0], other):
             np.testing.assert_array_equal(m0, m1)
             np.testing.assert_array_equal(s0, s1)
+    # the cached encoder table is PATCHED per call (row count + the batch's pointers): batches of other sizes through the same table, then the
+    # first batch again -- its bits must come back, and each must equal its stepwise evaluation
+    m.enable_timing(False)
+    others = [synth.make_pair(n, sd) for n, sd in ((200, 1001), (700, 1010))]
+    n_tables = len(m._enc_cache)
+    o_small = m.match_pairs([pair_to_data(p, 15, 2, 7, device="cuda") for p in others[:1]])
+    s_small = o_small[0]["matching_scores0"].cpu().numpy()
+    o_big = m.match_pairs([pair_to_data(p, 15, 2, 7, device="cuda") for p in others + pairs])
+    s_big = [o["matching_scores0"].cpu().numpy() for o in o_big]
+    again = m.match_pairs([pair_to_data(p, 15, 2, 7, device="cuda") for p in pairs])
+    for (m0, s0), o in zip(res[0], again):
+        np.testing.assert_array_equal(m0, o["matches0"].cpu().numpy())
+        np.testing.assert_array_equal(s0, o["matching_scores0"].cpu().numpy())
+    m.enable_timing(True, stepwise=True)
+    ref_small = m.match_pairs([pair_to_data(p, 15, 2, 7, device="cuda") for p in others[:1]])[0]["matching_scores0"].cpu().numpy()
+    ref_big = [o["matching_scores0"].cpu().numpy() for o in m.match_pairs([pair_to_data(p, 15, 2, 7, device="cuda") for p in others + pairs])]
+    m.enable_timing(False)
+    np.testing.assert_array_equal(s_small, ref_small)
+    for a, b in zip(s_big, ref_big):
+        np.testing.assert_array_equal(a, b)
+    assert len(m._enc_cache) <= n_tables + 1          # (the arena may have grown once for the largest batch: a new table then, not one per size)
 
 
 def test_graph_replay_equals_plain_replay(synth_sd):

@@ -35,7 +35,8 @@ def test_struct_layouts_match_header(tmp_path):
              ("gims_train_attn_problem", hip.TrainAttnProblem, ["nk"]),
              ("gims_train_attn_args", hip.TrainAttnArgs, ["qkv", "rows", "d", "scale", "problems", "o", "lse", "d_o", "d_qkv", "work", "work_floats", "reverse_precision"]),
              ("gims_ot_problem", hip.OtProblem, []), ("gims_agc_image", hip.AgcImage, ["kept", "max_edges_dir", "info"]),
-             ("gims_pack_image", hip.PackImage, []), ("gims_ingest_image", hip.IngestImage, []), ("gims_op", hip.Op, ["u"])]
+             ("gims_pack_image", hip.PackImage, []), ("gims_ingest_image", hip.IngestImage, []), ("gims_op", hip.Op, ["u"]),
+             ("gims_aux_args", hip.AuxArgs, ["fn", "p", "i"])]
     body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (c, c) + "".join('printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (c, f, c, f) for f in fs)
                    for c, _, fs in pairs)
     src = tmp_path / "layout.c"
