@@ -654,7 +654,7 @@ class GMatcher(nn.Module):
         # ---- GraphSAGE over the merged CSR of all images (gmatcher.py:145-162, 268-269)
         x3 = P["x3"]
         enc = None
-        if (x3 and not P["ln"] and not self._stepwise and os.environ.get("GIMS_NO_REPLAY") is None
+        if (x3 and not P["ln"] and not self._stepwise and os.environ.get("GIMS_NO_REPLAY") in (None, "3")
                 and D % 32 == 0 and P["kenc_w1"].shape[0] % 32 == 0):
             # the encoder stage as ONE replayed call (the stepwise code below is its definition and its cross-check)
             enc = self._encoder_replay(P, feat, kpts_all, seg, indptr_all, indices_all, norm3, n_tot)
@@ -767,7 +767,7 @@ class GMatcher(nn.Module):
                              self._act("hpl", n_tot, 4 * D, torch.bfloat16))
             hid_ln = None
             replay = (not self._stepwise and not ln and all(L["mlp0_fused"] is not None for L in P["layers"])
-                      and os.environ.get("GIMS_NO_REPLAY") is None)
+                      and os.environ.get("GIMS_NO_REPLAY") in (None, "2"))
             if replay:
                 # the 72 launches of the 18 layers as ONE call into the library (gims_run_ops): their arguments depend only on
                 # the buffer addresses and the batch geometry, which repeat from call to call in steady state
