@@ -522,7 +522,10 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
         "config": {"workload": f"{pairs} pairs/step/GPU of 2x{kpts} synthetic keypoints (kept {problems[0][0]}/{problems[0][1]} after AGC r=15 p=2 m=7), "
                                f"256-d descriptors, 18 attentional layers (9 self + 9 cross), {iters} Sinkhorn iterations, match_threshold {model.config['match_threshold']}",
                    "pairs_per_step_per_gpu": pairs, "keypoints": kpts, "sinkhorn_iterations": iters,
-                   "path": "GMatcher.match_pairs, production path (replayed layer launch table, per-launch HIP events recorded by the library); "
+                   "path": "GMatcher.match_pairs, production path ("
+                           + ("encoder + layer launches replayed from the cached gims_run_ops tables" if model._replays("layers", 2 * kpts * pairs)
+                              else "launch by launch: above config launch_replay_rows the replay tables are not used")
+                           + ", HIP events around every attention / GEMM launch on the launch stream); "
                            "Python's cyclic GC is frozen + disabled inside the K timed steps (host_step_ms.max reports the slowest step)",
                    "parallelism": f"pairs sharded over {world} GPU(s), all-gather of match statistics; {nl} stream lane(s) per GPU"},
         "roofline": roofline,

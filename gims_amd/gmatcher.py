@@ -17,8 +17,9 @@ so that every linear layer is ONE launch for the whole batch.
 """
 from __future__ import annotations
 
-import os
+import contextlib
 import math
+import os
 import time
 from typing import Dict, List
 
@@ -124,6 +125,9 @@ class GMatcher(nn.Module):
         'attention_auto_rare_batches': 3,
         'attention_f16_range': 3.0e4,
         'attention_monitor_period': 1,
+        # calls of up to this many keypoint rows (both images of every pair) issue the encoder and the 18 layers as gims_run_ops tables (the
+        # host's launch cost bounds them); larger batches launch one by one, which measures 0.8-1.5 % faster there (GMatcher._replays)
+        'launch_replay_rows': 16384,
         'train_precision': 'bf16x6',      # products of the training step's forward (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
         'train_backward_precision': 'bf16x3',      # products of its reverse pass: 'bf16x3' (default) or 'f32'.  The pass is linear in its operands, but the
                                                    # attention scores it recomputes carry 16 mantissa bits against the forward's exact-f32 lse: the error of
@@ -638,6 +642,21 @@ class GMatcher(nn.Module):
             g["graph"] = GraphHandle(g["indptr"], g["indices"],
                                      {"point": G["kpts_all"][ro:ro + nk], "feat": G["feat"][ro:ro + nk], "score": G["score_all"][ro:ro + nk]})
 
+    def _replays(self, part, n_tot):
+        """Whether `part` ("encoder" | "layers") of this call is issued as one gims_run_ops table or launch by launch.
+
+        The table removes the host's per-launch cost, which is what bounds small calls (one pair: 2.1 vs 2.4 ms).  Large batches
+        hide the host entirely behind the GPU, and there launch-by-launch issue measures 0.8-1.5 % FASTER on every box tried
+        (same kernels, same order, bit-equal results), so above `launch_replay_rows` keypoint rows the
+        table is not used.  GIMS_NO_REPLAY=1 | 2 | 3 (nothing | only the layers | only the encoder replayed) and GIMS_REPLAY=1
+        (always) override for A/B runs."""
+        if self._stepwise:
+            return False
+        env = os.environ.get("GIMS_NO_REPLAY")
+        if env is not None:
+            return env == ("3" if part == "encoder" else "2")
+        return os.environ.get("GIMS_REPLAY") == "1" or n_tot <= int(self.config['launch_replay_rows'])
+
     def _run_rest(self, ctx):
         """Phase 2: read the kept counts (the one host sync), then enqueue everything else."""
         images = ctx["images"]
@@ -654,11 +673,11 @@ class GMatcher(nn.Module):
         # ---- GraphSAGE over the merged CSR of all images (gmatcher.py:145-162, 268-269)
         x3 = P["x3"]
         enc = None
-        if (x3 and not P["ln"] and not self._stepwise and os.environ.get("GIMS_NO_REPLAY") in (None, "3")
+        if (x3 and not P["ln"] and self._replays("encoder", n_tot)
                 and D % 32 == 0 and P["kenc_w1"].shape[0] % 32 == 0):
             # the encoder stage as ONE replayed call (the stepwise code below is its definition and its cross-check)
             enc = self._encoder_replay(P, feat, kpts_all, seg, indptr_all, indices_all, norm3, n_tot)
-        with St("sage"):
+        with (St("sage") if enc is None else contextlib.nullcontext()):
             h = feat
             if enc is not None:
                 h = enc[0]
@@ -683,7 +702,7 @@ class GMatcher(nn.Module):
                     h = self._lin(e, h, a1=agg, act=hip.ACT_RELU if i < 2 else hip.ACT_NONE)
             sage = h
         # ---- keypoint encoder (gmatcher.py:26-33, 87-97) ; desc = sage + kenc (gmatcher.py:270-271)
-        with St("kenc"):
+        with (St("kenc") if enc is None else contextlib.nullcontext()):
             ln = P["ln"]
             if enc is None:
                 x = self._act("kenc_x", n_tot, P["kenc_w1"].shape[0], torch.float32)
@@ -766,8 +785,7 @@ class GMatcher(nn.Module):
             mpl, gpl, hpl = (self._act("mpl", n_tot, 2 * D, torch.bfloat16), self._act("gpl", n_tot, 2 * D, torch.bfloat16),
                              self._act("hpl", n_tot, 4 * D, torch.bfloat16))
             hid_ln = None
-            replay = (not self._stepwise and not ln and all(L["mlp0_fused"] is not None for L in P["layers"])
-                      and os.environ.get("GIMS_NO_REPLAY") in (None, "2"))
+            replay = not ln and all(L["mlp0_fused"] is not None for L in P["layers"]) and self._replays("layers", n_tot)
             if replay:
                 # the 72 launches of the 18 layers as ONE call into the library (gims_run_ops): their arguments depend only on
                 # the buffer addresses and the batch geometry, which repeat from call to call in steady state
@@ -987,9 +1005,12 @@ class GMatcher(nn.Module):
         kf = ops[ent["k_first"]].u.aux
         kf.p[0], kf.p[1], kf.p[2] = kpts_all.data_ptr(), norm3.data_ptr(), seg.data_ptr()
         if self._timers is not None:
-            pool = hip.EventPool(len(ops) + 1)
-            hip.run_ops_timed(ops, pool)
-            self._timers.setdefault("_ops", []).append((pool, ent["labels"]))
+            # stage timers: ONE event pair per stage (an event after each of the 15 ops -- and their creation -- sat in the host-bound stretch behind
+            # the synchronisation and cost a timed 1024 x 32 step 3 %)
+            with GMatcher._Stage(self, "sage"):
+                hip.run_ops(ops, 0, ent["k_first"])
+            with GMatcher._Stage(self, "kenc"):
+                hip.run_ops(ops, ent["k_first"], len(ops) - ent["k_first"])
         else:
             hip.run_ops(ops)
         return sage, desc

@@ -517,8 +517,11 @@ def make_ops(ops):
     return (Op * len(ops))(*ops)
 
 
-def run_ops(op_array):
-    _check(load().gims_run_ops(op_array, len(op_array), _stream()), "gims_run_ops")
+def run_ops(op_array, start: int = 0, count: int | None = None):
+    """Replay ops[start : start + count] (default: all of them) in one call."""
+    n = len(op_array) - start if count is None else count
+    assert 0 <= start and start + n <= len(op_array)
+    _check(load().gims_run_ops(C.byref(op_array, start * C.sizeof(Op)) if start else op_array, n, _stream()), "gims_run_ops")
 
 
 class EventPool:

@@ -381,3 +381,28 @@ def test_bench_ranks_keep_to_disjoint_core_slices():
         assert all(p == sorted(p) for p in parts)
     assert bench.rank_affinity(range(8), 3, 8) is None and bench.rank_affinity(range(15), 0, 8) is None
     assert bench.rank_affinity(range(64), 9, 8) == list(range(8, 16))          # (a global rank used as local rank wraps instead of running off the set)
+
+
+def test_launch_tables_are_for_small_calls(monkeypatch):
+    """GMatcher._replays: the gims_run_ops tables serve calls the host's launch cost bounds (<= launch_replay_rows keypoint rows);
+    larger batches launch one by one.  enable_timing(stepwise=True) and GIMS_NO_REPLAY / GIMS_REPLAY override."""
+    monkeypatch.delenv("GIMS_NO_REPLAY", raising=False)
+    monkeypatch.delenv("GIMS_REPLAY", raising=False)
+    m = GMatcher({}).eval()
+    rows = m.config['launch_replay_rows']
+    assert rows == 16384
+    for part in ("encoder", "layers"):
+        assert m._replays(part, 2 * 4096) and m._replays(part, rows) and not m._replays(part, rows + 1) and not m._replays(part, 8 * 2 * 4096)
+    assert GMatcher({"launch_replay_rows": 1 << 30})._replays("layers", 65536)
+    monkeypatch.setenv("GIMS_REPLAY", "1")
+    assert m._replays("layers", 65536) and m._replays("encoder", 65536)
+    monkeypatch.setenv("GIMS_NO_REPLAY", "1")
+    assert not m._replays("layers", 1024) and not m._replays("encoder", 1024)
+    monkeypatch.setenv("GIMS_NO_REPLAY", "2")
+    assert m._replays("layers", 65536) and not m._replays("encoder", 1024)
+    monkeypatch.setenv("GIMS_NO_REPLAY", "3")
+    assert not m._replays("layers", 1024) and m._replays("encoder", 65536)
+    monkeypatch.delenv("GIMS_NO_REPLAY")
+    monkeypatch.delenv("GIMS_REPLAY")
+    m._stepwise = True
+    assert not m._replays("layers", 1024)
