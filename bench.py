@@ -524,7 +524,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
                    "pairs_per_step_per_gpu": pairs, "keypoints": kpts, "sinkhorn_iterations": iters,
                    "path": "GMatcher.match_pairs, production path ("
                            + ("encoder + layer launches replayed from the cached gims_run_ops tables" if model._replays("layers", 2 * kpts * pairs)
-                              else "launch by launch: above config launch_replay_rows the replay tables are not used")
+                              else "launch by launch: config launch_replay_rows / GIMS_NO_REPLAY")
                            + ", HIP events around every attention / GEMM launch on the launch stream); "
                            "Python's cyclic GC is frozen + disabled inside the K timed steps (host_step_ms.max reports the slowest step)",
                    "parallelism": f"pairs sharded over {world} GPU(s), all-gather of match statistics; {nl} stream lane(s) per GPU"},

@@ -125,9 +125,10 @@ class GMatcher(nn.Module):
         'attention_auto_rare_batches': 3,
         'attention_f16_range': 3.0e4,
         'attention_monitor_period': 1,
-        # calls of up to this many keypoint rows (both images of every pair) issue the encoder and the 18 layers as gims_run_ops tables (the
-        # host's launch cost bounds them); larger batches launch one by one, which measures 0.8-1.5 % faster there (GMatcher._replays)
-        'launch_replay_rows': 16384,
+        # 0 (default): every call issues the encoder and the 18 layers as gims_run_ops tables.  > 0: only calls of up to this many keypoint rows
+        # (both images of every pair) do, larger batches launch one by one from Python -- on some boxes 0.8-1.5 % faster for 4096 x 8, on
+        # others 0.5 % slower, and with occasional 20-36 ms steps the tables never showed (GMatcher._replays)
+        'launch_replay_rows': 0,
         'train_precision': 'bf16x6',      # products of the training step's forward (gims_amd/trainstep.py): 'bf16x6' (f32 class) | 'bf16x3'
         'train_backward_precision': 'bf16x3',      # products of its reverse pass: 'bf16x3' (default) or 'f32'.  The pass is linear in its operands, but the
                                                    # attention scores it recomputes carry 16 mantissa bits against the forward's exact-f32 lse: the error of
@@ -645,17 +646,19 @@ class GMatcher(nn.Module):
     def _replays(self, part, n_tot):
         """Whether `part` ("encoder" | "layers") of this call is issued as one gims_run_ops table or launch by launch.
 
-        The table removes the host's per-launch cost, which is what bounds small calls (one pair: 2.1 vs 2.4 ms).  Large batches
-        hide the host entirely behind the GPU, and there launch-by-launch issue measures 0.8-1.5 % FASTER on every box tried
-        (same kernels, same order, bit-equal results), so above `launch_replay_rows` keypoint rows the
-        table is not used.  GIMS_NO_REPLAY=1 | 2 | 3 (nothing | only the layers | only the encoder replayed) and GIMS_REPLAY=1
-        (always) override for A/B runs."""
+        The table removes the host's per-launch cost, which is what bounds small calls (one pair: 2.1 vs 2.4 ms).  Large batches hide
+        the host behind the GPU either way; launch-by-launch issue measured 0.8-1.5 % faster there on four boxes and 0.5 % slower on a
+        fifth, where it also produced 3 runs in 32 with a 21-36 ms step against none in 32 with the tables (DESIGN.md section 4.5:
+        same kernels, same order, bit-equal results) -- so the tables are the default at every size, and `launch_replay_rows` > 0
+        restricts them to calls of at most that many keypoint rows.  GIMS_NO_REPLAY=1 | 2 | 3 (nothing | only the layers | only the
+        encoder replayed) and GIMS_REPLAY=1 (always) override for A/B runs."""
         if self._stepwise:
             return False
         env = os.environ.get("GIMS_NO_REPLAY")
         if env is not None:
             return env == ("3" if part == "encoder" else "2")
-        return os.environ.get("GIMS_REPLAY") == "1" or n_tot <= int(self.config['launch_replay_rows'])
+        rows = int(self.config['launch_replay_rows'])
+        return os.environ.get("GIMS_REPLAY") == "1" or rows <= 0 or n_tot <= rows
 
     def _run_rest(self, ctx):
         """Phase 2: read the kept counts (the one host sync), then enqueue everything else."""

@@ -383,17 +383,19 @@ def test_bench_ranks_keep_to_disjoint_core_slices():
     assert bench.rank_affinity(range(64), 9, 8) == list(range(8, 16))          # (a global rank used as local rank wraps instead of running off the set)
 
 
-def test_launch_tables_are_for_small_calls(monkeypatch):
-    """GMatcher._replays: the gims_run_ops tables serve calls the host's launch cost bounds (<= launch_replay_rows keypoint rows);
-    larger batches launch one by one.  enable_timing(stepwise=True) and GIMS_NO_REPLAY / GIMS_REPLAY override."""
+def test_launch_tables_and_their_size_limit(monkeypatch):
+    """GMatcher._replays: the gims_run_ops tables are the default at every size; `launch_replay_rows` > 0 restricts them to calls of at
+    most that many keypoint rows (larger batches then launch one by one).  enable_timing(stepwise=True) and GIMS_NO_REPLAY / GIMS_REPLAY
+    override."""
     monkeypatch.delenv("GIMS_NO_REPLAY", raising=False)
     monkeypatch.delenv("GIMS_REPLAY", raising=False)
     m = GMatcher({}).eval()
-    rows = m.config['launch_replay_rows']
-    assert rows == 16384
+    assert m.config['launch_replay_rows'] == 0
     for part in ("encoder", "layers"):
-        assert m._replays(part, 2 * 4096) and m._replays(part, rows) and not m._replays(part, rows + 1) and not m._replays(part, 8 * 2 * 4096)
-    assert GMatcher({"launch_replay_rows": 1 << 30})._replays("layers", 65536)
+        assert m._replays(part, 2 * 4096) and m._replays(part, 8 * 2 * 4096) and m._replays(part, 1 << 22)
+    m = GMatcher({"launch_replay_rows": 16384}).eval()
+    for part in ("encoder", "layers"):
+        assert m._replays(part, 2 * 4096) and m._replays(part, 16384) and not m._replays(part, 16385) and not m._replays(part, 8 * 2 * 4096)
     monkeypatch.setenv("GIMS_REPLAY", "1")
     assert m._replays("layers", 65536) and m._replays("encoder", 65536)
     monkeypatch.setenv("GIMS_NO_REPLAY", "1")
