@@ -328,7 +328,7 @@ __device__ __forceinline__ void linear_x3p_tile(const gims_linear_args& p, const
   if ((p.flags & 0x1000) && (slot & 1))
     for (int d = 0; d < p.conv_reserved; ++d) __builtin_amdgcn_s_sleep(127);
   const int li = lane & 31, lh = lane >> 5;
-  // diagnostic bits (tools/gemm_probe.py only): 0x100 = no main loop, 0x200 = no epilogue memory traffic
+  // diagnostic bits (tools/gemm_probe.py only): 0x100 = no main loop, 0x200 = no epilogue memory traffic, 0x400 / 0x800 / 0x2000 below
   const int nk = (p.flags & 0x100) ? 0 : p.k / BK;
 
   // this wave's LDS-DMA duty: PIECES consecutive 8-row pieces of the stage image [A rows | W rows]
@@ -453,12 +453,13 @@ __device__ __forceinline__ void linear_x3p_tile(const gims_linear_args& p, const
         for (int mi = 0; mi < T::MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s][ni], ah[s][mi], acc[ni][mi], 0, 0, 0);
     };
     static_assert(BK == 32, "two 16-deep K steps per stage");
-    rd(0);
-    if (!LO) rd(1);
+    const bool no_rd = p.flags & 0x2000;                       // 0x2000: MFMAs on whatever the fragment registers hold, no LDS reads (probe)
+    if (!no_rd) rd(0);
+    if (!LO && !no_rd) rd(1);
     __builtin_amdgcn_sched_barrier(0);
     lo_terms(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (LO) rd(1);
+    if (LO && !no_rd) rd(1);
     __builtin_amdgcn_sched_barrier(0);
     hi_term(0);
     lo_terms(1);

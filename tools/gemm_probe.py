@@ -2,7 +2,8 @@
 """Times the three per-layer split-bf16 GEMMs of the attentional GNN in isolation (HIP events, one stream).
 
 usage: python tools/gemm_probe.py [rows] [reps]      env GIMS_X3P_TILE selects the tile geometry
-Diagnostic flag columns: full | main loop only (no epilogue traffic) | epilogue only (no K loop)."""
+Diagnostic flag columns: full | main loop only (no epilogue traffic) | epilogue only (no K loop) | main loop without DMA / without MFMAs |
+repeats | main loop with neither DMA nor LDS fragment reads (MFMAs + barriers: the matrix floor at the clock the chip sustains) | without the reads only."""
 import os
 import sys
 import torch
@@ -51,7 +52,7 @@ def main():
     for name, (mk, flops, byts) in cases.items():
         res = []
         variants = [0, 0] + ([0x1000 + d for d in (1, 2, 3, 4, 6, 8)] if os.environ.get("GIMS_PROBE_DELAY") else [])   # repeats of the full kernel (the first timing of a case runs on a cold clock); 0x1000 + d: odd slots start d x 3.4 us late
-        for fl in [0, 0x200, 0x100, 0x200 | 0x400, 0x200 | 0x800] + variants:
+        for fl in [0, 0x200, 0x100, 0x200 | 0x400, 0x200 | 0x800] + variants + [0x200 | 0x400 | 0x2000, 0x200 | 0x2000]:
             a = mk()
             a.flags |= fl & ~0xff
             a.conv_reserved = fl & 0xff
@@ -66,7 +67,7 @@ def main():
             res.append(e0.elapsed_time(e1) / reps * 1e3)
         us = res[0]
         print(f"{name:30s} full {us:7.1f} us  ({flops / us * 1e-6:6.1f} TF/s alg, {byts / us * 1e-3:6.0f} GB/s alg) | "
-              f"main-only {res[1]:7.1f} us | epilogue-only {res[2]:7.1f} us | main w/o DMA {res[3]:7.1f} | main w/o MFMA {res[4]:7.1f} | variants(full) " + " ".join(f"{v:#x}:{r:.1f}" for v, r in zip(variants, res[5:])) + f" | MFMA floor {3 * flops / 2.5e15 * 1e6:5.1f} us, HBM floor {byts / 8e12 * 1e6:5.1f} us")
+              f"main-only {res[1]:7.1f} us | epilogue-only {res[2]:7.1f} us | main w/o DMA {res[3]:7.1f} | main w/o MFMA {res[4]:7.1f} | variants(full) " + " ".join(f"{v:#x}:{r:.1f}" for v, r in zip(variants, res[5:])) + f" | main MFMA + barriers only {res[-2]:.1f}, main w/o LDS reads {res[-1]:.1f}" + f" | MFMA floor {3 * flops / 2.5e15 * 1e6:5.1f} us, HBM floor {byts / 8e12 * 1e6:5.1f} us")
 
 
 if __name__ == "__main__":
