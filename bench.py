@@ -325,9 +325,20 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     torch.cuda.synchronize()
     from gims_amd import hip as _hip
     _hip.attention_launch_counts(reset=True)          # which attention kernel serves the TIMED steps (host-side counters of the library)
+    # HIP events cost time too (measured: 2.1 % of a 4096 x 8 step when every launch of every timed step is bracketed): the stage / per-launch
+    # events are recorded on every `--event-every`-th timed step (default 5: steps 2, 7, 12, 17 of K = 20 -- mid-stride, so that the sample weighs
+    # the first step after the synchronisation, which runs 10 % slower on a clock that has just idled, like the K steps do: not at all
+    # rather than at 1 in 4), the other steps run bare
+    timers = model._timers
+    every = max(1, min(int(args.event_every), args.steps))
+    ev_idx = list(range(every // 2, args.steps, every))
+    ev_steps = len(ev_idx) if timers is not None else 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if timers is not None:
+            model._timers = timers if i in ev_idx else None
         outs, stats = step()
+    model._timers = timers
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -372,9 +383,9 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     flats = outs.flat if isinstance(outs.flat, (list, tuple)) else [outs.flat]
     problems = [(a, b) for f in flats for a, b in zip(f["n0"], f["n1"])]
     nl = getattr(model, "n_lanes_last", 1)          # stream lanes: each stage is launched once per lane
-    stage_ms = {k: float(np.sum(v)) / args.steps for k, v in stage.items()}
+    stage_ms = {k: float(np.sum(v)) / ev_steps for k, v in stage.items()}
     for k, v in stage.items():
-        per = np.asarray(v).reshape(args.steps, -1).sum(1)
+        per = np.asarray(v).reshape(ev_steps, -1).sum(1)
         log(f"stage {k:14s} gpu ms/step: " + " ".join(f"{x:7.2f}" for x in per))
     # algorithmic work per step on this rank (SURVEY 8d formulas, on the kept counts)
     attn_flops_layer = sum(1024.0 * (a * a + b * b) for a, b in problems)          # self layer (both images)
@@ -389,7 +400,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     n_self = sum(1 for t in model.config["transformer_layers"] if t == "self")
     n_cross = len(model.config["transformer_layers"]) - n_self
     L = n_self + n_cross
-    per_step = lambda name: float(np.sum(stage.get(name, [0.0]))) / args.steps          # noqa: E731
+    per_step = lambda name: float(np.sum(stage.get(name, [0.0]))) / ev_steps          # noqa: E731
     # kernel -> (bound, algorithmic work per launch, avg launch ms (HIP events on the launch stream), peak, unit, launches/step)
     # The "qkv" and "mlp" intervals contain ONLY launches of the split-bf16 GEMM kernel.
     lin_name = "linear_x3p_kernel"
@@ -525,7 +536,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
                    "path": "GMatcher.match_pairs, production path ("
                            + ("encoder + layer launches replayed from the cached gims_run_ops tables" if model._replays("layers", 2 * kpts * pairs)
                               else "launch by launch: config launch_replay_rows / GIMS_NO_REPLAY")
-                           + ", HIP events around every attention / GEMM launch on the launch stream); "
+                           + f", HIP events around every attention / GEMM launch on the launch stream on {ev_steps} of the {args.steps} timed steps: every {every}th); "
                            "Python's cyclic GC is frozen + disabled inside the K timed steps (host_step_ms.max reports the slowest step)",
                    "parallelism": f"pairs sharded over {world} GPU(s), all-gather of match statistics; {nl} stream lane(s) per GPU"},
         "roofline": roofline,
@@ -574,6 +585,7 @@ def main():
     ap.add_argument("--attention-precision", default="auto", choices=["auto", "bf16", "f16", "bf16x3"],
                     help="'auto' (default): per-layer tiers decided from measured softmax statistics, with the device-side redo; the others fix one tier")
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches per step on separate HIP streams (1 = single stream)")
+    ap.add_argument("--event-every", type=int, default=5, help="record the stage / per-launch HIP events on every n-th timed step (1 = every step: costs 2 %% of the headline step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU-oracle work for the headline workload (a third of it for the second block)")
     ap.add_argument("--latency", action="store_true", help="also time ONE pair through the reference-shaped forward() (latency_ms_b1)")
