@@ -15,13 +15,13 @@ python bench.py --steps 20 --warmup 3 > $O/${TAG}_bench_default.json 2> $O/${TAG
 cp $R/bench_extra.json $O/${TAG}_bench_extra.json 2>/dev/null      # the full record of THAT run (later runs of this script overwrite bench_extra.json)
 cd /tmp && export TMPDIR=/tmp
 # kernel stats of the SAME command (no CPU baseline: it only adds host time)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_default -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/ks_default.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_default -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/ks_default.log 2>&1
 cp $(find $O/ks_default -name '*kernel_stats.csv' | head -1) $O/${TAG}_rocprofv3_kernel_stats_bench_default.csv
 rm -rf $O/ks_default
 for cfg in "1024 32" "4096 8"; do
   set -- $cfg
   tag=${1}x${2}
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$tag -- python3 $R/bench.py --kpts $1 --pairs $2 --steps 5 --warmup 2 --no-cpu-baseline > $O/ks_$tag.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$tag -- python3 $R/bench.py --kpts $1 --pairs $2 --steps 20 --warmup 3 --no-cpu-baseline > $O/ks_$tag.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pf_$tag -- python3 $R/bench.py --kpts $1 --pairs $2 --steps 1 --warmup 1 --no-cpu-baseline > $O/pf_$tag.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pw_$tag -- python3 $R/bench.py --kpts $1 --pairs $2 --steps 1 --warmup 1 --no-cpu-baseline > $O/pw_$tag.log 2>&1
   f=$(find $O/pf_$tag -name '*counter_collection.csv' | head -1)
