@@ -280,6 +280,12 @@ def spawn_ranks(n: int) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ one workload
+def event_steps(steps, every):
+    """Which of the K timed steps carry the stage / per-launch HIP events: every `every`-th, mid-stride (K = 20, every = 5 -> 2, 7, 12, 17)."""
+    every = max(1, min(int(every), int(steps)))
+    return every, list(range(every // 2, int(steps), every))
+
+
 def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, guard=True, maker=None, golden=True):
     import torch
     import torch.distributed as dist
@@ -330,8 +336,7 @@ def run_workload(model, kpts, pairs, args, world, rank, dev, with_cpu_baseline, 
     # the first step after the synchronisation, which runs 10 % slower on a clock that has just idled, like the K steps do: not at all
     # rather than at 1 in 4), the other steps run bare
     timers = model._timers
-    every = max(1, min(int(args.event_every), args.steps))
-    ev_idx = list(range(every // 2, args.steps, every))
+    every, ev_idx = event_steps(args.steps, args.event_every)
     ev_steps = len(ev_idx) if timers is not None else 0
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -408,3 +408,11 @@ def test_launch_tables_and_their_size_limit(monkeypatch):
     monkeypatch.delenv("GIMS_REPLAY")
     m._stepwise = True
     assert not m._replays("layers", 1024)
+
+
+def test_bench_event_sampling_schedule():
+    """bench.py records its HIP events on every 5th timed step, mid-stride (bracketing every launch of every step costs 2 % of the step)."""
+    import bench
+    assert bench.event_steps(20, 5) == (5, [2, 7, 12, 17])
+    assert bench.event_steps(5, 5) == (5, [2]) and bench.event_steps(3, 5) == (3, [1]) and bench.event_steps(1, 5) == (1, [0])
+    assert bench.event_steps(20, 1) == (1, list(range(20))) and bench.event_steps(7, 0) == (1, list(range(7)))
