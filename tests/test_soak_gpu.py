@@ -1,0 +1,67 @@
+"""A soak of the production entry point: many match_pairs calls whose batch size and keypoint counts change from call to call, so that
+the arena regrows, the cached launch tables (gims_run_ops: encoder + layers) are built, patched, missed and evicted, and the Sinkhorn
+plans change class -- and every batch is evaluated TWICE, the second time after other geometries have gone through the same model.
+Both evaluations must agree bit for bit (a stale address or row count in a cached table cannot hide behind a tolerance), a single pair
+through forward() must give the same rows as its slot of a batch (scores within 5e-5: other kernels serve a single pair), and the allocator's footprint must stop growing."""
+import numpy as np
+import pytest
+import torch
+
+from gims_amd import GMatcher, synth
+from tests.helpers import pair_to_data
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _batch(rng, k):
+    pairs = []
+    for _ in range(k):
+        n0 = int(rng.integers(100, 2600))
+        n1 = max(64, int(n0 * rng.uniform(0.7, 1.0)))                    # (a much sparser partner image loses every keypoint: the whole batch is refused,
+        if rng.integers(2):                                              # like the reference refuses such a pair -- tests/test_gmatcher_gpu.py covers that)
+            n0, n1 = n1, n0
+        common = int(rng.integers(min(n0, n1) // 2, min(n0, n1) + 1))
+        side = float(np.sqrt(max(n0, n1)) * 9.5)                       # dense enough that (nearly) everything is kept
+        pairs.append(synth.make_pair_unbalanced(n0, n1, common, int(rng.integers(1, 1 << 30)), canvas=(int(side * 1.25) + 8, int(side * 0.8) + 8)))
+    return pairs
+
+
+def _run(m, pairs):
+    datas = [pair_to_data(p, 15, 2, 7, device="cuda") for p in pairs]
+    outs = m.match_pairs(datas)
+    torch.cuda.synchronize()
+    return [(o["matches0"][0].cpu().numpy().copy(), o["matching_scores0"][0].cpu().numpy().copy(), o["matches1"][0].cpu().numpy().copy(),
+             d["kept_kpts0_indices"][0].cpu().numpy().copy()) for o, d in zip(outs, datas)]
+
+
+def test_changing_geometries_replay_bit_identically(synth_sd):
+    m = GMatcher({}).eval()
+    m.load_state_dict(synth_sd)
+    m(pair_to_data(synth.make_pair(256, 1002), 15, 2, 7, device="cuda"))          # 'auto' attention: the calibrating batch
+    rng = np.random.default_rng(77)
+    batches = [_batch(rng, int(rng.integers(1, 9))) for _ in range(30)]
+    first = [_run(m, b) for b in batches]
+    mem_after_first = torch.cuda.memory_reserved()
+    order = rng.permutation(len(batches))
+    for i in order:                                                               # every batch again, in another order, through whatever the caches hold now
+        again = _run(m, batches[i])
+        for (a0, a1, a2, a3), (b0, b1, b2, b3) in zip(first[i], again):
+            np.testing.assert_array_equal(a3, b3)
+            np.testing.assert_array_equal(a0, b0)
+            np.testing.assert_array_equal(a2, b2)
+            np.testing.assert_array_equal(a1.view(np.uint32), b1.view(np.uint32))    # scores: the same bits
+    for i in order[:10]:
+        _run(m, batches[i])
+    assert torch.cuda.memory_reserved() <= mem_after_first * 1.25 + (64 << 20), "the footprint keeps growing on geometries it has already seen"
+    rep = m.attention_report()
+    assert rep is not None and rep["calibrated"]
+    # one pair alone through forward(): the same rows as in its batch (well-conditioned decisions; scores to 5e-5, half the bar against the reference -- another batch shape
+    # takes other kernels: tile sizes, split keys)
+    b = batches[int(order[0])]
+    d = pair_to_data(b[0], 15, 2, 7, device="cuda")
+    o = m(d)
+    m0, s0 = o["matches0"][0].cpu().numpy(), o["matching_scores0"][0].cpu().numpy()
+    f0, fs, _, _ = first[int(order[0])][0]
+    same = m0 == f0
+    assert same.mean() > 0.99 and np.abs(s0 - fs)[same].max() < 5e-5
