@@ -65,3 +65,24 @@ def test_changing_geometries_replay_bit_identically(synth_sd):
     f0, fs, _, _ = first[int(order[0])][0]
     same = m0 == f0
     assert same.mean() > 0.99 and np.abs(s0 - fs)[same].max() < 5e-5
+
+
+def test_single_pairs_of_changing_size_replay_bit_identically(synth_sd):
+    """The same through forward() (one pair per call, the reference's call shape): sizes change from call to call, each pair is evaluated twice."""
+    m = GMatcher({"sinkhorn_iterations": 20, "match_threshold": 0.02}).eval()
+    m.load_state_dict(synth_sd)
+    m(pair_to_data(synth.make_pair(256, 1002), 15, 2, 7, device="cuda"))
+    rng = np.random.default_rng(78)
+    pairs = [p for _ in range(10) for p in _batch(rng, 1)]
+
+    def run(p):
+        d = pair_to_data(p, 15, 2, 7, device="cuda")
+        o = m(d)
+        return (o["matches0"][0].cpu().numpy().copy(), o["matching_scores0"][0].cpu().numpy().copy(), o["matches1"][0].cpu().numpy().copy(),
+                np.asarray(d["kept_kpts1_indices"][0]).copy())
+
+    first = [run(p) for p in pairs]
+    for i in rng.permutation(len(pairs)):
+        again = run(pairs[i])
+        for a, b in zip(first[i], again):
+            np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
